@@ -1,0 +1,293 @@
+"""ctypes binding of libeqf_vio_amd.so (the C ABI declared in include/eqf_vio_amd.h).
+
+There is no CPU fallback: if the shared library is missing or no MI355X is visible, loading /
+eqf_create fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeqf_vio_amd.so")
+
+EQF_OK = 0
+SKIPPED_BEFORE_FIRST_IMU = 1
+SKIPPED_NONPOSITIVE_DT = 2
+SKIPPED_NOT_INITIALISED = 3
+SKIPPED_NO_BEARINGS = 4
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSORTED, ERR_NUMERIC, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
+PRECISION_F64, PRECISION_F32 = 0, 1
+PROF_CLASSES = 7
+
+_ERR_NAMES = {
+    -1: "EQF_ERR_INVALID", -2: "EQF_ERR_NO_DEVICE", -3: "EQF_ERR_HIP", -4: "EQF_ERR_CAPACITY",
+    -5: "EQF_ERR_UNSORTED", -6: "EQF_ERR_NUMERIC", -7: "EQF_ERR_UNSUPPORTED",
+}
+
+
+class EqfError(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__(f"{what}: {_ERR_NAMES.get(code, code)}")
+        self.code = code
+
+
+class Settings(C.Structure):
+    """eqf_settings == VIOFilter::Settings (eqf_vio/include/eqf_vio/VIOFilterSettings.h:28-54)."""
+
+    _fields_ = [
+        ("biasOmegaProcessVariance", C.c_double), ("biasAccelProcessVariance", C.c_double),
+        ("gravityProcessVariance", C.c_double), ("velocityProcessVariance", C.c_double),
+        ("pointProcessVariance", C.c_double), ("velOmegaVariance", C.c_double), ("velAccelVariance", C.c_double),
+        ("measurementVariance", C.c_double), ("initialGravityVariance", C.c_double),
+        ("initialVelocityVariance", C.c_double), ("initialPointVariance", C.c_double),
+        ("initialBiasOmegaVariance", C.c_double), ("initialBiasAccelVariance", C.c_double),
+        ("initialSceneDepth", C.c_double), ("outlierThreshold", C.c_double),
+        ("useInnovationLift", C.c_int), ("useDiscreteInnovationLift", C.c_int), ("useDiscreteVelocityLift", C.c_int),
+        ("fastRiccati", C.c_int),
+        ("initialAccelBias", C.c_double * 3), ("initialOmegaBias", C.c_double * 3),
+        ("cameraOffset_x", C.c_double * 3), ("cameraOffset_q", C.c_double * 4),
+    ]
+
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+EXPORTED_SYMBOLS = [
+    "eqf_settings_default", "eqf_create", "eqf_destroy", "eqf_reset", "eqf_process_imu", "eqf_process_vision",
+    "eqf_stream_upload", "eqf_stream_imu", "eqf_stream_vision", "eqf_synchronize", "eqf_get_time", "eqf_num_landmarks",
+    "eqf_get_ids", "eqf_get_state_estimate", "eqf_get_origin", "eqf_get_group", "eqf_get_bias", "eqf_get_sigma",
+    "eqf_set_sigma", "eqf_get_last_update", "eqf_device_error", "eqf_set_dense_propagate", "eqf_profile_enable",
+    "eqf_profile_get", "eqf_profile_class_name", "eqf_version",
+]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  eqf_vio_amd has no CPU fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.eqf_settings_default.argtypes = [C.POINTER(Settings)]
+        L.eqf_settings_default.restype = None
+        L.eqf_create.argtypes = [C.POINTER(Settings), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+        L.eqf_destroy.argtypes = [vp]
+        L.eqf_destroy.restype = None
+        L.eqf_reset.argtypes = [vp]
+        L.eqf_process_imu.argtypes = [vp, _dp, _dp, _dp, _ip]
+        L.eqf_process_vision.argtypes = [vp, _dp, _ip, _ip, _dp, C.c_int, _ip]
+        L.eqf_stream_upload.argtypes = [vp, C.c_int, _dp, C.c_int, _dp, C.c_int, _ip, _dp]
+        L.eqf_stream_imu.argtypes = [vp, C.c_int]
+        L.eqf_stream_vision.argtypes = [vp, C.c_int]
+        L.eqf_synchronize.argtypes = [vp]
+        L.eqf_get_time.argtypes = [vp, _dp]
+        L.eqf_num_landmarks.argtypes = [vp, C.c_int]
+        L.eqf_get_ids.argtypes = [vp, C.c_int, _ip]
+        L.eqf_get_state_estimate.argtypes = [vp, C.c_int, _dp, _dp, _dp, _dp]
+        L.eqf_get_origin.argtypes = [vp, C.c_int, _dp, _dp, _dp, _dp]
+        L.eqf_get_group.argtypes = [vp, C.c_int, _dp, _dp, _dp, _dp, _dp]
+        L.eqf_get_bias.argtypes = [vp, C.c_int, _dp]
+        L.eqf_get_sigma.argtypes = [vp, C.c_int, _dp, C.c_int]
+        L.eqf_set_sigma.argtypes = [vp, C.c_int, _dp, C.c_int]
+        L.eqf_get_last_update.argtypes = [vp, C.c_int, _dp, _dp, _dp]
+        L.eqf_device_error.argtypes = [vp]
+        L.eqf_set_dense_propagate.argtypes = [vp, C.c_int]
+        L.eqf_profile_enable.argtypes = [vp, C.c_int]
+        L.eqf_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_longlong), _dp]
+        L.eqf_profile_class_name.argtypes = [C.c_int]
+        L.eqf_profile_class_name.restype = C.c_char_p
+        L.eqf_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def default_settings():
+    s = Settings()
+    lib().eqf_settings_default(C.byref(s))
+    return s
+
+
+def settings_from_dict(d):
+    """Reference setting names -> eqf_settings; unknown keys raise."""
+    s = default_settings()
+    for k, v in d.items():
+        if k in ("initialAccelBias", "initialOmegaBias", "cameraOffset_x", "cameraOffset_q"):
+            arr = getattr(s, k)
+            for i, x in enumerate(np.asarray(v, dtype=float)):
+                arr[i] = x
+        elif hasattr(s, k):
+            setattr(s, k, int(bool(v)) if k.startswith("use") or k == "fastRiccati" else float(v))
+        else:
+            raise AttributeError(k)
+    return s
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise EqfError(rc, what)
+    return rc
+
+
+class FilterBatch:
+    """A batch of independent EqF filters on one MI355X (one handle, one HIP stream)."""
+
+    def __init__(self, settings, capacity, batch=1, device=0, precision=PRECISION_F64):
+        if isinstance(settings, dict):
+            settings = settings_from_dict(settings)
+        self.settings = settings
+        self.B = int(batch)
+        self.cap = int(capacity)
+        self._h = C.c_void_p()
+        _check(lib().eqf_create(C.byref(settings), self.cap, self.B, int(device), int(precision), C.byref(self._h)), "eqf_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().eqf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- inputs
+    def process_imu(self, stamps, omega, accel):
+        st = np.ascontiguousarray(np.broadcast_to(np.asarray(stamps, dtype=np.float64), (self.B,)))
+        w = np.ascontiguousarray(np.broadcast_to(np.asarray(omega, dtype=np.float64), (self.B, 3)))
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(accel, dtype=np.float64), (self.B, 3)))
+        status = np.zeros(self.B, dtype=np.int32)
+        _check(lib().eqf_process_imu(self._h, _p(st), _p(w), _p(a), status.ctypes.data_as(_ip)), "eqf_process_imu")
+        return status
+
+    def process_vision(self, stamps, ids, bearings, nb=None):
+        """ids: (B, stride) or (stride,) ascending; bearings: (B, stride, 3) or (stride, 3)."""
+        ids = np.asarray(ids, dtype=np.int32)
+        y = np.asarray(bearings, dtype=np.float64)
+        if ids.ndim == 1:
+            ids = np.broadcast_to(ids, (self.B, ids.shape[0]))
+        if y.ndim == 2:
+            y = np.broadcast_to(y, (self.B,) + y.shape)
+        ids = np.ascontiguousarray(ids)
+        y = np.ascontiguousarray(y)
+        stride = ids.shape[1]
+        nbv = np.full(self.B, stride, dtype=np.int32) if nb is None else np.ascontiguousarray(nb, dtype=np.int32)
+        st = np.ascontiguousarray(np.broadcast_to(np.asarray(stamps, dtype=np.float64), (self.B,)))
+        status = np.zeros(self.B, dtype=np.int32)
+        _check(
+            lib().eqf_process_vision(self._h, _p(st), nbv.ctypes.data_as(_ip), ids.ctypes.data_as(_ip), _p(y), stride,
+                                     status.ctypes.data_as(_ip)),
+            "eqf_process_vision",
+        )
+        return status
+
+    def stream_upload(self, imu, vstamps, ids, bearings):
+        """imu (K,B,7) or (K,7); vstamps (F,B) or (F,); ids (nb,); bearings (F,B,nb,3) or (F,nb,3)."""
+        imu = np.asarray(imu, dtype=np.float64)
+        if imu.ndim == 2:
+            imu = np.broadcast_to(imu[:, None, :], (imu.shape[0], self.B, 7))
+        vs = np.asarray(vstamps, dtype=np.float64)
+        if vs.ndim == 1:
+            vs = np.broadcast_to(vs[:, None], (vs.shape[0], self.B))
+        y = np.asarray(bearings, dtype=np.float64)
+        if y.ndim == 3:
+            y = np.broadcast_to(y[:, None], (y.shape[0], self.B) + y.shape[1:])
+        imu, vs, y = np.ascontiguousarray(imu), np.ascontiguousarray(vs), np.ascontiguousarray(y)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        _check(
+            lib().eqf_stream_upload(self._h, imu.shape[0], _p(imu), vs.shape[0], _p(vs), len(ids), ids.ctypes.data_as(_ip), _p(y)),
+            "eqf_stream_upload",
+        )
+
+    def stream_imu(self, k):
+        return _check(lib().eqf_stream_imu(self._h, int(k)), "eqf_stream_imu")
+
+    def stream_vision(self, f):
+        return _check(lib().eqf_stream_vision(self._h, int(f)), "eqf_stream_vision")
+
+    def synchronize(self):
+        _check(lib().eqf_synchronize(self._h), "eqf_synchronize")
+
+    def reset(self):
+        _check(lib().eqf_reset(self._h), "eqf_reset")
+
+    # ---- outputs
+    def num_landmarks(self, b=0):
+        return _check(lib().eqf_num_landmarks(self._h, b), "eqf_num_landmarks")
+
+    def get_time(self):
+        t = np.zeros(self.B)
+        _check(lib().eqf_get_time(self._h, _p(t)), "eqf_get_time")
+        return t
+
+    def ids(self, b=0):
+        out = np.zeros(self.num_landmarks(b), dtype=np.int32)
+        _check(lib().eqf_get_ids(self._h, b, out.ctypes.data_as(_ip)), "eqf_get_ids")
+        return out
+
+    def _state(self, fn, b, what):
+        N = self.num_landmarks(b)
+        q, x, v, p = np.zeros(4), np.zeros(3), np.zeros(3), np.zeros((max(N, 1), 3))
+        _check(fn(self._h, b, _p(q), _p(x), _p(v), _p(p)), what)
+        return dict(q=q, x=x, v=v, p=p[:N])
+
+    def state_estimate(self, b=0):
+        return self._state(lib().eqf_get_state_estimate, b, "eqf_get_state_estimate")
+
+    def origin(self, b=0):
+        return self._state(lib().eqf_get_origin, b, "eqf_get_origin")
+
+    def group(self, b=0):
+        N = self.num_landmarks(b)
+        Aq, Ax, w = np.zeros(4), np.zeros(3), np.zeros(3)
+        Qq, Qa = np.zeros((max(N, 1), 4)), np.zeros(max(N, 1))
+        _check(lib().eqf_get_group(self._h, b, _p(Aq), _p(Ax), _p(w), _p(Qq), _p(Qa)), "eqf_get_group")
+        return dict(Aq=Aq, Ax=Ax, w=w, Qq=Qq[:N], Qa=Qa[:N])
+
+    def bias(self, b=0):
+        out = np.zeros(6)
+        _check(lib().eqf_get_bias(self._h, b, _p(out)), "eqf_get_bias")
+        return out
+
+    def sigma(self, b=0):
+        n = 11 + 3 * self.num_landmarks(b)
+        out = np.zeros((n, n))
+        _check(lib().eqf_get_sigma(self._h, b, _p(out), n), "eqf_get_sigma")
+        return out
+
+    def set_sigma(self, S, b=0):
+        S = np.ascontiguousarray(S, dtype=np.float64)
+        n = 11 + 3 * self.num_landmarks(b)
+        assert S.shape == (n, n)
+        _check(lib().eqf_set_sigma(self._h, b, _p(S), n), "eqf_set_sigma")
+
+    def last_update(self, b=0):
+        N = self.num_landmarks(b)
+        delta, gamma, Gamma = np.zeros(max(2 * N, 1)), np.zeros(11 + 3 * N), np.zeros(9 + 3 * N)
+        _check(lib().eqf_get_last_update(self._h, b, _p(delta), _p(gamma), _p(Gamma)), "eqf_get_last_update")
+        return dict(delta=delta[: 2 * N], gamma=gamma, Gamma=Gamma)
+
+    def device_error(self):
+        return lib().eqf_device_error(self._h)
+
+    # ---- profiling
+    def profile_enable(self, on=True):
+        _check(lib().eqf_profile_enable(self._h, int(bool(on))), "eqf_profile_enable")
+
+    def profile(self):
+        out = {}
+        for c in range(PROF_CLASSES):
+            n = C.c_longlong()
+            ms = C.c_double()
+            _check(lib().eqf_profile_get(self._h, c, C.byref(n), C.byref(ms)), "eqf_profile_get")
+            out[lib().eqf_profile_class_name(c).decode()] = (n.value, ms.value)
+        return out

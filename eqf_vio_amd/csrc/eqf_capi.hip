@@ -1,0 +1,996 @@
+// C ABI of the MI355X EqF hot path (include/eqf_vio_amd.h): handle management, host-side landmark
+// bookkeeping (integer id matching, eqf_vio/src/VIOFilter.cpp:211-230, :345-443) and kernel launches.
+// All arithmetic of the filter runs in the HIP kernels of eqf_propagate.hpp / eqf_update.hpp /
+// eqf_churn.hpp; there is no CPU fallback: without a usable GPU eqf_create fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/eqf_vio_amd.h"
+#include "eqf_churn.hpp"
+#include "eqf_device.hpp"
+#include "eqf_propagate.hpp"
+#include "eqf_update.hpp"
+
+using namespace eqf;
+
+#define HIPC(expr)                                                                              \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            std::fprintf(stderr, "eqf_vio_amd: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return EQF_ERR_HIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+
+namespace {
+constexpr int kRing = 64;
+
+struct ProfPair {
+    int cls;
+    hipEvent_t a, b;
+};
+}  // namespace
+
+struct eqf_filter {
+    int B = 0, cap = 0, device = 0, precision = 0;
+    size_t esz = 8;
+    eqf_settings set{};
+    Params prm{};
+    hipStream_t stream = nullptr;
+    int nTot = 0, ld = 0;
+    long long sigmaStride = 0;
+    void* Sigma[2] = {nullptr, nullptr};
+    Glob* g[2] = {nullptr, nullptr};
+    double* p0 = nullptr;
+    double* Q[2] = {nullptr, nullptr};
+    int pS = 0, pG = 0;
+    // update chains
+    double *SA = nullptr, *SL = nullptr, *YW = nullptr, *YO = nullptr, *EA = nullptr, *EL = nullptr, *ZW = nullptr, *ZO = nullptr;
+    int ldS = 0, ldY = 0, ldE = 0, ldZ = kNB;
+    long long strideS = 0, strideY = 0, strideE = 0, strideZ = 0;
+    double *dbgDelta = nullptr, *dbgGamma = nullptr, *dbgGammaTot = nullptr;
+    int* errflag = nullptr;
+    // churn scratch
+    int *dMap = nullptr, *dNewN = nullptr, *dPerm = nullptr, *dSrc = nullptr;
+    double *dChord = nullptr, *dDepth2 = nullptr, *dScratch = nullptr, *dMeas = nullptr, *dOut = nullptr;
+    int *hMap = nullptr, *hNewN = nullptr, *hPerm = nullptr, *hSrc = nullptr;  // pinned
+    double *hChord = nullptr, *hDepth2 = nullptr, *hMeas = nullptr, *hOut = nullptr;
+    hipEvent_t evMeas = nullptr;
+    // input ring for per-call records (batch > 1)
+    ImuRec* dRing = nullptr;
+    ImuRec* hRing = nullptr;
+    hipEvent_t evRing[kRing] = {};
+    bool ringUsed[kRing] = {};
+    long long ringCount = 0;
+    // stream mode
+    ImuRec* sImu = nullptr;   // [K][B]
+    ImuRec* sVis = nullptr;   // [F][B] (stamp only)
+    double* sBear = nullptr;  // [F][B][nb][3]
+    int sK = 0, sF = 0, sNb = 0;
+    std::vector<int> sIds;
+    std::vector<double> hImuStamp, hVisStamp;  // host mirrors of the stamps
+    // host mirrors
+    std::vector<std::vector<int>> ids;
+    std::vector<double> curTime;
+    std::vector<char> init;
+    int densePropagate = 0;
+    // profiling
+    bool prof = false;
+    std::vector<ProfPair> profPairs;
+    std::vector<hipEvent_t> evPool;
+    long long profCount[EQF_PROF_CLASSES] = {};
+    double profMs[EQF_PROF_CLASSES] = {};
+};
+
+namespace {
+
+template <typename F>
+int profiled(eqf_filter* f, int cls, F&& launch) {
+    if (!f->prof) {
+        launch();
+        return EQF_OK;
+    }
+    hipEvent_t a, b;
+    for (hipEvent_t* e : {&a, &b}) {
+        if (!f->evPool.empty()) {
+            *e = f->evPool.back();
+            f->evPool.pop_back();
+        } else {
+            HIPC(hipEventCreate(e));
+        }
+    }
+    HIPC(hipEventRecord(a, f->stream));
+    launch();
+    HIPC(hipEventRecord(b, f->stream));
+    f->profPairs.push_back({cls, a, b});
+    return EQF_OK;
+}
+
+int profDrain(eqf_filter* f) {
+    HIPC(hipStreamSynchronize(f->stream));
+    for (auto& p : f->profPairs) {
+        float ms = 0;
+        HIPC(hipEventElapsedTime(&ms, p.a, p.b));
+        f->profCount[p.cls]++;
+        f->profMs[p.cls] += ms;
+        f->evPool.push_back(p.a);
+        f->evPool.push_back(p.b);
+    }
+    f->profPairs.clear();
+    return EQF_OK;
+}
+
+template <typename T>
+int dmalloc(T** p, size_t count) {
+    HIPC(hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T)));
+    return EQF_OK;
+}
+template <typename T>
+int hmalloc(T** p, size_t count) {
+    HIPC(hipHostMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault));
+    return EQF_OK;
+}
+
+// VIOFilter(const Settings&) initial values (VIOFilter.cpp:60-73, VIOFilter.h:45-55)
+int initState(eqf_filter* f) {
+    const int B = f->B;
+    std::vector<Glob> g0(B);
+    for (auto& g : g0) {
+        std::memset(&g, 0, sizeof(Glob));
+        g.P0q[0] = 1.0;
+        g.Aq[0] = 1.0;
+        for (int i = 0; i < 3; ++i) {
+            g.bias[i] = f->set.initialOmegaBias[i];
+            g.bias[3 + i] = f->set.initialAccelBias[i];
+        }
+        g.curTime = -1.0;
+    }
+    for (int p = 0; p < 2; ++p) {
+        HIPC(hipMemcpyAsync(f->g[p], g0.data(), sizeof(Glob) * B, hipMemcpyHostToDevice, f->stream));
+        HIPC(hipMemsetAsync(f->Sigma[p], 0, f->esz * f->sigmaStride * B, f->stream));
+        HIPC(hipMemsetAsync(f->Q[p], 0, sizeof(double) * 5 * f->cap * B, f->stream));
+    }
+    HIPC(hipMemsetAsync(f->p0, 0, sizeof(double) * 3 * f->cap * B, f->stream));
+    HIPC(hipMemsetAsync(f->errflag, 0, sizeof(int), f->stream));
+    // Sigma base block diag
+    std::vector<double> base(12 * 12, 0.0);
+    for (int i = 0; i < 3; ++i) {
+        base[i * 12 + i] = f->set.initialBiasOmegaVariance;
+        base[(3 + i) * 12 + 3 + i] = f->set.initialBiasAccelVariance;
+        base[(8 + i) * 12 + 8 + i] = f->set.initialVelocityVariance;
+    }
+    base[6 * 12 + 6] = base[7 * 12 + 7] = f->set.initialGravityVariance;
+    std::vector<float> basef(base.begin(), base.end());
+    for (int b = 0; b < B; ++b) {
+        char* dst = static_cast<char*>(f->Sigma[0]) + f->esz * f->sigmaStride * b;
+        const void* src = f->precision == EQF_PRECISION_F32 ? static_cast<const void*>(basef.data()) : static_cast<const void*>(base.data());
+        HIPC(hipMemcpy2DAsync(dst, f->esz * f->ld, src, f->esz * 12, f->esz * 12, 12, hipMemcpyHostToDevice, f->stream));
+    }
+    HIPC(hipStreamSynchronize(f->stream));
+    f->pS = f->pG = 0;
+    f->ids.assign(B, {});
+    f->curTime.assign(B, -1.0);
+    f->init.assign(B, 0);
+    return EQF_OK;
+}
+
+int maxN(const eqf_filter* f) {
+    size_t m = 0;
+    for (auto& v : f->ids) m = std::max(m, v.size());
+    return int(m);
+}
+
+// Slot of the record ring holding `recs` ([B]) on the device; B == 1 passes the record inline.
+int stageRecs(eqf_filter* f, const ImuRec* recs, const ImuRec** dev, int* slotOut) {
+    *slotOut = -1;
+    if (f->B == 1) {
+        *dev = nullptr;
+        return EQF_OK;
+    }
+    const int slot = int(f->ringCount++ % kRing);
+    if (f->ringUsed[slot]) HIPC(hipEventSynchronize(f->evRing[slot]));
+    std::memcpy(f->hRing + (size_t)slot * f->B, recs, sizeof(ImuRec) * f->B);
+    HIPC(hipMemcpyAsync(f->dRing + (size_t)slot * f->B, f->hRing + (size_t)slot * f->B, sizeof(ImuRec) * f->B,
+        hipMemcpyHostToDevice, f->stream));
+    *dev = f->dRing + (size_t)slot * f->B;
+    *slotOut = slot;
+    return EQF_OK;
+}
+int releaseSlot(eqf_filter* f, int slot) {
+    if (slot < 0) return EQF_OK;
+    HIPC(hipEventRecord(f->evRing[slot], f->stream));
+    f->ringUsed[slot] = true;
+    return EQF_OK;
+}
+
+// integrateUpToTime on the device + host mirror of its control flow.  devRecs == nullptr -> inline (B == 1).
+int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, const double* stamps, bool isImu, bool doRiccati,
+    int* status) {
+    PropArgs a{};
+    a.gin = f->g[f->pG];
+    a.gout = f->g[f->pG ^ 1];
+    a.p0 = f->p0;
+    a.Qin = f->Q[f->pG];
+    a.Qout = f->Q[f->pG ^ 1];
+    a.Sin = f->Sigma[f->pS];
+    a.Sout = f->Sigma[f->pS ^ 1];
+    a.recs = devRecs;
+    a.inl = inl;
+    a.errflag = f->errflag;
+    a.sigmaStride = f->sigmaStride;
+    a.cap = f->cap;
+    a.ld = f->ld;
+    a.NT = std::max(1, (maxN(f) + kTileLm - 1) / kTileLm);
+    a.isImu = isImu ? 1 : 0;
+    a.doRiccati = doRiccati ? 1 : 0;
+    a.prm = f->prm;
+    const dim3 grid(a.NT * a.NT, f->B), block(256);
+    int rc = profiled(f, EQF_PROF_PROPAGATE, [&] {
+        if (f->precision == EQF_PRECISION_F32)
+            hipLaunchKernelGGL(k_propagate<float>, grid, block, 0, f->stream, a);
+        else
+            hipLaunchKernelGGL(k_propagate<double>, grid, block, 0, f->stream, a);
+    });
+    if (rc) return rc;
+    HIPC(hipGetLastError());
+    f->pG ^= 1;
+    f->pS ^= 1;
+    // host mirror (VIOFilter.cpp:120-131, :146-152, :207)
+    for (int b = 0; b < f->B; ++b) {
+        int st = EQF_OK;
+        if (isImu) f->init[b] = 1;  // lazy initialisation happens on the first IMU sample (:122-124)
+        if (f->curTime[b] < 0) st = EQF_SKIPPED_BEFORE_FIRST_IMU;
+        else if (!(stamps[b] - f->curTime[b] > 0)) st = EQF_SKIPPED_NONPOSITIVE_DT;
+        if (st == EQF_OK || isImu) f->curTime[b] = stamps[b];
+        if (!isImu && st == EQF_OK && !f->init[b]) st = EQF_SKIPPED_NOT_INITIALISED;
+        if (status) status[b] = st;
+    }
+    return EQF_OK;
+}
+
+UpdArgs makeUpdArgs(eqf_filter* f, const double* bearings, long long bearStride, const int* perm) {
+    UpdArgs a{};
+    a.g = f->g[f->pG];
+    a.p0 = f->p0;
+    a.Q = f->Q[f->pG];
+    a.Sin = f->Sigma[f->pS];
+    a.Sout = f->Sigma[f->pS ^ 1];
+    a.sigmaStride = f->sigmaStride;
+    a.cap = f->cap;
+    a.ld = f->ld;
+    a.bearings = bearings;
+    a.bearStride = bearStride;
+    a.perm = perm;
+    a.SA = f->SA; a.SL = f->SL; a.YW = f->YW; a.YO = f->YO;
+    a.ldS = f->ldS; a.ldY = f->ldY; a.strideS = f->strideS; a.strideY = f->strideY;
+    a.EA = f->EA; a.EL = f->EL; a.ZW = f->ZW; a.ZO = f->ZO;
+    a.ldE = f->ldE; a.ldZ = f->ldZ; a.strideE = f->strideE; a.strideZ = f->strideZ;
+    a.dbgDelta = f->dbgDelta;
+    a.dbgGamma = f->dbgGamma;
+    a.dbgGammaTot = f->dbgGammaTot;
+    a.errflag = f->errflag;
+    a.prm = f->prm;
+    return a;
+}
+
+template <typename T>
+int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, const int* perm, int Nmax) {
+    UpdArgs a = makeUpdArgs(f, bearings, bearStride, perm);
+    const int B = f->B;
+    const int mp = roundUp(sDim(Nmax), kNB), nep = roundUp(eDim(Nmax), kNB);
+    const int nv = kLm0 + 3 * Nmax;
+    // prep
+    const int nvPad = roundUp(nv, 16);
+    const size_t perWave = size_t(2) * nvPad * sizeof(double);
+    int wpb = int(std::min<size_t>(4, (150 * 1024) / perWave));
+    if (wpb < 1) return EQF_ERR_CAPACITY;
+    const int lmBlocks = (mp / 2 + wpb - 1) / wpb, eBlocks = nep / kNB;
+    const size_t lds = perWave * wpb;
+    static bool attrSet = false;
+    if (!attrSet) {
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attrSet = true;
+    }
+    int rc = profiled(f, EQF_PROF_UPDATE_PREP, [&] {
+        hipLaunchKernelGGL(k_update_prep<T>, dim3(lmBlocks + eBlocks, B), dim3(64 * wpb), lds, f->stream, a, lmBlocks, wpb, nvPad);
+    });
+    if (rc) return rc;
+    // chains
+    ChainArgs cS{}, cE{};
+    cS.g = a.g; cS.A = f->SA; cS.L = f->SL; cS.W = f->YW; cS.WO = f->YO;
+    cS.ldA = f->ldS; cS.ldW = f->ldY; cS.strideA = f->strideS; cS.strideW = f->strideY;
+    cS.kind = 0; cS.nbMax = mp / kNB; cS.wtMax = roundUp(yCols(Nmax), kNB) / kNB;
+    cE.g = a.g; cE.A = f->EA; cE.L = f->EL; cE.W = f->ZW; cE.WO = f->ZO;
+    cE.ldA = f->ldE; cE.ldW = f->ldZ; cE.strideA = f->strideE; cE.strideW = f->strideZ;
+    cE.kind = 1; cE.nbMax = nep / kNB; cE.wtMax = 1;
+    const int steps = std::max(cS.nbMax, cE.nbMax);
+    const int nblk = cS.nbMax * cS.nbMax + cS.wtMax * cS.nbMax + cE.nbMax * cE.nbMax + cE.wtMax * cE.nbMax;
+    for (int k = 0; k < steps; ++k) {
+        rc = profiled(f, EQF_PROF_CHOL_STEP,
+            [&] { hipLaunchKernelGGL(k_chol_step, dim3(nblk, B), dim3(256), 0, f->stream, cS, cE, k, f->errflag); });
+        if (rc) return rc;
+    }
+    rc = profiled(f, EQF_PROF_FINISH, [&] { hipLaunchKernelGGL(k_update_finish, dim3(B), dim3(256), 0, f->stream, a); });
+    if (rc) return rc;
+    const int nt = (nv + 63) / 64;
+    rc = profiled(f, EQF_PROF_DOWNDATE, [&] { hipLaunchKernelGGL(k_downdate<T>, dim3(nt, nt, B), dim3(256), 0, f->stream, a); });
+    if (rc) return rc;
+    HIPC(hipGetLastError());
+    f->pS ^= 1;
+    return EQF_OK;
+}
+
+int launchUpdate(eqf_filter* f, const double* bearings, long long bearStride, const int* perm, int Nmax) {
+    return f->precision == EQF_PRECISION_F32 ? launchUpdateT<float>(f, bearings, bearStride, perm, Nmax)
+                                             : launchUpdateT<double>(f, bearings, bearStride, perm, Nmax);
+}
+
+// Batch-wide compaction with host keep-lists keep[b] = old indices that survive (ascending).
+int compact(eqf_filter* f, const std::vector<std::vector<int>>& keep) {
+    const int B = f->B, cap = f->cap;
+    HIPC(hipStreamSynchronize(f->stream));  // pinned staging reuse
+    int nmax = 0;
+    for (int b = 0; b < B; ++b) {
+        f->hNewN[b] = int(keep[b].size());
+        nmax = std::max(nmax, f->hNewN[b]);
+        std::copy(keep[b].begin(), keep[b].end(), f->hMap + (size_t)b * cap);
+    }
+    HIPC(hipMemcpyAsync(f->dMap, f->hMap, sizeof(int) * B * cap, hipMemcpyHostToDevice, f->stream));
+    HIPC(hipMemcpyAsync(f->dNewN, f->hNewN, sizeof(int) * B, hipMemcpyHostToDevice, f->stream));
+    const int nvn = kLm0 + 3 * nmax;
+    int rc = profiled(f, EQF_PROF_CHURN, [&] {
+        const dim3 grid((nvn + 255) / 256, nvn, B);
+        if (f->precision == EQF_PRECISION_F32)
+            hipLaunchKernelGGL(k_compact_sigma<float>, grid, dim3(256), 0, f->stream, f->g[f->pG], f->dMap, f->dNewN, cap,
+                static_cast<const float*>(f->Sigma[f->pS]), static_cast<float*>(f->Sigma[f->pS ^ 1]), f->sigmaStride, f->ld);
+        else
+            hipLaunchKernelGGL(k_compact_sigma<double>, grid, dim3(256), 0, f->stream, f->g[f->pG], f->dMap, f->dNewN, cap,
+                static_cast<const double*>(f->Sigma[f->pS]), static_cast<double*>(f->Sigma[f->pS ^ 1]), f->sigmaStride, f->ld);
+        hipLaunchKernelGGL(k_compact_lm_gather, dim3(B), dim3(256), 0, f->stream, f->dMap, f->dNewN, cap, f->p0, f->Q[f->pG], f->dScratch);
+        hipLaunchKernelGGL(k_compact_lm_scatter, dim3(B), dim3(256), 0, f->stream, f->g[f->pG], f->dNewN, cap, f->p0, f->Q[f->pG], f->dScratch);
+    });
+    if (rc) return rc;
+    HIPC(hipGetLastError());
+    f->pS ^= 1;
+    return EQF_OK;
+}
+
+// perm[b][i] = index into the measurement of state landmark i (or -1)
+int uploadPerm(eqf_filter* f, const std::vector<std::vector<int>>& perm) {
+    const int B = f->B, cap = f->cap;
+    HIPC(hipStreamSynchronize(f->stream));
+    for (int b = 0; b < B; ++b) {
+        std::fill(f->hPerm + (size_t)b * cap, f->hPerm + (size_t)(b + 1) * cap, -1);
+        std::copy(perm[b].begin(), perm[b].end(), f->hPerm + (size_t)b * cap);
+    }
+    HIPC(hipMemcpyAsync(f->dPerm, f->hPerm, sizeof(int) * B * cap, hipMemcpyHostToDevice, f->stream));
+    return EQF_OK;
+}
+
+int probe(eqf_filter* f, const double* bearings, long long bearStride, bool withPerm) {
+    const int B = f->B, cap = f->cap;
+    const int nmax = std::max(1, maxN(f));
+    int rc = profiled(f, EQF_PROF_CHURN, [&] {
+        hipLaunchKernelGGL(k_probe, dim3((nmax + 127) / 128, B), dim3(128), 0, f->stream, f->g[f->pG], f->p0, f->Q[f->pG], cap, bearings,
+            bearStride, withPerm ? f->dPerm : nullptr, f->dChord, f->dDepth2);
+    });
+    if (rc) return rc;
+    HIPC(hipMemcpyAsync(f->hChord, f->dChord, sizeof(double) * B * cap, hipMemcpyDeviceToHost, f->stream));
+    HIPC(hipMemcpyAsync(f->hDepth2, f->dDepth2, sizeof(double) * B * cap, hipMemcpyDeviceToHost, f->stream));
+    HIPC(hipStreamSynchronize(f->stream));
+    return EQF_OK;
+}
+
+// processVisionData after integrateUpToTime: bookkeeping + update.  measIds[b] ascending ids of filter b,
+// device bearings at bearings + b*bearStride.  active[b] = integration succeeded && initialised.
+int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std::vector<int>& nb, const double* bearings,
+    long long bearStride, const std::vector<char>& active, int* status) {
+    const int B = f->B, cap = f->cap;
+    // ---- removeOldLandmarks (VIOFilter.cpp:393-419): state ids absent from the measurement
+    bool anyLost = false;
+    std::vector<std::vector<int>> keep(B);
+    for (int b = 0; b < B; ++b) {
+        auto& sid = f->ids[b];
+        keep[b].resize(sid.size());
+        for (size_t i = 0; i < sid.size(); ++i) keep[b][i] = int(i);
+        if (!active[b]) continue;
+        std::vector<int> kept;
+        for (size_t i = 0; i < sid.size(); ++i)
+            if (std::binary_search(measIds[b], measIds[b] + nb[b], sid[i])) kept.push_back(int(i));
+        if (kept.size() != sid.size()) {
+            anyLost = true;
+            keep[b] = kept;
+        }
+    }
+    if (anyLost) {
+        int rc = compact(f, keep);
+        if (rc) return rc;
+        for (int b = 0; b < B; ++b) {
+            std::vector<int> nid;
+            for (int o : keep[b]) nid.push_back(f->ids[b][o]);
+            f->ids[b] = nid;
+        }
+    }
+    // ---- matchMeasurementsToState (:211-230): perm[b][i] = measurement index of state landmark i
+    std::vector<std::vector<int>> perm(B);
+    auto buildPerm = [&]() {
+        for (int b = 0; b < B; ++b) {
+            perm[b].assign(f->ids[b].size(), -1);
+            if (!active[b]) continue;
+            for (size_t i = 0; i < f->ids[b].size(); ++i) {
+                const int* it = std::lower_bound(measIds[b], measIds[b] + nb[b], f->ids[b][i]);
+                perm[b][i] = int(it - measIds[b]);
+            }
+        }
+    };
+    buildPerm();
+    // ---- removeOutliers (:429-443).  A chord between unit vectors never exceeds 2.
+    std::vector<std::vector<char>> dropped(B);  // measurement indices erased together with their landmark
+    for (int b = 0; b < B; ++b) dropped[b].assign(nb[b], 0);
+    if (f->set.outlierThreshold < 2.0 && maxN(f) > 0) {
+        int rc = uploadPerm(f, perm);
+        if (rc) return rc;
+        rc = probe(f, bearings, bearStride, true);
+        if (rc) return rc;
+        bool anyOut = false;
+        for (int b = 0; b < B; ++b) {
+            keep[b].clear();
+            for (size_t i = 0; i < f->ids[b].size(); ++i) {
+                const bool out = active[b] && f->hChord[(size_t)b * cap + i] > f->set.outlierThreshold;
+                if (out) {
+                    anyOut = true;
+                    dropped[b][perm[b][i]] = 1;
+                } else {
+                    keep[b].push_back(int(i));
+                }
+            }
+        }
+        if (anyOut) {
+            rc = compact(f, keep);
+            if (rc) return rc;
+            for (int b = 0; b < B; ++b) {
+                std::vector<int> nid;
+                for (int o : keep[b]) nid.push_back(f->ids[b][o]);
+                f->ids[b] = nid;
+            }
+            buildPerm();
+        }
+    }
+    // ---- addNewLandmarks (:345-391)
+    bool needDepth = false;
+    std::vector<std::vector<int>> fresh(B);  // measurement indices of new landmarks, in measurement order
+    for (int b = 0; b < B; ++b) {
+        if (!active[b]) continue;
+        for (int k = 0; k < nb[b]; ++k) {
+            if (dropped[b][k]) continue;
+            if (std::find(f->ids[b].begin(), f->ids[b].end(), measIds[b][k]) == f->ids[b].end()) fresh[b].push_back(k);
+        }
+        if (!fresh[b].empty()) {
+            if (f->ids[b].size() + fresh[b].size() > (size_t)cap) return EQF_ERR_CAPACITY;
+            if (!f->ids[b].empty()) needDepth = true;
+        }
+    }
+    if (needDepth) {
+        int rc = probe(f, nullptr, 0, false);
+        if (rc) return rc;
+    }
+    for (int b = 0; b < B; ++b) {
+        if (fresh[b].empty()) continue;
+        const int nOld = int(f->ids[b].size()), nNew = int(fresh[b].size());
+        double depth = f->set.initialSceneDepth;
+        if (nOld > 0) {  // sqrt of the size/2-th order statistic of the squared depths (:357-366)
+            std::vector<double> d2(f->hDepth2 + (size_t)b * cap, f->hDepth2 + (size_t)b * cap + nOld);
+            std::nth_element(d2.begin(), d2.begin() + d2.size() / 2, d2.end());
+            depth = std::pow(d2[d2.size() / 2], 0.5);
+        }
+        HIPC(hipStreamSynchronize(f->stream));
+        std::copy(fresh[b].begin(), fresh[b].end(), f->hSrc);
+        HIPC(hipMemcpyAsync(f->dSrc, f->hSrc, sizeof(int) * nNew, hipMemcpyHostToDevice, f->stream));
+        const long long work = (long long)3 * nNew * (kLm0 + 3 * (nOld + nNew)) * 2;
+        const int blocks = int(std::min<long long>(1024, (work + 255) / 256));
+        int rc = profiled(f, EQF_PROF_CHURN, [&] {
+            if (f->precision == EQF_PRECISION_F32)
+                hipLaunchKernelGGL(k_append<float>, dim3(std::max(1, blocks)), dim3(256), 0, f->stream, f->g[f->pG], b, nOld, nNew, depth,
+                    f->set.initialPointVariance, cap, bearings + (long long)b * bearStride, f->dSrc, f->p0, f->Q[f->pG],
+                    static_cast<float*>(f->Sigma[f->pS]), f->sigmaStride, f->ld);
+            else
+                hipLaunchKernelGGL(k_append<double>, dim3(std::max(1, blocks)), dim3(256), 0, f->stream, f->g[f->pG], b, nOld, nNew, depth,
+                    f->set.initialPointVariance, cap, bearings + (long long)b * bearStride, f->dSrc, f->p0, f->Q[f->pG],
+                    static_cast<double*>(f->Sigma[f->pS]), f->sigmaStride, f->ld);
+        });
+        if (rc) return rc;
+        HIPC(hipGetLastError());
+        for (int k : fresh[b]) f->ids[b].push_back(measIds[b][k]);
+    }
+    // ---- the update proper (:258-297)
+    buildPerm();
+    bool identity = true, anyWork = false;
+    int Nmax = 0;
+    for (int b = 0; b < B; ++b) {
+        if (!active[b]) continue;
+        if (f->ids[b].empty()) {
+            if (status) status[b] = EQF_SKIPPED_NO_BEARINGS;
+            continue;
+        }
+        anyWork = true;
+        Nmax = std::max(Nmax, int(f->ids[b].size()));
+        for (size_t i = 0; i < perm[b].size(); ++i)
+            if (perm[b][i] != int(i)) identity = false;
+    }
+    if (!anyWork) return EQF_OK;
+    if (!identity) {
+        int rc = uploadPerm(f, perm);
+        if (rc) return rc;
+    }
+    return launchUpdate(f, bearings, bearStride, identity ? nullptr : f->dPerm, Nmax);
+}
+
+void freeAll(eqf_filter* f) {
+    if (!f) return;
+    for (int p = 0; p < 2; ++p) {
+        hipFree(f->Sigma[p]);
+        hipFree(f->g[p]);
+        hipFree(f->Q[p]);
+    }
+    for (void* p : {(void*)f->p0, (void*)f->SA, (void*)f->SL, (void*)f->YW, (void*)f->YO, (void*)f->EA, (void*)f->EL, (void*)f->ZW,
+             (void*)f->ZO, (void*)f->dbgDelta, (void*)f->dbgGamma, (void*)f->dbgGammaTot, (void*)f->errflag, (void*)f->dMap,
+             (void*)f->dNewN, (void*)f->dPerm, (void*)f->dSrc, (void*)f->dChord, (void*)f->dDepth2, (void*)f->dScratch, (void*)f->dMeas,
+             (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear})
+        hipFree(p);
+    for (void* p : {(void*)f->hMap, (void*)f->hNewN, (void*)f->hPerm, (void*)f->hSrc, (void*)f->hChord, (void*)f->hDepth2, (void*)f->hMeas,
+             (void*)f->hOut, (void*)f->hRing})
+        if (p) hipHostFree(p);
+    for (auto& e : f->evRing)
+        if (e) hipEventDestroy(e);
+    if (f->evMeas) hipEventDestroy(f->evMeas);
+    for (auto e : f->evPool) hipEventDestroy(e);
+    for (auto& p : f->profPairs) {
+        hipEventDestroy(p.a);
+        hipEventDestroy(p.b);
+    }
+    if (f->stream) hipStreamDestroy(f->stream);
+    delete f;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* eqf_version(void) { return "eqf_vio_amd 0.1 (gfx950)"; }
+
+void eqf_settings_default(eqf_settings* s) {  // VIOFilterSettings.h:29-50
+    std::memset(s, 0, sizeof(*s));
+    s->biasOmegaProcessVariance = 0.001;
+    s->biasAccelProcessVariance = 0.001;
+    s->gravityProcessVariance = 0.001;
+    s->velocityProcessVariance = 0.001;
+    s->pointProcessVariance = 0.001;
+    s->velOmegaVariance = 0.1;
+    s->velAccelVariance = 0.1;
+    s->measurementVariance = 0.1;
+    s->initialGravityVariance = 1.0;
+    s->initialVelocityVariance = 1.0;
+    s->initialPointVariance = 1.0;
+    s->initialBiasOmegaVariance = 1.0;
+    s->initialBiasAccelVariance = 1.0;
+    s->initialSceneDepth = 1.0;
+    s->outlierThreshold = 0.01;
+    s->useInnovationLift = 1;
+    s->useDiscreteInnovationLift = 1;
+    s->useDiscreteVelocityLift = 1;
+    s->fastRiccati = 0;
+    s->cameraOffset_q[0] = 1.0;
+}
+
+int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, int device, int precision, eqf_filter** out) {
+    if (!settings || !out || capacity_landmarks < 1 || batch < 1) return EQF_ERR_INVALID;
+    if (precision != EQF_PRECISION_F64 && precision != EQF_PRECISION_F32) return EQF_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return EQF_ERR_NO_DEVICE;
+    HIPC(hipSetDevice(device));
+    eqf_filter* f = new eqf_filter();
+    f->B = batch;
+    f->cap = capacity_landmarks;
+    f->device = device;
+    f->precision = precision;
+    f->esz = precision == EQF_PRECISION_F32 ? 4 : 8;
+    f->set = *settings;
+    Params& p = f->prm;
+    p.biasOmegaProcessVariance = settings->biasOmegaProcessVariance;
+    p.biasAccelProcessVariance = settings->biasAccelProcessVariance;
+    p.gravityProcessVariance = settings->gravityProcessVariance;
+    p.velocityProcessVariance = settings->velocityProcessVariance;
+    p.pointProcessVariance = settings->pointProcessVariance;
+    p.velOmegaVariance = settings->velOmegaVariance;
+    p.velAccelVariance = settings->velAccelVariance;
+    p.measurementVariance = settings->measurementVariance;
+    p.initialPointVariance = settings->initialPointVariance;
+    std::memcpy(p.camq, settings->cameraOffset_q, sizeof(p.camq));
+    std::memcpy(p.camx, settings->cameraOffset_x, sizeof(p.camx));
+    p.useInnovationLift = settings->useInnovationLift;
+    p.useDiscreteInnovationLift = settings->useDiscreteInnovationLift;
+    p.useDiscreteVelocityLift = settings->useDiscreteVelocityLift;
+
+    const int B = batch, cap = f->cap;
+    f->nTot = kLm0 + 3 * cap;
+    f->ld = roundUp(f->nTot, 16);
+    f->sigmaStride = (long long)f->nTot * f->ld;
+    const int mpC = roundUp(2 * cap, kNB), nepC = roundUp(eDim(cap), kNB), ycC = roundUp(yCols(cap), kNB);
+    f->ldS = mpC; f->ldY = ycC; f->ldE = nepC; f->ldZ = kNB;
+    f->strideS = (long long)mpC * mpC; f->strideY = (long long)mpC * ycC;
+    f->strideE = (long long)nepC * nepC; f->strideZ = (long long)nepC * kNB;
+    int rc = EQF_OK;
+    auto chk = [&](int r) { if (r && !rc) rc = r; };
+    if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) rc = EQF_ERR_HIP;
+    for (int q = 0; q < 2 && !rc; ++q) {
+        if (hipMalloc(&f->Sigma[q], f->esz * f->sigmaStride * B) != hipSuccess) rc = EQF_ERR_HIP;
+        chk(dmalloc(&f->g[q], B));
+        chk(dmalloc(&f->Q[q], (size_t)5 * cap * B));
+    }
+    chk(dmalloc(&f->p0, (size_t)3 * cap * B));
+    chk(dmalloc(&f->SA, f->strideS * B)); chk(dmalloc(&f->SL, f->strideS * B));
+    chk(dmalloc(&f->YW, f->strideY * B)); chk(dmalloc(&f->YO, f->strideY * B));
+    chk(dmalloc(&f->EA, f->strideE * B)); chk(dmalloc(&f->EL, f->strideE * B));
+    chk(dmalloc(&f->ZW, f->strideZ * B)); chk(dmalloc(&f->ZO, f->strideZ * B));
+    chk(dmalloc(&f->dbgDelta, (size_t)2 * cap * B));
+    chk(dmalloc(&f->dbgGamma, (size_t)(kLm0 + 3 * cap) * B));
+    chk(dmalloc(&f->dbgGammaTot, (size_t)(9 + 3 * cap) * B));
+    chk(dmalloc(&f->errflag, 1));
+    chk(dmalloc(&f->dMap, (size_t)cap * B)); chk(dmalloc(&f->dNewN, B)); chk(dmalloc(&f->dPerm, (size_t)cap * B));
+    chk(dmalloc(&f->dSrc, cap)); chk(dmalloc(&f->dChord, (size_t)cap * B)); chk(dmalloc(&f->dDepth2, (size_t)cap * B));
+    chk(dmalloc(&f->dScratch, (size_t)8 * cap * B)); chk(dmalloc(&f->dMeas, (size_t)3 * cap * B));
+    chk(dmalloc(&f->dOut, (size_t)f->nTot * f->nTot + 16));
+    chk(dmalloc(&f->dRing, (size_t)kRing * B));
+    chk(hmalloc(&f->hMap, (size_t)cap * B)); chk(hmalloc(&f->hNewN, B)); chk(hmalloc(&f->hPerm, (size_t)cap * B));
+    chk(hmalloc(&f->hSrc, cap)); chk(hmalloc(&f->hChord, (size_t)cap * B)); chk(hmalloc(&f->hDepth2, (size_t)cap * B));
+    chk(hmalloc(&f->hMeas, (size_t)3 * cap * B)); chk(hmalloc(&f->hOut, (size_t)f->nTot * f->nTot + 16));
+    chk(hmalloc(&f->hRing, (size_t)kRing * B));
+    if (!rc) {
+        for (auto& e : f->evRing)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = EQF_ERR_HIP;
+        if (hipEventCreateWithFlags(&f->evMeas, hipEventDisableTiming) != hipSuccess) rc = EQF_ERR_HIP;
+    }
+    if (!rc) rc = initState(f);
+    if (rc) {
+        freeAll(f);
+        return rc;
+    }
+    *out = f;
+    return EQF_OK;
+}
+
+void eqf_destroy(eqf_filter* f) {
+    if (!f) return;
+    hipSetDevice(f->device);
+    if (f->stream) hipStreamSynchronize(f->stream);
+    freeAll(f);
+}
+
+int eqf_reset(eqf_filter* f) {
+    if (!f) return EQF_ERR_INVALID;
+    HIPC(hipSetDevice(f->device));
+    HIPC(hipStreamSynchronize(f->stream));
+    return initState(f);
+}
+
+int eqf_synchronize(eqf_filter* f) {
+    if (!f) return EQF_ERR_INVALID;
+    HIPC(hipStreamSynchronize(f->stream));
+    return EQF_OK;
+}
+
+int eqf_process_imu(eqf_filter* f, const double* stamps, const double* omega, const double* accel, int* status) {
+    if (!f || !stamps || !omega || !accel) return EQF_ERR_INVALID;
+    HIPC(hipSetDevice(f->device));
+    std::vector<ImuRec> recs(f->B);
+    for (int b = 0; b < f->B; ++b) {
+        recs[b].stamp = stamps[b];
+        for (int i = 0; i < 3; ++i) {
+            recs[b].w[i] = omega[3 * b + i];
+            recs[b].a[i] = accel[3 * b + i];
+        }
+        recs[b].pad_ = 0;
+    }
+    const ImuRec* dev = nullptr;
+    int slot = -1;
+    int rc = stageRecs(f, recs.data(), &dev, &slot);
+    if (rc) return rc;
+    rc = launchPropagate(f, dev, recs[0], stamps, true, !f->set.fastRiccati, status);
+    if (rc) return rc;
+    return releaseSlot(f, slot);
+}
+
+int eqf_process_vision(eqf_filter* f, const double* stamps, const int* nb, const int* ids, const double* bearings, int stride,
+    int* status) {
+    if (!f || !stamps || !nb || (!ids && stride > 0) || (!bearings && stride > 0)) return EQF_ERR_INVALID;
+    HIPC(hipSetDevice(f->device));
+    const int B = f->B, cap = f->cap;
+    for (int b = 0; b < B; ++b) {
+        if (nb[b] < 0 || nb[b] > stride) return EQF_ERR_INVALID;
+        if (nb[b] > cap) return EQF_ERR_CAPACITY;
+        for (int k = 1; k < nb[b]; ++k)
+            if (ids[(size_t)b * stride + k] < ids[(size_t)b * stride + k - 1]) return EQF_ERR_UNSORTED;  // VIOFilter.cpp:239-240
+    }
+    // integrateUpToTime(measurement.stamp) (VIOFilter.cpp:234)
+    std::vector<ImuRec> recs(B);
+    for (int b = 0; b < B; ++b) {
+        std::memset(&recs[b], 0, sizeof(ImuRec));
+        recs[b].stamp = stamps[b];
+    }
+    const ImuRec* dev = nullptr;
+    int slot = -1;
+    int rc = stageRecs(f, recs.data(), &dev, &slot);
+    if (rc) return rc;
+    std::vector<int> st(B, EQF_OK);
+    rc = launchPropagate(f, dev, recs[0], stamps, false, true, st.data());
+    if (rc) return rc;
+    rc = releaseSlot(f, slot);
+    if (rc) return rc;
+    // bearings -> device
+    HIPC(hipEventSynchronize(f->evMeas));
+    std::vector<const int*> mids(B);
+    std::vector<int> nbv(nb, nb + B);
+    std::vector<char> active(B);
+    for (int b = 0; b < B; ++b) {
+        std::memcpy(f->hMeas + (size_t)b * 3 * cap, bearings + (size_t)b * stride * 3, sizeof(double) * 3 * nb[b]);
+        mids[b] = ids + (size_t)b * stride;
+        active[b] = st[b] == EQF_OK;
+    }
+    HIPC(hipMemcpyAsync(f->dMeas, f->hMeas, sizeof(double) * 3 * cap * B, hipMemcpyHostToDevice, f->stream));
+    HIPC(hipEventRecord(f->evMeas, f->stream));
+    rc = visionCore(f, mids, nbv, f->dMeas, (long long)3 * cap, active, st.data());
+    if (status) std::copy(st.begin(), st.end(), status);
+    return rc;
+}
+
+int eqf_stream_upload(eqf_filter* f, int K, const double* imu, int F, const double* vstamps, int nbear, const int* ids,
+    const double* bearings) {
+    if (!f || K < 0 || F < 0 || nbear < 0 || nbear > f->cap) return EQF_ERR_INVALID;
+    HIPC(hipSetDevice(f->device));
+    HIPC(hipStreamSynchronize(f->stream));
+    const int B = f->B;
+    for (int k = 1; k < nbear; ++k)
+        if (ids[k] < ids[k - 1]) return EQF_ERR_UNSORTED;
+    hipFree(f->sImu); hipFree(f->sVis); hipFree(f->sBear);
+    f->sImu = nullptr; f->sVis = nullptr; f->sBear = nullptr;
+    std::vector<ImuRec> ri((size_t)K * B), rv((size_t)F * B);
+    f->hImuStamp.resize((size_t)K * B);
+    f->hVisStamp.resize((size_t)F * B);
+    for (size_t e = 0; e < (size_t)K * B; ++e) {
+        const double* s = imu + 7 * e;
+        ri[e].stamp = s[0];
+        for (int i = 0; i < 3; ++i) {
+            ri[e].w[i] = s[1 + i];
+            ri[e].a[i] = s[4 + i];
+        }
+        ri[e].pad_ = 0;
+        f->hImuStamp[e] = s[0];
+    }
+    for (size_t e = 0; e < (size_t)F * B; ++e) {
+        std::memset(&rv[e], 0, sizeof(ImuRec));
+        rv[e].stamp = vstamps[e];
+        f->hVisStamp[e] = vstamps[e];
+    }
+    int rc = dmalloc(&f->sImu, ri.size());
+    if (!rc) rc = dmalloc(&f->sVis, rv.size());
+    if (!rc) rc = dmalloc(&f->sBear, (size_t)F * B * nbear * 3);
+    if (rc) return rc;
+    HIPC(hipMemcpy(f->sImu, ri.data(), sizeof(ImuRec) * ri.size(), hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(f->sVis, rv.data(), sizeof(ImuRec) * rv.size(), hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(f->sBear, bearings, sizeof(double) * (size_t)F * B * nbear * 3, hipMemcpyHostToDevice));
+    f->sK = K; f->sF = F; f->sNb = nbear;
+    f->sIds.assign(ids, ids + nbear);
+    return EQF_OK;
+}
+
+int eqf_stream_imu(eqf_filter* f, int k) {
+    if (!f || k < 0 || k >= f->sK) return EQF_ERR_INVALID;
+    ImuRec dummy{};
+    return launchPropagate(f, f->sImu + (size_t)k * f->B, dummy, f->hImuStamp.data() + (size_t)k * f->B, true, !f->set.fastRiccati, nullptr);
+}
+
+int eqf_stream_vision(eqf_filter* f, int fr) {
+    if (!f || fr < 0 || fr >= f->sF) return EQF_ERR_INVALID;
+    const int B = f->B;
+    ImuRec dummy{};
+    std::vector<int> st(B, EQF_OK);
+    int rc = launchPropagate(f, f->sVis + (size_t)fr * B, dummy, f->hVisStamp.data() + (size_t)fr * B, false, true, st.data());
+    if (rc) return rc;
+    std::vector<const int*> mids(B, f->sIds.data());
+    std::vector<int> nbv(B, f->sNb);
+    std::vector<char> active(B);
+    for (int b = 0; b < B; ++b) active[b] = st[b] == EQF_OK;
+    return visionCore(f, mids, nbv, f->sBear + (size_t)fr * B * f->sNb * 3, (long long)f->sNb * 3, active, st.data());
+}
+
+int eqf_get_time(eqf_filter* f, double* t) {
+    if (!f || !t) return EQF_ERR_INVALID;
+    std::copy(f->curTime.begin(), f->curTime.end(), t);
+    return EQF_OK;
+}
+
+int eqf_num_landmarks(eqf_filter* f, int b) {
+    if (!f || b < 0 || b >= f->B) return EQF_ERR_INVALID;
+    return int(f->ids[b].size());
+}
+
+int eqf_get_ids(eqf_filter* f, int b, int* ids) {
+    if (!f || b < 0 || b >= f->B || !ids) return EQF_ERR_INVALID;
+    std::copy(f->ids[b].begin(), f->ids[b].end(), ids);
+    return EQF_OK;
+}
+
+int eqf_get_state_estimate(eqf_filter* f, int b, double* pose_q, double* pose_x, double* velocity, double* p) {
+    if (!f || b < 0 || b >= f->B) return EQF_ERR_INVALID;
+    HIPC(hipSetDevice(f->device));
+    const int N = int(f->ids[b].size());
+    hipLaunchKernelGGL(k_state_estimate, dim3((N + 255) / 256 + 1), dim3(256), 0, f->stream, f->g[f->pG], b, f->p0, f->Q[f->pG], f->cap, f->dOut);
+    HIPC(hipMemcpyAsync(f->hOut, f->dOut, sizeof(double) * (10 + 3 * N), hipMemcpyDeviceToHost, f->stream));
+    HIPC(hipStreamSynchronize(f->stream));
+    if (pose_q) std::copy(f->hOut, f->hOut + 4, pose_q);
+    if (pose_x) std::copy(f->hOut + 4, f->hOut + 7, pose_x);
+    if (velocity) std::copy(f->hOut + 7, f->hOut + 10, velocity);
+    if (p) std::copy(f->hOut + 10, f->hOut + 10 + 3 * N, p);
+    return EQF_OK;
+}
+
+static int fetchGlob(eqf_filter* f, int b, Glob* g) {
+    HIPC(hipSetDevice(f->device));
+    HIPC(hipStreamSynchronize(f->stream));
+    HIPC(hipMemcpy(g, f->g[f->pG] + b, sizeof(Glob), hipMemcpyDeviceToHost));
+    return EQF_OK;
+}
+
+int eqf_get_origin(eqf_filter* f, int b, double* pose_q, double* pose_x, double* velocity, double* p) {
+    if (!f || b < 0 || b >= f->B) return EQF_ERR_INVALID;
+    Glob g;
+    int rc = fetchGlob(f, b, &g);
+    if (rc) return rc;
+    if (pose_q) std::copy(g.P0q, g.P0q + 4, pose_q);
+    if (pose_x) std::copy(g.P0x, g.P0x + 3, pose_x);
+    if (velocity) std::copy(g.v0, g.v0 + 3, velocity);
+    if (p) {
+        const int N = int(f->ids[b].size()), cap = f->cap;
+        std::vector<double> tmp((size_t)3 * cap);
+        HIPC(hipMemcpy(tmp.data(), f->p0 + (size_t)b * 3 * cap, sizeof(double) * 3 * cap, hipMemcpyDeviceToHost));
+        for (int i = 0; i < N; ++i)
+            for (int c = 0; c < 3; ++c) p[3 * i + c] = tmp[(size_t)c * cap + i];
+    }
+    return EQF_OK;
+}
+
+int eqf_get_group(eqf_filter* f, int b, double* A_q, double* A_x, double* w, double* Q_q, double* Q_a) {
+    if (!f || b < 0 || b >= f->B) return EQF_ERR_INVALID;
+    Glob g;
+    int rc = fetchGlob(f, b, &g);
+    if (rc) return rc;
+    if (A_q) std::copy(g.Aq, g.Aq + 4, A_q);
+    if (A_x) std::copy(g.Ax, g.Ax + 3, A_x);
+    if (w) std::copy(g.w, g.w + 3, w);
+    if (Q_q || Q_a) {
+        const int N = int(f->ids[b].size()), cap = f->cap;
+        std::vector<double> tmp((size_t)5 * cap);
+        HIPC(hipMemcpy(tmp.data(), f->Q[f->pG] + (size_t)b * 5 * cap, sizeof(double) * 5 * cap, hipMemcpyDeviceToHost));
+        for (int i = 0; i < N; ++i) {
+            if (Q_q)
+                for (int c = 0; c < 4; ++c) Q_q[4 * i + c] = tmp[(size_t)c * cap + i];
+            if (Q_a) Q_a[i] = tmp[(size_t)4 * cap + i];
+        }
+    }
+    return EQF_OK;
+}
+
+int eqf_get_bias(eqf_filter* f, int b, double* bias6) {
+    if (!f || b < 0 || b >= f->B || !bias6) return EQF_ERR_INVALID;
+    Glob g;
+    int rc = fetchGlob(f, b, &g);
+    if (rc) return rc;
+    std::copy(g.bias, g.bias + 6, bias6);
+    return EQF_OK;
+}
+
+int eqf_get_sigma(eqf_filter* f, int b, double* dst, int ld) {
+    if (!f || b < 0 || b >= f->B || !dst) return EQF_ERR_INVALID;
+    HIPC(hipSetDevice(f->device));
+    const int n = kBase + 3 * int(f->ids[b].size());
+    if (ld < n) return EQF_ERR_INVALID;
+    const dim3 grid((n + 255) / 256, n);
+    if (f->precision == EQF_PRECISION_F32)
+        hipLaunchKernelGGL(k_sigma_export<float>, grid, dim3(256), 0, f->stream,
+            static_cast<const float*>(f->Sigma[f->pS]) + (long long)b * f->sigmaStride, f->ld, n, f->dOut, n);
+    else
+        hipLaunchKernelGGL(k_sigma_export<double>, grid, dim3(256), 0, f->stream,
+            static_cast<const double*>(f->Sigma[f->pS]) + (long long)b * f->sigmaStride, f->ld, n, f->dOut, n);
+    HIPC(hipMemcpyAsync(f->hOut, f->dOut, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, f->stream));
+    HIPC(hipStreamSynchronize(f->stream));
+    for (int r = 0; r < n; ++r) std::copy(f->hOut + (size_t)r * n, f->hOut + (size_t)(r + 1) * n, dst + (size_t)r * ld);
+    return EQF_OK;
+}
+
+int eqf_set_sigma(eqf_filter* f, int b, const double* src, int ld) {
+    if (!f || b < 0 || b >= f->B || !src) return EQF_ERR_INVALID;
+    HIPC(hipSetDevice(f->device));
+    const int n = kBase + 3 * int(f->ids[b].size());
+    if (ld < n) return EQF_ERR_INVALID;
+    HIPC(hipStreamSynchronize(f->stream));
+    for (int r = 0; r < n; ++r) std::copy(src + (size_t)r * ld, src + (size_t)r * ld + n, f->hOut + (size_t)r * n);
+    HIPC(hipMemcpyAsync(f->dOut, f->hOut, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, f->stream));
+    const dim3 grid((n + 256) / 256, n + 1);
+    if (f->precision == EQF_PRECISION_F32)
+        hipLaunchKernelGGL(k_sigma_import<float>, grid, dim3(256), 0, f->stream,
+            static_cast<float*>(f->Sigma[f->pS]) + (long long)b * f->sigmaStride, f->ld, n, f->dOut, n);
+    else
+        hipLaunchKernelGGL(k_sigma_import<double>, grid, dim3(256), 0, f->stream,
+            static_cast<double*>(f->Sigma[f->pS]) + (long long)b * f->sigmaStride, f->ld, n, f->dOut, n);
+    HIPC(hipStreamSynchronize(f->stream));
+    return EQF_OK;
+}
+
+int eqf_get_last_update(eqf_filter* f, int b, double* delta, double* gamma, double* Gamma) {
+    if (!f || b < 0 || b >= f->B) return EQF_ERR_INVALID;
+    HIPC(hipSetDevice(f->device));
+    HIPC(hipStreamSynchronize(f->stream));
+    const int N = int(f->ids[b].size()), cap = f->cap;
+    if (delta) HIPC(hipMemcpy(delta, f->dbgDelta + (size_t)b * 2 * cap, sizeof(double) * 2 * N, hipMemcpyDeviceToHost));
+    if (gamma) {
+        std::vector<double> tmp(kLm0 + 3 * N);
+        HIPC(hipMemcpy(tmp.data(), f->dbgGamma + (size_t)b * (kLm0 + 3 * cap), sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < kBase; ++i) gamma[i] = tmp[i];
+        for (int i = 0; i < 3 * N; ++i) gamma[kBase + i] = tmp[kLm0 + i];
+    }
+    if (Gamma) HIPC(hipMemcpy(Gamma, f->dbgGammaTot + (size_t)b * (9 + 3 * cap), sizeof(double) * (9 + 3 * N), hipMemcpyDeviceToHost));
+    return EQF_OK;
+}
+
+int eqf_device_error(eqf_filter* f) {
+    if (!f) return EQF_ERR_INVALID;
+    if (hipSetDevice(f->device) != hipSuccess) return EQF_ERR_HIP;
+    if (hipStreamSynchronize(f->stream) != hipSuccess) return EQF_ERR_HIP;
+    int e = 0;
+    if (hipMemcpy(&e, f->errflag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return EQF_ERR_HIP;
+    return e;
+}
+
+int eqf_set_dense_propagate(eqf_filter* f, int on) {
+    if (!f) return EQF_ERR_INVALID;
+    if (on) return EQF_ERR_UNSUPPORTED;
+    f->densePropagate = 0;
+    return EQF_OK;
+}
+
+int eqf_profile_enable(eqf_filter* f, int on) {
+    if (!f) return EQF_ERR_INVALID;
+    if (f->prof && !on) {
+        int rc = profDrain(f);
+        if (rc) return rc;
+    }
+    f->prof = on != 0;
+    if (on) {
+        std::fill(std::begin(f->profCount), std::end(f->profCount), 0);
+        std::fill(std::begin(f->profMs), std::end(f->profMs), 0.0);
+    }
+    return EQF_OK;
+}
+
+int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_ms) {
+    if (!f || cls < 0 || cls >= EQF_PROF_CLASSES) return EQF_ERR_INVALID;
+    int rc = profDrain(f);
+    if (rc) return rc;
+    if (launches) *launches = f->profCount[cls];
+    if (total_ms) *total_ms = f->profMs[cls];
+    return EQF_OK;
+}
+
+const char* eqf_profile_class_name(int cls) {
+    static const char* names[EQF_PROF_CLASSES] = {"k_propagate", "k_update_prep", "k_chol_step", "k_backsolve", "k_update_finish",
+        "k_downdate", "churn"};
+    return (cls >= 0 && cls < EQF_PROF_CLASSES) ? names[cls] : "?";
+}
+
+}  // extern "C"

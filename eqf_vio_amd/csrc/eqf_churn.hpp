@@ -1,0 +1,156 @@
+// Landmark-set changes and read-out kernels (gfx950).
+//
+// Device side of VIOFilter::addNewLandmarks / removeLandmarkAtIndex / removeOutliers
+// (eqf_vio/src/VIOFilter.cpp:345-443) and of VIOFilter::stateEstimate (:304).  The id matching itself is
+// integer work on ids the host already holds (VIOFilter.cpp:211-230, :393-419) and stays on the host.
+#pragma once
+#include "eqf_device.hpp"
+#include "eqf_math.hpp"
+
+namespace eqf {
+
+// Per-landmark probe of the current estimate: chord between the measured bearing and the predicted one
+// (removeOutliers, VIOFilter.cpp:429-443) and squared depth (addNewLandmarks median, :357-366).
+__global__ void k_probe(const Glob* g, const double* p0, const double* Q, int cap, const double* bearings,
+    long long bearStride, const int* perm, double* chord, double* depth2) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g[b].N) return;
+    const double* P = p0 + (long long)b * 3 * cap;
+    const double* q = Q + (long long)b * 5 * cap;
+    const quat Qq = quat{q[i], q[cap + i], q[2 * cap + i], q[3 * cap + i]};
+    const d3 qhat = scl(1.0 / q[4 * cap + i], qrot(qinv(Qq), mk3(P[i], P[cap + i], P[2 * cap + i])));
+    depth2[(long long)b * cap + i] = dot3(qhat, qhat);
+    double ch = 0.0;
+    if (bearings) {
+        const int k = perm ? perm[(long long)b * cap + i] : i;
+        if (k >= 0) {
+            const double* y = bearings + (long long)b * bearStride + 3 * k;
+            ch = nrm3(sub(mk3(y[0], y[1], y[2]), unit3(qhat)));
+        }
+    }
+    chord[(long long)b * cap + i] = ch;
+}
+
+// Remove landmarks: Sigma_out = Sigma_in with the rows/cols of dropped landmarks erased, map[b][newI] = oldI.
+// Filters without removals pass the identity map (the ping-pong parity is shared by the whole batch).
+template <typename T>
+__global__ __launch_bounds__(256) void k_compact_sigma(const Glob* g, const int* map, const int* newN, int cap,
+    const T* Sin, T* Sout, long long sigmaStride, int ld) {
+    const int b = blockIdx.z;
+    const int Nn = newN[b];
+    const int nvn = kLm0 + 3 * Nn;
+    const int R = blockIdx.y;  // output row
+    if (R >= nvn) return;
+    const int* mp = map + (long long)b * cap;
+    const int Rs = (R < kLm0) ? R : kLm0 + 3 * mp[(R - kLm0) / 3] + (R - kLm0) % 3;
+    const T* src = Sin + (long long)b * sigmaStride + (long long)Rs * ld;
+    T* dst = Sout + (long long)b * sigmaStride + (long long)R * ld;
+    for (int Cc = blockIdx.x * blockDim.x + threadIdx.x; Cc < nvn; Cc += gridDim.x * blockDim.x) {
+        const int Cs = (Cc < kLm0) ? Cc : kLm0 + 3 * mp[(Cc - kLm0) / 3] + (Cc - kLm0) % 3;
+        dst[Cc] = src[Cs];
+    }
+}
+// Compact the per-landmark arrays through a scratch copy (gather then write back), one workgroup per filter.
+__global__ void k_compact_lm_gather(const int* map, const int* newN, int cap, const double* p0, const double* Q, double* scratch) {
+    const int b = blockIdx.x;
+    const int* mp = map + (long long)b * cap;
+    for (int i = threadIdx.x; i < newN[b]; i += blockDim.x) {
+        const int o = mp[i];
+        for (int c = 0; c < 3; ++c) scratch[((long long)b * 8 + c) * cap + i] = p0[((long long)b * 3 + c) * cap + o];
+        for (int c = 0; c < 5; ++c) scratch[((long long)b * 8 + 3 + c) * cap + i] = Q[((long long)b * 5 + c) * cap + o];
+    }
+}
+__global__ void k_compact_lm_scatter(Glob* g, const int* newN, int cap, double* p0, double* Q, const double* scratch) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < newN[b]; i += blockDim.x) {
+        for (int c = 0; c < 3; ++c) p0[((long long)b * 3 + c) * cap + i] = scratch[((long long)b * 8 + c) * cap + i];
+        for (int c = 0; c < 5; ++c) Q[((long long)b * 5 + c) * cap + i] = scratch[((long long)b * 8 + 3 + c) * cap + i];
+    }
+    if (threadIdx.x == 0) g[b].N = newN[b];
+}
+
+// Append landmarks to filter b: p0 = bearing * depth, Q = identity, Sigma grows with zero cross terms and
+// initialPointVariance on the new diagonal (VIOFilter.cpp:367-390).  src[j] = index of the bearing of the
+// j-th new landmark.
+template <typename T>
+__global__ __launch_bounds__(256) void k_append(Glob* g, int b, int nOld, int nNew, double depth, double pointVar, int cap,
+    const double* bearings /* filter b */, const int* src, double* p0, double* Q, T* S, long long sigmaStride, int ld) {
+    const int nvo = kLm0 + 3 * nOld, nvn = kLm0 + 3 * (nOld + nNew);
+    T* Sb = S + (long long)b * sigmaStride;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    // new rows (all columns) and new columns (old rows)
+    const long long total = (long long)(nvn - nvo) * nvn + (long long)nvo * (nvn - nvo);
+    for (long long e = tid; e < total; e += nth) {
+        int R, Cc;
+        if (e < (long long)(nvn - nvo) * nvn) {
+            R = nvo + (int)(e / nvn);
+            Cc = (int)(e % nvn);
+        } else {
+            const long long f = e - (long long)(nvn - nvo) * nvn;
+            R = (int)(f / (nvn - nvo));
+            Cc = nvo + (int)(f % (nvn - nvo));
+        }
+        Sb[(long long)R * ld + Cc] = (R == Cc) ? (T)pointVar : (T)0;
+    }
+    for (int j = tid; j < nNew; j += nth) {
+        const double* y = bearings + 3 * src[j];
+        const int i = nOld + j;
+        p0[((long long)b * 3 + 0) * cap + i] = y[0] * depth;
+        p0[((long long)b * 3 + 1) * cap + i] = y[1] * depth;
+        p0[((long long)b * 3 + 2) * cap + i] = y[2] * depth;
+        Q[((long long)b * 5 + 0) * cap + i] = 1.0;
+        Q[((long long)b * 5 + 1) * cap + i] = 0.0;
+        Q[((long long)b * 5 + 2) * cap + i] = 0.0;
+        Q[((long long)b * 5 + 3) * cap + i] = 0.0;
+        Q[((long long)b * 5 + 4) * cap + i] = 1.0;
+    }
+    if (tid == 0) g[b].N = nOld + nNew;
+}
+
+// stateEstimate = stateGroupAction(X, xi0) (VIOFilter.cpp:304, VIOGroup.cpp:23-45): out[b] = q(4) x(3) v(3) p(3N)
+__global__ void k_state_estimate(const Glob* g, int b, const double* p0, const double* Q, int cap, double* out) {
+    const Glob& s = g[b];
+    const se3 P0 = se3{quat{s.P0q[0], s.P0q[1], s.P0q[2], s.P0q[3]}, mk3(s.P0x[0], s.P0x[1], s.P0x[2])};
+    const se3 A = se3{quat{s.Aq[0], s.Aq[1], s.Aq[2], s.Aq[3]}, mk3(s.Ax[0], s.Ax[1], s.Ax[2])};
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid == 0) {
+        const se3 P = se3mul(P0, A);
+        const d3 v = qrot(qinv(A.q), mk3(s.v0[0] - s.w[0], s.v0[1] - s.w[1], s.v0[2] - s.w[2]));
+        out[0] = P.q.w; out[1] = P.q.x; out[2] = P.q.y; out[3] = P.q.z;
+        out[4] = P.x.x; out[5] = P.x.y; out[6] = P.x.z;
+        out[7] = v.x; out[8] = v.y; out[9] = v.z;
+    }
+    for (int i = tid; i < s.N; i += gridDim.x * blockDim.x) {
+        const double* P = p0 + (long long)b * 3 * cap;
+        const double* q = Q + (long long)b * 5 * cap;
+        const quat Qq = quat{q[i], q[cap + i], q[2 * cap + i], q[3 * cap + i]};
+        const d3 qh = scl(1.0 / q[4 * cap + i], qrot(qinv(Qq), mk3(P[i], P[cap + i], P[2 * cap + i])));
+        out[10 + 3 * i] = qh.x; out[11 + 3 * i] = qh.y; out[12 + 3 * i] = qh.z;
+    }
+}
+
+// Sigma <-> reference index map (drop / insert the pad row+column 11), fp64 on the host side.
+template <typename T>
+__global__ void k_sigma_export(const T* S, int ld, int n /* 11 + 3N */, double* out, int ldo) {
+    const int R = blockIdx.y;
+    const int Rs = R < kBase ? R : R + 1;
+    for (int Cc = blockIdx.x * blockDim.x + threadIdx.x; Cc < n; Cc += gridDim.x * blockDim.x) {
+        const int Cs = Cc < kBase ? Cc : Cc + 1;
+        out[(long long)R * ldo + Cc] = (double)S[(long long)Rs * ld + Cs];
+    }
+}
+template <typename T>
+__global__ void k_sigma_import(T* S, int ld, int n, const double* in, int ldi) {
+    const int R = blockIdx.y;  // internal row in [0, n + 1)
+    for (int Cc = blockIdx.x * blockDim.x + threadIdx.x; Cc < n + 1; Cc += gridDim.x * blockDim.x) {
+        T v = 0;
+        if (R != kBase && Cc != kBase) {
+            const int Rr = R < kBase ? R : R - 1, Cr = Cc < kBase ? Cc : Cc - 1;
+            v = (T)in[(long long)Rr * ldi + Cr];
+        }
+        S[(long long)R * ld + Cc] = v;
+    }
+}
+
+}  // namespace eqf

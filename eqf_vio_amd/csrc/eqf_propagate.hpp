@@ -1,0 +1,464 @@
+// Fused EqF propagate kernel (gfx950): per-landmark linearisation blocks + block-structured Riccati
+// step + group integration in ONE launch.
+//
+// Replaces, on the device, VIOFilter::integrateUpToTime (eqf_vio/src/VIOFilter.cpp:146-209) together
+// with EqFStateMatrixA_euclid_impl / EqFInputMatrixB_euclid_impl (src/EqFMatrices.cpp:277-317,
+// :346-382), stateGroupAction (src/VIOGroup.cpp:23-69), liftVelocityDiscrete / liftVelocity + VIOExp
+// (src/VIOGroup.cpp:178-255) and VIOGroup::operator* (:92-110).
+//
+// The reference forms F = I + T*[[0,0],[-B,A0]] densely and evaluates (F Sigma) F^T with two n^3 GEMMs.
+// F is  [[F_bb, 0], [L, D]]  with F_bb 11x11, L = 3N x 11 (non-zero columns: gyro-bias 0:3 and
+// velocity 8:11) and D block-diagonal 3x3, so per 3x3 landmark block
+//     Sigma'_IJ = (D_I Sigma_IJ + L_I Sigma_bJ) D_J^T + (L_I Sigma_bb + D_I Sigma_Ib) L_J^T + T*Q_IJ
+// which is ~10 MAC per output value: the step is bound by reading and writing Sigma once (HBM / L2),
+// not by flops.  One 256-thread workgroup owns a 16x16-landmark tile (48x48 values), one thread per 3x3
+// block; the 11-wide base panels of the tile are staged in LDS.  Sigma is ping-ponged (in -> out) because
+// every tile reads base panels that other tiles rewrite.
+#pragma once
+#include "eqf_device.hpp"
+#include "eqf_math.hpp"
+
+namespace eqf {
+
+struct PropArgs {
+    const Glob* gin;
+    Glob* gout;
+    const double* p0;    // [B][3][cap]
+    const double* Qin;   // [B][5][cap]
+    double* Qout;        // [B][5][cap]
+    const void* Sin;     // [B][rows][ld]  (T)
+    void* Sout;
+    const ImuRec* recs;  // [B] device records, or nullptr -> `inl`
+    ImuRec inl;
+    int* errflag;
+    long long sigmaStride;  // elements between filters
+    int cap, ld, NT;
+    int isImu;      // processIMUData (bias subtraction, lazy init, ZOH bookkeeping)
+    int doRiccati;  // VIOFilter.cpp:160
+    Params prm;
+};
+
+// Quantities shared by every landmark of one filter at one step.
+struct StepCommon {
+    int step;       // integrateUpToTime does integrate (currentTime >= 0 && dt > 0)
+    double dt, T;   // this call's dt; accumulated time T
+    d3 wbar;        // mean angular rate over the accumulated interval
+    d3 wcur, acur;  // currentVelocity (ZOH sample used for the group step)
+    m33 RA;         // R_A
+    d3 vhat, etahat, eta0;
+    d3 vC;          // linear part of Ad(T_IC^-1) (wbar, vhat)          (EqFMatrices.cpp:302-304)
+    se3 camInv;     // SE3Exp(-dt * Ad(T_IC^-1)(wcur, vhat))             (VIOGroup.cpp:225-227)
+    m33 RICt;       // R_IC^T as the reference builds it: matrix of the inverse quaternion
+    m33 RIC;        // R_IC
+    d3 xIC;
+    double Bg[6];     // B[0:2,0:3]   (EqFMatrices.cpp:364)
+    m33 Bvw;          // B[2:5,0:3] = R_A vhat^x        (:367)
+    double Avg[6];    // A0[2:5,0:2] = -g * InvDiff     (:289), 3x2 row-major
+};
+
+// ImuRec r: for a vision call only r.stamp is used.
+EQF_DI void stepCommon(Glob& g, const ImuRec& r, const PropArgs& a, StepCommon& c, d3* unbW, d3* unbA, int* bad) {
+    const Params& p = a.prm;
+    if (a.isImu) {  // VIOFilter.cpp:121-124
+        *unbW = mk3(r.w[0] - g.bias[0], r.w[1] - g.bias[1], r.w[2] - g.bias[2]);
+        *unbA = mk3(r.a[0] - g.bias[3], r.a[1] - g.bias[4], r.a[2] - g.bias[5]);
+        if (!g.initialised) {  // initialiseFromIMUData, VIOFilter.cpp:133-144
+            const quat q0 = so3FromVectors(*unbA, mk3(0, 0, 1), bad);
+            g.P0q[0] = q0.w; g.P0q[1] = q0.x; g.P0q[2] = q0.y; g.P0q[3] = q0.z;
+            g.P0x[0] = g.P0x[1] = g.P0x[2] = 0;
+            g.v0[0] = g.v0[1] = g.v0[2] = 0;
+            g.initialised = 1;
+        }
+    }
+    c.dt = r.stamp - g.curTime;
+    c.step = (g.curTime >= 0) && (c.dt > 0);  // VIOFilter.cpp:147-152
+    if (!c.step) return;
+    c.T = g.accTime + c.dt;  // :154
+    c.wcur = mk3(g.curVel[0], g.curVel[1], g.curVel[2]);
+    c.acur = mk3(g.curVel[3], g.curVel[4], g.curVel[5]);
+    // :155 accumulatedVelocity += currentVelocity * dt ; :169 mean = accumulatedVelocity * (1/T)
+    const double invT = 1.0 / c.T;
+    c.wbar = mk3((g.accVel[0] + c.wcur.x * c.dt) * invT, (g.accVel[1] + c.wcur.y * c.dt) * invT,
+        (g.accVel[2] + c.wcur.z * c.dt) * invT);
+    const quat Aq = quat{g.Aq[0], g.Aq[1], g.Aq[2], g.Aq[3]};
+    const quat Aqi = qinv(Aq);
+    const quat P0q = quat{g.P0q[0], g.P0q[1], g.P0q[2], g.P0q[3]};
+    c.RA = q2m(Aq);
+    c.vhat = qrot(Aqi, mk3(g.v0[0] - g.w[0], g.v0[1] - g.w[1], g.v0[2] - g.w[2]));  // VIOGroup.cpp:26
+    c.eta0 = qrot(qinv(P0q), mk3(0, 0, 1));                                           // VIOState.cpp:90
+    c.etahat = qrot(Aqi, c.eta0);                                                      // VIOGroup.cpp:49
+    const se3 cam = se3{quat{p.camq[0], p.camq[1], p.camq[2], p.camq[3]}, mk3(p.camx[0], p.camx[1], p.camx[2])};
+    const se3 camI = se3inv(cam);
+    d3 oC, vC;
+    se3AdjointApply(camI, c.wbar, c.vhat, &oC, &vC);
+    c.vC = vC;
+    se3AdjointApply(camI, c.wcur, c.vhat, &oC, &vC);
+    c.camInv = se3Exp(scl(-c.dt, oC), scl(-c.dt, vC));
+    c.RIC = q2m(cam.q);
+    c.RICt = q2m(qinv(cam.q));
+    c.xIC = cam.x;
+    if (a.doRiccati) {
+        double diff[6], idiff[6];
+        stereoChartDiff(c.eta0, c.eta0, diff, bad);
+        stereoChartInvDiffAtZero(c.eta0, idiff, bad);
+        const m33 RAg = mul33(c.RA, skew3(c.etahat));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                c.Bg[3 * i + j] = diff[3 * i] * RAg.a[j] + diff[3 * i + 1] * RAg.a[3 + j] + diff[3 * i + 2] * RAg.a[6 + j];
+        c.Bvw = mul33(c.RA, skew3(c.vhat));
+#pragma unroll
+        for (int i = 0; i < 6; ++i) c.Avg[i] = -kGravity * idiff[i];
+    }
+}
+
+// Linearisation blocks of one landmark, already scaled by T:
+//   D = I + T*A_q (EqFMatrices.cpp:308-311), Lw = -T*B_i (:376), Lv = T*A_v (:296)
+struct LmBlocks {
+    m33 D, Lw, Lv;
+};
+EQF_DI LmBlocks buildBlocks(const StepCommon& c, quat Qq, double Qa, d3 p0) {
+    const m33 RQ = q2m(Qq);
+    const d3 qhat = scl(1.0 / Qa, qrot(qinv(Qq), p0));  // Q^-1 p0, VIOGroup.cpp:63 / SOT3.cpp:121
+    const m33 Qhat = scl33(Qa, RQ);
+    LmBlocks b;
+    b.Lv = scl33(-c.T, mul33(Qhat, mulT33(tr33(c.RIC), c.RA)));  // T * (-Qhat R_IC^T R_A^T)
+    // A_q = -Qhat (q^x v^x - 2 v q^T + q v^T) Qhat^-1 / |q|^2 ; the scale a cancels, Qhat^-1 = R_Q^T / a
+    const m33 inner = add33(mul33(skew3(qhat), skew3(c.vC)), add33(scl33(-2.0, outer3(c.vC, qhat)), outer3(qhat, c.vC)));
+    const m33 Aq = scl33(-1.0 / dot3(qhat, qhat), mul33(RQ, mulT33(inner, RQ)));
+    b.D = add33(eye3(), scl33(c.T, Aq));
+    const m33 Bi = mul33(Qhat, add33(mul33(skew3(qhat), c.RICt), mul33(c.RICt, skew3(c.xIC))));
+    b.Lw = scl33(-c.T, Bi);
+    return b;
+}
+
+// Group step of one landmark: Q_i <- Q_i * lift_i   (VIOGroup.cpp:230-240 / :188-196 + SOT3Exp; :105-107)
+EQF_DI void stepLandmark(const StepCommon& c, const PropArgs& a, quat Qq, double Qa, d3 p0, quat* Qo, double* ao, int* bad) {
+    const d3 qhat = scl(1.0 / Qa, qrot(qinv(Qq), p0));
+    quat lq;
+    double la;
+    if (a.prm.useDiscreteVelocityLift) {
+        const d3 q1 = se3app(c.camInv, qhat);
+        lq = so3FromVectors(q1, qhat, bad);
+        la = nrm3(qhat) / nrm3(q1);
+    } else {
+        // W_i = (omega_C + q^x v_C / |q|^2, q.v_C / |q|^2) with U_C from the CURRENT sample; VIOExp(dt * W)
+        const Params& p = a.prm;
+        const se3 cam = se3{quat{p.camq[0], p.camq[1], p.camq[2], p.camq[3]}, mk3(p.camx[0], p.camx[1], p.camx[2])};
+        d3 oC, vC;
+        se3AdjointApply(se3inv(cam), c.wcur, c.vhat, &oC, &vC);
+        const double n2 = dot3(qhat, qhat);
+        const d3 Wr = add(oC, scl(1.0 / n2, crs(qhat, vC)));
+        lq = so3Exp(scl(c.dt, Wr));
+        la = exp(c.dt * dot3(qhat, vC) / n2);
+    }
+    *Qo = qmul(Qq, lq);
+    *ao = Qa * la;
+}
+
+// Scalar part of the step, one thread per filter: X.A, X.w, ZOH bookkeeping.
+EQF_DI void stepGlobal(Glob& g, const ImuRec& r, const PropArgs& a, const StepCommon& c, d3 unbW, d3 unbA) {
+    if (c.step) {
+        // VIOFilter.cpp:154-155
+        g.accTime = c.T;
+        for (int i = 0; i < 6; ++i) g.accVel[i] += g.curVel[i] * c.dt;
+        if (a.doRiccati) {  // :192-193
+            g.accTime = 0;
+            for (int i = 0; i < 6; ++i) g.accVel[i] = 0;
+        }
+        se3 lA;
+        d3 lw;
+        if (a.prm.useDiscreteVelocityLift) {  // VIOGroup.cpp:214-222
+            lA = se3Exp(scl(c.dt, c.wcur), scl(c.dt, c.vhat));
+            const d3 inner = add(c.vhat, scl(c.dt, add(add(neg(crs(c.wcur, c.vhat)), c.acur), scl(-kGravity, c.etahat))));
+            lw = sub(c.vhat, qrot(lA.q, inner));
+        } else {  // VIOGroup.cpp:182-187, :245-249
+            lA = se3Exp(scl(c.dt, c.wcur), scl(c.dt, c.vhat));
+            lw = scl(c.dt, add(neg(c.acur), scl(kGravity, c.etahat)));
+        }
+        const se3 A = se3{quat{g.Aq[0], g.Aq[1], g.Aq[2], g.Aq[3]}, mk3(g.Ax[0], g.Ax[1], g.Ax[2])};
+        const se3 An = se3mul(A, lA);              // VIOGroup.cpp:95
+        const d3 wn = add(mk3(g.w[0], g.w[1], g.w[2]), qrot(A.q, lw));  // :96
+        g.Aq[0] = An.q.w; g.Aq[1] = An.q.x; g.Aq[2] = An.q.y; g.Aq[3] = An.q.z;
+        g.Ax[0] = An.x.x; g.Ax[1] = An.x.y; g.Ax[2] = An.x.z;
+        g.w[0] = wn.x; g.w[1] = wn.y; g.w[2] = wn.z;
+        g.curTime = r.stamp;  // :207
+    }
+    if (a.isImu) {  // VIOFilter.cpp:129-130
+        g.curVel[0] = unbW.x; g.curVel[1] = unbW.y; g.curVel[2] = unbW.z;
+        g.curVel[3] = unbA.x; g.curVel[4] = unbA.y; g.curVel[5] = unbA.z;
+        g.curTime = r.stamp;
+    } else {
+        g.updateOk = (c.step && g.initialised) ? 1 : 0;  // VIOFilter.cpp:234-236
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int ti = blockIdx.x / a.NT, tj = blockIdx.x % a.NT;
+    const int cap = a.cap, ld = a.ld;
+
+    __shared__ T sD[32][9], sLw[32][9], sLv[32][9];  // [0,16): row landmarks I, [16,32): column landmarks J
+    __shared__ T sG[16][33];                          // G_I = L_I Sigma_bb + D_I Sigma_Ib   (3 x 11)
+    __shared__ T sGn[16][9];                          // G_I[:,0:3] + (sigma_w^2 / T) Lw_I  (process noise folded in)
+    __shared__ T sSbJ[11][kTile];                     // Sigma[base rows, tile columns]
+    __shared__ T sSIb[kTile][12];                     // Sigma[tile rows, base columns]
+    __shared__ T sSbb[11][12];
+    __shared__ T sF[11][12];                          // F_bb
+    __shared__ T sNb[11][3];                          // rows of B (gyro columns) for the base coordinates
+    __shared__ T sTmp[16][33];
+    __shared__ T sTb[11][12];
+
+    Glob g = a.gin[b];
+    const ImuRec r = a.recs ? a.recs[b] : a.inl;
+    const int N = g.N;
+    int bad = 0;
+    StepCommon c;
+    d3 unbW = mk3(0, 0, 0), unbA = mk3(0, 0, 0);
+    stepCommon(g, r, a, c, &unbW, &unbA, &bad);
+
+    const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
+    T* Sout = static_cast<T*>(a.Sout) + (long long)b * a.sigmaStride;
+    const double* p0 = a.p0 + (long long)b * 3 * cap;
+    const double* Qin = a.Qin + (long long)b * 5 * cap;
+    double* Qout = a.Qout + (long long)b * 5 * cap;
+
+    const int I0 = ti * kTileLm, J0 = tj * kTileLm;
+    const bool riccati = c.step && a.doRiccati;
+
+    // ---- group step of this tile's landmarks (diagonal tiles only) and the scalar state
+    if (ti == tj && tid < kTileLm) {
+        const int i = I0 + tid;
+        if (i < N) {
+            const quat Qq = quat{Qin[i], Qin[cap + i], Qin[2 * cap + i], Qin[3 * cap + i]};
+            const double Qa = Qin[4 * cap + i];
+            quat Qo = Qq;
+            double ao = Qa;
+            if (c.step) stepLandmark(c, a, Qq, Qa, mk3(p0[i], p0[cap + i], p0[2 * cap + i]), &Qo, &ao, &bad);
+            Qout[i] = Qo.w; Qout[cap + i] = Qo.x; Qout[2 * cap + i] = Qo.y; Qout[3 * cap + i] = Qo.z;
+            Qout[4 * cap + i] = ao;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 64) {
+        Glob go = g;
+        stepGlobal(go, r, a, c, unbW, unbA);
+        a.gout[b] = go;
+    }
+
+    if (!riccati) {
+        // Sigma is not touched by this call: copy the tile through so that the ping-pong parity of all
+        // filters of the batch stays in step.
+        for (int e = tid; e < kTile * kTile; e += 256) {
+            const int rr = e / kTile, cc = e % kTile;
+            const int R = kLm0 + 3 * I0 + rr, Cc = kLm0 + 3 * J0 + cc;
+            if (R < kLm0 + 3 * N && Cc < kLm0 + 3 * N) Sout[(long long)R * ld + Cc] = Sin[(long long)R * ld + Cc];
+        }
+        if (tj == 0)
+            for (int e = tid; e < kTile * 12; e += 256) {
+                const int R = kLm0 + 3 * I0 + e / 12, Cc = e % 12;
+                if (R < kLm0 + 3 * N) Sout[(long long)R * ld + Cc] = Sin[(long long)R * ld + Cc];
+            }
+        if (ti == 0)
+            for (int e = tid; e < 12 * kTile; e += 256) {
+                const int R = e / kTile, Cc = kLm0 + 3 * J0 + e % kTile;
+                if (Cc < kLm0 + 3 * N) Sout[(long long)R * ld + Cc] = Sin[(long long)R * ld + Cc];
+            }
+        if (blockIdx.x == 0 && tid < 144) Sout[(long long)(tid / 12) * ld + tid % 12] = Sin[(long long)(tid / 12) * ld + tid % 12];
+        if (bad && a.errflag) atomicOr(a.errflag, 1);
+        return;
+    }
+
+    // ---- per-landmark linearisation blocks for the 16 row and 16 column landmarks of the tile
+    if (tid < 32) {
+        const int i = (tid < 16) ? I0 + tid : J0 + tid - 16;
+        if (i < N) {
+            const quat Qq = quat{Qin[i], Qin[cap + i], Qin[2 * cap + i], Qin[3 * cap + i]};
+            const LmBlocks blk = buildBlocks(c, Qq, Qin[4 * cap + i], mk3(p0[i], p0[cap + i], p0[2 * cap + i]));
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                sD[tid][k] = (T)blk.D.a[k];
+                sLw[tid][k] = (T)blk.Lw.a[k];
+                sLv[tid][k] = (T)blk.Lv.a[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) sD[tid][k] = sLw[tid][k] = sLv[tid][k] = (T)0;
+        }
+    }
+    // ---- stage base panels
+    for (int e = tid; e < 11 * kTile; e += 256) {
+        const int rr = e / kTile, cc = e % kTile;
+        const int Cc = kLm0 + 3 * J0 + cc;
+        sSbJ[rr][cc] = (Cc < kLm0 + 3 * N) ? Sin[(long long)rr * ld + Cc] : (T)0;
+    }
+    for (int e = tid; e < kTile * 12; e += 256) {
+        const int rr = e / 12, cc = e % 12;
+        const int R = kLm0 + 3 * I0 + rr;
+        sSIb[rr][cc] = (R < kLm0 + 3 * N && cc < 11) ? Sin[(long long)R * ld + cc] : (T)0;
+    }
+    if (tid < 132) {
+        const int rr = tid / 12, cc = tid % 12;
+        sSbb[rr][cc] = (cc < 11) ? Sin[(long long)rr * ld + cc] : (T)0;
+        // F_bb = I + T * [[0,0,0,0],[-B_g^w,0,0,0],[-B_v^w,-R_A, A_vg, 0]]   (VIOFilter.cpp:178-183)
+        double f = (rr == cc) ? 1.0 : 0.0;
+        if (rr >= 6 && rr < 8 && cc < 3) f = -c.T * c.Bg[3 * (rr - 6) + cc];
+        if (rr >= 8) {
+            if (cc < 3) f = -c.T * c.Bvw.a[3 * (rr - 8) + cc];
+            else if (cc < 6) f = -c.T * c.RA.a[3 * (rr - 8) + cc - 3];
+            else if (cc < 8) f = c.T * c.Avg[2 * (rr - 8) + cc - 6];
+        }
+        sF[rr][cc] = (cc < 11) ? (T)f : (T)0;
+        if (cc < 3) {
+            double nb = 0.0;
+            if (rr >= 6 && rr < 8) nb = c.Bg[3 * (rr - 6) + cc];
+            if (rr >= 8) nb = c.Bvw.a[3 * (rr - 8) + cc];
+            sNb[rr][cc] = (T)nb;
+        }
+    }
+    __syncthreads();
+
+    const T sw2 = (T)a.prm.velOmegaVariance, sa2 = (T)a.prm.velAccelVariance;
+    const T Tt = (T)c.T;
+
+    // ---- G_I = Lw_I Sigma[0:3, 0:11] + Lv_I Sigma[8:11, 0:11] + D_I Sigma_Ib
+    for (int e = tid; e < 16 * 33; e += 256) {
+        const int i = e / 33, rc = e % 33, rr = rc / 11, cc = rc % 11;
+        T acc = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            acc += sLw[i][3 * rr + k] * sSbb[k][cc] + sLv[i][3 * rr + k] * sSbb[8 + k][cc] + sD[i][3 * rr + k] * sSIb[3 * i + k][cc];
+        sG[i][rc] = acc;
+    }
+    __syncthreads();
+    if (tid < 144) {
+        const int i = tid / 9, k = tid % 9;
+        sGn[i][k] = sG[i][(k / 3) * 11 + k % 3] + (sw2 / Tt) * sLw[i][k];
+    }
+    __syncthreads();
+
+    // ---- one 3x3 block per thread
+    {
+        const int i = tid >> 4, j = tid & 15;
+        const int I = I0 + i, J = J0 + j;
+        if (I < N && J < N) {
+            const T* src = Sin + (long long)(kLm0 + 3 * I) * ld + kLm0 + 3 * J;
+            T S[9];
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) S[3 * rr + cc] = src[(long long)rr * ld + cc];
+            T H[9];
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    T acc = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        acc += sD[i][3 * rr + k] * S[3 * k + cc] + sLw[i][3 * rr + k] * sSbJ[k][3 * j + cc] +
+                               sLv[i][3 * rr + k] * sSbJ[8 + k][3 * j + cc];
+                    H[3 * rr + cc] = acc;
+                }
+            T* dst = Sout + (long long)(kLm0 + 3 * I) * ld + kLm0 + 3 * J;
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    T acc = (I == J && rr == cc) ? Tt * (T)a.prm.pointProcessVariance : (T)0;  // T * P
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        acc += H[3 * rr + k] * sD[16 + j][3 * cc + k] + sGn[i][3 * rr + k] * sLw[16 + j][3 * cc + k] +
+                               sG[i][rr * 11 + 8 + k] * sLv[16 + j][3 * cc + k];
+                    dst[(long long)rr * ld + cc] = acc;
+                }
+        }
+    }
+
+    // ---- Sigma'_Ib = G_I F_bb^T + T (B R B^T)_Ib      (tiles in the first tile column)
+    if (tj == 0) {
+        for (int e = tid; e < 16 * 33; e += 256) {
+            const int i = e / 33, rc = e % 33, rr = rc / 11, cc = rc % 11;
+            const int I = I0 + i;
+            if (I >= N) continue;
+            T acc = 0;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) acc += sG[i][rr * 11 + k] * sF[cc][k];
+            // T*sw2*B_I^w (B_c^w)^T with Lw = -T B^w
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc -= sw2 * sLw[i][3 * rr + k] * sNb[cc][k];
+            Sout[(long long)(kLm0 + 3 * I + rr) * ld + cc] = acc;
+        }
+        if (tid < kTile) {
+            const int R = kLm0 + 3 * I0 + tid;
+            if (R < kLm0 + 3 * N) Sout[(long long)R * ld + 11] = (T)0;
+        }
+    }
+    // ---- Sigma'_bJ = F_bb (Sigma_bb L_J^T + Sigma_bJ D_J^T) + T (B R B^T)_bJ   (tiles in the first tile row)
+    if (ti == 0) {
+        for (int e = tid; e < 16 * 33; e += 256) {
+            const int j = e / 33, rc = e % 33, cc = rc / 3, rr = rc % 3;  // G~_J[cc][rr], cc base row, rr landmark comp
+            T acc = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                acc += sSbb[cc][k] * sLw[16 + j][3 * rr + k] + sSbb[cc][8 + k] * sLv[16 + j][3 * rr + k] +
+                       sSbJ[cc][3 * j + k] * sD[16 + j][3 * rr + k];
+            sTmp[j][rc] = acc;
+        }
+        __syncthreads();
+        for (int e = tid; e < 16 * 33; e += 256) {
+            const int j = e / 33, rc = e % 33, cc = rc / 3, rr = rc % 3;
+            const int J = J0 + j;
+            if (J >= N) continue;
+            T acc = 0;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) acc += sF[cc][k] * sTmp[j][3 * k + rr];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc -= sw2 * sNb[cc][k] * sLw[16 + j][3 * rr + k];
+            Sout[(long long)cc * ld + kLm0 + 3 * J + rr] = acc;
+        }
+        if (tid < kTile) {
+            const int Cc = kLm0 + 3 * J0 + tid;
+            if (Cc < kLm0 + 3 * N) Sout[(long long)11 * ld + Cc] = (T)0;
+        }
+    }
+    // ---- Sigma'_bb = F_bb Sigma_bb F_bb^T + T (P_bb + B_b R B_b^T)     (first workgroup)
+    if (blockIdx.x == 0) {
+        __syncthreads();
+        if (tid < 121) {
+            const int rr = tid / 11, cc = tid % 11;
+            T acc = 0;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) acc += sF[rr][k] * sSbb[k][cc];
+            sTb[rr][cc] = acc;
+        }
+        __syncthreads();
+        if (tid < 144) {
+            const int rr = tid / 12, cc = tid % 12;
+            T acc = 0;
+            if (rr < 11 && cc < 11) {
+#pragma unroll
+                for (int k = 0; k < 11; ++k) acc += sTb[rr][k] * sF[cc][k];
+                T nz = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) nz += sw2 * sNb[rr][k] * sNb[cc][k];
+                if (rr >= 8 && cc >= 8) {  // accel columns of B: rows 8:11 hold R_A
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) nz += sa2 * (T)c.RA.a[3 * (rr - 8) + k] * (T)c.RA.a[3 * (cc - 8) + k];
+                }
+                if (rr == cc) {
+                    const Params& p = a.prm;
+                    nz += (T)(rr < 3 ? p.biasOmegaProcessVariance
+                                     : (rr < 6 ? p.biasAccelProcessVariance : (rr < 8 ? p.gravityProcessVariance : p.velocityProcessVariance)));
+                }
+                acc += Tt * nz;
+            }
+            Sout[(long long)rr * ld + cc] = acc;  // row/col 11 stay zero
+        }
+    }
+    if (bad && a.errflag) atomicOr(a.errflag, 1);
+}
+
+}  // namespace eqf

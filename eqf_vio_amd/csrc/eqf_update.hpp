@@ -1,0 +1,737 @@
+// EqF vision update on the device (gfx950): innovation, gain, innovation lift and covariance downdate.
+//
+// Replaces VIOFilter::processVisionData's numerical core (eqf_vio/src/VIOFilter.cpp:264-297) together
+// with measureSystemState (src/VIOState.cpp:58-70), outputGroupAction (src/VIOGroup.cpp:71-90),
+// outputCoordinateChart (src/VisionMeasurement.cpp:24-34), EqFOutputMatrixC_euclid_impl
+// (src/EqFMatrices.cpp:319-344), bundleLift (:173-252) and liftTotalSpaceInnovationDiscrete (:254-275).
+//
+// The reference evaluates  S = C Sigma C^T + R,  K = Sigma C^T S^-1 (LU inverse),  Sigma - K C Sigma  and,
+// inside bundleLift, an explicit (5+3N)^2 inverse of Sigma[6:,6:].  Here the same quantities come from two
+// blocked Cholesky chains with extra right-hand-side columns and NO explicit inverse / back substitution:
+//
+//   S-chain:  S = L L^T ;  Y = L^-1 [ C Sigma | delta | V ]        (V = C0 Z_P, 6 columns)
+//             gamma = K delta = Y^T z  (z = L^-1 delta) ;  Sigma <- Sigma - Y^T Y
+//   E-chain:  Sigma_e = Sigma[6:,6:] = Le Le^T ;  [Zt | Et] = Le^-1 [ Z_P | E_top ]
+//             Z_P = D * pHatMat * Ad(P0) (6 columns: the weighted-least-squares regressors of bundleLift
+//             before the K_par / K_perp split), E_top = first five unit vectors.
+//   bundleLift's normal equations then are, with G6 = Zt^T Zt, T65 = Zt^T Et, hV = (L^-1 V)^T z:
+//             coeff^T W coeff = Kpar^T G6 Kpar
+//             coeff^T W obs   = Kpar^T ( -(hV - T65 gamma_e[0:5]) - G6 DeltaU_fixed )
+//   because D*alpha = -gamma_landmarks and Sigma_e^-1 gamma_e = C0^T S^-1 delta (gamma_e = Sigma_e C0^T S^-1 delta).
+//
+// All factorisation work is fp64 (v_mfma_f64_16x16x4_f64 for the 32x32x32 block products): Sigma has a
+// condition number of 1e6..1e8 while landmarks converge, fp32 cannot carry it.
+#pragma once
+#include "eqf_device.hpp"
+#include "eqf_math.hpp"
+
+namespace eqf {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int roundUp(int x, int m) { return (x + m - 1) / m * m; }
+// chain dimensions of one filter
+__host__ __device__ inline int sDim(int N) { return 2 * N; }              // measurement dim m
+__host__ __device__ inline int eDim(int N) { return 6 + 3 * N; }          // internal Sigma_e order (incl. pad at e = 5)
+__host__ __device__ inline int yCols(int N) { return kLm0 + 3 * N + 6; }  // C Sigma (delta in col 11) | V
+
+struct UpdArgs {
+    Glob* g;             // current scalar state [B] (updated in place by k_update_finish)
+    const double* p0;    // [B][3][cap]
+    double* Q;           // [B][5][cap] current group landmarks (updated in place by finish)
+    const void* Sin;     // Sigma (T) current
+    void* Sout;          // Sigma (T) next
+    long long sigmaStride;
+    int cap, ld;
+    // measurement: bearings[b][k][3], landmark i of the state reads k = perm ? perm[b][i] : i
+    const double* bearings;
+    long long bearStride;  // doubles between filters
+    const int* perm;       // [B][cap] or nullptr
+    // S-chain buffers (fp64): work matrix A, factor L, right-hand sides W (work) and Wout (solved)
+    double *SA, *SL, *YW, *YO;
+    int ldS, ldY;
+    long long strideS, strideY;
+    // E-chain buffers
+    double *EA, *EL, *ZW, *ZO;
+    int ldE, ldZ;
+    long long strideE, strideZ;
+    // outputs for getters / tests
+    double* dbgDelta;  // [B][2*cap]
+    double* dbgGamma;  // [B][12+3*cap] internal index map
+    double* dbgGammaTot;  // [B][9+3*cap]
+    int* errflag;
+    Params prm;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Per-landmark pieces shared by prep kernels
+// ------------------------------------------------------------------------------------------------
+// C0i (2x3) = 1/|q| * stereoSphereChartDiff(y, y) * (I - y y^T), y = q/|q|   (EqFMatrices.cpp:332-339)
+EQF_DI void outputBlockC(d3 p0, double* C, int* bad) {
+    const double n = nrm3(p0);
+    const d3 y = scl(1.0 / n, p0);
+    double D[6];
+    stereoChartDiff(y, y, D, bad);
+    const double s = 1.0 / n;
+    const m33 P = add33(eye3(), scl33(-1.0, outer3(y, y)));
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            C[3 * r + c] = (s * D[3 * r]) * P.a[c] + (s * D[3 * r + 1]) * P.a[3 + c] + (s * D[3 * r + 2]) * P.a[6 + c];
+}
+
+// Rows of Z_P for one landmark: Qhat_i R_C^T [ (x0 - pHat)^x R0 , R0 ]   (3x6)   (EqFMatrices.cpp:221-235)
+struct LiftCommon {
+    m33 RCt;   // R_C^T, R_C = R_Phat R_IC
+    se3 PC;    // xiHat.pose * cameraOffset
+    m33 R0;    // xi0.pose rotation
+    d3 x0;
+};
+EQF_DI LiftCommon liftCommon(const Glob& g, const Params& p) {
+    LiftCommon L;
+    const se3 P0 = se3{quat{g.P0q[0], g.P0q[1], g.P0q[2], g.P0q[3]}, mk3(g.P0x[0], g.P0x[1], g.P0x[2])};
+    const se3 A = se3{quat{g.Aq[0], g.Aq[1], g.Aq[2], g.Aq[3]}, mk3(g.Ax[0], g.Ax[1], g.Ax[2])};
+    const se3 cam = se3{quat{p.camq[0], p.camq[1], p.camq[2], p.camq[3]}, mk3(p.camx[0], p.camx[1], p.camx[2])};
+    const se3 Phat = se3mul(P0, A);  // stateGroupAction: pose * X.A  (VIOGroup.cpp:25)
+    L.RCt = q2m(qinv(qmul(Phat.q, cam.q)));
+    L.PC = se3mul(Phat, cam);
+    L.R0 = q2m(P0.q);
+    L.x0 = P0.x;
+    return L;
+}
+EQF_DI void liftRows(const LiftCommon& L, quat Qq, double Qa, d3 p0, double* Z /*[18]*/) {
+    const d3 qhat = scl(1.0 / Qa, qrot(qinv(Qq), p0));
+    const d3 pHat = se3app(L.PC, qhat);
+    const m33 M = mul33(scl33(Qa, q2m(Qq)), L.RCt);  // X.Q[i].asMatrix3d() * R_C^T
+    const m33 left = mul33(M, mul33(skew3(sub(L.x0, pHat)), L.R0));
+    const m33 right = mul33(M, L.R0);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            Z[6 * r + c] = left.a[3 * r + c];
+            Z[6 * r + 3 + c] = right.a[3 * r + c];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_update_prep: one WAVEFRONT per landmark.  Builds delta_i, C0i, the two rows of C*Sigma (lanes stride the
+// Sigma columns: coalesced 3-row reads), the two rows of S and of V; extra workgroups copy Sigma_e.
+// grid.x = lmBlocks + eBlocks, grid.y = B, block = 256 (4 waves = 4 landmarks).
+// ------------------------------------------------------------------------------------------------
+// Dynamic LDS: wpb (waves per workgroup) x 2 rows x nvPad doubles for the C*Sigma rows.
+template <typename T>
+__global__ __launch_bounds__(256) void k_update_prep(UpdArgs a, int lmBlocks, int wpb, int nvPad) {
+    const int b = blockIdx.y;
+    const Glob& g = a.g[b];
+    if (!g.updateOk) return;
+    const int N = g.N;
+    if (N == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cap = a.cap, ld = a.ld;
+    const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
+    const double* p0 = a.p0 + (long long)b * 3 * cap;
+    const double* Q = a.Q + (long long)b * 5 * cap;
+    const int nv = kLm0 + 3 * N;  // valid internal Sigma order
+    int bad = 0;
+
+    if ((int)blockIdx.x >= lmBlocks) {
+        // ---- E-chain operand: EA = Sigma[6:,6:] (pad e=5 -> identity), ZW = [Z_P | E_top], 32 rows per workgroup
+        const int ne = eDim(N), nep = roundUp(ne, kNB);
+        const int r0 = ((int)blockIdx.x - lmBlocks) * kNB;
+        if (r0 >= nep) return;
+        double* EA = a.EA + (long long)b * a.strideE;
+        double* ZW = a.ZW + (long long)b * a.strideZ;
+        for (int e = tid; e < kNB * nep; e += (int)blockDim.x) {
+            const int rr = r0 + e / nep, cc = e % nep;
+            double v;
+            if (rr < ne && cc < ne && rr != 5 && cc != 5) v = (double)Sin[(long long)(6 + rr) * ld + 6 + cc];
+            else v = (rr == cc) ? 1.0 : 0.0;
+            EA[(long long)rr * a.ldE + cc] = v;
+        }
+        if (tid < kNB) {
+            const int rr = r0 + tid;
+            double row[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) row[c] = 0.0;
+            if (rr >= 6 && rr < ne) {
+                const int i = (rr - 6) / 3, comp = (rr - 6) % 3;
+                const LiftCommon L = liftCommon(g, a.prm);
+                double Z[18];
+                liftRows(L, quat{Q[i], Q[cap + i], Q[2 * cap + i], Q[3 * cap + i]}, Q[4 * cap + i],
+                    mk3(p0[i], p0[cap + i], p0[2 * cap + i]), Z);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) row[c] = (comp == 0) ? Z[c] : (comp == 1 ? Z[6 + c] : Z[12 + c]);
+            }
+            if (rr < 5) row[6 + rr] = 1.0;  // E_top
+            for (int c = 0; c < kNB; ++c) ZW[(long long)rr * a.ldZ + c] = (c < 16) ? row[c] : 0.0;
+        }
+        return;
+    }
+
+    // ---- landmark waves
+    extern __shared__ __attribute__((aligned(16))) double sCSraw[];  // [wpb][2][nvPad]
+    double* sCS0 = sCSraw + (long long)(2 * wv) * nvPad;
+    double* sCS1 = sCS0 + nvPad;
+    const int i = blockIdx.x * wpb + wv;
+    const int m = sDim(N), mp = roundUp(m, kNB);
+    const int yc = yCols(N), ycp = roundUp(yc, kNB);
+    double* SA = a.SA + (long long)b * a.strideS;
+    double* YW = a.YW + (long long)b * a.strideY;
+    double C[6] = {0, 0, 0, 0, 0, 0};
+    double dl[2] = {0, 0};
+    double V[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) V[k] = 0.0;
+    const bool valid = i < N;
+    if (valid) {
+        const quat Qq = quat{Q[i], Q[cap + i], Q[2 * cap + i], Q[3 * cap + i]};
+        const double Qa = Q[4 * cap + i];
+        const d3 q0 = mk3(p0[i], p0[cap + i], p0[2 * cap + i]);
+        const int k = a.perm ? a.perm[(long long)b * cap + i] : i;
+        const double* yb = a.bearings + (long long)b * a.bearStride + 3 * k;
+        const d3 y = mk3(yb[0], yb[1], yb[2]);
+        // y0 = q0/|q0| (measureSystemState); yerr = (X^-1).Q_i.R()^-1 y (outputGroupAction, VIOGroup.cpp:84,130)
+        const d3 pole = unit3(q0);
+        const d3 yerr = qrot(qinv(qinv(Qq)), y);
+        stereoChart(yerr, pole, &dl[0], &dl[1], &bad);
+        outputBlockC(q0, C, &bad);
+        double Z[18];
+        liftRows(liftCommon(g, a.prm), Qq, Qa, q0, Z);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) V[6 * r + c] = C[3 * r] * Z[c] + C[3 * r + 1] * Z[6 + c] + C[3 * r + 2] * Z[12 + c];
+        // rows 2i, 2i+1 of C*Sigma: lanes stride the columns
+        const T* s0 = Sin + (long long)(kLm0 + 3 * i) * ld;
+        for (int col = lane; col < nv; col += 64) {
+            const double v0 = (double)s0[col], v1 = (double)s0[ld + col], v2 = (double)s0[2 * ld + col];
+            sCS0[col] = C[0] * v0 + C[1] * v1 + C[2] * v2;
+            sCS1[col] = C[3] * v0 + C[4] * v1 + C[5] * v2;
+        }
+    }
+    __syncthreads();
+    if (valid) {
+        // right-hand sides: [C Sigma (delta in column 11) | V], zero padded to ycp
+        for (int col = lane; col < ycp; col += 64) {
+            double v0 = 0.0, v1 = 0.0;
+            if (col == 11) {
+                v0 = dl[0];
+                v1 = dl[1];
+            } else if (col < nv) {
+                v0 = sCS0[col];
+                v1 = sCS1[col];
+            } else if (col < nv + 6) {
+                v0 = V[col - nv];
+                v1 = V[6 + col - nv];
+            }
+            YW[(long long)(2 * i) * a.ldY + col] = v0;
+            YW[(long long)(2 * i + 1) * a.ldY + col] = v1;
+        }
+        // S rows: S[2i+r][2j+s] = sum_c CS[r][12+3j+c] C_j[s][c]  (+ measurementVariance on the diagonal)
+        for (int j = lane; j < mp / 2; j += 64) {
+            double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+            if (j < N) {
+                double Cj[6];
+                outputBlockC(mk3(p0[j], p0[cap + j], p0[2 * cap + j]), Cj, &bad);
+                const double* c0 = &sCS0[kLm0 + 3 * j];
+                const double* c1 = &sCS1[kLm0 + 3 * j];
+                s00 = c0[0] * Cj[0] + c0[1] * Cj[1] + c0[2] * Cj[2];
+                s01 = c0[0] * Cj[3] + c0[1] * Cj[4] + c0[2] * Cj[5];
+                s10 = c1[0] * Cj[0] + c1[1] * Cj[1] + c1[2] * Cj[2];
+                s11 = c1[0] * Cj[3] + c1[1] * Cj[4] + c1[2] * Cj[5];
+                if (j == i) {
+                    s00 += a.prm.measurementVariance;
+                    s11 += a.prm.measurementVariance;
+                }
+            }
+            double* r0p = SA + (long long)(2 * i) * a.ldS + 2 * j;
+            r0p[0] = s00; r0p[1] = s01;
+            r0p[a.ldS] = s10; r0p[a.ldS + 1] = s11;
+        }
+        if (lane == 0 && a.dbgDelta) {
+            a.dbgDelta[(long long)b * 2 * cap + 2 * i] = dl[0];
+            a.dbgDelta[(long long)b * 2 * cap + 2 * i + 1] = dl[1];
+        }
+    } else if (2 * i < mp) {
+        // padding rows of the S-chain: identity in S, zero right-hand sides
+        for (int col = lane; col < ycp; col += 64) {
+            YW[(long long)(2 * i) * a.ldY + col] = 0.0;
+            YW[(long long)(2 * i + 1) * a.ldY + col] = 0.0;
+        }
+        for (int col = lane; col < mp; col += 64) {
+            SA[(long long)(2 * i) * a.ldS + col] = (col == 2 * i) ? 1.0 : 0.0;
+            SA[(long long)(2 * i + 1) * a.ldS + col] = (col == 2 * i + 1) ? 1.0 : 0.0;
+        }
+    }
+    if (bad && a.errflag) atomicOr(a.errflag, 2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Blocked right-looking Cholesky with right-hand sides, ONE launch per block column k, both chains in
+// the same launch.  Every workgroup re-derives L_kk (32x32 potrf, one wave) and the panel blocks it needs
+// (forward substitution, one lane per row), so a launch has no inter-workgroup dependency:
+//   tile (r,c), r >= c >= k of chain matrix A:   c == k: L_rk = A_rk L_kk^-T  -> L
+//                                                c  > k: A_rc -= L_rk L_ck^T   (in place)
+//   tile (t,c) of the right-hand sides W (n x wcols):
+//                                                c == k: Y_k = L_kk^-1 W_k     -> Wout
+//                                                c  > k: W_c -= L_ck Y_k       (in place)
+// ------------------------------------------------------------------------------------------------
+constexpr int kLdsP = kNB + 1;  // LDS row pitch (doubles): +1 breaks the power-of-two stride
+
+// 32x32 Cholesky by lanes 0..31 of one wave, row l in registers; writes L (lower) and 1/diag to LDS.
+EQF_DI void potrf32(double (*sA)[kLdsP], double* sRd, int lane, int* bad) {
+    double row[kNB];
+#pragma unroll
+    for (int c = 0; c < kNB; ++c) row[c] = (lane < kNB) ? sA[lane][c] : 0.0;
+#pragma unroll
+    for (int j = 0; j < kNB; ++j) {
+        double v = row[j];
+#pragma unroll
+        for (int c = 0; c < j; ++c) v -= row[c] * sA[j][c];  // row j of L is final for c < j (LDS broadcast read)
+        const double d = __shfl(v, j);
+        if (!(d > 0.0)) *bad = 1;
+        const double rd = rsqrt(d);
+        const double lj = (lane == j) ? d * rd : v * rd;
+        row[j] = lj;
+        if (lane >= j && lane < kNB) sA[lane][j] = lj;
+        if (lane == j) sRd[j] = rd;
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+// Forward substitution with the LDS-resident L (sA lower, sRd = 1/diag): solves L x = b for one vector
+// per lane (b in x[]).  Used both for rows of A_rk (x L^T = a) and for columns of W_k (L y = w).
+EQF_DI void fwdsub32(const double (*sA)[kLdsP], const double* sRd, double* x) {
+#pragma unroll
+    for (int j = 0; j < kNB; ++j) {
+        double v = x[j];
+#pragma unroll
+        for (int c = 0; c < j; ++c) v -= x[c] * sA[j][c];
+        x[j] = v * sRd[j];
+    }
+}
+
+struct ChainArgs {
+    Glob* g;
+    double *A, *L, *W, *WO;
+    int ldA, ldW;
+    long long strideA, strideW;
+    int kind;     // 0: S-chain, 1: E-chain
+    int nbMax;    // tiles per edge launched for A
+    int wtMax;    // right-hand-side column tiles launched
+};
+
+// per-filter chain sizes
+EQF_DI void chainDims(const ChainArgs& ch, int N, int* nb, int* wt) {
+    if (ch.kind == 0) {
+        *nb = roundUp(sDim(N), kNB) / kNB;
+        *wt = roundUp(yCols(N), kNB) / kNB;
+    } else {
+        *nb = roundUp(eDim(N), kNB) / kNB;
+        *wt = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_chol_step(ChainArgs c0, ChainArgs c1, int k, int* errflag) {
+    const int b = blockIdx.y;
+    const int n0 = c0.nbMax * c0.nbMax + c0.wtMax * c0.nbMax;
+    const bool second = (int)blockIdx.x >= n0;
+    const ChainArgs& ch = second ? c1 : c0;
+    int idx = second ? (int)blockIdx.x - n0 : (int)blockIdx.x;
+    const Glob& g = ch.g[b];
+    if (!g.updateOk || g.N == 0) return;
+    int nb, wt;
+    chainDims(ch, g.N, &nb, &wt);
+    if (k >= nb) return;
+    bool isW = false;
+    int r, c;  // A tile (r,c) or W tile (t = r, c)
+    if (idx < ch.nbMax * ch.nbMax) {
+        r = idx / ch.nbMax;
+        c = idx % ch.nbMax;
+        if (r >= nb || c > r || c < k) return;
+    } else {
+        idx -= ch.nbMax * ch.nbMax;
+        isW = true;
+        r = idx / ch.nbMax;  // column tile t
+        c = idx % ch.nbMax;
+        if (r >= wt || c >= nb || c < k) return;
+    }
+    double* A = ch.A + (long long)b * ch.strideA;
+    double* L = ch.L + (long long)b * ch.strideA;
+    double* W = ch.W + (long long)b * ch.strideW;
+    double* WO = ch.WO + (long long)b * ch.strideW;
+    const int ldA = ch.ldA, ldW = ch.ldW;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    __shared__ double sK[kNB][kLdsP];   // A_kk -> L_kk
+    __shared__ double sP[kNB][kLdsP];   // A_rk rows -> L_rk      (A tiles) / W_k -> Y_k (W tiles)
+    __shared__ double sQ[kNB][kLdsP];   // A_ck rows -> L_ck
+    __shared__ double sRd[kNB];
+    int bad = 0;
+
+    // ---- load A_kk (lower part is enough), and the panel blocks this tile needs
+    for (int e = tid; e < kNB * kNB; e += 256) {
+        const int rr = e / kNB, cc = e % kNB;
+        sK[rr][cc] = A[(long long)(k * kNB + rr) * ldA + k * kNB + cc];
+        if (!isW) {
+            if (r > k) sP[rr][cc] = A[(long long)(r * kNB + rr) * ldA + k * kNB + cc];
+        } else {
+            sP[rr][cc] = W[(long long)(k * kNB + rr) * ldW + r * kNB + cc];
+        }
+        if (c > k) sQ[rr][cc] = A[(long long)(c * kNB + rr) * ldA + k * kNB + cc];
+    }
+    __syncthreads();
+    if (wv == 0) potrf32(sK, sRd, lane, &bad);
+    __syncthreads();
+    // ---- panel solves: one lane per vector.  wave 0: lanes 0..31 -> sP, lanes 32..63 -> sQ
+    if (wv == 0) {
+        const int v = lane & 31;
+        const bool second_half = lane >= 32;
+        const bool doP = !second_half && (isW || r > k);
+        const bool doQ = second_half && (c > k);
+        if (doP || doQ) {
+            double x[kNB];
+            if (doQ) {
+#pragma unroll
+                for (int j = 0; j < kNB; ++j) x[j] = sQ[v][j];
+            } else if (isW) {
+#pragma unroll
+                for (int j = 0; j < kNB; ++j) x[j] = sP[j][v];  // column v of W_k
+            } else {
+#pragma unroll
+                for (int j = 0; j < kNB; ++j) x[j] = sP[v][j];  // row v of A_rk
+            }
+            fwdsub32(sK, sRd, x);
+            if (doQ) {
+#pragma unroll
+                for (int j = 0; j < kNB; ++j) sQ[v][j] = x[j];
+            } else if (isW) {
+#pragma unroll
+                for (int j = 0; j < kNB; ++j) sP[j][v] = x[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < kNB; ++j) sP[v][j] = x[j];
+            }
+        }
+    }
+    __syncthreads();
+    if (c == k) {
+        // ---- panel output
+        for (int e = tid; e < kNB * kNB; e += 256) {
+            const int rr = e / kNB, cc = e % kNB;
+            if (isW) {
+                WO[(long long)(k * kNB + rr) * ldW + r * kNB + cc] = sP[rr][cc];
+            } else if (r == k) {
+                L[(long long)(k * kNB + rr) * ldA + k * kNB + cc] = (cc <= rr) ? sK[rr][cc] : 0.0;
+            } else {
+                L[(long long)(r * kNB + rr) * ldA + k * kNB + cc] = sP[rr][cc];
+            }
+        }
+    } else {
+        // ---- trailing update of this tile with v_mfma_f64_16x16x4_f64: wave w owns the 16x16 sub-tile (w>>1, w&1)
+        const int tm = wv >> 1, tn = wv & 1;
+        const int lr = lane & 15, lk = lane >> 4;
+        double* Ct = isW ? (W + (long long)(c * kNB) * ldW + r * kNB) : (A + (long long)(r * kNB) * ldA + c * kNB);
+        const int ldc = isW ? ldW : ldA;
+        f64x4 acc;
+        // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = Ct[(long long)(16 * tm + lk + 4 * q) * ldc + 16 * tn + lr];
+        if (!isW) {
+            // A_rc -= L_rk L_ck^T ; for a diagonal tile (r == c) L_rk is sQ as well
+            const double (*P)[kLdsP] = (r == c) ? sQ : sP;
+#pragma unroll
+            for (int s = 0; s < kNB / 4; ++s) {
+                const double av = -P[16 * tm + lr][4 * s + lk];
+                const double bv = sQ[16 * tn + lr][4 * s + lk];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+        } else {
+            // W_c -= L_ck Y_k
+#pragma unroll
+            for (int s = 0; s < kNB / 4; ++s) {
+                const double av = -sQ[16 * tm + lr][4 * s + lk];
+                const double bv = sP[4 * s + lk][16 * tn + lr];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Ct[(long long)(16 * tm + lk + 4 * q) * ldc + 16 * tn + lr] = acc[q];
+    }
+    if (bad && errflag && tid == 0) atomicOr(errflag, 4);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_update_finish: one workgroup per filter.  gamma = Y^T z, the 4x4 weighted least squares of bundleLift,
+// Delta = liftTotalSpaceInnovationDiscrete(Gamma), X <- Delta * X, bias += gamma[0:6].
+// ------------------------------------------------------------------------------------------------
+EQF_DI void solve4(double M[4][4], double* rhs, double* x) {
+    // Gaussian elimination with partial pivoting (the reference uses Householder QR on the same 4x4 system)
+    int piv[4] = {0, 1, 2, 3};
+    for (int k = 0; k < 4; ++k) {
+        int p = k;
+        double best = fabs(M[piv[k]][k]);
+        for (int i = k + 1; i < 4; ++i)
+            if (fabs(M[piv[i]][k]) > best) {
+                best = fabs(M[piv[i]][k]);
+                p = i;
+            }
+        const int t = piv[k];
+        piv[k] = piv[p];
+        piv[p] = t;
+        const double inv = 1.0 / M[piv[k]][k];
+        for (int i = k + 1; i < 4; ++i) {
+            const double l = M[piv[i]][k] * inv;
+            for (int j = k; j < 4; ++j) M[piv[i]][j] -= l * M[piv[k]][j];
+            rhs[piv[i]] -= l * rhs[piv[k]];
+        }
+    }
+    for (int i = 3; i >= 0; --i) {
+        double s = rhs[piv[i]];
+        for (int j = i + 1; j < 4; ++j) s -= M[piv[i]][j] * x[j];
+        x[i] = s / M[piv[i]][i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_update_finish(UpdArgs a) {
+    const int b = blockIdx.x;
+    Glob& g = a.g[b];
+    if (!g.updateOk || g.N == 0) return;
+    const int N = g.N, cap = a.cap;
+    const int tid = threadIdx.x;
+    const int m = sDim(N), mp = roundUp(m, kNB), nv = kLm0 + 3 * N;
+    const int ne = eDim(N), nep = roundUp(ne, kNB);
+    const double* Y = a.YO + (long long)b * a.strideY;
+    const double* Z = a.ZO + (long long)b * a.strideZ;
+    double* gam = a.dbgGamma + (long long)b * (kLm0 + 3 * cap);
+    __shared__ double sG6[36], sT65[30], sHV[6], sSol[16];
+    __shared__ double sRed[256];
+    int bad = 0;
+
+    // gamma[col] = sum_r Y[r][col] z[r], z = Y[:, 11]; also hV[c] = sum_r Y[r][nv + c] z[r]
+    for (int col = tid; col < nv + 6; col += 256) {
+        double acc = 0;
+        for (int r = 0; r < mp; ++r) acc += Y[(long long)r * a.ldY + col] * Y[(long long)r * a.ldY + 11];
+        if (col < nv) gam[col] = (col == 11) ? 0.0 : acc;
+        else sHV[col - nv] = acc;
+    }
+    // G6 = Zt^T Zt (6x6), T65 = Zt^T Et (6x5): 66 dot products of length nep; 3 threads per product
+    {
+        const int pr = tid / 3, part = tid % 3;
+        double acc = 0;
+        if (pr < 66) {
+            const int c0 = (pr < 36) ? pr / 6 : (pr - 36) / 5;
+            const int c1 = (pr < 36) ? pr % 6 : 6 + (pr - 36) % 5;
+            for (int r = part; r < nep; r += 3) acc += Z[(long long)r * a.ldZ + c0] * Z[(long long)r * a.ldZ + c1];
+        }
+        sRed[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < 66) {
+        const double v = sRed[3 * tid] + sRed[3 * tid + 1] + sRed[3 * tid + 2];
+        if (tid < 36) sG6[tid] = v;
+        else sT65[tid - 36] = v;
+    }
+    __syncthreads();
+
+    // ---- Gamma[0:6] on one thread (bundleLift, EqFMatrices.cpp:173-252)
+    if (tid == 0) {
+        double dU[6] = {0, 0, 0, 0, 0, 0};
+        if (a.prm.useInnovationLift) {
+            const quat P0q = quat{g.P0q[0], g.P0q[1], g.P0q[2], g.P0q[3]};
+            const d3 eta0 = unit3(qrot(qinv(P0q), mk3(0, 0, 1)));
+            double idf[6];
+            stereoChartInvDiffAtZero(eta0, idf, &bad);
+            const double gg0 = gam[6], gg1 = gam[7];
+            const d3 t = mk3(idf[0] * gg0 + idf[1] * gg1, idf[2] * gg0 + idf[3] * gg1, idf[4] * gg0 + idf[5] * gg1);
+            const d3 dUw = neg(crs(eta0, t));
+            // DeltaU_fixed = K_perp DeltaU = ((I - eta eta^T) dUw ; 0)
+            const d3 fx = sub(dUw, scl(dot3(eta0, dUw), eta0));
+            const double dUf[6] = {fx.x, fx.y, fx.z, 0, 0, 0};
+            // h = hV - T65 * gamma_e[0:5]   (gamma_e[0:5] = gamma internal indices 6..10)
+            double h[6];
+            for (int c = 0; c < 6; ++c) {
+                double s = sHV[c];
+                for (int q = 0; q < 5; ++q) s -= sT65[5 * c + q] * gam[6 + q];
+                h[c] = s;
+            }
+            // rhs6 = -h - G6 dUf ; normal equations in the K_par basis: columns (eta;0), (0;e1), (0;e2), (0;e3)
+            double rhs6[6];
+            for (int c = 0; c < 6; ++c) {
+                double s = -h[c];
+                for (int q = 0; q < 6; ++q) s -= sG6[6 * c + q] * dUf[q];
+                rhs6[c] = s;
+            }
+            double Kp[6][4] = {};
+            Kp[0][0] = eta0.x; Kp[1][0] = eta0.y; Kp[2][0] = eta0.z;
+            Kp[3][1] = Kp[4][2] = Kp[5][3] = 1.0;
+            double M[4][4], rhs[4], sol[4];
+            for (int i = 0; i < 4; ++i) {
+                for (int j = 0; j < 4; ++j) {
+                    double s = 0;
+                    for (int p = 0; p < 6; ++p)
+                        for (int q = 0; q < 6; ++q) s += Kp[p][i] * sG6[6 * p + q] * Kp[q][j];
+                    M[i][j] = s;
+                }
+                double s = 0;
+                for (int p = 0; p < 6; ++p) s += Kp[p][i] * rhs6[p];
+                rhs[i] = s;
+            }
+            solve4(M, rhs, sol);
+            for (int i = 0; i < 6; ++i) {
+                double s = dUf[i];
+                for (int j = 0; j < 4; ++j) s += Kp[i][j] * sol[j];
+                dU[i] = s;
+            }
+        }
+        for (int i = 0; i < 6; ++i) sSol[i] = dU[i];
+    }
+    __syncthreads();
+
+    // ---- Delta and X <- Delta * X
+    double* Q = a.Q + (long long)b * 5 * cap;
+    const double* p0 = a.p0 + (long long)b * 3 * cap;
+    double* gT = a.dbgGammaTot ? a.dbgGammaTot + (long long)b * (9 + 3 * cap) : nullptr;
+    const d3 v0 = mk3(g.v0[0], g.v0[1], g.v0[2]);
+    const d3 gv = mk3(gam[8], gam[9], gam[10]);
+    se3 DA;
+    d3 Dw;
+    if (a.prm.useInnovationLift) {
+        if (a.prm.useDiscreteInnovationLift) {  // EqFMatrices.cpp:254-258
+            DA = se3Exp(mk3(sSol[0], sSol[1], sSol[2]), mk3(sSol[3], sSol[4], sSol[5]));
+            Dw = sub(v0, qrot(DA.q, add(v0, gv)));
+        } else {  // VIOExp(liftTotalSpaceInnovation), :69-79
+            DA = se3Exp(mk3(sSol[0], sSol[1], sSol[2]), mk3(sSol[3], sSol[4], sSol[5]));
+            Dw = sub(neg(gv), crs(mk3(sSol[0], sSol[1], sSol[2]), v0));
+        }
+    } else {  // VIOExp(liftInnovation(gamma_e, xi0)), :35-49
+        const quat P0q = quat{g.P0q[0], g.P0q[1], g.P0q[2], g.P0q[3]};
+        const d3 eta = qrot(qinv(P0q), mk3(0, 0, 1));
+        double idf[6];
+        stereoChartInvDiffAtZero(eta, idf, &bad);
+        const d3 t = mk3(idf[0] * gam[6] + idf[1] * gam[7], idf[2] * gam[6] + idf[3] * gam[7], idf[4] * gam[6] + idf[5] * gam[7]);
+        const d3 Uw = neg(crs(eta, t));
+        DA = se3Exp(Uw, mk3(0, 0, 0));
+        Dw = sub(neg(gv), crs(Uw, v0));
+    }
+    const bool discreteLm = a.prm.useInnovationLift && a.prm.useDiscreteInnovationLift;
+    for (int i = tid; i < N; i += 256) {
+        const d3 qi = mk3(p0[i], p0[cap + i], p0[2 * cap + i]);
+        const d3 gq = mk3(gam[kLm0 + 3 * i], gam[kLm0 + 3 * i + 1], gam[kLm0 + 3 * i + 2]);
+        quat dq;
+        double da;
+        if (discreteLm) {  // :262-270
+            const d3 q1 = add(qi, gq);
+            dq = so3FromVectors(q1, qi, &bad);
+            da = nrm3(qi) / nrm3(q1);
+        } else {  // :84-93 / :54-63 then SOT3Exp
+            const double n2 = dot3(qi, qi);
+            dq = so3Exp(scl(-1.0 / n2, crs(qi, gq)));
+            da = exp(-dot3(qi, gq) / n2);
+        }
+        const quat Qq = quat{Q[i], Q[cap + i], Q[2 * cap + i], Q[3 * cap + i]};
+        const quat Qn = qmul(dq, Qq);  // X = Delta * X  (VIOFilter.cpp:296, VIOGroup.cpp:105-107)
+        Q[i] = Qn.w; Q[cap + i] = Qn.x; Q[2 * cap + i] = Qn.y; Q[3 * cap + i] = Qn.z;
+        Q[4 * cap + i] = da * Q[4 * cap + i];
+        if (gT) {
+            gT[9 + 3 * i] = gq.x; gT[10 + 3 * i] = gq.y; gT[11 + 3 * i] = gq.z;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const se3 A = se3{quat{g.Aq[0], g.Aq[1], g.Aq[2], g.Aq[3]}, mk3(g.Ax[0], g.Ax[1], g.Ax[2])};
+        const se3 An = se3mul(DA, A);                                        // VIOGroup.cpp:95
+        const d3 wn = add(Dw, qrot(DA.q, mk3(g.w[0], g.w[1], g.w[2])));       // :96
+        g.Aq[0] = An.q.w; g.Aq[1] = An.q.x; g.Aq[2] = An.q.y; g.Aq[3] = An.q.z;
+        g.Ax[0] = An.x.x; g.Ax[1] = An.x.y; g.Ax[2] = An.x.z;
+        g.w[0] = wn.x; g.w[1] = wn.y; g.w[2] = wn.z;
+        for (int i = 0; i < 6; ++i) g.bias[i] += gam[i];  // VIOFilter.cpp:295
+        if (gT) {
+            for (int i = 0; i < 6; ++i) gT[i] = sSol[i];
+            gT[6] = gv.x; gT[7] = gv.y; gT[8] = gv.z;
+        }
+        if (bad && a.errflag) atomicOr(a.errflag, 8);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_downdate: Sigma_out = Sigma_in - Y^T Y on the matrix cores.  64x64 output tile per workgroup, each of
+// the 4 waves owns a 32x32 quadrant as 2x2 MFMA 16x16 tiles; the operands Y[:, I], Y[:, J] stream from
+// L2 (Y is m x n fp64, 2 MB at N = 200).  T = double: v_mfma_f64_16x16x4_f64; T = float:
+// v_mfma_f32_16x16x4_f32 on Y rounded to fp32.  Filters whose update was skipped copy Sigma through.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct MfmaT;
+template <>
+struct MfmaT<double> {
+    typedef f64x4 acc_t;
+    static EQF_DI acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static EQF_DI int row(int lane, int q) { return (lane >> 4) + 4 * q; }
+};
+template <>
+struct MfmaT<float> {
+    typedef f32x4 acc_t;
+    static EQF_DI acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static EQF_DI int row(int lane, int q) { return 4 * (lane >> 4) + q; }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_downdate(UpdArgs a) {
+    const int b = blockIdx.z;
+    const Glob& g = a.g[b];
+    const int N = g.N;
+    const int nv = kLm0 + 3 * N;
+    const int I0 = blockIdx.y * 64, J0 = blockIdx.x * 64;
+    if (I0 >= nv || J0 >= nv) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ld = a.ld;
+    const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
+    T* Sout = static_cast<T*>(a.Sout) + (long long)b * a.sigmaStride;
+    if (!g.updateOk || N == 0) {
+        for (int e = tid; e < 64 * 64; e += 256) {
+            const int R = I0 + e / 64, Cc = J0 + e % 64;
+            if (R < nv && Cc < nv) Sout[(long long)R * ld + Cc] = Sin[(long long)R * ld + Cc];
+        }
+        return;
+    }
+    const int mp = roundUp(sDim(N), kNB);
+    const double* Y = a.YO + (long long)b * a.strideY;
+    const int ldY = a.ldY;
+    const int qi = wv >> 1, qj = wv & 1;
+    const int lr = lane & 15, lk = lane >> 4;
+    typedef MfmaT<T> MF;
+    typename MF::acc_t acc[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[u][v][q] = 0;
+    const int ia = I0 + 32 * qi + lr, jb = J0 + 32 * qj + lr;  // (+16 for the second sub-tile)
+    for (int k0 = 0; k0 < mp; k0 += 4) {
+        const double* yr = Y + (long long)(k0 + lk) * ldY;
+        // column index 11 of Y holds z, not C*Sigma: rows/cols 11 of Sigma are structurally zero
+        const T a0 = (ia < nv && ia != 11) ? (T)yr[ia] : (T)0;
+        const T a1 = (ia + 16 < nv && ia + 16 != 11) ? (T)yr[ia + 16] : (T)0;
+        const T b0 = (jb < nv && jb != 11) ? (T)yr[jb] : (T)0;
+        const T b1 = (jb + 16 < nv && jb + 16 != 11) ? (T)yr[jb + 16] : (T)0;
+        acc[0][0] = MF::mfma(a0, b0, acc[0][0]);
+        acc[0][1] = MF::mfma(a0, b1, acc[0][1]);
+        acc[1][0] = MF::mfma(a1, b0, acc[1][0]);
+        acc[1][1] = MF::mfma(a1, b1, acc[1][1]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int R = I0 + 32 * qi + 16 * u + MF::row(lane, q);
+                const int Cc = J0 + 32 * qj + 16 * v + lr;
+                if (R < nv && Cc < nv) Sout[(long long)R * ld + Cc] = Sin[(long long)R * ld + Cc] - acc[u][v][q];
+            }
+}
+
+}  // namespace eqf

@@ -1,0 +1,146 @@
+/* eqf_vio_amd -- C ABI of the MI355X-native EqF propagate/update hot path.
+ *
+ * Drop-in boundary for pvangoor/eqf_vio's VIOFilter (eqf_vio/include/eqf_vio/VIOFilter.h:41-88).  The
+ * reference has no FFI: the C++ class *is* the boundary, so every entry point below names the member
+ * it replaces.  A handle owns a BATCH of `batch` independent filters (batch = 1 for the drop-in
+ * case; >1 for Monte-Carlo / multi-sequence runs, BASELINE cfg 4); per-filter arguments are arrays of
+ * length `batch`.  One handle = one HIP stream; calls on a handle must be serialised by the caller
+ * (the reference is single-threaded too).  Calls enqueue GPU work and return; getters synchronise.
+ *
+ * Sigma index map (unchanged from the reference, VIOFilter.cpp:54-57,163-167,425):
+ *   [0,3) gyro bias  [3,6) accel bias  [6,8) gravity dir  [8,11) velocity  [11+3i,14+3i) landmark i
+ *
+ * Status codes: 0 ok; >0 "silently skipped" exactly where the reference returns early;
+ *               <0 error.  The library NEVER computes on the CPU: without a GPU eqf_create fails.
+ */
+#ifndef EQF_VIO_AMD_H
+#define EQF_VIO_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EQF_OK 0
+#define EQF_SKIPPED_BEFORE_FIRST_IMU 1 /* VIOFilter.cpp:147-148 (currentTime < 0)            */
+#define EQF_SKIPPED_NONPOSITIVE_DT 2   /* VIOFilter.cpp:150-152, :234-236 (dt <= 0)          */
+#define EQF_SKIPPED_NOT_INITIALISED 3  /* VIOFilter.cpp:235 (!initialisedFlag)               */
+#define EQF_SKIPPED_NO_BEARINGS 4      /* VIOFilter.cpp:258-259                              */
+#define EQF_ERR_INVALID -1
+#define EQF_ERR_NO_DEVICE -2
+#define EQF_ERR_HIP -3
+#define EQF_ERR_CAPACITY -4      /* more landmarks than the handle was created for          */
+#define EQF_ERR_UNSORTED -5      /* bearings not sorted by ascending id (VIOFilter.cpp:239)  */
+#define EQF_ERR_NUMERIC -6       /* NaN / antipodal SO3FromVectors (SO3.cpp:160) on device   */
+#define EQF_ERR_UNSUPPORTED -7
+
+#define EQF_PRECISION_F64 0 /* Sigma stored and contracted in fp64 (parity grade, default)    */
+#define EQF_PRECISION_F32 1 /* Sigma stored fp32, propagate + downdate in fp32 (MFMA f32)      */
+
+/* VIOFilter::Settings, eqf_vio/include/eqf_vio/VIOFilterSettings.h:28-54 (same names, same defaults). */
+typedef struct eqf_settings {
+    double biasOmegaProcessVariance;
+    double biasAccelProcessVariance;
+    double gravityProcessVariance;
+    double velocityProcessVariance;
+    double pointProcessVariance;
+    double velOmegaVariance;
+    double velAccelVariance;
+    double measurementVariance;
+    double initialGravityVariance;
+    double initialVelocityVariance;
+    double initialPointVariance;
+    double initialBiasOmegaVariance;
+    double initialBiasAccelVariance;
+    double initialSceneDepth;
+    double outlierThreshold;
+    int useInnovationLift;
+    int useDiscreteInnovationLift;
+    int useDiscreteVelocityLift;
+    int fastRiccati;
+    double initialAccelBias[3];
+    double initialOmegaBias[3];
+    double cameraOffset_x[3]; /* SE3 cameraOffset: translation ...                             */
+    double cameraOffset_q[4]; /* ... and attitude quaternion (w, x, y, z), YAML order "xw"      */
+} eqf_settings;
+
+/* Fills the defaults of VIOFilterSettings.h:29-50. */
+void eqf_settings_default(eqf_settings* s);
+
+typedef struct eqf_filter eqf_filter; /* opaque */
+
+/* VIOFilter(const Settings&) (VIOFilter.cpp:60-73) for `batch` filters with room for
+ * `capacity_landmarks` landmarks each, on HIP device `device`, Sigma precision EQF_PRECISION_*. */
+int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, int device, int precision,
+    eqf_filter** out);
+void eqf_destroy(eqf_filter* f);
+/* VIOFilter::reset() (VIOFilter.cpp:84-91). */
+int eqf_reset(eqf_filter* f);
+
+/* VIOFilter::processIMUData (VIOFilter.cpp:120-131).  stamps[batch], omega[batch][3], accel[batch][3].
+ * status (may be NULL) receives one code per filter. */
+int eqf_process_imu(eqf_filter* f, const double* stamps, const double* omega, const double* accel, int* status);
+
+/* VIOFilter::processVisionData (VIOFilter.cpp:232-302).  For filter b: nb[b] bearings with ids
+ * ids[b*stride + k] (ascending) and unit vectors bearings[(b*stride + k)*3 + c]. */
+int eqf_process_vision(eqf_filter* f, const double* stamps, const int* nb, const int* ids, const double* bearings,
+    int stride, int* status);
+
+/* Stream mode: the whole input stream is made resident in HBM once, then events are replayed by index
+ * with no host->device traffic in the loop (how bench.py times the path).
+ *   imu:      [K][batch][7]  (stamp, wx, wy, wz, ax, ay, az)      -- IMUVelocity.h:24-37
+ *   vstamps:  [F][batch]; ids: [nbear] shared by all frames and filters, ascending;
+ *   bearings: [F][batch][nbear][3]                                 -- VisionMeasurement.h:24-28 */
+int eqf_stream_upload(eqf_filter* f, int K, const double* imu, int F, const double* vstamps, int nbear,
+    const int* ids, const double* bearings);
+int eqf_stream_imu(eqf_filter* f, int k);    /* == eqf_process_imu on record k    */
+int eqf_stream_vision(eqf_filter* f, int fr); /* == eqf_process_vision on frame fr */
+
+/* Getters (copy to caller memory, synchronise the handle's stream). b = filter index in the batch. */
+int eqf_synchronize(eqf_filter* f);
+int eqf_get_time(eqf_filter* f, double* t /* [batch] */);               /* VIOFilter::getTime          */
+int eqf_num_landmarks(eqf_filter* f, int b);                             /* xi0.bodyLandmarks.size()     */
+int eqf_get_ids(eqf_filter* f, int b, int* ids);
+/* VIOFilter::stateEstimate (VIOFilter.cpp:304): pose q[4] (w,x,y,z), pose x[3], velocity[3],
+ * landmarks p[N][3] (camera frame). */
+int eqf_get_state_estimate(eqf_filter* f, int b, double* pose_q, double* pose_x, double* velocity, double* p);
+/* Filter internals (what operator<<(VIOFilter) dumps, VIOFilter.cpp:311-341): origin state xi0 ...   */
+int eqf_get_origin(eqf_filter* f, int b, double* pose_q, double* pose_x, double* velocity, double* p);
+/* ... group element X = (A, w, Q_i = (q_i, a_i)) ...                                                   */
+int eqf_get_group(eqf_filter* f, int b, double* A_q, double* A_x, double* w, double* Q_q /*[N][4]*/,
+    double* Q_a /*[N]*/);
+/* ... and input bias (b_omega, b_accel).                                                               */
+int eqf_get_bias(eqf_filter* f, int b, double* bias6);
+/* VIOFilter::stateCovariance (VIOFilter.cpp:306-309): n x n, n = 11 + 3N, row-major with leading
+ * dimension ld >= n, in the reference's index map. */
+int eqf_get_sigma(eqf_filter* f, int b, double* dst, int ld);
+/* Test hook: overwrite Sigma (same layout as eqf_get_sigma). */
+int eqf_set_sigma(eqf_filter* f, int b, const double* src, int ld);
+/* Internals of the most recent update of filter b: delta[2N], gamma[11+3N] (K*delta), Gamma[9+3N]. */
+int eqf_get_last_update(eqf_filter* f, int b, double* delta, double* gamma, double* Gamma);
+/* Sticky device-side error flag (NaN / antipodal), 0 if none. */
+int eqf_device_error(eqf_filter* f);
+
+/* Propagate backend: 0 = block-structured HBM-bound kernel (default, product path),
+ * 1 = dense F Sigma F^T on MFMA (what the reference executes; BASELINE cfg 3 cross-check). */
+int eqf_set_dense_propagate(eqf_filter* f, int on);
+
+/* Per-kernel-class timing with HIP events on the handle's stream (bench.py roofline leg).
+ * eqf_profile_get: for class c in [0, EQF_PROF_CLASSES) -> launches and total milliseconds. */
+#define EQF_PROF_PROPAGATE 0
+#define EQF_PROF_UPDATE_PREP 1
+#define EQF_PROF_CHOL_STEP 2
+#define EQF_PROF_BACKSOLVE 3
+#define EQF_PROF_FINISH 4
+#define EQF_PROF_DOWNDATE 5
+#define EQF_PROF_CHURN 6
+#define EQF_PROF_CLASSES 7
+int eqf_profile_enable(eqf_filter* f, int on);
+int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_ms);
+const char* eqf_profile_class_name(int cls);
+
+const char* eqf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EQF_VIO_AMD_H */
