@@ -173,3 +173,31 @@ def template_settings_dict():
         cameraOffset_x=CAM_OFFSET_X.copy(),
         cameraOffset_q=CAM_OFFSET_Q.copy(),
     )
+
+
+def churn_measurements(stream, seed=7, max_visible=None, outlier_frames=(), outlier_angle=0.05):
+    """Per-frame (ids, bearings) with landmarks entering and leaving the field of view, to exercise the
+    reference's landmark bookkeeping (eqf_vio/src/VIOFilter.cpp:345-443).  Landmark j is visible on a random
+    window of frames; ids stay sorted ascending (VIOFilter.cpp:239-240).  On `outlier_frames` one visible
+    bearing is rotated by `outlier_angle` rad (caught by removeOutliers when the threshold is the default)."""
+    rng = np.random.default_rng(seed)
+    F, N = stream.bearings.shape[0], stream.bearings.shape[1]
+    start = rng.integers(0, max(1, F // 2), size=N)
+    length = rng.integers(max(2, F // 4), F, size=N)
+    start[: max(2, N // 3)] = 0  # some landmarks are there from the first frame
+    length[:3] = F  # ... and three stay for the whole run: with fewer than two landmarks bundleLift's 4x4
+    # normal equations (EqFMatrices.cpp:240-242) are rank deficient and any solver's answer is arbitrary
+    out = []
+    for f in range(F):
+        vis = np.where((start <= f) & (f < start + length))[0]
+        if max_visible is not None and len(vis) > max_visible:
+            vis = np.sort(rng.choice(vis, size=max_visible, replace=False))
+        y = stream.bearings[f, vis].copy()
+        if f in outlier_frames and len(vis) > 0:
+            k = int(rng.integers(0, len(vis)))
+            axis = np.cross(y[k], np.array([1.0, 0.3, -0.2]))
+            axis /= np.linalg.norm(axis)
+            y[k] = y[k] * np.cos(outlier_angle) + np.cross(axis, y[k]) * np.sin(outlier_angle)
+            y[k] /= np.linalg.norm(y[k])
+        out.append((stream.ids[vis].astype(np.int32), y))
+    return out

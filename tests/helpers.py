@@ -1,0 +1,72 @@
+"""Shared helpers of the parity tests: golden-fixture loading and running a filter over a fixture."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BOOL_KEYS = ("useInnovationLift", "useDiscreteInnovationLift", "useDiscreteVelocityLift", "fastRiccati")
+
+
+def load_golden(name):
+    d = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    settings = {str(k): float(v) for k, v in zip(d["setting_names"], d["setting_values"])}
+    for k in BOOL_KEYS:
+        settings[k] = bool(settings[k])
+    settings["cameraOffset_x"] = d["cameraOffset_x"]
+    settings["cameraOffset_q"] = d["cameraOffset_q"]
+    return d, settings
+
+
+def events_of(imu, vision_stamps):
+    """Event interleave of the reference's runner (eqf_vio/src/main.cpp:113): IMU while imu.stamp < meas.stamp."""
+    k = f = 0
+    while k < len(imu) and f < len(vision_stamps):
+        if imu[k, 0] < vision_stamps[f]:
+            yield ("imu", k)
+            k += 1
+        else:
+            yield ("vision", f)
+            f += 1
+
+
+def frame_record(q, x, v, bias, S, n):
+    return np.concatenate([q, x, v, bias, [np.linalg.norm(S), n]])
+
+
+def run_oracle_on_golden(ob, d, settings, capture=()):
+    """C++ oracle over a golden fixture -> per-frame records, final filter, captured internals."""
+    f = ob.OracleFilter(settings)
+    frames, internals = [], {}
+    for kind, k in events_of(d["imu"], d["vision_stamps"]):
+        if kind == "imu":
+            r = d["imu"][k]
+            f.processIMUData(r[0], r[1:4], r[4:7])
+        else:
+            nb = int(d["meas_nb"][k])
+            f.processVisionData(d["vision_stamps"][k], d["meas_ids"][k, :nb], d["meas_y"][k, :nb])
+            e = f.stateEstimate()
+            frames.append(frame_record(e["q"], e["x"], e["v"], f.bias(), f.stateCovariance(), f.N))
+            if k in capture:
+                internals[k] = f.last_update()
+    return np.array(frames), f, internals
+
+
+def run_hip_on_golden(binding, d, settings, capacity, capture=(), precision=0):
+    fb = binding.FilterBatch(settings, capacity=capacity, batch=1, precision=precision)
+    frames, internals = [], {}
+    for kind, k in events_of(d["imu"], d["vision_stamps"]):
+        if kind == "imu":
+            r = d["imu"][k]
+            fb.process_imu([r[0]], r[1:4], r[4:7])
+        else:
+            nb = int(d["meas_nb"][k])
+            fb.process_vision([d["vision_stamps"][k]], d["meas_ids"][k, :nb], d["meas_y"][k, :nb])
+            e = fb.state_estimate()
+            frames.append(frame_record(e["q"], e["x"], e["v"], fb.bias(), fb.sigma(), fb.num_landmarks()))
+            if k in capture:
+                internals[k] = fb.last_update()
+    return np.array(frames), fb, internals
+
+
+def rel_fro(A, B):
+    return np.linalg.norm(A - B) / np.linalg.norm(B)

@@ -1,0 +1,80 @@
+"""CPU-only checks of the drop-in boundary: the shared library loads, exports every symbol that
+include/eqf_vio_amd.h declares, its settings defaults are the reference's, and it fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "eqf_vio_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(eqf_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from eqf_vio_amd import binding
+
+    L = binding.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/eqf_vio_amd.h but not exported"
+    assert set(syms) == set(binding.EXPORTED_SYMBOLS)
+
+
+def test_settings_defaults_match_the_reference():
+    """eqf_vio/include/eqf_vio/VIOFilterSettings.h:29-50"""
+    from eqf_vio_amd import binding
+
+    s = binding.default_settings()
+    for k in ("biasOmegaProcessVariance", "biasAccelProcessVariance", "gravityProcessVariance", "velocityProcessVariance",
+              "pointProcessVariance"):
+        assert getattr(s, k) == 0.001
+    for k in ("velOmegaVariance", "velAccelVariance", "measurementVariance"):
+        assert getattr(s, k) == 0.1
+    for k in ("initialGravityVariance", "initialVelocityVariance", "initialPointVariance", "initialBiasOmegaVariance",
+              "initialBiasAccelVariance", "initialSceneDepth"):
+        assert getattr(s, k) == 1.0
+    assert s.outlierThreshold == 0.01
+    assert (s.useInnovationLift, s.useDiscreteInnovationLift, s.useDiscreteVelocityLift, s.fastRiccati) == (1, 1, 1, 0)
+    assert list(s.cameraOffset_q) == [1.0, 0.0, 0.0, 0.0] and list(s.cameraOffset_x) == [0.0, 0.0, 0.0]
+
+
+def test_no_cpu_fallback_without_a_gpu():
+    """The product path must fail loudly when no MI355X is visible (no silent CPU fallback)."""
+    import torch
+
+    from eqf_vio_amd import binding
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(binding.EqfError) as ei:
+        binding.FilterBatch({}, capacity=8)
+    assert ei.value.code in (binding.ERR_NO_DEVICE, binding.ERR_HIP)
+
+
+def test_invalid_arguments_are_rejected():
+    from eqf_vio_amd import binding
+
+    L = binding.lib()
+    h = C.c_void_p()
+    s = binding.default_settings()
+    assert L.eqf_create(C.byref(s), 0, 1, 0, 0, C.byref(h)) == binding.ERR_INVALID
+    assert L.eqf_create(C.byref(s), 8, 0, 0, 0, C.byref(h)) == binding.ERR_INVALID
+    assert L.eqf_create(C.byref(s), 8, 1, 0, 7, C.byref(h)) == binding.ERR_INVALID
+    assert L.eqf_process_imu(None, None, None, None, None) == binding.ERR_INVALID
+    assert L.eqf_version().startswith(b"eqf_vio_amd")
+
+
+def test_product_package_does_not_import_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, "eqf_vio_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in txt.replace("the fp64 oracle", "").replace("fp64 oracle", ""), f"{fn} mentions the oracle"
