@@ -99,7 +99,7 @@ def roofline(fb, events, N, B, precision):
         "k_chol_step": ("mfma", (m**3 / 3.0 + m * m * (n + 7.0) + ne**3 / 3.0 + ne * ne * 11.0) * B / max(nb_s, nb_e)),
         "k_downdate": ("mfma", 2.0 * n * n * m * B),
         "k_update_prep": ("hbm", (n * n * esz + 8.0 * (m * (n + 7) + m * m + ne * ne)) * B),
-        "k_update_finish": ("hbm", 8.0 * (m * (n + 7) + ne * 32) * B),
+        "k_update_reduce": ("hbm", 8.0 * (m * (n + 7) + ne * 32) * B),
     }
     rows = []
     for name, (cnt, ms) in prof.items():

@@ -1,0 +1,53 @@
+// Minimal C++ caller of the facade, shaped like the reference's offline runner (eqf_vio/src/main.cpp:111-170):
+// events are interleaved by "imu.stamp < meas.stamp", the state is read after every vision call.
+// Usage: eqf_example <N landmarks> <frames>   -- runs a small synthetic orbit and prints the final pose and |Sigma|_F.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "VIOFilter.h"
+
+using namespace eqf_vio_amd;
+
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? std::atoi(argv[1]) : 20;
+    const int frames = argc > 2 ? std::atoi(argv[2]) : 10;
+    VIOFilter::Settings s;
+    s.initialPointVariance = 5000.0;  // eqf_vio/EQVIO_config_template.yaml values
+    s.measurementVariance = 0.003;
+    s.velOmegaVariance = s.velAccelVariance = 1e-4;
+    s.outlierThreshold = 1e9;
+    VIOFilter filter(s, N);
+    std::vector<Vector3d> lm(N);
+    for (int i = 0; i < N; ++i) lm[i] = {2 * std::sin(1.3 * i), 2 * std::cos(0.7 * i), 5 + std::sin(0.37 * i)};
+    // vehicle at rest, tilted so that body x is "up" (a level start makes the reference's gravity chart singular)
+    IMUVelocity imu;
+    imu.accel = {GRAVITY_CONSTANT, 0, 0};
+    int k = 0;
+    for (int f = 0; f < frames; ++f) {
+        VisionMeasurement meas;
+        meas.stamp = 0.05 * f + 0.0025;
+        for (; 0.005 * k < meas.stamp; ++k) {  // main.cpp:113
+            imu.stamp = 0.005 * k;
+            filter.processIMUData(imu);
+        }
+        meas.numberOfBearings = N;
+        meas.bearings.resize(N);
+        for (int i = 0; i < N; ++i) {
+            const double n = std::sqrt(lm[i][0] * lm[i][0] + lm[i][1] * lm[i][1] + lm[i][2] * lm[i][2]);
+            meas.bearings[i].p = {lm[i][0] / n, lm[i][1] / n, lm[i][2] / n};
+            meas.bearings[i].id = i;
+        }
+        filter.processVisionData(meas);
+        const VIOState est = filter.stateEstimate();
+        if (f == frames - 1) {
+            const MatrixXd S = filter.stateCovariance();
+            double fro = 0;
+            for (double v : S.data) fro += v * v;
+            std::printf("t=%.4f N=%zu pos=(%.6f %.6f %.6f) q=(%.6f %.6f %.6f %.6f) |Sigma|_F=%.6e\n", filter.getTime(),
+                est.bodyLandmarks.size(), est.pose.x[0], est.pose.x[1], est.pose.x[2], est.pose.R.w, est.pose.R.x, est.pose.R.y,
+                est.pose.R.z, std::sqrt(fro));
+        }
+    }
+    return 0;
+}

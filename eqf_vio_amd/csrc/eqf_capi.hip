@@ -53,7 +53,7 @@ struct eqf_filter {
     double *SA = nullptr, *SL = nullptr, *YW = nullptr, *YO = nullptr, *EA = nullptr, *EL = nullptr, *ZW = nullptr, *ZO = nullptr;
     int ldS = 0, ldY = 0, ldE = 0, ldZ = kNB;
     long long strideS = 0, strideY = 0, strideE = 0, strideZ = 0;
-    double *dbgDelta = nullptr, *dbgGamma = nullptr, *dbgGammaTot = nullptr;
+    double *dbgDelta = nullptr, *dbgGamma = nullptr, *dbgGammaTot = nullptr, *red = nullptr;
     int* errflag = nullptr;
     // churn scratch
     int *dMap = nullptr, *dNewN = nullptr, *dPerm = nullptr, *dSrc = nullptr;
@@ -273,6 +273,7 @@ UpdArgs makeUpdArgs(eqf_filter* f, const double* bearings, long long bearStride,
     a.dbgDelta = f->dbgDelta;
     a.dbgGamma = f->dbgGamma;
     a.dbgGammaTot = f->dbgGammaTot;
+    a.red = f->red;
     a.errflag = f->errflag;
     a.prm = f->prm;
     return a;
@@ -316,6 +317,10 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             [&] { hipLaunchKernelGGL(k_chol_step, dim3(nblk, B), dim3(256), 0, f->stream, cS, cE, k, f->errflag); });
         if (rc) return rc;
     }
+    const int colBlocks = (nv + 6 + 63) / 64;
+    rc = profiled(f, EQF_PROF_REDUCE,
+        [&] { hipLaunchKernelGGL(k_update_reduce, dim3(colBlocks + 1, B), dim3(256), 0, f->stream, a, colBlocks); });
+    if (rc) return rc;
     rc = profiled(f, EQF_PROF_FINISH, [&] { hipLaunchKernelGGL(k_update_finish, dim3(B), dim3(256), 0, f->stream, a); });
     if (rc) return rc;
     const int nt = (nv + 63) / 64;
@@ -539,7 +544,7 @@ void freeAll(eqf_filter* f) {
         hipFree(f->Q[p]);
     }
     for (void* p : {(void*)f->p0, (void*)f->SA, (void*)f->SL, (void*)f->YW, (void*)f->YO, (void*)f->EA, (void*)f->EL, (void*)f->ZW,
-             (void*)f->ZO, (void*)f->dbgDelta, (void*)f->dbgGamma, (void*)f->dbgGammaTot, (void*)f->errflag, (void*)f->dMap,
+             (void*)f->ZO, (void*)f->dbgDelta, (void*)f->dbgGamma, (void*)f->dbgGammaTot, (void*)f->red, (void*)f->errflag, (void*)f->dMap,
              (void*)f->dNewN, (void*)f->dPerm, (void*)f->dSrc, (void*)f->dChord, (void*)f->dDepth2, (void*)f->dScratch, (void*)f->dMeas,
              (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear})
         hipFree(p);
@@ -616,6 +621,18 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     p.useInnovationLift = settings->useInnovationLift;
     p.useDiscreteInnovationLift = settings->useDiscreteInnovationLift;
     p.useDiscreteVelocityLift = settings->useDiscreteVelocityLift;
+    {  // camera-offset constants, same formulas as on the device (eqf_math.hpp is host+device)
+        const quat cq = quat{p.camq[0], p.camq[1], p.camq[2], p.camq[3]};
+        const se3 camI = se3inv(se3{cq, mk3(p.camx[0], p.camx[1], p.camx[2])});
+        const m33 RIC = q2m(cq), RICt = q2m(qinv(cq)), RcI = q2m(camI.q);
+        for (int i = 0; i < 9; ++i) {
+            p.RIC[i] = RIC.a[i];
+            p.RICt[i] = RICt.a[i];
+            p.RcamI[i] = RcI.a[i];
+        }
+        p.camIq[0] = camI.q.w; p.camIq[1] = camI.q.x; p.camIq[2] = camI.q.y; p.camIq[3] = camI.q.z;
+        p.camIx[0] = camI.x.x; p.camIx[1] = camI.x.y; p.camIx[2] = camI.x.z;
+    }
 
     const int B = batch, cap = f->cap;
     f->nTot = kLm0 + 3 * cap;
@@ -641,6 +658,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     chk(dmalloc(&f->dbgDelta, (size_t)2 * cap * B));
     chk(dmalloc(&f->dbgGamma, (size_t)(kLm0 + 3 * cap) * B));
     chk(dmalloc(&f->dbgGammaTot, (size_t)(9 + 3 * cap) * B));
+    chk(dmalloc(&f->red, (size_t)256 * B));
     chk(dmalloc(&f->errflag, 1));
     chk(dmalloc(&f->dMap, (size_t)cap * B)); chk(dmalloc(&f->dNewN, B)); chk(dmalloc(&f->dPerm, (size_t)cap * B));
     chk(dmalloc(&f->dSrc, cap)); chk(dmalloc(&f->dChord, (size_t)cap * B)); chk(dmalloc(&f->dDepth2, (size_t)cap * B));
@@ -988,7 +1006,7 @@ int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_m
 }
 
 const char* eqf_profile_class_name(int cls) {
-    static const char* names[EQF_PROF_CLASSES] = {"k_propagate", "k_update_prep", "k_chol_step", "k_backsolve", "k_update_finish",
+    static const char* names[EQF_PROF_CLASSES] = {"k_propagate", "k_update_prep", "k_chol_step", "k_update_reduce", "k_update_finish",
         "k_downdate", "churn"};
     return (cls >= 0 && cls < EQF_PROF_CLASSES) ? names[cls] : "?";
 }

@@ -32,6 +32,10 @@ struct Glob {
     int N;                  // number of landmarks
     int updateOk;           // vision call: integrateUpToTime succeeded && initialised (VIOFilter.cpp:234-236)
     int pad_;
+    // Functions of xi0.pose only, cached when the pose is set (xi0 never changes between landmark-set changes):
+    double eta0[3];         // gravity direction R_P0^T e3                         (VIOState.cpp:90)
+    double cDiff[6];        // stereoSphereChartDiff(eta0, eta0)       2x3         (EqFMatrices.cpp:364)
+    double cInv[6];         // stereoSphereChartInvDiff(0, eta0)       3x2         (EqFMatrices.cpp:289)
 };
 
 // Tunables the kernels need (VIOFilterSettings.h:28-54), passed by value.
@@ -40,6 +44,11 @@ struct Params {
         pointProcessVariance, velOmegaVariance, velAccelVariance, measurementVariance, initialPointVariance;
     double camq[4], camx[3];
     int useInnovationLift, useDiscreteInnovationLift, useDiscreteVelocityLift;
+    // constants of the camera offset, precomputed on the host with the same formulas the kernels use
+    double RIC[9];          // matrix of cameraOffset.R
+    double RICt[9];         // matrix of cameraOffset.R.inverse()      (EqFMatrices.cpp:371)
+    double camIq[4], camIx[3];  // cameraOffset.inverse()               (SE3.cpp:80-83)
+    double RcamI[9];        // matrix of cameraOffset.inverse().R       (for Ad(T_IC^-1), SE3.cpp:95-103)
 };
 
 // One IMU record: stamp, omega, accel, pad (IMUVelocity.h:24-37)

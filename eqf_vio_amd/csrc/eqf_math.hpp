@@ -9,7 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define EQF_DI __device__ __forceinline__
+#define EQF_DI __host__ __device__ __forceinline__
 
 namespace eqf {
 

@@ -45,9 +45,10 @@ struct StepCommon {
     d3 wbar;        // mean angular rate over the accumulated interval
     d3 wcur, acur;  // currentVelocity (ZOH sample used for the group step)
     m33 RA;         // R_A
-    d3 vhat, etahat, eta0;
+    d3 vhat, etahat;
     d3 vC;          // linear part of Ad(T_IC^-1) (wbar, vhat)          (EqFMatrices.cpp:302-304)
-    se3 camInv;     // SE3Exp(-dt * Ad(T_IC^-1)(wcur, vhat))             (VIOGroup.cpp:225-227)
+    d3 oCcur, vCcur;  // Ad(T_IC^-1) (wcur, vhat)                       (VIOGroup.cpp:225)
+    se3 camInv;     // SE3Exp(-dt * Ad(T_IC^-1)(wcur, vhat))             (VIOGroup.cpp:226)
     m33 RICt;       // R_IC^T as the reference builds it: matrix of the inverse quaternion
     m33 RIC;        // R_IC
     d3 xIC;
@@ -56,60 +57,80 @@ struct StepCommon {
     double Avg[6];    // A0[2:5,0:2] = -g * InvDiff     (:289), 3x2 row-major
 };
 
-// ImuRec r: for a vision call only r.stamp is used.
-EQF_DI void stepCommon(Glob& g, const ImuRec& r, const PropArgs& a, StepCommon& c, d3* unbW, d3* unbA, int* bad) {
+// Functions of xi0.pose alone; cached in Glob when the pose is set.
+EQF_DI void poseConstants(quat P0q, double* eta0, double* cDiff, double* cInv, int* bad) {
+    const d3 e = qrot(qinv(P0q), mk3(0, 0, 1));  // VIOState.cpp:90
+    eta0[0] = e.x; eta0[1] = e.y; eta0[2] = e.z;
+    stereoChartDiff(e, e, cDiff, bad);
+    stereoChartInvDiffAtZero(e, cInv, bad);
+}
+
+// The per-step scalar chain.  G is the (read-only) current state; for a vision call only r.stamp is used.
+EQF_DI void stepCommon(const Glob& G, const ImuRec& r, const PropArgs& a, StepCommon& c, int* bad) {
     const Params& p = a.prm;
-    if (a.isImu) {  // VIOFilter.cpp:121-124
-        *unbW = mk3(r.w[0] - g.bias[0], r.w[1] - g.bias[1], r.w[2] - g.bias[2]);
-        *unbA = mk3(r.a[0] - g.bias[3], r.a[1] - g.bias[4], r.a[2] - g.bias[5]);
-        if (!g.initialised) {  // initialiseFromIMUData, VIOFilter.cpp:133-144
-            const quat q0 = so3FromVectors(*unbA, mk3(0, 0, 1), bad);
-            g.P0q[0] = q0.w; g.P0q[1] = q0.x; g.P0q[2] = q0.y; g.P0q[3] = q0.z;
-            g.P0x[0] = g.P0x[1] = g.P0x[2] = 0;
-            g.v0[0] = g.v0[1] = g.v0[2] = 0;
-            g.initialised = 1;
-        }
-    }
-    c.dt = r.stamp - g.curTime;
-    c.step = (g.curTime >= 0) && (c.dt > 0);  // VIOFilter.cpp:147-152
+    c.dt = r.stamp - G.curTime;
+    c.step = (G.curTime >= 0) && (c.dt > 0);  // VIOFilter.cpp:147-152
     if (!c.step) return;
-    c.T = g.accTime + c.dt;  // :154
-    c.wcur = mk3(g.curVel[0], g.curVel[1], g.curVel[2]);
-    c.acur = mk3(g.curVel[3], g.curVel[4], g.curVel[5]);
+    c.T = G.accTime + c.dt;  // :154
+    c.wcur = mk3(G.curVel[0], G.curVel[1], G.curVel[2]);
+    c.acur = mk3(G.curVel[3], G.curVel[4], G.curVel[5]);
     // :155 accumulatedVelocity += currentVelocity * dt ; :169 mean = accumulatedVelocity * (1/T)
     const double invT = 1.0 / c.T;
-    c.wbar = mk3((g.accVel[0] + c.wcur.x * c.dt) * invT, (g.accVel[1] + c.wcur.y * c.dt) * invT,
-        (g.accVel[2] + c.wcur.z * c.dt) * invT);
-    const quat Aq = quat{g.Aq[0], g.Aq[1], g.Aq[2], g.Aq[3]};
+    c.wbar = mk3((G.accVel[0] + c.wcur.x * c.dt) * invT, (G.accVel[1] + c.wcur.y * c.dt) * invT,
+        (G.accVel[2] + c.wcur.z * c.dt) * invT);
+    const quat Aq = quat{G.Aq[0], G.Aq[1], G.Aq[2], G.Aq[3]};
     const quat Aqi = qinv(Aq);
-    const quat P0q = quat{g.P0q[0], g.P0q[1], g.P0q[2], g.P0q[3]};
     c.RA = q2m(Aq);
-    c.vhat = qrot(Aqi, mk3(g.v0[0] - g.w[0], g.v0[1] - g.w[1], g.v0[2] - g.w[2]));  // VIOGroup.cpp:26
-    c.eta0 = qrot(qinv(P0q), mk3(0, 0, 1));                                           // VIOState.cpp:90
-    c.etahat = qrot(Aqi, c.eta0);                                                      // VIOGroup.cpp:49
-    const se3 cam = se3{quat{p.camq[0], p.camq[1], p.camq[2], p.camq[3]}, mk3(p.camx[0], p.camx[1], p.camx[2])};
-    const se3 camI = se3inv(cam);
-    d3 oC, vC;
-    se3AdjointApply(camI, c.wbar, c.vhat, &oC, &vC);
-    c.vC = vC;
-    se3AdjointApply(camI, c.wcur, c.vhat, &oC, &vC);
-    c.camInv = se3Exp(scl(-c.dt, oC), scl(-c.dt, vC));
-    c.RIC = q2m(cam.q);
-    c.RICt = q2m(qinv(cam.q));
-    c.xIC = cam.x;
+    c.vhat = qrot(Aqi, mk3(G.v0[0] - G.w[0], G.v0[1] - G.w[1], G.v0[2] - G.w[2]));  // VIOGroup.cpp:26
+    // constants of the origin pose: cached at initialisation; recomputed only in the (reset) corner case where a
+    // step happens in the very call that initialises the pose
+    double eta0[3], cDiff[6], cInv[6];
+    if (G.initialised) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) eta0[i] = G.eta0[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            cDiff[i] = G.cDiff[i];
+            cInv[i] = G.cInv[i];
+        }
+    } else {
+        quat P0q = quat{G.P0q[0], G.P0q[1], G.P0q[2], G.P0q[3]};
+        if (a.isImu)
+            P0q = so3FromVectors(mk3(r.a[0] - G.bias[3], r.a[1] - G.bias[4], r.a[2] - G.bias[5]), mk3(0, 0, 1), bad);
+        poseConstants(P0q, eta0, cDiff, cInv, bad);
+    }
+    c.etahat = qrot(Aqi, mk3(eta0[0], eta0[1], eta0[2]));  // VIOGroup.cpp:49
+    // Ad(T_IC^-1) (w, v) = (R w ; x^ R w + R v) with the host-precomputed inverse camera offset
+    m33 RcI;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        RcI.a[i] = p.RcamI[i];
+        c.RIC.a[i] = p.RIC[i];
+        c.RICt.a[i] = p.RICt[i];
+    }
+    const d3 xcI = mk3(p.camIx[0], p.camIx[1], p.camIx[2]);
+    const d3 Rv = mv33(RcI, c.vhat);
+    {
+        const d3 Rw = mv33(RcI, c.wbar);
+        c.vC = add(crs(xcI, Rw), Rv);
+    }
+    {
+        const d3 Rw = mv33(RcI, c.wcur);
+        c.oCcur = Rw;
+        c.vCcur = add(crs(xcI, Rw), Rv);
+    }
+    if (p.useDiscreteVelocityLift) c.camInv = se3Exp(scl(-c.dt, c.oCcur), scl(-c.dt, c.vCcur));
+    c.xIC = mk3(p.camx[0], p.camx[1], p.camx[2]);
     if (a.doRiccati) {
-        double diff[6], idiff[6];
-        stereoChartDiff(c.eta0, c.eta0, diff, bad);
-        stereoChartInvDiffAtZero(c.eta0, idiff, bad);
         const m33 RAg = mul33(c.RA, skew3(c.etahat));
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j)
-                c.Bg[3 * i + j] = diff[3 * i] * RAg.a[j] + diff[3 * i + 1] * RAg.a[3 + j] + diff[3 * i + 2] * RAg.a[6 + j];
+                c.Bg[3 * i + j] = cDiff[3 * i] * RAg.a[j] + cDiff[3 * i + 1] * RAg.a[3 + j] + cDiff[3 * i + 2] * RAg.a[6 + j];
         c.Bvw = mul33(c.RA, skew3(c.vhat));
 #pragma unroll
-        for (int i = 0; i < 6; ++i) c.Avg[i] = -kGravity * idiff[i];
+        for (int i = 0; i < 6; ++i) c.Avg[i] = -kGravity * cInv[i];
     }
 }
 
@@ -144,42 +165,49 @@ EQF_DI void stepLandmark(const StepCommon& c, const PropArgs& a, quat Qq, double
         la = nrm3(qhat) / nrm3(q1);
     } else {
         // W_i = (omega_C + q^x v_C / |q|^2, q.v_C / |q|^2) with U_C from the CURRENT sample; VIOExp(dt * W)
-        const Params& p = a.prm;
-        const se3 cam = se3{quat{p.camq[0], p.camq[1], p.camq[2], p.camq[3]}, mk3(p.camx[0], p.camx[1], p.camx[2])};
-        d3 oC, vC;
-        se3AdjointApply(se3inv(cam), c.wcur, c.vhat, &oC, &vC);
         const double n2 = dot3(qhat, qhat);
-        const d3 Wr = add(oC, scl(1.0 / n2, crs(qhat, vC)));
+        const d3 Wr = add(c.oCcur, scl(1.0 / n2, crs(qhat, c.vCcur)));
         lq = so3Exp(scl(c.dt, Wr));
-        la = exp(c.dt * dot3(qhat, vC) / n2);
+        la = exp(c.dt * dot3(qhat, c.vCcur) / n2);
     }
     *Qo = qmul(Qq, lq);
     *ao = Qa * la;
 }
 
-// Scalar part of the step, one thread per filter: X.A, X.w, ZOH bookkeeping.
-EQF_DI void stepGlobal(Glob& g, const ImuRec& r, const PropArgs& a, const StepCommon& c, d3 unbW, d3 unbA) {
-    if (c.step) {
-        // VIOFilter.cpp:154-155
-        g.accTime = c.T;
-        for (int i = 0; i < 6; ++i) g.accVel[i] += g.curVel[i] * c.dt;
-        if (a.doRiccati) {  // :192-193
-            g.accTime = 0;
-            for (int i = 0; i < 6; ++i) g.accVel[i] = 0;
+// Scalar part of the step, one lane per filter: lazy initialisation, X.A, X.w, ZOH bookkeeping.
+EQF_DI void stepGlobal(const Glob& G, Glob* out, const ImuRec& r, const PropArgs& a, const StepCommon& c, int* bad) {
+    Glob g = G;
+    d3 unbW = mk3(0, 0, 0), unbA = mk3(0, 0, 0);
+    if (a.isImu) {  // VIOFilter.cpp:121-124
+        unbW = mk3(r.w[0] - G.bias[0], r.w[1] - G.bias[1], r.w[2] - G.bias[2]);
+        unbA = mk3(r.a[0] - G.bias[3], r.a[1] - G.bias[4], r.a[2] - G.bias[5]);
+        if (!G.initialised) {  // initialiseFromIMUData, VIOFilter.cpp:133-144
+            const quat q0 = so3FromVectors(unbA, mk3(0, 0, 1), bad);
+            g.P0q[0] = q0.w; g.P0q[1] = q0.x; g.P0q[2] = q0.y; g.P0q[3] = q0.z;
+            g.P0x[0] = g.P0x[1] = g.P0x[2] = 0;
+            g.v0[0] = g.v0[1] = g.v0[2] = 0;
+            g.initialised = 1;
+            // NB: a level start (accel along +z) makes the gravity chart singular; the reference then throws from
+            // the first Riccati step (SO3.cpp:160).  The flag raised here is sticky (eqf_device_error).
+            poseConstants(q0, g.eta0, g.cDiff, g.cInv, bad);
         }
-        se3 lA;
+    }
+    if (c.step) {
+        // VIOFilter.cpp:154-155, :192-193
+        g.accTime = a.doRiccati ? 0.0 : c.T;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) g.accVel[i] = a.doRiccati ? 0.0 : G.accVel[i] + G.curVel[i] * c.dt;
+        const se3 lA = se3Exp(scl(c.dt, c.wcur), scl(c.dt, c.vhat));  // VIOGroup.cpp:214-217 / :182-185 + :247
         d3 lw;
-        if (a.prm.useDiscreteVelocityLift) {  // VIOGroup.cpp:214-222
-            lA = se3Exp(scl(c.dt, c.wcur), scl(c.dt, c.vhat));
+        if (a.prm.useDiscreteVelocityLift) {  // VIOGroup.cpp:219-222
             const d3 inner = add(c.vhat, scl(c.dt, add(add(neg(crs(c.wcur, c.vhat)), c.acur), scl(-kGravity, c.etahat))));
             lw = sub(c.vhat, qrot(lA.q, inner));
-        } else {  // VIOGroup.cpp:182-187, :245-249
-            lA = se3Exp(scl(c.dt, c.wcur), scl(c.dt, c.vhat));
+        } else {  // VIOGroup.cpp:187, :248
             lw = scl(c.dt, add(neg(c.acur), scl(kGravity, c.etahat)));
         }
-        const se3 A = se3{quat{g.Aq[0], g.Aq[1], g.Aq[2], g.Aq[3]}, mk3(g.Ax[0], g.Ax[1], g.Ax[2])};
-        const se3 An = se3mul(A, lA);              // VIOGroup.cpp:95
-        const d3 wn = add(mk3(g.w[0], g.w[1], g.w[2]), qrot(A.q, lw));  // :96
+        const se3 A = se3{quat{G.Aq[0], G.Aq[1], G.Aq[2], G.Aq[3]}, mk3(G.Ax[0], G.Ax[1], G.Ax[2])};
+        const se3 An = se3mul(A, lA);                                      // VIOGroup.cpp:95
+        const d3 wn = add(mk3(G.w[0], G.w[1], G.w[2]), qrot(A.q, lw));     // :96
         g.Aq[0] = An.q.w; g.Aq[1] = An.q.x; g.Aq[2] = An.q.y; g.Aq[3] = An.q.z;
         g.Ax[0] = An.x.x; g.Ax[1] = An.x.y; g.Ax[2] = An.x.z;
         g.w[0] = wn.x; g.w[1] = wn.y; g.w[2] = wn.z;
@@ -190,9 +218,16 @@ EQF_DI void stepGlobal(Glob& g, const ImuRec& r, const PropArgs& a, const StepCo
         g.curVel[3] = unbA.x; g.curVel[4] = unbA.y; g.curVel[5] = unbA.z;
         g.curTime = r.stamp;
     } else {
-        g.updateOk = (c.step && g.initialised) ? 1 : 0;  // VIOFilter.cpp:234-236
+        g.updateOk = (c.step && G.initialised) ? 1 : 0;  // VIOFilter.cpp:234-236
     }
+    *out = g;
 }
+
+// LDS image of the few common values the base-panel code of waves 1..3 needs
+struct CommonLds {
+    double T;
+    double Bg[6], Bvw[9], RA[9], Avg[6];
+};
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
@@ -211,41 +246,74 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     __shared__ T sNb[11][3];                          // rows of B (gyro columns) for the base coordinates
     __shared__ T sTmp[16][33];
     __shared__ T sTb[11][12];
+    __shared__ CommonLds sC;
 
-    Glob g = a.gin[b];
-    const ImuRec r = a.recs ? a.recs[b] : a.inl;
-    const int N = g.N;
-    int bad = 0;
-    StepCommon c;
-    d3 unbW = mk3(0, 0, 0), unbA = mk3(0, 0, 0);
-    stepCommon(g, r, a, c, &unbW, &unbA, &bad);
+    const Glob& G = a.gin[b];
+    const ImuRec& r = a.recs ? a.recs[b] : a.inl;
+    const int N = G.N;
+    // cheap, every thread: does this call integrate, and does it touch Sigma?
+    const double dt0 = r.stamp - G.curTime;
+    const bool step = (G.curTime >= 0) && (dt0 > 0);
+    const bool riccati = step && a.doRiccati;
 
     const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
     T* Sout = static_cast<T*>(a.Sout) + (long long)b * a.sigmaStride;
     const double* p0 = a.p0 + (long long)b * 3 * cap;
     const double* Qin = a.Qin + (long long)b * 5 * cap;
     double* Qout = a.Qout + (long long)b * 5 * cap;
-
     const int I0 = ti * kTileLm, J0 = tj * kTileLm;
-    const bool riccati = c.step && a.doRiccati;
+    int bad = 0;
 
-    // ---- group step of this tile's landmarks (diagonal tiles only) and the scalar state
-    if (ti == tj && tid < kTileLm) {
-        const int i = I0 + tid;
-        if (i < N) {
-            const quat Qq = quat{Qin[i], Qin[cap + i], Qin[2 * cap + i], Qin[3 * cap + i]};
-            const double Qa = Qin[4 * cap + i];
-            quat Qo = Qq;
-            double ao = Qa;
-            if (c.step) stepLandmark(c, a, Qq, Qa, mk3(p0[i], p0[cap + i], p0[2 * cap + i]), &Qo, &ao, &bad);
-            Qout[i] = Qo.w; Qout[cap + i] = Qo.x; Qout[2 * cap + i] = Qo.y; Qout[3 * cap + i] = Qo.z;
-            Qout[4 * cap + i] = ao;
+    if (tid < 64) {
+        // ---- wave 0 owns the scalar chain: common quantities, this tile's linearisation blocks, group step
+        StepCommon c;
+        c.step = 0;
+        const bool needCommon = step && (riccati || ti == tj || blockIdx.x == 0);
+        if (needCommon) stepCommon(G, r, a, c, &bad);
+        if (riccati) {
+            if (tid < 32) {
+                const int i = (tid < 16) ? I0 + tid : J0 + tid - 16;
+                if (i < N) {
+                    const quat Qq = quat{Qin[i], Qin[cap + i], Qin[2 * cap + i], Qin[3 * cap + i]};
+                    const LmBlocks blk = buildBlocks(c, Qq, Qin[4 * cap + i], mk3(p0[i], p0[cap + i], p0[2 * cap + i]));
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        sD[tid][k] = (T)blk.D.a[k];
+                        sLw[tid][k] = (T)blk.Lw.a[k];
+                        sLv[tid][k] = (T)blk.Lv.a[k];
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) sD[tid][k] = sLw[tid][k] = sLv[tid][k] = (T)0;
+                }
+            }
+            if (tid == 32) {
+                sC.T = c.T;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    sC.Bg[k] = c.Bg[k];
+                    sC.Avg[k] = c.Avg[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    sC.Bvw[k] = c.Bvw.a[k];
+                    sC.RA[k] = c.RA.a[k];
+                }
+            }
         }
-    }
-    if (blockIdx.x == 0 && tid == 64) {
-        Glob go = g;
-        stepGlobal(go, r, a, c, unbW, unbA);
-        a.gout[b] = go;
+        if (ti == tj && tid < kTileLm) {
+            const int i = I0 + tid;
+            if (i < N) {
+                const quat Qq = quat{Qin[i], Qin[cap + i], Qin[2 * cap + i], Qin[3 * cap + i]};
+                const double Qa = Qin[4 * cap + i];
+                quat Qo = Qq;
+                double ao = Qa;
+                if (step) stepLandmark(c, a, Qq, Qa, mk3(p0[i], p0[cap + i], p0[2 * cap + i]), &Qo, &ao, &bad);
+                Qout[i] = Qo.w; Qout[cap + i] = Qo.x; Qout[2 * cap + i] = Qo.y; Qout[3 * cap + i] = Qo.z;
+                Qout[4 * cap + i] = ao;
+            }
+        }
+        if (blockIdx.x == 0 && tid == 48) stepGlobal(G, a.gout + b, r, a, c, &bad);
     }
 
     if (!riccati) {
@@ -271,57 +339,57 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
         return;
     }
 
-    // ---- per-landmark linearisation blocks for the 16 row and 16 column landmarks of the tile
-    if (tid < 32) {
-        const int i = (tid < 16) ? I0 + tid : J0 + tid - 16;
-        if (i < N) {
-            const quat Qq = quat{Qin[i], Qin[cap + i], Qin[2 * cap + i], Qin[3 * cap + i]};
-            const LmBlocks blk = buildBlocks(c, Qq, Qin[4 * cap + i], mk3(p0[i], p0[cap + i], p0[2 * cap + i]));
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                sD[tid][k] = (T)blk.D.a[k];
-                sLw[tid][k] = (T)blk.Lw.a[k];
-                sLv[tid][k] = (T)blk.Lv.a[k];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) sD[tid][k] = sLw[tid][k] = sLv[tid][k] = (T)0;
+    // ---- waves 1..3 stage the base panels while wave 0 runs the scalar chain
+    if (tid >= 64) {
+        for (int e = tid - 64; e < 11 * kTile; e += 192) {
+            const int rr = e / kTile, cc = e % kTile;
+            const int Cc = kLm0 + 3 * J0 + cc;
+            sSbJ[rr][cc] = (Cc < kLm0 + 3 * N) ? Sin[(long long)rr * ld + Cc] : (T)0;
+        }
+        for (int e = tid - 64; e < kTile * 12; e += 192) {
+            const int rr = e / 12, cc = e % 12;
+            const int R = kLm0 + 3 * I0 + rr;
+            sSIb[rr][cc] = (R < kLm0 + 3 * N && cc < 11) ? Sin[(long long)R * ld + cc] : (T)0;
+        }
+        if (tid - 64 < 132) {
+            const int rr = (tid - 64) / 12, cc = (tid - 64) % 12;
+            sSbb[rr][cc] = (cc < 11) ? Sin[(long long)rr * ld + cc] : (T)0;
         }
     }
-    // ---- stage base panels
-    for (int e = tid; e < 11 * kTile; e += 256) {
-        const int rr = e / kTile, cc = e % kTile;
-        const int Cc = kLm0 + 3 * J0 + cc;
-        sSbJ[rr][cc] = (Cc < kLm0 + 3 * N) ? Sin[(long long)rr * ld + Cc] : (T)0;
+    // this thread's own 3x3 block of Sigma: issue the loads before the barrier
+    const int bi = tid >> 4, bj = tid & 15;
+    const int BI = I0 + bi, BJ = J0 + bj;
+    const bool blockValid = BI < N && BJ < N;
+    T S[9];
+    if (blockValid) {
+        const T* src = Sin + (long long)(kLm0 + 3 * BI) * ld + kLm0 + 3 * BJ;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) S[3 * rr + cc] = src[(long long)rr * ld + cc];
     }
-    for (int e = tid; e < kTile * 12; e += 256) {
-        const int rr = e / 12, cc = e % 12;
-        const int R = kLm0 + 3 * I0 + rr;
-        sSIb[rr][cc] = (R < kLm0 + 3 * N && cc < 11) ? Sin[(long long)R * ld + cc] : (T)0;
-    }
+    __syncthreads();
     if (tid < 132) {
         const int rr = tid / 12, cc = tid % 12;
-        sSbb[rr][cc] = (cc < 11) ? Sin[(long long)rr * ld + cc] : (T)0;
         // F_bb = I + T * [[0,0,0,0],[-B_g^w,0,0,0],[-B_v^w,-R_A, A_vg, 0]]   (VIOFilter.cpp:178-183)
         double f = (rr == cc) ? 1.0 : 0.0;
-        if (rr >= 6 && rr < 8 && cc < 3) f = -c.T * c.Bg[3 * (rr - 6) + cc];
+        if (rr >= 6 && rr < 8 && cc < 3) f = -sC.T * sC.Bg[3 * (rr - 6) + cc];
         if (rr >= 8) {
-            if (cc < 3) f = -c.T * c.Bvw.a[3 * (rr - 8) + cc];
-            else if (cc < 6) f = -c.T * c.RA.a[3 * (rr - 8) + cc - 3];
-            else if (cc < 8) f = c.T * c.Avg[2 * (rr - 8) + cc - 6];
+            if (cc < 3) f = -sC.T * sC.Bvw[3 * (rr - 8) + cc];
+            else if (cc < 6) f = -sC.T * sC.RA[3 * (rr - 8) + cc - 3];
+            else if (cc < 8) f = sC.T * sC.Avg[2 * (rr - 8) + cc - 6];
         }
         sF[rr][cc] = (cc < 11) ? (T)f : (T)0;
         if (cc < 3) {
             double nb = 0.0;
-            if (rr >= 6 && rr < 8) nb = c.Bg[3 * (rr - 6) + cc];
-            if (rr >= 8) nb = c.Bvw.a[3 * (rr - 8) + cc];
+            if (rr >= 6 && rr < 8) nb = sC.Bg[3 * (rr - 6) + cc];
+            if (rr >= 8) nb = sC.Bvw[3 * (rr - 8) + cc];
             sNb[rr][cc] = (T)nb;
         }
     }
-    __syncthreads();
 
     const T sw2 = (T)a.prm.velOmegaVariance, sa2 = (T)a.prm.velAccelVariance;
-    const T Tt = (T)c.T;
+    const T Tt = (T)sC.T;
 
     // ---- G_I = Lw_I Sigma[0:3, 0:11] + Lv_I Sigma[8:11, 0:11] + D_I Sigma_Ib
     for (int e = tid; e < 16 * 33; e += 256) {
@@ -340,41 +408,32 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     __syncthreads();
 
     // ---- one 3x3 block per thread
-    {
-        const int i = tid >> 4, j = tid & 15;
-        const int I = I0 + i, J = J0 + j;
-        if (I < N && J < N) {
-            const T* src = Sin + (long long)(kLm0 + 3 * I) * ld + kLm0 + 3 * J;
-            T S[9];
+    if (blockValid) {
+        const int i = bi, j = bj;
+        T H[9];
 #pragma unroll
-            for (int rr = 0; rr < 3; ++rr)
+        for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-                for (int cc = 0; cc < 3; ++cc) S[3 * rr + cc] = src[(long long)rr * ld + cc];
-            T H[9];
+            for (int cc = 0; cc < 3; ++cc) {
+                T acc = 0;
 #pragma unroll
-            for (int rr = 0; rr < 3; ++rr)
+                for (int k = 0; k < 3; ++k)
+                    acc += sD[i][3 * rr + k] * S[3 * k + cc] + sLw[i][3 * rr + k] * sSbJ[k][3 * j + cc] +
+                           sLv[i][3 * rr + k] * sSbJ[8 + k][3 * j + cc];
+                H[3 * rr + cc] = acc;
+            }
+        T* dst = Sout + (long long)(kLm0 + 3 * BI) * ld + kLm0 + 3 * BJ;
 #pragma unroll
-                for (int cc = 0; cc < 3; ++cc) {
-                    T acc = 0;
+        for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-                    for (int k = 0; k < 3; ++k)
-                        acc += sD[i][3 * rr + k] * S[3 * k + cc] + sLw[i][3 * rr + k] * sSbJ[k][3 * j + cc] +
-                               sLv[i][3 * rr + k] * sSbJ[8 + k][3 * j + cc];
-                    H[3 * rr + cc] = acc;
-                }
-            T* dst = Sout + (long long)(kLm0 + 3 * I) * ld + kLm0 + 3 * J;
+            for (int cc = 0; cc < 3; ++cc) {
+                T acc = (BI == BJ && rr == cc) ? Tt * (T)a.prm.pointProcessVariance : (T)0;  // T * P
 #pragma unroll
-            for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-                for (int cc = 0; cc < 3; ++cc) {
-                    T acc = (I == J && rr == cc) ? Tt * (T)a.prm.pointProcessVariance : (T)0;  // T * P
-#pragma unroll
-                    for (int k = 0; k < 3; ++k)
-                        acc += H[3 * rr + k] * sD[16 + j][3 * cc + k] + sGn[i][3 * rr + k] * sLw[16 + j][3 * cc + k] +
-                               sG[i][rr * 11 + 8 + k] * sLv[16 + j][3 * cc + k];
-                    dst[(long long)rr * ld + cc] = acc;
-                }
-        }
+                for (int k = 0; k < 3; ++k)
+                    acc += H[3 * rr + k] * sD[16 + j][3 * cc + k] + sGn[i][3 * rr + k] * sLw[16 + j][3 * cc + k] +
+                           sG[i][rr * 11 + 8 + k] * sLv[16 + j][3 * cc + k];
+                dst[(long long)rr * ld + cc] = acc;
+            }
     }
 
     // ---- Sigma'_Ib = G_I F_bb^T + T (B R B^T)_Ib      (tiles in the first tile column)
@@ -446,7 +505,7 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
                 for (int k = 0; k < 3; ++k) nz += sw2 * sNb[rr][k] * sNb[cc][k];
                 if (rr >= 8 && cc >= 8) {  // accel columns of B: rows 8:11 hold R_A
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) nz += sa2 * (T)c.RA.a[3 * (rr - 8) + k] * (T)c.RA.a[3 * (cc - 8) + k];
+                    for (int k = 0; k < 3; ++k) nz += sa2 * (T)sC.RA[3 * (rr - 8) + k] * (T)sC.RA[3 * (cc - 8) + k];
                 }
                 if (rr == cc) {
                     const Params& p = a.prm;

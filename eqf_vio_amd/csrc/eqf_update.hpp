@@ -60,6 +60,7 @@ struct UpdArgs {
     double* dbgDelta;  // [B][2*cap]
     double* dbgGamma;  // [B][12+3*cap] internal index map
     double* dbgGammaTot;  // [B][9+3*cap]
+    double* red;          // [B][256]: hV (6) at 0, G11 = [Zt|Et]^T [Zt|Et] (11x11) at 8
     int* errflag;
     Params prm;
 };
@@ -464,6 +465,50 @@ __global__ __launch_bounds__(256) void k_chol_step(ChainArgs c0, ChainArgs c1, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_update_reduce: the length-m / length-n_e dot products of the update, spread over many workgroups:
+//   gamma[col] = sum_r Y[r][col] z[r]  (z = Y[:, 11]),  hV = (L^-1 V)^T z,  G11 = [Zt | Et]^T [Zt | Et].
+// grid.x = colBlocks (64 columns of Y each) + 1 (the E-chain block), grid.y = B, block = 256.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_update_reduce(UpdArgs a, int colBlocks) {
+    const int b = blockIdx.y;
+    const Glob& g = a.g[b];
+    if (!g.updateOk || g.N == 0) return;
+    const int N = g.N, cap = a.cap;
+    const int tid = threadIdx.x;
+    __shared__ double sRed[256];
+    if ((int)blockIdx.x < colBlocks) {
+        const int mp = roundUp(sDim(N), kNB), nv = kLm0 + 3 * N;
+        const double* Y = a.YO + (long long)b * a.strideY;
+        const int col = blockIdx.x * 64 + (tid & 63), part = tid >> 6;
+        double acc = 0;
+        if (col < nv + 6) {
+#pragma unroll 4
+            for (int r = part; r < mp; r += 4) acc += Y[(long long)r * a.ldY + col] * Y[(long long)r * a.ldY + 11];
+        }
+        sRed[tid] = acc;
+        __syncthreads();
+        if (tid < 64 && col < nv + 6) {
+            const double v = (sRed[tid] + sRed[64 + tid]) + (sRed[128 + tid] + sRed[192 + tid]);
+            if (col < nv) a.dbgGamma[(long long)b * (kLm0 + 3 * cap) + col] = (col == 11) ? 0.0 : v;
+            else a.red[(long long)b * 256 + col - nv] = v;
+        }
+    } else {
+        const int nep = roundUp(eDim(N), kNB);
+        const double* Z = a.ZO + (long long)b * a.strideZ;
+        const int pr = tid % 121, part = tid / 121;  // 121 column pairs x 2 row halves (threads 242..255 idle)
+        double acc = 0;
+        if (part < 2) {
+            const int c0 = pr / 11, c1 = pr % 11;
+#pragma unroll 4
+            for (int r = part; r < nep; r += 2) acc += Z[(long long)r * a.ldZ + c0] * Z[(long long)r * a.ldZ + c1];
+        }
+        sRed[tid] = acc;
+        __syncthreads();
+        if (tid < 121) a.red[(long long)b * 256 + 8 + tid] = sRed[tid] + sRed[121 + tid];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_update_finish: one workgroup per filter.  gamma = Y^T z, the 4x4 weighted least squares of bundleLift,
 // Delta = liftTotalSpaceInnovationDiscrete(Gamma), X <- Delta * X, bias += gamma[0:6].
 // ------------------------------------------------------------------------------------------------
@@ -501,39 +546,13 @@ __global__ __launch_bounds__(256) void k_update_finish(UpdArgs a) {
     if (!g.updateOk || g.N == 0) return;
     const int N = g.N, cap = a.cap;
     const int tid = threadIdx.x;
-    const int m = sDim(N), mp = roundUp(m, kNB), nv = kLm0 + 3 * N;
-    const int ne = eDim(N), nep = roundUp(ne, kNB);
-    const double* Y = a.YO + (long long)b * a.strideY;
-    const double* Z = a.ZO + (long long)b * a.strideZ;
-    double* gam = a.dbgGamma + (long long)b * (kLm0 + 3 * cap);
+    double* gam = a.dbgGamma + (long long)b * (kLm0 + 3 * cap);  // written by k_update_reduce
+    const double* red = a.red + (long long)b * 256;
     __shared__ double sG6[36], sT65[30], sHV[6], sSol[16];
-    __shared__ double sRed[256];
     int bad = 0;
-
-    // gamma[col] = sum_r Y[r][col] z[r], z = Y[:, 11]; also hV[c] = sum_r Y[r][nv + c] z[r]
-    for (int col = tid; col < nv + 6; col += 256) {
-        double acc = 0;
-        for (int r = 0; r < mp; ++r) acc += Y[(long long)r * a.ldY + col] * Y[(long long)r * a.ldY + 11];
-        if (col < nv) gam[col] = (col == 11) ? 0.0 : acc;
-        else sHV[col - nv] = acc;
-    }
-    // G6 = Zt^T Zt (6x6), T65 = Zt^T Et (6x5): 66 dot products of length nep; 3 threads per product
-    {
-        const int pr = tid / 3, part = tid % 3;
-        double acc = 0;
-        if (pr < 66) {
-            const int c0 = (pr < 36) ? pr / 6 : (pr - 36) / 5;
-            const int c1 = (pr < 36) ? pr % 6 : 6 + (pr - 36) % 5;
-            for (int r = part; r < nep; r += 3) acc += Z[(long long)r * a.ldZ + c0] * Z[(long long)r * a.ldZ + c1];
-        }
-        sRed[tid] = acc;
-    }
-    __syncthreads();
-    if (tid < 66) {
-        const double v = sRed[3 * tid] + sRed[3 * tid + 1] + sRed[3 * tid + 2];
-        if (tid < 36) sG6[tid] = v;
-        else sT65[tid - 36] = v;
-    }
+    if (tid < 6) sHV[tid] = red[tid];
+    if (tid < 36) sG6[tid] = red[8 + 11 * (tid / 6) + tid % 6];             // Zt^T Zt
+    if (tid >= 64 && tid < 94) sT65[tid - 64] = red[8 + 11 * ((tid - 64) / 5) + 6 + (tid - 64) % 5];  // Zt^T Et
     __syncthreads();
 
     // ---- Gamma[0:6] on one thread (bundleLift, EqFMatrices.cpp:173-252)

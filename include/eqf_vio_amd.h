@@ -129,7 +129,7 @@ int eqf_set_dense_propagate(eqf_filter* f, int on);
 #define EQF_PROF_PROPAGATE 0
 #define EQF_PROF_UPDATE_PREP 1
 #define EQF_PROF_CHOL_STEP 2
-#define EQF_PROF_BACKSOLVE 3
+#define EQF_PROF_REDUCE 3
 #define EQF_PROF_FINISH 4
 #define EQF_PROF_DOWNDATE 5
 #define EQF_PROF_CHURN 6

@@ -244,3 +244,34 @@ def test_fp32_mode_runs_and_is_bounded(oracle_lib, hip):
     worst, _, _ = _drive(oracle_lib, hip, 25, 1.0, precision=1)
     assert worst["sigma"] < 5e-2, worst
     assert worst["pos"] < 5e-2, worst
+
+
+def test_cpp_facade_matches_the_oracle(oracle_lib):
+    """The C++ host facade (eqf_vio_amd/cpp/VIOFilter.h, the reference's class interface) driven by the example
+    runner reproduces the oracle on the same inputs."""
+    import os
+    import re
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "eqf_vio_amd", "cpp", "eqf_example")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    N, frames = 20, 10
+    out = subprocess.run([exe, str(N), str(frames)], capture_output=True, text=True, check=True).stdout
+    nums = [float(x) for x in re.findall(r"[-+]?\d+\.\d+(?:e[-+]?\d+)?", out)]
+    t, pos, q, fro = nums[0], nums[1:4], nums[4:8], nums[8]
+    i = np.arange(N)
+    lm = np.stack([2 * np.sin(1.3 * i), 2 * np.cos(0.7 * i), 5 + np.sin(0.37 * i)], axis=1)
+    y = lm / np.linalg.norm(lm, axis=1, keepdims=True)
+    fo = oracle_lib.OracleFilter(dict(initialPointVariance=5000.0, measurementVariance=0.003, velOmegaVariance=1e-4,
+                                      velAccelVariance=1e-4, outlierThreshold=1e9))
+    k = 0
+    for f in range(frames):
+        stamp = 0.05 * f + 0.0025
+        while 0.005 * k < stamp:
+            fo.processIMUData(0.005 * k, [0, 0, 0], [9.81, 0, 0])
+            k += 1
+        fo.processVisionData(stamp, i.astype(np.int32), y)
+    e = fo.stateEstimate()
+    assert abs(t - fo.getTime()) < 1e-9
+    assert np.abs(np.array(pos) - e["x"]).max() < 2e-6 and np.abs(np.array(q) - e["q"]).max() < 2e-6  # printed with 6 digits
+    assert abs(fro / np.linalg.norm(fo.stateCovariance()) - 1) < 1e-6
