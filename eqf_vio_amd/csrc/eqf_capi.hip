@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -310,6 +311,10 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     cE.g = a.g; cE.A = f->EA; cE.L = f->EL; cE.W = f->ZW; cE.WO = f->ZO;
     cE.ldA = f->ldE; cE.ldW = f->ldZ; cE.strideA = f->strideE; cE.strideW = f->strideZ;
     cE.kind = 1; cE.nbMax = nep / kNB; cE.wtMax = 1;
+    {
+        static const int dbg = std::getenv("EQF_DEBUG_CHOL") ? std::atoi(std::getenv("EQF_DEBUG_CHOL")) : 0;
+        cS.dbg = cE.dbg = dbg;
+    }
     const int steps = std::max(cS.nbMax, cE.nbMax);
     const int nblk = cS.nbMax * cS.nbMax + cS.wtMax * cS.nbMax + cE.nbMax * cE.nbMax + cE.wtMax * cE.nbMax;
     for (int k = 0; k < steps; ++k) {

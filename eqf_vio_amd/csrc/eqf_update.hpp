@@ -282,35 +282,90 @@ __global__ __launch_bounds__(256) void k_update_prep(UpdArgs a, int lmBlocks, in
 // ------------------------------------------------------------------------------------------------
 constexpr int kLdsP = kNB + 1;  // LDS row pitch (doubles): +1 breaks the power-of-two stride
 
-// 32x32 Cholesky by lanes 0..31 of one wave, row l in registers; writes L (lower) and 1/diag to LDS.
-EQF_DI void potrf32(double (*sA)[kLdsP], double* sRd, int lane, int* bad) {
+// Broadcast of a double held by lane `src` (compile-time constant after unrolling) through SGPRs.
+EQF_DI double readlane64(double v, int src) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+#else
+    (void)src;
+    return v;
+#endif
+}
+// 1/sqrt(d): hardware v_rsq_f64 seed + two Newton steps (full fp64 accuracy, ~8 dependent instructions).
+EQF_DI double rsqrtPivot(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(d);
+#else
+    double y = 1.0 / sqrt(d);
+#endif
+    const double h = 0.5 * d;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return y;
+}
+
+// 32x32 Cholesky by one wave, right-looking, row `lane & 31` of the block in registers.
+// Measured on gfx950 (scripts/micro/lat.hip): fp64 VALU op ~6 cycles, v_readlane ~15, LDS round trip ~110,
+// so only the pivot chain (and the next kLA columns it needs) uses SGPR broadcasts; the bulk of each rank-1
+// update reads the finished column from LDS one iteration later (wide uniform-address reads), off the chain.
+// Output: L^T in sLT (sLT[j][c] = L[c][j], c >= j) and the reciprocal diagonal in sRd.
+constexpr int kLtP = kNB + 2;  // even pitch: rows 16-byte aligned for ds_read_b128
+constexpr int kLA = 2;         // columns ahead of the pivot that are updated through v_readlane
+EQF_DI void potrf32(const double (*sA)[kLdsP], double (*sLT)[kLtP], double* sRd, int lane, int* bad) {
     double row[kNB];
+    const int lr = lane & (kNB - 1);
 #pragma unroll
-    for (int c = 0; c < kNB; ++c) row[c] = (lane < kNB) ? sA[lane][c] : 0.0;
+    for (int c = 0; c < kNB; ++c) row[c] = sA[lr][c];
+    double ljPrev = 0.0;
 #pragma unroll
     for (int j = 0; j < kNB; ++j) {
-        double v = row[j];
+        // (1) start fetching column j-1 (written to LDS one iteration ago) for its bulk update
+        double colPrev[kNB];
+        if (j >= 1) {
 #pragma unroll
-        for (int c = 0; c < j; ++c) v -= row[c] * sA[j][c];  // row j of L is final for c < j (LDS broadcast read)
-        const double d = __shfl(v, j);
+            for (int c = j + kLA; c < kNB; ++c) colPrev[c] = sLT[j - 1][c];
+        }
+        // (2) pivot chain of column j while those reads are in flight
+        const double d = readlane64(row[j], j);
         if (!(d > 0.0)) *bad = 1;
-        const double rd = rsqrt(d);
-        const double lj = (lane == j) ? d * rd : v * rd;
-        row[j] = lj;
-        if (lane >= j && lane < kNB) sA[lane][j] = lj;
+        const double rd = rsqrtPivot(d);
+        const double lj = row[j] * rd;  // lane j: sqrt(d); lanes > j: L[lane][j]
+#pragma unroll
+        for (int q = 1; q <= kLA; ++q)
+            if (j + q < kNB) row[j + q] = fma(-lj, readlane64(lj, j + q), row[j + q]);
+        // (3) bulk rank-1 update with column j-1
+        if (j >= 1) {
+#pragma unroll
+            for (int c = j + kLA; c < kNB; ++c) row[c] = fma(-ljPrev, colPrev[c], row[c]);
+        }
+        // (4) publish column j
+        if (lane < kNB) sLT[j][lane] = lj;
         if (lane == j) sRd[j] = rd;
-        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ljPrev = lj;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // Pin the updated row here: hipcc otherwise sinks every rank-1 update to the point where the element is
+        // consumed, which re-creates one long dependent FMA chain in front of each pivot.
+#pragma unroll
+        for (int c = j + 1; c < kNB; ++c) __asm__ volatile("" : "+v"(row[c]));
+#endif
     }
 }
-// Forward substitution with the LDS-resident L (sA lower, sRd = 1/diag): solves L x = b for one vector
-// per lane (b in x[]).  Used both for rows of A_rk (x L^T = a) and for columns of W_k (L y = w).
-EQF_DI void fwdsub32(const double (*sA)[kLdsP], const double* sRd, double* x) {
+// Forward substitution with L^T in LDS (sLT[j][c] = L[c][j]) and sRd = 1/diag: solves L x = b for one vector per
+// lane (b in x[]), right-looking: the FMAs of one column are independent and read contiguous L values.
+// Used both for rows of A_rk (x L^T = a) and for columns of W_k (L y = w).
+EQF_DI void fwdsub32(const double (*sLT)[kLtP], const double* sRd, double* x) {
 #pragma unroll
     for (int j = 0; j < kNB; ++j) {
-        double v = x[j];
+        const double xj = x[j] * sRd[j];
+        x[j] = xj;
 #pragma unroll
-        for (int c = 0; c < j; ++c) v -= x[c] * sA[j][c];
-        x[j] = v * sRd[j];
+        for (int c = j + 1; c < kNB; ++c) x[c] = fma(-xj, sLT[j][c], x[c]);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int c = j + 1; c < kNB; ++c) __asm__ volatile("" : "+v"(x[c]));
+#endif
     }
 }
 
@@ -322,6 +377,7 @@ struct ChainArgs {
     int kind;     // 0: S-chain, 1: E-chain
     int nbMax;    // tiles per edge launched for A
     int wtMax;    // right-hand-side column tiles launched
+    int dbg;      // development only: bit0 skip potrf, bit1 skip panel solves, bit2 skip tile update, bit3 skip loads
 };
 
 // per-filter chain sizes
@@ -366,13 +422,22 @@ __global__ __launch_bounds__(256) void k_chol_step(ChainArgs c0, ChainArgs c1, i
     const int ldA = ch.ldA, ldW = ch.ldW;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-    __shared__ double sK[kNB][kLdsP];   // A_kk -> L_kk
+    __shared__ double sK[kNB][kLdsP];   // A_kk
+    __shared__ __attribute__((aligned(16))) double sLT[kNB][kLtP];  // L_kk^T
     __shared__ double sP[kNB][kLdsP];   // A_rk rows -> L_rk      (A tiles) / W_k -> Y_k (W tiles)
     __shared__ double sQ[kNB][kLdsP];   // A_ck rows -> L_ck
     __shared__ double sRd[kNB];
     int bad = 0;
 
     // ---- load A_kk (lower part is enough), and the panel blocks this tile needs
+    if (ch.dbg & 8) {
+        for (int e = tid; e < kNB * kNB; e += 256) {
+            const int rr = e / kNB, cc = e % kNB;
+            sK[rr][cc] = rr == cc ? 4.0 : 0.0;
+            sP[rr][cc] = 1.0;
+            sQ[rr][cc] = 1.0;
+        }
+    } else
     for (int e = tid; e < kNB * kNB; e += 256) {
         const int rr = e / kNB, cc = e % kNB;
         sK[rr][cc] = A[(long long)(k * kNB + rr) * ldA + k * kNB + cc];
@@ -384,7 +449,7 @@ __global__ __launch_bounds__(256) void k_chol_step(ChainArgs c0, ChainArgs c1, i
         if (c > k) sQ[rr][cc] = A[(long long)(c * kNB + rr) * ldA + k * kNB + cc];
     }
     __syncthreads();
-    if (wv == 0) potrf32(sK, sRd, lane, &bad);
+    if (wv == 0 && !(ch.dbg & 1)) potrf32(sK, sLT, sRd, lane, &bad);
     __syncthreads();
     // ---- panel solves: one lane per vector.  wave 0: lanes 0..31 -> sP, lanes 32..63 -> sQ
     if (wv == 0) {
@@ -392,7 +457,7 @@ __global__ __launch_bounds__(256) void k_chol_step(ChainArgs c0, ChainArgs c1, i
         const bool second_half = lane >= 32;
         const bool doP = !second_half && (isW || r > k);
         const bool doQ = second_half && (c > k);
-        if (doP || doQ) {
+        if ((doP || doQ) && !(ch.dbg & 2)) {
             double x[kNB];
             if (doQ) {
 #pragma unroll
@@ -404,7 +469,7 @@ __global__ __launch_bounds__(256) void k_chol_step(ChainArgs c0, ChainArgs c1, i
 #pragma unroll
                 for (int j = 0; j < kNB; ++j) x[j] = sP[v][j];  // row v of A_rk
             }
-            fwdsub32(sK, sRd, x);
+            fwdsub32(sLT, sRd, x);
             if (doQ) {
 #pragma unroll
                 for (int j = 0; j < kNB; ++j) sQ[v][j] = x[j];
@@ -425,12 +490,12 @@ __global__ __launch_bounds__(256) void k_chol_step(ChainArgs c0, ChainArgs c1, i
             if (isW) {
                 WO[(long long)(k * kNB + rr) * ldW + r * kNB + cc] = sP[rr][cc];
             } else if (r == k) {
-                L[(long long)(k * kNB + rr) * ldA + k * kNB + cc] = (cc <= rr) ? sK[rr][cc] : 0.0;
+                L[(long long)(k * kNB + rr) * ldA + k * kNB + cc] = (cc <= rr) ? sLT[cc][rr] : 0.0;
             } else {
                 L[(long long)(r * kNB + rr) * ldA + k * kNB + cc] = sP[rr][cc];
             }
         }
-    } else {
+    } else if (!(ch.dbg & 4)) {
         // ---- trailing update of this tile with v_mfma_f64_16x16x4_f64: wave w owns the 16x16 sub-tile (w>>1, w&1)
         const int tm = wv >> 1, tn = wv & 1;
         const int lr = lane & 15, lk = lane >> 4;
