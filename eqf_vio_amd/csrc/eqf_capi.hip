@@ -229,6 +229,10 @@ int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, con
     a.NT = std::max(1, (maxN(f) + kTileLm - 1) / kTileLm);
     a.isImu = isImu ? 1 : 0;
     a.doRiccati = doRiccati ? 1 : 0;
+    {
+        static const int dbg = std::getenv("EQF_DEBUG_PROP") ? std::atoi(std::getenv("EQF_DEBUG_PROP")) : 0;
+        a.dbg = dbg;
+    }
     a.prm = f->prm;
     const dim3 grid(a.NT * a.NT, f->B), block(256);
     int rc = profiled(f, EQF_PROF_PROPAGATE, [&] {

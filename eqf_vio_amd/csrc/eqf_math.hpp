@@ -150,13 +150,42 @@ EQF_DI m33 rotFromUnitVectors(d3 o, d3 d, int* bad) {
 }
 EQF_DI quat so3FromVectors(d3 origin, d3 dest, int* bad) { return m2q(rotFromUnitVectors(unit3(origin), unit3(dest), bad)); }
 
-EQF_DI quat so3Exp(d3 w) {  // SO3.cpp:122-140
-    const double th = nrm3(w);
-    double A = 1.0, B = 0.5;
-    if (fabs(th) >= 1e-8) {
-        A = sin(th) / th;
-        B = (1 - cos(th)) / (th * th);
+// Coefficients of the SO(3)/SE(3) exponentials (SO3.cpp:122-140, SE3.cpp:139-164):
+//   A = sin(th)/th,  B = (1-cos th)/th^2,  C = (1-A)/th^2      as functions of t = th^2.
+// For th^2 < 0.25 (every IMU- or innovation-sized increment) they come from their Maclaurin series in t: no sqrt,
+// no sin/cos (fp64 sin/cos cost thousands of cycles on one lane) and no cancellation -- the reference's
+// (1-cos th)/th^2 loses ~1e-16/th^2 relative accuracy for small th; the series is exact to rounding.  Larger angles
+// use the reference's closed forms.
+EQF_DI void expCoefficients(double t, double* A, double* B, double* C) {
+    if (t < 0.25) {
+        // A = sum (-t)^k/(2k+1)!,  B = sum (-t)^k/(2k+2)!,  C = sum (-t)^k/(2k+3)!   (k = 0..9: remainder < 1e-20)
+        double a = 1.0 / 121645100408832000.0, b = 1.0 / 2432902008176640000.0, c = 1.0 / 51090942171709440000.0;
+        const double ia[9] = {1.0 / 355687428096000.0, 1.0 / 1307674368000.0, 1.0 / 6227020800.0, 1.0 / 39916800.0,
+            1.0 / 362880.0, 1.0 / 5040.0, 1.0 / 120.0, 1.0 / 6.0, 1.0};
+        const double ib[9] = {1.0 / 6402373705728000.0, 1.0 / 20922789888000.0, 1.0 / 87178291200.0, 1.0 / 479001600.0,
+            1.0 / 3628800.0, 1.0 / 40320.0, 1.0 / 720.0, 1.0 / 24.0, 0.5};
+        const double ic[9] = {1.0 / 121645100408832000.0, 1.0 / 355687428096000.0, 1.0 / 1307674368000.0, 1.0 / 6227020800.0,
+            1.0 / 39916800.0, 1.0 / 362880.0, 1.0 / 5040.0, 1.0 / 120.0, 1.0 / 6.0};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            a = ia[k] - t * a;
+            b = ib[k] - t * b;
+            c = ic[k] - t * c;
+        }
+        *A = a;
+        *B = b;
+        *C = c;
+    } else {
+        const double th = sqrt(t);
+        *A = sin(th) / th;
+        *B = (1 - cos(th)) / t;
+        *C = (1 - *A) / t;
     }
+}
+
+EQF_DI quat so3Exp(d3 w) {  // SO3.cpp:122-140
+    double A, B, C;
+    expCoefficients(dot3(w, w), &A, &B, &C);
     const m33 wx = skew3(w);
     return m2q(add33(eye3(), add33(scl33(A, wx), scl33(B, mul33(wx, wx)))));
 }
@@ -172,13 +201,8 @@ EQF_DI se3 se3inv(se3 a) {                                                      
 }
 EQF_DI d3 se3app(se3 a, d3 p) { return add(qrot(a.q, p), a.x); }  // SE3.cpp:63
 EQF_DI se3 se3Exp(d3 w, d3 v) {                                      // SE3.cpp:139-164
-    const double th = nrm3(w);
-    double A = 1.0, B = 0.5, C = 1.0 / 6.0;
-    if (fabs(th) >= 1e-12) {
-        A = sin(th) / th;
-        B = (1 - cos(th)) / (th * th);
-        C = (1 - A) / (th * th);
-    }
+    double A, B, C;
+    expCoefficients(dot3(w, w), &A, &B, &C);
     const m33 wx = skew3(w);
     const m33 wx2 = mul33(wx, wx);
     const m33 R = add33(eye3(), add33(scl33(A, wx), scl33(B, wx2)));

@@ -35,6 +35,7 @@ struct PropArgs {
     int cap, ld, NT;
     int isImu;      // processIMUData (bias subtraction, lazy init, ZOH bookkeeping)
     int doRiccati;  // VIOFilter.cpp:160
+    int dbg;        // development only: bit0 skip common+blocks, bit1 skip landmark step, bit2 skip scalar step, bit3 skip Sigma math
     Params prm;
 };
 
@@ -65,8 +66,14 @@ EQF_DI void poseConstants(quat P0q, double* eta0, double* cDiff, double* cInv, i
     stereoChartInvDiffAtZero(e, cInv, bad);
 }
 
-// The per-step scalar chain.  G is the (read-only) current state; for a vision call only r.stamp is used.
-EQF_DI void stepCommon(const Glob& G, const ImuRec& r, const PropArgs& a, StepCommon& c, int* bad) {
+// The per-step scalar chain, in three independently computable parts so that three wavefronts (three SIMDs) can
+// run them side by side: a lone wavefront retires one fp64 operation per ~6 cycles whatever the dependencies.
+//   kPartBase  dt, T, ZOH sample, mean rate, R_A, vhat, etahat      (everyone)
+//   kPartRicc  v_C, camera-offset matrices, B / A0 base blocks     (wave 0: linearisation blocks, F_bb)
+//   kPartLift  Ad(T_IC^-1)(w_cur, vhat), SE3Exp(-dt U_C)            (the landmark group step)
+constexpr int kPartBase = 1, kPartRicc = 2, kPartLift = 4;
+// G is the (read-only) current state; for a vision call only r.stamp is used.
+EQF_DI void stepCommon(const Glob& G, const ImuRec& r, const PropArgs& a, StepCommon& c, int parts, int* bad) {
     const Params& p = a.prm;
     c.dt = r.stamp - G.curTime;
     c.step = (G.curTime >= 0) && (c.dt > 0);  // VIOFilter.cpp:147-152
@@ -78,10 +85,9 @@ EQF_DI void stepCommon(const Glob& G, const ImuRec& r, const PropArgs& a, StepCo
     const double invT = 1.0 / c.T;
     c.wbar = mk3((G.accVel[0] + c.wcur.x * c.dt) * invT, (G.accVel[1] + c.wcur.y * c.dt) * invT,
         (G.accVel[2] + c.wcur.z * c.dt) * invT);
-    const quat Aq = quat{G.Aq[0], G.Aq[1], G.Aq[2], G.Aq[3]};
-    const quat Aqi = qinv(Aq);
-    c.RA = q2m(Aq);
-    c.vhat = qrot(Aqi, mk3(G.v0[0] - G.w[0], G.v0[1] - G.w[1], G.v0[2] - G.w[2]));  // VIOGroup.cpp:26
+    c.RA = q2m(quat{G.Aq[0], G.Aq[1], G.Aq[2], G.Aq[3]});
+    // X.A.R().inverse() * v (VIOGroup.cpp:26,49): R_A^T v with the matrix already at hand
+    c.vhat = mtv33(c.RA, mk3(G.v0[0] - G.w[0], G.v0[1] - G.w[1], G.v0[2] - G.w[2]));
     // constants of the origin pose: cached at initialisation; recomputed only in the (reset) corner case where a
     // step happens in the very call that initialises the pose
     double eta0[3], cDiff[6], cInv[6];
@@ -99,38 +105,43 @@ EQF_DI void stepCommon(const Glob& G, const ImuRec& r, const PropArgs& a, StepCo
             P0q = so3FromVectors(mk3(r.a[0] - G.bias[3], r.a[1] - G.bias[4], r.a[2] - G.bias[5]), mk3(0, 0, 1), bad);
         poseConstants(P0q, eta0, cDiff, cInv, bad);
     }
-    c.etahat = qrot(Aqi, mk3(eta0[0], eta0[1], eta0[2]));  // VIOGroup.cpp:49
-    // Ad(T_IC^-1) (w, v) = (R w ; x^ R w + R v) with the host-precomputed inverse camera offset
-    m33 RcI;
+    c.etahat = mtv33(c.RA, mk3(eta0[0], eta0[1], eta0[2]));
+    if (parts & (kPartRicc | kPartLift)) {
+        // Ad(T_IC^-1) (w, v) = (R w ; x^ R w + R v) with the host-precomputed inverse camera offset
+        m33 RcI;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        RcI.a[i] = p.RcamI[i];
-        c.RIC.a[i] = p.RIC[i];
-        c.RICt.a[i] = p.RICt[i];
+        for (int i = 0; i < 9; ++i) RcI.a[i] = p.RcamI[i];
+        const d3 xcI = mk3(p.camIx[0], p.camIx[1], p.camIx[2]);
+        const d3 Rv = mv33(RcI, c.vhat);
+        if (parts & kPartRicc) {
+            const d3 Rw = mv33(RcI, c.wbar);
+            c.vC = add(crs(xcI, Rw), Rv);
+        }
+        if (parts & kPartLift) {
+            const d3 Rw = mv33(RcI, c.wcur);
+            c.oCcur = Rw;
+            c.vCcur = add(crs(xcI, Rw), Rv);
+            if (p.useDiscreteVelocityLift) c.camInv = se3Exp(scl(-c.dt, c.oCcur), scl(-c.dt, c.vCcur));
+        }
     }
-    const d3 xcI = mk3(p.camIx[0], p.camIx[1], p.camIx[2]);
-    const d3 Rv = mv33(RcI, c.vhat);
-    {
-        const d3 Rw = mv33(RcI, c.wbar);
-        c.vC = add(crs(xcI, Rw), Rv);
-    }
-    {
-        const d3 Rw = mv33(RcI, c.wcur);
-        c.oCcur = Rw;
-        c.vCcur = add(crs(xcI, Rw), Rv);
-    }
-    if (p.useDiscreteVelocityLift) c.camInv = se3Exp(scl(-c.dt, c.oCcur), scl(-c.dt, c.vCcur));
-    c.xIC = mk3(p.camx[0], p.camx[1], p.camx[2]);
-    if (a.doRiccati) {
-        const m33 RAg = mul33(c.RA, skew3(c.etahat));
+    if (parts & kPartRicc) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 9; ++i) {
+            c.RIC.a[i] = p.RIC[i];
+            c.RICt.a[i] = p.RICt[i];
+        }
+        c.xIC = mk3(p.camx[0], p.camx[1], p.camx[2]);
+        if (a.doRiccati) {
+            const m33 RAg = mul33(c.RA, skew3(c.etahat));
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-                c.Bg[3 * i + j] = cDiff[3 * i] * RAg.a[j] + cDiff[3 * i + 1] * RAg.a[3 + j] + cDiff[3 * i + 2] * RAg.a[6 + j];
-        c.Bvw = mul33(c.RA, skew3(c.vhat));
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) c.Avg[i] = -kGravity * cInv[i];
+                for (int j = 0; j < 3; ++j)
+                    c.Bg[3 * i + j] = cDiff[3 * i] * RAg.a[j] + cDiff[3 * i + 1] * RAg.a[3 + j] + cDiff[3 * i + 2] * RAg.a[6 + j];
+            c.Bvw = mul33(c.RA, skew3(c.vhat));
+#pragma unroll
+            for (int i = 0; i < 6; ++i) c.Avg[i] = -kGravity * cInv[i];
+        }
     }
 }
 
@@ -175,28 +186,37 @@ EQF_DI void stepLandmark(const StepCommon& c, const PropArgs& a, quat Qq, double
 }
 
 // Scalar part of the step, one lane per filter: lazy initialisation, X.A, X.w, ZOH bookkeeping.
+// `out` already holds a copy of G (made word-parallel by the calling wave); only changed fields are written, so no
+// private Glob copy (which hipcc would place in scratch) is needed.
 EQF_DI void stepGlobal(const Glob& G, Glob* out, const ImuRec& r, const PropArgs& a, const StepCommon& c, int* bad) {
-    Glob g = G;
     d3 unbW = mk3(0, 0, 0), unbA = mk3(0, 0, 0);
     if (a.isImu) {  // VIOFilter.cpp:121-124
         unbW = mk3(r.w[0] - G.bias[0], r.w[1] - G.bias[1], r.w[2] - G.bias[2]);
         unbA = mk3(r.a[0] - G.bias[3], r.a[1] - G.bias[4], r.a[2] - G.bias[5]);
         if (!G.initialised) {  // initialiseFromIMUData, VIOFilter.cpp:133-144
             const quat q0 = so3FromVectors(unbA, mk3(0, 0, 1), bad);
-            g.P0q[0] = q0.w; g.P0q[1] = q0.x; g.P0q[2] = q0.y; g.P0q[3] = q0.z;
-            g.P0x[0] = g.P0x[1] = g.P0x[2] = 0;
-            g.v0[0] = g.v0[1] = g.v0[2] = 0;
-            g.initialised = 1;
+            out->P0q[0] = q0.w; out->P0q[1] = q0.x; out->P0q[2] = q0.y; out->P0q[3] = q0.z;
+            out->P0x[0] = out->P0x[1] = out->P0x[2] = 0;
+            out->v0[0] = out->v0[1] = out->v0[2] = 0;
+            out->initialised = 1;
             // NB: a level start (accel along +z) makes the gravity chart singular; the reference then throws from
             // the first Riccati step (SO3.cpp:160).  The flag raised here is sticky (eqf_device_error).
-            poseConstants(q0, g.eta0, g.cDiff, g.cInv, bad);
+            double e0[3], cd[6], ci[6];
+            poseConstants(q0, e0, cd, ci, bad);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) out->eta0[i] = e0[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                out->cDiff[i] = cd[i];
+                out->cInv[i] = ci[i];
+            }
         }
     }
     if (c.step) {
         // VIOFilter.cpp:154-155, :192-193
-        g.accTime = a.doRiccati ? 0.0 : c.T;
+        out->accTime = a.doRiccati ? 0.0 : c.T;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) g.accVel[i] = a.doRiccati ? 0.0 : G.accVel[i] + G.curVel[i] * c.dt;
+        for (int i = 0; i < 6; ++i) out->accVel[i] = a.doRiccati ? 0.0 : G.accVel[i] + G.curVel[i] * c.dt;
         const se3 lA = se3Exp(scl(c.dt, c.wcur), scl(c.dt, c.vhat));  // VIOGroup.cpp:214-217 / :182-185 + :247
         d3 lw;
         if (a.prm.useDiscreteVelocityLift) {  // VIOGroup.cpp:219-222
@@ -208,19 +228,18 @@ EQF_DI void stepGlobal(const Glob& G, Glob* out, const ImuRec& r, const PropArgs
         const se3 A = se3{quat{G.Aq[0], G.Aq[1], G.Aq[2], G.Aq[3]}, mk3(G.Ax[0], G.Ax[1], G.Ax[2])};
         const se3 An = se3mul(A, lA);                                      // VIOGroup.cpp:95
         const d3 wn = add(mk3(G.w[0], G.w[1], G.w[2]), qrot(A.q, lw));     // :96
-        g.Aq[0] = An.q.w; g.Aq[1] = An.q.x; g.Aq[2] = An.q.y; g.Aq[3] = An.q.z;
-        g.Ax[0] = An.x.x; g.Ax[1] = An.x.y; g.Ax[2] = An.x.z;
-        g.w[0] = wn.x; g.w[1] = wn.y; g.w[2] = wn.z;
-        g.curTime = r.stamp;  // :207
+        out->Aq[0] = An.q.w; out->Aq[1] = An.q.x; out->Aq[2] = An.q.y; out->Aq[3] = An.q.z;
+        out->Ax[0] = An.x.x; out->Ax[1] = An.x.y; out->Ax[2] = An.x.z;
+        out->w[0] = wn.x; out->w[1] = wn.y; out->w[2] = wn.z;
+        out->curTime = r.stamp;  // :207
     }
     if (a.isImu) {  // VIOFilter.cpp:129-130
-        g.curVel[0] = unbW.x; g.curVel[1] = unbW.y; g.curVel[2] = unbW.z;
-        g.curVel[3] = unbA.x; g.curVel[4] = unbA.y; g.curVel[5] = unbA.z;
-        g.curTime = r.stamp;
+        out->curVel[0] = unbW.x; out->curVel[1] = unbW.y; out->curVel[2] = unbW.z;
+        out->curVel[3] = unbA.x; out->curVel[4] = unbA.y; out->curVel[5] = unbA.z;
+        out->curTime = r.stamp;
     } else {
-        g.updateOk = (c.step && G.initialised) ? 1 : 0;  // VIOFilter.cpp:234-236
+        out->updateOk = (c.step && G.initialised) ? 1 : 0;  // VIOFilter.cpp:234-236
     }
-    *out = g;
 }
 
 // LDS image of the few common values the base-panel code of waves 1..3 needs
@@ -264,56 +283,72 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     const int I0 = ti * kTileLm, J0 = tj * kTileLm;
     int bad = 0;
 
-    if (tid < 64) {
-        // ---- wave 0 owns the scalar chain: common quantities, this tile's linearisation blocks, group step
+    const int wv = tid >> 6, ln = tid & 63;
+    if (wv == 0 && riccati && !(a.dbg & 1)) {
+        // ---- wave 0: common quantities of the linearisation + this tile's per-landmark blocks
         StepCommon c;
-        c.step = 0;
-        const bool needCommon = step && (riccati || ti == tj || blockIdx.x == 0);
-        if (needCommon) stepCommon(G, r, a, c, &bad);
-        if (riccati) {
-            if (tid < 32) {
-                const int i = (tid < 16) ? I0 + tid : J0 + tid - 16;
-                if (i < N) {
-                    const quat Qq = quat{Qin[i], Qin[cap + i], Qin[2 * cap + i], Qin[3 * cap + i]};
-                    const LmBlocks blk = buildBlocks(c, Qq, Qin[4 * cap + i], mk3(p0[i], p0[cap + i], p0[2 * cap + i]));
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) {
-                        sD[tid][k] = (T)blk.D.a[k];
-                        sLw[tid][k] = (T)blk.Lw.a[k];
-                        sLv[tid][k] = (T)blk.Lv.a[k];
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) sD[tid][k] = sLw[tid][k] = sLv[tid][k] = (T)0;
-                }
-            }
-            if (tid == 32) {
-                sC.T = c.T;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    sC.Bg[k] = c.Bg[k];
-                    sC.Avg[k] = c.Avg[k];
-                }
+        stepCommon(G, r, a, c, kPartBase | kPartRicc, &bad);
+        if (ln < 32) {
+            const int i = (ln < 16) ? I0 + ln : J0 + ln - 16;
+            if (i < N) {
+                const quat Qq = quat{Qin[i], Qin[cap + i], Qin[2 * cap + i], Qin[3 * cap + i]};
+                const LmBlocks blk = buildBlocks(c, Qq, Qin[4 * cap + i], mk3(p0[i], p0[cap + i], p0[2 * cap + i]));
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
-                    sC.Bvw[k] = c.Bvw.a[k];
-                    sC.RA[k] = c.RA.a[k];
+                    sD[ln][k] = (T)blk.D.a[k];
+                    sLw[ln][k] = (T)blk.Lw.a[k];
+                    sLv[ln][k] = (T)blk.Lv.a[k];
                 }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) sD[ln][k] = sLw[ln][k] = sLv[ln][k] = (T)0;
             }
         }
-        if (ti == tj && tid < kTileLm) {
-            const int i = I0 + tid;
+        if (ln == 32) {
+            sC.T = c.T;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                sC.Bg[k] = c.Bg[k];
+                sC.Avg[k] = c.Avg[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                sC.Bvw[k] = c.Bvw.a[k];
+                sC.RA[k] = c.RA.a[k];
+            }
+        }
+    }
+    if (wv == 1 && ti == tj) {
+        // ---- wave 1 of the diagonal tiles: group step of the tile's landmarks
+        if (ln < kTileLm) {
+            const int i = I0 + ln;
             if (i < N) {
                 const quat Qq = quat{Qin[i], Qin[cap + i], Qin[2 * cap + i], Qin[3 * cap + i]};
                 const double Qa = Qin[4 * cap + i];
                 quat Qo = Qq;
                 double ao = Qa;
-                if (step) stepLandmark(c, a, Qq, Qa, mk3(p0[i], p0[cap + i], p0[2 * cap + i]), &Qo, &ao, &bad);
+                if (step && !(a.dbg & 2)) {
+                    StepCommon c;
+                    stepCommon(G, r, a, c, kPartBase | kPartLift, &bad);
+                    stepLandmark(c, a, Qq, Qa, mk3(p0[i], p0[cap + i], p0[2 * cap + i]), &Qo, &ao, &bad);
+                }
                 Qout[i] = Qo.w; Qout[cap + i] = Qo.x; Qout[2 * cap + i] = Qo.y; Qout[3 * cap + i] = Qo.z;
                 Qout[4 * cap + i] = ao;
             }
         }
-        if (blockIdx.x == 0 && tid == 48) stepGlobal(G, a.gout + b, r, a, c, &bad);
+    }
+    if (wv == 2 && blockIdx.x == 0) {
+        // ---- wave 2 of workgroup 0: scalar state.  Word-parallel copy in -> out, then one lane patches the changed fields
+        static_assert(sizeof(Glob) % 8 == 0 && sizeof(Glob) / 8 <= 64, "Glob copy is one word per lane");
+        const double* src = reinterpret_cast<const double*>(&G);
+        double* dst = reinterpret_cast<double*>(a.gout + b);
+        if (ln < (int)(sizeof(Glob) / 8)) dst[ln] = src[ln];
+        if (ln == 0 && !(a.dbg & 4)) {
+            StepCommon c;
+            c.step = 0;
+            if (step) stepCommon(G, r, a, c, kPartBase, &bad);
+            stepGlobal(G, a.gout + b, r, a, c, &bad);
+        }
     }
 
     if (!riccati) {
@@ -369,6 +404,7 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
             for (int cc = 0; cc < 3; ++cc) S[3 * rr + cc] = src[(long long)rr * ld + cc];
     }
     __syncthreads();
+    if (a.dbg & 8) return;
     if (tid < 132) {
         const int rr = tid / 12, cc = tid % 12;
         // F_bb = I + T * [[0,0,0,0],[-B_g^w,0,0,0],[-B_v^w,-R_A, A_vg, 0]]   (VIOFilter.cpp:178-183)
