@@ -309,11 +309,11 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     if (rc) return rc;
     // chains
     ChainArgs cS{}, cE{};
-    cS.g = a.g; cS.A = f->SA; cS.L = f->SL; cS.W = f->YW; cS.WO = f->YO;
-    cS.ldA = f->ldS; cS.ldW = f->ldY; cS.strideA = f->strideS; cS.strideW = f->strideY;
+    cS.g = a.g; cS.A = f->SA; cS.D = f->SL; cS.W = f->YW; cS.WO = f->YO;
+    cS.ldA = f->ldS; cS.ldW = f->ldY; cS.strideA = f->strideS; cS.strideD = f->strideS; cS.strideW = f->strideY;
     cS.kind = 0; cS.nbMax = mp / kNB; cS.wtMax = roundUp(yCols(Nmax), kNB) / kNB;
-    cE.g = a.g; cE.A = f->EA; cE.L = f->EL; cE.W = f->ZW; cE.WO = f->ZO;
-    cE.ldA = f->ldE; cE.ldW = f->ldZ; cE.strideA = f->strideE; cE.strideW = f->strideZ;
+    cE.g = a.g; cE.A = f->EA; cE.D = f->EL; cE.W = f->ZW; cE.WO = f->ZO;
+    cE.ldA = f->ldE; cE.ldW = f->ldZ; cE.strideA = f->strideE; cE.strideD = f->strideE; cE.strideW = f->strideZ;
     cE.kind = 1; cE.nbMax = nep / kNB; cE.wtMax = 1;
     {
         static const int dbg = std::getenv("EQF_DEBUG_CHOL") ? std::atoi(std::getenv("EQF_DEBUG_CHOL")) : 0;

@@ -371,13 +371,13 @@ EQF_DI void fwdsub32(const double (*sLT)[kLtP], const double* sRd, double* x) {
 
 struct ChainArgs {
     Glob* g;
-    double *A, *L, *W, *WO;
+    double *A, *D, *W, *WO;   // work matrix, diagonal factors [nb][2][32][32] (L_kk, inv L_kk), rhs work, rhs solved
     int ldA, ldW;
-    long long strideA, strideW;
+    long long strideA, strideD, strideW;
     int kind;     // 0: S-chain, 1: E-chain
     int nbMax;    // tiles per edge launched for A
     int wtMax;    // right-hand-side column tiles launched
-    int dbg;      // development only: bit0 skip potrf, bit1 skip panel solves, bit2 skip tile update, bit3 skip loads
+    int dbg;
 };
 
 // per-filter chain sizes
@@ -391,6 +391,32 @@ EQF_DI void chainDims(const ChainArgs& ch, int N, int* nb, int* wt) {
     }
 }
 
+// 32x32x32 product on v_mfma_f64_16x16x4_f64, one 16x16 quadrant (tm, tn) per wave, operands in LDS.
+//   NT: acc += sgn * P Q^T      NN: acc += sgn * P Q
+template <bool NT>
+EQF_DI f64x4 mm32(f64x4 acc, const double (*P)[kLdsP], const double (*Q)[kLdsP], int tm, int tn, int lane, double sgn) {
+    const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < kNB / 4; ++s) {
+        const double av = sgn * P[16 * tm + lr][4 * s + lk];
+        const double bv = NT ? Q[16 * tn + lr][4 * s + lk] : Q[4 * s + lk][16 * tn + lr];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+    return acc;
+}
+// accumulator quadrant (C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg) <-> LDS / global
+EQF_DI void accToLds(const f64x4& acc, double (*M)[kLdsP], int tm, int tn, int lane) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) M[16 * tm + (lane >> 4) + 4 * q][16 * tn + (lane & 15)] = acc[q];
+}
+
+// Blocked right-looking Cholesky with right-hand sides and one-step look-ahead; one launch per block column k,
+// both chains in the same launch.  Entering launch k, D[k] holds L_kk and W_k = L_kk^-1 (from launch k-1's
+// diagonal workgroup; at k = 0 every workgroup derives them itself), so the panel blocks are plain products
+//   L_rk = A_rk W_k^T,  Y_k = W_k R_k           (v_mfma_f64_16x16x4_f64)
+// and only ONE workgroup per chain runs the serial 32x32 factorisation, for the NEXT column:
+//   tile (r,c), r >= c > k :  A_rc -= L_rk L_ck^T ; if r == c == k+1: potrf + inverse of the updated tile -> D[k+1]
+//   rhs tile (t,c), c == k :  Y_k -> WO ;            c > k: R_c -= L_ck Y_k
 __global__ __launch_bounds__(256) void k_chol_step(ChainArgs c0, ChainArgs c1, int k, int* errflag) {
     const int b = blockIdx.y;
     const int n0 = c0.nbMax * c0.nbMax + c0.wtMax * c0.nbMax;
@@ -403,11 +429,11 @@ __global__ __launch_bounds__(256) void k_chol_step(ChainArgs c0, ChainArgs c1, i
     chainDims(ch, g.N, &nb, &wt);
     if (k >= nb) return;
     bool isW = false;
-    int r, c;  // A tile (r,c) or W tile (t = r, c)
+    int r, c;  // A tile (r,c) or rhs tile (t = r, c)
     if (idx < ch.nbMax * ch.nbMax) {
         r = idx / ch.nbMax;
         c = idx % ch.nbMax;
-        if (r >= nb || c > r || c < k) return;
+        if (r >= nb || c > r || c <= k) return;  // the panel column itself needs no workgroup any more
     } else {
         idx -= ch.nbMax * ch.nbMax;
         isW = true;
@@ -416,115 +442,96 @@ __global__ __launch_bounds__(256) void k_chol_step(ChainArgs c0, ChainArgs c1, i
         if (r >= wt || c >= nb || c < k) return;
     }
     double* A = ch.A + (long long)b * ch.strideA;
-    double* L = ch.L + (long long)b * ch.strideA;
+    double* D = ch.D + (long long)b * ch.strideD;
     double* W = ch.W + (long long)b * ch.strideW;
     double* WO = ch.WO + (long long)b * ch.strideW;
     const int ldA = ch.ldA, ldW = ch.ldW;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tm = wv >> 1, tn = wv & 1;
 
-    __shared__ double sK[kNB][kLdsP];   // A_kk
-    __shared__ __attribute__((aligned(16))) double sLT[kNB][kLtP];  // L_kk^T
-    __shared__ double sP[kNB][kLdsP];   // A_rk rows -> L_rk      (A tiles) / W_k -> Y_k (W tiles)
-    __shared__ double sQ[kNB][kLdsP];   // A_ck rows -> L_ck
+    __shared__ double sWk[kNB][kLdsP];  // W_k = L_kk^-1
+    __shared__ double sP[kNB][kLdsP];   // A_rk -> L_rk   (A tiles)   /  R_k -> Y_k (rhs tiles)
+    __shared__ double sQ[kNB][kLdsP];   // A_ck -> L_ck
+    __shared__ __attribute__((aligned(16))) double sLT[kNB][kLtP];
     __shared__ double sRd[kNB];
     int bad = 0;
+    const bool diagNext = !isW && r == c && c == k + 1;  // this workgroup factors the next diagonal block
+    const bool needQ = c > k;
 
-    // ---- load A_kk (lower part is enough), and the panel blocks this tile needs
-    if (ch.dbg & 8) {
-        for (int e = tid; e < kNB * kNB; e += 256) {
-            const int rr = e / kNB, cc = e % kNB;
-            sK[rr][cc] = rr == cc ? 4.0 : 0.0;
-            sP[rr][cc] = 1.0;
-            sQ[rr][cc] = 1.0;
-        }
-    } else
+    // ---- operands
     for (int e = tid; e < kNB * kNB; e += 256) {
         const int rr = e / kNB, cc = e % kNB;
-        sK[rr][cc] = A[(long long)(k * kNB + rr) * ldA + k * kNB + cc];
-        if (!isW) {
-            if (r > k) sP[rr][cc] = A[(long long)(r * kNB + rr) * ldA + k * kNB + cc];
-        } else {
-            sP[rr][cc] = W[(long long)(k * kNB + rr) * ldW + r * kNB + cc];
-        }
-        if (c > k) sQ[rr][cc] = A[(long long)(c * kNB + rr) * ldA + k * kNB + cc];
+        if (k == 0) sWk[rr][cc] = A[(long long)rr * ldA + cc];  // A_00: factored below by every workgroup
+        else sWk[rr][cc] = D[((long long)k * 2 + 1) * kNB * kNB + rr * kNB + cc];
+        if (isW) sP[rr][cc] = W[(long long)(k * kNB + rr) * ldW + r * kNB + cc];
+        else if (r != c) sP[rr][cc] = A[(long long)(r * kNB + rr) * ldA + k * kNB + cc];
+        if (needQ) sQ[rr][cc] = A[(long long)(c * kNB + rr) * ldA + k * kNB + cc];
     }
     __syncthreads();
-    if (wv == 0 && !(ch.dbg & 1)) potrf32(sK, sLT, sRd, lane, &bad);
-    __syncthreads();
-    // ---- panel solves: one lane per vector.  wave 0: lanes 0..31 -> sP, lanes 32..63 -> sQ
-    if (wv == 0) {
-        const int v = lane & 31;
-        const bool second_half = lane >= 32;
-        const bool doP = !second_half && (isW || r > k);
-        const bool doQ = second_half && (c > k);
-        if ((doP || doQ) && !(ch.dbg & 2)) {
+    if (k == 0) {
+        // first column: no look-ahead yet, every workgroup factors and inverts A_00 itself
+        if (wv == 0) {
+            potrf32(sWk, sLT, sRd, lane, &bad);
             double x[kNB];
-            if (doQ) {
 #pragma unroll
-                for (int j = 0; j < kNB; ++j) x[j] = sQ[v][j];
-            } else if (isW) {
+            for (int j = 0; j < kNB; ++j) x[j] = ((lane & 31) == j) ? 1.0 : 0.0;
+            fwdsub32(sLT, sRd, x);  // column (lane & 31) of L^-1
+            if (lane < kNB) {
 #pragma unroll
-                for (int j = 0; j < kNB; ++j) x[j] = sP[j][v];  // column v of W_k
-            } else {
-#pragma unroll
-                for (int j = 0; j < kNB; ++j) x[j] = sP[v][j];  // row v of A_rk
-            }
-            fwdsub32(sLT, sRd, x);
-            if (doQ) {
-#pragma unroll
-                for (int j = 0; j < kNB; ++j) sQ[v][j] = x[j];
-            } else if (isW) {
-#pragma unroll
-                for (int j = 0; j < kNB; ++j) sP[j][v] = x[j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < kNB; ++j) sP[v][j] = x[j];
+                for (int j = 0; j < kNB; ++j) sWk[j][lane] = x[j];
             }
         }
+        __syncthreads();
     }
+    // ---- panel blocks by MFMA: L_rk = A_rk W^T, L_ck = A_ck W^T, Y_k = W R_k   (in place, barrier in between)
+    f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+    f64x4 pP = zero, pQ = zero;
+    if (isW) pP = mm32<false>(zero, sWk, sP, tm, tn, lane, 1.0);
+    else if (r != c) pP = mm32<true>(zero, sP, sWk, tm, tn, lane, 1.0);
+    if (needQ) pQ = mm32<true>(zero, sQ, sWk, tm, tn, lane, 1.0);
     __syncthreads();
-    if (c == k) {
-        // ---- panel output
+    if (isW || r != c) accToLds(pP, sP, tm, tn, lane);
+    if (needQ) accToLds(pQ, sQ, tm, tn, lane);
+    __syncthreads();
+
+    if (isW && c == k) {
         for (int e = tid; e < kNB * kNB; e += 256) {
             const int rr = e / kNB, cc = e % kNB;
-            if (isW) {
-                WO[(long long)(k * kNB + rr) * ldW + r * kNB + cc] = sP[rr][cc];
-            } else if (r == k) {
-                L[(long long)(k * kNB + rr) * ldA + k * kNB + cc] = (cc <= rr) ? sLT[cc][rr] : 0.0;
-            } else {
-                L[(long long)(r * kNB + rr) * ldA + k * kNB + cc] = sP[rr][cc];
-            }
+            WO[(long long)(k * kNB + rr) * ldW + r * kNB + cc] = sP[rr][cc];
         }
-    } else if (!(ch.dbg & 4)) {
-        // ---- trailing update of this tile with v_mfma_f64_16x16x4_f64: wave w owns the 16x16 sub-tile (w>>1, w&1)
-        const int tm = wv >> 1, tn = wv & 1;
-        const int lr = lane & 15, lk = lane >> 4;
+    } else {
+        // ---- trailing update of this tile
         double* Ct = isW ? (W + (long long)(c * kNB) * ldW + r * kNB) : (A + (long long)(r * kNB) * ldA + c * kNB);
         const int ldc = isW ? ldW : ldA;
         f64x4 acc;
-        // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = Ct[(long long)(16 * tm + lk + 4 * q) * ldc + 16 * tn + lr];
-        if (!isW) {
-            // A_rc -= L_rk L_ck^T ; for a diagonal tile (r == c) L_rk is sQ as well
-            const double (*P)[kLdsP] = (r == c) ? sQ : sP;
+        for (int q = 0; q < 4; ++q) acc[q] = Ct[(long long)(16 * tm + (lane >> 4) + 4 * q) * ldc + 16 * tn + (lane & 15)];
+        if (isW) acc = mm32<false>(acc, sQ, sP, tm, tn, lane, -1.0);          // R_c -= L_ck Y_k
+        else acc = mm32<true>(acc, (r == c) ? sQ : sP, sQ, tm, tn, lane, -1.0);  // A_rc -= L_rk L_ck^T
+        if (!diagNext) {
 #pragma unroll
-            for (int s = 0; s < kNB / 4; ++s) {
-                const double av = -P[16 * tm + lr][4 * s + lk];
-                const double bv = sQ[16 * tn + lr][4 * s + lk];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-            }
+            for (int q = 0; q < 4; ++q) Ct[(long long)(16 * tm + (lane >> 4) + 4 * q) * ldc + 16 * tn + (lane & 15)] = acc[q];
         } else {
-            // W_c -= L_ck Y_k
+            // ---- look-ahead: factor and invert the freshly updated diagonal block for launch k + 1
+            __syncthreads();
+            accToLds(acc, sP, tm, tn, lane);
+            __syncthreads();
+            if (wv == 0) {
+                potrf32(sP, sLT, sRd, lane, &bad);
+                double x[kNB];
 #pragma unroll
-            for (int s = 0; s < kNB / 4; ++s) {
-                const double av = -sQ[16 * tm + lr][4 * s + lk];
-                const double bv = sP[4 * s + lk][16 * tn + lr];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                for (int j = 0; j < kNB; ++j) x[j] = ((lane & 31) == j) ? 1.0 : 0.0;
+                fwdsub32(sLT, sRd, x);
+                if (lane < kNB) {
+                    double* Dn = D + ((long long)(k + 1) * 2) * kNB * kNB;
+#pragma unroll
+                    for (int j = 0; j < kNB; ++j) {
+                        Dn[kNB * kNB + j * kNB + lane] = x[j];                 // W_{k+1}[j][lane]
+                        Dn[j * kNB + lane] = (lane <= j) ? sLT[lane][j] : 0.0;  // L_{k+1}[j][lane]
+                    }
+                }
             }
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Ct[(long long)(16 * tm + lk + 4 * q) * ldc + 16 * tn + lr] = acc[q];
     }
     if (bad && errflag && tid == 0) atomicOr(errflag, 4);
 }
