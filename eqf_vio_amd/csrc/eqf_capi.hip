@@ -48,6 +48,7 @@ struct eqf_filter {
     void* Sigma[2] = {nullptr, nullptr};
     Glob* g[2] = {nullptr, nullptr};
     double* p0 = nullptr;
+    double* lmc = nullptr;  // [B][15][cap] per-landmark constants (C0i, chart rotation)
     double* Q[2] = {nullptr, nullptr};
     int pS = 0, pG = 0;
     // update chains
@@ -262,6 +263,7 @@ UpdArgs makeUpdArgs(eqf_filter* f, const double* bearings, long long bearStride,
     UpdArgs a{};
     a.g = f->g[f->pG];
     a.p0 = f->p0;
+    a.lmc = f->lmc;
     a.Q = f->Q[f->pG];
     a.Sin = f->Sigma[f->pS];
     a.Sout = f->Sigma[f->pS ^ 1];
@@ -328,7 +330,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     }
     const int colBlocks = (nv + 6 + 63) / 64;
     rc = profiled(f, EQF_PROF_REDUCE,
-        [&] { hipLaunchKernelGGL(k_update_reduce, dim3(colBlocks + 1, B), dim3(256), 0, f->stream, a, colBlocks); });
+        [&] { hipLaunchKernelGGL(k_update_reduce, dim3(colBlocks + 1, B), dim3(1024), 0, f->stream, a, colBlocks); });
     if (rc) return rc;
     rc = profiled(f, EQF_PROF_FINISH, [&] { hipLaunchKernelGGL(k_update_finish, dim3(B), dim3(256), 0, f->stream, a); });
     if (rc) return rc;
@@ -366,8 +368,8 @@ int compact(eqf_filter* f, const std::vector<std::vector<int>>& keep) {
         else
             hipLaunchKernelGGL(k_compact_sigma<double>, grid, dim3(256), 0, f->stream, f->g[f->pG], f->dMap, f->dNewN, cap,
                 static_cast<const double*>(f->Sigma[f->pS]), static_cast<double*>(f->Sigma[f->pS ^ 1]), f->sigmaStride, f->ld);
-        hipLaunchKernelGGL(k_compact_lm_gather, dim3(B), dim3(256), 0, f->stream, f->dMap, f->dNewN, cap, f->p0, f->Q[f->pG], f->dScratch);
-        hipLaunchKernelGGL(k_compact_lm_scatter, dim3(B), dim3(256), 0, f->stream, f->g[f->pG], f->dNewN, cap, f->p0, f->Q[f->pG], f->dScratch);
+        hipLaunchKernelGGL(k_compact_lm_gather, dim3(B), dim3(256), 0, f->stream, f->dMap, f->dNewN, cap, f->p0, f->Q[f->pG], f->lmc, f->dScratch);
+        hipLaunchKernelGGL(k_compact_lm_scatter, dim3(B), dim3(256), 0, f->stream, f->g[f->pG], f->dNewN, cap, f->p0, f->Q[f->pG], f->lmc, f->dScratch);
     });
     if (rc) return rc;
     HIPC(hipGetLastError());
@@ -511,11 +513,11 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
         int rc = profiled(f, EQF_PROF_CHURN, [&] {
             if (f->precision == EQF_PRECISION_F32)
                 hipLaunchKernelGGL(k_append<float>, dim3(std::max(1, blocks)), dim3(256), 0, f->stream, f->g[f->pG], b, nOld, nNew, depth,
-                    f->set.initialPointVariance, cap, bearings + (long long)b * bearStride, f->dSrc, f->p0, f->Q[f->pG],
+                    f->set.initialPointVariance, cap, bearings + (long long)b * bearStride, f->dSrc, f->p0, f->Q[f->pG], f->lmc, f->errflag,
                     static_cast<float*>(f->Sigma[f->pS]), f->sigmaStride, f->ld);
             else
                 hipLaunchKernelGGL(k_append<double>, dim3(std::max(1, blocks)), dim3(256), 0, f->stream, f->g[f->pG], b, nOld, nNew, depth,
-                    f->set.initialPointVariance, cap, bearings + (long long)b * bearStride, f->dSrc, f->p0, f->Q[f->pG],
+                    f->set.initialPointVariance, cap, bearings + (long long)b * bearStride, f->dSrc, f->p0, f->Q[f->pG], f->lmc, f->errflag,
                     static_cast<double*>(f->Sigma[f->pS]), f->sigmaStride, f->ld);
         });
         if (rc) return rc;
@@ -552,7 +554,7 @@ void freeAll(eqf_filter* f) {
         hipFree(f->g[p]);
         hipFree(f->Q[p]);
     }
-    for (void* p : {(void*)f->p0, (void*)f->SA, (void*)f->SL, (void*)f->YW, (void*)f->YO, (void*)f->EA, (void*)f->EL, (void*)f->ZW,
+    for (void* p : {(void*)f->p0, (void*)f->lmc, (void*)f->SA, (void*)f->SL, (void*)f->YW, (void*)f->YO, (void*)f->EA, (void*)f->EL, (void*)f->ZW,
              (void*)f->ZO, (void*)f->dbgDelta, (void*)f->dbgGamma, (void*)f->dbgGammaTot, (void*)f->red, (void*)f->errflag, (void*)f->dMap,
              (void*)f->dNewN, (void*)f->dPerm, (void*)f->dSrc, (void*)f->dChord, (void*)f->dDepth2, (void*)f->dScratch, (void*)f->dMeas,
              (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear})
@@ -660,6 +662,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
         chk(dmalloc(&f->Q[q], (size_t)5 * cap * B));
     }
     chk(dmalloc(&f->p0, (size_t)3 * cap * B));
+    chk(dmalloc(&f->lmc, (size_t)15 * cap * B));
     chk(dmalloc(&f->SA, f->strideS * B)); chk(dmalloc(&f->SL, f->strideS * B));
     chk(dmalloc(&f->YW, f->strideY * B)); chk(dmalloc(&f->YO, f->strideY * B));
     chk(dmalloc(&f->EA, f->strideE * B)); chk(dmalloc(&f->EL, f->strideE * B));
@@ -671,7 +674,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     chk(dmalloc(&f->errflag, 1));
     chk(dmalloc(&f->dMap, (size_t)cap * B)); chk(dmalloc(&f->dNewN, B)); chk(dmalloc(&f->dPerm, (size_t)cap * B));
     chk(dmalloc(&f->dSrc, cap)); chk(dmalloc(&f->dChord, (size_t)cap * B)); chk(dmalloc(&f->dDepth2, (size_t)cap * B));
-    chk(dmalloc(&f->dScratch, (size_t)8 * cap * B)); chk(dmalloc(&f->dMeas, (size_t)3 * cap * B));
+    chk(dmalloc(&f->dScratch, (size_t)kLmRec * cap * B)); chk(dmalloc(&f->dMeas, (size_t)3 * cap * B));
     chk(dmalloc(&f->dOut, (size_t)f->nTot * f->nTot + 16));
     chk(dmalloc(&f->dRing, (size_t)kRing * B));
     chk(hmalloc(&f->hMap, (size_t)cap * B)); chk(hmalloc(&f->hNewN, B)); chk(hmalloc(&f->hPerm, (size_t)cap * B));

@@ -6,6 +6,7 @@
 #pragma once
 #include "eqf_device.hpp"
 #include "eqf_math.hpp"
+#include "eqf_update.hpp"
 
 namespace eqf {
 
@@ -52,20 +53,24 @@ __global__ __launch_bounds__(256) void k_compact_sigma(const Glob* g, const int*
     }
 }
 // Compact the per-landmark arrays through a scratch copy (gather then write back), one workgroup per filter.
-__global__ void k_compact_lm_gather(const int* map, const int* newN, int cap, const double* p0, const double* Q, double* scratch) {
+constexpr int kLmRec = 3 + 5 + 15;  // scratch record per landmark: p0, Q, constants
+__global__ void k_compact_lm_gather(const int* map, const int* newN, int cap, const double* p0, const double* Q, const double* lmc,
+    double* scratch) {
     const int b = blockIdx.x;
     const int* mp = map + (long long)b * cap;
     for (int i = threadIdx.x; i < newN[b]; i += blockDim.x) {
         const int o = mp[i];
-        for (int c = 0; c < 3; ++c) scratch[((long long)b * 8 + c) * cap + i] = p0[((long long)b * 3 + c) * cap + o];
-        for (int c = 0; c < 5; ++c) scratch[((long long)b * 8 + 3 + c) * cap + i] = Q[((long long)b * 5 + c) * cap + o];
+        for (int c = 0; c < 3; ++c) scratch[((long long)b * kLmRec + c) * cap + i] = p0[((long long)b * 3 + c) * cap + o];
+        for (int c = 0; c < 5; ++c) scratch[((long long)b * kLmRec + 3 + c) * cap + i] = Q[((long long)b * 5 + c) * cap + o];
+        for (int c = 0; c < 15; ++c) scratch[((long long)b * kLmRec + 8 + c) * cap + i] = lmc[((long long)b * 15 + c) * cap + o];
     }
 }
-__global__ void k_compact_lm_scatter(Glob* g, const int* newN, int cap, double* p0, double* Q, const double* scratch) {
+__global__ void k_compact_lm_scatter(Glob* g, const int* newN, int cap, double* p0, double* Q, double* lmc, const double* scratch) {
     const int b = blockIdx.x;
     for (int i = threadIdx.x; i < newN[b]; i += blockDim.x) {
-        for (int c = 0; c < 3; ++c) p0[((long long)b * 3 + c) * cap + i] = scratch[((long long)b * 8 + c) * cap + i];
-        for (int c = 0; c < 5; ++c) Q[((long long)b * 5 + c) * cap + i] = scratch[((long long)b * 8 + 3 + c) * cap + i];
+        for (int c = 0; c < 3; ++c) p0[((long long)b * 3 + c) * cap + i] = scratch[((long long)b * kLmRec + c) * cap + i];
+        for (int c = 0; c < 5; ++c) Q[((long long)b * 5 + c) * cap + i] = scratch[((long long)b * kLmRec + 3 + c) * cap + i];
+        for (int c = 0; c < 15; ++c) lmc[((long long)b * 15 + c) * cap + i] = scratch[((long long)b * kLmRec + 8 + c) * cap + i];
     }
     if (threadIdx.x == 0) g[b].N = newN[b];
 }
@@ -75,7 +80,8 @@ __global__ void k_compact_lm_scatter(Glob* g, const int* newN, int cap, double* 
 // j-th new landmark.
 template <typename T>
 __global__ __launch_bounds__(256) void k_append(Glob* g, int b, int nOld, int nNew, double depth, double pointVar, int cap,
-    const double* bearings /* filter b */, const int* src, double* p0, double* Q, T* S, long long sigmaStride, int ld) {
+    const double* bearings /* filter b */, const int* src, double* p0, double* Q, double* lmc, int* errflag, T* S, long long sigmaStride,
+    int ld) {
     const int nvo = kLm0 + 3 * nOld, nvn = kLm0 + 3 * (nOld + nNew);
     T* Sb = S + (long long)b * sigmaStride;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
@@ -104,6 +110,11 @@ __global__ __launch_bounds__(256) void k_append(Glob* g, int b, int nOld, int nN
         Q[((long long)b * 5 + 2) * cap + i] = 0.0;
         Q[((long long)b * 5 + 3) * cap + i] = 0.0;
         Q[((long long)b * 5 + 4) * cap + i] = 1.0;
+        double cst[15];
+        int bad = 0;
+        landmarkConstants(mk3(y[0] * depth, y[1] * depth, y[2] * depth), cst, &bad);
+        for (int c = 0; c < 15; ++c) lmc[((long long)b * 15 + c) * cap + i] = cst[c];
+        if (bad && errflag) atomicOr(errflag, 16);
     }
     if (tid == 0) g[b].N = nOld + nNew;
 }

@@ -39,6 +39,7 @@ __host__ __device__ inline int yCols(int N) { return kLm0 + 3 * N + 6; }  // C S
 struct UpdArgs {
     Glob* g;             // current scalar state [B] (updated in place by k_update_finish)
     const double* p0;    // [B][3][cap]
+    const double* lmc;   // [B][15][cap] per-landmark constants of the origin landmark: C0i (6), chart rotation R_s (9)
     double* Q;           // [B][5][cap] current group landmarks (updated in place by finish)
     const void* Sin;     // Sigma (T) current
     void* Sout;          // Sigma (T) next
@@ -81,6 +82,16 @@ EQF_DI void outputBlockC(d3 p0, double* C, int* bad) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             C[3 * r + c] = (s * D[3 * r]) * P.a[c] + (s * D[3 * r + 1]) * P.a[3 + c] + (s * D[3 * r + 2]) * P.a[6 + c];
+}
+
+// Constants of one origin landmark p0 (they change only when the landmark set changes): C0i and the matrix of the
+// chart rotation R_s = SO3FromVectors(-y0, e3), y0 = p0/|p0|, that the residual chart uses (VisionMeasurement.cpp:30,
+// VIOState.cpp:230-234).  Layout: out[0..5] = C0i row-major, out[6..14] = R_s row-major.
+EQF_DI void landmarkConstants(d3 p0, double* out, int* bad) {
+    outputBlockC(p0, out, bad);
+    const m33 Rs = q2m(sphereRotQ(unit3(p0), bad));
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[6 + k] = Rs.a[k];
 }
 
 // Rows of Z_P for one landmark: Qhat_i R_C^T [ (x0 - pHat)^x R0 , R0 ]   (3x6)   (EqFMatrices.cpp:221-235)
@@ -187,6 +198,7 @@ __global__ __launch_bounds__(256) void k_update_prep(UpdArgs a, int lmBlocks, in
 #pragma unroll
     for (int k = 0; k < 12; ++k) V[k] = 0.0;
     const bool valid = i < N;
+    const double* lmc = a.lmc + (long long)b * 15 * cap;
     if (valid) {
         const quat Qq = quat{Q[i], Q[cap + i], Q[2 * cap + i], Q[3 * cap + i]};
         const double Qa = Q[4 * cap + i];
@@ -194,11 +206,16 @@ __global__ __launch_bounds__(256) void k_update_prep(UpdArgs a, int lmBlocks, in
         const int k = a.perm ? a.perm[(long long)b * cap + i] : i;
         const double* yb = a.bearings + (long long)b * a.bearStride + 3 * k;
         const d3 y = mk3(yb[0], yb[1], yb[2]);
-        // y0 = q0/|q0| (measureSystemState); yerr = (X^-1).Q_i.R()^-1 y (outputGroupAction, VIOGroup.cpp:84,130)
-        const d3 pole = unit3(q0);
+        // yerr = (X^-1).Q_i.R()^-1 y (outputGroupAction, VIOGroup.cpp:84,130); delta = e3ProjectSphere(R_s yerr)
         const d3 yerr = qrot(qinv(qinv(Qq)), y);
-        stereoChart(yerr, pole, &dl[0], &dl[1], &bad);
-        outputBlockC(q0, C, &bad);
+        m33 Rs;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) C[q] = lmc[(long long)q * cap + i];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) Rs.a[q] = lmc[(long long)(6 + q) * cap + i];
+        const d3 rr = mv33(Rs, yerr);
+        dl[0] = rr.x / (1 - rr.z);  // VIOState.cpp:199-204
+        dl[1] = rr.y / (1 - rr.z);
         double Z[18];
         liftRows(liftCommon(g, a.prm), Qq, Qa, q0, Z);
 #pragma unroll
@@ -236,7 +253,8 @@ __global__ __launch_bounds__(256) void k_update_prep(UpdArgs a, int lmBlocks, in
             double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
             if (j < N) {
                 double Cj[6];
-                outputBlockC(mk3(p0[j], p0[cap + j], p0[2 * cap + j]), Cj, &bad);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) Cj[q] = lmc[(long long)q * cap + j];
                 const double* c0 = &sCS0[kLm0 + 3 * j];
                 const double* c1 = &sCS1[kLm0 + 3 * j];
                 s00 = c0[0] * Cj[0] + c0[1] * Cj[1] + c0[2] * Cj[2];
@@ -541,42 +559,56 @@ __global__ __launch_bounds__(256) void k_chol_step(ChainArgs c0, ChainArgs c1, i
 //   gamma[col] = sum_r Y[r][col] z[r]  (z = Y[:, 11]),  hV = (L^-1 V)^T z,  G11 = [Zt | Et]^T [Zt | Et].
 // grid.x = colBlocks (64 columns of Y each) + 1 (the E-chain block), grid.y = B, block = 256.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_update_reduce(UpdArgs a, int colBlocks) {
+__global__ __launch_bounds__(1024) void k_update_reduce(UpdArgs a, int colBlocks) {
     const int b = blockIdx.y;
     const Glob& g = a.g[b];
     if (!g.updateOk || g.N == 0) return;
     const int N = g.N, cap = a.cap;
     const int tid = threadIdx.x;
-    __shared__ double sRed[256];
+    __shared__ double sRed[1024];
     if ((int)blockIdx.x < colBlocks) {
+        // 64 columns x 16 row slices per workgroup: many independent loads in flight (the data was written by other
+        // XCDs in the previous launch, every access is a ~2 us miss)
         const int mp = roundUp(sDim(N), kNB), nv = kLm0 + 3 * N;
         const double* Y = a.YO + (long long)b * a.strideY;
         const int col = blockIdx.x * 64 + (tid & 63), part = tid >> 6;
-        double acc = 0;
+        double acc0 = 0, acc1 = 0;
         if (col < nv + 6) {
+            int r = part;
 #pragma unroll 4
-            for (int r = part; r < mp; r += 4) acc += Y[(long long)r * a.ldY + col] * Y[(long long)r * a.ldY + 11];
+            for (; r + 16 < mp; r += 32) {
+                acc0 += Y[(long long)r * a.ldY + col] * Y[(long long)r * a.ldY + 11];
+                acc1 += Y[(long long)(r + 16) * a.ldY + col] * Y[(long long)(r + 16) * a.ldY + 11];
+            }
+            if (r < mp) acc0 += Y[(long long)r * a.ldY + col] * Y[(long long)r * a.ldY + 11];
         }
-        sRed[tid] = acc;
+        sRed[tid] = acc0 + acc1;
         __syncthreads();
         if (tid < 64 && col < nv + 6) {
-            const double v = (sRed[tid] + sRed[64 + tid]) + (sRed[128 + tid] + sRed[192 + tid]);
+            double v = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v += sRed[64 * q + tid];
             if (col < nv) a.dbgGamma[(long long)b * (kLm0 + 3 * cap) + col] = (col == 11) ? 0.0 : v;
             else a.red[(long long)b * 256 + col - nv] = v;
         }
     } else {
         const int nep = roundUp(eDim(N), kNB);
         const double* Z = a.ZO + (long long)b * a.strideZ;
-        const int pr = tid % 121, part = tid / 121;  // 121 column pairs x 2 row halves (threads 242..255 idle)
+        const int pr = tid % 121, part = tid / 121;  // 121 column pairs x 8 row slices (threads 968..1023 idle)
         double acc = 0;
-        if (part < 2) {
+        if (part < 8) {
             const int c0 = pr / 11, c1 = pr % 11;
 #pragma unroll 4
-            for (int r = part; r < nep; r += 2) acc += Z[(long long)r * a.ldZ + c0] * Z[(long long)r * a.ldZ + c1];
+            for (int r = part; r < nep; r += 8) acc += Z[(long long)r * a.ldZ + c0] * Z[(long long)r * a.ldZ + c1];
         }
         sRed[tid] = acc;
         __syncthreads();
-        if (tid < 121) a.red[(long long)b * 256 + 8 + tid] = sRed[tid] + sRed[121 + tid];
+        if (tid < 121) {
+            double v = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v += sRed[121 * q + tid];
+            a.red[(long long)b * 256 + 8 + tid] = v;
+        }
     }
 }
 
