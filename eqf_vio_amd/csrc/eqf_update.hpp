@@ -800,60 +800,107 @@ struct MfmaT<float> {
     static EQF_DI int row(int lane, int q) { return 4 * (lane >> 4) + q; }
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_downdate(UpdArgs a) {
-    const int b = blockIdx.z;
+// Symmetric, LDS-staged version: only tiles with J0 >= I0 are computed (grid.x enumerates the upper triangle of
+// tiles), the mirror tile is written from the same accumulators.  Y row chunks of 32 x 64 values per operand are
+// staged through LDS with the next chunk's global loads issued before the MFMAs of the current one.
+// TS = output tile edge: 64 (each wave a 32x32 quadrant as 2x2 MFMA tiles; best operand reuse, used when there are
+// enough tiles to fill the chip) or 32 (each wave one 16x16 MFMA tile; 4x more workgroups for a single small filter).
+template <typename T, int TS>
+__global__ __launch_bounds__(256) void k_downdate(UpdArgs a, int nt) {
+    constexpr int WM = TS / 32;  // MFMA tiles per wave and dimension
+    const int b = blockIdx.y;
     const Glob& g = a.g[b];
     const int N = g.N;
     const int nv = kLm0 + 3 * N;
-    const int I0 = blockIdx.y * 64, J0 = blockIdx.x * 64;
+    // tile pair (ti <= tj) from the linear index over the upper triangle
+    int ti = 0, rem = blockIdx.x;
+    while (rem >= nt - ti) {
+        rem -= nt - ti;
+        ++ti;
+    }
+    const int tj = ti + rem;
+    const int I0 = ti * TS, J0 = tj * TS;
     if (I0 >= nv || J0 >= nv) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ld = a.ld;
     const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
     T* Sout = static_cast<T*>(a.Sout) + (long long)b * a.sigmaStride;
     if (!g.updateOk || N == 0) {
-        for (int e = tid; e < 64 * 64; e += 256) {
-            const int R = I0 + e / 64, Cc = J0 + e % 64;
-            if (R < nv && Cc < nv) Sout[(long long)R * ld + Cc] = Sin[(long long)R * ld + Cc];
+        for (int e = tid; e < TS * TS; e += 256) {
+            const int R = I0 + e / TS, Cc = J0 + e % TS;
+            if (R < nv && Cc < nv) {
+                Sout[(long long)R * ld + Cc] = Sin[(long long)R * ld + Cc];
+                if (ti != tj) Sout[(long long)Cc * ld + R] = Sin[(long long)Cc * ld + R];
+            }
         }
         return;
     }
     const int mp = roundUp(sDim(N), kNB);
     const double* Y = a.YO + (long long)b * a.strideY;
     const int ldY = a.ldY;
+    constexpr int KC = 32;                 // rows of Y per chunk
+    __shared__ T sI[KC][TS + 1];           // Y[k0 + r][I0 + c]
+    __shared__ T sJ[KC][TS + 1];           // Y[k0 + r][J0 + c]
     const int qi = wv >> 1, qj = wv & 1;
     const int lr = lane & 15, lk = lane >> 4;
     typedef MfmaT<T> MF;
-    typename MF::acc_t acc[2][2];
+    typename MF::acc_t acc[WM][WM];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < WM; ++u)
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int v = 0; v < WM; ++v)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[u][v][q] = 0;
-    const int ia = I0 + 32 * qi + lr, jb = J0 + 32 * qj + lr;  // (+16 for the second sub-tile)
-    for (int k0 = 0; k0 < mp; k0 += 4) {
-        const double* yr = Y + (long long)(k0 + lk) * ldY;
-        // column index 11 of Y holds z, not C*Sigma: rows/cols 11 of Sigma are structurally zero
-        const T a0 = (ia < nv && ia != 11) ? (T)yr[ia] : (T)0;
-        const T a1 = (ia + 16 < nv && ia + 16 != 11) ? (T)yr[ia + 16] : (T)0;
-        const T b0 = (jb < nv && jb != 11) ? (T)yr[jb] : (T)0;
-        const T b1 = (jb + 16 < nv && jb + 16 != 11) ? (T)yr[jb + 16] : (T)0;
-        acc[0][0] = MF::mfma(a0, b0, acc[0][0]);
-        acc[0][1] = MF::mfma(a0, b1, acc[0][1]);
-        acc[1][0] = MF::mfma(a1, b0, acc[1][0]);
-        acc[1][1] = MF::mfma(a1, b1, acc[1][1]);
+    // staging assignment: thread -> row tid / 8 (0..31), PT consecutive columns starting at PT * (tid % 8)
+    constexpr int PT = TS / 8;
+    const int sr = tid >> 3, sc = (tid & 7) * PT;
+    double pi[PT], pj[PT];
+    auto fetch = [&](int k0) {
+        const double* yr = Y + (long long)(k0 + sr) * ldY;
+#pragma unroll
+        for (int q = 0; q < PT; ++q) {
+            const int ci = I0 + sc + q, cj = J0 + sc + q;
+            // column 11 of Y holds z, not C*Sigma: rows/cols 11 of Sigma are structurally zero
+            pi[q] = (ci < nv && ci != 11) ? yr[ci] : 0.0;
+            pj[q] = (cj < nv && cj != 11) ? yr[cj] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < mp; k0 += KC) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PT; ++q) {
+            sI[sr][sc + q] = (T)pi[q];
+            sJ[sr][sc + q] = (T)pj[q];
+        }
+        __syncthreads();
+        if (k0 + KC < mp) fetch(k0 + KC);
+#pragma unroll
+        for (int s = 0; s < KC / 4; ++s) {
+            T av[WM], bv[WM];
+#pragma unroll
+            for (int u = 0; u < WM; ++u) {
+                av[u] = sI[4 * s + lk][16 * WM * qi + 16 * u + lr];
+                bv[u] = sJ[4 * s + lk][16 * WM * qj + 16 * u + lr];
+            }
+#pragma unroll
+            for (int u = 0; u < WM; ++u)
+#pragma unroll
+                for (int v = 0; v < WM; ++v) acc[u][v] = MF::mfma(av[u], bv[v], acc[u][v]);
+        }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < WM; ++u)
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int v = 0; v < WM; ++v)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int R = I0 + 32 * qi + 16 * u + MF::row(lane, q);
-                const int Cc = J0 + 32 * qj + 16 * v + lr;
-                if (R < nv && Cc < nv) Sout[(long long)R * ld + Cc] = Sin[(long long)R * ld + Cc] - acc[u][v][q];
+                const int R = I0 + 16 * WM * qi + 16 * u + MF::row(lane, q);
+                const int Cc = J0 + 16 * WM * qj + 16 * v + lr;
+                if (R < nv && Cc < nv) {
+                    Sout[(long long)R * ld + Cc] = Sin[(long long)R * ld + Cc] - acc[u][v][q];
+                    if (ti != tj) Sout[(long long)Cc * ld + R] = Sin[(long long)Cc * ld + R] - acc[u][v][q];
+                }
             }
 }
 
