@@ -58,7 +58,7 @@ EXPORTED_SYMBOLS = [
     "eqf_settings_default", "eqf_create", "eqf_destroy", "eqf_reset", "eqf_process_imu", "eqf_process_vision",
     "eqf_stream_upload", "eqf_stream_imu", "eqf_stream_vision", "eqf_synchronize", "eqf_get_time", "eqf_num_landmarks",
     "eqf_get_ids", "eqf_get_state_estimate", "eqf_get_origin", "eqf_get_group", "eqf_get_bias", "eqf_get_sigma",
-    "eqf_set_sigma", "eqf_get_last_update", "eqf_device_error", "eqf_set_dense_propagate", "eqf_profile_enable",
+    "eqf_set_sigma", "eqf_set_state", "eqf_get_integrator", "eqf_get_last_update", "eqf_device_error", "eqf_set_dense_propagate", "eqf_profile_enable",
     "eqf_profile_get", "eqf_profile_class_name", "eqf_version",
 ]
 
@@ -95,6 +95,8 @@ def lib():
         L.eqf_get_sigma.argtypes = [vp, C.c_int, _dp, C.c_int]
         L.eqf_set_sigma.argtypes = [vp, C.c_int, _dp, C.c_int]
         L.eqf_get_last_update.argtypes = [vp, C.c_int, _dp, _dp, _dp]
+        L.eqf_set_state.argtypes = [vp, C.c_int, C.c_int, _ip] + [_dp] * 11 + [C.c_int, C.c_double, _dp, _dp, C.c_double, C.c_int]
+        L.eqf_get_integrator.argtypes = [vp, C.c_int, _dp, _dp, _dp, _ip]
         L.eqf_device_error.argtypes = [vp]
         L.eqf_set_dense_propagate.argtypes = [vp, C.c_int]
         L.eqf_profile_enable.argtypes = [vp, C.c_int]
@@ -269,6 +271,37 @@ class FilterBatch:
         n = 11 + 3 * self.num_landmarks(b)
         assert S.shape == (n, n)
         _check(lib().eqf_set_sigma(self._h, b, _p(S), n), "eqf_set_sigma")
+
+    def dump_state(self, b=0):
+        """Lossless snapshot of filter b (everything eqf_set_state needs)."""
+        cv, av, at, ini = np.zeros(6), np.zeros(6), np.zeros(1), np.zeros(1, dtype=np.int32)
+        _check(lib().eqf_get_integrator(self._h, b, _p(cv), _p(av), _p(at), ini.ctypes.data_as(_ip)), "eqf_get_integrator")
+        return dict(ids=self.ids(b), origin=self.origin(b), group=self.group(b), bias=self.bias(b), sigma=self.sigma(b),
+                    time=float(self.get_time()[b]), currentVelocity=cv, accumulatedVelocity=av, accumulatedTime=float(at[0]),
+                    initialised=int(ini[0]))
+
+    def restore_state(self, st, b=0):
+        """Inverse of dump_state (checkpoint / resume, cross-backend state injection)."""
+        ids = np.ascontiguousarray(st["ids"], dtype=np.int32)
+        N = len(ids)
+        o, g = st["origin"], st["group"]
+
+        def arr(a, shape):
+            out = np.zeros(shape)
+            if N:
+                out[...] = np.asarray(a, dtype=np.float64).reshape(shape)
+            return np.ascontiguousarray(out)
+
+        p0, Qq, Qa = arr(o["p"], (max(N, 1), 3)), arr(g["Qq"], (max(N, 1), 4)), arr(g["Qa"], (max(N, 1),))
+        S = np.ascontiguousarray(st["sigma"], dtype=np.float64)
+        cv = np.ascontiguousarray(st["currentVelocity"], dtype=np.float64)
+        av = np.ascontiguousarray(st["accumulatedVelocity"], dtype=np.float64)
+        arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (o["q"], o["x"], o["v"], p0, g["Aq"], g["Ax"], g["w"], Qq, Qa, st["bias"], S)]
+        _check(
+            lib().eqf_set_state(self._h, b, N, ids.ctypes.data_as(_ip), *[_p(a) for a in arrs], S.shape[0], float(st["time"]), _p(cv), _p(av),
+                                float(st["accumulatedTime"]), int(st["initialised"])),
+            "eqf_set_state",
+        )
 
     def last_update(self, b=0):
         N = self.num_landmarks(b)

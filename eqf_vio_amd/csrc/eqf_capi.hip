@@ -969,6 +969,65 @@ int eqf_set_sigma(eqf_filter* f, int b, const double* src, int ld) {
     return EQF_OK;
 }
 
+int eqf_get_integrator(eqf_filter* f, int b, double* currentVelocity6, double* accumulatedVelocity6, double* accumulatedTime,
+    int* initialised) {
+    if (!f || b < 0 || b >= f->B) return EQF_ERR_INVALID;
+    Glob g;
+    int rc = fetchGlob(f, b, &g);
+    if (rc) return rc;
+    if (currentVelocity6) std::copy(g.curVel, g.curVel + 6, currentVelocity6);
+    if (accumulatedVelocity6) std::copy(g.accVel, g.accVel + 6, accumulatedVelocity6);
+    if (accumulatedTime) *accumulatedTime = g.accTime;
+    if (initialised) *initialised = g.initialised;
+    return EQF_OK;
+}
+
+int eqf_set_state(eqf_filter* f, int b, int N, const int* ids, const double* pose_q, const double* pose_x, const double* velocity,
+    const double* p0, const double* A_q, const double* A_x, const double* w, const double* Q_q, const double* Q_a, const double* bias6,
+    const double* sigma, int ld, double currentTime, const double* currentVelocity6, const double* accumulatedVelocity6,
+    double accumulatedTime, int initialised) {
+    if (!f || b < 0 || b >= f->B || N < 0 || !pose_q || !pose_x || !velocity || !A_q || !A_x || !w || !bias6 || !sigma) return EQF_ERR_INVALID;
+    if (N > 0 && (!ids || !p0 || !Q_q || !Q_a)) return EQF_ERR_INVALID;
+    if (N > f->cap) return EQF_ERR_CAPACITY;
+    if (ld < kBase + 3 * N) return EQF_ERR_INVALID;
+    HIPC(hipSetDevice(f->device));
+    Glob g;
+    int rc = fetchGlob(f, b, &g);
+    if (rc) return rc;
+    std::copy(pose_q, pose_q + 4, g.P0q);
+    std::copy(pose_x, pose_x + 3, g.P0x);
+    std::copy(velocity, velocity + 3, g.v0);
+    std::copy(A_q, A_q + 4, g.Aq);
+    std::copy(A_x, A_x + 3, g.Ax);
+    std::copy(w, w + 3, g.w);
+    std::copy(bias6, bias6 + 6, g.bias);
+    for (int i = 0; i < 6; ++i) {
+        g.curVel[i] = currentVelocity6 ? currentVelocity6[i] : 0.0;
+        g.accVel[i] = accumulatedVelocity6 ? accumulatedVelocity6[i] : 0.0;
+    }
+    g.accTime = accumulatedTime;
+    g.curTime = currentTime;
+    g.initialised = initialised ? 1 : 0;
+    g.N = N;
+    g.updateOk = 0;
+    HIPC(hipMemcpy(f->g[f->pG] + b, &g, sizeof(Glob), hipMemcpyHostToDevice));
+    const int cap = f->cap;
+    std::vector<double> tp((size_t)3 * cap, 0.0), tq((size_t)5 * cap, 0.0);
+    for (int i = 0; i < N; ++i) {
+        for (int c = 0; c < 3; ++c) tp[(size_t)c * cap + i] = p0[3 * i + c];
+        for (int c = 0; c < 4; ++c) tq[(size_t)c * cap + i] = Q_q[4 * i + c];
+        tq[(size_t)4 * cap + i] = Q_a[i];
+    }
+    HIPC(hipMemcpy(f->p0 + (size_t)b * 3 * cap, tp.data(), sizeof(double) * 3 * cap, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(f->Q[f->pG] + (size_t)b * 5 * cap, tq.data(), sizeof(double) * 5 * cap, hipMemcpyHostToDevice));
+    f->ids[b].assign(ids, ids + N);
+    f->curTime[b] = currentTime;
+    f->init[b] = initialised ? 1 : 0;
+    hipLaunchKernelGGL(k_restore_constants, dim3((N + 127) / 128 + 1), dim3(128), 0, f->stream, f->g[f->pG], b, f->p0, f->lmc, cap, f->errflag);
+    HIPC(hipGetLastError());
+    return eqf_set_sigma(f, b, sigma, ld);
+}
+
 int eqf_get_last_update(eqf_filter* f, int b, double* delta, double* gamma, double* Gamma) {
     if (!f || b < 0 || b >= f->B) return EQF_ERR_INVALID;
     HIPC(hipSetDevice(f->device));

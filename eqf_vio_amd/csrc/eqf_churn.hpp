@@ -6,6 +6,7 @@
 #pragma once
 #include "eqf_device.hpp"
 #include "eqf_math.hpp"
+#include "eqf_propagate.hpp"
 #include "eqf_update.hpp"
 
 namespace eqf {
@@ -117,6 +118,28 @@ __global__ __launch_bounds__(256) void k_append(Glob* g, int b, int nOld, int nN
         if (bad && errflag) atomicOr(errflag, 16);
     }
     if (tid == 0) g[b].N = nOld + nNew;
+}
+
+// Restore path: per-landmark constants and cached pose constants recomputed on the device after eqf_set_state.
+__global__ void k_restore_constants(Glob* g, int b, const double* p0, double* lmc, int cap, int* errflag) {
+    Glob& s = g[b];
+    int bad = 0;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = tid; i < s.N; i += gridDim.x * blockDim.x) {
+        double cst[15];
+        landmarkConstants(mk3(p0[((long long)b * 3 + 0) * cap + i], p0[((long long)b * 3 + 1) * cap + i], p0[((long long)b * 3 + 2) * cap + i]), cst, &bad);
+        for (int c = 0; c < 15; ++c) lmc[((long long)b * 15 + c) * cap + i] = cst[c];
+    }
+    if (tid == 0 && s.initialised) {
+        double e0[3], cd[6], ci[6];
+        poseConstants(quat{s.P0q[0], s.P0q[1], s.P0q[2], s.P0q[3]}, e0, cd, ci, &bad);
+        for (int i = 0; i < 3; ++i) s.eta0[i] = e0[i];
+        for (int i = 0; i < 6; ++i) {
+            s.cDiff[i] = cd[i];
+            s.cInv[i] = ci[i];
+        }
+    }
+    if (bad && errflag) atomicOr(errflag, 32);
 }
 
 // stateEstimate = stateGroupAction(X, xi0) (VIOFilter.cpp:304, VIOGroup.cpp:23-45): out[b] = q(4) x(3) v(3) p(3N)

@@ -115,6 +115,20 @@ int eqf_get_bias(eqf_filter* f, int b, double* bias6);
 int eqf_get_sigma(eqf_filter* f, int b, double* dst, int ld);
 /* Test hook: overwrite Sigma (same layout as eqf_get_sigma). */
 int eqf_set_sigma(eqf_filter* f, int b, const double* src, int ld);
+/* Checkpoint / resume (full precision; the reference's only dump is the lossy, write-only operator<<,
+ * VIOFilter.cpp:311-341).  eqf_set_state overwrites filter b with: N landmarks with ids[N]; origin state xi0
+ * (pose_q, pose_x, velocity, p0[N][3]); group element X (A_q, A_x, w, Q_q[N][4], Q_a[N]); bias6; Sigma (n x n, n =
+ * 11 + 3N, leading dimension ld, reference index map); currentTime; currentVelocity6 (omega, accel) and the
+ * accumulated velocity/time of the fastRiccati path; initialised flag.  Everything eqf_get_* returns can be fed back. */
+int eqf_set_state(eqf_filter* f, int b, int N, const int* ids, const double* pose_q, const double* pose_x,
+    const double* velocity, const double* p0, const double* A_q, const double* A_x, const double* w, const double* Q_q,
+    const double* Q_a, const double* bias6, const double* sigma, int ld, double currentTime, const double* currentVelocity6,
+    const double* accumulatedVelocity6, double accumulatedTime, int initialised);
+/* The remaining scalar state needed for a lossless dump: currentVelocity6, accumulatedVelocity6, accumulatedTime,
+ * initialised flag (any pointer may be NULL). */
+int eqf_get_integrator(eqf_filter* f, int b, double* currentVelocity6, double* accumulatedVelocity6, double* accumulatedTime,
+    int* initialised);
+
 /* Internals of the most recent update of filter b: delta[2N], gamma[11+3N] (K*delta), Gamma[9+3N]. */
 int eqf_get_last_update(eqf_filter* f, int b, double* delta, double* gamma, double* Gamma);
 /* Sticky device-side error flag (NaN / antipodal), 0 if none. */
