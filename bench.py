@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--landmarks", type=int, default=200)
     ap.add_argument("--filters-per-gpu", type=int, default=1)
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--dense-propagate", action="store_true", help="Riccati step as dense F Sigma F^T on MFMA (BASELINE cfg 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -98,6 +99,8 @@ def roofline(fb, events, N, B, precision):
         # Cholesky of S + forward solves of n+7 rhs + Cholesky of Sigma_e + 11 rhs, spread over the step launches
         "k_chol_step": ("mfma", (m**3 / 3.0 + m * m * (n + 7.0) + ne**3 / 3.0 + ne * ne * 11.0) * B / max(nb_s, nb_e)),
         "k_downdate": ("mfma", 2.0 * n * n * m * B),
+        # dense backend (cfg 3): build F + two n^3 GEMMs = 4 n^3 flops per Riccati step (SURVEY.md 8d "mfma_dense_equiv")
+        "k_dense_riccati": ("mfma", 4.0 * n**3 * B),
         "k_update_prep": ("hbm", (n * n * esz + 8.0 * (m * (n + 7) + m * m + ne * ne)) * B),
         "k_update_reduce": ("hbm", 8.0 * (m * (n + 7) + ne * 32) * B),
     }
@@ -115,7 +118,7 @@ def roofline(fb, events, N, B, precision):
             else:
                 ach = work / (avg_us * 1e-6) / 1e12
                 pk = MFMA_PEAK_TF["f64"]  # factorisation is always fp64
-                if name == "k_downdate":
+                if name in ("k_downdate", "k_dense_riccati"):
                     pk = MFMA_PEAK_TF[precision]
                 row.update(bound="mfma", achieved=round(ach, 4), peak=pk, unit="TFLOP/s", frac=round(ach / pk, 5))
         rows.append(row)
@@ -158,6 +161,8 @@ def main():
 
     prec = binding.PRECISION_F64 if args.precision == "f64" else binding.PRECISION_F32
     fb = binding.FilterBatch(synth.template_settings_dict(), capacity=N, batch=B, device=device, precision=prec)
+    if args.dense_propagate:
+        fb.set_dense_propagate(True)
     fb.stream_upload(imu, vst, ids, bear)
 
     warm, timed = events[: args.warmup], events[args.warmup:]

@@ -18,7 +18,7 @@ SKIPPED_NOT_INITIALISED = 3
 SKIPPED_NO_BEARINGS = 4
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSORTED, ERR_NUMERIC, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
 PRECISION_F64, PRECISION_F32 = 0, 1
-PROF_CLASSES = 7
+PROF_CLASSES = 8
 
 _ERR_NAMES = {
     -1: "EQF_ERR_INVALID", -2: "EQF_ERR_NO_DEVICE", -3: "EQF_ERR_HIP", -4: "EQF_ERR_CAPACITY",
@@ -215,6 +215,10 @@ class FilterBatch:
 
     def stream_vision(self, f):
         return _check(lib().eqf_stream_vision(self._h, int(f)), "eqf_stream_vision")
+
+    def set_dense_propagate(self, on=True):
+        """Riccati step as dense F Sigma F^T on the matrix cores (BASELINE cfg 3 cross-check backend)."""
+        _check(lib().eqf_set_dense_propagate(self._h, int(bool(on))), "eqf_set_dense_propagate")
 
     def synchronize(self):
         _check(lib().eqf_synchronize(self._h), "eqf_synchronize")

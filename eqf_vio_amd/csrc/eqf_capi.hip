@@ -13,6 +13,7 @@
 
 #include "../../include/eqf_vio_amd.h"
 #include "eqf_churn.hpp"
+#include "eqf_dense.hpp"
 #include "eqf_device.hpp"
 #include "eqf_propagate.hpp"
 #include "eqf_update.hpp"
@@ -81,6 +82,7 @@ struct eqf_filter {
     std::vector<double> curTime;
     std::vector<char> init;
     int densePropagate = 0;
+    void *dF = nullptr, *dG = nullptr, *dBn = nullptr;  // dense backend: F, G = F Sigma, Bn (n x 6)
     // profiling
     bool prof = false;
     std::vector<ProfPair> profPairs;
@@ -236,7 +238,31 @@ int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, con
     }
     a.prm = f->prm;
     const dim3 grid(a.NT * a.NT, f->B), block(256);
-    int rc = profiled(f, EQF_PROF_PROPAGATE, [&] {
+    int rc = EQF_OK;
+    if (f->densePropagate && doRiccati) {
+        // dense backend: F and Bn from the same linearisation blocks, then two MFMA GEMMs; k_propagate below only
+        // does the group step and the scalar bookkeeping
+        a.sigmaExternal = 1;
+        const int nmax = maxN(f), nv = kLm0 + 3 * nmax, nt = (nv + 63) / 64;
+        const long long bStride = (long long)f->nTot * 6;
+        rc = profiled(f, EQF_PROF_DENSE, [&] {
+            if (f->precision == EQF_PRECISION_F32) {
+                hipLaunchKernelGGL(k_dense_build<float>, dim3(nmax + 1, f->B), block, 0, f->stream, a, (float*)f->dF, (float*)f->dBn, f->sigmaStride, bStride);
+                hipLaunchKernelGGL((k_dense_gemm<float, false>), dim3(nt, nt, f->B), block, 0, f->stream, a.gin, a.recs, a.inl, (const float*)f->dF,
+                    (const float*)a.Sin, (float*)f->dG, (const float*)nullptr, f->sigmaStride, bStride, f->ld, f->prm);
+                hipLaunchKernelGGL((k_dense_gemm<float, true>), dim3(nt, nt, f->B), block, 0, f->stream, a.gin, a.recs, a.inl, (const float*)f->dG,
+                    (const float*)f->dF, (float*)a.Sout, (const float*)f->dBn, f->sigmaStride, bStride, f->ld, f->prm);
+            } else {
+                hipLaunchKernelGGL(k_dense_build<double>, dim3(nmax + 1, f->B), block, 0, f->stream, a, (double*)f->dF, (double*)f->dBn, f->sigmaStride, bStride);
+                hipLaunchKernelGGL((k_dense_gemm<double, false>), dim3(nt, nt, f->B), block, 0, f->stream, a.gin, a.recs, a.inl, (const double*)f->dF,
+                    (const double*)a.Sin, (double*)f->dG, (const double*)nullptr, f->sigmaStride, bStride, f->ld, f->prm);
+                hipLaunchKernelGGL((k_dense_gemm<double, true>), dim3(nt, nt, f->B), block, 0, f->stream, a.gin, a.recs, a.inl, (const double*)f->dG,
+                    (const double*)f->dF, (double*)a.Sout, (const double*)f->dBn, f->sigmaStride, bStride, f->ld, f->prm);
+            }
+        });
+        if (rc) return rc;
+    }
+    rc = profiled(f, EQF_PROF_PROPAGATE, [&] {
         if (f->precision == EQF_PRECISION_F32)
             hipLaunchKernelGGL(k_propagate<float>, grid, block, 0, f->stream, a);
         else
@@ -564,7 +590,7 @@ void freeAll(eqf_filter* f) {
     for (void* p : {(void*)f->p0, (void*)f->lmc, (void*)f->SA, (void*)f->SL, (void*)f->YW, (void*)f->YO, (void*)f->EA, (void*)f->EL, (void*)f->ZW,
              (void*)f->ZO, (void*)f->dbgDelta, (void*)f->dbgGamma, (void*)f->dbgGammaTot, (void*)f->red, (void*)f->errflag, (void*)f->dMap,
              (void*)f->dNewN, (void*)f->dPerm, (void*)f->dSrc, (void*)f->dChord, (void*)f->dDepth2, (void*)f->dScratch, (void*)f->dMeas,
-             (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear})
+             (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn})
         hipFree(p);
     for (void* p : {(void*)f->hMap, (void*)f->hNewN, (void*)f->hPerm, (void*)f->hSrc, (void*)f->hChord, (void*)f->hDepth2, (void*)f->hMeas,
              (void*)f->hOut, (void*)f->hRing})
@@ -1055,8 +1081,16 @@ int eqf_device_error(eqf_filter* f) {
 
 int eqf_set_dense_propagate(eqf_filter* f, int on) {
     if (!f) return EQF_ERR_INVALID;
-    if (on) return EQF_ERR_UNSUPPORTED;
-    f->densePropagate = 0;
+    HIPC(hipSetDevice(f->device));
+    if (on && !f->dF) {
+        const size_t bytes = f->esz * f->sigmaStride * f->B;
+        HIPC(hipMalloc(&f->dF, bytes));
+        HIPC(hipMalloc(&f->dG, bytes));
+        HIPC(hipMalloc(&f->dBn, f->esz * (size_t)f->nTot * 6 * f->B));
+        HIPC(hipMemset(f->dF, 0, bytes));
+        HIPC(hipMemset(f->dG, 0, bytes));
+    }
+    f->densePropagate = on ? 1 : 0;
     return EQF_OK;
 }
 
@@ -1085,7 +1119,7 @@ int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_m
 
 const char* eqf_profile_class_name(int cls) {
     static const char* names[EQF_PROF_CLASSES] = {"k_propagate", "k_update_prep", "k_chol_step", "k_update_reduce", "k_update_finish",
-        "k_downdate", "churn"};
+        "k_downdate", "churn", "k_dense_riccati"};
     return (cls >= 0 && cls < EQF_PROF_CLASSES) ? names[cls] : "?";
 }
 

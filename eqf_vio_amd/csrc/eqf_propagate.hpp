@@ -35,6 +35,7 @@ struct PropArgs {
     int cap, ld, NT;
     int isImu;      // processIMUData (bias subtraction, lazy init, ZOH bookkeeping)
     int doRiccati;  // VIOFilter.cpp:160
+    int sigmaExternal;  // the Riccati step of this call is done by the dense MFMA backend: touch no Sigma here
     int dbg;        // development only: bit0 skip common+blocks, bit1 skip landmark step, bit2 skip scalar step, bit3 skip Sigma math
     Params prm;
 };
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     // cheap, every thread: does this call integrate, and does it touch Sigma?
     const double dt0 = r.stamp - G.curTime;
     const bool step = (G.curTime >= 0) && (dt0 > 0);
-    const bool riccati = step && a.doRiccati;
+    const bool riccati = step && a.doRiccati && !a.sigmaExternal;
 
     const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
     T* Sout = static_cast<T*>(a.Sout) + (long long)b * a.sigmaStride;
@@ -351,6 +352,10 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
         }
     }
 
+    if (!riccati && a.sigmaExternal && step && a.doRiccati) {
+        if (bad && a.errflag) atomicOr(a.errflag, 1);
+        return;  // Sigma_out was written by k_dense_gemm
+    }
     if (!riccati) {
         // Sigma is not touched by this call: copy the tile through so that the ping-pong parity of all
         // filters of the batch stays in step.

@@ -147,7 +147,8 @@ int eqf_set_dense_propagate(eqf_filter* f, int on);
 #define EQF_PROF_FINISH 4
 #define EQF_PROF_DOWNDATE 5
 #define EQF_PROF_CHURN 6
-#define EQF_PROF_CLASSES 7
+#define EQF_PROF_DENSE 7 /* k_dense_build + the two k_dense_gemm launches of the dense Riccati backend */
+#define EQF_PROF_CLASSES 8
 int eqf_profile_enable(eqf_filter* f, int on);
 int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_ms);
 const char* eqf_profile_class_name(int cls);

@@ -275,3 +275,32 @@ def test_cpp_facade_matches_the_oracle(oracle_lib):
     assert abs(t - fo.getTime()) < 1e-9
     assert np.abs(np.array(pos) - e["x"]).max() < 2e-6 and np.abs(np.array(q) - e["q"]).max() < 2e-6  # printed with 6 digits
     assert abs(fro / np.linalg.norm(fo.stateCovariance()) - 1) < 1e-6
+
+
+@pytest.mark.parametrize("N", [7, 40])
+def test_dense_mfma_riccati_backend_equals_structured(oracle_lib, hip, N):
+    """BASELINE cfg 3's path: F formed densely, (F Sigma) F^T on v_mfma_f64_16x16x4_f64 -- the operation sequence the
+    reference executes -- against the block-structured kernel and the oracle on the same stream."""
+    from eqf_vio_amd import synth
+
+    st = synth.make_stream(N, duration=0.5)
+    d = synth.template_settings_dict()
+    a = hip.FilterBatch(d, capacity=N, batch=1)
+    b = hip.FilterBatch(d, capacity=N, batch=1)
+    b.set_dense_propagate(True)
+    fo = oracle_lib.OracleFilter(d)
+    for kind, k in st.events():
+        if kind == "imu":
+            r = st.imu[k]
+            a.process_imu([r[0]], r[1:4], r[4:7])
+            b.process_imu([r[0]], r[1:4], r[4:7])
+            fo.processIMUData(r[0], r[1:4], r[4:7])
+        else:
+            a.process_vision([st.vision_stamps[k]], st.ids, st.bearings[k])
+            b.process_vision([st.vision_stamps[k]], st.ids, st.bearings[k])
+            fo.processVisionData(st.vision_stamps[k], st.ids, st.bearings[k])
+    assert rel_fro(b.sigma(), a.sigma()) < 1e-9
+    assert rel_fro(b.sigma(), fo.stateCovariance()) < SIGMA_TOL
+    ea, eb = a.state_estimate(), b.state_estimate()
+    assert np.abs(ea["x"] - eb["x"]).max() < 1e-9 and np.abs(ea["q"] - eb["q"]).max() < 1e-9
+    assert b.device_error() == 0
