@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--dense-propagate", action="store_true", help="Riccati step as dense F Sigma F^T on MFMA (BASELINE cfg 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -133,6 +135,60 @@ def roofline(fb, events, N, B, precision):
     return out, rows
 
 
+def pmc_traffic(args, kernel):
+    """HBM bytes per launch of `kernel` from rocprofv3 PMC counters, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
+    WRITE_SIZE in SEPARATE passes (kernel-trace only), values in KiB.  On gfx950 FETCH_SIZE under-reports coalesced
+    reads by 2x; the factor is calibrated in the same pass on k_sigma_export, which reads exactly n^2 doubles."""
+    import csv
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not found"
+    out = {}
+    note = ""
+    n = 11 + 3 * args.landmarks
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="eqf_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "b", "--", sys.executable,
+               os.path.abspath(__file__), "--steps", "220", "--warmup", "110", "--landmarks", str(args.landmarks), "--filters-per-gpu",
+               str(args.filters_per_gpu), "--precision", args.precision, "--pmc-child"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=300, check=True)
+            path = None
+            for root, _, files in os.walk(d):
+                for fn in files:
+                    if fn.endswith("counter_collection.csv"):
+                        path = os.path.join(root, fn)
+            vals, calib = [], []
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    name = row["Kernel_Name"]
+                    if kernel in name:
+                        vals.append(float(row["Counter_Value"]))
+                    if "k_sigma_export" in name:
+                        calib.append(float(row["Counter_Value"]))
+            out[counter] = (statistics.mean(vals) * 1024.0 if vals else None, calib)
+        except Exception as e:  # profiling is best effort: never fail the bench because of it
+            return None, f"{counter} pass failed: {type(e).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch, calib = out["FETCH_SIZE"]
+    write, _ = out["WRITE_SIZE"]
+    if fetch is None or write is None:
+        return None, "kernel not found in the counter trace"
+    esz = 8 if args.precision == "f64" else 4
+    factor = 2.0  # MI355X_MICROARCH.md, section HBM
+    if calib:
+        factor = (n * n * esz) / (statistics.mean(calib) * 1024.0)
+        note = f"FETCH_SIZE x{factor:.2f} (calibrated on k_sigma_export's known {n}x{n} read)"
+    return fetch * factor + write, note
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -219,10 +275,19 @@ def main():
         "device_error_flag": err,
         "sigma_fro_filter0": float(res[0, 7]) if res is not None else None,
     }
+    if args.pmc_child:
+        fb.sigma(0)  # one k_sigma_export launch: known byte count, calibrates FETCH_SIZE
+        return
     if rank == 0 and not args.no_roofline:
         rl, rows = roofline(fb, timed, N, B, args.precision)
         line["roofline"] = rl
         line["kernels"] = rows
+        if rl is not None and world == 1 and not args.no_traffic:
+            del fb  # free the GPU for the profiled child runs
+            traffic, note = pmc_traffic(args, rl["kernel"])
+            rl["traffic"] = traffic
+            if note:
+                rl["traffic_note"] = note
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(N)
     if dist is not None:
