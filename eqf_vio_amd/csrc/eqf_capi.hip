@@ -319,7 +319,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     const int mp = roundUp(sDim(Nmax), kNB), nep = roundUp(eDim(Nmax), kNB);
     const int nv = kLm0 + 3 * Nmax;
     // prep
-    const int nvPad = roundUp(nv, 16);
+    const int nvPad = roundUp(std::min(nv, kLm0 + 3 * kPrepLmChunk), 16);
     const size_t perWave = size_t(2) * nvPad * sizeof(double);
     int wpb = int(std::min<size_t>(4, (150 * 1024) / perWave));
     if (wpb < 1) return EQF_ERR_CAPACITY;

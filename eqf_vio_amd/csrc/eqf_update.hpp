@@ -133,7 +133,8 @@ EQF_DI void liftRows(const LiftCommon& L, quat Qq, double Qa, d3 p0, double* Z /
 // Sigma columns: coalesced 3-row reads), the two rows of S and of V; extra workgroups copy Sigma_e.
 // grid.x = lmBlocks + eBlocks, grid.y = B, block = 256 (4 waves = 4 landmarks).
 // ------------------------------------------------------------------------------------------------
-// Dynamic LDS: wpb (waves per workgroup) x 2 rows x nvPad doubles for the C*Sigma rows.
+// Dynamic LDS: wpb (waves per workgroup) x 2 rows x nvPad doubles for one column chunk of the C*Sigma rows.
+constexpr int kPrepLmChunk = 512;
 template <typename T>
 __global__ __launch_bounds__(256) void k_update_prep(UpdArgs a, int lmBlocks, int wpb, int nvPad) {
     const int b = blockIdx.y;
@@ -183,7 +184,8 @@ __global__ __launch_bounds__(256) void k_update_prep(UpdArgs a, int lmBlocks, in
         return;
     }
 
-    // ---- landmark waves
+    // ---- landmark waves.  The two C*Sigma rows of a landmark are staged through LDS in column chunks that cover
+    // kPrepLmChunk landmarks each (one chunk up to N = 512; larger N loops), so LDS use does not grow with N.
     extern __shared__ __attribute__((aligned(16))) double sCSraw[];  // [wpb][2][nvPad]
     double* sCS0 = sCSraw + (long long)(2 * wv) * nvPad;
     double* sCS1 = sCS0 + nvPad;
@@ -222,53 +224,57 @@ __global__ __launch_bounds__(256) void k_update_prep(UpdArgs a, int lmBlocks, in
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int c = 0; c < 6; ++c) V[6 * r + c] = C[3 * r] * Z[c] + C[3 * r + 1] * Z[6 + c] + C[3 * r + 2] * Z[12 + c];
-        // rows 2i, 2i+1 of C*Sigma: lanes stride the columns
-        const T* s0 = Sin + (long long)(kLm0 + 3 * i) * ld;
-        for (int col = lane; col < nv; col += 64) {
-            const double v0 = (double)s0[col], v1 = (double)s0[ld + col], v2 = (double)s0[2 * ld + col];
-            sCS0[col] = C[0] * v0 + C[1] * v1 + C[2] * v2;
-            sCS1[col] = C[3] * v0 + C[4] * v1 + C[5] * v2;
-        }
     }
-    __syncthreads();
-    if (valid) {
-        // right-hand sides: [C Sigma (delta in column 11) | V], zero padded to ycp
-        for (int col = lane; col < ycp; col += 64) {
-            double v0 = 0.0, v1 = 0.0;
-            if (col == 11) {
-                v0 = dl[0];
-                v1 = dl[1];
-            } else if (col < nv) {
-                v0 = sCS0[col];
-                v1 = sCS1[col];
-            } else if (col < nv + 6) {
-                v0 = V[col - nv];
-                v1 = V[6 + col - nv];
+    const T* s0 = Sin + (long long)(kLm0 + 3 * (valid ? i : 0)) * ld;
+    for (int q0 = 0; q0 < N; q0 += kPrepLmChunk) {
+        const int q1 = min(N, q0 + kPrepLmChunk);
+        const int colLo = (q0 == 0) ? 0 : kLm0 + 3 * q0, colHi = kLm0 + 3 * q1;
+        if (valid) {
+            // rows 2i, 2i+1 of C*Sigma for this column chunk: lanes stride the columns (coalesced 3-row reads)
+            for (int col = colLo + lane; col < colHi; col += 64) {
+                const double v0 = (double)s0[col], v1 = (double)s0[ld + col], v2 = (double)s0[2 * ld + col];
+                sCS0[col - colLo] = C[0] * v0 + C[1] * v1 + C[2] * v2;
+                sCS1[col - colLo] = C[3] * v0 + C[4] * v1 + C[5] * v2;
             }
-            YW[(long long)(2 * i) * a.ldY + col] = v0;
-            YW[(long long)(2 * i + 1) * a.ldY + col] = v1;
         }
-        // S rows: S[2i+r][2j+s] = sum_c CS[r][12+3j+c] C_j[s][c]  (+ measurementVariance on the diagonal)
-        for (int j = lane; j < mp / 2; j += 64) {
-            double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
-            if (j < N) {
+        __syncthreads();
+        if (valid) {
+            for (int col = colLo + lane; col < colHi; col += 64) {  // right-hand sides: C Sigma, delta in column 11
+                const bool isz = (col == 11);
+                YW[(long long)(2 * i) * a.ldY + col] = isz ? dl[0] : sCS0[col - colLo];
+                YW[(long long)(2 * i + 1) * a.ldY + col] = isz ? dl[1] : sCS1[col - colLo];
+            }
+            // S[2i+r][2j+s] = sum_c CS[r][12+3j+c] C_j[s][c]  (+ measurementVariance on the diagonal)
+            for (int j = q0 + lane; j < q1; j += 64) {
                 double Cj[6];
 #pragma unroll
                 for (int q = 0; q < 6; ++q) Cj[q] = lmc[(long long)q * cap + j];
-                const double* c0 = &sCS0[kLm0 + 3 * j];
-                const double* c1 = &sCS1[kLm0 + 3 * j];
-                s00 = c0[0] * Cj[0] + c0[1] * Cj[1] + c0[2] * Cj[2];
-                s01 = c0[0] * Cj[3] + c0[1] * Cj[4] + c0[2] * Cj[5];
-                s10 = c1[0] * Cj[0] + c1[1] * Cj[1] + c1[2] * Cj[2];
-                s11 = c1[0] * Cj[3] + c1[1] * Cj[4] + c1[2] * Cj[5];
+                const double* c0 = &sCS0[kLm0 + 3 * j - colLo];
+                const double* c1 = &sCS1[kLm0 + 3 * j - colLo];
+                double s00 = c0[0] * Cj[0] + c0[1] * Cj[1] + c0[2] * Cj[2];
+                const double s01 = c0[0] * Cj[3] + c0[1] * Cj[4] + c0[2] * Cj[5];
+                const double s10 = c1[0] * Cj[0] + c1[1] * Cj[1] + c1[2] * Cj[2];
+                double s11 = c1[0] * Cj[3] + c1[1] * Cj[4] + c1[2] * Cj[5];
                 if (j == i) {
                     s00 += a.prm.measurementVariance;
                     s11 += a.prm.measurementVariance;
                 }
+                double* r0p = SA + (long long)(2 * i) * a.ldS + 2 * j;
+                r0p[0] = s00; r0p[1] = s01;
+                r0p[a.ldS] = s10; r0p[a.ldS + 1] = s11;
             }
+        }
+        __syncthreads();
+    }
+    const int nvv = kLm0 + 3 * N;
+    if (valid) {
+        for (int col = nvv + lane; col < ycp; col += 64) {  // V (6 columns) and zero padding
+            YW[(long long)(2 * i) * a.ldY + col] = (col < nvv + 6) ? V[col - nvv] : 0.0;
+            YW[(long long)(2 * i + 1) * a.ldY + col] = (col < nvv + 6) ? V[6 + col - nvv] : 0.0;
+        }
+        for (int j = N + lane; j < mp / 2; j += 64) {  // padding columns of S
             double* r0p = SA + (long long)(2 * i) * a.ldS + 2 * j;
-            r0p[0] = s00; r0p[1] = s01;
-            r0p[a.ldS] = s10; r0p[a.ldS + 1] = s11;
+            r0p[0] = r0p[1] = r0p[a.ldS] = r0p[a.ldS + 1] = 0.0;
         }
         if (lane == 0 && a.dbgDelta) {
             a.dbgDelta[(long long)b * 2 * cap + 2 * i] = dl[0];
