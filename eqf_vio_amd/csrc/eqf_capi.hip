@@ -83,6 +83,9 @@ struct eqf_filter {
     std::vector<char> init;
     int densePropagate = 0;
     void *dF = nullptr, *dG = nullptr, *dBn = nullptr;  // dense backend: F, G = F Sigma, Bn (n x 6)
+    void* dBlk = nullptr;          // split propagate path: per-landmark blocks [B][cap][27] (T)
+    CommonLds* dBlkCommon = nullptr;
+    int splitPropagate = -1;       // -1 heuristic, 0 never, 1 always (EQF_SPLIT_PROPAGATE)
     // profiling
     bool prof = false;
     std::vector<ProfPair> profPairs;
@@ -262,11 +265,26 @@ int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, con
         });
         if (rc) return rc;
     }
+    a.blk = f->dBlk;
+    a.blkCommon = f->dBlkCommon;
+    // Split path (builder + lean streaming kernel) when there are enough tiles for occupancy to matter; a single small
+    // filter keeps the fused single-launch kernel (one kernel boundary less per step).
+    const bool split = f->splitPropagate >= 0 ? f->splitPropagate != 0 : (long long)a.NT * a.NT * f->B >= 1024;
     rc = profiled(f, EQF_PROF_PROPAGATE, [&] {
-        if (f->precision == EQF_PRECISION_F32)
-            hipLaunchKernelGGL(k_propagate<float>, grid, block, 0, f->stream, a);
-        else
-            hipLaunchKernelGGL(k_propagate<double>, grid, block, 0, f->stream, a);
+        if (split) {
+            const dim3 bgrid((std::max(1, maxN(f)) + 63) / 64, f->B);
+            if (f->precision == EQF_PRECISION_F32) {
+                hipLaunchKernelGGL(k_build_blocks<float>, bgrid, dim3(64), 0, f->stream, a);
+                hipLaunchKernelGGL((k_propagate<float, true>), grid, block, 0, f->stream, a);
+            } else {
+                hipLaunchKernelGGL(k_build_blocks<double>, bgrid, dim3(64), 0, f->stream, a);
+                hipLaunchKernelGGL((k_propagate<double, true>), grid, block, 0, f->stream, a);
+            }
+        } else if (f->precision == EQF_PRECISION_F32) {
+            hipLaunchKernelGGL((k_propagate<float, false>), grid, block, 0, f->stream, a);
+        } else {
+            hipLaunchKernelGGL((k_propagate<double, false>), grid, block, 0, f->stream, a);
+        }
     });
     if (rc) return rc;
     HIPC(hipGetLastError());
@@ -590,7 +608,7 @@ void freeAll(eqf_filter* f) {
     for (void* p : {(void*)f->p0, (void*)f->lmc, (void*)f->SA, (void*)f->SL, (void*)f->YW, (void*)f->YO, (void*)f->EA, (void*)f->EL, (void*)f->ZW,
              (void*)f->ZO, (void*)f->dbgDelta, (void*)f->dbgGamma, (void*)f->dbgGammaTot, (void*)f->red, (void*)f->errflag, (void*)f->dMap,
              (void*)f->dNewN, (void*)f->dPerm, (void*)f->dSrc, (void*)f->dChord, (void*)f->dDepth2, (void*)f->dScratch, (void*)f->dMeas,
-             (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn})
+             (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn, f->dBlk, (void*)f->dBlkCommon})
         hipFree(p);
     for (void* p : {(void*)f->hMap, (void*)f->hNewN, (void*)f->hPerm, (void*)f->hSrc, (void*)f->hChord, (void*)f->hDepth2, (void*)f->hMeas,
              (void*)f->hOut, (void*)f->hRing})
@@ -710,6 +728,9 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     chk(dmalloc(&f->dScratch, (size_t)kLmRec * cap * B)); chk(dmalloc(&f->dMeas, (size_t)3 * cap * B));
     chk(dmalloc(&f->dOut, (size_t)f->nTot * f->nTot + 16));
     chk(dmalloc(&f->dRing, (size_t)kRing * B));
+    if (!rc && hipMalloc(&f->dBlk, f->esz * (size_t)27 * cap * B) != hipSuccess) rc = EQF_ERR_HIP;
+    chk(dmalloc(&f->dBlkCommon, B));
+    if (const char* e = std::getenv("EQF_SPLIT_PROPAGATE")) f->splitPropagate = std::atoi(e);
     chk(hmalloc(&f->hMap, (size_t)cap * B)); chk(hmalloc(&f->hNewN, B)); chk(hmalloc(&f->hPerm, (size_t)cap * B));
     chk(hmalloc(&f->hSrc, cap)); chk(hmalloc(&f->hChord, (size_t)cap * B)); chk(hmalloc(&f->hDepth2, (size_t)cap * B));
     chk(hmalloc(&f->hMeas, (size_t)3 * cap * B)); chk(hmalloc(&f->hOut, (size_t)f->nTot * f->nTot + 16));

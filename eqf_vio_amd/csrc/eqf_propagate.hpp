@@ -20,6 +20,12 @@
 
 namespace eqf {
 
+// LDS image of the few common values the base-panel code of waves 1..3 needs
+struct CommonLds {
+    double T;
+    double Bg[6], Bvw[9], RA[9], Avg[6];
+};
+
 struct PropArgs {
     const Glob* gin;
     Glob* gout;
@@ -35,6 +41,8 @@ struct PropArgs {
     int cap, ld, NT;
     int isImu;      // processIMUData (bias subtraction, lazy init, ZOH bookkeeping)
     int doRiccati;  // VIOFilter.cpp:160
+    void* blk;          // [B][cap][27] (T) per-landmark blocks D, Lw, Lv written by k_build_blocks (split path)
+    CommonLds* blkCommon;  // [B] common values written by k_build_blocks
     int sigmaExternal;  // the Riccati step of this call is done by the dense MFMA backend: touch no Sigma here
     int dbg;        // development only: bit0 skip common+blocks, bit1 skip landmark step, bit2 skip scalar step, bit3 skip Sigma math
     Params prm;
@@ -243,13 +251,10 @@ EQF_DI void stepGlobal(const Glob& G, Glob* out, const ImuRec& r, const PropArgs
     }
 }
 
-// LDS image of the few common values the base-panel code of waves 1..3 needs
-struct CommonLds {
-    double T;
-    double Bg[6], Bvw[9], RA[9], Avg[6];
-};
-
-template <typename T>
+// PRE = false: fused kernel (single small filter: one launch per step, scalar chain on waves 0..2).
+// PRE = true : streaming kernel of the split path; the blocks, the group step and the scalar state were produced by
+//              k_build_blocks, so this instantiation carries no fp64 scalar chain (few registers, high occupancy).
+template <typename T, bool PRE>
 __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
@@ -285,6 +290,19 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     int bad = 0;
 
     const int wv = tid >> 6, ln = tid & 63;
+    if (PRE) {
+        if (riccati && tid < 32) {
+            const int i = (tid < 16) ? I0 + tid : J0 + tid - 16;
+            const T* bp = static_cast<const T*>(a.blk) + ((long long)b * cap + i) * 27;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                sD[tid][k] = (i < N) ? bp[k] : (T)0;
+                sLw[tid][k] = (i < N) ? bp[9 + k] : (T)0;
+                sLv[tid][k] = (i < N) ? bp[18 + k] : (T)0;
+            }
+        }
+        if (riccati && tid == 32) sC = a.blkCommon[b];
+    } else {
     if (wv == 0 && riccati && !(a.dbg & 1)) {
         // ---- wave 0: common quantities of the linearisation + this tile's per-landmark blocks
         StepCommon c;
@@ -352,6 +370,7 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
         }
     }
 
+    }
     if (!riccati && a.sigmaExternal && step && a.doRiccati) {
         if (bad && a.errflag) atomicOr(a.errflag, 1);
         return;  // Sigma_out was written by k_dense_gemm
@@ -556,6 +575,70 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
                 acc += Tt * nz;
             }
             Sout[(long long)rr * ld + cc] = acc;  // row/col 11 stay zero
+        }
+    }
+    if (bad && a.errflag) atomicOr(a.errflag, 1);
+}
+
+// Builder of the split path: one lane per landmark.  Writes the per-landmark blocks (as T), the stepped group
+// landmarks Q_i, and -- workgroup 0 -- the scalar state and the common values of the base panels.
+template <typename T>
+__global__ __launch_bounds__(64) void k_build_blocks(PropArgs a) {
+    const int b = blockIdx.y, lane = threadIdx.x;
+    const int i = blockIdx.x * 64 + lane;
+    const int cap = a.cap;
+    const Glob& G = a.gin[b];
+    const ImuRec& r = a.recs ? a.recs[b] : a.inl;
+    const int N = G.N;
+    const double dt0 = r.stamp - G.curTime;
+    const bool step = (G.curTime >= 0) && (dt0 > 0);
+    const bool riccati = step && a.doRiccati && !a.sigmaExternal;
+    const double* p0 = a.p0 + (long long)b * 3 * cap;
+    const double* Qin = a.Qin + (long long)b * 5 * cap;
+    double* Qout = a.Qout + (long long)b * 5 * cap;
+    int bad = 0;
+    StepCommon c;
+    c.step = 0;
+    if (step) stepCommon(G, r, a, c, kPartBase | kPartRicc | kPartLift, &bad);
+    if (i < N) {
+        const quat Qq = quat{Qin[i], Qin[cap + i], Qin[2 * cap + i], Qin[3 * cap + i]};
+        const double Qa = Qin[4 * cap + i];
+        const d3 q0 = mk3(p0[i], p0[cap + i], p0[2 * cap + i]);
+        if (riccati) {
+            const LmBlocks blk = buildBlocks(c, Qq, Qa, q0);
+            T* bp = static_cast<T*>(a.blk) + ((long long)b * cap + i) * 27;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                bp[k] = (T)blk.D.a[k];
+                bp[9 + k] = (T)blk.Lw.a[k];
+                bp[18 + k] = (T)blk.Lv.a[k];
+            }
+        }
+        quat Qo = Qq;
+        double ao = Qa;
+        if (step) stepLandmark(c, a, Qq, Qa, q0, &Qo, &ao, &bad);
+        Qout[i] = Qo.w; Qout[cap + i] = Qo.x; Qout[2 * cap + i] = Qo.y; Qout[3 * cap + i] = Qo.z;
+        Qout[4 * cap + i] = ao;
+    }
+    if (blockIdx.x == 0) {
+        const double* src = reinterpret_cast<const double*>(&G);
+        double* dst = reinterpret_cast<double*>(a.gout + b);
+        if (lane < (int)(sizeof(Glob) / 8)) dst[lane] = src[lane];
+        if (lane == 0) stepGlobal(G, a.gout + b, r, a, c, &bad);
+        if (lane == 1 && riccati) {
+            CommonLds cl;
+            cl.T = c.T;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                cl.Bg[k] = c.Bg[k];
+                cl.Avg[k] = c.Avg[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                cl.Bvw[k] = c.Bvw.a[k];
+                cl.RA[k] = c.RA.a[k];
+            }
+            a.blkCommon[b] = cl;
         }
     }
     if (bad && a.errflag) atomicOr(a.errflag, 1);

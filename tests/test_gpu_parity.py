@@ -304,3 +304,26 @@ def test_dense_mfma_riccati_backend_equals_structured(oracle_lib, hip, N):
     ea, eb = a.state_estimate(), b.state_estimate()
     assert np.abs(ea["x"] - eb["x"]).max() < 1e-9 and np.abs(ea["q"] - eb["q"]).max() < 1e-9
     assert b.device_error() == 0
+
+
+def test_split_propagate_path_equals_fused(hip, monkeypatch):
+    """Large tile counts (batch / large N) use a builder kernel + a lean streaming kernel instead of the fused one;
+    both must give the same numbers (EQF_SPLIT_PROPAGATE forces either path)."""
+    from eqf_vio_amd import synth
+
+    N = 40
+    st = synth.make_stream(N, duration=0.5)
+    d = synth.template_settings_dict()
+    out = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EQF_SPLIT_PROPAGATE", mode)
+        f = hip.FilterBatch(d, capacity=N, batch=1)
+        f.stream_upload(st.imu, st.vision_stamps, st.ids, st.bearings)
+        for kind, k in st.events():
+            (f.stream_imu if kind == "imu" else f.stream_vision)(k)
+        out.append((f.sigma(), f.state_estimate(), f.bias()))
+        assert f.device_error() == 0
+    # same formulas, differently compiled (FMA contraction): agreement to rounding amplified by cond(Sigma) ~ 1e7
+    assert rel_fro(out[1][0], out[0][0]) < 1e-9
+    assert all(np.abs(out[0][1][k] - out[1][1][k]).max() < 1e-9 for k in out[0][1])
+    assert np.abs(out[0][2] - out[1][2]).max() < 1e-9
