@@ -197,13 +197,13 @@ def main():
     import torch
 
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: RCCL path even for a single rank
         import torch.distributed as dist_
 
         dist = dist_
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = local_rank if world > 1 else 0
+    device = local_rank
 
     from eqf_vio_amd import binding, synth
 

@@ -30,7 +30,7 @@ def pack(streams):
 
 def scatter_streams(dist, rank, world, N, filters_per_rank, nevents, device=None):
     """Returns (imu, vst, bear, events) of THIS rank's filters as numpy arrays.  dist=None: single process."""
-    if dist is None or world == 1:
+    if dist is None:
         streams, events = build_streams(N, filters_per_rank, 0, nevents)
         return (*pack(streams), events)
     import torch
@@ -58,7 +58,7 @@ def scatter_streams(dist, rank, world, N, filters_per_rank, nevents, device=None
 
 def gather_results(dist, rank, world, res, device=None):
     """res: (B, k) float64 per-filter results of this rank -> (B*world, k) on rank 0 (None elsewhere)."""
-    if dist is None or world == 1:
+    if dist is None:
         return res
     import torch
 
