@@ -92,6 +92,7 @@ struct eqf_filter {
     std::vector<hipEvent_t> evPool;
     long long profCount[EQF_PROF_CLASSES] = {};
     double profMs[EQF_PROF_CLASSES] = {};
+    double profOverheadMs = 0.0;  // elapsed time of an EMPTY event bracket (calibrated when profiling is switched on)
 };
 
 namespace {
@@ -1123,8 +1124,20 @@ int eqf_profile_enable(eqf_filter* f, int on) {
     }
     f->prof = on != 0;
     if (on) {
+        // calibrate the bracket itself: two event records with nothing in between still measure a few microseconds,
+        // which would otherwise be charged to every kernel
         std::fill(std::begin(f->profCount), std::end(f->profCount), 0);
         std::fill(std::begin(f->profMs), std::end(f->profMs), 0.0);
+        f->profOverheadMs = 0.0;
+        for (int i = 0; i < 64; ++i) {
+            int rc = profiled(f, EQF_PROF_CHURN, [] {});
+            if (rc) return rc;
+        }
+        int rc = profDrain(f);
+        if (rc) return rc;
+        f->profOverheadMs = f->profMs[EQF_PROF_CHURN] / 64.0;
+        f->profCount[EQF_PROF_CHURN] = 0;
+        f->profMs[EQF_PROF_CHURN] = 0.0;
     }
     return EQF_OK;
 }
@@ -1134,7 +1147,7 @@ int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_m
     int rc = profDrain(f);
     if (rc) return rc;
     if (launches) *launches = f->profCount[cls];
-    if (total_ms) *total_ms = f->profMs[cls];
+    if (total_ms) *total_ms = std::max(0.0, f->profMs[cls] - f->profOverheadMs * f->profCount[cls]);
     return EQF_OK;
 }
 
