@@ -236,10 +236,6 @@ int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, con
     a.NT = std::max(1, (maxN(f) + kTileLm - 1) / kTileLm);
     a.isImu = isImu ? 1 : 0;
     a.doRiccati = doRiccati ? 1 : 0;
-    {
-        static const int dbg = std::getenv("EQF_DEBUG_PROP") ? std::atoi(std::getenv("EQF_DEBUG_PROP")) : 0;
-        a.dbg = dbg;
-    }
     a.prm = f->prm;
     const dim3 grid(a.NT * a.NT, f->B), block(256);
     int rc = EQF_OK;
@@ -362,10 +358,6 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     cE.g = a.g; cE.A = f->EA; cE.D = f->EL; cE.W = f->ZW; cE.WO = f->ZO;
     cE.ldA = f->ldE; cE.ldW = f->ldZ; cE.strideA = f->strideE; cE.strideD = f->strideE; cE.strideW = f->strideZ;
     cE.kind = 1; cE.nbMax = nep / kNB; cE.wtMax = 1;
-    {
-        static const int dbg = std::getenv("EQF_DEBUG_CHOL") ? std::atoi(std::getenv("EQF_DEBUG_CHOL")) : 0;
-        cS.dbg = cE.dbg = dbg;
-    }
     const int steps = std::max(cS.nbMax, cE.nbMax);
     const int nblk = cS.nbMax * cS.nbMax + cS.wtMax * cS.nbMax + cE.nbMax * cE.nbMax + cE.wtMax * cE.nbMax;
     for (int k = 0; k < steps; ++k) {

@@ -44,7 +44,6 @@ struct PropArgs {
     void* blk;          // [B][cap][27] (T) per-landmark blocks D, Lw, Lv written by k_build_blocks (split path)
     CommonLds* blkCommon;  // [B] common values written by k_build_blocks
     int sigmaExternal;  // the Riccati step of this call is done by the dense MFMA backend: touch no Sigma here
-    int dbg;        // development only: bit0 skip common+blocks, bit1 skip landmark step, bit2 skip scalar step, bit3 skip Sigma math
     Params prm;
 };
 
@@ -303,7 +302,7 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
         }
         if (riccati && tid == 32) sC = a.blkCommon[b];
     } else {
-    if (wv == 0 && riccati && !(a.dbg & 1)) {
+    if (wv == 0 && riccati) {
         // ---- wave 0: common quantities of the linearisation + this tile's per-landmark blocks
         StepCommon c;
         stepCommon(G, r, a, c, kPartBase | kPartRicc, &bad);
@@ -346,7 +345,7 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
                 const double Qa = Qin[4 * cap + i];
                 quat Qo = Qq;
                 double ao = Qa;
-                if (step && !(a.dbg & 2)) {
+                if (step) {
                     StepCommon c;
                     stepCommon(G, r, a, c, kPartBase | kPartLift, &bad);
                     stepLandmark(c, a, Qq, Qa, mk3(p0[i], p0[cap + i], p0[2 * cap + i]), &Qo, &ao, &bad);
@@ -362,7 +361,7 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
         const double* src = reinterpret_cast<const double*>(&G);
         double* dst = reinterpret_cast<double*>(a.gout + b);
         if (ln < (int)(sizeof(Glob) / 8)) dst[ln] = src[ln];
-        if (ln == 0 && !(a.dbg & 4)) {
+        if (ln == 0) {
             StepCommon c;
             c.step = 0;
             if (step) stepCommon(G, r, a, c, kPartBase, &bad);
@@ -428,7 +427,6 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
             for (int cc = 0; cc < 3; ++cc) S[3 * rr + cc] = src[(long long)rr * ld + cc];
     }
     __syncthreads();
-    if (a.dbg & 8) return;
     if (tid < 132) {
         const int rr = tid / 12, cc = tid % 12;
         // F_bb = I + T * [[0,0,0,0],[-B_g^w,0,0,0],[-B_v^w,-R_A, A_vg, 0]]   (VIOFilter.cpp:178-183)

@@ -401,7 +401,6 @@ struct ChainArgs {
     int kind;     // 0: S-chain, 1: E-chain
     int nbMax;    // tiles per edge launched for A
     int wtMax;    // right-hand-side column tiles launched
-    int dbg;
 };
 
 // per-filter chain sizes
