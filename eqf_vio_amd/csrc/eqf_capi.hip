@@ -360,9 +360,14 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     cE.kind = 1; cE.nbMax = nep / kNB; cE.wtMax = 1;
     const int steps = std::max(cS.nbMax, cE.nbMax);
     const int nblk = cS.nbMax * cS.nbMax + cS.wtMax * cS.nbMax + cE.nbMax * cE.nbMax + cE.wtMax * cE.nbMax;
+    // Panel blocks by explicit inverse + MFMA when the launch is throughput-bound (many tiles), by per-workgroup forward
+    // substitution when it is latency-bound (one small filter): see k_chol_step.
+    const bool inverse = (long long)nblk * B >= 2048;
     for (int k = 0; k < steps; ++k) {
-        rc = profiled(f, EQF_PROF_CHOL_STEP,
-            [&] { hipLaunchKernelGGL(k_chol_step, dim3(nblk, B), dim3(256), 0, f->stream, cS, cE, k, f->errflag); });
+        rc = profiled(f, EQF_PROF_CHOL_STEP, [&] {
+            if (inverse) hipLaunchKernelGGL(k_chol_step<true>, dim3(nblk, B), dim3(256), 0, f->stream, cS, cE, k, f->errflag);
+            else hipLaunchKernelGGL(k_chol_step<false>, dim3(nblk, B), dim3(256), 0, f->stream, cS, cE, k, f->errflag);
+        });
         if (rc) return rc;
     }
     const int colBlocks = (nv + 6 + 63) / 64;

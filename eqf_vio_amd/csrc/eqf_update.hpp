@@ -434,12 +434,18 @@ EQF_DI void accToLds(const f64x4& acc, double (*M)[kLdsP], int tm, int tn, int l
 }
 
 // Blocked right-looking Cholesky with right-hand sides and one-step look-ahead; one launch per block column k,
-// both chains in the same launch.  Entering launch k, D[k] holds L_kk and W_k = L_kk^-1 (from launch k-1's
-// diagonal workgroup; at k = 0 every workgroup derives them itself), so the panel blocks are plain products
-//   L_rk = A_rk W_k^T,  Y_k = W_k R_k           (v_mfma_f64_16x16x4_f64)
-// and only ONE workgroup per chain runs the serial 32x32 factorisation, for the NEXT column:
-//   tile (r,c), r >= c > k :  A_rc -= L_rk L_ck^T ; if r == c == k+1: potrf + inverse of the updated tile -> D[k+1]
+// both chains in the same launch.  Entering launch k, D[k] holds the factor of the k-th diagonal block (from launch
+// k-1's diagonal workgroup; at k = 0 every workgroup derives it itself).  Only ONE workgroup per chain runs the serial
+// 32x32 factorisation, for the NEXT column:
+//   tile (r,c), r >= c > k :  A_rc -= L_rk L_ck^T ; if r == c == k+1: potrf of the updated tile -> D[k+1]
 //   rhs tile (t,c), c == k :  Y_k -> WO ;            c > k: R_c -= L_ck Y_k
+// Two ways to form the panel blocks L_rk = A_rk L_kk^-T, Y_k = L_kk^-1 R_k:
+//   INVERSE = true  (throughput: batches, large N): D[k] also holds W_k = L_kk^-1 and the panel blocks are products
+//                   on v_mfma_f64_16x16x4_f64; the diagonal workgroup pays the explicit inverse (+3.9 us on its chain).
+//   INVERSE = false (latency: one small filter): every workgroup solves its own panel blocks by forward substitution
+//                   (one lane per row / column) WHILE the diagonal workgroup factors the next block, so a launch
+//                   costs max(potrf, solve) instead of potrf + inverse.
+template <bool INVERSE>
 __global__ __launch_bounds__(256) void k_chol_step(ChainArgs c0, ChainArgs c1, int k, int* errflag) {
     const int b = blockIdx.y;
     const int n0 = c0.nbMax * c0.nbMax + c0.wtMax * c0.nbMax;
@@ -472,50 +478,90 @@ __global__ __launch_bounds__(256) void k_chol_step(ChainArgs c0, ChainArgs c1, i
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tm = wv >> 1, tn = wv & 1;
 
-    __shared__ double sWk[kNB][kLdsP];  // W_k = L_kk^-1
+    __shared__ double sWk[kNB][kLdsP];  // INVERSE: W_k = L_kk^-1 ; k = 0: A_00
     __shared__ double sP[kNB][kLdsP];   // A_rk -> L_rk   (A tiles)   /  R_k -> Y_k (rhs tiles)
     __shared__ double sQ[kNB][kLdsP];   // A_ck -> L_ck
-    __shared__ __attribute__((aligned(16))) double sLT[kNB][kLtP];
-    __shared__ double sRd[kNB];
+    __shared__ __attribute__((aligned(16))) double sLT[kNB][kLtP];  // L_kk^T
+    __shared__ double sRd[kNB];                                     // 1 / diag(L_kk)
     int bad = 0;
     const bool diagNext = !isW && r == c && c == k + 1;  // this workgroup factors the next diagonal block
     const bool needQ = c > k;
+    const double* Dk = D + ((long long)k * 2) * kNB * kNB;  // [0]: L_kk^T (sLT image), [1]: W_k or (row 0) 1/diag
 
     // ---- operands
     for (int e = tid; e < kNB * kNB; e += 256) {
         const int rr = e / kNB, cc = e % kNB;
         if (k == 0) sWk[rr][cc] = A[(long long)rr * ldA + cc];  // A_00: factored below by every workgroup
-        else sWk[rr][cc] = D[((long long)k * 2 + 1) * kNB * kNB + rr * kNB + cc];
+        else if (INVERSE) sWk[rr][cc] = Dk[kNB * kNB + rr * kNB + cc];
+        else sLT[rr][cc] = Dk[rr * kNB + cc];
         if (isW) sP[rr][cc] = W[(long long)(k * kNB + rr) * ldW + r * kNB + cc];
         else if (r != c) sP[rr][cc] = A[(long long)(r * kNB + rr) * ldA + k * kNB + cc];
         if (needQ) sQ[rr][cc] = A[(long long)(c * kNB + rr) * ldA + k * kNB + cc];
     }
+    if (!INVERSE && k > 0 && tid < kNB) sRd[tid] = Dk[kNB * kNB + tid];
     __syncthreads();
     if (k == 0) {
-        // first column: no look-ahead yet, every workgroup factors and inverts A_00 itself
+        // first column: no look-ahead yet, every workgroup factors (and, INVERSE, inverts) A_00 itself
         if (wv == 0) {
             potrf32(sWk, sLT, sRd, lane, &bad);
-            double x[kNB];
+            if (INVERSE) {
+                double x[kNB];
 #pragma unroll
-            for (int j = 0; j < kNB; ++j) x[j] = ((lane & 31) == j) ? 1.0 : 0.0;
-            fwdsub32(sLT, sRd, x);  // column (lane & 31) of L^-1
-            if (lane < kNB) {
+                for (int j = 0; j < kNB; ++j) x[j] = ((lane & 31) == j) ? 1.0 : 0.0;
+                fwdsub32(sLT, sRd, x);  // column (lane & 31) of L^-1
+                if (lane < kNB) {
 #pragma unroll
-                for (int j = 0; j < kNB; ++j) sWk[j][lane] = x[j];
+                    for (int j = 0; j < kNB; ++j) sWk[j][lane] = x[j];
+                }
             }
         }
         __syncthreads();
     }
-    // ---- panel blocks by MFMA: L_rk = A_rk W^T, L_ck = A_ck W^T, Y_k = W R_k   (in place, barrier in between)
-    f64x4 zero = {0.0, 0.0, 0.0, 0.0};
-    f64x4 pP = zero, pQ = zero;
-    if (isW) pP = mm32<false>(zero, sWk, sP, tm, tn, lane, 1.0);
-    else if (r != c) pP = mm32<true>(zero, sP, sWk, tm, tn, lane, 1.0);
-    if (needQ) pQ = mm32<true>(zero, sQ, sWk, tm, tn, lane, 1.0);
-    __syncthreads();
-    if (isW || r != c) accToLds(pP, sP, tm, tn, lane);
-    if (needQ) accToLds(pQ, sQ, tm, tn, lane);
-    __syncthreads();
+    if (INVERSE) {
+        // ---- panel blocks by MFMA: L_rk = A_rk W^T, L_ck = A_ck W^T, Y_k = W R_k   (in place, barrier in between)
+        f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+        f64x4 pP = zero, pQ = zero;
+        if (isW) pP = mm32<false>(zero, sWk, sP, tm, tn, lane, 1.0);
+        else if (r != c) pP = mm32<true>(zero, sP, sWk, tm, tn, lane, 1.0);
+        if (needQ) pQ = mm32<true>(zero, sQ, sWk, tm, tn, lane, 1.0);
+        __syncthreads();
+        if (isW || r != c) accToLds(pP, sP, tm, tn, lane);
+        if (needQ) accToLds(pQ, sQ, tm, tn, lane);
+        __syncthreads();
+    } else {
+        // ---- panel blocks by forward substitution, one lane per vector: wave 0, lanes 0..31 -> sP, lanes 32..63 -> sQ
+        if (wv == 0) {
+            const int v = lane & 31;
+            const bool secondHalf = lane >= 32;
+            const bool doP = !secondHalf && (isW || r != c);
+            const bool doQ = secondHalf && needQ;
+            if (doP || doQ) {
+                double x[kNB];
+                if (doQ) {
+#pragma unroll
+                    for (int j = 0; j < kNB; ++j) x[j] = sQ[v][j];
+                } else if (isW) {
+#pragma unroll
+                    for (int j = 0; j < kNB; ++j) x[j] = sP[j][v];  // column v of R_k
+                } else {
+#pragma unroll
+                    for (int j = 0; j < kNB; ++j) x[j] = sP[v][j];  // row v of A_rk
+                }
+                fwdsub32(sLT, sRd, x);
+                if (doQ) {
+#pragma unroll
+                    for (int j = 0; j < kNB; ++j) sQ[v][j] = x[j];
+                } else if (isW) {
+#pragma unroll
+                    for (int j = 0; j < kNB; ++j) sP[j][v] = x[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < kNB; ++j) sP[v][j] = x[j];
+                }
+            }
+        }
+        __syncthreads();
+    }
 
     if (isW && c == k) {
         for (int e = tid; e < kNB * kNB; e += 256) {
@@ -535,23 +581,26 @@ __global__ __launch_bounds__(256) void k_chol_step(ChainArgs c0, ChainArgs c1, i
 #pragma unroll
             for (int q = 0; q < 4; ++q) Ct[(long long)(16 * tm + (lane >> 4) + 4 * q) * ldc + 16 * tn + (lane & 15)] = acc[q];
         } else {
-            // ---- look-ahead: factor and invert the freshly updated diagonal block for launch k + 1
+            // ---- look-ahead: factor (and, INVERSE, invert) the freshly updated diagonal block for launch k + 1
             __syncthreads();
             accToLds(acc, sP, tm, tn, lane);
             __syncthreads();
             if (wv == 0) {
                 potrf32(sP, sLT, sRd, lane, &bad);
-                double x[kNB];
+                double* Dn = D + ((long long)(k + 1) * 2) * kNB * kNB;
+                if (INVERSE) {
+                    double x[kNB];
 #pragma unroll
-                for (int j = 0; j < kNB; ++j) x[j] = ((lane & 31) == j) ? 1.0 : 0.0;
-                fwdsub32(sLT, sRd, x);
-                if (lane < kNB) {
-                    double* Dn = D + ((long long)(k + 1) * 2) * kNB * kNB;
+                    for (int j = 0; j < kNB; ++j) x[j] = ((lane & 31) == j) ? 1.0 : 0.0;
+                    fwdsub32(sLT, sRd, x);
+                    if (lane < kNB) {
 #pragma unroll
-                    for (int j = 0; j < kNB; ++j) {
-                        Dn[kNB * kNB + j * kNB + lane] = x[j];                 // W_{k+1}[j][lane]
-                        Dn[j * kNB + lane] = (lane <= j) ? sLT[lane][j] : 0.0;  // L_{k+1}[j][lane]
+                        for (int j = 0; j < kNB; ++j) Dn[kNB * kNB + j * kNB + lane] = x[j];  // W_{k+1}[j][lane]
                     }
+                } else if (lane < kNB) {
+#pragma unroll
+                    for (int j = 0; j < kNB; ++j) Dn[j * kNB + lane] = (lane >= j) ? sLT[j][lane] : 0.0;  // L_{k+1}^T image
+                    Dn[kNB * kNB + lane] = sRd[lane];
                 }
             }
         }
