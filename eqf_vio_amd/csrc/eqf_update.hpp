@@ -157,12 +157,22 @@ __global__ __launch_bounds__(256) void k_update_prep(UpdArgs a, int lmBlocks, in
         if (r0 >= nep) return;
         double* EA = a.EA + (long long)b * a.strideE;
         double* ZW = a.ZW + (long long)b * a.strideZ;
-        for (int e = tid; e < kNB * nep; e += (int)blockDim.x) {
-            const int rr = r0 + e / nep, cc = e % nep;
-            double v;
-            if (rr < ne && cc < ne && rr != 5 && cc != 5) v = (double)Sin[(long long)(6 + rr) * ld + 6 + cc];
-            else v = (rr == cc) ? 1.0 : 0.0;
-            EA[(long long)rr * a.ldE + cc] = v;
+        // one row per wave at a time, lanes stride the columns, 4 column groups per trip (independent loads in flight)
+        const int nw = (int)blockDim.x >> 6;
+        for (int rl = wv; rl < kNB; rl += nw) {
+            const int rr = r0 + rl;
+            for (int cc = lane; cc < nep; cc += 256) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c2 = cc + 64 * u;
+                    if (rr < ne && c2 < ne && rr != 5 && c2 != 5) v[u] = (double)Sin[(long long)(6 + rr) * ld + 6 + c2];
+                    else v[u] = (rr == c2) ? 1.0 : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (cc + 64 * u < nep) EA[(long long)rr * a.ldE + cc + 64 * u] = v[u];
+            }
         }
         if (tid < kNB) {
             const int rr = r0 + tid;
@@ -231,10 +241,24 @@ __global__ __launch_bounds__(256) void k_update_prep(UpdArgs a, int lmBlocks, in
         const int colLo = (q0 == 0) ? 0 : kLm0 + 3 * q0, colHi = kLm0 + 3 * q1;
         if (valid) {
             // rows 2i, 2i+1 of C*Sigma for this column chunk: lanes stride the columns (coalesced 3-row reads)
-            for (int col = colLo + lane; col < colHi; col += 64) {
-                const double v0 = (double)s0[col], v1 = (double)s0[ld + col], v2 = (double)s0[2 * ld + col];
-                sCS0[col - colLo] = C[0] * v0 + C[1] * v1 + C[2] * v2;
-                sCS1[col - colLo] = C[3] * v0 + C[4] * v1 + C[5] * v2;
+            // (4 column groups per trip: 12 independent loads in flight -- Sigma was written by the previous launch on
+            // other XCDs, every access is a ~2 us miss)
+            for (int col = colLo + lane; col < colHi; col += 256) {
+                double v[4][3];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cc = col + 64 * u;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) v[u][q] = (cc < colHi) ? (double)s0[(long long)q * ld + cc] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cc = col + 64 * u;
+                    if (cc < colHi) {
+                        sCS0[cc - colLo] = C[0] * v[u][0] + C[1] * v[u][1] + C[2] * v[u][2];
+                        sCS1[cc - colLo] = C[3] * v[u][0] + C[4] * v[u][1] + C[5] * v[u][2];
+                    }
+                }
             }
         }
         __syncthreads();
@@ -488,7 +512,17 @@ __global__ __launch_bounds__(256) void k_chol_step(ChainArgs c0, ChainArgs c1, i
     const bool needQ = c > k;
     const double* Dk = D + ((long long)k * 2) * kNB * kNB;  // [0]: L_kk^T (sLT image), [1]: W_k or (row 0) 1/diag
 
+    // ---- the tile this workgroup updates: fetched first, its (cold) miss overlaps the panel work below
+    const bool hasTile = !(isW && c == k);
+    double* Ct = isW ? (W + (long long)(c * kNB) * ldW + r * kNB) : (A + (long long)(r * kNB) * ldA + c * kNB);
+    const int ldc = isW ? ldW : ldA;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    if (hasTile) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = Ct[(long long)(16 * tm + (lane >> 4) + 4 * q) * ldc + 16 * tn + (lane & 15)];
+    }
     // ---- operands
+#pragma unroll
     for (int e = tid; e < kNB * kNB; e += 256) {
         const int rr = e / kNB, cc = e % kNB;
         if (k == 0) sWk[rr][cc] = A[(long long)rr * ldA + cc];  // A_00: factored below by every workgroup
@@ -570,11 +604,6 @@ __global__ __launch_bounds__(256) void k_chol_step(ChainArgs c0, ChainArgs c1, i
         }
     } else {
         // ---- trailing update of this tile
-        double* Ct = isW ? (W + (long long)(c * kNB) * ldW + r * kNB) : (A + (long long)(r * kNB) * ldA + c * kNB);
-        const int ldc = isW ? ldW : ldA;
-        f64x4 acc;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = Ct[(long long)(16 * tm + (lane >> 4) + 4 * q) * ldc + 16 * tn + (lane & 15)];
         if (isW) acc = mm32<false>(acc, sQ, sP, tm, tn, lane, -1.0);          // R_c -= L_ck Y_k
         else acc = mm32<true>(acc, (r == c) ? sQ : sP, sQ, tm, tn, lane, -1.0);  // A_rc -= L_rk L_ck^T
         if (!diagNext) {
@@ -706,131 +735,117 @@ __global__ __launch_bounds__(256) void k_update_finish(UpdArgs a) {
     const int tid = threadIdx.x;
     double* gam = a.dbgGamma + (long long)b * (kLm0 + 3 * cap);  // written by k_update_reduce
     const double* red = a.red + (long long)b * 256;
-    __shared__ double sG6[36], sT65[30], sHV[6], sSol[16];
+    double* gT = a.dbgGammaTot ? a.dbgGammaTot + (long long)b * (9 + 3 * cap) : nullptr;
     int bad = 0;
-    if (tid < 6) sHV[tid] = red[tid];
-    if (tid < 36) sG6[tid] = red[8 + 11 * (tid / 6) + tid % 6];             // Zt^T Zt
-    if (tid >= 64 && tid < 94) sT65[tid - 64] = red[8 + 11 * ((tid - 64) / 5) + 6 + (tid - 64) % 5];  // Zt^T Et
-    __syncthreads();
-
-    // ---- Gamma[0:6] on one thread (bundleLift, EqFMatrices.cpp:173-252)
+    // The weighted least squares + the scalar part of X <- Delta X is serial work for one lane; the per-landmark part
+    // of Delta only needs gamma, so it runs on the other wavefronts at the same time.
     if (tid == 0) {
+        double G6[36], T65[30], hV[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) hV[i] = red[i];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) G6[i] = red[8 + 11 * (i / 6) + i % 6];             // Zt^T Zt
+#pragma unroll
+        for (int i = 0; i < 30; ++i) T65[i] = red[8 + 11 * (i / 5) + 6 + i % 5];        // Zt^T Et
+        const d3 v0 = mk3(g.v0[0], g.v0[1], g.v0[2]);
+        const d3 gv = mk3(gam[8], gam[9], gam[10]);
         double dU[6] = {0, 0, 0, 0, 0, 0};
-        if (a.prm.useInnovationLift) {
-            const quat P0q = quat{g.P0q[0], g.P0q[1], g.P0q[2], g.P0q[3]};
-            const d3 eta0 = unit3(qrot(qinv(P0q), mk3(0, 0, 1)));
-            double idf[6];
-            stereoChartInvDiffAtZero(eta0, idf, &bad);
+        se3 DA;
+        d3 Dw;
+        if (a.prm.useInnovationLift) {  // bundleLift, EqFMatrices.cpp:173-252
+            const d3 eta0 = unit3(mk3(g.eta0[0], g.eta0[1], g.eta0[2]));
             const double gg0 = gam[6], gg1 = gam[7];
-            const d3 t = mk3(idf[0] * gg0 + idf[1] * gg1, idf[2] * gg0 + idf[3] * gg1, idf[4] * gg0 + idf[5] * gg1);
+            // stereoSphereChartInvDiff(0, eta0) is cached in g.cInv (3x2)
+            const d3 t = mk3(g.cInv[0] * gg0 + g.cInv[1] * gg1, g.cInv[2] * gg0 + g.cInv[3] * gg1, g.cInv[4] * gg0 + g.cInv[5] * gg1);
             const d3 dUw = neg(crs(eta0, t));
-            // DeltaU_fixed = K_perp DeltaU = ((I - eta eta^T) dUw ; 0)
-            const d3 fx = sub(dUw, scl(dot3(eta0, dUw), eta0));
-            const double dUf[6] = {fx.x, fx.y, fx.z, 0, 0, 0};
-            // h = hV - T65 * gamma_e[0:5]   (gamma_e[0:5] = gamma internal indices 6..10)
-            double h[6];
-            for (int c = 0; c < 6; ++c) {
-                double s = sHV[c];
-                for (int q = 0; q < 5; ++q) s -= sT65[5 * c + q] * gam[6 + q];
-                h[c] = s;
-            }
-            // rhs6 = -h - G6 dUf ; normal equations in the K_par basis: columns (eta;0), (0;e1), (0;e2), (0;e3)
+            const d3 fx = sub(dUw, scl(dot3(eta0, dUw), eta0));  // DeltaU_fixed = K_perp DeltaU = ((I - eta eta^T) dUw ; 0)
+            const double dUf[3] = {fx.x, fx.y, fx.z};
+            const double eta[3] = {eta0.x, eta0.y, eta0.z};
+            // rhs6 = -(hV - T65 gamma_e[0:5]) - G6 [dUf; 0]
             double rhs6[6];
+#pragma unroll
             for (int c = 0; c < 6; ++c) {
-                double s = -h[c];
-                for (int q = 0; q < 6; ++q) s -= sG6[6 * c + q] * dUf[q];
-                rhs6[c] = s;
+                double sacc = -hV[c];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) sacc += T65[5 * c + q] * gam[6 + q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) sacc -= G6[6 * c + q] * dUf[q];
+                rhs6[c] = sacc;
             }
-            double Kp[6][4] = {};
-            Kp[0][0] = eta0.x; Kp[1][0] = eta0.y; Kp[2][0] = eta0.z;
-            Kp[3][1] = Kp[4][2] = Kp[5][3] = 1.0;
+            // normal equations in the K_par basis, columns (eta;0), (0;e1), (0;e2), (0;e3):  M = Kp^T G6 Kp
             double M[4][4], rhs[4], sol[4];
-            for (int i = 0; i < 4; ++i) {
-                for (int j = 0; j < 4; ++j) {
-                    double s = 0;
-                    for (int p = 0; p < 6; ++p)
-                        for (int q = 0; q < 6; ++q) s += Kp[p][i] * sG6[6 * p + q] * Kp[q][j];
-                    M[i][j] = s;
-                }
-                double s = 0;
-                for (int p = 0; p < 6; ++p) s += Kp[p][i] * rhs6[p];
-                rhs[i] = s;
+            double Gw_eta[6];  // G6[:, 0:3] eta
+#pragma unroll
+            for (int p = 0; p < 6; ++p) Gw_eta[p] = G6[6 * p] * eta[0] + G6[6 * p + 1] * eta[1] + G6[6 * p + 2] * eta[2];
+            M[0][0] = eta[0] * Gw_eta[0] + eta[1] * Gw_eta[1] + eta[2] * Gw_eta[2];
+            rhs[0] = eta[0] * rhs6[0] + eta[1] * rhs6[1] + eta[2] * rhs6[2];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                M[0][1 + j] = eta[0] * G6[3 + j] + eta[1] * G6[6 + 3 + j] + eta[2] * G6[12 + 3 + j];
+                M[1 + j][0] = Gw_eta[3 + j];
+                rhs[1 + j] = rhs6[3 + j];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) M[1 + i][1 + j] = G6[6 * (3 + i) + 3 + j];
             }
             solve4(M, rhs, sol);
-            for (int i = 0; i < 6; ++i) {
-                double s = dUf[i];
-                for (int j = 0; j < 4; ++j) s += Kp[i][j] * sol[j];
-                dU[i] = s;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                dU[i] = dUf[i] + eta[i] * sol[0];
+                dU[3 + i] = sol[1 + i];
             }
+            DA = se3Exp(mk3(dU[0], dU[1], dU[2]), mk3(dU[3], dU[4], dU[5]));
+            if (a.prm.useDiscreteInnovationLift) Dw = sub(v0, qrot(DA.q, add(v0, gv)));  // EqFMatrices.cpp:254-258
+            else Dw = sub(neg(gv), crs(mk3(dU[0], dU[1], dU[2]), v0));                  // :69-79
+        } else {  // VIOExp(liftInnovation(gamma_e, xi0)), :35-49
+            const d3 eta = mk3(g.eta0[0], g.eta0[1], g.eta0[2]);
+            const d3 t = mk3(g.cInv[0] * gam[6] + g.cInv[1] * gam[7], g.cInv[2] * gam[6] + g.cInv[3] * gam[7],
+                g.cInv[4] * gam[6] + g.cInv[5] * gam[7]);
+            const d3 Uw = neg(crs(eta, t));
+            DA = se3Exp(Uw, mk3(0, 0, 0));
+            Dw = sub(neg(gv), crs(Uw, v0));
         }
-        for (int i = 0; i < 6; ++i) sSol[i] = dU[i];
-    }
-    __syncthreads();
-
-    // ---- Delta and X <- Delta * X
-    double* Q = a.Q + (long long)b * 5 * cap;
-    const double* p0 = a.p0 + (long long)b * 3 * cap;
-    double* gT = a.dbgGammaTot ? a.dbgGammaTot + (long long)b * (9 + 3 * cap) : nullptr;
-    const d3 v0 = mk3(g.v0[0], g.v0[1], g.v0[2]);
-    const d3 gv = mk3(gam[8], gam[9], gam[10]);
-    se3 DA;
-    d3 Dw;
-    if (a.prm.useInnovationLift) {
-        if (a.prm.useDiscreteInnovationLift) {  // EqFMatrices.cpp:254-258
-            DA = se3Exp(mk3(sSol[0], sSol[1], sSol[2]), mk3(sSol[3], sSol[4], sSol[5]));
-            Dw = sub(v0, qrot(DA.q, add(v0, gv)));
-        } else {  // VIOExp(liftTotalSpaceInnovation), :69-79
-            DA = se3Exp(mk3(sSol[0], sSol[1], sSol[2]), mk3(sSol[3], sSol[4], sSol[5]));
-            Dw = sub(neg(gv), crs(mk3(sSol[0], sSol[1], sSol[2]), v0));
-        }
-    } else {  // VIOExp(liftInnovation(gamma_e, xi0)), :35-49
-        const quat P0q = quat{g.P0q[0], g.P0q[1], g.P0q[2], g.P0q[3]};
-        const d3 eta = qrot(qinv(P0q), mk3(0, 0, 1));
-        double idf[6];
-        stereoChartInvDiffAtZero(eta, idf, &bad);
-        const d3 t = mk3(idf[0] * gam[6] + idf[1] * gam[7], idf[2] * gam[6] + idf[3] * gam[7], idf[4] * gam[6] + idf[5] * gam[7]);
-        const d3 Uw = neg(crs(eta, t));
-        DA = se3Exp(Uw, mk3(0, 0, 0));
-        Dw = sub(neg(gv), crs(Uw, v0));
-    }
-    const bool discreteLm = a.prm.useInnovationLift && a.prm.useDiscreteInnovationLift;
-    for (int i = tid; i < N; i += 256) {
-        const d3 qi = mk3(p0[i], p0[cap + i], p0[2 * cap + i]);
-        const d3 gq = mk3(gam[kLm0 + 3 * i], gam[kLm0 + 3 * i + 1], gam[kLm0 + 3 * i + 2]);
-        quat dq;
-        double da;
-        if (discreteLm) {  // :262-270
-            const d3 q1 = add(qi, gq);
-            dq = so3FromVectors(q1, qi, &bad);
-            da = nrm3(qi) / nrm3(q1);
-        } else {  // :84-93 / :54-63 then SOT3Exp
-            const double n2 = dot3(qi, qi);
-            dq = so3Exp(scl(-1.0 / n2, crs(qi, gq)));
-            da = exp(-dot3(qi, gq) / n2);
-        }
-        const quat Qq = quat{Q[i], Q[cap + i], Q[2 * cap + i], Q[3 * cap + i]};
-        const quat Qn = qmul(dq, Qq);  // X = Delta * X  (VIOFilter.cpp:296, VIOGroup.cpp:105-107)
-        Q[i] = Qn.w; Q[cap + i] = Qn.x; Q[2 * cap + i] = Qn.y; Q[3 * cap + i] = Qn.z;
-        Q[4 * cap + i] = da * Q[4 * cap + i];
-        if (gT) {
-            gT[9 + 3 * i] = gq.x; gT[10 + 3 * i] = gq.y; gT[11 + 3 * i] = gq.z;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
         const se3 A = se3{quat{g.Aq[0], g.Aq[1], g.Aq[2], g.Aq[3]}, mk3(g.Ax[0], g.Ax[1], g.Ax[2])};
-        const se3 An = se3mul(DA, A);                                        // VIOGroup.cpp:95
+        const se3 An = se3mul(DA, A);                                        // X = Delta * X  (VIOFilter.cpp:296, VIOGroup.cpp:95)
         const d3 wn = add(Dw, qrot(DA.q, mk3(g.w[0], g.w[1], g.w[2])));       // :96
         g.Aq[0] = An.q.w; g.Aq[1] = An.q.x; g.Aq[2] = An.q.y; g.Aq[3] = An.q.z;
         g.Ax[0] = An.x.x; g.Ax[1] = An.x.y; g.Ax[2] = An.x.z;
         g.w[0] = wn.x; g.w[1] = wn.y; g.w[2] = wn.z;
+#pragma unroll
         for (int i = 0; i < 6; ++i) g.bias[i] += gam[i];  // VIOFilter.cpp:295
         if (gT) {
-            for (int i = 0; i < 6; ++i) gT[i] = sSol[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) gT[i] = dU[i];
             gT[6] = gv.x; gT[7] = gv.y; gT[8] = gv.z;
         }
-        if (bad && a.errflag) atomicOr(a.errflag, 8);
+    } else if (tid >= 64) {
+        // ---- per-landmark part of Delta and Q_i <- Delta_i Q_i   (VIOGroup.cpp:105-107)
+        double* Q = a.Q + (long long)b * 5 * cap;
+        const double* p0 = a.p0 + (long long)b * 3 * cap;
+        const bool discreteLm = a.prm.useInnovationLift && a.prm.useDiscreteInnovationLift;
+        for (int i = tid - 64; i < N; i += 192) {
+            const d3 qi = mk3(p0[i], p0[cap + i], p0[2 * cap + i]);
+            const d3 gq = mk3(gam[kLm0 + 3 * i], gam[kLm0 + 3 * i + 1], gam[kLm0 + 3 * i + 2]);
+            quat dq;
+            double da;
+            if (discreteLm) {  // EqFMatrices.cpp:262-270
+                const d3 q1 = add(qi, gq);
+                dq = so3FromVectors(q1, qi, &bad);
+                da = nrm3(qi) / nrm3(q1);
+            } else {  // :84-93 / :54-63 then SOT3Exp
+                const double n2 = dot3(qi, qi);
+                dq = so3Exp(scl(-1.0 / n2, crs(qi, gq)));
+                da = exp(-dot3(qi, gq) / n2);
+            }
+            const quat Qq = quat{Q[i], Q[cap + i], Q[2 * cap + i], Q[3 * cap + i]};
+            const quat Qn = qmul(dq, Qq);
+            Q[i] = Qn.w; Q[cap + i] = Qn.x; Q[2 * cap + i] = Qn.y; Q[3 * cap + i] = Qn.z;
+            Q[4 * cap + i] = da * Q[4 * cap + i];
+            if (gT) {
+                gT[9 + 3 * i] = gq.x; gT[10 + 3 * i] = gq.y; gT[11 + 3 * i] = gq.z;
+            }
+        }
     }
+    if (bad && a.errflag) atomicOr(a.errflag, 8);
 }
 
 // ------------------------------------------------------------------------------------------------
