@@ -374,16 +374,15 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     rc = profiled(f, EQF_PROF_REDUCE,
         [&] { hipLaunchKernelGGL(k_update_reduce, dim3(colBlocks + 1, B), dim3(1024), 0, f->stream, a, colBlocks); });
     if (rc) return rc;
-    rc = profiled(f, EQF_PROF_FINISH, [&] { hipLaunchKernelGGL(k_update_finish, dim3(B), dim3(256), 0, f->stream, a); });
-    if (rc) return rc;
-    // 64x64 tiles when they fill the chip, 32x32 tiles (4x the workgroups) for a single small filter
+    // 64x64 tiles when they fill the chip, 32x32 tiles (4x the workgroups) for a single small filter; the last workgroup
+    // of the launch runs the (independent) innovation-lift / group-update part
     const int nt64 = (nv + 63) / 64, nt32 = (nv + 31) / 32;
     const bool small = (long long)nt64 * (nt64 + 1) / 2 * B < 512;
     rc = profiled(f, EQF_PROF_DOWNDATE, [&] {
         if (small)
-            hipLaunchKernelGGL((k_downdate<T, 32>), dim3(nt32 * (nt32 + 1) / 2, B), dim3(256), 0, f->stream, a, nt32);
+            hipLaunchKernelGGL((k_downdate<T, 32>), dim3(nt32 * (nt32 + 1) / 2 + 1, B), dim3(256), 0, f->stream, a, nt32);
         else
-            hipLaunchKernelGGL((k_downdate<T, 64>), dim3(nt64 * (nt64 + 1) / 2, B), dim3(256), 0, f->stream, a, nt64);
+            hipLaunchKernelGGL((k_downdate<T, 64>), dim3(nt64 * (nt64 + 1) / 2 + 1, B), dim3(256), 0, f->stream, a, nt64);
     });
     if (rc) return rc;
     HIPC(hipGetLastError());

@@ -727,8 +727,7 @@ EQF_DI void solve4(double M[4][4], double* rhs, double* x) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_update_finish(UpdArgs a) {
-    const int b = blockIdx.x;
+EQF_DI void updateFinishBody(const UpdArgs& a, int b) {
     Glob& g = a.g[b];
     if (!g.updateOk || g.N == 0) return;
     const int N = g.N, cap = a.cap;
@@ -848,6 +847,8 @@ __global__ __launch_bounds__(256) void k_update_finish(UpdArgs a) {
     if (bad && a.errflag) atomicOr(a.errflag, 8);
 }
 
+__global__ __launch_bounds__(256) void k_update_finish(UpdArgs a) { updateFinishBody(a, blockIdx.x); }
+
 // ------------------------------------------------------------------------------------------------
 // k_downdate: Sigma_out = Sigma_in - Y^T Y on the matrix cores.  64x64 output tile per workgroup, each of
 // the 4 waves owns a 32x32 quadrant as 2x2 MFMA 16x16 tiles; the operands Y[:, I], Y[:, J] stream from
@@ -878,6 +879,12 @@ template <typename T, int TS>
 __global__ __launch_bounds__(256) void k_downdate(UpdArgs a, int nt) {
     constexpr int WM = TS / 32;  // MFMA tiles per wave and dimension
     const int b = blockIdx.y;
+    if (blockIdx.x == gridDim.x - 1) {
+        // the innovation lift / X <- Delta X / bias update is independent of the downdate: one extra workgroup of this
+        // launch does it (saves a kernel boundary; both only need gamma from k_update_reduce)
+        updateFinishBody(a, b);
+        return;
+    }
     const Glob& g = a.g[b];
     const int N = g.N;
     const int nv = kLm0 + 3 * N;
