@@ -58,7 +58,7 @@ EXPORTED_SYMBOLS = [
     "eqf_settings_default", "eqf_create", "eqf_destroy", "eqf_reset", "eqf_process_imu", "eqf_process_vision",
     "eqf_stream_upload", "eqf_stream_imu", "eqf_stream_vision", "eqf_synchronize", "eqf_get_time", "eqf_num_landmarks",
     "eqf_get_ids", "eqf_get_state_estimate", "eqf_get_origin", "eqf_get_group", "eqf_get_bias", "eqf_get_sigma",
-    "eqf_set_sigma", "eqf_set_state", "eqf_get_integrator", "eqf_get_last_update", "eqf_device_error", "eqf_set_dense_propagate", "eqf_profile_enable",
+    "eqf_set_sigma", "eqf_set_state", "eqf_set_camera_offset", "eqf_get_integrator", "eqf_get_last_update", "eqf_device_error", "eqf_set_dense_propagate", "eqf_profile_enable",
     "eqf_profile_get", "eqf_profile_class_name", "eqf_version",
 ]
 
@@ -306,6 +306,10 @@ class FilterBatch:
                                 float(st["accumulatedTime"]), int(st["initialised"])),
             "eqf_set_state",
         )
+
+    def set_camera_offset(self, q, x):
+        q, x = np.ascontiguousarray(q, dtype=np.float64), np.ascontiguousarray(x, dtype=np.float64)
+        _check(lib().eqf_set_camera_offset(self._h, _p(q), _p(x)), "eqf_set_camera_offset")
 
     def last_update(self, b=0):
         N = self.num_landmarks(b)

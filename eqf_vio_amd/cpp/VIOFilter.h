@@ -72,6 +72,17 @@ struct MatrixXd {
     int cols() const { return n; }
 };
 
+struct AuxiliaryFilterData {  // eqf_vio/include/eqf_vio/VIOFilter.h:30-39
+    Quaterniond initialAttitude;
+    Vector3d initialPosition{0, 0, 0};
+    double initialTime = 0;
+    double measurementVariance = 0.1;
+    double processVariance = 1.0;
+    double omegaVariance = 0.1;
+    double accelVariance = 0.1;
+    SE3 cameraOffset;
+};
+
 class VIOFilter {
   public:
     // eqf_vio/include/eqf_vio/VIOFilterSettings.h:28-54.  YAML parsing is host plumbing outside this path: fill
@@ -96,6 +107,12 @@ class VIOFilter {
         if (rc != EQF_OK) throw std::runtime_error("eqf_create failed with status " + std::to_string(rc) + " (no CPU fallback)");
         handle_.reset(h);
     }
+    // VIOFilter(const AuxiliaryFilterData&, const VIOFilter::Settings&) (VIOFilter.cpp:51-58)
+    VIOFilter(const AuxiliaryFilterData& auxiliaryData, const Settings& s, int capacity = 256, int device = 0,
+        int precision = EQF_PRECISION_F64)
+        : VIOFilter(s, capacity, device, precision) {
+        setAuxiliaryData(auxiliaryData);
+    }
     VIOFilter(VIOFilter&&) = default;             // move-only, like the reference (unique_ptr settings)
     VIOFilter& operator=(VIOFilter&&) = default;  // eqf_vio_ros_node.cpp:59 move-assigns
 
@@ -116,6 +133,55 @@ class VIOFilter {
             for (int c = 0; c < 3; ++c) y_[size_t(3) * i + c] = measurement.bearings[i].p[c];
         }
         check(eqf_process_vision(handle_.get(), &measurement.stamp, &nb, ids_.data(), y_.data(), nb, &lastStatus_), "eqf_process_vision");
+    }
+
+    // VIOFilter.cpp:74-82: origin pose from the given attitude / position, zero origin velocity, camera offset replaced,
+    // filter marked initialised (so the first IMU sample does no gravity alignment).
+    void setAuxiliaryData(const AuxiliaryFilterData& auxiliaryData) {
+        auxData = auxiliaryData;
+        Snapshot st = dump();
+        st.pq = {auxiliaryData.initialAttitude.w, auxiliaryData.initialAttitude.x, auxiliaryData.initialAttitude.y, auxiliaryData.initialAttitude.z};
+        st.px = auxiliaryData.initialPosition;
+        st.v = {0, 0, 0};
+        st.initialised = 1;
+        const SE3& T = auxiliaryData.cameraOffset;
+        const double cq[4] = {T.R.w, T.R.x, T.R.y, T.R.z};
+        check(eqf_set_camera_offset(handle_.get(), cq, T.x.data()), "eqf_set_camera_offset");
+        for (int i = 0; i < 4; ++i) settings->cameraOffset_q[i] = cq[i];
+        for (int i = 0; i < 3; ++i) settings->cameraOffset_x[i] = T.x[i];
+        restore(st);
+    }
+    // VIOFilter.cpp:93-118: the landmark set becomes the given inertial-frame points (ids as given), Q_i = identity,
+    // Sigma = initialPointVariance * I outside the 11 x 11 base block.
+    void setInertialPoints(const std::vector<Point3d>& inertialPoints) {
+        const int N = int(inertialPoints.size());
+        Snapshot st = dump();
+        // inertialToCameraTF = (xi0.pose * xi0.cameraOffset)^-1
+        const double* cq = settings->cameraOffset_q;
+        const double* cx = settings->cameraOffset_x;
+        const std::array<double, 4> tq = qmul(st.pq, {cq[0], cq[1], cq[2], cq[3]});
+        const Vector3d rx = qrot(st.pq, {cx[0], cx[1], cx[2]});
+        const Vector3d tx = {st.px[0] + rx[0], st.px[1] + rx[1], st.px[2] + rx[2]};
+        const std::array<double, 4> tqi = {tq[0], -tq[1], -tq[2], -tq[3]};
+        st.ids.resize(N);
+        st.p0.assign(size_t(3) * N, 0.0);
+        st.Qq.assign(size_t(4) * N, 0.0);
+        st.Qa.assign(N, 1.0);
+        for (int i = 0; i < N; ++i) {
+            const Vector3d& p = inertialPoints[i].p;
+            const Vector3d q = qrot(tqi, {p[0] - tx[0], p[1] - tx[1], p[2] - tx[2]});
+            st.ids[i] = inertialPoints[i].id;
+            for (int c = 0; c < 3; ++c) st.p0[size_t(3) * i + c] = q[c];
+            st.Qq[size_t(4) * i] = 1.0;
+        }
+        const int n = 11 + 3 * N;
+        std::vector<double> S(size_t(n) * n, 0.0);
+        for (int i = 0; i < n; ++i) S[size_t(i) * n + i] = settings->initialPointVariance;
+        for (int r = 0; r < 11; ++r)
+            for (int c = 0; c < 11; ++c) S[size_t(r) * n + c] = st.sigma[size_t(r) * st.n + c];
+        st.sigma.swap(S);
+        st.n = n;
+        restore(st);
     }
 
     double getTime() const {  // VIOFilter.cpp:343
@@ -175,7 +241,56 @@ class VIOFilter {
         return os;
     }
 
+    AuxiliaryFilterData auxData;  // VIOFilter.h:43
+
   private:
+    // full-precision snapshot of the filter (what eqf_set_state takes)
+    struct Snapshot {
+        std::vector<int> ids;
+        std::array<double, 4> pq{1, 0, 0, 0}, Aq{1, 0, 0, 0};
+        Vector3d px{0, 0, 0}, v{0, 0, 0}, Ax{0, 0, 0}, w{0, 0, 0};
+        std::vector<double> p0, Qq, Qa, sigma;
+        double bias[6], curVel[6], accVel[6], accTime = 0, time = -1;
+        int initialised = 0, n = 11;
+    };
+    Snapshot dump() const {
+        Snapshot st;
+        eqf_filter* h = handle_.get();
+        const int N = eqf_num_landmarks(h, 0);
+        const int M = N > 0 ? N : 1;
+        st.ids.resize(M);
+        st.p0.resize(size_t(3) * M);
+        st.Qq.resize(size_t(4) * M);
+        st.Qa.resize(M);
+        check(eqf_get_ids(h, 0, st.ids.data()), "eqf_get_ids");
+        check(eqf_get_origin(h, 0, st.pq.data(), st.px.data(), st.v.data(), st.p0.data()), "eqf_get_origin");
+        check(eqf_get_group(h, 0, st.Aq.data(), st.Ax.data(), st.w.data(), st.Qq.data(), st.Qa.data()), "eqf_get_group");
+        check(eqf_get_bias(h, 0, st.bias), "eqf_get_bias");
+        check(eqf_get_integrator(h, 0, st.curVel, st.accVel, &st.accTime, &st.initialised), "eqf_get_integrator");
+        check(eqf_get_time(h, &st.time), "eqf_get_time");
+        st.ids.resize(N);
+        st.n = 11 + 3 * N;
+        st.sigma.resize(size_t(st.n) * st.n);
+        check(eqf_get_sigma(h, 0, st.sigma.data(), st.n), "eqf_get_sigma");
+        return st;
+    }
+    void restore(const Snapshot& st) {
+        const int N = int(st.ids.size());
+        check(eqf_set_state(handle_.get(), 0, N, st.ids.data(), st.pq.data(), st.px.data(), st.v.data(), st.p0.data(), st.Aq.data(),
+                  st.Ax.data(), st.w.data(), st.Qq.data(), st.Qa.data(), st.bias, st.sigma.data(), st.n, st.time, st.curVel, st.accVel,
+                  st.accTime, st.initialised),
+            "eqf_set_state");
+    }
+    static std::array<double, 4> qmul(const std::array<double, 4>& a, const std::array<double, 4>& b) {
+        return {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+            a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3], a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1]};
+    }
+    static Vector3d qrot(const std::array<double, 4>& q, const Vector3d& v) {
+        const Vector3d u = {q[1], q[2], q[3]};
+        const Vector3d t = {2 * (u[1] * v[2] - u[2] * v[1]), 2 * (u[2] * v[0] - u[0] * v[2]), 2 * (u[0] * v[1] - u[1] * v[0])};
+        return {v[0] + q[0] * t[0] + u[1] * t[2] - u[2] * t[1], v[1] + q[0] * t[1] + u[2] * t[0] - u[0] * t[2],
+            v[2] + q[0] * t[2] + u[0] * t[1] - u[1] * t[0]};
+    }
     struct Deleter {
         void operator()(eqf_filter* h) const { eqf_destroy(h); }
     };

@@ -1,9 +1,12 @@
 // Minimal C++ caller of the facade, shaped like the reference's offline runner (eqf_vio/src/main.cpp:111-170):
 // events are interleaved by "imu.stamp < meas.stamp", the state is read after every vision call.
-// Usage: eqf_example <N landmarks> <frames>   -- runs a small synthetic orbit and prints the final pose and |Sigma|_F.
+// Usage: eqf_example <N landmarks> <frames> [aux]  -- runs a small synthetic sequence and prints the final pose and
+// |Sigma|_F.  With "aux" the filter starts from AuxiliaryFilterData + setInertialPoints (VIOFilter.cpp:51-58, 74-118)
+// instead of the gravity alignment at the first IMU sample.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 #include "VIOFilter.h"
 
@@ -17,9 +20,32 @@ int main(int argc, char** argv) {
     s.measurementVariance = 0.003;
     s.velOmegaVariance = s.velAccelVariance = 1e-4;
     s.outlierThreshold = 1e9;
-    VIOFilter filter(s, N);
+    const bool aux = argc > 3 && std::string(argv[3]) == "aux";
     std::vector<Vector3d> lm(N);
     for (int i = 0; i < N; ++i) lm[i] = {2 * std::sin(1.3 * i), 2 * std::cos(0.7 * i), 5 + std::sin(0.37 * i)};
+    AuxiliaryFilterData ad;
+    ad.initialAttitude = {std::sqrt(0.5), 0, -std::sqrt(0.5), 0};  // body x = inertial up
+    ad.initialPosition = {0.3, -0.2, 1.0};
+    ad.cameraOffset.R = {0.98, 0.1, -0.1, std::sqrt(1 - 0.98 * 0.98 - 0.02)};
+    ad.cameraOffset.x = {0.1, -0.05, 0.02};
+    VIOFilter filter = aux ? VIOFilter(ad, s, N) : VIOFilter(s, N);
+    if (aux) {
+        // inertial position of landmark i = pose * cameraOffset * (camera-frame point)
+        auto rot = [](const Quaterniond& q, const Vector3d& v) {
+            const Vector3d u = {q.x, q.y, q.z};
+            const Vector3d t = {2 * (u[1] * v[2] - u[2] * v[1]), 2 * (u[2] * v[0] - u[0] * v[2]), 2 * (u[0] * v[1] - u[1] * v[0])};
+            return Vector3d{v[0] + q.w * t[0] + u[1] * t[2] - u[2] * t[1], v[1] + q.w * t[1] + u[2] * t[0] - u[0] * t[2],
+                v[2] + q.w * t[2] + u[0] * t[1] - u[1] * t[0]};
+        };
+        std::vector<Point3d> pts(N);
+        for (int i = 0; i < N; ++i) {
+            const Vector3d b = rot(ad.cameraOffset.R, lm[i]);
+            const Vector3d w = rot(ad.initialAttitude, {b[0] + ad.cameraOffset.x[0], b[1] + ad.cameraOffset.x[1], b[2] + ad.cameraOffset.x[2]});
+            pts[i].p = {w[0] + ad.initialPosition[0], w[1] + ad.initialPosition[1], w[2] + ad.initialPosition[2]};
+            pts[i].id = 100 + 2 * i;
+        }
+        filter.setInertialPoints(pts);
+    }
     // vehicle at rest, tilted so that body x is "up" (a level start makes the reference's gravity chart singular)
     IMUVelocity imu;
     imu.accel = {GRAVITY_CONSTANT, 0, 0};
@@ -36,7 +62,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < N; ++i) {
             const double n = std::sqrt(lm[i][0] * lm[i][0] + lm[i][1] * lm[i][1] + lm[i][2] * lm[i][2]);
             meas.bearings[i].p = {lm[i][0] / n, lm[i][1] / n, lm[i][2] / n};
-            meas.bearings[i].id = i;
+            meas.bearings[i].id = aux ? 100 + 2 * i : i;
         }
         filter.processVisionData(meas);
         const VIOState est = filter.stateEstimate();

@@ -652,6 +652,20 @@ void eqf_settings_default(eqf_settings* s) {  // VIOFilterSettings.h:29-50
     s->cameraOffset_q[0] = 1.0;
 }
 
+// camera-offset constants, same formulas as on the device (eqf_math.hpp is host+device)
+static void setCameraConstants(Params& p) {
+    const quat cq = quat{p.camq[0], p.camq[1], p.camq[2], p.camq[3]};
+    const se3 camI = se3inv(se3{cq, mk3(p.camx[0], p.camx[1], p.camx[2])});
+    const m33 RIC = q2m(cq), RICt = q2m(qinv(cq)), RcI = q2m(camI.q);
+    for (int i = 0; i < 9; ++i) {
+        p.RIC[i] = RIC.a[i];
+        p.RICt[i] = RICt.a[i];
+        p.RcamI[i] = RcI.a[i];
+    }
+    p.camIq[0] = camI.q.w; p.camIq[1] = camI.q.x; p.camIq[2] = camI.q.y; p.camIq[3] = camI.q.z;
+    p.camIx[0] = camI.x.x; p.camIx[1] = camI.x.y; p.camIx[2] = camI.x.z;
+}
+
 int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, int device, int precision, eqf_filter** out) {
     if (!settings || !out || capacity_landmarks < 1 || batch < 1) return EQF_ERR_INVALID;
     if (precision != EQF_PRECISION_F64 && precision != EQF_PRECISION_F32) return EQF_ERR_INVALID;
@@ -680,18 +694,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     p.useInnovationLift = settings->useInnovationLift;
     p.useDiscreteInnovationLift = settings->useDiscreteInnovationLift;
     p.useDiscreteVelocityLift = settings->useDiscreteVelocityLift;
-    {  // camera-offset constants, same formulas as on the device (eqf_math.hpp is host+device)
-        const quat cq = quat{p.camq[0], p.camq[1], p.camq[2], p.camq[3]};
-        const se3 camI = se3inv(se3{cq, mk3(p.camx[0], p.camx[1], p.camx[2])});
-        const m33 RIC = q2m(cq), RICt = q2m(qinv(cq)), RcI = q2m(camI.q);
-        for (int i = 0; i < 9; ++i) {
-            p.RIC[i] = RIC.a[i];
-            p.RICt[i] = RICt.a[i];
-            p.RcamI[i] = RcI.a[i];
-        }
-        p.camIq[0] = camI.q.w; p.camIq[1] = camI.q.x; p.camIq[2] = camI.q.y; p.camIq[3] = camI.q.z;
-        p.camIx[0] = camI.x.x; p.camIx[1] = camI.x.y; p.camIx[2] = camI.x.z;
-    }
+    setCameraConstants(p);
 
     const int B = batch, cap = f->cap;
     f->nTot = kLm0 + 3 * cap;
@@ -1070,6 +1073,20 @@ int eqf_set_state(eqf_filter* f, int b, int N, const int* ids, const double* pos
     hipLaunchKernelGGL(k_restore_constants, dim3((N + 127) / 128 + 1), dim3(128), 0, f->stream, f->g[f->pG], b, f->p0, f->lmc, cap, f->errflag);
     HIPC(hipGetLastError());
     return eqf_set_sigma(f, b, sigma, ld);
+}
+
+int eqf_set_camera_offset(eqf_filter* f, const double* q, const double* x) {
+    if (!f || !q || !x) return EQF_ERR_INVALID;
+    const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    if (!(std::fabs(n2 - 1.0) < 1e-6)) return EQF_ERR_INVALID;
+    HIPC(hipSetDevice(f->device));
+    HIPC(hipStreamSynchronize(f->stream));
+    std::copy(q, q + 4, f->prm.camq);
+    std::copy(x, x + 3, f->prm.camx);
+    std::copy(q, q + 4, f->set.cameraOffset_q);
+    std::copy(x, x + 3, f->set.cameraOffset_x);
+    setCameraConstants(f->prm);
+    return EQF_OK;
 }
 
 int eqf_get_last_update(eqf_filter* f, int b, double* delta, double* gamma, double* Gamma) {

@@ -124,6 +124,9 @@ int eqf_set_state(eqf_filter* f, int b, int N, const int* ids, const double* pos
     const double* velocity, const double* p0, const double* A_q, const double* A_x, const double* w, const double* Q_q,
     const double* Q_a, const double* bias6, const double* sigma, int ld, double currentTime, const double* currentVelocity6,
     const double* accumulatedVelocity6, double accumulatedTime, int initialised);
+/* xi0.cameraOffset = T_IC for the whole batch (VIOFilter::setAuxiliaryData, VIOFilter.cpp:74-82, overwrites the value
+ * taken from the settings at construction, :68).  q must be a unit quaternion (w,x,y,z). */
+int eqf_set_camera_offset(eqf_filter* f, const double* q, const double* x);
 /* The remaining scalar state needed for a lossless dump: currentVelocity6, accumulatedVelocity6, accumulatedTime,
  * initialised flag (any pointer may be NULL). */
 int eqf_get_integrator(eqf_filter* f, int b, double* currentVelocity6, double* accumulatedVelocity6, double* accumulatedTime,

@@ -767,6 +767,29 @@ class VIOFilter:
         self.accumulatedTime = 0.0
         self.last = {}  # internals of the most recent update, for kernel-level parity tests
 
+    # -- VIOFilter.cpp:74-82.  aux: object with initialAttitude (quaternion wxyz), initialPosition, cameraOffset (SE3)
+    def setAuxiliaryData(self, aux):
+        self.auxData = aux
+        self.xi0.pose = SE3(np.array(aux.initialAttitude, dtype=float), np.array(aux.initialPosition, dtype=float))
+        self.xi0.velocity = np.zeros(3)
+        self.initialisedFlag = True
+        self.xi0.cameraOffset = aux.cameraOffset.copy()
+
+    # -- VIOFilter.cpp:93-118: landmarks given in the inertial frame; Sigma = initialPointVariance * I with the
+    # 11x11 base block kept.
+    def setInertialPoints(self, points, ids):
+        points = np.asarray(points, dtype=float).reshape(-1, 3)
+        N = len(points)
+        tf = (self.xi0.pose * self.xi0.cameraOffset).inverse()
+        self.xi0.p = np.array([tf.apply(pt) for pt in points]).reshape(-1, 3)
+        self.xi0.ids = np.array(ids, dtype=np.int64)
+        self.X.Q = [SOT3() for _ in range(N)]
+        self.X.ids = np.array(ids, dtype=np.int64)
+        n = SIGMA_BASE_SIZE + 3 * N
+        Sn = np.eye(n) * self.settings.initialPointVariance
+        Sn[0:SIGMA_BASE_SIZE, 0:SIGMA_BASE_SIZE] = self.Sigma[0:SIGMA_BASE_SIZE, 0:SIGMA_BASE_SIZE]
+        self.Sigma = Sn
+
     # -- outputs (VIOFilter.cpp:304-309, :343)
     def stateEstimate(self):
         return state_group_action(self.X, self.xi0)

@@ -327,3 +327,86 @@ def test_split_propagate_path_equals_fused(hip, monkeypatch):
     assert rel_fro(out[1][0], out[0][0]) < 1e-9
     assert all(np.abs(out[0][1][k] - out[1][1][k]).max() < 1e-9 for k in out[0][1])
     assert np.abs(out[0][2] - out[1][2]).max() < 1e-9
+
+
+def _aux_case(N):
+    from oracle import eqf_numpy as en
+
+    i = np.arange(N)
+    lm = np.stack([2 * np.sin(1.3 * i), 2 * np.cos(0.7 * i), 5 + np.sin(0.37 * i)], axis=1)
+    att = np.array([np.sqrt(0.5), 0, -np.sqrt(0.5), 0])
+    pos = np.array([0.3, -0.2, 1.0])
+    cq = np.array([0.98, 0.1, -0.1, np.sqrt(1 - 0.98 * 0.98 - 0.02)])
+    cx = np.array([0.1, -0.05, 0.02])
+    T = en.SE3(att, pos) * en.SE3(cq, cx)
+    pts = np.array([T.apply(p) for p in lm])
+    return lm, att, pos, cq, cx, pts, (100 + 2 * i).astype(np.int32)
+
+
+def _aux_oracle(N, frames):
+    """numpy oracle started through setAuxiliaryData + setInertialPoints (VIOFilter.cpp:51-58, 74-118)."""
+    from types import SimpleNamespace
+
+    from oracle import eqf_numpy as en
+
+    lm, att, pos, cq, cx, pts, ids = _aux_case(N)
+    s = en.Settings()
+    s.initialPointVariance, s.measurementVariance, s.velOmegaVariance, s.velAccelVariance, s.outlierThreshold = 5000.0, 0.003, 1e-4, 1e-4, 1e9
+    fo = en.VIOFilter(s)
+    fo.setAuxiliaryData(SimpleNamespace(initialAttitude=att, initialPosition=pos, cameraOffset=en.SE3(cq, cx)))
+    fo.setInertialPoints(pts, ids)
+    y = lm / np.linalg.norm(lm, axis=1, keepdims=True)
+    k = 0
+    for f in range(frames):
+        stamp = 0.05 * f + 0.0025
+        while 0.005 * k < stamp:
+            fo.processIMUData(en.IMUVelocity(0.005 * k, np.zeros(3), np.array([9.81, 0, 0])))
+            k += 1
+        fo.processVisionData(stamp, ids, y)
+    return fo, y, ids
+
+
+def test_auxiliary_data_and_inertial_points_start(hip):
+    """setAuxiliaryData + setInertialPoints through the Python mirror of the class."""
+    from eqf_vio_amd import filter as vf
+
+    N, frames = 12, 6
+    fo, y, ids = _aux_oracle(N, frames)
+    lm, att, pos, cq, cx, pts, _ = _aux_case(N)
+    st = hip.settings_from_dict(dict(initialPointVariance=5000.0, measurementVariance=0.003, velOmegaVariance=1e-4, velAccelVariance=1e-4,
+                                outlierThreshold=1e9))
+    fg = vf.VIOFilter(st, capacity=N, auxiliaryData=vf.AuxiliaryFilterData(att, pos, 0.0, cq, cx))
+    fg.setInertialPoints(pts, ids)
+    e0 = fg.stateEstimate()
+    assert np.abs(e0.bodyLandmarks - lm).max() < 1e-12  # (pose * cameraOffset)^-1 * inertial point = camera-frame point
+    k = 0
+    for f in range(frames):
+        stamp = 0.05 * f + 0.0025
+        while 0.005 * k < stamp:
+            fg.processIMUData(vf.IMUVelocity(0.005 * k, np.zeros(3), np.array([9.81, 0, 0])))
+            k += 1
+        fg.processVisionData(vf.VisionMeasurement(stamp, ids, y))
+    eo, eg = fo.stateEstimate(), fg.stateEstimate()
+    assert rel_fro(fg.stateCovariance(), fo.stateCovariance()) < SIGMA_TOL
+    assert np.abs(eg.pose_x - eo.pose.x).max() < 1e-8 and np.abs(eg.pose_q - eo.pose.q).max() < 1e-8
+    assert np.abs(eg.bodyLandmarks - eo.p).max() < 1e-7
+    assert np.array_equal(eg.ids, ids)
+    # true start + exact bearings: the estimate stays at the truth
+    assert np.abs(eg.pose_x - pos).max() < 1e-6
+
+
+def test_cpp_facade_auxiliary_start_matches_the_oracle():
+    import os
+    import re
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "eqf_vio_amd", "cpp", "eqf_example")
+    N, frames = 12, 6
+    out = subprocess.run([exe, str(N), str(frames), "aux"], capture_output=True, text=True, check=True).stdout
+    nums = [float(x) for x in re.findall(r"[-+]?\d+\.\d+(?:e[-+]?\d+)?", out)]
+    pos, q, fro = nums[1:4], nums[4:8], nums[8]
+    fo, _, _ = _aux_oracle(N, frames)
+    e = fo.stateEstimate()
+    assert np.abs(np.array(pos) - e.pose.x).max() < 2e-6  # printed with 6 decimals
+    assert np.abs(np.array(q) - e.pose.q).max() < 2e-6
+    assert abs(fro - np.linalg.norm(fo.stateCovariance())) < 1e-5 * fro

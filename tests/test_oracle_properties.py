@@ -335,3 +335,32 @@ def test_closed_forms_used_on_the_device():
             inner = O.skew(q) @ O.skew(v_C) - 2 * np.outer(v_C, q) + np.outer(q, v_C)
             Aq = -RQ @ inner @ RQ.T / (q @ q)  # the scale a_i cancels: no 3x3 inverse needed
             assert np.abs(Aq - A0[5 + 3 * i:8 + 3 * i, 5 + 3 * i:8 + 3 * i]).max() < 1e-11
+
+
+def test_auxiliary_start_places_landmarks_in_the_camera_frame():
+    """setAuxiliaryData + setInertialPoints (VIOFilter.cpp:74-118): xi0 landmarks = (pose * cameraOffset)^-1 * p,
+    Sigma = initialPointVariance * I outside the base block, no gravity alignment at the first IMU sample."""
+    from types import SimpleNamespace
+
+    rng = np.random.default_rng(5)
+    att = rng.normal(size=4)
+    att /= np.linalg.norm(att)
+    cq = rng.normal(size=4)
+    cq /= np.linalg.norm(cq)
+    pos, cx = rng.normal(size=3), 0.1 * rng.normal(size=3)
+    cam_pts = rng.normal(size=(7, 3)) + np.array([0, 0, 5.0])
+    T = O.SE3(att, pos) * O.SE3(cq, cx)
+    pts = np.array([T.apply(p) for p in cam_pts])
+    f = O.VIOFilter(O.Settings(initialPointVariance=12.5, initialVelocityVariance=3.0))
+    f.setAuxiliaryData(SimpleNamespace(initialAttitude=att, initialPosition=pos, cameraOffset=O.SE3(cq, cx)))
+    f.setInertialPoints(pts, np.arange(7) + 40)
+    est = f.stateEstimate()
+    assert np.abs(est.p - cam_pts).max() < 1e-13
+    assert np.array_equal(est.ids, np.arange(7) + 40)
+    S = f.stateCovariance()
+    assert S.shape == (32, 32)
+    assert np.array_equal(S[11:, 11:], 12.5 * np.eye(21)) and not S[:11, 11:].any()
+    assert S[8, 8] == 3.0
+    # already initialised: the first IMU sample must not re-align the attitude with gravity (VIOFilter.cpp:123-125)
+    f.processIMUData(O.IMUVelocity(0.0, np.zeros(3), np.array([0.0, 9.81, 0.0])))
+    assert np.array_equal(f.xi0.pose.q, att)
