@@ -16,6 +16,7 @@
 #include "eqf_dense.hpp"
 #include "eqf_device.hpp"
 #include "eqf_propagate.hpp"
+#include "eqf_chol64.hpp"
 #include "eqf_update.hpp"
 
 using namespace eqf;
@@ -54,7 +55,8 @@ struct eqf_filter {
     int pS = 0, pG = 0;
     // update chains
     double *SA = nullptr, *SL = nullptr, *YW = nullptr, *YO = nullptr, *EA = nullptr, *EL = nullptr, *ZW = nullptr, *ZO = nullptr;
-    int ldS = 0, ldY = 0, ldE = 0, ldZ = kNB;
+    int ldS = 0, ldY = 0, ldE = 0, ldZ = kSB;
+    long long strideDS = 0, strideDE = 0;  // diagonal-factor records of the two chains
     long long strideS = 0, strideY = 0, strideE = 0, strideZ = 0;
     double *dbgDelta = nullptr, *dbgGamma = nullptr, *dbgGammaTot = nullptr, *red = nullptr;
     int* errflag = nullptr;
@@ -331,7 +333,22 @@ template <typename T>
 int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, const int* perm, int Nmax) {
     UpdArgs a = makeUpdArgs(f, bearings, bearStride, perm);
     const int B = f->B;
-    const int mp = roundUp(sDim(Nmax), kNB), nep = roundUp(eDim(Nmax), kNB);
+    // Which factorisation kernel: 64-wide block columns with per-workgroup panel solves when the update is latency-bound
+    // (few tiles: one or a few small filters), 32-wide tiles with explicit block inverses + MFMA panels when it is
+    // throughput-bound.  EQF_CHOL_MODE = 64 | 32 | 32inv overrides (experiments).
+    const int nb64S = roundUp(sDim(Nmax), kSB) / kSB, nb64E = roundUp(eDim(Nmax), kSB) / kSB;
+    const int wt64 = roundUp(yCols(Nmax), kSB) / kSB;
+    const int nblk64 = nb64S * nb64S + wt64 * nb64S + nb64E * nb64E + nb64E;
+    static const char* modeEnv = std::getenv("EQF_CHOL_MODE");
+    bool use64 = (long long)nblk64 * B <= 768;
+    int forceInv = -1;
+    if (modeEnv) {
+        use64 = std::strcmp(modeEnv, "64") == 0;
+        if (std::strcmp(modeEnv, "32inv") == 0) forceInv = 1;
+        if (std::strcmp(modeEnv, "32") == 0) forceInv = 0;
+    }
+    a.pad = use64 ? kSB : kNB;
+    const int mp = roundUp(sDim(Nmax), a.pad), nep = roundUp(eDim(Nmax), a.pad);
     const int nv = kLm0 + 3 * Nmax;
     // prep
     const int nvPad = roundUp(std::min(nv, kLm0 + 3 * kPrepLmChunk), 16);
@@ -344,6 +361,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     if (!attrSet) {
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         attrSet = true;
     }
     int rc = profiled(f, EQF_PROF_UPDATE_PREP, [&] {
@@ -353,22 +371,36 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     // chains
     ChainArgs cS{}, cE{};
     cS.g = a.g; cS.A = f->SA; cS.D = f->SL; cS.W = f->YW; cS.WO = f->YO;
-    cS.ldA = f->ldS; cS.ldW = f->ldY; cS.strideA = f->strideS; cS.strideD = f->strideS; cS.strideW = f->strideY;
-    cS.kind = 0; cS.nbMax = mp / kNB; cS.wtMax = roundUp(yCols(Nmax), kNB) / kNB;
+    cS.ldA = f->ldS; cS.ldW = f->ldY; cS.strideA = f->strideS; cS.strideD = f->strideDS; cS.strideW = f->strideY;
+    cS.kind = 0;
     cE.g = a.g; cE.A = f->EA; cE.D = f->EL; cE.W = f->ZW; cE.WO = f->ZO;
-    cE.ldA = f->ldE; cE.ldW = f->ldZ; cE.strideA = f->strideE; cE.strideD = f->strideE; cE.strideW = f->strideZ;
-    cE.kind = 1; cE.nbMax = nep / kNB; cE.wtMax = 1;
-    const int steps = std::max(cS.nbMax, cE.nbMax);
-    const int nblk = cS.nbMax * cS.nbMax + cS.wtMax * cS.nbMax + cE.nbMax * cE.nbMax + cE.wtMax * cE.nbMax;
-    // Panel blocks by explicit inverse + MFMA when the launch is throughput-bound (many tiles), by per-workgroup forward
-    // substitution when it is latency-bound (one small filter): see k_chol_step.
-    const bool inverse = (long long)nblk * B >= 2048;
-    for (int k = 0; k < steps; ++k) {
-        rc = profiled(f, EQF_PROF_CHOL_STEP, [&] {
-            if (inverse) hipLaunchKernelGGL(k_chol_step<true>, dim3(nblk, B), dim3(256), 0, f->stream, cS, cE, k, f->errflag);
-            else hipLaunchKernelGGL(k_chol_step<false>, dim3(nblk, B), dim3(256), 0, f->stream, cS, cE, k, f->errflag);
-        });
-        if (rc) return rc;
+    cE.ldA = f->ldE; cE.ldW = f->ldZ; cE.strideA = f->strideE; cE.strideD = f->strideDE; cE.strideW = f->strideZ;
+    cE.kind = 1;
+    if (use64) {
+        cS.nbMax = nb64S; cS.wtMax = wt64;
+        cE.nbMax = nb64E; cE.wtMax = 1;
+        const int steps = std::max(nb64S, nb64E);
+        for (int k = 0; k < steps; ++k) {
+            rc = profiled(f, EQF_PROF_CHOL_STEP, [&] {
+                hipLaunchKernelGGL(k_chol_step64, dim3(nblk64, B), dim3(256), sizeof(Step64Lds), f->stream, cS, cE, k, f->errflag);
+            });
+            if (rc) return rc;
+        }
+    } else {
+        cS.nbMax = mp / kNB; cS.wtMax = roundUp(yCols(Nmax), kNB) / kNB;
+        cE.nbMax = nep / kNB; cE.wtMax = 1;
+        const int steps = std::max(cS.nbMax, cE.nbMax);
+        const int nblk = cS.nbMax * cS.nbMax + cS.wtMax * cS.nbMax + cE.nbMax * cE.nbMax + cE.wtMax * cE.nbMax;
+        // Panel blocks by explicit inverse + MFMA when the launch is throughput-bound (many tiles), by per-workgroup
+        // forward substitution otherwise: see k_chol_step.
+        const bool inverse = forceInv >= 0 ? forceInv == 1 : (long long)nblk * B >= 2048;
+        for (int k = 0; k < steps; ++k) {
+            rc = profiled(f, EQF_PROF_CHOL_STEP, [&] {
+                if (inverse) hipLaunchKernelGGL(k_chol_step<true>, dim3(nblk, B), dim3(256), 0, f->stream, cS, cE, k, f->errflag);
+                else hipLaunchKernelGGL(k_chol_step<false>, dim3(nblk, B), dim3(256), 0, f->stream, cS, cE, k, f->errflag);
+            });
+            if (rc) return rc;
+        }
     }
     const int colBlocks = (nv + 6 + 63) / 64;
     rc = profiled(f, EQF_PROF_REDUCE,
@@ -700,10 +732,10 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     f->nTot = kLm0 + 3 * cap;
     f->ld = roundUp(f->nTot, 16);
     f->sigmaStride = (long long)f->nTot * f->ld;
-    const int mpC = roundUp(2 * cap, kNB), nepC = roundUp(eDim(cap), kNB), ycC = roundUp(yCols(cap), kNB);
-    f->ldS = mpC; f->ldY = ycC; f->ldE = nepC; f->ldZ = kNB;
+    const int mpC = roundUp(2 * cap, kSB), nepC = roundUp(eDim(cap), kSB), ycC = roundUp(yCols(cap), kSB);
+    f->ldS = mpC; f->ldY = ycC; f->ldE = nepC; f->ldZ = kSB;
     f->strideS = (long long)mpC * mpC; f->strideY = (long long)mpC * ycC;
-    f->strideE = (long long)nepC * nepC; f->strideZ = (long long)nepC * kNB;
+    f->strideE = (long long)nepC * nepC; f->strideZ = (long long)nepC * kSB;
     int rc = EQF_OK;
     auto chk = [&](int r) { if (r && !rc) rc = r; };
     if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) rc = EQF_ERR_HIP;
@@ -714,9 +746,11 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     }
     chk(dmalloc(&f->p0, (size_t)3 * cap * B));
     chk(dmalloc(&f->lmc, (size_t)15 * cap * B));
-    chk(dmalloc(&f->SA, f->strideS * B)); chk(dmalloc(&f->SL, f->strideS * B));
+    f->strideDS = std::max<long long>(f->strideS, (long long)(mpC / kSB) * kDRec);
+    f->strideDE = std::max<long long>(f->strideE, (long long)(nepC / kSB) * kDRec);
+    chk(dmalloc(&f->SA, f->strideS * B)); chk(dmalloc(&f->SL, f->strideDS * B));
     chk(dmalloc(&f->YW, f->strideY * B)); chk(dmalloc(&f->YO, f->strideY * B));
-    chk(dmalloc(&f->EA, f->strideE * B)); chk(dmalloc(&f->EL, f->strideE * B));
+    chk(dmalloc(&f->EA, f->strideE * B)); chk(dmalloc(&f->EL, f->strideDE * B));
     chk(dmalloc(&f->ZW, f->strideZ * B)); chk(dmalloc(&f->ZO, f->strideZ * B));
     chk(dmalloc(&f->dbgDelta, (size_t)2 * cap * B));
     chk(dmalloc(&f->dbgGamma, (size_t)(kLm0 + 3 * cap) * B));

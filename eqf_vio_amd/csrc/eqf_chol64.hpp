@@ -1,0 +1,377 @@
+// k_chol_step64: the two Cholesky chains of the vision update in 64-wide block columns (gfx950, fp64).
+//
+// Latency variant of k_chol_step (eqf_update.hpp) for ONE small filter, where a frame is bound by the number of
+// dependent launches and by the serial pivot chain, not by flops: half as many launches (n/64 instead of n/32), and the
+// serial part of a launch -- factoring the next 64x64 diagonal block -- is organised so that nothing is solved twice:
+//
+//   diagonal block  factored in four 16-column stages: one wave holds the 64 rows of the panel in registers (lane =
+//                   row), so the right-looking 16-column potrf scales / updates the rows below the diagonal block in
+//                   the same instruction stream (L_rj = A_rj L_jj^-T for free) -- and 16 otherwise idle lanes carry the
+//                   rows of the identity, which leave as W_jj^T = L_jj^-T, the inverse the other workgroups need.  The
+//                   16x16 tiles of the next column are updated on the matrix cores between two stages; all other
+//                   trailing tiles are updated by the idle waves WHILE the next 16 columns are being factored.
+//   panel blocks    X = A_RK L_KK^-T (and Y_K = L_KK^-1 R_K) as a 4-stage blocked substitution made of 16x16x16
+//                   products only, in the transposed form X_j^T = W_jj (A_j^T - sum_{i<j} L_ji X_i^T): the accumulator
+//                   layout of v_mfma_f64_16x16x4_f64 (row = (lane>>4) + 4 reg, col = lane & 15) IS its B-operand layout
+//                   for the matrix held in the accumulator, so each result feeds the next product straight from
+//                   registers; only L / W blocks are read from LDS.  Every wave owns a 16-row (16-column) strip, no
+//                   barriers, no long unrolled scalar code.  (A launch executes its code exactly once, so straight-line
+//                   scalar code runs at instruction-fetch / LDS-latency speed: an unrolled 32-column forward
+//                   substitution measured 27 cycles per FMA.)
+//                   Every workgroup solves the two panel blocks its tile needs while the diagonal workgroup factors
+//                   the next block (one-step look-ahead as in k_chol_step).
+//
+// Same mathematics as k_chol_step (see the header of eqf_update.hpp: S-chain Y = L^-1 [C Sigma | delta | V], E-chain
+// [Zt | Et] = Le^-1 [Z_P | E_top], replacing S.inverse() / Sigma_e.inverse() of VIOFilter.cpp:276-277 and
+// EqFMatrices.cpp:239); chain dimensions are padded to multiples of 64 with identity (UpdArgs::pad = 64).
+#pragma once
+#include "eqf_update.hpp"
+
+namespace eqf {
+
+constexpr int kSB = 64;        // block-column width
+constexpr int kSP = kSB + 1;   // LDS pitch of a 64x64 tile
+constexpr int kQB = 16;        // sub-block (one MFMA tile)
+constexpr int kWP = kQB + 1;   // LDS pitch of a 16x16 inverse block
+constexpr int kDRec = kSB * kSB + 4 * kQB * kQB;  // doubles per diagonal-factor record in ChainArgs::D:
+// [0, 4096) L_KK row-major 64x64 (lower block triangle) ; [4096, 5120) W_jj = L_jj^-1, j = 0..3, row-major 16x16
+
+struct Step64Lds {
+    double P[kSB][kSP];   // A_RK -> L_RK (A tiles) / R_K -> Y_K (rhs tiles)
+    double Q[kSB][kSP];   // A_CK -> L_CK
+    double L[kSB][kSP];   // L_KK ; the diagonal workgroup factors the next block in here
+    double Wd[4][kQB][kWP];
+    double D0[kQB][kWP];  // copy of the leading 16x16 block of the matrix being factored (read by the identity-row wave)
+};
+
+EQF_DI void chainDims64(const ChainArgs& ch, int N, int* nb, int* wt) {
+    if (ch.kind == 0) {
+        *nb = roundUp(sDim(N), kSB) / kSB;
+        *wt = roundUp(yCols(N), kSB) / kSB;
+    } else {
+        *nb = roundUp(eDim(N), kSB) / kSB;
+        *wt = 1;
+    }
+}
+
+// One 16x16 output tile on v_mfma_f64_16x16x4_f64:  acc += sgn * sum_{k<KD} A(i0+i, k) * B(k, j0+j).
+//   A(i,k) = Am[i * lda + k] ;  B(k,j) = TB ? Bm[j * ldb + k] : Bm[k * ldb + j]
+template <bool TB, int KD>
+EQF_DI f64x4 mmTile(f64x4 acc, const double* Am, int lda, int i0, const double* Bm, int ldb, int j0, int lane, double sgn) {
+    const int lr = lane & 15, lk = lane >> 4;
+    double av[KD / 4], bv[KD / 4];
+#pragma unroll
+    for (int s = 0; s < KD / 4; ++s) {  // all operand reads first: one LDS latency per tile, not one per MFMA
+        av[s] = Am[(i0 + lr) * lda + 4 * s + lk];
+        bv[s] = TB ? Bm[(j0 + lr) * ldb + 4 * s + lk] : Bm[(4 * s + lk) * ldb + j0 + lr];
+    }
+#pragma unroll
+    for (int s = 0; s < KD / 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sgn * av[s], bv[s], acc, 0, 0, 0);
+    return acc;
+}
+// acc += sgn * A * Bm with the 16x16 matrix Bm held in ANOTHER accumulator tile: register s of the accumulator layout
+// (element [(lane>>4) + 4s][lane & 15]) is exactly the B operand of k-step s (element [4s + (lane>>4)][lane & 15]).
+//   A(i,k) = Am[(i0 + i) * lda + k0 + k], 16 x 16
+EQF_DI f64x4 mmRegB(f64x4 acc, const double* Am, int lda, int i0, int k0, const f64x4& Breg, int lane, double sgn) {
+    const int lr = lane & 15, lk = lane >> 4;
+    double av[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) av[s] = Am[(i0 + lr) * lda + k0 + 4 * s + lk];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sgn * av[s], Breg[s], acc, 0, 0, 0);
+    return acc;
+}
+// 16x16 tile in the accumulator layout (row = (lane >> 4) + 4 * reg, col = lane & 15) <-> memory
+EQF_DI f64x4 ldTile(const double* M, int ld, int r0, int c0, int lane) {
+    f64x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = M[(r0 + (lane >> 4) + 4 * q) * ld + c0 + (lane & 15)];
+    return v;
+}
+EQF_DI void stTile(const f64x4& v, double* M, int ld, int r0, int c0, int lane) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) M[(r0 + (lane >> 4) + 4 * q) * ld + c0 + (lane & 15)] = v[q];
+}
+
+#ifdef EQF_STEP64_STAMPS
+__device__ long long g_stamps[64][16];
+#define EQF_STAMP(i) do { if (diagNext && tid == 0 && !second) g_stamps[K][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define EQF_STAMP(i) do { } while (0)
+#endif
+
+// Right-looking Cholesky of 16 columns of a 64-row panel by one wave, one row per lane.  The rows are ROTATED so that
+// every lane index in the loop is a compile-time constant (a run-time lane select costs an SALU add + hazard nops per
+// v_readlane): lane l holds row (l + rot) & 63 of src, the pivots sit in lanes 0..15.
+//   lanes [0, nReal)   real rows (columns colBase..colBase+15 of src).  Rows below the diagonal block take part in every
+//                      scaling / rank-1 update, so they leave as L_rj = A_rj L_jj^-T.
+//   lanes [48, 64)     if hasId: the rows of the identity, which leave as the rows of L_jj^-T:
+//                      Wj[c][i] = (L_jj^-1)[c][i] comes from lane 48 + i, register c.   (needs nReal <= 48)
+// No LDS inside the loop: the pivot chain, the next column (immediately) and the rest of each rank-1 update (one
+// iteration later, filling the latency of the next pivot's rsqrt chain) all use v_readlane broadcasts.
+// Measured in isolation (scripts/micro/potrf16_bench.hip): 4.1 k cycles warm, of which the pivot chain alone is 2.6 k.
+EQF_DI void potrf16(double (*T)[kSP], const double* src, int srcLd, double (*Wj)[kWP], int colBase, int rot, int nReal, bool hasId,
+    bool writeBack, int lane, int* bad) {
+    double row[kQB];
+    const bool isId = hasId && lane >= 48;
+    const bool isReal = lane < nReal;
+    const int r = (lane + rot) & (kSB - 1);
+#pragma unroll
+    for (int c = 0; c < kQB; ++c) row[c] = isId ? ((lane - 48 == c) ? 1.0 : 0.0) : (isReal ? src[r * srcLd + colBase + c] : 0.0);
+    double ljPrev = 0.0;
+#pragma unroll
+    for (int c = 0; c < kQB; ++c) {
+        const double d = readlane64(row[c], c);
+        if (!(d > 0.0)) *bad = 1;
+        const double rd = rsqrtPivot(d);
+        if (c >= 1) {
+#pragma unroll
+            for (int c2 = c + 1; c2 < kQB; ++c2) row[c2] = fma(-ljPrev, readlane64(ljPrev, c2), row[c2]);
+        }
+        const double lj = row[c] * rd;
+        if (c + 1 < kQB) row[c + 1] = fma(-lj, readlane64(lj, c + 1), row[c + 1]);
+        row[c] = lj;
+        ljPrev = lj;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int c2 = c + 1; c2 < kQB; ++c2) __asm__ volatile("" : "+v"(row[c2]));
+#endif
+    }
+    if (writeBack && isReal) {
+#pragma unroll
+        for (int c = 0; c < kQB; ++c) T[r][colBase + c] = (lane >= c) ? row[c] : 0.0;
+    }
+    if (isId) {
+#pragma unroll
+        for (int c = 0; c < kQB; ++c) Wj[c][lane - 48] = row[c];
+    }
+}
+
+// Factor the 64x64 symmetric block in s.L in place (lower block triangle; the upper triangles of the diagonal blocks are
+// zeroed) and form s.Wd.  All 256 threads.  `pre` is extra work for waves 2 and 3 during the first stage (the diagonal
+// workgroup's remaining trailing-update tiles): pre(wave).
+template <typename Pre>
+EQF_DI void factor64(Step64Lds& s, int tid, int* bad, Pre pre, long long* st = nullptr) {
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+        const int base = kQB * j;
+        // ---- phase P: the next 16 columns (wave 0; wave 1 carries the identity rows at stage 0, where wave 0 has no idle
+        // lanes) while waves 2, 3 apply the deferred updates of stage j-1 to the columns >= j+1
+        if (wv == 0) potrf16(s.L, &s.L[0][0], kSP, s.Wd[j], base, base, kSB - base, j > 0, true, lane, bad);
+        else if (wv == 1 && j == 0) potrf16(s.L, &s.D0[0][0], kWP, s.Wd[0], 0, 0, kQB, true, false, lane, bad);
+        else if (wv >= 2) {
+            if (j == 0) pre(wv);
+            else {
+                int t = 0;
+#pragma unroll 1
+                for (int c = j + 1; c < 4; ++c)
+#pragma unroll 1
+                    for (int r = c; r < 4; ++r, ++t) {
+                        if ((t & 1) != (wv & 1)) continue;
+                        f64x4 acc = ldTile(&s.L[0][0], kSP, kQB * r, kQB * c, lane);
+                        acc = mmTile<true, kQB>(acc, &s.L[0][base - kQB], kSP, kQB * r, &s.L[0][base - kQB], kSP, kQB * c, lane, -1.0);
+                        stTile(acc, &s.L[0][0], kSP, kQB * r, kQB * c, lane);
+                    }
+            }
+        }
+#ifdef EQF_STEP64_STAMPS
+        if (st && tid == 0) st[2 * j] = __builtin_readcyclecounter();
+#endif
+        __syncthreads();
+        // ---- phase U: the tiles of column j+1 (needed by the next stage), one per wave:  T_r,j+1 -= L_rj L_j+1,j^T
+        if (j < 3 && wv < 3 - j) {
+            const int r = j + 1 + wv;
+            f64x4 acc = ldTile(&s.L[0][0], kSP, kQB * r, base + kQB, lane);
+            acc = mmTile<true, kQB>(acc, &s.L[0][base], kSP, kQB * r, &s.L[0][base], kSP, base + kQB, lane, -1.0);
+            stTile(acc, &s.L[0][0], kSP, kQB * r, base + kQB, lane);
+        }
+#ifdef EQF_STEP64_STAMPS
+        if (st && tid == 0) st[2 * j + 1] = __builtin_readcyclecounter();
+#endif
+        __syncthreads();
+    }
+}
+
+// Panel solve of one 16-wide strip of M in place, four 16x16 stages chained through the accumulators:
+//   TR = true : the strip is rows x0..x0+15,    M <- M L^-T   (held transposed:  X_j^T = W_jj (A_j^T - sum L_ji X_i^T))
+//   TR = false: the strip is columns x0..x0+15, M <- L^-1 M   (                  Y_j   = W_jj (R_j   - sum L_ji Y_i))
+template <bool TR>
+EQF_DI void solveStrip(double (*M)[kSP], const Step64Lds& s, int x0, int lane) {
+    f64x4 Z[4], X[4];
+    const int lc = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Z[j][q] = TR ? M[x0 + lc][kQB * j + lg + 4 * q] : M[kQB * j + lg + 4 * q][x0 + lc];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+        X[j] = mmRegB(zero, &s.Wd[j][0][0], kWP, 0, 0, Z[j], lane, 1.0);
+#pragma unroll
+        for (int j2 = j + 1; j2 < 4; ++j2) Z[j2] = mmRegB(Z[j2], &s.L[0][0], kSP, kQB * j2, kQB * j, X[j], lane, -1.0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (TR) M[x0 + lc][kQB * j + lg + 4 * q] = X[j][q];
+            else M[kQB * j + lg + 4 * q][x0 + lc] = X[j][q];
+        }
+}
+
+// grid.x = sum over the two chains of nbMax^2 (A tiles) + wtMax * nbMax (rhs tiles), nbMax / wtMax in 64-blocks;
+// grid.y = B; block = 256; dynamic LDS = sizeof(Step64Lds).
+__global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1, int K, int* errflag) {
+    const int b = blockIdx.y;
+    const int n0 = c0.nbMax * c0.nbMax + c0.wtMax * c0.nbMax;
+    const bool second = (int)blockIdx.x >= n0;
+    const ChainArgs& ch = second ? c1 : c0;
+    int idx = second ? (int)blockIdx.x - n0 : (int)blockIdx.x;
+    const Glob& g = ch.g[b];
+    if (!g.updateOk || g.N == 0) return;
+    int nb, wt;
+    chainDims64(ch, g.N, &nb, &wt);
+    if (K >= nb) return;
+    bool isW = false;
+    int R, C;  // A tile (R,C) or rhs tile (t = R, C)
+    if (idx < ch.nbMax * ch.nbMax) {
+        R = idx / ch.nbMax;
+        C = idx % ch.nbMax;
+        if (R >= nb || C > R || C <= K) return;
+    } else {
+        idx -= ch.nbMax * ch.nbMax;
+        isW = true;
+        R = idx / ch.nbMax;
+        C = idx % ch.nbMax;
+        if (R >= wt || C >= nb || C < K) return;
+    }
+    double* A = ch.A + (long long)b * ch.strideA;
+    double* D = ch.D + (long long)b * ch.strideD;
+    double* W = ch.W + (long long)b * ch.strideW;
+    double* WO = ch.WO + (long long)b * ch.strideW;
+    const int ldA = ch.ldA, ldW = ch.ldW;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
+    Step64Lds& s = *reinterpret_cast<Step64Lds*>(smem64);
+    int bad = 0;
+    const bool diagNext = !isW && R == C && C == K + 1;
+    const bool needQ = C > K;
+    const bool needP = isW || R != C;
+    const bool solveOnly = isW && C == K;
+
+    // ---- which 16x16 tiles of the 64x64 output tile this wave owns: its 16-row strip (tiles (wv, 0..3)); the diagonal
+    // workgroup needs the lower triangle only and the first column first: slot 0 = (wv, 0), then the other tiles spread
+    // over waves 2, 3 (they run while waves 0, 1 factor the first 16 columns)
+    int tr[4], tc[4], nt;
+    if (!diagNext) {
+        nt = 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { tr[i] = wv; tc[i] = i; }
+    } else {
+        // deferred tiles (1,1) (2,1) (3,1) (2,2) (3,2) (3,3): wave 2 takes the even, wave 3 the odd ones
+        nt = wv >= 2 ? 4 : 1;
+        tr[0] = wv; tc[0] = 0;
+        tr[1] = wv == 2 ? 1 : 2; tc[1] = 1;
+        tr[2] = wv == 2 ? 3 : 2; tc[2] = wv == 2 ? 1 : 2;
+        tr[3] = 3;               tc[3] = wv == 2 ? 2 : 3;
+    }
+
+    EQF_STAMP(0);
+    // ---- every global read of the launch is issued up front (the data was written by the previous launch on other
+    // XCDs: each access is a ~2 us miss, so they must all be in flight together)
+    double* Ct = isW ? (W + (long long)(C * kSB) * ldW + R * kSB) : (A + (long long)(R * kSB) * ldA + C * kSB);
+    const int ldc = isW ? ldW : ldA;
+    f64x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            acc[i][q] = (solveOnly || i >= nt) ? 0.0 : Ct[(long long)(kQB * tr[i] + (lane >> 4) + 4 * q) * ldc + kQB * tc[i] + (lane & 15)];
+    const double* Dk = D + (long long)K * kDRec;
+    const double* Pg = isW ? (W + (long long)(K * kSB) * ldW + R * kSB) : (A + (long long)(R * kSB) * ldA + K * kSB);
+    const double* Qg = A + (long long)(C * kSB) * ldA + K * kSB;
+    const int ldp = isW ? ldW : ldA;
+    double rL[16], rW[4], rP[16], rQ[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int e = tid + 256 * u, rr = e >> 6, cc = e & 63;
+        rL[u] = (K == 0) ? A[(long long)rr * ldA + cc] : Dk[e];
+        rP[u] = needP ? Pg[(long long)rr * ldp + cc] : 0.0;
+        rQ[u] = needQ ? Qg[(long long)rr * ldA + cc] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) rW[u] = (K == 0) ? 0.0 : Dk[kSB * kSB + tid + 256 * u];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int e = tid + 256 * u, rr = e >> 6, cc = e & 63;
+        s.L[rr][cc] = rL[u];
+        if (rr < kQB && cc < kQB) s.D0[rr][cc] = rL[u];
+        s.P[rr][cc] = rP[u];
+        s.Q[rr][cc] = rQ[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = tid + 256 * u;
+        s.Wd[e >> 8][(e >> 4) & 15][e & 15] = rW[u];
+    }
+    __syncthreads();
+    // first block column: no look-ahead yet, every workgroup factors A_00 itself
+    if (K == 0) factor64(s, tid, &bad, [](int) {});
+    EQF_STAMP(1);
+    // ---- panel blocks: each wave solves its 16-row strip of P and of Q (16-column strip of the rhs block)
+    if (needP) {
+        if (isW) solveStrip<false>(s.P, s, kQB * wv, lane);
+        else solveStrip<true>(s.P, s, kQB * wv, lane);
+    }
+    if (needQ) solveStrip<true>(s.Q, s, kQB * wv, lane);
+    __syncthreads();
+    EQF_STAMP(2);
+
+    if (solveOnly) {
+        for (int e = tid; e < kSB * kSB; e += 256) WO[(long long)(K * kSB + (e >> 6)) * ldW + R * kSB + (e & 63)] = s.P[e >> 6][e & 63];
+    } else {
+        // ---- trailing update of this tile: A_RC -= L_RK L_CK^T  /  R_C -= L_CK Y_K
+        const double (*Am)[kSP] = isW ? s.Q : (needP ? s.P : s.Q);
+        auto upd = [&](int i) {
+            if (isW) acc[i] = mmTile<false, kSB>(acc[i], &Am[0][0], kSP, kQB * tr[i], &s.P[0][0], kSP, kQB * tc[i], lane, -1.0);
+            else acc[i] = mmTile<true, kSB>(acc[i], &Am[0][0], kSP, kQB * tr[i], &s.Q[0][0], kSP, kQB * tc[i], lane, -1.0);
+        };
+        if (!diagNext) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) upd(i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Ct[(long long)(kQB * tr[i] + (lane >> 4) + 4 * q) * ldc + kQB * tc[i] + (lane & 15)] = acc[i][q];
+        } else {
+            // ---- look-ahead: factor the freshly updated diagonal block for launch K + 1 in s.L (nobody reads it any more)
+            upd(0);
+            stTile(acc[0], &s.L[0][0], kSP, kQB * tr[0], kQB * tc[0], lane);
+            if (wv == 0) stTile(acc[0], &s.D0[0][0], kWP, 0, 0, lane);
+            __syncthreads();
+            EQF_STAMP(3);
+            auto pre = [&](int) {
+#pragma unroll
+                for (int i = 1; i < 4; ++i) {
+                    upd(i);
+                    stTile(acc[i], &s.L[0][0], kSP, kQB * tr[i], kQB * tc[i], lane);
+                }
+            };
+#ifdef EQF_STEP64_STAMPS
+            factor64(s, tid, &bad, pre, !second ? &g_stamps[K][8] : nullptr);
+#else
+            factor64(s, tid, &bad, pre);
+#endif
+            EQF_STAMP(4);
+            double* Dn = D + (long long)(K + 1) * kDRec;
+            for (int e = tid; e < kSB * kSB; e += 256) Dn[e] = s.L[e >> 6][e & 63];
+            for (int e = tid; e < 4 * kQB * kQB; e += 256) Dn[kSB * kSB + e] = s.Wd[e >> 8][(e >> 4) & 15][e & 15];
+            EQF_STAMP(5);
+        }
+    }
+    if (bad && errflag && tid == 0) atomicOr(errflag, 4);
+}
+
+}  // namespace eqf

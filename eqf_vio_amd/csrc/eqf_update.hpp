@@ -63,6 +63,7 @@ struct UpdArgs {
     double* dbgGammaTot;  // [B][9+3*cap]
     double* red;          // [B][256]: hV (6) at 0, G11 = [Zt|Et]^T [Zt|Et] (11x11) at 8
     int* errflag;
+    int pad;              // chain dimensions are padded (with identity) to multiples of this: 32 (k_chol_step) or 64 (k_chol_step64)
     Params prm;
 };
 
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void k_update_prep(UpdArgs a, int lmBlocks, in
 
     if ((int)blockIdx.x >= lmBlocks) {
         // ---- E-chain operand: EA = Sigma[6:,6:] (pad e=5 -> identity), ZW = [Z_P | E_top], 32 rows per workgroup
-        const int ne = eDim(N), nep = roundUp(ne, kNB);
+        const int ne = eDim(N), nep = roundUp(ne, a.pad);
         const int r0 = ((int)blockIdx.x - lmBlocks) * kNB;
         if (r0 >= nep) return;
         double* EA = a.EA + (long long)b * a.strideE;
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void k_update_prep(UpdArgs a, int lmBlocks, in
                 for (int c = 0; c < 6; ++c) row[c] = (comp == 0) ? Z[c] : (comp == 1 ? Z[6 + c] : Z[12 + c]);
             }
             if (rr < 5) row[6 + rr] = 1.0;  // E_top
-            for (int c = 0; c < kNB; ++c) ZW[(long long)rr * a.ldZ + c] = (c < 16) ? row[c] : 0.0;
+            for (int c = 0; c < a.ldZ; ++c) ZW[(long long)rr * a.ldZ + c] = (c < 16) ? row[c] : 0.0;
         }
         return;
     }
@@ -200,8 +201,8 @@ __global__ __launch_bounds__(256) void k_update_prep(UpdArgs a, int lmBlocks, in
     double* sCS0 = sCSraw + (long long)(2 * wv) * nvPad;
     double* sCS1 = sCS0 + nvPad;
     const int i = blockIdx.x * wpb + wv;
-    const int m = sDim(N), mp = roundUp(m, kNB);
-    const int yc = yCols(N), ycp = roundUp(yc, kNB);
+    const int m = sDim(N), mp = roundUp(m, a.pad);
+    const int yc = yCols(N), ycp = roundUp(yc, a.pad);
     double* SA = a.SA + (long long)b * a.strideS;
     double* YW = a.YW + (long long)b * a.strideY;
     double C[6] = {0, 0, 0, 0, 0, 0};
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(1024) void k_update_reduce(UpdArgs a, int colBlocks
     if ((int)blockIdx.x < colBlocks) {
         // 64 columns x 16 row slices per workgroup: many independent loads in flight (the data was written by other
         // XCDs in the previous launch, every access is a ~2 us miss)
-        const int mp = roundUp(sDim(N), kNB), nv = kLm0 + 3 * N;
+        const int mp = roundUp(sDim(N), a.pad), nv = kLm0 + 3 * N;
         const double* Y = a.YO + (long long)b * a.strideY;
         const int col = blockIdx.x * 64 + (tid & 63), part = tid >> 6;
         double acc0 = 0, acc1 = 0;
@@ -675,7 +676,7 @@ __global__ __launch_bounds__(1024) void k_update_reduce(UpdArgs a, int colBlocks
             else a.red[(long long)b * 256 + col - nv] = v;
         }
     } else {
-        const int nep = roundUp(eDim(N), kNB);
+        const int nep = roundUp(eDim(N), a.pad);
         const double* Z = a.ZO + (long long)b * a.strideZ;
         const int pr = tid % 121, part = tid / 121;  // 121 column pairs x 8 row slices (threads 968..1023 idle)
         double acc = 0;
@@ -911,7 +912,7 @@ __global__ __launch_bounds__(256) void k_downdate(UpdArgs a, int nt) {
         }
         return;
     }
-    const int mp = roundUp(sDim(N), kNB);
+    const int mp = roundUp(sDim(N), a.pad);
     const double* Y = a.YO + (long long)b * a.strideY;
     const int ldY = a.ldY;
     constexpr int KC = 32;                 // rows of Y per chunk
