@@ -239,7 +239,7 @@ int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, con
     a.isImu = isImu ? 1 : 0;
     a.doRiccati = doRiccati ? 1 : 0;
     a.prm = f->prm;
-    const dim3 grid(a.NT * a.NT, f->B), block(256);
+    const dim3 grid(a.NT * a.NT + 1, f->B), block(256);  // tiles + the scalar-state / base-block workgroup
     int rc = EQF_OK;
     if (f->densePropagate && doRiccati) {
         // dense backend: F and Bn from the same linearisation blocks, then two MFMA GEMMs; k_propagate below only
@@ -658,6 +658,11 @@ void freeAll(eqf_filter* f) {
 
 extern "C" {
 
+#ifdef EQF_PROP_STAMPS
+extern "C" int eqf_debug_prop_stamps(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_propStamps), sizeof(long long) * 32) == hipSuccess ? 0 : -1;
+}
+#endif
 const char* eqf_version(void) { return "eqf_vio_amd 0.1 (gfx950)"; }
 
 void eqf_settings_default(eqf_settings* s) {  // VIOFilterSettings.h:29-50

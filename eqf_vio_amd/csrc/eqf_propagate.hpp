@@ -253,11 +253,21 @@ EQF_DI void stepGlobal(const Glob& G, Glob* out, const ImuRec& r, const PropArgs
 // PRE = false: fused kernel (single small filter: one launch per step, scalar chain on waves 0..2).
 // PRE = true : streaming kernel of the split path; the blocks, the group step and the scalar state were produced by
 //              k_build_blocks, so this instantiation carries no fp64 scalar chain (few registers, high occupancy).
+#ifdef EQF_PROP_STAMPS
+__device__ long long g_propStamps[4][8];
+#define EQF_PSTAMP(i) do { if ((tid & 63) == 0 && (blockIdx.x == a.NT * a.NT || blockIdx.x == a.NT + 1)) g_propStamps[(blockIdx.x == a.NT + 1 ? 2 : 0) + ((tid >> 6) == 2 ? 1 : 0)][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define EQF_PSTAMP(i) do { } while (0)
+#endif
 template <typename T, bool PRE>
 __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     const int tid = threadIdx.x;
+    EQF_PSTAMP(0);
     const int b = blockIdx.y;
-    const int ti = blockIdx.x / a.NT, tj = blockIdx.x % a.NT;
+    // the last workgroup of a filter carries no tile: it steps the scalar state and propagates the 11 x 11 base block
+    const bool isExtra = (int)blockIdx.x == a.NT * a.NT;
+    const int ti = isExtra ? 0 : blockIdx.x / a.NT, tj = isExtra ? 0 : blockIdx.x % a.NT;
+    const int lastT = a.NT - 1;
     const int cap = a.cap, ld = a.ld;
 
     __shared__ T sD[32][9], sLw[32][9], sLv[32][9];  // [0,16): row landmarks I, [16,32): column landmarks J
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
 
     const int wv = tid >> 6, ln = tid & 63;
     if (PRE) {
-        if (riccati && tid < 32) {
+        if (riccati && tid < 32 && !isExtra) {
             const int i = (tid < 16) ? I0 + tid : J0 + tid - 16;
             const T* bp = static_cast<const T*>(a.blk) + ((long long)b * cap + i) * 27;
 #pragma unroll
@@ -306,7 +316,7 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
         // ---- wave 0: common quantities of the linearisation + this tile's per-landmark blocks
         StepCommon c;
         stepCommon(G, r, a, c, kPartBase | kPartRicc, &bad);
-        if (ln < 32) {
+        if (ln < 32 && !isExtra) {
             const int i = (ln < 16) ? I0 + ln : J0 + ln - 16;
             if (i < N) {
                 const quat Qq = quat{Qin[i], Qin[cap + i], Qin[2 * cap + i], Qin[3 * cap + i]};
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
             }
         }
     }
-    if (wv == 1 && ti == tj) {
+    if (wv == 1 && ti == tj && !isExtra) {
         // ---- wave 1 of the diagonal tiles: group step of the tile's landmarks
         if (ln < kTileLm) {
             const int i = I0 + ln;
@@ -355,8 +365,8 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
             }
         }
     }
-    if (wv == 2 && blockIdx.x == 0) {
-        // ---- wave 2 of workgroup 0: scalar state.  Word-parallel copy in -> out, then one lane patches the changed fields
+    if (wv == 2 && isExtra) {
+        // ---- wave 2 of the extra workgroup: scalar state.  Word-parallel copy in -> out, then one lane patches the changed fields
         static_assert(sizeof(Glob) % 8 == 0 && sizeof(Glob) / 8 <= 64, "Glob copy is one word per lane");
         const double* src = reinterpret_cast<const double*>(&G);
         double* dst = reinterpret_cast<double*>(a.gout + b);
@@ -367,6 +377,7 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
             if (step) stepCommon(G, r, a, c, kPartBase, &bad);
             stepGlobal(G, a.gout + b, r, a, c, &bad);
         }
+        EQF_PSTAMP(5);
     }
 
     }
@@ -377,22 +388,22 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     if (!riccati) {
         // Sigma is not touched by this call: copy the tile through so that the ping-pong parity of all
         // filters of the batch stays in step.
-        for (int e = tid; e < kTile * kTile; e += 256) {
+        for (int e = tid; e < kTile * kTile && !isExtra; e += 256) {
             const int rr = e / kTile, cc = e % kTile;
             const int R = kLm0 + 3 * I0 + rr, Cc = kLm0 + 3 * J0 + cc;
             if (R < kLm0 + 3 * N && Cc < kLm0 + 3 * N) Sout[(long long)R * ld + Cc] = Sin[(long long)R * ld + Cc];
         }
-        if (tj == 0)
+        if (tj == lastT && !isExtra)
             for (int e = tid; e < kTile * 12; e += 256) {
                 const int R = kLm0 + 3 * I0 + e / 12, Cc = e % 12;
                 if (R < kLm0 + 3 * N) Sout[(long long)R * ld + Cc] = Sin[(long long)R * ld + Cc];
             }
-        if (ti == 0)
+        if (ti == lastT && !isExtra)
             for (int e = tid; e < 12 * kTile; e += 256) {
                 const int R = e / kTile, Cc = kLm0 + 3 * J0 + e % kTile;
                 if (Cc < kLm0 + 3 * N) Sout[(long long)R * ld + Cc] = Sin[(long long)R * ld + Cc];
             }
-        if (blockIdx.x == 0 && tid < 144) Sout[(long long)(tid / 12) * ld + tid % 12] = Sin[(long long)(tid / 12) * ld + tid % 12];
+        if (isExtra && tid < 144) Sout[(long long)(tid / 12) * ld + tid % 12] = Sin[(long long)(tid / 12) * ld + tid % 12];
         if (bad && a.errflag) atomicOr(a.errflag, 1);
         return;
     }
@@ -417,7 +428,7 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     // this thread's own 3x3 block of Sigma: issue the loads before the barrier
     const int bi = tid >> 4, bj = tid & 15;
     const int BI = I0 + bi, BJ = J0 + bj;
-    const bool blockValid = BI < N && BJ < N;
+    const bool blockValid = !isExtra && BI < N && BJ < N;
     T S[9];
     if (blockValid) {
         const T* src = Sin + (long long)(kLm0 + 3 * BI) * ld + kLm0 + 3 * BJ;
@@ -426,7 +437,9 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc) S[3 * rr + cc] = src[(long long)rr * ld + cc];
     }
+    EQF_PSTAMP(1);
     __syncthreads();
+    EQF_PSTAMP(2);
     if (tid < 132) {
         const int rr = tid / 12, cc = tid % 12;
         // F_bb = I + T * [[0,0,0,0],[-B_g^w,0,0,0],[-B_v^w,-R_A, A_vg, 0]]   (VIOFilter.cpp:178-183)
@@ -449,7 +462,8 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     const T sw2 = (T)a.prm.velOmegaVariance, sa2 = (T)a.prm.velAccelVariance;
     const T Tt = (T)sC.T;
 
-    // ---- G_I = Lw_I Sigma[0:3, 0:11] + Lv_I Sigma[8:11, 0:11] + D_I Sigma_Ib
+    if (!isExtra) {
+    // ---- G_I = Lw_I Sigma[0:3, 0:11] + Lv_I Sigma[8:11, 0:11] + D_I Sigma_Ib ; Gn_I = G_I[:,0:3] + (sigma_w^2 / T) Lw_I
     for (int e = tid; e < 16 * 33; e += 256) {
         const int i = e / 33, rc = e % 33, rr = rc / 11, cc = rc % 11;
         T acc = 0;
@@ -457,18 +471,12 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
         for (int k = 0; k < 3; ++k)
             acc += sLw[i][3 * rr + k] * sSbb[k][cc] + sLv[i][3 * rr + k] * sSbb[8 + k][cc] + sD[i][3 * rr + k] * sSIb[3 * i + k][cc];
         sG[i][rc] = acc;
+        if (cc < 3) sGn[i][3 * rr + cc] = acc + (sw2 / Tt) * sLw[i][3 * rr + cc];
     }
-    __syncthreads();
-    if (tid < 144) {
-        const int i = tid / 9, k = tid % 9;
-        sGn[i][k] = sG[i][(k / 3) * 11 + k % 3] + (sw2 / Tt) * sLw[i][k];
-    }
-    __syncthreads();
-
-    // ---- one 3x3 block per thread
+    // ---- one 3x3 block per thread; the first product needs nothing from G_I and runs before the barrier
+    T H[9];
+    const int i = bi, j = bj;
     if (blockValid) {
-        const int i = bi, j = bj;
-        T H[9];
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
@@ -480,6 +488,9 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
                            sLv[i][3 * rr + k] * sSbJ[8 + k][3 * j + cc];
                 H[3 * rr + cc] = acc;
             }
+    }
+    __syncthreads();
+    if (blockValid) {
         T* dst = Sout + (long long)(kLm0 + 3 * BI) * ld + kLm0 + 3 * BJ;
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr)
@@ -494,8 +505,9 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
             }
     }
 
-    // ---- Sigma'_Ib = G_I F_bb^T + T (B R B^T)_Ib      (tiles in the first tile column)
-    if (tj == 0) {
+    EQF_PSTAMP(3);
+    // ---- Sigma'_Ib = G_I F_bb^T + T (B R B^T)_Ib      (the tiles of the LAST tile column own it: they are the lightest)
+    if (tj == lastT) {
         for (int e = tid; e < 16 * 33; e += 256) {
             const int i = e / 33, rc = e % 33, rr = rc / 11, cc = rc % 11;
             const int I = I0 + i;
@@ -513,8 +525,8 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
             if (R < kLm0 + 3 * N) Sout[(long long)R * ld + 11] = (T)0;
         }
     }
-    // ---- Sigma'_bJ = F_bb (Sigma_bb L_J^T + Sigma_bJ D_J^T) + T (B R B^T)_bJ   (tiles in the first tile row)
-    if (ti == 0) {
+    // ---- Sigma'_bJ = F_bb (Sigma_bb L_J^T + Sigma_bJ D_J^T) + T (B R B^T)_bJ   (tiles of the last tile row)
+    if (ti == lastT) {
         for (int e = tid; e < 16 * 33; e += 256) {
             const int j = e / 33, rc = e % 33, cc = rc / 3, rr = rc % 3;  // G~_J[cc][rr], cc base row, rr landmark comp
             T acc = 0;
@@ -541,8 +553,9 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
             if (Cc < kLm0 + 3 * N) Sout[(long long)11 * ld + Cc] = (T)0;
         }
     }
-    // ---- Sigma'_bb = F_bb Sigma_bb F_bb^T + T (P_bb + B_b R B_b^T)     (first workgroup)
-    if (blockIdx.x == 0) {
+    }  // !isExtra
+    // ---- Sigma'_bb = F_bb Sigma_bb F_bb^T + T (P_bb + B_b R B_b^T)     (the extra workgroup)
+    if (isExtra) {
         __syncthreads();
         if (tid < 121) {
             const int rr = tid / 11, cc = tid % 11;
@@ -575,6 +588,7 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
             Sout[(long long)rr * ld + cc] = acc;  // row/col 11 stay zero
         }
     }
+    EQF_PSTAMP(4);
     if (bad && a.errflag) atomicOr(a.errflag, 1);
 }
 
