@@ -361,7 +361,8 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     if (!attrSet) {
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<float>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         attrSet = true;
     }
     int rc = profiled(f, EQF_PROF_UPDATE_PREP, [&] {
@@ -376,16 +377,33 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     cE.g = a.g; cE.A = f->EA; cE.D = f->EL; cE.W = f->ZW; cE.WO = f->ZO;
     cE.ldA = f->ldE; cE.ldW = f->ldZ; cE.strideA = f->strideE; cE.strideD = f->strideDE; cE.strideW = f->strideZ;
     cE.kind = 1;
+    // downdate tiling: 64x64 tiles when they fill the chip, 32x32 tiles (4x the workgroups) for a single small filter
+    const int nt64 = (nv + 63) / 64, nt32 = (nv + 31) / 32;
+    const bool small = (long long)nt64 * (nt64 + 1) / 2 * B < 512;
+    const int ddNt = small ? nt32 : nt64, ddTiles = ddNt * (ddNt + 1) / 2;
+    bool tailLaunch = true;  // reduce / downdate / finish as launches of their own after the chains
     if (use64) {
         cS.nbMax = nb64S; cS.wtMax = wt64;
         cE.nbMax = nb64E; cE.wtMax = 1;
         const int steps = std::max(nb64S, nb64E);
+        // The reductions ride along in the rhs workgroups; the downdate and the innovation lift ride along too when
+        // every filter's S-chain is shorter than its E-chain (always, except for a handful of landmarks).
+        bool embed = nb64S < nb64E;
+        for (int b = 0; b < B && embed; ++b) {
+            const int Nb = int(f->ids[b].size());
+            if (Nb > 0 && roundUp(sDim(Nb), kSB) >= roundUp(eDim(Nb), kSB)) embed = false;
+        }
+        static const char* embedEnv = std::getenv("EQF_CHOL_EMBED");
+        if (embedEnv && embedEnv[0] == '0') embed = false;
         for (int k = 0; k < steps; ++k) {
+            const int dd = (embed && k == nb64S) ? ddTiles : 0;
             rc = profiled(f, EQF_PROF_CHOL_STEP, [&] {
-                hipLaunchKernelGGL(k_chol_step64, dim3(nblk64, B), dim3(256), sizeof(Step64Lds), f->stream, cS, cE, k, f->errflag);
+                hipLaunchKernelGGL(k_chol_step64<T>, dim3(nblk64 + dd, B), dim3(256), sizeof(Step64Lds), f->stream, cS, cE, a, k, dd ? ddNt : 0,
+                    small ? 1 : 0, embed ? 1 : 0, f->errflag);
             });
             if (rc) return rc;
         }
+        tailLaunch = !embed;
     } else {
         cS.nbMax = mp / kNB; cS.wtMax = roundUp(yCols(Nmax), kNB) / kNB;
         cE.nbMax = nep / kNB; cE.wtMax = 1;
@@ -402,21 +420,20 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             if (rc) return rc;
         }
     }
-    const int colBlocks = (nv + 6 + 63) / 64;
-    rc = profiled(f, EQF_PROF_REDUCE,
-        [&] { hipLaunchKernelGGL(k_update_reduce, dim3(colBlocks + 1, B), dim3(1024), 0, f->stream, a, colBlocks); });
-    if (rc) return rc;
-    // 64x64 tiles when they fill the chip, 32x32 tiles (4x the workgroups) for a single small filter; the last workgroup
-    // of the launch runs the (independent) innovation-lift / group-update part
-    const int nt64 = (nv + 63) / 64, nt32 = (nv + 31) / 32;
-    const bool small = (long long)nt64 * (nt64 + 1) / 2 * B < 512;
-    rc = profiled(f, EQF_PROF_DOWNDATE, [&] {
-        if (small)
-            hipLaunchKernelGGL((k_downdate<T, 32>), dim3(nt32 * (nt32 + 1) / 2 + 1, B), dim3(256), 0, f->stream, a, nt32);
-        else
-            hipLaunchKernelGGL((k_downdate<T, 64>), dim3(nt64 * (nt64 + 1) / 2 + 1, B), dim3(256), 0, f->stream, a, nt64);
-    });
-    if (rc) return rc;
+    if (!use64) {
+        const int colBlocks = (nv + 6 + 63) / 64;
+        rc = profiled(f, EQF_PROF_REDUCE,
+            [&] { hipLaunchKernelGGL(k_update_reduce, dim3(colBlocks + 1, B), dim3(1024), 0, f->stream, a, colBlocks); });
+        if (rc) return rc;
+    }
+    if (tailLaunch) {
+        // the last workgroup of the launch runs the (independent) innovation-lift / group-update part
+        rc = profiled(f, EQF_PROF_DOWNDATE, [&] {
+            if (small) hipLaunchKernelGGL((k_downdate<T, 32>), dim3(ddTiles + 1, B), dim3(256), 0, f->stream, a, nt32);
+            else hipLaunchKernelGGL((k_downdate<T, 64>), dim3(ddTiles + 1, B), dim3(256), 0, f->stream, a, nt64);
+        });
+        if (rc) return rc;
+    }
     HIPC(hipGetLastError());
     f->pS ^= 1;
     return EQF_OK;
@@ -1181,15 +1198,23 @@ int eqf_profile_enable(eqf_filter* f, int on) {
         std::fill(std::begin(f->profCount), std::end(f->profCount), 0);
         std::fill(std::begin(f->profMs), std::end(f->profMs), 0.0);
         f->profOverheadMs = 0.0;
+        // (median of 64 empty brackets: a single hiccup must not be charged to every kernel)
         for (int i = 0; i < 64; ++i) {
             int rc = profiled(f, EQF_PROF_CHURN, [] {});
             if (rc) return rc;
         }
-        int rc = profDrain(f);
-        if (rc) return rc;
-        f->profOverheadMs = f->profMs[EQF_PROF_CHURN] / 64.0;
-        f->profCount[EQF_PROF_CHURN] = 0;
-        f->profMs[EQF_PROF_CHURN] = 0.0;
+        HIPC(hipStreamSynchronize(f->stream));
+        std::vector<float> el;
+        for (auto& p : f->profPairs) {
+            float ms = 0;
+            HIPC(hipEventElapsedTime(&ms, p.a, p.b));
+            el.push_back(ms);
+            f->evPool.push_back(p.a);
+            f->evPool.push_back(p.b);
+        }
+        f->profPairs.clear();
+        std::sort(el.begin(), el.end());
+        f->profOverheadMs = el.empty() ? 0.0 : el[el.size() / 2];
     }
     return EQF_OK;
 }

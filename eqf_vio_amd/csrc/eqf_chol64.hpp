@@ -42,6 +42,8 @@ struct Step64Lds {
     double L[kSB][kSP];   // L_KK ; the diagonal workgroup factors the next block in here
     double Wd[4][kQB][kWP];
     double D0[kQB][kWP];  // copy of the leading 16x16 block of the matrix being factored (read by the identity-row wave)
+    double Zs[kSB][kWP];  // rhs workgroups of the S-chain: the innovation column z_K = L_KK^-1 delta_K (column 0)
+    double redL[256];     // last E-chain rhs workgroup: the reduced products handed to the innovation lift
 };
 
 EQF_DI void chainDims64(const ChainArgs& ch, int N, int* nb, int* wt) {
@@ -125,8 +127,17 @@ EQF_DI void potrf16(double (*T)[kSP], const double* src, int srcLd, double (*Wj)
         if (!(d > 0.0)) *bad = 1;
         const double rd = rsqrtPivot(d);
         if (c >= 1) {
+            // all broadcasts of the column first (distinct SGPR pairs, pinned), then the FMAs: one v_readlane -> VALU
+            // hazard per column instead of one per element (4.1 k -> 3.75 k cycles)
+            double bc[kQB];
 #pragma unroll
-            for (int c2 = c + 1; c2 < kQB; ++c2) row[c2] = fma(-ljPrev, readlane64(ljPrev, c2), row[c2]);
+            for (int c2 = c + 1; c2 < kQB; ++c2) bc[c2] = readlane64(ljPrev, c2);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int c2 = c + 1; c2 < kQB; ++c2) __asm__ volatile("" : "+s"(bc[c2]));
+#endif
+#pragma unroll
+            for (int c2 = c + 1; c2 < kQB; ++c2) row[c2] = fma(-ljPrev, bc[c2], row[c2]);
         }
         const double lj = row[c] * rd;
         if (c + 1 < kQB) row[c + 1] = fma(-lj, readlane64(lj, c + 1), row[c + 1]);
@@ -197,13 +208,13 @@ EQF_DI void factor64(Step64Lds& s, int tid, int* bad, Pre pre, long long* st = n
 //   TR = true : the strip is rows x0..x0+15,    M <- M L^-T   (held transposed:  X_j^T = W_jj (A_j^T - sum L_ji X_i^T))
 //   TR = false: the strip is columns x0..x0+15, M <- L^-1 M   (                  Y_j   = W_jj (R_j   - sum L_ji Y_i))
 template <bool TR>
-EQF_DI void solveStrip(double (*M)[kSP], const Step64Lds& s, int x0, int lane) {
+EQF_DI void solveStrip(double* M, int ld, const Step64Lds& s, int x0, int lane) {
     f64x4 Z[4], X[4];
     const int lc = lane & 15, lg = lane >> 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Z[j][q] = TR ? M[x0 + lc][kQB * j + lg + 4 * q] : M[kQB * j + lg + 4 * q][x0 + lc];
+        for (int q = 0; q < 4; ++q) Z[j][q] = TR ? M[(x0 + lc) * ld + kQB * j + lg + 4 * q] : M[(kQB * j + lg + 4 * q) * ld + x0 + lc];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
@@ -215,16 +226,36 @@ EQF_DI void solveStrip(double (*M)[kSP], const Step64Lds& s, int x0, int lane) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (TR) M[x0 + lc][kQB * j + lg + 4 * q] = X[j][q];
-            else M[kQB * j + lg + 4 * q][x0 + lc] = X[j][q];
+            if (TR) M[(x0 + lc) * ld + kQB * j + lg + 4 * q] = X[j][q];
+            else M[(kQB * j + lg + 4 * q) * ld + x0 + lc] = X[j][q];
         }
 }
 
-// grid.x = sum over the two chains of nbMax^2 (A tiles) + wtMax * nbMax (rhs tiles), nbMax / wtMax in 64-blocks;
+// grid.x = sum over the two chains of nbMax^2 (A tiles) + wtMax * nbMax (rhs tiles), nbMax / wtMax in 64-blocks,
+//          + the tiles of the covariance downdate in the ONE launch that carries it (ddNt > 0);
 // grid.y = B; block = 256; dynamic LDS = sizeof(Step64Lds).
-__global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1, int K, int* errflag) {
+//
+// What used to be three more launches rides along (they only exist as separate kernels for the 32-wide path):
+//   * gamma = Y^T z, hV = (L^-1 V)^T z and G11 = [Zt|Et]^T [Zt|Et] (k_update_reduce) are accumulated block row by block
+//     row by the rhs workgroups that produce Y_K / Z_K (the S-chain ones solve the 64 entries of z_K along);
+//   * Sigma <- Sigma - Y^T Y (k_downdate) runs as extra workgroups of the first launch after the S-chain has finished,
+//     next to the remaining E-chain steps (the S-chain is always the shorter one);
+//   * the innovation lift / X <- Delta X (k_update_finish) is done by the E-chain's rhs workgroup in its last step.
+// embedFinish = 0 (some filter of the batch has chains of equal length): the host launches k_downdate afterwards.
+template <typename T>
+__global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1, UpdArgs a, int K, int ddNt, int ddSmall,
+    int embedFinish, int* errflag) {
     const int b = blockIdx.y;
     const int n0 = c0.nbMax * c0.nbMax + c0.wtMax * c0.nbMax;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
+    {
+        const int nChain = n0 + c1.nbMax * c1.nbMax + c1.wtMax * c1.nbMax;
+        if ((int)blockIdx.x >= nChain) {  // covariance downdate tile
+            if (ddSmall) downdateTile<T, 32>(a, ddNt, b, (int)blockIdx.x - nChain, reinterpret_cast<T*>(smem64));
+            else downdateTile<T, 64>(a, ddNt, b, (int)blockIdx.x - nChain, reinterpret_cast<T*>(smem64));
+            return;
+        }
+    }
     const bool second = (int)blockIdx.x >= n0;
     const ChainArgs& ch = second ? c1 : c0;
     int idx = second ? (int)blockIdx.x - n0 : (int)blockIdx.x;
@@ -253,7 +284,6 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
     const int ldA = ch.ldA, ldW = ch.ldW;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
     Step64Lds& s = *reinterpret_cast<Step64Lds*>(smem64);
     int bad = 0;
     const bool diagNext = !isW && R == C && C == K + 1;
@@ -289,6 +319,20 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             acc[i][q] = (solveOnly || i >= nt) ? 0.0 : Ct[(long long)(kQB * tr[i] + (lane >> 4) + 4 * q) * ldc + kQB * tc[i] + (lane & 15)];
+    // running sums of the reductions (rhs workgroups): previous value of this thread's entry, fetched with everything else
+    double prevSum = 0.0;
+    double* sumPtr = nullptr;
+    if (solveOnly) {
+        const int nvv = kLm0 + 3 * g.N;
+        if (ch.kind == 0) {
+            const int col = R * kSB + tid;
+            if (tid < kSB && col < nvv) sumPtr = a.dbgGamma + (long long)b * (kLm0 + 3 * a.cap) + col;
+            else if (tid < kSB && col < nvv + 6) sumPtr = a.red + (long long)b * 256 + col - nvv;
+        } else if (tid < 121) {
+            sumPtr = a.red + (long long)b * 256 + 8 + tid;
+        }
+        if (sumPtr && K) prevSum = *sumPtr;
+    }
     const double* Dk = D + (long long)K * kDRec;
     const double* Pg = isW ? (W + (long long)(K * kSB) * ldW + R * kSB) : (A + (long long)(R * kSB) * ldA + K * kSB);
     const double* Qg = A + (long long)(C * kSB) * ldA + K * kSB;
@@ -316,21 +360,54 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
         const int e = tid + 256 * u;
         s.Wd[e >> 8][(e >> 4) & 15][e & 15] = rW[u];
     }
+    if (solveOnly && ch.kind == 0) {  // the innovation column: rows of this block row, column 11 of the right-hand sides
+        for (int e = tid; e < kSB * kQB; e += 256)
+            s.Zs[e >> 4][e & 15] = ((e & 15) == 0) ? W[(long long)(K * kSB + (e >> 4)) * ldW + 11] : 0.0;
+    }
     __syncthreads();
     // first block column: no look-ahead yet, every workgroup factors A_00 itself
     if (K == 0) factor64(s, tid, &bad, [](int) {});
     EQF_STAMP(1);
     // ---- panel blocks: each wave solves its 16-row strip of P and of Q (16-column strip of the rhs block)
     if (needP) {
-        if (isW) solveStrip<false>(s.P, s, kQB * wv, lane);
-        else solveStrip<true>(s.P, s, kQB * wv, lane);
+        if (isW) solveStrip<false>(&s.P[0][0], kSP, s, kQB * wv, lane);
+        else solveStrip<true>(&s.P[0][0], kSP, s, kQB * wv, lane);
     }
-    if (needQ) solveStrip<true>(s.Q, s, kQB * wv, lane);
+    if (needQ) solveStrip<true>(&s.Q[0][0], kSP, s, kQB * wv, lane);
+    if (solveOnly && ch.kind == 0 && wv == 0) solveStrip<false>(&s.Zs[0][0], kWP, s, 0, lane);
     __syncthreads();
     EQF_STAMP(2);
 
     if (solveOnly) {
         for (int e = tid; e < kSB * kSB; e += 256) WO[(long long)(K * kSB + (e >> 6)) * ldW + R * kSB + (e & 63)] = s.P[e >> 6][e & 63];
+        const double* red = a.red + (long long)b * 256;
+        if (ch.kind == 0) {
+            // gamma[col] += Y_K[:, col] . z_K ; the six columns after nv are hV ; column 11 is z itself (gamma[11] = 0)
+            if (sumPtr) {
+                double v = 0.0;
+#pragma unroll 8
+                for (int r = 0; r < kSB; ++r) v = fma(s.P[r][tid], s.Zs[r][0], v);
+                *sumPtr = (R * kSB + tid == 11) ? 0.0 : prevSum + v;
+            }
+        } else {
+            // G11 += [Zt|Et]_K^T [Zt|Et]_K ; in the chain's last step the totals go straight to the innovation lift
+            const bool last = embedFinish && K == nb - 1;
+            if (sumPtr) {
+                const int q0 = tid / 11, q1 = tid % 11;
+                double v = 0.0;
+#pragma unroll 8
+                for (int r = 0; r < kSB; ++r) v = fma(s.P[r][q0], s.P[r][q1], v);
+                const double tot = prevSum + v;
+                *sumPtr = tot;
+                if (last) s.redL[8 + tid] = tot;
+            } else if (last && tid >= 128 && tid < 134) {
+                s.redL[tid - 128] = red[tid - 128];
+            }
+            if (last) {
+                __syncthreads();
+                updateFinishBody(a, b, s.redL);
+            }
+        }
     } else {
         // ---- trailing update of this tile: A_RC -= L_RK L_CK^T  /  R_C -= L_CK Y_K
         const double (*Am)[kSP] = isW ? s.Q : (needP ? s.P : s.Q);

@@ -701,40 +701,49 @@ __global__ __launch_bounds__(1024) void k_update_reduce(UpdArgs a, int colBlocks
 // Delta = liftTotalSpaceInnovationDiscrete(Gamma), X <- Delta * X, bias += gamma[0:6].
 // ------------------------------------------------------------------------------------------------
 EQF_DI void solve4(double M[4][4], double* rhs, double* x) {
-    // Gaussian elimination with partial pivoting (the reference uses Householder QR on the same 4x4 system)
-    int piv[4] = {0, 1, 2, 3};
+    // Gaussian elimination with partial pivoting (the reference uses Householder QR on the same 4x4 system).  Fully
+    // unrolled with static indices -- row exchanges are conditional swaps -- so that everything stays in registers (a
+    // permutation vector would make M dynamically indexed, i.e. live in scratch memory).
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
-        int p = k;
-        double best = fabs(M[piv[k]][k]);
-        for (int i = k + 1; i < 4; ++i)
-            if (fabs(M[piv[i]][k]) > best) {
-                best = fabs(M[piv[i]][k]);
-                p = i;
-            }
-        const int t = piv[k];
-        piv[k] = piv[p];
-        piv[p] = t;
-        const double inv = 1.0 / M[piv[k]][k];
+#pragma unroll
         for (int i = k + 1; i < 4; ++i) {
-            const double l = M[piv[i]][k] * inv;
-            for (int j = k; j < 4; ++j) M[piv[i]][j] -= l * M[piv[k]][j];
-            rhs[piv[i]] -= l * rhs[piv[k]];
+            const bool sw = fabs(M[i][k]) > fabs(M[k][k]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double u = M[k][j], v = M[i][j];
+                M[k][j] = sw ? v : u;
+                M[i][j] = sw ? u : v;
+            }
+            const double u = rhs[k], v = rhs[i];
+            rhs[k] = sw ? v : u;
+            rhs[i] = sw ? u : v;
+        }
+        const double inv = 1.0 / M[k][k];
+#pragma unroll
+        for (int i = k + 1; i < 4; ++i) {
+            const double l = M[i][k] * inv;
+#pragma unroll
+            for (int j = k; j < 4; ++j) M[i][j] -= l * M[k][j];
+            rhs[i] -= l * rhs[k];
         }
     }
+#pragma unroll
     for (int i = 3; i >= 0; --i) {
-        double s = rhs[piv[i]];
-        for (int j = i + 1; j < 4; ++j) s -= M[piv[i]][j] * x[j];
-        x[i] = s / M[piv[i]][i];
+        double sacc = rhs[i];
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j) sacc -= M[i][j] * x[j];
+        x[i] = sacc / M[i][i];
     }
 }
 
-EQF_DI void updateFinishBody(const UpdArgs& a, int b) {
+// red: hV (6) at 0, G11 = [Zt|Et]^T [Zt|Et] (11 x 11) at 8 (global a.red of filter b, or an LDS copy of it)
+EQF_DI void updateFinishBody(const UpdArgs& a, int b, const double* red) {
     Glob& g = a.g[b];
     if (!g.updateOk || g.N == 0) return;
     const int N = g.N, cap = a.cap;
     const int tid = threadIdx.x;
-    double* gam = a.dbgGamma + (long long)b * (kLm0 + 3 * cap);  // written by k_update_reduce
-    const double* red = a.red + (long long)b * 256;
+    double* gam = a.dbgGamma + (long long)b * (kLm0 + 3 * cap);  // gamma = Y^T z
     double* gT = a.dbgGammaTot ? a.dbgGammaTot + (long long)b * (9 + 3 * cap) : nullptr;
     int bad = 0;
     // The weighted least squares + the scalar part of X <- Delta X is serial work for one lane; the per-landmark part
@@ -848,7 +857,7 @@ EQF_DI void updateFinishBody(const UpdArgs& a, int b) {
     if (bad && a.errflag) atomicOr(a.errflag, 8);
 }
 
-__global__ __launch_bounds__(256) void k_update_finish(UpdArgs a) { updateFinishBody(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_update_finish(UpdArgs a) { updateFinishBody(a, blockIdx.x, a.red + (long long)blockIdx.x * 256); }
 
 // ------------------------------------------------------------------------------------------------
 // k_downdate: Sigma_out = Sigma_in - Y^T Y on the matrix cores.  64x64 output tile per workgroup, each of
@@ -876,21 +885,15 @@ struct MfmaT<float> {
 // staged through LDS with the next chunk's global loads issued before the MFMAs of the current one.
 // TS = output tile edge: 64 (each wave a 32x32 quadrant as 2x2 MFMA tiles; best operand reuse, used when there are
 // enough tiles to fill the chip) or 32 (each wave one 16x16 MFMA tile; 4x more workgroups for a single small filter).
+// One symmetric tile pair of the downdate; lds: 2 * 32 * (TS + 1) elements of T.  All 256 threads.
 template <typename T, int TS>
-__global__ __launch_bounds__(256) void k_downdate(UpdArgs a, int nt) {
+EQF_DI void downdateTile(const UpdArgs& a, int nt, int b, int tileIdx, T* lds) {
     constexpr int WM = TS / 32;  // MFMA tiles per wave and dimension
-    const int b = blockIdx.y;
-    if (blockIdx.x == gridDim.x - 1) {
-        // the innovation lift / X <- Delta X / bias update is independent of the downdate: one extra workgroup of this
-        // launch does it (saves a kernel boundary; both only need gamma from k_update_reduce)
-        updateFinishBody(a, b);
-        return;
-    }
     const Glob& g = a.g[b];
     const int N = g.N;
     const int nv = kLm0 + 3 * N;
     // tile pair (ti <= tj) from the linear index over the upper triangle
-    int ti = 0, rem = blockIdx.x;
+    int ti = 0, rem = tileIdx;
     while (rem >= nt - ti) {
         rem -= nt - ti;
         ++ti;
@@ -916,8 +919,8 @@ __global__ __launch_bounds__(256) void k_downdate(UpdArgs a, int nt) {
     const double* Y = a.YO + (long long)b * a.strideY;
     const int ldY = a.ldY;
     constexpr int KC = 32;                 // rows of Y per chunk
-    __shared__ T sI[KC][TS + 1];           // Y[k0 + r][I0 + c]
-    __shared__ T sJ[KC][TS + 1];           // Y[k0 + r][J0 + c]
+    T (*sI)[TS + 1] = reinterpret_cast<T (*)[TS + 1]>(lds);                    // Y[k0 + r][I0 + c]
+    T (*sJ)[TS + 1] = reinterpret_cast<T (*)[TS + 1]>(lds + KC * (TS + 1));    // Y[k0 + r][J0 + c]
     const int qi = wv >> 1, qj = wv & 1;
     const int lr = lane & 15, lk = lane >> 4;
     typedef MfmaT<T> MF;
@@ -979,6 +982,19 @@ __global__ __launch_bounds__(256) void k_downdate(UpdArgs a, int nt) {
                     if (ti != tj) Sout[(long long)Cc * ld + R] = Sin[(long long)Cc * ld + R] - acc[u][v][q];
                 }
             }
+}
+
+template <typename T, int TS>
+__global__ __launch_bounds__(256) void k_downdate(UpdArgs a, int nt) {
+    const int b = blockIdx.y;
+    if (blockIdx.x == gridDim.x - 1) {
+        // the innovation lift / X <- Delta X / bias update is independent of the downdate: one extra workgroup of this
+        // launch does it (saves a kernel boundary; both only need gamma and the reduced products)
+        updateFinishBody(a, b, a.red + (long long)b * 256);
+        return;
+    }
+    __shared__ T sBuf[2 * 32 * (TS + 1)];
+    downdateTile<T, TS>(a, nt, b, (int)blockIdx.x, sBuf);
 }
 
 }  // namespace eqf

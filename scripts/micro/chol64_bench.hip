@@ -53,7 +53,10 @@ int main(int argc, char** argv) {
     ChainArgs c0{}, c1{};
     c0.g = dg; c0.A = dA; c0.D = dD; c0.W = dW; c0.WO = dWO; c0.ldA = n; c0.ldW = ldW; c0.kind = 1; c0.nbMax = nb; c0.wtMax = 1;
     c1 = c0; c1.nbMax = 0; c1.wtMax = 0;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds)));
+    UpdArgs ua{};
+    double* dred; hipMalloc(&dred, 256 * sizeof(double));
+    ua.red = dred; ua.g = dg; ua.cap = N;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds)));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
@@ -61,7 +64,7 @@ int main(int argc, char** argv) {
         hipMemcpy(dW, W.data(), sizeof(double) * n * ldW, hipMemcpyHostToDevice);
         hipDeviceSynchronize();
         hipEventRecord(e0, 0);
-        for (int K = 0; K < nb; ++K) hipLaunchKernelGGL(k_chol_step64, dim3(nb * nb + nb), dim3(256), sizeof(Step64Lds), 0, c0, c1, K, derr);
+        for (int K = 0; K < nb; ++K) hipLaunchKernelGGL(k_chol_step64<double>, dim3(nb * nb + nb), dim3(256), sizeof(Step64Lds), 0, c0, c1, ua, K, 0, 0, 0, derr);
         hipEventRecord(e1, 0);
         hipDeviceSynchronize();
         float ms;

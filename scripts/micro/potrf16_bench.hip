@@ -44,6 +44,122 @@ __device__ __forceinline__ void variant(double (*T)[kSP], double (*colS)[kQB + 2
     }
 }
 
+// MODE 4: LDL^T-style chain (reciprocal of the pivot on the chain, the square root off it)
+__device__ __forceinline__ void variantLdl(double (*T)[kSP], int base, int lane, int* bad) {
+    double u[kQB], out[kQB];
+#pragma unroll
+    for (int c = 0; c < kQB; ++c) u[c] = T[lane][base + c];
+    double tPrev = 0.0, uPrev = 0.0;
+#pragma unroll
+    for (int c = 0; c < kQB; ++c) {
+        const double d = readlane64(u[c], base + c);
+        if (!(d > 0.0)) *bad = 1;
+        double r = __builtin_amdgcn_rcp(d);
+        r = fma(r, fma(-d, r, 1.0), r);
+        r = fma(r, fma(-d, r, 1.0), r);
+        if (c >= 1) {
+#pragma unroll
+            for (int c2 = c + 1; c2 < kQB; ++c2) u[c2] = fma(-tPrev, readlane64(uPrev, base + c2), u[c2]);
+        }
+        const double uc = u[c];
+        const double t = uc * r;
+        if (c + 1 < kQB) u[c + 1] = fma(-t, readlane64(uc, base + c + 1), u[c + 1]);
+        out[c] = uc * rsqrtPivot(d);
+        tPrev = t;
+        uPrev = uc;
+#pragma unroll
+        for (int c2 = c + 1; c2 < kQB; ++c2) __asm__ volatile("" : "+v"(u[c2]));
+    }
+    if (lane >= base) {
+#pragma unroll
+        for (int c = 0; c < kQB; ++c) T[lane][base + c] = (lane - base >= c) ? out[c] : 0.0;
+    }
+}
+// MODE 5: the bulk FMAs of column c-1 hand-interleaved between the dependent operations of pivot c's chain
+#define SB() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ void variantIl(double (*T)[kSP], int base, int lane, int* bad) {
+    double row[kQB];
+#pragma unroll
+    for (int c = 0; c < kQB; ++c) row[c] = T[lane][base + c];
+    double ljPrev = 0.0;
+#pragma unroll
+    for (int c = 0; c < kQB; ++c) {
+        // bulk items of this iteration: c2 = c+1 .. 15 (column c-1), spread over 7 slots
+        auto bulk = [&](int slot) {
+            if (c >= 1) {
+#pragma unroll
+                for (int c2 = c + 1; c2 < kQB; ++c2)
+                    if ((c2 - c - 1) % 7 == slot) row[c2] = fma(-ljPrev, readlane64(ljPrev, base + c2), row[c2]);
+            }
+        };
+        const double d = readlane64(row[c], base + c);
+        if (!(d > 0.0)) *bad = 1;
+        double y = __builtin_amdgcn_rsq(d);
+        const double h = 0.5 * d;
+        SB(); bulk(0); SB();
+        double t = h * y;
+        SB(); bulk(1); SB();
+        t = fma(-y, t, 1.5);
+        SB(); bulk(2); SB();
+        y = y * t;
+        SB(); bulk(3); SB();
+        t = h * y;
+        SB(); bulk(4); SB();
+        t = fma(-y, t, 1.5);
+        SB(); bulk(5); SB();
+        y = y * t;
+        SB(); bulk(6); SB();
+        const double lj = row[c] * y;
+        if (c + 1 < kQB) row[c + 1] = fma(-lj, readlane64(lj, base + c + 1), row[c + 1]);
+        row[c] = lj;
+        ljPrev = lj;
+        SB();
+    }
+    if (lane >= base) {
+#pragma unroll
+        for (int c = 0; c < kQB; ++c) T[lane][base + c] = (lane - base >= c) ? row[c] : 0.0;
+    }
+}
+// MODE 6: all broadcasts of a column first (distinct SGPR pairs), then the FMAs
+__device__ __forceinline__ void variantGrp(double (*T)[kSP], int base, int lane, int* bad) {
+    double row[kQB];
+#pragma unroll
+    for (int c = 0; c < kQB; ++c) row[c] = T[lane][base + c];
+    double ljPrev = 0.0;
+#pragma unroll
+    for (int c = 0; c < kQB; ++c) {
+        const double d = readlane64(row[c], base + c);
+        if (!(d > 0.0)) *bad = 1;
+        const double rd = rsqrtPivot(d);
+        if (c >= 1) {
+            double bc[kQB];
+#pragma unroll
+            for (int c2 = c + 1; c2 < kQB; ++c2) bc[c2] = readlane64(ljPrev, base + c2);
+#pragma unroll
+            for (int c2 = c + 1; c2 < kQB; ++c2) __asm__ volatile("" : "+s"(bc[c2]));
+#pragma unroll
+            for (int c2 = c + 1; c2 < kQB; ++c2) row[c2] = fma(-ljPrev, bc[c2], row[c2]);
+        }
+        const double lj = row[c] * rd;
+        if (c + 1 < kQB) row[c + 1] = fma(-lj, readlane64(lj, base + c + 1), row[c + 1]);
+        row[c] = lj;
+        ljPrev = lj;
+#pragma unroll
+        for (int c2 = c + 1; c2 < kQB; ++c2) __asm__ volatile("" : "+v"(row[c2]));
+    }
+    if (lane >= base) {
+#pragma unroll
+        for (int c = 0; c < kQB; ++c) T[lane][base + c] = (lane - base >= c) ? row[c] : 0.0;
+    }
+}
+template <int MODE>
+__device__ __forceinline__ void dispatch(double (*T)[kSP], double (*colS)[kQB + 2], int base, int lane, int* bad) {
+    if (MODE == 4) variantLdl(T, base, lane, bad);
+    else if (MODE == 5) variantIl(T, base, lane, bad);
+    else if (MODE == 6) variantGrp(T, base, lane, bad);
+    else variant<MODE>(T, colS, base, lane, bad);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_bench(double* out, int reps) {
     __shared__ double T[kSB][kSP];
@@ -59,11 +175,11 @@ __global__ __launch_bounds__(256) void k_bench(double* out, int reps) {
     if (wv == 0) {
         for (int c = 0; c < kSB; ++c) T[lane][c] = T0[lane][c];
         long long t0 = __builtin_readcyclecounter();
-        variant<MODE>(T, colS, 16, lane, &bad);
+        dispatch<MODE>(T, colS, 16, lane, &bad);
         long long t1 = __builtin_readcyclecounter();
         for (int i = 0; i < reps; ++i) {
             for (int c = 0; c < kQB; ++c) T[lane][16 + c] = T0[lane][16 + c];
-            variant<MODE>(T, colS, 16, lane, &bad);
+            dispatch<MODE>(T, colS, 16, lane, &bad);
         }
         long long t2 = __builtin_readcyclecounter();
         if (lane == 0) {
@@ -87,6 +203,9 @@ int main() {
     run<1>("pivot chain only", o);
     run<2>("readlane bulk, 1 Newton step", o);
     run<3>("LDS-broadcast bulk", o);
+    run<4>("LDL^T chain (rcp on chain)", o);
+    run<5>("hand-interleaved + sched_barrier", o);
+    run<6>("grouped broadcasts", o);
     run<0>("readlane bulk again", o);
     return 0;
 }
