@@ -357,7 +357,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     if (wpb < 1) return EQF_ERR_CAPACITY;
     const int lmBlocks = (mp / 2 + wpb - 1) / wpb, eBlocks = nep / kNB;
     const size_t lds = perWave * wpb;
-    static bool attrSet = false;
+    static bool attrSet = false, attrSet64 = false;
     if (!attrSet) {
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -365,10 +365,6 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         attrSet = true;
     }
-    int rc = profiled(f, EQF_PROF_UPDATE_PREP, [&] {
-        hipLaunchKernelGGL(k_update_prep<T>, dim3(lmBlocks + eBlocks, B), dim3(64 * wpb), lds, f->stream, a, lmBlocks, wpb, nvPad);
-    });
-    if (rc) return rc;
     // chains
     ChainArgs cS{}, cE{};
     cS.g = a.g; cS.A = f->SA; cS.D = f->SL; cS.W = f->YW; cS.WO = f->YO;
@@ -377,6 +373,23 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     cE.g = a.g; cE.A = f->EA; cE.D = f->EL; cE.W = f->ZW; cE.WO = f->ZO;
     cE.ldA = f->ldE; cE.ldW = f->ldZ; cE.strideA = f->strideE; cE.strideD = f->strideDE; cE.strideW = f->strideZ;
     cE.kind = 1;
+    if (!attrSet64) {
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_first64), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        attrSet64 = true;
+    }
+    int rc = profiled(f, EQF_PROF_UPDATE_PREP, [&] {
+        // 64-wide path: two more workgroups per filter factor the first diagonal block of each chain straight from Sigma
+        if (use64 && wpb == 4)
+            hipLaunchKernelGGL(k_update_prep64<T>, dim3(lmBlocks + eBlocks + 2, B), dim3(256), std::max(lds, sizeof(Step64Lds)), f->stream, a, cS,
+                cE, lmBlocks, eBlocks, wpb, nvPad);
+        else {
+            hipLaunchKernelGGL(k_update_prep<T>, dim3(lmBlocks + eBlocks, B), dim3(64 * wpb), lds, f->stream, a, lmBlocks, wpb, nvPad);
+            if (use64) hipLaunchKernelGGL(k_factor_first64, dim3(2, B), dim3(256), sizeof(Step64Lds), f->stream, cS, cE, f->errflag);
+        }
+    });
+    if (rc) return rc;
     // downdate tiling: 64x64 tiles when they fill the chip, 32x32 tiles (4x the workgroups) for a single small filter
     const int nt64 = (nv + 63) / 64, nt32 = (nv + 31) / 32;
     const bool small = (long long)nt64 * (nt64 + 1) / 2 * B < 512;

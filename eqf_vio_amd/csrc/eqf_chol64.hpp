@@ -231,6 +231,100 @@ EQF_DI void solveStrip(double* M, int ld, const Step64Lds& s, int x0, int lane) 
         }
 }
 
+// Store / load of a diagonal-factor record (s.L, s.Wd <-> ChainArgs::D)
+EQF_DI void storeDiagRecord(const Step64Lds& s, double* Dn, int tid) {
+    for (int e = tid; e < kSB * kSB; e += 256) Dn[e] = s.L[e >> 6][e & 63];
+    for (int e = tid; e < 4 * kQB * kQB; e += 256) Dn[kSB * kSB + e] = s.Wd[e >> 8][(e >> 4) & 15][e & 15];
+}
+
+// The first diagonal blocks of the two chains, formed straight from Sigma and factored INSIDE the prep launch (two extra
+// workgroups per filter that finish in the shadow of the landmark waves), so that the first chain launch is an ordinary
+// one:   kind 0:  S_00 = C Sigma C^T + R for the first 32 landmarks   (same expression order as k_update_prep)
+//        kind 1:  Sigma_e[0:64, 0:64]                                 (identity at the pad index 5 and beyond n_e)
+template <typename T>
+EQF_DI void factorFirstFromSigma(const UpdArgs& a, const ChainArgs& ch, int b, Step64Lds& s, int* bad) {
+    const Glob& g = a.g[b];
+    if (!g.updateOk || g.N == 0) return;
+    const int N = g.N, cap = a.cap, ld = a.ld, tid = threadIdx.x;
+    const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
+    if (ch.kind == 0) {
+        const double* lmc = a.lmc + (long long)b * 15 * cap;
+        for (int e = tid; e < 32 * 32; e += 256) {
+            const int i = e >> 5, j = e & 31;
+            double o[4] = {0.0, 0.0, 0.0, 0.0};
+            if (i < N && j < N) {
+                double Ci[6], Cj[6], v[9];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    Ci[q] = lmc[(long long)q * cap + i];
+                    Cj[q] = lmc[(long long)q * cap + j];
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[3 * q + c] = (double)Sin[(long long)(kLm0 + 3 * i + q) * ld + kLm0 + 3 * j + c];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    double cs[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) cs[c] = Ci[3 * r] * v[c] + Ci[3 * r + 1] * v[3 + c] + Ci[3 * r + 2] * v[6 + c];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) o[2 * r + q] = cs[0] * Cj[3 * q] + cs[1] * Cj[3 * q + 1] + cs[2] * Cj[3 * q + 2];
+                }
+                if (i == j) {
+                    o[0] += a.prm.measurementVariance;
+                    o[3] += a.prm.measurementVariance;
+                }
+            } else if (i == j) {
+                o[0] = o[3] = 1.0;
+            }
+            s.L[2 * i][2 * j] = o[0]; s.L[2 * i][2 * j + 1] = o[1];
+            s.L[2 * i + 1][2 * j] = o[2]; s.L[2 * i + 1][2 * j + 1] = o[3];
+        }
+    } else {
+        const int ne = eDim(N);
+        for (int e = tid; e < kSB * kSB; e += 256) {
+            const int rr = e >> 6, cc = e & 63;
+            s.L[rr][cc] = (rr < ne && cc < ne && rr != 5 && cc != 5) ? (double)Sin[(long long)(6 + rr) * ld + 6 + cc] : (rr == cc ? 1.0 : 0.0);
+        }
+    }
+    __syncthreads();
+    if (tid < kQB * kQB) s.D0[tid >> 4][tid & 15] = s.L[tid >> 4][tid & 15];
+    __syncthreads();
+    factor64(s, tid, bad, [](int) {});
+    storeDiagRecord(s, ch.D + (long long)b * ch.strideD, tid);
+}
+// k_update_prep + the two first-block workgroups (grid.x = lmBlocks + eBlocks + 2)
+template <typename T>
+__global__ __launch_bounds__(256) void k_update_prep64(UpdArgs a, ChainArgs cS, ChainArgs cE, int lmBlocks, int eBlocks, int wpb, int nvPad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
+    const int role = (int)blockIdx.x - (lmBlocks + eBlocks);
+    if (role < 0) {
+        updatePrepBody<T>(a, lmBlocks, wpb, nvPad, reinterpret_cast<double*>(smem64));
+        return;
+    }
+    int bad = 0;
+    factorFirstFromSigma<T>(a, role == 0 ? cS : cE, blockIdx.y, *reinterpret_cast<Step64Lds*>(smem64), &bad);
+    if (bad && a.errflag && threadIdx.x == 0) atomicOr(a.errflag, 4);
+}
+// Stand-alone variant (tests / microbenchmarks without a prep launch): factor A_00 of each chain from ChainArgs::A.
+__global__ __launch_bounds__(256) void k_factor_first64(ChainArgs c0, ChainArgs c1, int* errflag) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
+    Step64Lds& s = *reinterpret_cast<Step64Lds*>(smem64);
+    const ChainArgs& ch = blockIdx.x ? c1 : c0;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if (ch.nbMax == 0 || !ch.g[b].updateOk || ch.g[b].N == 0) return;
+    const double* A = ch.A + (long long)b * ch.strideA;
+    for (int e = tid; e < kSB * kSB; e += 256) s.L[e >> 6][e & 63] = A[(long long)(e >> 6) * ch.ldA + (e & 63)];
+    __syncthreads();
+    if (tid < kQB * kQB) s.D0[tid >> 4][tid & 15] = s.L[tid >> 4][tid & 15];
+    __syncthreads();
+    int bad = 0;
+    factor64(s, tid, &bad, [](int) {});
+    storeDiagRecord(s, ch.D + (long long)b * ch.strideD, tid);
+    if (bad && errflag && tid == 0) atomicOr(errflag, 4);
+}
+
 // grid.x = sum over the two chains of nbMax^2 (A tiles) + wtMax * nbMax (rhs tiles), nbMax / wtMax in 64-blocks,
 //          + the tiles of the covariance downdate in the ONE launch that carries it (ddNt > 0);
 // grid.y = B; block = 256; dynamic LDS = sizeof(Step64Lds).
@@ -341,17 +435,16 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
         const int e = tid + 256 * u, rr = e >> 6, cc = e & 63;
-        rL[u] = (K == 0) ? A[(long long)rr * ldA + cc] : Dk[e];
+        rL[u] = Dk[e];
         rP[u] = needP ? Pg[(long long)rr * ldp + cc] : 0.0;
         rQ[u] = needQ ? Qg[(long long)rr * ldA + cc] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) rW[u] = (K == 0) ? 0.0 : Dk[kSB * kSB + tid + 256 * u];
+    for (int u = 0; u < 4; ++u) rW[u] = Dk[kSB * kSB + tid + 256 * u];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
         const int e = tid + 256 * u, rr = e >> 6, cc = e & 63;
         s.L[rr][cc] = rL[u];
-        if (rr < kQB && cc < kQB) s.D0[rr][cc] = rL[u];
         s.P[rr][cc] = rP[u];
         s.Q[rr][cc] = rQ[u];
     }
@@ -365,8 +458,6 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
             s.Zs[e >> 4][e & 15] = ((e & 15) == 0) ? W[(long long)(K * kSB + (e >> 4)) * ldW + 11] : 0.0;
     }
     __syncthreads();
-    // first block column: no look-ahead yet, every workgroup factors A_00 itself
-    if (K == 0) factor64(s, tid, &bad, [](int) {});
     EQF_STAMP(1);
     // ---- panel blocks: each wave solves its 16-row strip of P and of Q (16-column strip of the rhs block)
     if (needP) {
@@ -442,9 +533,7 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
             factor64(s, tid, &bad, pre);
 #endif
             EQF_STAMP(4);
-            double* Dn = D + (long long)(K + 1) * kDRec;
-            for (int e = tid; e < kSB * kSB; e += 256) Dn[e] = s.L[e >> 6][e & 63];
-            for (int e = tid; e < 4 * kQB * kQB; e += 256) Dn[kSB * kSB + e] = s.Wd[e >> 8][(e >> 4) & 15][e & 15];
+            storeDiagRecord(s, D + (long long)(K + 1) * kDRec, tid);
             EQF_STAMP(5);
         }
     }

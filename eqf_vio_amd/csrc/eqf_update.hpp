@@ -137,7 +137,7 @@ EQF_DI void liftRows(const LiftCommon& L, quat Qq, double Qa, d3 p0, double* Z /
 // Dynamic LDS: wpb (waves per workgroup) x 2 rows x nvPad doubles for one column chunk of the C*Sigma rows.
 constexpr int kPrepLmChunk = 512;
 template <typename T>
-__global__ __launch_bounds__(256) void k_update_prep(UpdArgs a, int lmBlocks, int wpb, int nvPad) {
+EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, double* sCSraw) {
     const int b = blockIdx.y;
     const Glob& g = a.g[b];
     if (!g.updateOk) return;
@@ -197,7 +197,6 @@ __global__ __launch_bounds__(256) void k_update_prep(UpdArgs a, int lmBlocks, in
 
     // ---- landmark waves.  The two C*Sigma rows of a landmark are staged through LDS in column chunks that cover
     // kPrepLmChunk landmarks each (one chunk up to N = 512; larger N loops), so LDS use does not grow with N.
-    extern __shared__ __attribute__((aligned(16))) double sCSraw[];  // [wpb][2][nvPad]
     double* sCS0 = sCSraw + (long long)(2 * wv) * nvPad;
     double* sCS1 = sCS0 + nvPad;
     const int i = blockIdx.x * wpb + wv;
@@ -317,6 +316,11 @@ __global__ __launch_bounds__(256) void k_update_prep(UpdArgs a, int lmBlocks, in
         }
     }
     if (bad && a.errflag) atomicOr(a.errflag, 2);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_update_prep(UpdArgs a, int lmBlocks, int wpb, int nvPad) {
+    extern __shared__ __attribute__((aligned(16))) double sPrepLds[];  // [wpb][2][nvPad]
+    updatePrepBody<T>(a, lmBlocks, wpb, nvPad, sPrepLds);
 }
 
 // ------------------------------------------------------------------------------------------------
