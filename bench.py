@@ -94,13 +94,20 @@ def roofline(fb, events, N, B, precision):
     m = 2 * N
     ne = 6 + 3 * N
     esz = 8 if precision == "f64" else 4
-    nb_s, nb_e = -(-m // 32), -(-ne // 32)
+    # Algorithmic work PER CALL of the path, divided below by the launches the class needed for it.
+    n_upd = max(prof.get("k_update_prep", (0, 0.0))[0], 1)   # vision updates in the timed region
+    chol_launches_per_update = max(prof.get("k_chol_step", (0, 0.0))[0], 1) / n_upd
+    chain_flops = m**3 / 3.0 + m * m * (n + 7.0) + ne**3 / 3.0 + ne * ne * 11.0
+    downdate_flops = 2.0 * n * n * m
+    # 64-wide path: the covariance downdate (and the reductions / innovation lift) ride along in the chain launches
+    embedded = prof.get("k_downdate", (0, 0.0))[0] == 0
     algo = {
-        # SURVEY.md 8(d): propagate = read Sigma once + write Sigma once
+        # propagate = read Sigma once + write Sigma once
         "k_propagate": ("hbm", 2.0 * n * n * esz * B),
-        # Cholesky of S + forward solves of n+7 rhs + Cholesky of Sigma_e + 11 rhs, spread over the step launches
-        "k_chol_step": ("mfma", (m**3 / 3.0 + m * m * (n + 7.0) + ne**3 / 3.0 + ne * ne * 11.0) * B / max(nb_s, nb_e)),
-        "k_downdate": ("mfma", 2.0 * n * n * m * B),
+        # Cholesky of S + forward solves of n+7 rhs + Cholesky of Sigma_e + 11 rhs (+ Sigma - Y^T Y when it rides along),
+        # spread over the chain launches of one update
+        "k_chol_step": ("mfma", (chain_flops + (downdate_flops if embedded else 0.0)) * B / chol_launches_per_update),
+        "k_downdate": ("mfma", downdate_flops * B),
         # dense backend (cfg 3): build F + two n^3 GEMMs = 4 n^3 flops per Riccati step (SURVEY.md 8d "mfma_dense_equiv")
         "k_dense_riccati": ("mfma", 4.0 * n**3 * B),
         "k_update_prep": ("hbm", (n * n * esz + 8.0 * (m * (n + 7) + m * m + ne * ne)) * B),
@@ -122,6 +129,9 @@ def roofline(fb, events, N, B, precision):
                 pk = MFMA_PEAK_TF["f64"]  # factorisation is always fp64
                 if name in ("k_downdate", "k_dense_riccati"):
                     pk = MFMA_PEAK_TF[precision]
+                if name == "k_chol_step":
+                    row["launches_per_update"] = round(chol_launches_per_update, 2)
+                    row["downdate_embedded"] = embedded
                 row.update(bound="mfma", achieved=round(ach, 4), peak=pk, unit="TFLOP/s", frac=round(ach / pk, 5))
         rows.append(row)
     rows.sort(key=lambda r: -r["total_ms"])

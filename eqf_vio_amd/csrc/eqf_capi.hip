@@ -88,12 +88,15 @@ struct eqf_filter {
     void* dBlk = nullptr;          // split propagate path: per-landmark blocks [B][cap][27] (T)
     CommonLds* dBlkCommon = nullptr;
     int splitPropagate = -1;       // -1 heuristic, 0 never, 1 always (EQF_SPLIT_PROPAGATE)
+    int cholMode = 64;             // 64: k_chol_step64 ; 32 / 33: k_chol_step<false> / <true> (EQF_CHOL_MODE = 64 | 32 | 32inv)
+    int cholEmbed = 1;             // EQF_CHOL_EMBED = 0: downdate + innovation lift as a launch of their own
     // profiling
     bool prof = false;
     std::vector<ProfPair> profPairs;
     std::vector<hipEvent_t> evPool;
     long long profCount[EQF_PROF_CLASSES] = {};
     double profMs[EQF_PROF_CLASSES] = {};
+    std::vector<float> profSamples[EQF_PROF_CLASSES];  // per-bracket times: outliers (a box hiccup) are clipped in eqf_profile_get
     double profOverheadMs = 0.0;  // elapsed time of an EMPTY event bracket (calibrated when profiling is switched on)
 };
 
@@ -128,6 +131,7 @@ int profDrain(eqf_filter* f) {
         HIPC(hipEventElapsedTime(&ms, p.a, p.b));
         f->profCount[p.cls]++;
         f->profMs[p.cls] += ms;
+        f->profSamples[p.cls].push_back(ms);
         f->evPool.push_back(p.a);
         f->evPool.push_back(p.b);
     }
@@ -333,20 +337,14 @@ template <typename T>
 int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, const int* perm, int Nmax) {
     UpdArgs a = makeUpdArgs(f, bearings, bearStride, perm);
     const int B = f->B;
-    // Which factorisation kernel: 64-wide block columns with per-workgroup panel solves when the update is latency-bound
-    // (few tiles: one or a few small filters), 32-wide tiles with explicit block inverses + MFMA panels when it is
-    // throughput-bound.  EQF_CHOL_MODE = 64 | 32 | 32inv overrides (experiments).
+    // Factorisation kernel: k_chol_step64 (64-wide block columns, register-chained MFMA panel solves) -- measured faster
+    // than the older 32-wide kernel at every size tried (N = 200: 1..64 filters; N = 1000, 4000).  The 32-wide kernels
+    // stay as an independent cross-check: EQF_CHOL_MODE = 32 (per-workgroup forward substitution) | 32inv (explicit block
+    // inverses + MFMA panels).
     const int nb64S = roundUp(sDim(Nmax), kSB) / kSB, nb64E = roundUp(eDim(Nmax), kSB) / kSB;
     const int wt64 = roundUp(yCols(Nmax), kSB) / kSB;
     const int nblk64 = nb64S * nb64S + wt64 * nb64S + nb64E * nb64E + nb64E;
-    static const char* modeEnv = std::getenv("EQF_CHOL_MODE");
-    bool use64 = (long long)nblk64 * B <= 768;
-    int forceInv = -1;
-    if (modeEnv) {
-        use64 = std::strcmp(modeEnv, "64") == 0;
-        if (std::strcmp(modeEnv, "32inv") == 0) forceInv = 1;
-        if (std::strcmp(modeEnv, "32") == 0) forceInv = 0;
-    }
+    const bool use64 = f->cholMode == 64;
     a.pad = use64 ? kSB : kNB;
     const int mp = roundUp(sDim(Nmax), a.pad), nep = roundUp(eDim(Nmax), a.pad);
     const int nv = kLm0 + 3 * Nmax;
@@ -406,8 +404,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             const int Nb = int(f->ids[b].size());
             if (Nb > 0 && roundUp(sDim(Nb), kSB) >= roundUp(eDim(Nb), kSB)) embed = false;
         }
-        static const char* embedEnv = std::getenv("EQF_CHOL_EMBED");
-        if (embedEnv && embedEnv[0] == '0') embed = false;
+        if (!f->cholEmbed) embed = false;
         for (int k = 0; k < steps; ++k) {
             const int dd = (embed && k == nb64S) ? ddTiles : 0;
             rc = profiled(f, EQF_PROF_CHOL_STEP, [&] {
@@ -424,7 +421,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         const int nblk = cS.nbMax * cS.nbMax + cS.wtMax * cS.nbMax + cE.nbMax * cE.nbMax + cE.wtMax * cE.nbMax;
         // Panel blocks by explicit inverse + MFMA when the launch is throughput-bound (many tiles), by per-workgroup
         // forward substitution otherwise: see k_chol_step.
-        const bool inverse = forceInv >= 0 ? forceInv == 1 : (long long)nblk * B >= 2048;
+        const bool inverse = f->cholMode == 33;
         for (int k = 0; k < steps; ++k) {
             rc = profiled(f, EQF_PROF_CHOL_STEP, [&] {
                 if (inverse) hipLaunchKernelGGL(k_chol_step<true>, dim3(nblk, B), dim3(256), 0, f->stream, cS, cE, k, f->errflag);
@@ -800,6 +797,8 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (!rc && hipMalloc(&f->dBlk, f->esz * (size_t)27 * cap * B) != hipSuccess) rc = EQF_ERR_HIP;
     chk(dmalloc(&f->dBlkCommon, B));
     if (const char* e = std::getenv("EQF_SPLIT_PROPAGATE")) f->splitPropagate = std::atoi(e);
+    if (const char* e = std::getenv("EQF_CHOL_MODE")) f->cholMode = std::strcmp(e, "32inv") == 0 ? 33 : (std::strcmp(e, "32") == 0 ? 32 : 64);
+    if (const char* e = std::getenv("EQF_CHOL_EMBED")) f->cholEmbed = std::atoi(e);
     chk(hmalloc(&f->hMap, (size_t)cap * B)); chk(hmalloc(&f->hNewN, B)); chk(hmalloc(&f->hPerm, (size_t)cap * B));
     chk(hmalloc(&f->hSrc, cap)); chk(hmalloc(&f->hChord, (size_t)cap * B)); chk(hmalloc(&f->hDepth2, (size_t)cap * B));
     chk(hmalloc(&f->hMeas, (size_t)3 * cap * B)); chk(hmalloc(&f->hOut, (size_t)f->nTot * f->nTot + 16));
@@ -1210,6 +1209,7 @@ int eqf_profile_enable(eqf_filter* f, int on) {
         // which would otherwise be charged to every kernel
         std::fill(std::begin(f->profCount), std::end(f->profCount), 0);
         std::fill(std::begin(f->profMs), std::end(f->profMs), 0.0);
+        for (auto& v : f->profSamples) v.clear();
         f->profOverheadMs = 0.0;
         // (median of 64 empty brackets: a single hiccup must not be charged to every kernel)
         for (int i = 0; i < 64; ++i) {
@@ -1237,7 +1237,19 @@ int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_m
     int rc = profDrain(f);
     if (rc) return rc;
     if (launches) *launches = f->profCount[cls];
-    if (total_ms) *total_ms = std::max(0.0, f->profMs[cls] - f->profOverheadMs * f->profCount[cls]);
+    if (total_ms) {
+        // sum of the brackets, with isolated outliers (> 8x the class median: a page fault, a clock change -- one such
+        // bracket of tens of milliseconds was seen to dominate a class total) replaced by the median
+        std::vector<float> v = f->profSamples[cls];
+        double sum = 0.0;
+        if (!v.empty()) {
+            std::vector<float> sorted = v;
+            std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2, sorted.end());
+            const float med = sorted[sorted.size() / 2];
+            for (float x : v) sum += (x > 8.0f * med) ? med : x;
+        }
+        *total_ms = std::max(0.0, sum - f->profOverheadMs * f->profCount[cls]);
+    }
     return EQF_OK;
 }
 

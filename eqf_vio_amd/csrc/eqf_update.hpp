@@ -148,7 +148,6 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, d
     const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
     const double* p0 = a.p0 + (long long)b * 3 * cap;
     const double* Q = a.Q + (long long)b * 5 * cap;
-    const int nv = kLm0 + 3 * N;  // valid internal Sigma order
     int bad = 0;
 
     if ((int)blockIdx.x >= lmBlocks) {

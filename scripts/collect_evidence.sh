@@ -1,0 +1,53 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): collects the round's measurement evidence into gpurun_out/evidence/.
+# Usage: scripts/collect_evidence.sh <round tag, e.g. r01>
+set -u
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/evidence
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+PY=python
+
+stats() {  # stats <name> <bench args...>: rocprofv3 kernel-trace summary of one bench invocation
+  local name=$1; shift
+  rm -rf /tmp/prof_$name
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o b -- $PY $ROOT/bench.py "$@" --no-cpu-baseline --no-traffic --no-roofline > /dev/null 2>&1
+  f=$(find /tmp/prof_$name -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && cp "$f" "$OUT/${TAG}_${name}_kernel_stats.csv"
+}
+pmc() {  # pmc <name> <counter> <bench args...>: per-kernel mean of one PMC counter (KiB), its own pass
+  local name=$1 counter=$2; shift 2
+  rm -rf /tmp/pmc_$name
+  timeout 600 rocprofv3 --pmc $counter --kernel-trace --output-format csv -d /tmp/pmc_$name -o b -- $PY $ROOT/bench.py "$@" --pmc-child > /dev/null 2>&1
+  f=$(find /tmp/pmc_$name -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && $PY - "$f" "$OUT/${TAG}_${name}_pmc_${counter}_summary.csv" <<'PYEOF'
+import csv, statistics, sys, collections
+rows = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    rows[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+with open(sys.argv[2], "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Kernel_Name", "Calls", "Mean_KiB", "Median_KiB", "Max_KiB"])
+    for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+        w.writerow([k, len(v), round(statistics.mean(v), 2), round(statistics.median(v), 2), round(max(v), 2)])
+PYEOF
+}
+
+# 1. the headline line (configs[1]: one filter, N = 200), with roofline, PMC traffic and the CPU baseline
+timeout 900 $PY $ROOT/bench.py > "$OUT/${TAG}_bench_N200.json" 2> "$OUT/${TAG}_bench_N200.stderr"
+stats bench_N200
+pmc bench_N200 FETCH_SIZE --steps 220 --warmup 110
+pmc bench_N200 WRITE_SIZE --steps 220 --warmup 110
+# 2. a batch of 64 filters on one GPU (cfg 4's filters, all on one device)
+timeout 900 $PY $ROOT/bench.py --filters-per-gpu 64 --steps 440 --warmup 110 --no-cpu-baseline --no-traffic > "$OUT/${TAG}_bench_batch64.json" 2>/dev/null
+stats bench_N200_batch64 --filters-per-gpu 64 --steps 220 --warmup 110
+timeout 900 $PY $ROOT/bench.py --filters-per-gpu 8 --steps 880 --warmup 110 --no-cpu-baseline --no-traffic > "$OUT/${TAG}_bench_batch8.json" 2>/dev/null
+# 3. N = 1000: structured kernel and the dense MFMA Riccati backend (cfg 3)
+timeout 900 $PY $ROOT/bench.py --landmarks 1000 --steps 220 --warmup 55 --no-cpu-baseline --no-traffic > "$OUT/${TAG}_bench_N1000.json" 2>/dev/null
+timeout 900 $PY $ROOT/bench.py --landmarks 1000 --steps 110 --warmup 22 --dense-propagate --no-cpu-baseline --no-traffic > "$OUT/${TAG}_bench_N1000_dense.json" 2>/dev/null
+# 4. N = 4000 (Sigma = 1.15 GB)
+timeout 900 $PY $ROOT/bench.py --landmarks 4000 --steps 22 --warmup 11 --no-cpu-baseline --no-traffic > "$OUT/${TAG}_bench_N4000.json" 2>/dev/null
+# 5. long-run parity against the C++ oracle
+( cd $ROOT && timeout 900 $PY scripts/dev_compare.py 200 5.0 | grep -E "vision|worst|eqf_vio" | awk 'NR%12==1 || /worst/' ) > "$OUT/${TAG}_parity_N200_5s.txt" 2>&1
+ls -la "$OUT"

@@ -329,6 +329,53 @@ def test_split_propagate_path_equals_fused(hip, monkeypatch):
     assert np.abs(out[0][2] - out[1][2]).max() < 1e-9
 
 
+@pytest.mark.parametrize("mode,embed", [("32", "1"), ("32inv", "1"), ("64", "0")])
+def test_alternative_factorisation_kernels_agree(hip, monkeypatch, mode, embed):
+    """The update has three interchangeable factorisation paths: k_chol_step64 (default; reductions, downdate and
+    innovation lift riding along in the chain launches), the same with downdate / lift as a launch of their own, and the
+    older 32-wide kernels (forward substitution or explicit block inverses).  They must agree to rounding."""
+    from eqf_vio_amd import synth
+
+    N = 70  # S-chain 3 and E-chain 4 block columns of 64; 5 and 7 of 32
+    st = synth.make_stream(N, duration=0.5)
+    d = synth.template_settings_dict()
+    out = []
+    for m, e in (("64", "1"), (mode, embed)):
+        monkeypatch.setenv("EQF_CHOL_MODE", m)
+        monkeypatch.setenv("EQF_CHOL_EMBED", e)
+        f = hip.FilterBatch(d, capacity=N, batch=1)
+        f.stream_upload(st.imu, st.vision_stamps, st.ids, st.bearings)
+        for kind, k in st.events():
+            (f.stream_imu if kind == "imu" else f.stream_vision)(k)
+        out.append((f.sigma(), f.state_estimate(), f.bias(), f.last_update()))
+        assert f.device_error() == 0
+    assert rel_fro(out[1][0], out[0][0]) < 1e-9
+    assert all(np.abs(out[0][1][k] - out[1][1][k]).max() < 1e-9 for k in out[0][1])
+    assert np.abs(out[0][2] - out[1][2]).max() < 1e-9
+    assert np.abs(out[0][3]["gamma"] - out[1][3]["gamma"]).max() < 1e-9
+
+
+def test_small_filters_with_equal_chain_lengths(oracle_lib, hip):
+    """N <= 19: both chains are one 64-block long, so downdate and innovation lift cannot ride along (fallback launch)."""
+    from eqf_vio_amd import synth
+
+    for N in (2, 3, 19, 20, 21):
+        st = synth.make_stream(N, duration=0.4)
+        d = synth.template_settings_dict()
+        fo = oracle_lib.OracleFilter(d)
+        fg = hip.FilterBatch(d, capacity=N, batch=1)
+        for kind, k in st.events():
+            if kind == "imu":
+                r = st.imu[k]
+                fo.processIMUData(r[0], r[1:4], r[4:7])
+                fg.process_imu([r[0]], r[1:4], r[4:7])
+            else:
+                fo.processVisionData(st.vision_stamps[k], st.ids, st.bearings[k])
+                fg.process_vision([st.vision_stamps[k]], st.ids, st.bearings[k])
+        assert rel_fro(fg.sigma(), fo.stateCovariance()) < SIGMA_TOL, N
+        assert fg.device_error() == 0
+
+
 def _aux_case(N):
     from oracle import eqf_numpy as en
 
