@@ -374,17 +374,18 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     if (!attrSet64) {
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_first64), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_first_sigma<float>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_first_sigma<double>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         attrSet64 = true;
     }
     int rc = profiled(f, EQF_PROF_UPDATE_PREP, [&] {
         // 64-wide path: two more workgroups per filter factor the first diagonal block of each chain straight from Sigma
-        if (use64 && wpb == 4)
+        if (use64 && wpb == 4 && (long long)(lmBlocks + eBlocks + 2) * B <= 512)
             hipLaunchKernelGGL(k_update_prep64<T>, dim3(lmBlocks + eBlocks + 2, B), dim3(256), std::max(lds, sizeof(Step64Lds)), f->stream, a, cS,
                 cE, lmBlocks, eBlocks, wpb, nvPad);
         else {
             hipLaunchKernelGGL(k_update_prep<T>, dim3(lmBlocks + eBlocks, B), dim3(64 * wpb), lds, f->stream, a, lmBlocks, wpb, nvPad);
-            if (use64) hipLaunchKernelGGL(k_factor_first64, dim3(2, B), dim3(256), sizeof(Step64Lds), f->stream, cS, cE, f->errflag);
+            if (use64) hipLaunchKernelGGL(k_factor_first_sigma<T>, dim3(2, B), dim3(256), sizeof(Step64Lds), f->stream, a, cS, cE);
         }
     });
     if (rc) return rc;
