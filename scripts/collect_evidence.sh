@@ -48,6 +48,9 @@ timeout 900 $PY $ROOT/bench.py --landmarks 1000 --steps 220 --warmup 55 --no-cpu
 timeout 900 $PY $ROOT/bench.py --landmarks 1000 --steps 110 --warmup 22 --dense-propagate --no-cpu-baseline --no-traffic > "$OUT/${TAG}_bench_N1000_dense.json" 2>/dev/null
 # 4. N = 4000 (Sigma = 1.15 GB)
 timeout 900 $PY $ROOT/bench.py --landmarks 4000 --steps 22 --warmup 11 --no-cpu-baseline --no-traffic > "$OUT/${TAG}_bench_N4000.json" 2>/dev/null
+# 4b. the same two sizes on the older 32-wide factorisation path, where the covariance downdate is a launch of its own
+EQF_CHOL_MODE=32inv timeout 900 $PY $ROOT/bench.py --landmarks 1000 --steps 220 --warmup 55 --no-cpu-baseline --no-traffic > "$OUT/${TAG}_bench_N1000_chol32.json" 2>/dev/null
+EQF_CHOL_MODE=32inv timeout 900 $PY $ROOT/bench.py --landmarks 4000 --steps 22 --warmup 11 --no-cpu-baseline --no-traffic > "$OUT/${TAG}_bench_N4000_chol32.json" 2>/dev/null
 # 5. long-run parity against the C++ oracle
 ( cd $ROOT && timeout 900 $PY scripts/dev_compare.py 200 5.0 | grep -E "vision|worst|eqf_vio" | awk 'NR%12==1 || /worst/' ) > "$OUT/${TAG}_parity_N200_5s.txt" 2>&1
 ls -la "$OUT"
