@@ -272,7 +272,7 @@ int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, con
     a.blkCommon = f->dBlkCommon;
     // Split path (builder + lean streaming kernel) when there are enough tiles for occupancy to matter; a single small
     // filter keeps the fused single-launch kernel (one kernel boundary less per step).
-    const bool split = f->splitPropagate >= 0 ? f->splitPropagate != 0 : (long long)a.NT * a.NT * f->B >= 1024;
+    const bool split = f->splitPropagate >= 0 ? f->splitPropagate != 0 : (long long)a.NT * a.NT * f->B >= 2500;  // measured cross-over at N = 200: 16 filters
     rc = profiled(f, EQF_PROF_PROPAGATE, [&] {
         if (split) {
             const dim3 bgrid((std::max(1, maxN(f)) + 63) / 64, f->B);
