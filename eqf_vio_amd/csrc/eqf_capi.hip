@@ -251,20 +251,29 @@ int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, con
         a.sigmaExternal = 1;
         const int nmax = maxN(f), nv = kLm0 + 3 * nmax, nt = (nv + 63) / 64;
         const long long bStride = (long long)f->nTot * 6;
+        // 128 x 64 tiles (twice the MFMAs per staged operand byte) measured SLOWER than 64 x 64 at N = 1000 (fp64 43.6 vs
+        // 50.4 TFLOP/s, fp32 73.5 vs 89.4: fewer, fatter workgroups leave a poor last wave); EQF_DENSE_TALL=1 selects them
+        static const char* tallEnv = std::getenv("EQF_DENSE_TALL");
+        const bool tall = tallEnv && tallEnv[0] == '1';
+        const int ntr = tall ? (nv + 127) / 128 : nt;
         rc = profiled(f, EQF_PROF_DENSE, [&] {
-            if (f->precision == EQF_PRECISION_F32) {
-                hipLaunchKernelGGL(k_dense_build<float>, dim3(nmax + 1, f->B), block, 0, f->stream, a, (float*)f->dF, (float*)f->dBn, f->sigmaStride, bStride);
-                hipLaunchKernelGGL((k_dense_gemm<float, false>), dim3(nt, nt, f->B), block, 0, f->stream, a.gin, a.recs, a.inl, (const float*)f->dF,
-                    (const float*)a.Sin, (float*)f->dG, (const float*)nullptr, f->sigmaStride, bStride, f->ld, f->prm);
-                hipLaunchKernelGGL((k_dense_gemm<float, true>), dim3(nt, nt, f->B), block, 0, f->stream, a.gin, a.recs, a.inl, (const float*)f->dG,
-                    (const float*)f->dF, (float*)a.Sout, (const float*)f->dBn, f->sigmaStride, bStride, f->ld, f->prm);
-            } else {
-                hipLaunchKernelGGL(k_dense_build<double>, dim3(nmax + 1, f->B), block, 0, f->stream, a, (double*)f->dF, (double*)f->dBn, f->sigmaStride, bStride);
-                hipLaunchKernelGGL((k_dense_gemm<double, false>), dim3(nt, nt, f->B), block, 0, f->stream, a.gin, a.recs, a.inl, (const double*)f->dF,
-                    (const double*)a.Sin, (double*)f->dG, (const double*)nullptr, f->sigmaStride, bStride, f->ld, f->prm);
-                hipLaunchKernelGGL((k_dense_gemm<double, true>), dim3(nt, nt, f->B), block, 0, f->stream, a.gin, a.recs, a.inl, (const double*)f->dG,
-                    (const double*)f->dF, (double*)a.Sout, (const double*)f->dBn, f->sigmaStride, bStride, f->ld, f->prm);
-            }
+            auto go = [&](auto zero) {
+                typedef decltype(zero) TT;
+                hipLaunchKernelGGL(k_dense_build<TT>, dim3(nmax + 1, f->B), block, 0, f->stream, a, (TT*)f->dF, (TT*)f->dBn, f->sigmaStride, bStride);
+                if (tall) {
+                    hipLaunchKernelGGL((k_dense_gemm<TT, false, 128>), dim3(nt, ntr, f->B), block, 0, f->stream, a.gin, a.recs, a.inl,
+                        (const TT*)f->dF, (const TT*)a.Sin, (TT*)f->dG, (const TT*)nullptr, f->sigmaStride, bStride, f->ld, f->prm);
+                    hipLaunchKernelGGL((k_dense_gemm<TT, true, 128>), dim3(nt, ntr, f->B), block, 0, f->stream, a.gin, a.recs, a.inl,
+                        (const TT*)f->dG, (const TT*)f->dF, (TT*)a.Sout, (const TT*)f->dBn, f->sigmaStride, bStride, f->ld, f->prm);
+                } else {
+                    hipLaunchKernelGGL((k_dense_gemm<TT, false, 64>), dim3(nt, ntr, f->B), block, 0, f->stream, a.gin, a.recs, a.inl,
+                        (const TT*)f->dF, (const TT*)a.Sin, (TT*)f->dG, (const TT*)nullptr, f->sigmaStride, bStride, f->ld, f->prm);
+                    hipLaunchKernelGGL((k_dense_gemm<TT, true, 64>), dim3(nt, ntr, f->B), block, 0, f->stream, a.gin, a.recs, a.inl,
+                        (const TT*)f->dG, (const TT*)f->dF, (TT*)a.Sout, (const TT*)f->dBn, f->sigmaStride, bStride, f->ld, f->prm);
+                }
+            };
+            if (f->precision == EQF_PRECISION_F32) go(0.0f);
+            else go(0.0);
         });
         if (rc) return rc;
     }

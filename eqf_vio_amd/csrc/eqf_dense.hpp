@@ -69,46 +69,67 @@ __global__ __launch_bounds__(256) void k_dense_build(PropArgs a, T* F, T* Bn, lo
     if (bad && a.errflag) atomicOr(a.errflag, 64);
 }
 
-// C = A op(B) (+ epilogue), square n x n operands with leading dimension ld, 64x64 tile per workgroup, K chunks of 32
-// staged through LDS, next chunk prefetched into registers during the MFMAs.
+// C = A op(B) (+ epilogue), square n x n operands with leading dimension ld, TM x 64 tile per workgroup (each wave a
+// (TM/2) x 32 quadrant as (TM/32) x 2 MFMA tiles), K chunks of 32 staged through LDS, next chunk prefetched into registers
+// during the MFMAs.  Interior tiles (the bulk) take unguarded contiguous reads.
 //   TRANSB = false: C = A B          (G = F Sigma)
 //   TRANSB = true : C = A B^T + T*P + Bn Bn^T   (Sigma' = G F^T + process noise)
-template <typename T, bool TRANSB>
+template <typename T, bool TRANSB, int TM>
 __global__ __launch_bounds__(256) void k_dense_gemm(const Glob* gin, const ImuRec* recs, ImuRec inl, const T* A, const T* Bm, T* Cm,
     const T* Bn, long long mStride, long long bStride, int ld, Params prm) {
+    constexpr int WU = TM / 32;  // MFMA tiles per wave along the rows
+    constexpr int PA = TM / 64;  // staging passes for the A tile
     const int b = blockIdx.z;
     const Glob& G = gin[b];
     const ImuRec& r = recs ? recs[b] : inl;
     const double dt0 = r.stamp - G.curTime;
     if (!((G.curTime >= 0) && (dt0 > 0))) return;
     const int nv = kLm0 + 3 * G.N;
-    const int I0 = blockIdx.y * 64, J0 = blockIdx.x * 64;
+    const int I0 = blockIdx.y * TM, J0 = blockIdx.x * 64;
     if (I0 >= nv || J0 >= nv) return;
     const T* Ab = A + (long long)b * mStride;
     const T* Bb = Bm + (long long)b * mStride;
     T* Cb = Cm + (long long)b * mStride;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     constexpr int KC = 32;
-    __shared__ T sA[64][KC + 1];
+    __shared__ T sA[TM][KC + 1];
     __shared__ T sB[TRANSB ? 64 : KC][TRANSB ? KC + 1 : 64 + 1];
     const int qi = wv >> 1, qj = wv & 1, lr = lane & 15, lk = lane >> 4;
     typedef MfmaT<T> MF;
-    typename MF::acc_t acc[2][2];
+    typename MF::acc_t acc[WU][2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < WU; ++u)
 #pragma unroll
         for (int v = 0; v < 2; ++v)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[u][v][q] = 0;
-    // staging: A (and B^T): row = tid / 4, 8 consecutive k from 8 * (tid % 4);  B (NN): k = tid / 8, 8 consecutive columns
+    // staging: A (and B^T): row = tid / 4 (+ 64 per pass), 8 consecutive k from 8 * (tid % 4);  B (NN): k = tid / 8,
+    // 8 consecutive columns
     const int ar = tid >> 2, ak = (tid & 3) * 8;
     const int bk = tid >> 3, bc = (tid & 7) * 8;
-    T pa[8], pb[8];
+    T pa[PA][8], pb[8];
+    const bool interiorIJ = I0 + TM <= nv && J0 + 64 <= nv;
     auto fetch = [&](int k0) {
+        if (interiorIJ && k0 + KC <= nv) {
+            const T* bp = TRANSB ? Bb + (long long)(J0 + ar) * ld + k0 + ak : Bb + (long long)(k0 + bk) * ld + J0 + bc;
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+                const T* ap = Ab + (long long)(I0 + 64 * p + ar) * ld + k0 + ak;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) pa[p][q] = ap[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pb[q] = bp[q];
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int R = I0 + ar, K = k0 + ak + q;
-            pa[q] = (R < nv && K < nv) ? Ab[(long long)R * ld + K] : (T)0;
+            const int K = k0 + ak + q;
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+                const int R = I0 + 64 * p + ar;
+                pa[p][q] = (R < nv && K < nv) ? Ab[(long long)R * ld + K] : (T)0;
+            }
             if (TRANSB) {
                 const int Rb = J0 + ar;
                 pb[q] = (Rb < nv && K < nv) ? Bb[(long long)Rb * ld + K] : (T)0;
@@ -123,7 +144,8 @@ __global__ __launch_bounds__(256) void k_dense_gemm(const Glob* gin, const ImuRe
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            sA[ar][ak + q] = pa[q];
+#pragma unroll
+            for (int p = 0; p < PA; ++p) sA[64 * p + ar][ak + q] = pa[p][q];
             if (TRANSB) sB[ar][ak + q] = pb[q];
             else sB[bk][bc + q] = pb[q];
         }
@@ -131,14 +153,13 @@ __global__ __launch_bounds__(256) void k_dense_gemm(const Glob* gin, const ImuRe
         if (k0 + KC < nv) fetch(k0 + KC);
 #pragma unroll
         for (int s = 0; s < KC / 4; ++s) {
-            T av[2], bv[2];
+            T av[WU], bv[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                av[u] = sA[32 * qi + 16 * u + lr][4 * s + lk];
-                bv[u] = TRANSB ? sB[32 * qj + 16 * u + lr][4 * s + lk] : sB[4 * s + lk][32 * qj + 16 * u + lr];
-            }
+            for (int u = 0; u < WU; ++u) av[u] = sA[(TM / 2) * qi + 16 * u + lr][4 * s + lk];
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int v = 0; v < 2; ++v) bv[v] = TRANSB ? sB[32 * qj + 16 * v + lr][4 * s + lk] : sB[4 * s + lk][32 * qj + 16 * v + lr];
+#pragma unroll
+            for (int u = 0; u < WU; ++u)
 #pragma unroll
                 for (int v = 0; v < 2; ++v) acc[u][v] = MF::mfma(av[u], bv[v], acc[u][v]);
         }
@@ -146,12 +167,12 @@ __global__ __launch_bounds__(256) void k_dense_gemm(const Glob* gin, const ImuRe
     const T Tt = (T)(G.accTime + dt0);
     const T* Bnb = Bn ? Bn + (long long)b * bStride : nullptr;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < WU; ++u)
 #pragma unroll
         for (int v = 0; v < 2; ++v)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int R = I0 + 32 * qi + 16 * u + MF::row(lane, q);
+                const int R = I0 + (TM / 2) * qi + 16 * u + MF::row(lane, q);
                 const int Cc = J0 + 32 * qj + 16 * v + lr;
                 if (R < nv && Cc < nv) {
                     T val = acc[u][v][q];
