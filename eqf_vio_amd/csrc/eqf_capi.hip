@@ -90,6 +90,7 @@ struct eqf_filter {
     int splitPropagate = -1;       // -1 heuristic, 0 never, 1 always (EQF_SPLIT_PROPAGATE)
     int cholMode = 64;             // 64: k_chol_step64 ; 32 / 33: k_chol_step<false> / <true> (EQF_CHOL_MODE = 64 | 32 | 32inv)
     int cholEmbed = 1;             // EQF_CHOL_EMBED = 0: downdate + innovation lift as a launch of their own
+    int cholSplit = -1;            // -1 heuristic, 0 fused chain launches, 1 panel + update launches (EQF_CHOL_SPLIT)
     // profiling
     bool prof = false;
     std::vector<ProfPair> profPairs;
@@ -368,8 +369,12 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     if (!attrSet) {
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<float>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
-        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<float, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<float, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<float, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsUpdateBytes));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsUpdateBytes));
         attrSet = true;
     }
     // chains
@@ -415,12 +420,30 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             if (Nb > 0 && roundUp(sDim(Nb), kSB) >= roundUp(eDim(Nb), kSB)) embed = false;
         }
         if (!f->cholEmbed) embed = false;
+        // Fused launches (each tile solves its own panel blocks) while a launch is bound by the serial diagonal chain;
+        // panel + update launches (every panel block solved once, 2 workgroups per CU) once it is bound by throughput.
+        const bool splitChain = f->cholSplit >= 0 ? f->cholSplit != 0 : (long long)nblk64 * B >= 1500;  // measured: N = 200 from 8 filters on, N >= ~600
+        auto blocks = [&](int k, int phase) {
+            return chainBlocks64(cS.nbMax, cS.wtMax, k, phase) + chainBlocks64(cE.nbMax, cE.wtMax, k, phase);
+        };
         for (int k = 0; k < steps; ++k) {
-            const int dd = (embed && k == nb64S) ? ddTiles : 0;
-            rc = profiled(f, EQF_PROF_CHOL_STEP, [&] {
-                hipLaunchKernelGGL(k_chol_step64<T>, dim3(nblk64 + dd, B), dim3(256), sizeof(Step64Lds), f->stream, cS, cE, a, k, dd ? ddNt : 0,
-                    small ? 1 : 0, embed ? 1 : 0, f->errflag);
-            });
+            if (!splitChain) {
+                const int dd = (embed && k == nb64S) ? ddTiles : 0;
+                rc = profiled(f, EQF_PROF_CHOL_STEP, [&] {
+                    hipLaunchKernelGGL((k_chol_step64<T, 0>), dim3(blocks(k, 0) + dd, B), dim3(256), sizeof(Step64Lds), f->stream, cS, cE, a, k,
+                        dd ? ddNt : 0, small ? 1 : 0, embed ? 1 : 0, f->errflag);
+                });
+            } else {
+                // the S-chain's right-hand sides are complete after panel launch nb64S - 1: the downdate joins that update launch
+                const int dd = (embed && k == nb64S - 1) ? ddTiles : 0;
+                rc = profiled(f, EQF_PROF_CHOL_STEP, [&] {
+                    hipLaunchKernelGGL((k_chol_step64<T, 1>), dim3(blocks(k, 1), B), dim3(256), sizeof(Step64Lds), f->stream, cS, cE, a, k, 0, 0,
+                        embed ? 1 : 0, f->errflag);
+                    if (k + 1 < steps)
+                        hipLaunchKernelGGL((k_chol_step64<T, 2>), dim3(blocks(k, 2) + dd, B), dim3(256), kLdsUpdateBytes, f->stream, cS, cE, a, k,
+                            dd ? ddNt : 0, small ? 1 : 0, embed ? 1 : 0, f->errflag);
+                });
+            }
             if (rc) return rc;
         }
         tailLaunch = !embed;
@@ -809,6 +832,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (const char* e = std::getenv("EQF_SPLIT_PROPAGATE")) f->splitPropagate = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_MODE")) f->cholMode = std::strcmp(e, "32inv") == 0 ? 33 : (std::strcmp(e, "32") == 0 ? 32 : 64);
     if (const char* e = std::getenv("EQF_CHOL_EMBED")) f->cholEmbed = std::atoi(e);
+    if (const char* e = std::getenv("EQF_CHOL_SPLIT")) f->cholSplit = std::atoi(e);
     chk(hmalloc(&f->hMap, (size_t)cap * B)); chk(hmalloc(&f->hNewN, B)); chk(hmalloc(&f->hPerm, (size_t)cap * B));
     chk(hmalloc(&f->hSrc, cap)); chk(hmalloc(&f->hChord, (size_t)cap * B)); chk(hmalloc(&f->hDepth2, (size_t)cap * B));
     chk(hmalloc(&f->hMeas, (size_t)3 * cap * B)); chk(hmalloc(&f->hOut, (size_t)f->nTot * f->nTot + 16));

@@ -46,6 +46,33 @@ struct Step64Lds {
     double redL[256];     // last E-chain rhs workgroup: the reduced products handed to the innovation lift
 };
 
+// Pointer view of the LDS workspace.  Two layouts:
+//   full   (fused / panel launches): Step64Lds as is                                         (119 KB, 1 workgroup / CU)
+//   update (update-only launches of the split chain): Q | P (the diagonal workgroup factors in it: L aliases P) | Wd | D0
+//                                                                                             (77 KB, 2 workgroups / CU)
+struct Lds64 {
+    double (*P)[kSP];
+    double (*Q)[kSP];
+    double (*L)[kSP];
+    double (*Wd)[kQB][kWP];
+    double (*D0)[kWP];
+    double (*Zs)[kWP];
+    double* redL;
+};
+constexpr int kLdsUpdateBytes = int(sizeof(double)) * (2 * kSB * kSP + 4 * kQB * kWP + kQB * kWP);
+EQF_DI Lds64 ldsFull(unsigned char* smem) {
+    Step64Lds* f = reinterpret_cast<Step64Lds*>(smem);
+    return Lds64{f->P, f->Q, f->L, f->Wd, f->D0, f->Zs, f->redL};
+}
+EQF_DI Lds64 ldsUpdate(unsigned char* smem) {
+    double* d = reinterpret_cast<double*>(smem);
+    double (*Q)[kSP] = reinterpret_cast<double (*)[kSP]>(d);
+    double (*P)[kSP] = reinterpret_cast<double (*)[kSP]>(d + kSB * kSP);
+    double (*Wd)[kQB][kWP] = reinterpret_cast<double (*)[kQB][kWP]>(d + 2 * kSB * kSP);
+    double (*D0)[kWP] = reinterpret_cast<double (*)[kWP]>(d + 2 * kSB * kSP + 4 * kQB * kWP);
+    return Lds64{P, Q, P, Wd, D0, nullptr, nullptr};
+}
+
 EQF_DI void chainDims64(const ChainArgs& ch, int N, int* nb, int* wt) {
     if (ch.kind == 0) {
         *nb = roundUp(sDim(N), kSB) / kSB;
@@ -54,6 +81,18 @@ EQF_DI void chainDims64(const ChainArgs& ch, int N, int* nb, int* wt) {
         *nb = roundUp(eDim(N), kSB) / kSB;
         *wt = 1;
     }
+}
+
+// Workgroups one chain needs in launch K (host and device use the same count): the index space only covers what is left
+// of the matrix -- block rows / columns K+1.. -- so late launches do not spawn thousands of workgroups that exit at once.
+//   phase 0 (fused):  rem x rem A tiles (lower triangle used) + wt x (rem + 1) rhs tiles (column K solves, K+1.. update)
+//   phase 1 (panel):  rem A blocks (R, K)                    + wt rhs tiles (column K)
+//   phase 2 (update): rem x rem A tiles                      + wt x rem rhs tiles
+__host__ __device__ inline int chainBlocks64(int nbMax, int wtMax, int K, int phase) {
+    const int rem = nbMax - K - 1;
+    if (rem < 0) return 0;
+    if (phase == 1) return rem + wtMax;
+    return rem * rem + wtMax * (phase == 0 ? rem + 1 : rem);
 }
 
 // One 16x16 output tile on v_mfma_f64_16x16x4_f64:  acc += sgn * sum_{k<KD} A(i0+i, k) * B(k, j0+j).
@@ -162,7 +201,7 @@ EQF_DI void potrf16(double (*T)[kSP], const double* src, int srcLd, double (*Wj)
 // zeroed) and form s.Wd.  All 256 threads.  `pre` is extra work for waves 2 and 3 during the first stage (the diagonal
 // workgroup's remaining trailing-update tiles): pre(wave).
 template <typename Pre>
-EQF_DI void factor64(Step64Lds& s, int tid, int* bad, Pre pre, long long* st = nullptr) {
+EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, long long* st = nullptr) {
     const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll 1
     for (int j = 0; j < 4; ++j) {
@@ -208,7 +247,7 @@ EQF_DI void factor64(Step64Lds& s, int tid, int* bad, Pre pre, long long* st = n
 //   TR = true : the strip is rows x0..x0+15,    M <- M L^-T   (held transposed:  X_j^T = W_jj (A_j^T - sum L_ji X_i^T))
 //   TR = false: the strip is columns x0..x0+15, M <- L^-1 M   (                  Y_j   = W_jj (R_j   - sum L_ji Y_i))
 template <bool TR>
-EQF_DI void solveStrip(double* M, int ld, const Step64Lds& s, int x0, int lane) {
+EQF_DI void solveStrip(double* M, int ld, const Lds64& s, int x0, int lane) {
     f64x4 Z[4], X[4];
     const int lc = lane & 15, lg = lane >> 4;
 #pragma unroll
@@ -232,7 +271,7 @@ EQF_DI void solveStrip(double* M, int ld, const Step64Lds& s, int x0, int lane) 
 }
 
 // Store / load of a diagonal-factor record (s.L, s.Wd <-> ChainArgs::D)
-EQF_DI void storeDiagRecord(const Step64Lds& s, double* Dn, int tid) {
+EQF_DI void storeDiagRecord(const Lds64& s, double* Dn, int tid) {
     for (int e = tid; e < kSB * kSB; e += 256) Dn[e] = s.L[e >> 6][e & 63];
     for (int e = tid; e < 4 * kQB * kQB; e += 256) Dn[kSB * kSB + e] = s.Wd[e >> 8][(e >> 4) & 15][e & 15];
 }
@@ -242,7 +281,7 @@ EQF_DI void storeDiagRecord(const Step64Lds& s, double* Dn, int tid) {
 // one:   kind 0:  S_00 = C Sigma C^T + R for the first 32 landmarks   (same expression order as k_update_prep)
 //        kind 1:  Sigma_e[0:64, 0:64]                                 (identity at the pad index 5 and beyond n_e)
 template <typename T>
-EQF_DI void factorFirstFromSigma(const UpdArgs& a, const ChainArgs& ch, int b, Step64Lds& s, int* bad) {
+EQF_DI void factorFirstFromSigma(const UpdArgs& a, const ChainArgs& ch, int b, const Lds64& s, int* bad) {
     const Glob& g = a.g[b];
     if (!g.updateOk || g.N == 0) return;
     const int N = g.N, cap = a.cap, ld = a.ld, tid = threadIdx.x;
@@ -304,7 +343,7 @@ __global__ __launch_bounds__(256) void k_update_prep64(UpdArgs a, ChainArgs cS, 
         return;
     }
     int bad = 0;
-    factorFirstFromSigma<T>(a, role == 0 ? cS : cE, blockIdx.y, *reinterpret_cast<Step64Lds*>(smem64), &bad);
+    factorFirstFromSigma<T>(a, role == 0 ? cS : cE, blockIdx.y, ldsFull(smem64), &bad);
     if (bad && a.errflag && threadIdx.x == 0) atomicOr(a.errflag, 4);
 }
 // The two first-block workgroups as a launch of their own (grid = (2, B)): used when the prep launch has more workgroups
@@ -313,13 +352,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_factor_first_sigma(UpdArgs a, ChainArgs cS, ChainArgs cE) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
     int bad = 0;
-    factorFirstFromSigma<T>(a, blockIdx.x == 0 ? cS : cE, blockIdx.y, *reinterpret_cast<Step64Lds*>(smem64), &bad);
+    factorFirstFromSigma<T>(a, blockIdx.x == 0 ? cS : cE, blockIdx.y, ldsFull(smem64), &bad);
     if (bad && a.errflag && threadIdx.x == 0) atomicOr(a.errflag, 4);
 }
 // Stand-alone variant (tests / microbenchmarks without a prep launch): factor A_00 of each chain from ChainArgs::A.
 __global__ __launch_bounds__(256) void k_factor_first64(ChainArgs c0, ChainArgs c1, int* errflag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
-    Step64Lds& s = *reinterpret_cast<Step64Lds*>(smem64);
+    const Lds64 s = ldsFull(smem64);
     const ChainArgs& ch = blockIdx.x ? c1 : c0;
     const int b = blockIdx.y, tid = threadIdx.x;
     if (ch.nbMax == 0 || !ch.g[b].updateOk || ch.g[b].N == 0) return;
@@ -345,14 +384,20 @@ __global__ __launch_bounds__(256) void k_factor_first64(ChainArgs c0, ChainArgs 
 //     next to the remaining E-chain steps (the S-chain is always the shorter one);
 //   * the innovation lift / X <- Delta X (k_update_finish) is done by the E-chain's rhs workgroup in its last step.
 // embedFinish = 0 (some filter of the batch has chains of equal length): the host launches k_downdate afterwards.
-template <typename T>
+//
+// PHASE 0: fused launch (above): every tile workgroup solves the two panel blocks it needs itself -- right when a launch
+//          is bound by the serial diagonal chain (one / a few small filters).
+// PHASE 1 + PHASE 2: the split chain for throughput (many tiles per launch): a panel launch solves every block of column
+//          K ONCE, in place (A_RK <- L_RK, Y_K -> WO), an update launch then only multiplies: no redundant solves
+//          (2.25x fewer MFMAs per tile) and the 77 KB LDS layout lets two workgroups share a CU.
+template <typename T, int PHASE>
 __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1, UpdArgs a, int K, int ddNt, int ddSmall,
     int embedFinish, int* errflag) {
     const int b = blockIdx.y;
-    const int n0 = c0.nbMax * c0.nbMax + c0.wtMax * c0.nbMax;
+    const int n0 = chainBlocks64(c0.nbMax, c0.wtMax, K, PHASE);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
     {
-        const int nChain = n0 + c1.nbMax * c1.nbMax + c1.wtMax * c1.nbMax;
+        const int nChain = n0 + chainBlocks64(c1.nbMax, c1.wtMax, K, PHASE);
         if ((int)blockIdx.x >= nChain) {  // covariance downdate tile
             if (ddSmall) downdateTile<T, 32>(a, ddNt, b, (int)blockIdx.x - nChain, reinterpret_cast<T*>(smem64));
             else downdateTile<T, 64>(a, ddNt, b, (int)blockIdx.x - nChain, reinterpret_cast<T*>(smem64));
@@ -369,16 +414,30 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
     if (K >= nb) return;
     bool isW = false;
     int R, C;  // A tile (R,C) or rhs tile (t = R, C)
-    if (idx < ch.nbMax * ch.nbMax) {
-        R = idx / ch.nbMax;
-        C = idx % ch.nbMax;
-        if (R >= nb || C > R || C <= K) return;
+    const int rem = ch.nbMax - K - 1;
+    if (rem < 0) return;
+    if (PHASE == 1) {
+        if (idx < rem) {  // panel launch: the blocks (R, K) below the diagonal
+            R = K + 1 + idx;
+            C = K;
+            if (R >= nb) return;
+        } else {
+            isW = true;
+            R = idx - rem;
+            C = K;
+            if (R >= wt) return;
+        }
+    } else if (idx < rem * rem) {
+        R = K + 1 + idx / rem;
+        C = K + 1 + idx % rem;
+        if (R >= nb || C > R) return;
     } else {
-        idx -= ch.nbMax * ch.nbMax;
+        idx -= rem * rem;
         isW = true;
-        R = idx / ch.nbMax;
-        C = idx % ch.nbMax;
-        if (R >= wt || C >= nb || C < K) return;
+        const int cols = PHASE == 0 ? rem + 1 : rem;  // block rows of the right-hand sides still in play
+        R = idx / cols;
+        C = (PHASE == 0 ? K : K + 1) + idx % cols;
+        if (R >= wt || C >= nb) return;
     }
     double* A = ch.A + (long long)b * ch.strideA;
     double* D = ch.D + (long long)b * ch.strideD;
@@ -387,12 +446,13 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
     const int ldA = ch.ldA, ldW = ch.ldW;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-    Step64Lds& s = *reinterpret_cast<Step64Lds*>(smem64);
+    const Lds64 s = PHASE == 2 ? ldsUpdate(smem64) : ldsFull(smem64);
     int bad = 0;
-    const bool diagNext = !isW && R == C && C == K + 1;
+    const bool diagNext = PHASE != 1 && !isW && R == C && C == K + 1;
     const bool needQ = C > K;
     const bool needP = isW || R != C;
     const bool solveOnly = isW && C == K;
+    const bool panelA = PHASE == 1 && !isW;  // solve in place, no update
 
     // ---- which 16x16 tiles of the 64x64 output tile this wave owns: its 16-row strip (tiles (wv, 0..3)); the diagonal
     // workgroup needs the lower triangle only and the first column first: slot 0 = (wv, 0), then the other tiles spread
@@ -421,7 +481,7 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            acc[i][q] = (solveOnly || i >= nt) ? 0.0 : Ct[(long long)(kQB * tr[i] + (lane >> 4) + 4 * q) * ldc + kQB * tc[i] + (lane & 15)];
+            acc[i][q] = (solveOnly || panelA || i >= nt) ? 0.0 : Ct[(long long)(kQB * tr[i] + (lane >> 4) + 4 * q) * ldc + kQB * tc[i] + (lane & 15)];
     // running sums of the reductions (rhs workgroups): previous value of this thread's entry, fetched with everything else
     double prevSum = 0.0;
     double* sumPtr = nullptr;
@@ -437,30 +497,33 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
         if (sumPtr && K) prevSum = *sumPtr;
     }
     const double* Dk = D + (long long)K * kDRec;
-    const double* Pg = isW ? (W + (long long)(K * kSB) * ldW + R * kSB) : (A + (long long)(R * kSB) * ldA + K * kSB);
+    // (update launches of the split chain read the SOLVED blocks: Y_K from WO, L_RK / L_CK in place in A)
+    const double* Pg = isW ? ((PHASE == 2 ? WO : W) + (long long)(K * kSB) * ldW + R * kSB) : (A + (long long)(R * kSB) * ldA + K * kSB);
     const double* Qg = A + (long long)(C * kSB) * ldA + K * kSB;
     const int ldp = isW ? ldW : ldA;
     double rL[16], rW[4], rP[16], rQ[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
         const int e = tid + 256 * u, rr = e >> 6, cc = e & 63;
-        rL[u] = Dk[e];
+        rL[u] = PHASE == 2 ? 0.0 : Dk[e];
         rP[u] = needP ? Pg[(long long)rr * ldp + cc] : 0.0;
         rQ[u] = needQ ? Qg[(long long)rr * ldA + cc] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) rW[u] = Dk[kSB * kSB + tid + 256 * u];
+    for (int u = 0; u < 4; ++u) rW[u] = PHASE == 2 ? 0.0 : Dk[kSB * kSB + tid + 256 * u];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
         const int e = tid + 256 * u, rr = e >> 6, cc = e & 63;
-        s.L[rr][cc] = rL[u];
+        if (PHASE != 2) s.L[rr][cc] = rL[u];
         s.P[rr][cc] = rP[u];
         s.Q[rr][cc] = rQ[u];
     }
+    if (PHASE != 2) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int e = tid + 256 * u;
-        s.Wd[e >> 8][(e >> 4) & 15][e & 15] = rW[u];
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u;
+            s.Wd[e >> 8][(e >> 4) & 15][e & 15] = rW[u];
+        }
     }
     if (solveOnly && ch.kind == 0) {  // the innovation column: rows of this block row, column 11 of the right-hand sides
         for (int e = tid; e < kSB * kQB; e += 256)
@@ -469,16 +532,20 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
     __syncthreads();
     EQF_STAMP(1);
     // ---- panel blocks: each wave solves its 16-row strip of P and of Q (16-column strip of the rhs block)
-    if (needP) {
-        if (isW) solveStrip<false>(&s.P[0][0], kSP, s, kQB * wv, lane);
-        else solveStrip<true>(&s.P[0][0], kSP, s, kQB * wv, lane);
+    if (PHASE != 2) {
+        if (needP) {
+            if (isW) solveStrip<false>(&s.P[0][0], kSP, s, kQB * wv, lane);
+            else solveStrip<true>(&s.P[0][0], kSP, s, kQB * wv, lane);
+        }
+        if (needQ && PHASE == 0) solveStrip<true>(&s.Q[0][0], kSP, s, kQB * wv, lane);
+        if (solveOnly && ch.kind == 0 && wv == 0) solveStrip<false>(&s.Zs[0][0], kWP, s, 0, lane);
+        __syncthreads();
     }
-    if (needQ) solveStrip<true>(&s.Q[0][0], kSP, s, kQB * wv, lane);
-    if (solveOnly && ch.kind == 0 && wv == 0) solveStrip<false>(&s.Zs[0][0], kWP, s, 0, lane);
-    __syncthreads();
     EQF_STAMP(2);
 
-    if (solveOnly) {
+    if (panelA) {
+        for (int e = tid; e < kSB * kSB; e += 256) A[(long long)(R * kSB + (e >> 6)) * ldA + K * kSB + (e & 63)] = s.P[e >> 6][e & 63];
+    } else if (solveOnly) {
         for (int e = tid; e < kSB * kSB; e += 256) WO[(long long)(K * kSB + (e >> 6)) * ldW + R * kSB + (e & 63)] = s.P[e >> 6][e & 63];
         const double* red = a.red + (long long)b * 256;
         if (ch.kind == 0) {

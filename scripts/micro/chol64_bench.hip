@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
     UpdArgs ua{};
     double* dred; hipMalloc(&dred, 256 * sizeof(double));
     ua.red = dred; ua.g = dg; ua.cap = N;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds)));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds)));
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_first64), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds)));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -66,7 +66,7 @@ int main(int argc, char** argv) {
         hipDeviceSynchronize();
         hipEventRecord(e0, 0);
         hipLaunchKernelGGL(k_factor_first64, dim3(2, 1), dim3(256), sizeof(Step64Lds), 0, c0, c1, derr);
-        for (int K = 0; K < nb; ++K) hipLaunchKernelGGL(k_chol_step64<double>, dim3(nb * nb + nb), dim3(256), sizeof(Step64Lds), 0, c0, c1, ua, K, 0, 0, 0, derr);
+        for (int K = 0; K < nb; ++K) hipLaunchKernelGGL((k_chol_step64<double, 0>), dim3(chainBlocks64(nb, 1, K, 0)), dim3(256), sizeof(Step64Lds), 0, c0, c1, ua, K, 0, 0, 0, derr);
         hipEventRecord(e1, 0);
         hipDeviceSynchronize();
         float ms;

@@ -329,20 +329,22 @@ def test_split_propagate_path_equals_fused(hip, monkeypatch):
     assert np.abs(out[0][2] - out[1][2]).max() < 1e-9
 
 
-@pytest.mark.parametrize("mode,embed", [("32", "1"), ("32inv", "1"), ("64", "0")])
-def test_alternative_factorisation_kernels_agree(hip, monkeypatch, mode, embed):
+@pytest.mark.parametrize("mode,embed,split", [("32", "1", "0"), ("32inv", "1", "0"), ("64", "0", "0"), ("64", "1", "1"), ("64", "0", "1")])
+def test_alternative_factorisation_kernels_agree(hip, monkeypatch, mode, embed, split):
     """The update has three interchangeable factorisation paths: k_chol_step64 (default; reductions, downdate and
-    innovation lift riding along in the chain launches), the same with downdate / lift as a launch of their own, and the
-    older 32-wide kernels (forward substitution or explicit block inverses).  They must agree to rounding."""
+    innovation lift riding along in the chain launches), the same with downdate / lift as a launch of their own, the split
+    chain (panel + update launches, the throughput variant), and the older 32-wide kernels (forward substitution or
+    explicit block inverses).  They must agree to rounding."""
     from eqf_vio_amd import synth
 
     N = 70  # S-chain 3 and E-chain 4 block columns of 64; 5 and 7 of 32
     st = synth.make_stream(N, duration=0.5)
     d = synth.template_settings_dict()
     out = []
-    for m, e in (("64", "1"), (mode, embed)):
+    for m, e, sp in (("64", "1", "0"), (mode, embed, split)):
         monkeypatch.setenv("EQF_CHOL_MODE", m)
         monkeypatch.setenv("EQF_CHOL_EMBED", e)
+        monkeypatch.setenv("EQF_CHOL_SPLIT", sp)
         f = hip.FilterBatch(d, capacity=N, batch=1)
         f.stream_upload(st.imu, st.vision_stamps, st.ids, st.bearings)
         for kind, k in st.events():
