@@ -357,6 +357,36 @@ def test_alternative_factorisation_kernels_agree(hip, monkeypatch, mode, embed, 
     assert np.abs(out[0][3]["gamma"] - out[1][3]["gamma"]).max() < 1e-9
 
 
+def test_large_filter_split_chain_agrees_with_the_32_wide_kernels(hip, monkeypatch):
+    """N = 600 (19 / 29 block columns of 64): the default picks the split chain (panel + update launches); cross-check
+    against the independent 32-wide kernels with explicit block inverses, and against the fused 64-wide launches."""
+    from eqf_vio_amd import synth
+
+    N = 600
+    st = synth.make_stream(N, duration=0.12)
+    d = synth.template_settings_dict()
+    out = []
+    for m, sp in (("64", None), ("32inv", None), ("64", "0")):
+        monkeypatch.setenv("EQF_CHOL_MODE", m)
+        if sp is None:
+            monkeypatch.delenv("EQF_CHOL_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("EQF_CHOL_SPLIT", sp)
+        f = hip.FilterBatch(d, capacity=N, batch=1)
+        f.stream_upload(st.imu, st.vision_stamps, st.ids, st.bearings)
+        for kind, k in st.events():
+            (f.stream_imu if kind == "imu" else f.stream_vision)(k)
+        S = f.sigma()
+        out.append((S, f.state_estimate(), f.last_update()))
+        assert f.device_error() == 0
+        assert np.all(np.diag(S) > 0) and np.abs(S - S.T).max() <= 1e-9 * np.abs(S).max()
+        del f
+    for o in out[1:]:
+        assert rel_fro(o[0], out[0][0]) < 1e-8
+        assert np.abs(o[1]["x"] - out[0][1]["x"]).max() < 1e-9
+        assert np.abs(o[2]["gamma"] - out[0][2]["gamma"]).max() < 1e-8
+
+
 def test_small_filters_with_equal_chain_lengths(oracle_lib, hip):
     """N <= 19: both chains are one 64-block long, so downdate and innovation lift cannot ride along (fallback launch)."""
     from eqf_vio_amd import synth
