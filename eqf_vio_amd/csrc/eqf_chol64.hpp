@@ -197,11 +197,17 @@ EQF_DI void potrf16(double (*T)[kSP], const double* src, int srcLd, double (*Wj)
     }
 }
 
+// Columns [16 j, 16 j + 16) of s.L and the inverse block Wd[j] -> diagonal-factor record Dn, by threads t = 0..nthr-1
+EQF_DI void storeDiagColumns(const Lds64& s, double* Dn, int j, int t, int nthr) {
+    for (int e = t; e < kSB * kQB; e += nthr) Dn[(e >> 4) * kSB + kQB * j + (e & 15)] = s.L[e >> 4][kQB * j + (e & 15)];
+    for (int e = t; e < kQB * kQB; e += nthr) Dn[kSB * kSB + kQB * kQB * j + e] = s.Wd[j][e >> 4][e & 15];
+}
+
 // Factor the 64x64 symmetric block in s.L in place (lower block triangle; the upper triangles of the diagonal blocks are
 // zeroed) and form s.Wd.  All 256 threads.  `pre` is extra work for waves 2 and 3 during the first stage (the diagonal
 // workgroup's remaining trailing-update tiles): pre(wave).
 template <typename Pre>
-EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, long long* st = nullptr) {
+EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn = nullptr, long long* st = nullptr) {
     const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll 1
     for (int j = 0; j < 4; ++j) {
@@ -213,6 +219,9 @@ EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, long long* st =
         else if (wv >= 2) {
             if (j == 0) pre(wv);
             else {
+                // the 16 columns finished in the previous stage (and their inverse block) go to the record in global memory
+                // now, in the shadow of wave 0's pivot chain, instead of all at the end of the launch
+                if (Dn) storeDiagColumns(s, Dn, j - 1, tid - 128, 128);
                 int t = 0;
 #pragma unroll 1
                 for (int c = j + 1; c < 4; ++c)
@@ -241,6 +250,7 @@ EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, long long* st =
 #endif
         __syncthreads();
     }
+    if (Dn) storeDiagColumns(s, Dn, 3, tid, 256);
 }
 
 // Panel solve of one 16-wide strip of M in place, four 16x16 stages chained through the accumulators:
@@ -268,12 +278,6 @@ EQF_DI void solveStrip(double* M, int ld, const Lds64& s, int x0, int lane) {
             if (TR) M[(x0 + lc) * ld + kQB * j + lg + 4 * q] = X[j][q];
             else M[(kQB * j + lg + 4 * q) * ld + x0 + lc] = X[j][q];
         }
-}
-
-// Store / load of a diagonal-factor record (s.L, s.Wd <-> ChainArgs::D)
-EQF_DI void storeDiagRecord(const Lds64& s, double* Dn, int tid) {
-    for (int e = tid; e < kSB * kSB; e += 256) Dn[e] = s.L[e >> 6][e & 63];
-    for (int e = tid; e < 4 * kQB * kQB; e += 256) Dn[kSB * kSB + e] = s.Wd[e >> 8][(e >> 4) & 15][e & 15];
 }
 
 // The first diagonal blocks of the two chains, formed straight from Sigma and factored INSIDE the prep launch (two extra
@@ -330,8 +334,7 @@ EQF_DI void factorFirstFromSigma(const UpdArgs& a, const ChainArgs& ch, int b, c
     __syncthreads();
     if (tid < kQB * kQB) s.D0[tid >> 4][tid & 15] = s.L[tid >> 4][tid & 15];
     __syncthreads();
-    factor64(s, tid, bad, [](int) {});
-    storeDiagRecord(s, ch.D + (long long)b * ch.strideD, tid);
+    factor64(s, tid, bad, [](int) {}, ch.D + (long long)b * ch.strideD);
 }
 // k_update_prep + the two first-block workgroups (grid.x = lmBlocks + eBlocks + 2)
 template <typename T>
@@ -368,8 +371,7 @@ __global__ __launch_bounds__(256) void k_factor_first64(ChainArgs c0, ChainArgs 
     if (tid < kQB * kQB) s.D0[tid >> 4][tid & 15] = s.L[tid >> 4][tid & 15];
     __syncthreads();
     int bad = 0;
-    factor64(s, tid, &bad, [](int) {});
-    storeDiagRecord(s, ch.D + (long long)b * ch.strideD, tid);
+    factor64(s, tid, &bad, [](int) {}, ch.D + (long long)b * ch.strideD);
     if (bad && errflag && tid == 0) atomicOr(errflag, 4);
 }
 
@@ -604,12 +606,11 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
                 }
             };
 #ifdef EQF_STEP64_STAMPS
-            factor64(s, tid, &bad, pre, !second ? &g_stamps[K][8] : nullptr);
+            factor64(s, tid, &bad, pre, D + (long long)(K + 1) * kDRec, !second ? &g_stamps[K][8] : nullptr);
 #else
-            factor64(s, tid, &bad, pre);
+            factor64(s, tid, &bad, pre, D + (long long)(K + 1) * kDRec);
 #endif
             EQF_STAMP(4);
-            storeDiagRecord(s, D + (long long)(K + 1) * kDRec, tid);
             EQF_STAMP(5);
         }
     }
