@@ -90,6 +90,7 @@ struct eqf_filter {
     int splitPropagate = -1;       // -1 heuristic, 0 never, 1 always (EQF_SPLIT_PROPAGATE)
     int cholMode = 64;             // 64: k_chol_step64 ; 32 / 33: k_chol_step<false> / <true> (EQF_CHOL_MODE = 64 | 32 | 32inv)
     int cholEmbed = 1;             // EQF_CHOL_EMBED = 0: downdate + innovation lift as a launch of their own
+    bool ldsAttrSet[2] = {false, false};  // hipFuncAttributeMaxDynamicSharedMemorySize applied on this handle's device
     int cholSplit = -1;            // -1 heuristic, 0 fused chain launches, 1 panel + update launches (EQF_CHOL_SPLIT)
     // profiling
     bool prof = false;
@@ -365,7 +366,9 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     if (wpb < 1) return EQF_ERR_CAPACITY;
     const int lmBlocks = (mp / 2 + wpb - 1) / wpb, eBlocks = nep / kNB;
     const size_t lds = perWave * wpb;
-    static bool attrSet = false, attrSet64 = false;
+    // (function attributes are per device: remembered per handle, not per process)
+    bool& attrSet = f->ldsAttrSet[0];
+    bool& attrSet64 = f->ldsAttrSet[1];
     if (!attrSet) {
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
