@@ -292,6 +292,18 @@ def main():
         rl, rows = roofline(fb, timed, N, B, args.precision)
         line["roofline"] = rl
         line["kernels"] = rows
+        # propagate-only and update-only time per call (kernel time from the HIP events), frames/s
+        t = {r["kernel"]: (r["total_ms"], r["launches"]) for r in rows}
+        n_imu_vis = len(timed)
+        n_upd = max(t.get("k_update_prep", (0, 1))[1], 1)
+        prop_ms = t.get("k_propagate", (0, 0))[0] + t.get("k_dense_riccati", (0, 0))[0]
+        upd_ms = sum(t.get(k, (0, 0))[0] for k in ("k_update_prep", "k_chol_step", "k_update_reduce", "k_update_finish", "k_downdate"))
+        line["per_call"] = {
+            "propagate_us": round(prop_ms * 1e3 / max(n_imu_vis, 1), 3),
+            "update_us": round(upd_ms * 1e3 / n_upd, 3),
+            "frames_per_s": round(line["value"] / B / world * n_upd / max(n_imu_vis, 1), 1),
+            "note": "kernel time of the profiled pass (dispatch gaps excluded); a frame = 10 IMU calls + 1 vision call",
+        }
         if rl is not None and world == 1 and not args.no_traffic:
             del fb  # free the GPU for the profiled child runs
             traffic, note = pmc_traffic(args, rl["kernel"])

@@ -85,8 +85,9 @@ struct eqf_filter {
     std::vector<char> init;
     int densePropagate = 0;
     void *dF = nullptr, *dG = nullptr, *dBn = nullptr;  // dense backend: F, G = F Sigma, Bn (n x 6)
-    void* dBlk = nullptr;          // split propagate path: per-landmark blocks [B][cap][27] (T)
+    void* dBlk = nullptr;          // split propagate path: per-landmark records [B][cap][kBlkRec] (T)
     CommonLds* dBlkCommon = nullptr;
+    int streamPropagate = 1;       // split path: landmark blocks by k_riccati_stream (EQF_STREAM_PROPAGATE = 0: by the tile kernel)
     int splitPropagate = -1;       // -1 heuristic, 0 never, 1 always (EQF_SPLIT_PROPAGATE)
     int cholMode = 64;             // 64: k_chol_step64 ; 32 / 33: k_chol_step<false> / <true> (EQF_CHOL_MODE = 64 | 32 | 32inv)
     int cholEmbed = 1;             // EQF_CHOL_EMBED = 0: downdate + innovation lift as a launch of their own
@@ -287,11 +288,18 @@ int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, con
     rc = profiled(f, EQF_PROF_PROPAGATE, [&] {
         if (split) {
             const dim3 bgrid((std::max(1, maxN(f)) + 63) / 64, f->B);
+            // builder (blocks + G rows + group step), then the landmark x landmark blocks by the lean streaming kernel and the
+            // base rows / columns by the tile kernel restricted to its last tile row / column (+ the base-block workgroup)
+            const int nmx = std::max(1, maxN(f));
+            const dim3 sgrid((nmx + 255) / 256, (nmx + kStreamRows - 1) / kStreamRows, f->B);
+            a.tailsOnly = f->streamPropagate ? 1 : 0;
             if (f->precision == EQF_PRECISION_F32) {
                 hipLaunchKernelGGL(k_build_blocks<float>, bgrid, dim3(64), 0, f->stream, a);
+                if (a.tailsOnly) hipLaunchKernelGGL(k_riccati_stream<float>, sgrid, block, 0, f->stream, a);
                 hipLaunchKernelGGL((k_propagate<float, true>), grid, block, 0, f->stream, a);
             } else {
                 hipLaunchKernelGGL(k_build_blocks<double>, bgrid, dim3(64), 0, f->stream, a);
+                if (a.tailsOnly) hipLaunchKernelGGL(k_riccati_stream<double>, sgrid, block, 0, f->stream, a);
                 hipLaunchKernelGGL((k_propagate<double, true>), grid, block, 0, f->stream, a);
             }
         } else if (f->precision == EQF_PRECISION_F32) {
@@ -830,9 +838,10 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     chk(dmalloc(&f->dScratch, (size_t)kLmRec * cap * B)); chk(dmalloc(&f->dMeas, (size_t)3 * cap * B));
     chk(dmalloc(&f->dOut, (size_t)f->nTot * f->nTot + 16));
     chk(dmalloc(&f->dRing, (size_t)kRing * B));
-    if (!rc && hipMalloc(&f->dBlk, f->esz * (size_t)27 * cap * B) != hipSuccess) rc = EQF_ERR_HIP;
+    if (!rc && hipMalloc(&f->dBlk, f->esz * (size_t)kBlkRec * cap * B) != hipSuccess) rc = EQF_ERR_HIP;
     chk(dmalloc(&f->dBlkCommon, B));
     if (const char* e = std::getenv("EQF_SPLIT_PROPAGATE")) f->splitPropagate = std::atoi(e);
+    if (const char* e = std::getenv("EQF_STREAM_PROPAGATE")) f->streamPropagate = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_MODE")) f->cholMode = std::strcmp(e, "32inv") == 0 ? 33 : (std::strcmp(e, "32") == 0 ? 32 : 64);
     if (const char* e = std::getenv("EQF_CHOL_EMBED")) f->cholEmbed = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_SPLIT")) f->cholSplit = std::atoi(e);

@@ -26,6 +26,10 @@ struct CommonLds {
     double Bg[6], Bvw[9], RA[9], Avg[6];
 };
 
+// per-landmark record written by k_build_blocks (element type T): D, Lw, Lv (3x3 each, already scaled by T), then the rows
+// Gn = G[:,0:3] + (sigma_w^2 / T) Lw and Gv = G[:,8:11] of G = Lw Sigma[0:3,:] + Lv Sigma[8:11,:] + D Sigma_Ib
+constexpr int kBlkRec = 45;
+
 struct PropArgs {
     const Glob* gin;
     Glob* gout;
@@ -44,6 +48,7 @@ struct PropArgs {
     void* blk;          // [B][cap][27] (T) per-landmark blocks D, Lw, Lv written by k_build_blocks (split path)
     CommonLds* blkCommon;  // [B] common values written by k_build_blocks
     int sigmaExternal;  // the Riccati step of this call is done by the dense MFMA backend: touch no Sigma here
+    int tailsOnly;      // streaming path: the landmark x landmark blocks belong to k_riccati_stream; only the base rows / columns here
     Params prm;
 };
 
@@ -268,6 +273,7 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     const bool isExtra = (int)blockIdx.x == a.NT * a.NT;
     const int ti = isExtra ? 0 : blockIdx.x / a.NT, tj = isExtra ? 0 : blockIdx.x % a.NT;
     const int lastT = a.NT - 1;
+    if (PRE && a.tailsOnly && !isExtra && ti != lastT && tj != lastT) return;
     const int cap = a.cap, ld = a.ld;
 
     __shared__ T sD[32][9], sLw[32][9], sLv[32][9];  // [0,16): row landmarks I, [16,32): column landmarks J
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     if (PRE) {
         if (riccati && tid < 32 && !isExtra) {
             const int i = (tid < 16) ? I0 + tid : J0 + tid - 16;
-            const T* bp = static_cast<const T*>(a.blk) + ((long long)b * cap + i) * 27;
+            const T* bp = static_cast<const T*>(a.blk) + ((long long)b * cap + i) * kBlkRec;
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 sD[tid][k] = (i < N) ? bp[k] : (T)0;
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     // this thread's own 3x3 block of Sigma: issue the loads before the barrier
     const int bi = tid >> 4, bj = tid & 15;
     const int BI = I0 + bi, BJ = J0 + bj;
-    const bool blockValid = !isExtra && BI < N && BJ < N;
+    const bool blockValid = !isExtra && BI < N && BJ < N && !(PRE && a.tailsOnly);
     T S[9];
     if (blockValid) {
         const T* src = Sin + (long long)(kLm0 + 3 * BI) * ld + kLm0 + 3 * BJ;
@@ -618,12 +624,37 @@ __global__ __launch_bounds__(64) void k_build_blocks(PropArgs a) {
         const d3 q0 = mk3(p0[i], p0[cap + i], p0[2 * cap + i]);
         if (riccati) {
             const LmBlocks blk = buildBlocks(c, Qq, Qa, q0);
-            T* bp = static_cast<T*>(a.blk) + ((long long)b * cap + i) * 27;
+            T* bp = static_cast<T*>(a.blk) + ((long long)b * cap + i) * kBlkRec;
+            T D[9], Lw[9], Lv[9];
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                bp[k] = (T)blk.D.a[k];
-                bp[9 + k] = (T)blk.Lw.a[k];
-                bp[18 + k] = (T)blk.Lv.a[k];
+                D[k] = (T)blk.D.a[k];
+                Lw[k] = (T)blk.Lw.a[k];
+                Lv[k] = (T)blk.Lv.a[k];
+                bp[k] = D[k];
+                bp[9 + k] = Lw[k];
+                bp[18 + k] = Lv[k];
+            }
+            // the two 3x3 pieces of G_I = Lw Sigma[0:3, :] + Lv Sigma[8:11, :] + D Sigma_Ib that the landmark blocks need
+            // (same expression order as k_propagate's tile code)
+            if (!a.sigmaExternal) {
+                const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
+                const T sw2 = (T)a.prm.velOmegaVariance, Tt = (T)c.T;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int c0 = half ? 8 : 0;
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc) {
+                            T acc = 0;
+#pragma unroll
+                            for (int k = 0; k < 3; ++k)
+                                acc += Lw[3 * rr + k] * Sin[(long long)k * a.ld + c0 + cc] + Lv[3 * rr + k] * Sin[(long long)(8 + k) * a.ld + c0 + cc] +
+                                       D[3 * rr + k] * Sin[(long long)(kLm0 + 3 * i + k) * a.ld + c0 + cc];
+                            bp[27 + 9 * half + 3 * rr + cc] = half ? acc : acc + (sw2 / Tt) * Lw[3 * rr + cc];
+                        }
+                }
             }
         }
         quat Qo = Qq;
@@ -654,6 +685,111 @@ __global__ __launch_bounds__(64) void k_build_blocks(PropArgs a) {
         }
     }
     if (bad && a.errflag) atomicOr(a.errflag, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_riccati_stream: the landmark x landmark blocks of the structured Riccati step for throughput-bound sizes.
+//   Sigma'_IJ = (D_I Sigma_IJ + Lw_I Sigma_wJ + Lv_I Sigma_vJ) D_J^T + Gn_I Lw_J^T + Gv_I Lv_J^T  (+ T p I on the diagonal)
+// One lane per COLUMN landmark J (its blocks D_J, Lw_J, Lv_J and the base rows Sigma_wJ, Sigma_vJ stay in registers), a
+// workgroup walks kStreamRows ROW landmarks whose constants are wave-uniform LDS broadcasts: per 3x3 block 9 loads,
+// 9 stores, 162 FMAs and a handful of address instructions -- k_propagate's tile code spends ~1500 instructions on the
+// same block (staging loops, integer divisions, 64-bit address arithmetic) and is issue-bound, not memory-bound.
+// grid = (column strips of 256 landmarks, ceil(N / kStreamRows), B), block = 256 (4 waves = 4 strips of 64 columns).
+// The base rows / columns come from k_propagate<T, true> with tailsOnly = 1; blocks and G rows from k_build_blocks.
+// ------------------------------------------------------------------------------------------------
+constexpr int kStreamRows = 16;
+template <typename T>
+__global__ __launch_bounds__(256) void k_riccati_stream(PropArgs a) {
+    const int b = blockIdx.z;
+    const Glob& G = a.gin[b];
+    const ImuRec& r = a.recs ? a.recs[b] : a.inl;
+    const int N = G.N;
+    const double dt0 = r.stamp - G.curTime;
+    const bool step = (G.curTime >= 0) && (dt0 > 0);
+    const bool riccati = step && a.doRiccati && !a.sigmaExternal;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int I0 = blockIdx.y * kStreamRows;
+    const int J = (4 * blockIdx.x + wv) * 64 + lane;
+    if (I0 >= N) return;
+    const int ld = a.ld;
+    const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
+    T* Sout = static_cast<T*>(a.Sout) + (long long)b * a.sigmaStride;
+    const int nI = min(kStreamRows, N - I0);
+    const bool validJ = J < N;
+    const T* colIn = Sin + kLm0 + 3 * (validJ ? J : 0);
+    T* colOut = Sout + kLm0 + 3 * (validJ ? J : 0);
+    if (!riccati) {
+        if (a.sigmaExternal && step && a.doRiccati) return;  // Sigma_out was written by k_dense_gemm
+        if (validJ)
+            for (int i = 0; i < 3 * nI; ++i) {
+                const long long ro = (long long)(kLm0 + 3 * I0 + i) * ld;
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) colOut[ro + cc] = colIn[ro + cc];
+            }
+        return;
+    }
+    __shared__ T sRow[kStreamRows][kBlkRec];
+    const T* blk = static_cast<const T*>(a.blk) + (long long)b * a.cap * kBlkRec;
+    for (int e = tid; e < nI * kBlkRec; e += 256) sRow[e / kBlkRec][e % kBlkRec] = blk[(long long)I0 * kBlkRec + e];
+    // column constants
+    T DJ[9], LwJ[9], LvJ[9], SwJ[9], SvJ[9];
+    {
+        const T* bj = blk + (long long)(validJ ? J : 0) * kBlkRec;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            DJ[k] = bj[k];
+            LwJ[k] = bj[9 + k];
+            LvJ[k] = bj[18 + k];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                SwJ[3 * rr + cc] = colIn[(long long)rr * ld + cc];
+                SvJ[3 * rr + cc] = colIn[(long long)(8 + rr) * ld + cc];
+            }
+    }
+    const T TtP = (T)a.blkCommon[b].T * (T)a.prm.pointProcessVariance;
+    T S[9];
+    auto fetch = [&](int i) {
+        const long long ro = (long long)(kLm0 + 3 * (I0 + i)) * ld;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) S[3 * rr + cc] = colIn[ro + (long long)rr * ld + cc];
+    };
+    fetch(0);
+    __syncthreads();
+    for (int i = 0; i < nI; ++i) {
+        T Sc[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Sc[k] = S[k];
+        if (i + 1 < nI) fetch(i + 1);  // next block's loads fly during this block's arithmetic
+        const T* rc = sRow[i];         // wave-uniform: LDS broadcast reads
+        T H[9];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                T acc = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    acc += rc[3 * rr + k] * Sc[3 * k + cc] + rc[9 + 3 * rr + k] * SwJ[3 * k + cc] + rc[18 + 3 * rr + k] * SvJ[3 * k + cc];
+                H[3 * rr + cc] = acc;
+            }
+        const long long ro = (long long)(kLm0 + 3 * (I0 + i)) * ld;
+        const bool diag = (I0 + i) == J;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                T acc = (diag && rr == cc) ? TtP : (T)0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    acc += H[3 * rr + k] * DJ[3 * cc + k] + rc[27 + 3 * rr + k] * LwJ[3 * cc + k] + rc[36 + 3 * rr + k] * LvJ[3 * cc + k];
+                if (validJ) colOut[ro + (long long)rr * ld + cc] = acc;
+            }
+    }
 }
 
 }  // namespace eqf

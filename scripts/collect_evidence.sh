@@ -52,5 +52,7 @@ timeout 900 $PY $ROOT/bench.py --landmarks 4000 --steps 22 --warmup 11 --no-cpu-
 EQF_CHOL_MODE=32inv timeout 900 $PY $ROOT/bench.py --landmarks 1000 --steps 220 --warmup 55 --no-cpu-baseline --no-traffic > "$OUT/${TAG}_bench_N1000_chol32.json" 2>/dev/null
 EQF_CHOL_MODE=32inv timeout 900 $PY $ROOT/bench.py --landmarks 4000 --steps 22 --warmup 11 --no-cpu-baseline --no-traffic > "$OUT/${TAG}_bench_N4000_chol32.json" 2>/dev/null
 # 5. long-run parity against the C++ oracle
-( cd $ROOT && timeout 900 $PY scripts/dev_compare.py 200 5.0 | grep -E "vision|worst|eqf_vio" | awk 'NR%12==1 || /worst/' ) > "$OUT/${TAG}_parity_N200_5s.txt" 2>&1
+( echo "# scripts/dev_compare.py 200 10.0 on MI355X: HIP path (fp64, per-call C ABI) vs oracle/eqf_oracle.cpp, same synthetic stream"
+  echo "# (2000 IMU + 200 vision events, N = 200, template settings); relS = |Sigma_gpu - Sigma_ref|_F / |Sigma_ref|_F after the event"
+  cd $ROOT && timeout 1200 $PY scripts/dev_compare.py 200 10.0 | grep -E "vision|worst|eqf_vio" | awk 'NR%20==1 || /worst/' ) > "$OUT/${TAG}_parity_N200_10s.txt" 2>&1
 ls -la "$OUT"

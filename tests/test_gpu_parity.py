@@ -315,8 +315,9 @@ def test_split_propagate_path_equals_fused(hip, monkeypatch):
     st = synth.make_stream(N, duration=0.5)
     d = synth.template_settings_dict()
     out = []
-    for mode in ("0", "1"):
+    for mode, stream in (("0", "1"), ("1", "1"), ("1", "0")):  # fused / builder + streaming kernel / builder + tile kernel
         monkeypatch.setenv("EQF_SPLIT_PROPAGATE", mode)
+        monkeypatch.setenv("EQF_STREAM_PROPAGATE", stream)
         f = hip.FilterBatch(d, capacity=N, batch=1)
         f.stream_upload(st.imu, st.vision_stamps, st.ids, st.bearings)
         for kind, k in st.events():
@@ -324,9 +325,10 @@ def test_split_propagate_path_equals_fused(hip, monkeypatch):
         out.append((f.sigma(), f.state_estimate(), f.bias()))
         assert f.device_error() == 0
     # same formulas, differently compiled (FMA contraction): agreement to rounding amplified by cond(Sigma) ~ 1e7
-    assert rel_fro(out[1][0], out[0][0]) < 1e-9
-    assert all(np.abs(out[0][1][k] - out[1][1][k]).max() < 1e-9 for k in out[0][1])
-    assert np.abs(out[0][2] - out[1][2]).max() < 1e-9
+    for o in out[1:]:
+        assert rel_fro(o[0], out[0][0]) < 1e-9
+        assert all(np.abs(out[0][1][k] - o[1][k]).max() < 1e-9 for k in out[0][1])
+        assert np.abs(out[0][2] - o[2]).max() < 1e-9
 
 
 @pytest.mark.parametrize("mode,embed,split", [("32", "1", "0"), ("32inv", "1", "0"), ("64", "0", "0"), ("64", "1", "1"), ("64", "0", "1")])
