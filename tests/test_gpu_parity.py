@@ -116,6 +116,53 @@ def test_batch_of_filters_matches_independent_oracles(oracle_lib, hip):
     assert rel_fro(fg.sigma(0), fg.sigma(1)) > 1e-3  # the filters really are different
 
 
+def test_ragged_batch_with_churn_and_outlier_gate(oracle_lib, hip):
+    """Four filters in one handle with DIFFERENT landmark counts (3 .. 90: one, two and three 64-blocks per chain, so the
+    chain lengths differ inside one launch), landmarks entering and leaving every few frames, an outlier on two frames
+    and the outlier gate switched on: each filter must follow its own reference filter."""
+    from eqf_vio_amd import synth
+
+    B, pools = 4, [6, 30, 70, 110]
+    dur = 0.8
+    sts = [synth.make_stream(pools[b], seed=77 + b, duration=dur) for b in range(B)]
+    meas = [synth.churn_measurements(sts[b], seed=5 + b, max_visible=[3, 25, 60, 90][b], outlier_frames=(5, 9) if b % 2 else ())
+            for b in range(B)]
+    d = synth.template_settings_dict()
+    d["outlierThreshold"] = 0.05  # gate active every frame (probe + readback), loose enough not to decimate the landmarks
+    fos = [oracle_lib.OracleFilter(d) for _ in range(B)]
+    fg = hip.FilterBatch(d, capacity=max(pools), batch=B)
+    stride = max(pools)
+    chain_blocks = set()
+    for kind, k in sts[0].events():
+        if kind == "imu":
+            for b in range(B):
+                r = sts[b].imu[k]
+                fos[b].processIMUData(r[0], r[1:4], r[4:7])
+            fg.process_imu([s.imu[k, 0] for s in sts], [s.imu[k, 1:4] for s in sts], [s.imu[k, 4:7] for s in sts])
+        else:
+            ids = np.zeros((B, stride), dtype=np.int32)
+            y = np.zeros((B, stride, 3))
+            nb = np.zeros(B, dtype=np.int32)
+            for b in range(B):
+                mi, my = meas[b][k]
+                fos[b].processVisionData(sts[b].vision_stamps[k], mi, my)
+                nb[b] = len(mi)
+                ids[b, : len(mi)] = mi
+                y[b, : len(mi)] = my
+            fg.process_vision([s.vision_stamps[k] for s in sts], ids, y, nb=nb)
+            for b in range(B):
+                assert fg.num_landmarks(b) == fos[b].N, (k, b)
+                assert np.array_equal(fg.ids(b), fos[b].ids()), (k, b)
+                assert rel_fro(fg.sigma(b), fos[b].stateCovariance()) < SIGMA_TOL, (k, b)
+            chain_blocks.add(tuple(-(-(6 + 3 * fg.num_landmarks(b)) // 64) for b in range(B)))
+    # chains of different lengths (1 .. 4+ block columns of 64) were in flight inside one launch
+    assert any(len(set(c)) >= 3 for c in chain_blocks), chain_blocks
+    for b in range(B):
+        eo, eg = fos[b].stateEstimate(), fg.state_estimate(b)
+        assert np.abs(eo["x"] - eg["x"]).max() < POSE_TOL and np.abs(eo["q"] - eg["q"]).max() < POSE_TOL
+    assert fg.device_error() == 0
+
+
 def test_stream_mode_equals_per_call_mode(hip):
     """eqf_stream_* (inputs resident in HBM, what bench.py times) is the same computation as the per-call API."""
     from eqf_vio_amd import synth
