@@ -113,6 +113,9 @@ def roofline(fb, events, N, B, precision):
         "k_update_prep": ("hbm", (n * n * esz + 8.0 * (m * (n + 7) + m * m + ne * ne)) * B),
         "k_update_reduce": ("hbm", 8.0 * (m * (n + 7) + ne * 32) * B),
     }
+    if prof.get("k_dense_riccati", (0, 0.0))[0]:
+        # dense backend: k_propagate only steps the group / scalar state there, Sigma is moved by the GEMMs
+        del algo["k_propagate"]
     rows = []
     for name, (cnt, ms) in prof.items():
         if cnt == 0:
