@@ -73,7 +73,11 @@ typedef struct eqf_filter eqf_filter; /* opaque */
 int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, int device, int precision,
     eqf_filter** out);
 void eqf_destroy(eqf_filter* f);
-/* VIOFilter::reset() (VIOFilter.cpp:84-91). */
+/* Back to the freshly constructed state (every filter of the batch): no landmarks, identity group element, Sigma and
+ * bias from the settings, not initialised, time -1.  Takes the place of VIOFilter::reset() (VIOFilter.cpp:84-91), which
+ * no caller in the reference uses and which is deliberately NOT reproduced literally: it also forgets xi0.cameraOffset,
+ * sets Sigma to the 11x11 identity and keeps initialisedFlag / inputBias -- with a level identity pose its next Riccati
+ * step throws from SO3FromVectors (SO3.cpp:160). */
 int eqf_reset(eqf_filter* f);
 
 /* VIOFilter::processIMUData (VIOFilter.cpp:120-131).  stamps[batch], omega[batch][3], accel[batch][3].

@@ -163,6 +163,34 @@ def test_ragged_batch_with_churn_and_outlier_gate(oracle_lib, hip):
     assert fg.device_error() == 0
 
 
+def test_reset_returns_to_the_constructed_state(hip):
+    """eqf_reset: a handle that has run (landmarks, churned Sigma, advanced time) and is reset behaves bitwise like a
+    fresh one."""
+    from eqf_vio_amd import synth
+
+    N = 30
+    st = synth.make_stream(N, duration=0.4)
+    d = synth.template_settings_dict()
+
+    def run(f):
+        for kind, k in st.events():
+            if kind == "imu":
+                r = st.imu[k]
+                f.process_imu([r[0]], r[1:4], r[4:7])
+            else:
+                f.process_vision([st.vision_stamps[k]], st.ids, st.bearings[k])
+        return f.sigma(), f.state_estimate(), f.bias()
+
+    a = hip.FilterBatch(d, capacity=N, batch=1)
+    first = run(a)
+    a.reset()
+    assert a.num_landmarks() == 0 and a.get_time()[0] == -1.0 and a.sigma().shape == (11, 11)
+    second = run(a)
+    assert np.array_equal(first[0], second[0]) and np.array_equal(first[2], second[2])
+    assert all(np.array_equal(first[1][k], second[1][k]) for k in first[1])
+    assert a.device_error() == 0
+
+
 def test_stream_mode_equals_per_call_mode(hip):
     """eqf_stream_* (inputs resident in HBM, what bench.py times) is the same computation as the per-call API."""
     from eqf_vio_amd import synth
