@@ -39,6 +39,15 @@ struct ProfPair {
 };
 }  // namespace
 
+// Ring of pinned int buffers for the small host->device uploads of the landmark bookkeeping (permutation, compaction map,
+// sources of new landmarks): the host never has to drain the stream before reusing a staging buffer.
+struct IntStage {
+    static constexpr int kSlots = 8;
+    int* host[kSlots] = {};
+    hipEvent_t ev[kSlots] = {};
+    int next = 0;
+};
+
 struct eqf_filter {
     int B = 0, cap = 0, device = 0, precision = 0;
     size_t esz = 8;
@@ -63,8 +72,9 @@ struct eqf_filter {
     // churn scratch
     int *dMap = nullptr, *dNewN = nullptr, *dPerm = nullptr, *dSrc = nullptr;
     double *dChord = nullptr, *dDepth2 = nullptr, *dScratch = nullptr, *dMeas = nullptr, *dOut = nullptr;
-    int *hMap = nullptr, *hNewN = nullptr, *hPerm = nullptr, *hSrc = nullptr;  // pinned
-    double *hChord = nullptr, *hDepth2 = nullptr, *hMeas = nullptr, *hOut = nullptr;
+    IntStage stMap, stPerm, stSrc;  // pinned rings: [B*cap + B] (map + new counts), [B*cap], [cap]
+    double* dDepthSel = nullptr;    // [B] median scene depth selected on the device
+    double *hChord = nullptr, *hMeas = nullptr, *hOut = nullptr;
     hipEvent_t evMeas = nullptr;
     // input ring for per-call records (batch > 1)
     ImuRec* dRing = nullptr;
@@ -150,6 +160,29 @@ int dmalloc(T** p, size_t count) {
 template <typename T>
 int hmalloc(T** p, size_t count) {
     HIPC(hipHostMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault));
+    return EQF_OK;
+}
+
+int stageInit(IntStage& s, size_t count) {
+    for (int i = 0; i < IntStage::kSlots; ++i) {
+        int rc = hmalloc(&s.host[i], count);
+        if (rc) return rc;
+        HIPC(hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming));
+    }
+    return EQF_OK;
+}
+void stageFree(IntStage& s) {
+    for (int i = 0; i < IntStage::kSlots; ++i) {
+        if (s.host[i]) hipHostFree(s.host[i]);
+        if (s.ev[i]) hipEventDestroy(s.ev[i]);
+    }
+}
+// next free staging buffer (waits only if its previous upload, 8 uploads ago, is still in flight)
+int stageAcquire(IntStage& s, int** host, int* slot) {
+    *slot = s.next;
+    s.next = (s.next + 1) % IntStage::kSlots;
+    HIPC(hipEventSynchronize(s.ev[*slot]));
+    *host = s.host[*slot];
     return EQF_OK;
 }
 
@@ -501,15 +534,19 @@ int launchUpdate(eqf_filter* f, const double* bearings, long long bearStride, co
 // Batch-wide compaction with host keep-lists keep[b] = old indices that survive (ascending).
 int compact(eqf_filter* f, const std::vector<std::vector<int>>& keep) {
     const int B = f->B, cap = f->cap;
-    HIPC(hipStreamSynchronize(f->stream));  // pinned staging reuse
+    int* h = nullptr;
+    int slot = 0;
+    int rcs = stageAcquire(f->stMap, &h, &slot);
+    if (rcs) return rcs;
     int nmax = 0;
     for (int b = 0; b < B; ++b) {
-        f->hNewN[b] = int(keep[b].size());
-        nmax = std::max(nmax, f->hNewN[b]);
-        std::copy(keep[b].begin(), keep[b].end(), f->hMap + (size_t)b * cap);
+        h[(size_t)B * cap + b] = int(keep[b].size());
+        nmax = std::max(nmax, int(keep[b].size()));
+        std::copy(keep[b].begin(), keep[b].end(), h + (size_t)b * cap);
     }
-    HIPC(hipMemcpyAsync(f->dMap, f->hMap, sizeof(int) * B * cap, hipMemcpyHostToDevice, f->stream));
-    HIPC(hipMemcpyAsync(f->dNewN, f->hNewN, sizeof(int) * B, hipMemcpyHostToDevice, f->stream));
+    HIPC(hipMemcpyAsync(f->dMap, h, sizeof(int) * B * cap, hipMemcpyHostToDevice, f->stream));
+    HIPC(hipMemcpyAsync(f->dNewN, h + (size_t)B * cap, sizeof(int) * B, hipMemcpyHostToDevice, f->stream));
+    HIPC(hipEventRecord(f->stMap.ev[slot], f->stream));
     const int nvn = kLm0 + 3 * nmax;
     int rc = profiled(f, EQF_PROF_CHURN, [&] {
         const dim3 grid((nvn + 255) / 256, nvn, B);
@@ -531,16 +568,22 @@ int compact(eqf_filter* f, const std::vector<std::vector<int>>& keep) {
 // perm[b][i] = index into the measurement of state landmark i (or -1)
 int uploadPerm(eqf_filter* f, const std::vector<std::vector<int>>& perm) {
     const int B = f->B, cap = f->cap;
-    HIPC(hipStreamSynchronize(f->stream));
+    int* h = nullptr;
+    int slot = 0;
+    int rc = stageAcquire(f->stPerm, &h, &slot);
+    if (rc) return rc;
     for (int b = 0; b < B; ++b) {
-        std::fill(f->hPerm + (size_t)b * cap, f->hPerm + (size_t)(b + 1) * cap, -1);
-        std::copy(perm[b].begin(), perm[b].end(), f->hPerm + (size_t)b * cap);
+        std::fill(h + (size_t)b * cap, h + (size_t)(b + 1) * cap, -1);
+        std::copy(perm[b].begin(), perm[b].end(), h + (size_t)b * cap);
     }
-    HIPC(hipMemcpyAsync(f->dPerm, f->hPerm, sizeof(int) * B * cap, hipMemcpyHostToDevice, f->stream));
+    HIPC(hipMemcpyAsync(f->dPerm, h, sizeof(int) * B * cap, hipMemcpyHostToDevice, f->stream));
+    HIPC(hipEventRecord(f->stPerm.ev[slot], f->stream));
     return EQF_OK;
 }
 
-int probe(eqf_filter* f, const double* bearings, long long bearStride, bool withPerm) {
+// chord errors (when bearings are given) and squared depths of every landmark of the current estimate -> dChord, dDepth2;
+// readback = true also copies them to the host and waits (only the outlier gate needs that: the host owns the ids)
+int probe(eqf_filter* f, const double* bearings, long long bearStride, bool withPerm, bool readback) {
     const int B = f->B, cap = f->cap;
     const int nmax = std::max(1, maxN(f));
     int rc = profiled(f, EQF_PROF_CHURN, [&] {
@@ -548,9 +591,10 @@ int probe(eqf_filter* f, const double* bearings, long long bearStride, bool with
             bearStride, withPerm ? f->dPerm : nullptr, f->dChord, f->dDepth2);
     });
     if (rc) return rc;
-    HIPC(hipMemcpyAsync(f->hChord, f->dChord, sizeof(double) * B * cap, hipMemcpyDeviceToHost, f->stream));
-    HIPC(hipMemcpyAsync(f->hDepth2, f->dDepth2, sizeof(double) * B * cap, hipMemcpyDeviceToHost, f->stream));
-    HIPC(hipStreamSynchronize(f->stream));
+    if (readback) {
+        HIPC(hipMemcpyAsync(f->hChord, f->dChord, sizeof(double) * B * cap, hipMemcpyDeviceToHost, f->stream));
+        HIPC(hipStreamSynchronize(f->stream));
+    }
     return EQF_OK;
 }
 
@@ -603,7 +647,7 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
     if (f->set.outlierThreshold < 2.0 && maxN(f) > 0) {
         int rc = uploadPerm(f, perm);
         if (rc) return rc;
-        rc = probe(f, bearings, bearStride, true);
+        rc = probe(f, bearings, bearStride, true, true);
         if (rc) return rc;
         bool anyOut = false;
         for (int b = 0; b < B; ++b) {
@@ -644,32 +688,36 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
         }
     }
     if (needDepth) {
-        int rc = probe(f, nullptr, 0, false);
+        // squared depths of the current estimate and their median, both on the device: adding landmarks needs no readback
+        int rc = probe(f, nullptr, 0, false, false);
+        if (rc) return rc;
+        const int nmx = std::max(1, maxN(f));
+        rc = profiled(f, EQF_PROF_CHURN, [&] {
+            hipLaunchKernelGGL(k_median_depth, dim3((nmx + 255) / 256, B), dim3(256), 0, f->stream, f->g[f->pG], f->dDepth2, cap, f->dDepthSel);
+        });
         if (rc) return rc;
     }
     for (int b = 0; b < B; ++b) {
         if (fresh[b].empty()) continue;
         const int nOld = int(f->ids[b].size()), nNew = int(fresh[b].size());
-        double depth = f->set.initialSceneDepth;
-        if (nOld > 0) {  // sqrt of the size/2-th order statistic of the squared depths (:357-366)
-            std::vector<double> d2(f->hDepth2 + (size_t)b * cap, f->hDepth2 + (size_t)b * cap + nOld);
-            std::nth_element(d2.begin(), d2.begin() + d2.size() / 2, d2.end());
-            depth = std::pow(d2[d2.size() / 2], 0.5);
-        }
-        HIPC(hipStreamSynchronize(f->stream));
-        std::copy(fresh[b].begin(), fresh[b].end(), f->hSrc);
-        HIPC(hipMemcpyAsync(f->dSrc, f->hSrc, sizeof(int) * nNew, hipMemcpyHostToDevice, f->stream));
+        int* h = nullptr;
+        int slot = 0;
+        int rc = stageAcquire(f->stSrc, &h, &slot);
+        if (rc) return rc;
+        std::copy(fresh[b].begin(), fresh[b].end(), h);
+        HIPC(hipMemcpyAsync(f->dSrc, h, sizeof(int) * nNew, hipMemcpyHostToDevice, f->stream));
+        HIPC(hipEventRecord(f->stSrc.ev[slot], f->stream));
         const long long work = (long long)3 * nNew * (kLm0 + 3 * (nOld + nNew)) * 2;
         const int blocks = int(std::min<long long>(1024, (work + 255) / 256));
-        int rc = profiled(f, EQF_PROF_CHURN, [&] {
+        rc = profiled(f, EQF_PROF_CHURN, [&] {
             if (f->precision == EQF_PRECISION_F32)
-                hipLaunchKernelGGL(k_append<float>, dim3(std::max(1, blocks)), dim3(256), 0, f->stream, f->g[f->pG], b, nOld, nNew, depth,
-                    f->set.initialPointVariance, cap, bearings + (long long)b * bearStride, f->dSrc, f->p0, f->Q[f->pG], f->lmc, f->errflag,
-                    static_cast<float*>(f->Sigma[f->pS]), f->sigmaStride, f->ld);
+                hipLaunchKernelGGL(k_append<float>, dim3(std::max(1, blocks)), dim3(256), 0, f->stream, f->g[f->pG], b, nOld, nNew, f->dDepthSel,
+                    f->set.initialSceneDepth, f->set.initialPointVariance, cap, bearings + (long long)b * bearStride, f->dSrc, f->p0,
+                    f->Q[f->pG], f->lmc, f->errflag, static_cast<float*>(f->Sigma[f->pS]), f->sigmaStride, f->ld);
             else
-                hipLaunchKernelGGL(k_append<double>, dim3(std::max(1, blocks)), dim3(256), 0, f->stream, f->g[f->pG], b, nOld, nNew, depth,
-                    f->set.initialPointVariance, cap, bearings + (long long)b * bearStride, f->dSrc, f->p0, f->Q[f->pG], f->lmc, f->errflag,
-                    static_cast<double*>(f->Sigma[f->pS]), f->sigmaStride, f->ld);
+                hipLaunchKernelGGL(k_append<double>, dim3(std::max(1, blocks)), dim3(256), 0, f->stream, f->g[f->pG], b, nOld, nNew, f->dDepthSel,
+                    f->set.initialSceneDepth, f->set.initialPointVariance, cap, bearings + (long long)b * bearStride, f->dSrc, f->p0,
+                    f->Q[f->pG], f->lmc, f->errflag, static_cast<double*>(f->Sigma[f->pS]), f->sigmaStride, f->ld);
         });
         if (rc) return rc;
         HIPC(hipGetLastError());
@@ -707,10 +755,13 @@ void freeAll(eqf_filter* f) {
     }
     for (void* p : {(void*)f->p0, (void*)f->lmc, (void*)f->SA, (void*)f->SL, (void*)f->YW, (void*)f->YO, (void*)f->EA, (void*)f->EL, (void*)f->ZW,
              (void*)f->ZO, (void*)f->dbgDelta, (void*)f->dbgGamma, (void*)f->dbgGammaTot, (void*)f->red, (void*)f->errflag, (void*)f->dMap,
-             (void*)f->dNewN, (void*)f->dPerm, (void*)f->dSrc, (void*)f->dChord, (void*)f->dDepth2, (void*)f->dScratch, (void*)f->dMeas,
+             (void*)f->dNewN, (void*)f->dPerm, (void*)f->dSrc, (void*)f->dChord, (void*)f->dDepth2, (void*)f->dDepthSel, (void*)f->dScratch, (void*)f->dMeas,
              (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn, f->dBlk, (void*)f->dBlkCommon})
         hipFree(p);
-    for (void* p : {(void*)f->hMap, (void*)f->hNewN, (void*)f->hPerm, (void*)f->hSrc, (void*)f->hChord, (void*)f->hDepth2, (void*)f->hMeas,
+    stageFree(f->stMap);
+    stageFree(f->stPerm);
+    stageFree(f->stSrc);
+    for (void* p : {(void*)f->hChord, (void*)f->hMeas,
              (void*)f->hOut, (void*)f->hRing})
         if (p) hipHostFree(p);
     for (auto& e : f->evRing)
@@ -845,8 +896,8 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (const char* e = std::getenv("EQF_CHOL_MODE")) f->cholMode = std::strcmp(e, "32inv") == 0 ? 33 : (std::strcmp(e, "32") == 0 ? 32 : 64);
     if (const char* e = std::getenv("EQF_CHOL_EMBED")) f->cholEmbed = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_SPLIT")) f->cholSplit = std::atoi(e);
-    chk(hmalloc(&f->hMap, (size_t)cap * B)); chk(hmalloc(&f->hNewN, B)); chk(hmalloc(&f->hPerm, (size_t)cap * B));
-    chk(hmalloc(&f->hSrc, cap)); chk(hmalloc(&f->hChord, (size_t)cap * B)); chk(hmalloc(&f->hDepth2, (size_t)cap * B));
+    chk(stageInit(f->stMap, (size_t)cap * B + B)); chk(stageInit(f->stPerm, (size_t)cap * B)); chk(stageInit(f->stSrc, cap));
+    chk(hmalloc(&f->hChord, (size_t)cap * B)); chk(dmalloc(&f->dDepthSel, B));
     chk(hmalloc(&f->hMeas, (size_t)3 * cap * B)); chk(hmalloc(&f->hOut, (size_t)f->nTot * f->nTot + 16));
     chk(hmalloc(&f->hRing, (size_t)kRing * B));
     if (!rc) {

@@ -34,6 +34,20 @@ __global__ void k_probe(const Glob* g, const double* p0, const double* Q, int ca
     chord[(long long)b * cap + i] = ch;
 }
 
+// Median scene depth for addNewLandmarks (VIOFilter.cpp:357-366): sqrt of the (N/2)-th order statistic of the squared
+// depths k_probe wrote -- by rank counting, on the device, so that adding landmarks needs no readback.
+__global__ void k_median_depth(const Glob* g, const double* depth2, int cap, double* sel) {
+    const int b = blockIdx.y;
+    const int N = g[b].N;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double* d = depth2 + (long long)b * cap;
+    const double di = d[i];
+    int rank = 0;
+    for (int j = 0; j < N; ++j) rank += (d[j] < di) || (d[j] == di && j < i);
+    if (rank == N / 2) sel[b] = sqrt(di);
+}
+
 // Remove landmarks: Sigma_out = Sigma_in with the rows/cols of dropped landmarks erased, map[b][newI] = oldI.
 // Filters without removals pass the identity map (the ping-pong parity is shared by the whole batch).
 template <typename T>
@@ -78,12 +92,13 @@ __global__ void k_compact_lm_scatter(Glob* g, const int* newN, int cap, double* 
 
 // Append landmarks to filter b: p0 = bearing * depth, Q = identity, Sigma grows with zero cross terms and
 // initialPointVariance on the new diagonal (VIOFilter.cpp:367-390).  src[j] = index of the bearing of the
-// j-th new landmark.
+// j-th new landmark; depthSel[b] = k_median_depth's result.
 template <typename T>
-__global__ __launch_bounds__(256) void k_append(Glob* g, int b, int nOld, int nNew, double depth, double pointVar, int cap,
+__global__ __launch_bounds__(256) void k_append(Glob* g, int b, int nOld, int nNew, const double* depthSel, double depthDefault, double pointVar, int cap,
     const double* bearings /* filter b */, const int* src, double* p0, double* Q, double* lmc, int* errflag, T* S, long long sigmaStride,
     int ld) {
     const int nvo = kLm0 + 3 * nOld, nvn = kLm0 + 3 * (nOld + nNew);
+    const double depth = nOld > 0 ? depthSel[b] : depthDefault;  // median of the current estimate, or initialSceneDepth (:361-366)
     T* Sb = S + (long long)b * sigmaStride;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     // new rows (all columns) and new columns (old rows)
