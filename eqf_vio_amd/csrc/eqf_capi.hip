@@ -75,6 +75,7 @@ struct eqf_filter {
     IntStage stMap, stPerm, stSrc;  // pinned rings: [B*cap + B] (map + new counts), [B*cap], [cap]
     double* dDepthSel = nullptr;    // [B] median scene depth selected on the device
     double *hChord = nullptr, *hMeas = nullptr, *hOut = nullptr;
+    double* hChordDev = nullptr;  // device-side address of the pinned hChord
     hipEvent_t evMeas = nullptr;
     // input ring for per-call records (batch > 1)
     ImuRec* dRing = nullptr;
@@ -586,15 +587,14 @@ int uploadPerm(eqf_filter* f, const std::vector<std::vector<int>>& perm) {
 int probe(eqf_filter* f, const double* bearings, long long bearStride, bool withPerm, bool readback) {
     const int B = f->B, cap = f->cap;
     const int nmax = std::max(1, maxN(f));
+    // with readback the kernel writes the chords straight into pinned host memory (no copy command behind it)
+    double* chordDst = readback ? f->hChordDev : f->dChord;
     int rc = profiled(f, EQF_PROF_CHURN, [&] {
         hipLaunchKernelGGL(k_probe, dim3((nmax + 127) / 128, B), dim3(128), 0, f->stream, f->g[f->pG], f->p0, f->Q[f->pG], cap, bearings,
-            bearStride, withPerm ? f->dPerm : nullptr, f->dChord, f->dDepth2);
+            bearStride, withPerm ? f->dPerm : nullptr, chordDst, f->dDepth2);
     });
     if (rc) return rc;
-    if (readback) {
-        HIPC(hipMemcpyAsync(f->hChord, f->dChord, sizeof(double) * B * cap, hipMemcpyDeviceToHost, f->stream));
-        HIPC(hipStreamSynchronize(f->stream));
-    }
+    if (readback) HIPC(hipStreamSynchronize(f->stream));
     return EQF_OK;
 }
 
@@ -645,9 +645,16 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
     std::vector<std::vector<char>> dropped(B);  // measurement indices erased together with their landmark
     for (int b = 0; b < B; ++b) dropped[b].assign(nb[b], 0);
     if (f->set.outlierThreshold < 2.0 && maxN(f) > 0) {
-        int rc = uploadPerm(f, perm);
+        bool identityPerm = true;
+        for (int b = 0; b < B && identityPerm; ++b)
+            for (size_t i = 0; i < perm[b].size(); ++i)
+                if (perm[b][i] != int(i)) {
+                    identityPerm = false;
+                    break;
+                }
+        int rc = identityPerm ? EQF_OK : uploadPerm(f, perm);
         if (rc) return rc;
-        rc = probe(f, bearings, bearStride, true, true);
+        rc = probe(f, bearings, bearStride, !identityPerm, true);
         if (rc) return rc;
         bool anyOut = false;
         for (int b = 0; b < B; ++b) {
@@ -898,6 +905,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (const char* e = std::getenv("EQF_CHOL_SPLIT")) f->cholSplit = std::atoi(e);
     chk(stageInit(f->stMap, (size_t)cap * B + B)); chk(stageInit(f->stPerm, (size_t)cap * B)); chk(stageInit(f->stSrc, cap));
     chk(hmalloc(&f->hChord, (size_t)cap * B)); chk(dmalloc(&f->dDepthSel, B));
+    if (!rc && hipHostGetDevicePointer(reinterpret_cast<void**>(&f->hChordDev), f->hChord, 0) != hipSuccess) rc = EQF_ERR_HIP;
     chk(hmalloc(&f->hMeas, (size_t)3 * cap * B)); chk(hmalloc(&f->hOut, (size_t)f->nTot * f->nTot + 16));
     chk(hmalloc(&f->hRing, (size_t)kRing * B));
     if (!rc) {
