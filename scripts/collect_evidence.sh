@@ -16,7 +16,7 @@ stats() {  # stats <name> <bench args...>: rocprofv3 kernel-trace summary of one
   f=$(find /tmp/prof_$name -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/${TAG}_${name}_kernel_stats.csv"
 }
-pmc() {  # pmc <name> <counter> <bench args...>: per-kernel mean of one PMC counter (KiB), its own pass
+pmc() {  # pmc <name> <counter> <bench args...>: per-kernel mean of one PMC counter (FETCH/WRITE_SIZE: KiB), its own pass
   local name=$1 counter=$2; shift 2
   rm -rf /tmp/pmc_$name
   timeout 600 rocprofv3 --pmc $counter --kernel-trace --output-format csv -d /tmp/pmc_$name -o b -- $PY $ROOT/bench.py "$@" --pmc-child > /dev/null 2>&1
@@ -28,7 +28,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     rows[r["Kernel_Name"]].append(float(r["Counter_Value"]))
 with open(sys.argv[2], "w") as f:
     w = csv.writer(f)
-    w.writerow(["Kernel_Name", "Calls", "Mean_KiB", "Median_KiB", "Max_KiB"])
+    w.writerow(["Kernel_Name", "Calls", "Mean", "Median", "Max"])  # FETCH_SIZE / WRITE_SIZE: KiB per launch; cycle counters: summed over the chip
     for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
         w.writerow([k, len(v), round(statistics.mean(v), 2), round(statistics.median(v), 2), round(max(v), 2)])
 PYEOF
@@ -46,6 +46,11 @@ timeout 900 $PY $ROOT/bench.py --filters-per-gpu 8 --steps 880 --warmup 110 --no
 # 3. N = 1000: structured kernel and the dense MFMA Riccati backend (cfg 3)
 timeout 900 $PY $ROOT/bench.py --landmarks 1000 --steps 220 --warmup 55 --no-cpu-baseline --no-traffic > "$OUT/${TAG}_bench_N1000.json" 2>/dev/null
 timeout 900 $PY $ROOT/bench.py --landmarks 1000 --steps 110 --warmup 22 --dense-propagate --no-cpu-baseline --no-traffic > "$OUT/${TAG}_bench_N1000_dense.json" 2>/dev/null
+# 3b. MFMA busy cycles next to the GPU-active cycles for the N = 1000 runs (structured path and dense Riccati), separate passes
+pmc bench_N1000 SQ_VALU_MFMA_BUSY_CYCLES --landmarks 1000 --steps 44 --warmup 11
+pmc bench_N1000 GRBM_GUI_ACTIVE --landmarks 1000 --steps 44 --warmup 11
+pmc bench_N1000_dense SQ_VALU_MFMA_BUSY_CYCLES --landmarks 1000 --steps 22 --warmup 11 --dense-propagate
+pmc bench_N1000_dense GRBM_GUI_ACTIVE --landmarks 1000 --steps 22 --warmup 11 --dense-propagate
 # 4. N = 4000 (Sigma = 1.15 GB)
 timeout 900 $PY $ROOT/bench.py --landmarks 4000 --steps 22 --warmup 11 --no-cpu-baseline --no-traffic > "$OUT/${TAG}_bench_N4000.json" 2>/dev/null
 # 4b. the same two sizes on the older 32-wide factorisation path, where the covariance downdate is a launch of its own
