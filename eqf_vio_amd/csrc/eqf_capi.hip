@@ -322,19 +322,18 @@ int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, con
     rc = profiled(f, EQF_PROF_PROPAGATE, [&] {
         if (split) {
             const dim3 bgrid((std::max(1, maxN(f)) + 63) / 64, f->B);
-            // builder (blocks + G rows + group step), then the landmark x landmark blocks by the lean streaming kernel and the
-            // base rows / columns by the tile kernel restricted to its last tile row / column (+ the base-block workgroup)
+            // builder (blocks + G rows + group step + scalar state), then everything of Sigma by the lean streaming kernel
+            // (EQF_STREAM_PROPAGATE=0: by the tile kernel instead -- kept as a cross-check)
             const int nmx = std::max(1, maxN(f));
             const dim3 sgrid((nmx + 255) / 256, (nmx + kStreamRows - 1) / kStreamRows, f->B);
-            a.tailsOnly = f->streamPropagate ? 1 : 0;
             if (f->precision == EQF_PRECISION_F32) {
                 hipLaunchKernelGGL(k_build_blocks<float>, bgrid, dim3(64), 0, f->stream, a);
-                if (a.tailsOnly) hipLaunchKernelGGL(k_riccati_stream<float>, sgrid, block, 0, f->stream, a);
-                hipLaunchKernelGGL((k_propagate<float, true>), grid, block, 0, f->stream, a);
+                if (f->streamPropagate) hipLaunchKernelGGL(k_riccati_stream<float>, sgrid, block, 0, f->stream, a);
+                else hipLaunchKernelGGL((k_propagate<float, true>), grid, block, 0, f->stream, a);
             } else {
                 hipLaunchKernelGGL(k_build_blocks<double>, bgrid, dim3(64), 0, f->stream, a);
-                if (a.tailsOnly) hipLaunchKernelGGL(k_riccati_stream<double>, sgrid, block, 0, f->stream, a);
-                hipLaunchKernelGGL((k_propagate<double, true>), grid, block, 0, f->stream, a);
+                if (f->streamPropagate) hipLaunchKernelGGL(k_riccati_stream<double>, sgrid, block, 0, f->stream, a);
+                else hipLaunchKernelGGL((k_propagate<double, true>), grid, block, 0, f->stream, a);
             }
         } else if (f->precision == EQF_PRECISION_F32) {
             hipLaunchKernelGGL((k_propagate<float, false>), grid, block, 0, f->stream, a);

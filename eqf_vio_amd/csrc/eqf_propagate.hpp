@@ -48,7 +48,6 @@ struct PropArgs {
     void* blk;          // [B][cap][27] (T) per-landmark blocks D, Lw, Lv written by k_build_blocks (split path)
     CommonLds* blkCommon;  // [B] common values written by k_build_blocks
     int sigmaExternal;  // the Riccati step of this call is done by the dense MFMA backend: touch no Sigma here
-    int tailsOnly;      // streaming path: the landmark x landmark blocks belong to k_riccati_stream; only the base rows / columns here
     Params prm;
 };
 
@@ -273,7 +272,6 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     const bool isExtra = (int)blockIdx.x == a.NT * a.NT;
     const int ti = isExtra ? 0 : blockIdx.x / a.NT, tj = isExtra ? 0 : blockIdx.x % a.NT;
     const int lastT = a.NT - 1;
-    if (PRE && a.tailsOnly && !isExtra && ti != lastT && tj != lastT) return;
     const int cap = a.cap, ld = a.ld;
 
     __shared__ T sD[32][9], sLw[32][9], sLv[32][9];  // [0,16): row landmarks I, [16,32): column landmarks J
@@ -434,7 +432,7 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     // this thread's own 3x3 block of Sigma: issue the loads before the barrier
     const int bi = tid >> 4, bj = tid & 15;
     const int BI = I0 + bi, BJ = J0 + bj;
-    const bool blockValid = !isExtra && BI < N && BJ < N && !(PRE && a.tailsOnly);
+    const bool blockValid = !isExtra && BI < N && BJ < N;
     T S[9];
     if (blockValid) {
         const T* src = Sin + (long long)(kLm0 + 3 * BI) * ld + kLm0 + 3 * BJ;
@@ -695,7 +693,8 @@ __global__ __launch_bounds__(64) void k_build_blocks(PropArgs a) {
 // 9 stores, 162 FMAs and a handful of address instructions -- k_propagate's tile code spends ~1500 instructions on the
 // same block (staging loops, integer divisions, 64-bit address arithmetic) and is issue-bound, not memory-bound.
 // grid = (column strips of 256 landmarks, ceil(N / kStreamRows), B), block = 256 (4 waves = 4 strips of 64 columns).
-// The base rows / columns come from k_propagate<T, true> with tailsOnly = 1; blocks and G rows from k_build_blocks.
+// The workgroups of the first row chunk also write the base rows / columns of their column landmarks (and the 11 x 11 base
+// block); blocks and G rows come from k_build_blocks.  The split path is these two launches.
 // ------------------------------------------------------------------------------------------------
 constexpr int kStreamRows = 16;
 template <typename T>
@@ -710,22 +709,33 @@ __global__ __launch_bounds__(256) void k_riccati_stream(PropArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int I0 = blockIdx.y * kStreamRows;
     const int J = (4 * blockIdx.x + wv) * 64 + lane;
-    if (I0 >= N) return;
+    if (I0 >= N && blockIdx.y != 0) return;  // (the first row chunk also owns the base block: it runs even without landmarks)
     const int ld = a.ld;
     const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
     T* Sout = static_cast<T*>(a.Sout) + (long long)b * a.sigmaStride;
-    const int nI = min(kStreamRows, N - I0);
+    const int nI = max(0, min(kStreamRows, N - I0));
     const bool validJ = J < N;
     const T* colIn = Sin + kLm0 + 3 * (validJ ? J : 0);
     T* colOut = Sout + kLm0 + 3 * (validJ ? J : 0);
     if (!riccati) {
         if (a.sigmaExternal && step && a.doRiccati) return;  // Sigma_out was written by k_dense_gemm
-        if (validJ)
+        // Sigma is not touched by this call: copy through (the ping-pong parity of the batch stays in step)
+        if (validJ) {
             for (int i = 0; i < 3 * nI; ++i) {
                 const long long ro = (long long)(kLm0 + 3 * I0 + i) * ld;
 #pragma unroll
                 for (int cc = 0; cc < 3; ++cc) colOut[ro + cc] = colIn[ro + cc];
             }
+            if (blockIdx.y == 0) {
+                for (int cc = 0; cc < 12; ++cc)
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr) {
+                        colOut[(long long)cc * ld + rr] = colIn[(long long)cc * ld + rr];
+                        Sout[(long long)(kLm0 + 3 * J + rr) * ld + cc] = Sin[(long long)(kLm0 + 3 * J + rr) * ld + cc];
+                    }
+            }
+        }
+        if (blockIdx.y == 0 && blockIdx.x == 0 && tid < 144) Sout[(long long)(tid / 12) * ld + tid % 12] = Sin[(long long)(tid / 12) * ld + tid % 12];
         return;
     }
     __shared__ T sRow[kStreamRows][kBlkRec];
@@ -750,6 +760,107 @@ __global__ __launch_bounds__(256) void k_riccati_stream(PropArgs a) {
             }
     }
     const T TtP = (T)a.blkCommon[b].T * (T)a.prm.pointProcessVariance;
+    if (blockIdx.y == 0) {
+        // ---- the first row chunk also owns the base rows / columns of its column landmarks (and, its first workgroup,
+        // the 11 x 11 base block):  Sigma'_bJ = F_bb (Sigma_bb L_J^T + Sigma_bJ D_J^T) - sigma_w^2 Nb Lw_J^T, and
+        // Sigma'_Jb is written as its transpose (the tile kernel evaluates G_J F_bb^T: the same number up to rounding).
+        __shared__ T sF[11][12], sNb[11][3], sSbb[11][12], sTb[11][12];
+        __shared__ CommonLds sC;
+        if (tid == 0) sC = a.blkCommon[b];
+        if (tid < 132) {
+            const int rr = tid / 12, cc = tid % 12;
+            sSbb[rr][cc] = (cc < 11) ? Sin[(long long)rr * ld + cc] : (T)0;
+        }
+        __syncthreads();
+        if (tid < 132) {
+            const int rr = tid / 12, cc = tid % 12;
+            // F_bb = I + T * [[0,0,0,0],[-B_g^w,0,0,0],[-B_v^w,-R_A, A_vg, 0]]   (VIOFilter.cpp:178-183)
+            double f = (rr == cc) ? 1.0 : 0.0;
+            if (rr >= 6 && rr < 8 && cc < 3) f = -sC.T * sC.Bg[3 * (rr - 6) + cc];
+            if (rr >= 8) {
+                if (cc < 3) f = -sC.T * sC.Bvw[3 * (rr - 8) + cc];
+                else if (cc < 6) f = -sC.T * sC.RA[3 * (rr - 8) + cc - 3];
+                else if (cc < 8) f = sC.T * sC.Avg[2 * (rr - 8) + cc - 6];
+            }
+            sF[rr][cc] = (cc < 11) ? (T)f : (T)0;
+            if (cc < 3) {
+                double nb = 0.0;
+                if (rr >= 6 && rr < 8) nb = sC.Bg[3 * (rr - 6) + cc];
+                if (rr >= 8) nb = sC.Bvw[3 * (rr - 8) + cc];
+                sNb[rr][cc] = (T)nb;
+            }
+        }
+        __syncthreads();
+        const T sw2 = (T)a.prm.velOmegaVariance, sa2 = (T)a.prm.velAccelVariance, Tt = (T)sC.T;
+        if (validJ) {
+            T Gt[11][3];  // Sigma_bb L_J^T + Sigma_bJ D_J^T
+#pragma unroll
+            for (int cc = 0; cc < 11; ++cc) {
+                T sb[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    sb[k] = (cc < 3) ? SwJ[3 * cc + k] : ((cc >= 8) ? SvJ[3 * (cc - 8) + k] : colIn[(long long)cc * ld + k]);
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) {
+                    T acc = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        acc += sSbb[cc][k] * LwJ[3 * rr + k] + sSbb[cc][8 + k] * LvJ[3 * rr + k] + sb[k] * DJ[3 * rr + k];
+                    Gt[cc][rr] = acc;
+                }
+            }
+#pragma unroll
+            for (int cc = 0; cc < 11; ++cc)
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) {
+                    T acc = 0;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) acc += sF[cc][k] * Gt[k][rr];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc -= sw2 * sNb[cc][k] * LwJ[3 * rr + k];
+                    colOut[(long long)cc * ld + rr] = acc;                                       // Sigma'_bJ
+                    Sout[(long long)(kLm0 + 3 * J + rr) * ld + cc] = acc;                        // Sigma'_Jb
+                }
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {  // the structural pad row / column 11
+                colOut[(long long)11 * ld + rr] = (T)0;
+                Sout[(long long)(kLm0 + 3 * J + rr) * ld + 11] = (T)0;
+            }
+        }
+        if (blockIdx.x == 0) {
+            // Sigma'_bb = F_bb Sigma_bb F_bb^T + T (P_bb + B_b R B_b^T)
+            if (tid < 121) {
+                const int rr = tid / 11, cc = tid % 11;
+                T acc = 0;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) acc += sF[rr][k] * sSbb[k][cc];
+                sTb[rr][cc] = acc;
+            }
+            __syncthreads();
+            if (tid < 144) {
+                const int rr = tid / 12, cc = tid % 12;
+                T acc = 0;
+                if (rr < 11 && cc < 11) {
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) acc += sTb[rr][k] * sF[cc][k];
+                    T nz = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) nz += sw2 * sNb[rr][k] * sNb[cc][k];
+                    if (rr >= 8 && cc >= 8) {  // accel columns of B: rows 8:11 hold R_A
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) nz += sa2 * (T)sC.RA[3 * (rr - 8) + k] * (T)sC.RA[3 * (cc - 8) + k];
+                    }
+                    if (rr == cc) {
+                        const Params& p = a.prm;
+                        nz += (T)(rr < 3 ? p.biasOmegaProcessVariance
+                                         : (rr < 6 ? p.biasAccelProcessVariance : (rr < 8 ? p.gravityProcessVariance : p.velocityProcessVariance)));
+                    }
+                    acc += Tt * nz;
+                }
+                Sout[(long long)rr * ld + cc] = acc;  // row/col 11 stay zero
+            }
+        }
+    }
     T S[9];
     auto fetch = [&](int i) {
         const long long ro = (long long)(kLm0 + 3 * (I0 + i)) * ld;
@@ -758,7 +869,7 @@ __global__ __launch_bounds__(256) void k_riccati_stream(PropArgs a) {
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc) S[3 * rr + cc] = colIn[ro + (long long)rr * ld + cc];
     };
-    fetch(0);
+    if (nI > 0) fetch(0);
     __syncthreads();
     for (int i = 0; i < nI; ++i) {
         T Sc[9];
