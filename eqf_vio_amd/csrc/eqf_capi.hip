@@ -321,17 +321,17 @@ int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, con
     const bool split = f->splitPropagate >= 0 ? f->splitPropagate != 0 : (long long)a.NT * a.NT * f->B >= 2500;  // measured cross-over at N = 200: 16 filters
     rc = profiled(f, EQF_PROF_PROPAGATE, [&] {
         if (split) {
-            const dim3 bgrid((std::max(1, maxN(f)) + 63) / 64, f->B);
+            const dim3 bgrid((std::max(1, maxN(f)) + 63) / 64 + 1, f->B);  // landmark workgroups + the scalar-state workgroup
             // builder (blocks + G rows + group step + scalar state), then everything of Sigma by the lean streaming kernel
             // (EQF_STREAM_PROPAGATE=0: by the tile kernel instead -- kept as a cross-check)
             const int nmx = std::max(1, maxN(f));
             const dim3 sgrid((nmx + 255) / 256, (nmx + kStreamRows - 1) / kStreamRows, f->B);
             if (f->precision == EQF_PRECISION_F32) {
-                hipLaunchKernelGGL(k_build_blocks<float>, bgrid, dim3(64), 0, f->stream, a);
+                hipLaunchKernelGGL(k_build_blocks<float>, bgrid, dim3(128), 0, f->stream, a);
                 if (f->streamPropagate) hipLaunchKernelGGL(k_riccati_stream<float>, sgrid, block, 0, f->stream, a);
                 else hipLaunchKernelGGL((k_propagate<float, true>), grid, block, 0, f->stream, a);
             } else {
-                hipLaunchKernelGGL(k_build_blocks<double>, bgrid, dim3(64), 0, f->stream, a);
+                hipLaunchKernelGGL(k_build_blocks<double>, bgrid, dim3(128), 0, f->stream, a);
                 if (f->streamPropagate) hipLaunchKernelGGL(k_riccati_stream<double>, sgrid, block, 0, f->stream, a);
                 else hipLaunchKernelGGL((k_propagate<double, true>), grid, block, 0, f->stream, a);
             }

@@ -596,11 +596,15 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     if (bad && a.errflag) atomicOr(a.errflag, 1);
 }
 
-// Builder of the split path: one lane per landmark.  Writes the per-landmark blocks (as T), the stepped group
-// landmarks Q_i, and -- workgroup 0 -- the scalar state and the common values of the base panels.
+// Builder of the split path.  grid = (ceil(N / 64) + 1, B), block = 128.  As in the fused kernel the fp64 scalar chain is
+// spread over wavefronts (a lone wave is issue-bound, so three chains side by side cost the time of the longest one):
+//   landmark workgroups  wave 0: common linearisation values + the blocks D, Lw, Lv and the G rows of 64 landmarks
+//                        wave 1: the group step Q_i <- Q_i * lift_i of the same landmarks
+//   last workgroup       wave 0: the scalar state (X.A, X.w, ZOH bookkeeping);  wave 1: the common values for the base panels
 template <typename T>
-__global__ __launch_bounds__(64) void k_build_blocks(PropArgs a) {
-    const int b = blockIdx.y, lane = threadIdx.x;
+__global__ __launch_bounds__(128) void k_build_blocks(PropArgs a) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool isState = blockIdx.x == gridDim.x - 1;
     const int i = blockIdx.x * 64 + lane;
     const int cap = a.cap;
     const Glob& G = a.gin[b];
@@ -613,60 +617,20 @@ __global__ __launch_bounds__(64) void k_build_blocks(PropArgs a) {
     const double* Qin = a.Qin + (long long)b * 5 * cap;
     double* Qout = a.Qout + (long long)b * 5 * cap;
     int bad = 0;
-    StepCommon c;
-    c.step = 0;
-    if (step) stepCommon(G, r, a, c, kPartBase | kPartRicc | kPartLift, &bad);
-    if (i < N) {
-        const quat Qq = quat{Qin[i], Qin[cap + i], Qin[2 * cap + i], Qin[3 * cap + i]};
-        const double Qa = Qin[4 * cap + i];
-        const d3 q0 = mk3(p0[i], p0[cap + i], p0[2 * cap + i]);
-        if (riccati) {
-            const LmBlocks blk = buildBlocks(c, Qq, Qa, q0);
-            T* bp = static_cast<T*>(a.blk) + ((long long)b * cap + i) * kBlkRec;
-            T D[9], Lw[9], Lv[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                D[k] = (T)blk.D.a[k];
-                Lw[k] = (T)blk.Lw.a[k];
-                Lv[k] = (T)blk.Lv.a[k];
-                bp[k] = D[k];
-                bp[9 + k] = Lw[k];
-                bp[18 + k] = Lv[k];
+    if (isState) {
+        if (wv == 0) {
+            const double* src = reinterpret_cast<const double*>(&G);
+            double* dst = reinterpret_cast<double*>(a.gout + b);
+            if (lane < (int)(sizeof(Glob) / 8)) dst[lane] = src[lane];
+            if (lane == 0) {
+                StepCommon c;
+                c.step = 0;
+                if (step) stepCommon(G, r, a, c, kPartBase, &bad);
+                stepGlobal(G, a.gout + b, r, a, c, &bad);
             }
-            // the two 3x3 pieces of G_I = Lw Sigma[0:3, :] + Lv Sigma[8:11, :] + D Sigma_Ib that the landmark blocks need
-            // (same expression order as k_propagate's tile code)
-            if (!a.sigmaExternal) {
-                const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
-                const T sw2 = (T)a.prm.velOmegaVariance, Tt = (T)c.T;
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int c0 = half ? 8 : 0;
-#pragma unroll
-                    for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-                        for (int cc = 0; cc < 3; ++cc) {
-                            T acc = 0;
-#pragma unroll
-                            for (int k = 0; k < 3; ++k)
-                                acc += Lw[3 * rr + k] * Sin[(long long)k * a.ld + c0 + cc] + Lv[3 * rr + k] * Sin[(long long)(8 + k) * a.ld + c0 + cc] +
-                                       D[3 * rr + k] * Sin[(long long)(kLm0 + 3 * i + k) * a.ld + c0 + cc];
-                            bp[27 + 9 * half + 3 * rr + cc] = half ? acc : acc + (sw2 / Tt) * Lw[3 * rr + cc];
-                        }
-                }
-            }
-        }
-        quat Qo = Qq;
-        double ao = Qa;
-        if (step) stepLandmark(c, a, Qq, Qa, q0, &Qo, &ao, &bad);
-        Qout[i] = Qo.w; Qout[cap + i] = Qo.x; Qout[2 * cap + i] = Qo.y; Qout[3 * cap + i] = Qo.z;
-        Qout[4 * cap + i] = ao;
-    }
-    if (blockIdx.x == 0) {
-        const double* src = reinterpret_cast<const double*>(&G);
-        double* dst = reinterpret_cast<double*>(a.gout + b);
-        if (lane < (int)(sizeof(Glob) / 8)) dst[lane] = src[lane];
-        if (lane == 0) stepGlobal(G, a.gout + b, r, a, c, &bad);
-        if (lane == 1 && riccati) {
+        } else if (lane == 0 && riccati) {
+            StepCommon c;
+            stepCommon(G, r, a, c, kPartBase | kPartRicc, &bad);
             CommonLds cl;
             cl.T = c.T;
 #pragma unroll
@@ -681,6 +645,59 @@ __global__ __launch_bounds__(64) void k_build_blocks(PropArgs a) {
             }
             a.blkCommon[b] = cl;
         }
+        if (bad && a.errflag) atomicOr(a.errflag, 1);
+        return;
+    }
+    if (i >= N) return;
+    const quat Qq = quat{Qin[i], Qin[cap + i], Qin[2 * cap + i], Qin[3 * cap + i]};
+    const double Qa = Qin[4 * cap + i];
+    const d3 q0 = mk3(p0[i], p0[cap + i], p0[2 * cap + i]);
+    if (wv == 0) {
+        if (riccati) {
+            StepCommon c;
+            stepCommon(G, r, a, c, kPartBase | kPartRicc, &bad);
+            const LmBlocks blk = buildBlocks(c, Qq, Qa, q0);
+            T* bp = static_cast<T*>(a.blk) + ((long long)b * cap + i) * kBlkRec;
+            T D[9], Lw[9], Lv[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                D[k] = (T)blk.D.a[k];
+                Lw[k] = (T)blk.Lw.a[k];
+                Lv[k] = (T)blk.Lv.a[k];
+                bp[k] = D[k];
+                bp[9 + k] = Lw[k];
+                bp[18 + k] = Lv[k];
+            }
+            // the two 3x3 pieces of G_I = Lw Sigma[0:3, :] + Lv Sigma[8:11, :] + D Sigma_Ib that the landmark blocks need
+            // (same expression order as k_propagate's tile code)
+            const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
+            const T sw2 = (T)a.prm.velOmegaVariance, Tt = (T)c.T;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int c0 = half ? 8 : 0;
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        T acc = 0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            acc += Lw[3 * rr + k] * Sin[(long long)k * a.ld + c0 + cc] + Lv[3 * rr + k] * Sin[(long long)(8 + k) * a.ld + c0 + cc] +
+                                   D[3 * rr + k] * Sin[(long long)(kLm0 + 3 * i + k) * a.ld + c0 + cc];
+                        bp[27 + 9 * half + 3 * rr + cc] = half ? acc : acc + (sw2 / Tt) * Lw[3 * rr + cc];
+                    }
+            }
+        }
+    } else {
+        quat Qo = Qq;
+        double ao = Qa;
+        if (step) {
+            StepCommon c;
+            stepCommon(G, r, a, c, kPartBase | kPartLift, &bad);
+            stepLandmark(c, a, Qq, Qa, q0, &Qo, &ao, &bad);
+        }
+        Qout[i] = Qo.w; Qout[cap + i] = Qo.x; Qout[2 * cap + i] = Qo.y; Qout[3 * cap + i] = Qo.z;
+        Qout[4 * cap + i] = ao;
     }
     if (bad && a.errflag) atomicOr(a.errflag, 1);
 }
