@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void k_factor_first64(ChainArgs c0, ChainArgs 
 //     row by the rhs workgroups that produce Y_K / Z_K (the S-chain ones solve the 64 entries of z_K along);
 //   * Sigma <- Sigma - Y^T Y (k_downdate) runs as extra workgroups of the first launch after the S-chain has finished,
 //     next to the remaining E-chain steps (the S-chain is always the shorter one);
-//   * the innovation lift / X <- Delta X (k_update_finish) is done by the E-chain's rhs workgroup in its last step.
+//   * the innovation lift / X <- Delta X (updateFinishBody) is done by the E-chain's rhs workgroup in its last step.
 // embedFinish = 0 (some filter of the batch has chains of equal length): the host launches k_downdate afterwards.
 //
 // PHASE 0: fused launch (above): every tile workgroup solves the two panel blocks it needs itself -- right when a launch

@@ -37,7 +37,7 @@ __host__ __device__ inline int eDim(int N) { return 6 + 3 * N; }          // int
 __host__ __device__ inline int yCols(int N) { return kLm0 + 3 * N + 6; }  // C Sigma (delta in col 11) | V
 
 struct UpdArgs {
-    Glob* g;             // current scalar state [B] (updated in place by k_update_finish)
+    Glob* g;             // current scalar state [B] (updated in place by updateFinishBody)
     const double* p0;    // [B][3][cap]
     const double* lmc;   // [B][15][cap] per-landmark constants of the origin landmark: C0i (6), chart rotation R_s (9)
     double* Q;           // [B][5][cap] current group landmarks (updated in place by finish)
@@ -700,7 +700,8 @@ __global__ __launch_bounds__(1024) void k_update_reduce(UpdArgs a, int colBlocks
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_update_finish: one workgroup per filter.  gamma = Y^T z, the 4x4 weighted least squares of bundleLift,
+// updateFinishBody (one workgroup per filter; runs inside the last chain launch, or as the extra workgroup of k_downdate):
+// gamma = Y^T z, the 4x4 weighted least squares of bundleLift,
 // Delta = liftTotalSpaceInnovationDiscrete(Gamma), X <- Delta * X, bias += gamma[0:6].
 // ------------------------------------------------------------------------------------------------
 EQF_DI void solve4(double M[4][4], double* rhs, double* x) {
@@ -859,8 +860,6 @@ EQF_DI void updateFinishBody(const UpdArgs& a, int b, const double* red) {
     }
     if (bad && a.errflag) atomicOr(a.errflag, 8);
 }
-
-__global__ __launch_bounds__(256) void k_update_finish(UpdArgs a) { updateFinishBody(a, blockIdx.x, a.red + (long long)blockIdx.x * 256); }
 
 // ------------------------------------------------------------------------------------------------
 // k_downdate: Sigma_out = Sigma_in - Y^T Y on the matrix cores.  64x64 output tile per workgroup, each of
