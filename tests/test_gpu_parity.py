@@ -52,10 +52,12 @@ def _drive(ob, hip, N, duration, overrides=None, capacity=None, precision=0, che
     return worst, fo, fg
 
 
-@pytest.mark.parametrize("N,duration", [(1, 0.5), (5, 1.0), (16, 0.6), (17, 0.6), (33, 0.8), (200, 0.36)])
+@pytest.mark.parametrize("N,duration", [(1, 0.5), (5, 1.0), (16, 0.6), (17, 0.6), (21, 0.4), (32, 0.4), (33, 0.8), (43, 0.4), (64, 0.4),
+                                        (107, 0.4), (200, 0.36)])
 def test_stream_parity_with_the_oracle(oracle_lib, hip, N, duration):
     """Same IMU/vision stream through both filters: Sigma (rel. Frobenius) and pose after every vision update.
-    N = 16/17/33 straddle the 16-landmark tile and the 32-wide Cholesky block edges."""
+    N = 16/17/33 straddle the 16-landmark tile edges, 21/32/43/64/107 the block edges of the 64-wide Cholesky chains
+    (2N and 6+3N around multiples of 64)."""
     if N == 1:
         # one landmark: bundleLift's normal equations are rank deficient; run the no-lift update instead
         worst, _, _ = _drive(oracle_lib, hip, N, duration, overrides={"useInnovationLift": False}, capacity=4)
