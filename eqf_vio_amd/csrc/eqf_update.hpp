@@ -162,16 +162,21 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, d
         for (int rl = wv; rl < kNB; rl += nw) {
             const int rr = r0 + rl;
             for (int cc = lane; cc < nep; cc += 256) {
-                double v[4];
+                // raw loads first, conversion afterwards: with T = float a convert right behind each load makes hipcc wait
+                // for every load separately (a chain of cold misses instead of one)
+                T v[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int c2 = cc + 64 * u;
-                    if (rr < ne && c2 < ne && rr != 5 && c2 != 5) v[u] = (double)Sin[(long long)(6 + rr) * ld + 6 + c2];
-                    else v[u] = (rr == c2) ? 1.0 : 0.0;
+                    const bool in = rr < ne && c2 < ne && rr != 5 && c2 != 5;
+                    v[u] = Sin[in ? (long long)(6 + rr) * ld + 6 + c2 : 0];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (cc + 64 * u < nep) EA[(long long)rr * a.ldE + cc + 64 * u] = v[u];
+                for (int u = 0; u < 4; ++u) {
+                    const int c2 = cc + 64 * u;
+                    const bool in = rr < ne && c2 < ne && rr != 5 && c2 != 5;
+                    if (c2 < nep) EA[(long long)rr * a.ldE + c2] = in ? (double)v[u] : ((rr == c2) ? 1.0 : 0.0);
+                }
             }
         }
         if (tid < kNB) {
@@ -243,19 +248,20 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, d
             // (4 column groups per trip: 12 independent loads in flight -- Sigma was written by the previous launch on
             // other XCDs, every access is a ~2 us miss)
             for (int col = colLo + lane; col < colHi; col += 256) {
-                double v[4][3];
+                T vr[4][3];  // raw loads first (clamped column, always in bounds), conversion afterwards -- see above
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int cc = col + 64 * u;
+                    const int cc = min(col + 64 * u, colHi - 1);
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) v[u][q] = (cc < colHi) ? (double)s0[(long long)q * ld + cc] : 0.0;
+                    for (int q = 0; q < 3; ++q) vr[u][q] = s0[(long long)q * ld + cc];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int cc = col + 64 * u;
                     if (cc < colHi) {
-                        sCS0[cc - colLo] = C[0] * v[u][0] + C[1] * v[u][1] + C[2] * v[u][2];
-                        sCS1[cc - colLo] = C[3] * v[u][0] + C[4] * v[u][1] + C[5] * v[u][2];
+                        const double v0 = (double)vr[u][0], v1 = (double)vr[u][1], v2 = (double)vr[u][2];
+                        sCS0[cc - colLo] = C[0] * v0 + C[1] * v1 + C[2] * v2;
+                        sCS1[cc - colLo] = C[3] * v0 + C[4] * v1 + C[5] * v2;
                     }
                 }
             }
