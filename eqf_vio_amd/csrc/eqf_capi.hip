@@ -103,6 +103,20 @@ struct eqf_filter {
     int cholMode = 64;             // 64: k_chol_step64 ; 32 / 33: k_chol_step<false> / <true> (EQF_CHOL_MODE = 64 | 32 | 32inv)
     int cholEmbed = 1;             // EQF_CHOL_EMBED = 0: downdate + innovation lift as a launch of their own
     bool ldsAttrSet[2] = {false, false};  // hipFuncAttributeMaxDynamicSharedMemorySize applied on this handle's device
+    // speculative outlier gate: the frame whose gate answer the host has not looked at yet
+    struct {
+        bool pending = false;
+        std::vector<std::vector<int>> ids;  // measurement ids per filter
+        std::vector<int> nb;
+        std::vector<char> active;
+        const double* bearings = nullptr;   // device
+        long long bearStride = 0;
+    } gate;
+    int* hGate = nullptr;        // pinned [B]: raised by k_probe
+    int* hGateDev = nullptr;     // device-side address of hGate
+    int* dMask = nullptr;        // [B]
+    hipEvent_t evGate = nullptr;
+    int gateSpeculative = 1;     // EQF_GATE_SPECULATIVE = 0: always wait for the gate's answer before the update
     int cholSplit = -1;            // -1 heuristic, 0 fused chain launches, 1 panel + update launches (EQF_CHOL_SPLIT)
     // profiling
     bool prof = false;
@@ -224,11 +238,19 @@ int initState(eqf_filter* f) {
     }
     HIPC(hipStreamSynchronize(f->stream));
     f->pS = f->pG = 0;
+    f->gate.pending = false;
     f->ids.assign(B, {});
     f->curTime.assign(B, -1.0);
     f->init.assign(B, 0);
     return EQF_OK;
 }
+
+int resolveGate(eqf_filter* f);
+#define GATE(f)                          \
+    do {                                 \
+        const int grc_ = resolveGate(f); \
+        if (grc_) return grc_;           \
+    } while (0)
 
 int maxN(const eqf_filter* f) {
     size_t m = 0;
@@ -583,14 +605,14 @@ int uploadPerm(eqf_filter* f, const std::vector<std::vector<int>>& perm) {
 
 // chord errors (when bearings are given) and squared depths of every landmark of the current estimate -> dChord, dDepth2;
 // readback = true also copies them to the host and waits (only the outlier gate needs that: the host owns the ids)
-int probe(eqf_filter* f, const double* bearings, long long bearStride, bool withPerm, bool readback) {
+int probe(eqf_filter* f, const double* bearings, long long bearStride, bool withPerm, bool readback, bool speculative = false) {
     const int B = f->B, cap = f->cap;
     const int nmax = std::max(1, maxN(f));
     // with readback the kernel writes the chords straight into pinned host memory (no copy command behind it)
     double* chordDst = readback ? f->hChordDev : f->dChord;
     int rc = profiled(f, EQF_PROF_CHURN, [&] {
         hipLaunchKernelGGL(k_probe, dim3((nmax + 127) / 128, B), dim3(128), 0, f->stream, f->g[f->pG], f->p0, f->Q[f->pG], cap, bearings,
-            bearStride, withPerm ? f->dPerm : nullptr, chordDst, f->dDepth2);
+            bearStride, withPerm ? f->dPerm : nullptr, chordDst, f->dDepth2, f->set.outlierThreshold, speculative ? f->hGateDev : nullptr);
     });
     if (rc) return rc;
     if (readback) HIPC(hipStreamSynchronize(f->stream));
@@ -643,7 +665,35 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
     // ---- removeOutliers (:429-443).  A chord between unit vectors never exceeds 2.
     std::vector<std::vector<char>> dropped(B);  // measurement indices erased together with their landmark
     for (int b = 0; b < B; ++b) dropped[b].assign(nb[b], 0);
-    if (f->set.outlierThreshold < 2.0 && maxN(f) > 0) {
+    const bool gateOn = f->set.outlierThreshold < 2.0 && maxN(f) > 0;
+    // Speculative gate on pure tracking frames (no landmark lost, none new -- the common case): the probe decides on the
+    // device, the update is enqueued without waiting for the answer, and a frame that did have an outlier is redone the
+    // slow way by resolveGate() the next time the host touches the handle.
+    bool speculate = gateOn && f->gateSpeculative && !anyLost && !f->gate.pending;
+    for (int b = 0; b < B && speculate; ++b)
+        if (active[b] && nb[b] != int(f->ids[b].size())) speculate = false;
+    if (speculate) {
+        bool identityPerm = true;
+        for (int b = 0; b < B && identityPerm; ++b)
+            for (size_t i = 0; i < perm[b].size(); ++i)
+                if (perm[b][i] != int(i)) {
+                    identityPerm = false;
+                    break;
+                }
+        int rc = identityPerm ? EQF_OK : uploadPerm(f, perm);
+        if (rc) return rc;
+        std::fill(f->hGate, f->hGate + B, 0);
+        rc = probe(f, bearings, bearStride, !identityPerm, false, true);
+        if (rc) return rc;
+        HIPC(hipEventRecord(f->evGate, f->stream));
+        f->gate.pending = true;
+        f->gate.ids.assign(B, {});
+        for (int b = 0; b < B; ++b) f->gate.ids[b].assign(measIds[b], measIds[b] + nb[b]);
+        f->gate.nb = nb;
+        f->gate.active = active;
+        f->gate.bearings = bearings;
+        f->gate.bearStride = bearStride;
+    } else if (gateOn) {
         bool identityPerm = true;
         for (int b = 0; b < B && identityPerm; ++b)
             for (size_t i = 0; i < perm[b].size(); ++i)
@@ -752,6 +802,37 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
     return launchUpdate(f, bearings, bearStride, identity ? nullptr : f->dPerm, Nmax);
 }
 
+// Look at the answer of a speculative outlier gate.  No outlier (the common case): nothing to do.  Otherwise the filters
+// that saw one had their update switched off on the device; the frame is redone for them the synchronous way (remove the
+// outliers, then update), exactly what a non-speculative call would have done at the time.
+int resolveGate(eqf_filter* f) {
+    if (!f->gate.pending) return EQF_OK;
+    HIPC(hipSetDevice(f->device));
+    HIPC(hipEventSynchronize(f->evGate));
+    f->gate.pending = false;
+    const int B = f->B;
+    bool any = false;
+    std::vector<char> act(B, 0);
+    std::vector<int> mask(B, 0);
+    for (int b = 0; b < B; ++b)
+        if (f->hGate[b] && f->gate.active[b]) {
+            any = true;
+            act[b] = 1;
+            mask[b] = 1;
+        }
+    if (!any) return EQF_OK;
+    HIPC(hipMemcpyAsync(f->dMask, mask.data(), sizeof(int) * B, hipMemcpyHostToDevice, f->stream));
+    hipLaunchKernelGGL(k_set_update_ok, dim3((B + 63) / 64), dim3(64), 0, f->stream, f->g[f->pG], f->dMask, B);
+    HIPC(hipStreamSynchronize(f->stream));  // mask.data() is pageable host memory
+    std::vector<const int*> mids(B);
+    for (int b = 0; b < B; ++b) mids[b] = f->gate.ids[b].data();
+    const int keep = f->gateSpeculative;
+    f->gateSpeculative = 0;
+    const int rc = visionCore(f, mids, f->gate.nb, f->gate.bearings, f->gate.bearStride, act, nullptr);
+    f->gateSpeculative = keep;
+    return rc;
+}
+
 void freeAll(eqf_filter* f) {
     if (!f) return;
     for (int p = 0; p < 2; ++p) {
@@ -764,6 +845,9 @@ void freeAll(eqf_filter* f) {
              (void*)f->dNewN, (void*)f->dPerm, (void*)f->dSrc, (void*)f->dChord, (void*)f->dDepth2, (void*)f->dDepthSel, (void*)f->dScratch, (void*)f->dMeas,
              (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn, f->dBlk, (void*)f->dBlkCommon})
         hipFree(p);
+    if (f->hGate) hipHostFree(f->hGate);
+    if (f->dMask) hipFree(f->dMask);
+    if (f->evGate) hipEventDestroy(f->evGate);
     stageFree(f->stMap);
     stageFree(f->stPerm);
     stageFree(f->stSrc);
@@ -902,8 +986,12 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (const char* e = std::getenv("EQF_CHOL_MODE")) f->cholMode = std::strcmp(e, "32inv") == 0 ? 33 : (std::strcmp(e, "32") == 0 ? 32 : 64);
     if (const char* e = std::getenv("EQF_CHOL_EMBED")) f->cholEmbed = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_SPLIT")) f->cholSplit = std::atoi(e);
+    if (const char* e = std::getenv("EQF_GATE_SPECULATIVE")) f->gateSpeculative = std::atoi(e);
     chk(stageInit(f->stMap, (size_t)cap * B + B)); chk(stageInit(f->stPerm, (size_t)cap * B)); chk(stageInit(f->stSrc, cap));
     chk(hmalloc(&f->hChord, (size_t)cap * B)); chk(dmalloc(&f->dDepthSel, B));
+    chk(hmalloc(&f->hGate, B)); chk(dmalloc(&f->dMask, B));
+    if (!rc && hipHostGetDevicePointer(reinterpret_cast<void**>(&f->hGateDev), f->hGate, 0) != hipSuccess) rc = EQF_ERR_HIP;
+    if (!rc && hipEventCreateWithFlags(&f->evGate, hipEventDisableTiming) != hipSuccess) rc = EQF_ERR_HIP;
     if (!rc && hipHostGetDevicePointer(reinterpret_cast<void**>(&f->hChordDev), f->hChord, 0) != hipSuccess) rc = EQF_ERR_HIP;
     chk(hmalloc(&f->hMeas, (size_t)3 * cap * B)); chk(hmalloc(&f->hOut, (size_t)f->nTot * f->nTot + 16));
     chk(hmalloc(&f->hRing, (size_t)kRing * B));
@@ -930,6 +1018,7 @@ void eqf_destroy(eqf_filter* f) {
 
 int eqf_reset(eqf_filter* f) {
     if (!f) return EQF_ERR_INVALID;
+    GATE(f);
     HIPC(hipSetDevice(f->device));
     HIPC(hipStreamSynchronize(f->stream));
     return initState(f);
@@ -937,12 +1026,14 @@ int eqf_reset(eqf_filter* f) {
 
 int eqf_synchronize(eqf_filter* f) {
     if (!f) return EQF_ERR_INVALID;
+    GATE(f);
     HIPC(hipStreamSynchronize(f->stream));
     return EQF_OK;
 }
 
 int eqf_process_imu(eqf_filter* f, const double* stamps, const double* omega, const double* accel, int* status) {
     if (!f || !stamps || !omega || !accel) return EQF_ERR_INVALID;
+    GATE(f);
     HIPC(hipSetDevice(f->device));
     std::vector<ImuRec> recs(f->B);
     for (int b = 0; b < f->B; ++b) {
@@ -965,6 +1056,7 @@ int eqf_process_imu(eqf_filter* f, const double* stamps, const double* omega, co
 int eqf_process_vision(eqf_filter* f, const double* stamps, const int* nb, const int* ids, const double* bearings, int stride,
     int* status) {
     if (!f || !stamps || !nb || (!ids && stride > 0) || (!bearings && stride > 0)) return EQF_ERR_INVALID;
+    GATE(f);
     HIPC(hipSetDevice(f->device));
     const int B = f->B, cap = f->cap;
     for (int b = 0; b < B; ++b) {
@@ -1008,6 +1100,7 @@ int eqf_process_vision(eqf_filter* f, const double* stamps, const int* nb, const
 int eqf_stream_upload(eqf_filter* f, int K, const double* imu, int F, const double* vstamps, int nbear, const int* ids,
     const double* bearings) {
     if (!f || K < 0 || F < 0 || nbear < 0 || nbear > f->cap) return EQF_ERR_INVALID;
+    GATE(f);
     HIPC(hipSetDevice(f->device));
     HIPC(hipStreamSynchronize(f->stream));
     const int B = f->B;
@@ -1047,12 +1140,14 @@ int eqf_stream_upload(eqf_filter* f, int K, const double* imu, int F, const doub
 
 int eqf_stream_imu(eqf_filter* f, int k) {
     if (!f || k < 0 || k >= f->sK) return EQF_ERR_INVALID;
+    GATE(f);
     ImuRec dummy{};
     return launchPropagate(f, f->sImu + (size_t)k * f->B, dummy, f->hImuStamp.data() + (size_t)k * f->B, true, !f->set.fastRiccati, nullptr);
 }
 
 int eqf_stream_vision(eqf_filter* f, int fr) {
     if (!f || fr < 0 || fr >= f->sF) return EQF_ERR_INVALID;
+    GATE(f);
     const int B = f->B;
     ImuRec dummy{};
     std::vector<int> st(B, EQF_OK);
@@ -1073,17 +1168,20 @@ int eqf_get_time(eqf_filter* f, double* t) {
 
 int eqf_num_landmarks(eqf_filter* f, int b) {
     if (!f || b < 0 || b >= f->B) return EQF_ERR_INVALID;
+    if (resolveGate(f)) return EQF_ERR_HIP;
     return int(f->ids[b].size());
 }
 
 int eqf_get_ids(eqf_filter* f, int b, int* ids) {
     if (!f || b < 0 || b >= f->B || !ids) return EQF_ERR_INVALID;
+    GATE(f);
     std::copy(f->ids[b].begin(), f->ids[b].end(), ids);
     return EQF_OK;
 }
 
 int eqf_get_state_estimate(eqf_filter* f, int b, double* pose_q, double* pose_x, double* velocity, double* p) {
     if (!f || b < 0 || b >= f->B) return EQF_ERR_INVALID;
+    GATE(f);
     HIPC(hipSetDevice(f->device));
     const int N = int(f->ids[b].size());
     hipLaunchKernelGGL(k_state_estimate, dim3((N + 255) / 256 + 1), dim3(256), 0, f->stream, f->g[f->pG], b, f->p0, f->Q[f->pG], f->cap, f->dOut);
@@ -1105,6 +1203,7 @@ static int fetchGlob(eqf_filter* f, int b, Glob* g) {
 
 int eqf_get_origin(eqf_filter* f, int b, double* pose_q, double* pose_x, double* velocity, double* p) {
     if (!f || b < 0 || b >= f->B) return EQF_ERR_INVALID;
+    GATE(f);
     Glob g;
     int rc = fetchGlob(f, b, &g);
     if (rc) return rc;
@@ -1123,6 +1222,7 @@ int eqf_get_origin(eqf_filter* f, int b, double* pose_q, double* pose_x, double*
 
 int eqf_get_group(eqf_filter* f, int b, double* A_q, double* A_x, double* w, double* Q_q, double* Q_a) {
     if (!f || b < 0 || b >= f->B) return EQF_ERR_INVALID;
+    GATE(f);
     Glob g;
     int rc = fetchGlob(f, b, &g);
     if (rc) return rc;
@@ -1144,6 +1244,7 @@ int eqf_get_group(eqf_filter* f, int b, double* A_q, double* A_x, double* w, dou
 
 int eqf_get_bias(eqf_filter* f, int b, double* bias6) {
     if (!f || b < 0 || b >= f->B || !bias6) return EQF_ERR_INVALID;
+    GATE(f);
     Glob g;
     int rc = fetchGlob(f, b, &g);
     if (rc) return rc;
@@ -1153,6 +1254,7 @@ int eqf_get_bias(eqf_filter* f, int b, double* bias6) {
 
 int eqf_get_sigma(eqf_filter* f, int b, double* dst, int ld) {
     if (!f || b < 0 || b >= f->B || !dst) return EQF_ERR_INVALID;
+    GATE(f);
     HIPC(hipSetDevice(f->device));
     const int n = kBase + 3 * int(f->ids[b].size());
     if (ld < n) return EQF_ERR_INVALID;
@@ -1171,6 +1273,7 @@ int eqf_get_sigma(eqf_filter* f, int b, double* dst, int ld) {
 
 int eqf_set_sigma(eqf_filter* f, int b, const double* src, int ld) {
     if (!f || b < 0 || b >= f->B || !src) return EQF_ERR_INVALID;
+    GATE(f);
     HIPC(hipSetDevice(f->device));
     const int n = kBase + 3 * int(f->ids[b].size());
     if (ld < n) return EQF_ERR_INVALID;
@@ -1191,6 +1294,7 @@ int eqf_set_sigma(eqf_filter* f, int b, const double* src, int ld) {
 int eqf_get_integrator(eqf_filter* f, int b, double* currentVelocity6, double* accumulatedVelocity6, double* accumulatedTime,
     int* initialised) {
     if (!f || b < 0 || b >= f->B) return EQF_ERR_INVALID;
+    GATE(f);
     Glob g;
     int rc = fetchGlob(f, b, &g);
     if (rc) return rc;
@@ -1206,6 +1310,7 @@ int eqf_set_state(eqf_filter* f, int b, int N, const int* ids, const double* pos
     const double* sigma, int ld, double currentTime, const double* currentVelocity6, const double* accumulatedVelocity6,
     double accumulatedTime, int initialised) {
     if (!f || b < 0 || b >= f->B || N < 0 || !pose_q || !pose_x || !velocity || !A_q || !A_x || !w || !bias6 || !sigma) return EQF_ERR_INVALID;
+    GATE(f);
     if (N > 0 && (!ids || !p0 || !Q_q || !Q_a)) return EQF_ERR_INVALID;
     if (N > f->cap) return EQF_ERR_CAPACITY;
     if (ld < kBase + 3 * N) return EQF_ERR_INVALID;
@@ -1249,6 +1354,7 @@ int eqf_set_state(eqf_filter* f, int b, int N, const int* ids, const double* pos
 
 int eqf_set_camera_offset(eqf_filter* f, const double* q, const double* x) {
     if (!f || !q || !x) return EQF_ERR_INVALID;
+    GATE(f);
     const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
     if (!(std::fabs(n2 - 1.0) < 1e-6)) return EQF_ERR_INVALID;
     HIPC(hipSetDevice(f->device));
@@ -1263,6 +1369,7 @@ int eqf_set_camera_offset(eqf_filter* f, const double* q, const double* x) {
 
 int eqf_get_last_update(eqf_filter* f, int b, double* delta, double* gamma, double* Gamma) {
     if (!f || b < 0 || b >= f->B) return EQF_ERR_INVALID;
+    GATE(f);
     HIPC(hipSetDevice(f->device));
     HIPC(hipStreamSynchronize(f->stream));
     const int N = int(f->ids[b].size()), cap = f->cap;
@@ -1279,6 +1386,7 @@ int eqf_get_last_update(eqf_filter* f, int b, double* delta, double* gamma, doub
 
 int eqf_device_error(eqf_filter* f) {
     if (!f) return EQF_ERR_INVALID;
+    if (resolveGate(f)) return EQF_ERR_HIP;
     if (hipSetDevice(f->device) != hipSuccess) return EQF_ERR_HIP;
     if (hipStreamSynchronize(f->stream) != hipSuccess) return EQF_ERR_HIP;
     int e = 0;
@@ -1288,6 +1396,7 @@ int eqf_device_error(eqf_filter* f) {
 
 int eqf_set_dense_propagate(eqf_filter* f, int on) {
     if (!f) return EQF_ERR_INVALID;
+    GATE(f);
     HIPC(hipSetDevice(f->device));
     if (on && !f->dF) {
         const size_t bytes = f->esz * f->sigmaStride * f->B;
@@ -1303,6 +1412,7 @@ int eqf_set_dense_propagate(eqf_filter* f, int on) {
 
 int eqf_profile_enable(eqf_filter* f, int on) {
     if (!f) return EQF_ERR_INVALID;
+    GATE(f);
     if (f->prof && !on) {
         int rc = profDrain(f);
         if (rc) return rc;
@@ -1338,6 +1448,7 @@ int eqf_profile_enable(eqf_filter* f, int on) {
 
 int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_ms) {
     if (!f || cls < 0 || cls >= EQF_PROF_CLASSES) return EQF_ERR_INVALID;
+    GATE(f);
     int rc = profDrain(f);
     if (rc) return rc;
     if (launches) *launches = f->profCount[cls];

@@ -13,8 +13,11 @@ namespace eqf {
 
 // Per-landmark probe of the current estimate: chord between the measured bearing and the predicted one
 // (removeOutliers, VIOFilter.cpp:429-443) and squared depth (addNewLandmarks median, :357-366).
-__global__ void k_probe(const Glob* g, const double* p0, const double* Q, int cap, const double* bearings,
-    long long bearStride, const int* perm, double* chord, double* depth2) {
+// Speculative outlier gate (gateFlag != nullptr): a landmark whose chord exceeds gateThr switches the filter's queued
+// update off (updateOk = 0) and raises gateFlag[b] in pinned host memory -- the host, which enqueued the update without
+// waiting for this answer, redoes the frame the slow way when it next touches the handle.
+__global__ void k_probe(Glob* g, const double* p0, const double* Q, int cap, const double* bearings,
+    long long bearStride, const int* perm, double* chord, double* depth2, double gateThr, int* gateFlag) {
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= g[b].N) return;
@@ -32,6 +35,15 @@ __global__ void k_probe(const Glob* g, const double* p0, const double* Q, int ca
         }
     }
     chord[(long long)b * cap + i] = ch;
+    if (gateFlag && ch > gateThr) {
+        g[b].updateOk = 0;
+        gateFlag[b] = 1;
+    }
+}
+// updateOk[b] = mask[b] (redo of a speculatively skipped update: only the flagged filters take part)
+__global__ void k_set_update_ok(Glob* g, const int* mask, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) g[b].updateOk = mask[b] ? 1 : 0;
 }
 
 // Median scene depth for addNewLandmarks (VIOFilter.cpp:357-366): sqrt of the (N/2)-th order statistic of the squared

@@ -18,7 +18,7 @@ d = synth.template_settings_dict()
 def run(mode):
     dd = dict(d)
     if "gate" in mode:
-        dd["outlierThreshold"] = 0.01  # the reference default (VIOFilterSettings.h): chord probe + readback every frame
+        dd["outlierThreshold"] = float(os.environ.get("GATE_THR", "0.01"))  # the reference default is 0.01 (VIOFilterSettings.h)
     fb = hip.FilterBatch(dd, capacity=NP, batch=1)
     ev = list(st.events())
     nvis, nch = 0, 0

@@ -165,6 +165,54 @@ def test_ragged_batch_with_churn_and_outlier_gate(oracle_lib, hip):
     assert fg.device_error() == 0
 
 
+@pytest.mark.parametrize("peek", [True, False])
+def test_speculative_outlier_gate(oracle_lib, hip, peek):
+    """Gate on, fixed landmark set: the device decides and the update is enqueued without waiting.  Frames with an
+    outlier (3 and 7 here) are redone the slow way when the host next touches the handle -- at a getter right after
+    the frame (peek) or only at the next IMU call; two filters so that one is redone while the other is not."""
+    from eqf_vio_amd import synth
+
+    N, B = 30, 2
+    sts = [synth.make_stream(N, seed=500 + b, duration=0.6) for b in range(B)]
+    d = synth.template_settings_dict()
+    d["outlierThreshold"] = 0.05
+    fos = [oracle_lib.OracleFilter(d) for _ in range(B)]
+    fg = hip.FilterBatch(d, capacity=N, batch=B)
+
+    def bearings(b, k):
+        y = sts[b].bearings[k].copy()
+        if b == 1 and k in (3, 7):  # rotate one bearing by ~0.2 rad: chord 0.2 >> 0.05
+            axis = np.cross(y[5], np.array([1.0, 0.3, -0.2]))
+            axis /= np.linalg.norm(axis)
+            y[5] = y[5] * np.cos(0.2) + np.cross(axis, y[5]) * np.sin(0.2)
+        return y
+
+    for kind, k in sts[0].events():
+        if kind == "imu":
+            for b in range(B):
+                r = sts[b].imu[k]
+                fos[b].processIMUData(r[0], r[1:4], r[4:7])
+            fg.process_imu([s.imu[k, 0] for s in sts], [s.imu[k, 1:4] for s in sts], [s.imu[k, 4:7] for s in sts])
+        else:
+            ys = [bearings(b, k) for b in range(B)]
+            ids = [sts[b].ids if k < 3 or b == 0 else None for b in range(B)]
+            for b in range(B):
+                # after its landmark was thrown out the reference re-adds it as a NEW landmark on the next frame it is
+                # seen: same measurement for both implementations
+                fos[b].processVisionData(sts[b].vision_stamps[k], sts[b].ids, ys[b])
+            fg.process_vision([s.vision_stamps[k] for s in sts], sts[0].ids, np.stack(ys))
+            if peek:
+                for b in range(B):
+                    assert fg.num_landmarks(b) == fos[b].N, (k, b)
+                    assert rel_fro(fg.sigma(b), fos[b].stateCovariance()) < SIGMA_TOL, (k, b)
+    for b in range(B):
+        assert np.array_equal(fg.ids(b), fos[b].ids())
+        assert rel_fro(fg.sigma(b), fos[b].stateCovariance()) < SIGMA_TOL
+        eo, eg = fos[b].stateEstimate(), fg.state_estimate(b)
+        assert np.abs(eo["x"] - eg["x"]).max() < POSE_TOL
+    assert fg.device_error() == 0
+
+
 def test_reset_returns_to_the_constructed_state(hip):
     """eqf_reset: a handle that has run (landmarks, churned Sigma, advanced time) and is reset behaves bitwise like a
     fresh one."""
