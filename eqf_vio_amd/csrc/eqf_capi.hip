@@ -666,10 +666,10 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
     std::vector<std::vector<char>> dropped(B);  // measurement indices erased together with their landmark
     for (int b = 0; b < B; ++b) dropped[b].assign(nb[b], 0);
     const bool gateOn = f->set.outlierThreshold < 2.0 && maxN(f) > 0;
-    // Speculative gate on pure tracking frames (no landmark lost, none new -- the common case): the probe decides on the
+    // Speculative gate on frames without NEW landmarks (the common case): the probe decides on the
     // device, the update is enqueued without waiting for the answer, and a frame that did have an outlier is redone the
     // slow way by resolveGate() the next time the host touches the handle.
-    bool speculate = gateOn && f->gateSpeculative && !anyLost && !f->gate.pending;
+    bool speculate = gateOn && f->gateSpeculative && !f->gate.pending;  // (lost landmarks are already compacted away)
     for (int b = 0; b < B && speculate; ++b)
         if (active[b] && nb[b] != int(f->ids[b].size())) speculate = false;
     if (speculate) {
