@@ -302,7 +302,8 @@ int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, con
     a.isImu = isImu ? 1 : 0;
     a.doRiccati = doRiccati ? 1 : 0;
     a.prm = f->prm;
-    const dim3 grid(a.NT * a.NT + 1, f->B), block(256);  // tiles + the scalar-state / base-block workgroup
+    // tiles + base-block workgroup + scalar-state workgroup + NT row-tail + NT column-tail workgroups (see k_propagate)
+    const dim3 grid(a.NT * a.NT + 2 + 2 * a.NT, f->B), block(256);
     int rc = EQF_OK;
     if (f->densePropagate && doRiccati) {
         // dense backend: F and Bn from the same linearisation blocks, then two MFMA GEMMs; k_propagate below only
@@ -357,10 +358,11 @@ int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, con
                 if (f->streamPropagate) hipLaunchKernelGGL(k_riccati_stream<double>, sgrid, block, 0, f->stream, a);
                 else hipLaunchKernelGGL((k_propagate<double, true>), grid, block, 0, f->stream, a);
             }
-        } else if (f->precision == EQF_PRECISION_F32) {
-            hipLaunchKernelGGL((k_propagate<float, false>), grid, block, 0, f->stream, a);
         } else {
-            hipLaunchKernelGGL((k_propagate<double, false>), grid, block, 0, f->stream, a);
+            // fused kernel: ... + one workgroup per 64 landmarks (group step)
+            const dim3 fgrid(a.NT * a.NT + 2 + 2 * a.NT + (std::max(1, maxN(f)) + 63) / 64, f->B);
+            if (f->precision == EQF_PRECISION_F32) hipLaunchKernelGGL((k_propagate<float, false>), fgrid, block, 0, f->stream, a);
+            else hipLaunchKernelGGL((k_propagate<double, false>), fgrid, block, 0, f->stream, a);
         }
     });
     if (rc) return rc;

@@ -268,10 +268,25 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     const int tid = threadIdx.x;
     EQF_PSTAMP(0);
     const int b = blockIdx.y;
-    // the last workgroup of a filter carries no tile: it steps the scalar state and propagates the 11 x 11 base block
-    const bool isExtra = (int)blockIdx.x == a.NT * a.NT;
-    const int ti = isExtra ? 0 : blockIdx.x / a.NT, tj = isExtra ? 0 : blockIdx.x % a.NT;
-    const int lastT = a.NT - 1;
+    const bool isExtra = (int)blockIdx.x == a.NT * a.NT;  // the base-block workgroup
+    // Workgroups after the tiles carry no tile (index relative to NT^2):
+    //   0              the 11 x 11 base block
+    //   1              the scalar state (X.A, X.w, ZOH bookkeeping)                      [fused kernel only]
+    //   2 .. 2+NT-1    "row tails":    Sigma'_Ib of one landmark group (they run that group's linearisation chain, no tile math)
+    //   2+NT .. 2+2NT-1 "column tails": Sigma'_bJ of one landmark group
+    //   2+2NT ..       the group step Q_i <- Q_i lift_i of 64 landmarks each              [fused kernel only]
+    // Measured per-workgroup durations (N = 200, cycles): tiles 15.5 k; with the tails inside the tiles of the last tile
+    // row / column that corner tile took 21.4 k, one workgroup doing both tails of a group 19.6 k, base block + scalar
+    // state in one workgroup 18.4 k, the landmark group step inside the diagonal tiles held their barrier up by 3 k.
+    const int rel = (int)blockIdx.x - a.NT * a.NT;
+    const bool isState = rel == 1;
+    const bool isRowTail = rel >= 2 && rel < 2 + a.NT;
+    const bool isColTail = rel >= 2 + a.NT && rel < 2 + 2 * a.NT;
+    const bool isTail = isRowTail || isColTail;
+    const int tailG = isRowTail ? rel - 2 : rel - 2 - a.NT;
+    const bool isLmWg = !PRE && rel >= 2 + 2 * a.NT;
+    const int ti = isTail ? tailG : (rel >= 0 ? 0 : blockIdx.x / a.NT);
+    const int tj = isTail ? tailG : (rel >= 0 ? 0 : blockIdx.x % a.NT);
     const int cap = a.cap, ld = a.ld;
 
     __shared__ T sD[32][9], sLw[32][9], sLv[32][9];  // [0,16): row landmarks I, [16,32): column landmarks J
@@ -303,6 +318,42 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     int bad = 0;
 
     const int wv = tid >> 6, ln = tid & 63;
+    if (isLmWg) {
+        // ---- group step Q_i <- Q_i * lift_i of 64 landmarks (VIOGroup.cpp:230-240 / :188-196, :105-107)
+        const int i = (rel - 2 - 2 * a.NT) * 64 + ln;
+        if (wv == 0 && i < N) {
+            const quat Qq = quat{Qin[i], Qin[cap + i], Qin[2 * cap + i], Qin[3 * cap + i]};
+            const double Qa = Qin[4 * cap + i];
+            quat Qo = Qq;
+            double ao = Qa;
+            if (step) {
+                StepCommon c;
+                stepCommon(G, r, a, c, kPartBase | kPartLift, &bad);
+                stepLandmark(c, a, Qq, Qa, mk3(p0[i], p0[cap + i], p0[2 * cap + i]), &Qo, &ao, &bad);
+            }
+            Qout[i] = Qo.w; Qout[cap + i] = Qo.x; Qout[2 * cap + i] = Qo.y; Qout[3 * cap + i] = Qo.z;
+            Qout[4 * cap + i] = ao;
+            if (bad && a.errflag) atomicOr(a.errflag, 1);
+        }
+        return;
+    }
+    if (isState) {
+        // ---- scalar state.  Word-parallel copy in -> out, then one lane patches the changed fields
+        if (!PRE && wv == 0) {
+            static_assert(sizeof(Glob) % 8 == 0 && sizeof(Glob) / 8 <= 64, "Glob copy is one word per lane");
+            const double* src = reinterpret_cast<const double*>(&G);
+            double* dst = reinterpret_cast<double*>(a.gout + b);
+            if (ln < (int)(sizeof(Glob) / 8)) dst[ln] = src[ln];
+            if (ln == 0) {
+                StepCommon c;
+                c.step = 0;
+                if (step) stepCommon(G, r, a, c, kPartBase, &bad);
+                stepGlobal(G, a.gout + b, r, a, c, &bad);
+                if (bad && a.errflag) atomicOr(a.errflag, 1);
+            }
+        }
+        return;
+    }
     if (PRE) {
         if (riccati && tid < 32 && !isExtra) {
             const int i = (tid < 16) ? I0 + tid : J0 + tid - 16;
@@ -350,40 +401,6 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
             }
         }
     }
-    if (wv == 1 && ti == tj && !isExtra) {
-        // ---- wave 1 of the diagonal tiles: group step of the tile's landmarks
-        if (ln < kTileLm) {
-            const int i = I0 + ln;
-            if (i < N) {
-                const quat Qq = quat{Qin[i], Qin[cap + i], Qin[2 * cap + i], Qin[3 * cap + i]};
-                const double Qa = Qin[4 * cap + i];
-                quat Qo = Qq;
-                double ao = Qa;
-                if (step) {
-                    StepCommon c;
-                    stepCommon(G, r, a, c, kPartBase | kPartLift, &bad);
-                    stepLandmark(c, a, Qq, Qa, mk3(p0[i], p0[cap + i], p0[2 * cap + i]), &Qo, &ao, &bad);
-                }
-                Qout[i] = Qo.w; Qout[cap + i] = Qo.x; Qout[2 * cap + i] = Qo.y; Qout[3 * cap + i] = Qo.z;
-                Qout[4 * cap + i] = ao;
-            }
-        }
-    }
-    if (wv == 2 && isExtra) {
-        // ---- wave 2 of the extra workgroup: scalar state.  Word-parallel copy in -> out, then one lane patches the changed fields
-        static_assert(sizeof(Glob) % 8 == 0 && sizeof(Glob) / 8 <= 64, "Glob copy is one word per lane");
-        const double* src = reinterpret_cast<const double*>(&G);
-        double* dst = reinterpret_cast<double*>(a.gout + b);
-        if (ln < (int)(sizeof(Glob) / 8)) dst[ln] = src[ln];
-        if (ln == 0) {
-            StepCommon c;
-            c.step = 0;
-            if (step) stepCommon(G, r, a, c, kPartBase, &bad);
-            stepGlobal(G, a.gout + b, r, a, c, &bad);
-        }
-        EQF_PSTAMP(5);
-    }
-
     }
     if (!riccati && a.sigmaExternal && step && a.doRiccati) {
         if (bad && a.errflag) atomicOr(a.errflag, 1);
@@ -392,17 +409,17 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     if (!riccati) {
         // Sigma is not touched by this call: copy the tile through so that the ping-pong parity of all
         // filters of the batch stays in step.
-        for (int e = tid; e < kTile * kTile && !isExtra; e += 256) {
+        for (int e = tid; e < kTile * kTile && !isExtra && !isTail; e += 256) {
             const int rr = e / kTile, cc = e % kTile;
             const int R = kLm0 + 3 * I0 + rr, Cc = kLm0 + 3 * J0 + cc;
             if (R < kLm0 + 3 * N && Cc < kLm0 + 3 * N) Sout[(long long)R * ld + Cc] = Sin[(long long)R * ld + Cc];
         }
-        if (tj == lastT && !isExtra)
+        if (isRowTail)
             for (int e = tid; e < kTile * 12; e += 256) {
                 const int R = kLm0 + 3 * I0 + e / 12, Cc = e % 12;
                 if (R < kLm0 + 3 * N) Sout[(long long)R * ld + Cc] = Sin[(long long)R * ld + Cc];
             }
-        if (ti == lastT && !isExtra)
+        if (isColTail)
             for (int e = tid; e < 12 * kTile; e += 256) {
                 const int R = e / kTile, Cc = kLm0 + 3 * J0 + e % kTile;
                 if (Cc < kLm0 + 3 * N) Sout[(long long)R * ld + Cc] = Sin[(long long)R * ld + Cc];
@@ -432,7 +449,7 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     // this thread's own 3x3 block of Sigma: issue the loads before the barrier
     const int bi = tid >> 4, bj = tid & 15;
     const int BI = I0 + bi, BJ = J0 + bj;
-    const bool blockValid = !isExtra && BI < N && BJ < N;
+    const bool blockValid = !isExtra && !isTail && BI < N && BJ < N;
     T S[9];
     if (blockValid) {
         const T* src = Sin + (long long)(kLm0 + 3 * BI) * ld + kLm0 + 3 * BJ;
@@ -510,8 +527,8 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     }
 
     EQF_PSTAMP(3);
-    // ---- Sigma'_Ib = G_I F_bb^T + T (B R B^T)_Ib      (the tiles of the LAST tile column own it: they are the lightest)
-    if (tj == lastT) {
+    // ---- Sigma'_Ib = G_I F_bb^T + T (B R B^T)_Ib      (the row-tail workgroup of landmark group I)
+    if (isRowTail) {
         for (int e = tid; e < 16 * 33; e += 256) {
             const int i = e / 33, rc = e % 33, rr = rc / 11, cc = rc % 11;
             const int I = I0 + i;
@@ -529,8 +546,8 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
             if (R < kLm0 + 3 * N) Sout[(long long)R * ld + 11] = (T)0;
         }
     }
-    // ---- Sigma'_bJ = F_bb (Sigma_bb L_J^T + Sigma_bJ D_J^T) + T (B R B^T)_bJ   (tiles of the last tile row)
-    if (ti == lastT) {
+    // ---- Sigma'_bJ = F_bb (Sigma_bb L_J^T + Sigma_bJ D_J^T) + T (B R B^T)_bJ   (the column-tail workgroup of landmark group J)
+    if (isColTail) {
         for (int e = tid; e < 16 * 33; e += 256) {
             const int j = e / 33, rc = e % 33, cc = rc / 3, rr = rc % 3;  // G~_J[cc][rr], cc base row, rr landmark comp
             T acc = 0;
