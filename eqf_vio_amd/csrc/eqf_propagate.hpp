@@ -162,18 +162,28 @@ EQF_DI void stepCommon(const Glob& G, const ImuRec& r, const PropArgs& a, StepCo
 struct LmBlocks {
     m33 D, Lw, Lv;
 };
-EQF_DI LmBlocks buildBlocks(const StepCommon& c, quat Qq, double Qa, d3 p0) {
-    const m33 RQ = q2m(Qq);
+// Lw = -T * B_i needs nothing of the state but T: B_i = Qhat (q^x R_IC^T + R_IC^T x_IC^x)   (EqFMatrices.cpp:371-376)
+EQF_DI m33 buildLw(double T, const m33& RICt, d3 xIC, quat Qq, double Qa, d3 p0) {
     const d3 qhat = scl(1.0 / Qa, qrot(qinv(Qq), p0));  // Q^-1 p0, VIOGroup.cpp:63 / SOT3.cpp:121
+    const m33 Qhat = scl33(Qa, q2m(Qq));
+    const m33 Bi = mul33(Qhat, add33(mul33(skew3(qhat), RICt), mul33(RICt, skew3(xIC))));
+    return scl33(-T, Bi);
+}
+// D = I + T*A_q and Lv = T*A_v need the common linearisation values
+EQF_DI void buildDLv(const StepCommon& c, quat Qq, double Qa, d3 p0, m33* D, m33* Lv) {
+    const m33 RQ = q2m(Qq);
+    const d3 qhat = scl(1.0 / Qa, qrot(qinv(Qq), p0));
     const m33 Qhat = scl33(Qa, RQ);
-    LmBlocks b;
-    b.Lv = scl33(-c.T, mul33(Qhat, mulT33(tr33(c.RIC), c.RA)));  // T * (-Qhat R_IC^T R_A^T)
+    *Lv = scl33(-c.T, mul33(Qhat, mulT33(tr33(c.RIC), c.RA)));  // T * (-Qhat R_IC^T R_A^T)
     // A_q = -Qhat (q^x v^x - 2 v q^T + q v^T) Qhat^-1 / |q|^2 ; the scale a cancels, Qhat^-1 = R_Q^T / a
     const m33 inner = add33(mul33(skew3(qhat), skew3(c.vC)), add33(scl33(-2.0, outer3(c.vC, qhat)), outer3(qhat, c.vC)));
     const m33 Aq = scl33(-1.0 / dot3(qhat, qhat), mul33(RQ, mulT33(inner, RQ)));
-    b.D = add33(eye3(), scl33(c.T, Aq));
-    const m33 Bi = mul33(Qhat, add33(mul33(skew3(qhat), c.RICt), mul33(c.RICt, skew3(c.xIC))));
-    b.Lw = scl33(-c.T, Bi);
+    *D = add33(eye3(), scl33(c.T, Aq));
+}
+EQF_DI LmBlocks buildBlocks(const StepCommon& c, quat Qq, double Qa, d3 p0) {
+    LmBlocks b;
+    buildDLv(c, Qq, Qa, p0, &b.D, &b.Lv);
+    b.Lw = buildLw(c.T, c.RICt, c.xIC, Qq, Qa, p0);
     return b;
 }
 
@@ -318,6 +328,52 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
     int bad = 0;
 
     const int wv = tid >> 6, ln = tid & 63;
+    // ---- waves 1..3 stage the base panels, every thread fetches its own 3x3 block (called after the scalar chains: issuing
+    // these loads before the chains, with the landmark count passed by kernel argument, measured slower)
+    const int bi = tid >> 4, bj = tid & 15;
+    const int BI = I0 + bi, BJ = J0 + bj;
+    const bool blockValid = !isExtra && !isTail && rel < 0 && BI < N && BJ < N;
+    T S[9];
+    auto stageAll = [&]() {
+        if (tid >= 64) {
+            // one flat index space over the three panels; all loads are issued before the first LDS store (one cold-miss
+            // latency for the lot instead of one per trip)
+            constexpr int nA = 11 * kTile, nB = kTile * 12, nC = 132, nAll = nA + nB + nC, kTrips = (nAll + 191) / 192;
+            T buf[kTrips];
+#pragma unroll
+            for (int u = 0; u < kTrips; ++u) {
+                const int e = tid - 64 + 192 * u;
+                T v = (T)0;
+                if (e < nA) {
+                    const int rr = e / kTile, cc = e % kTile;
+                    const int Cc = kLm0 + 3 * J0 + cc;
+                    if (Cc < kLm0 + 3 * N) v = Sin[(long long)rr * ld + Cc];
+                } else if (e < nA + nB) {
+                    const int f = e - nA, rr = f / 12, cc = f % 12;
+                    const int R = kLm0 + 3 * I0 + rr;
+                    if (R < kLm0 + 3 * N && cc < 11) v = Sin[(long long)R * ld + cc];
+                } else if (e < nAll) {
+                    const int f = e - nA - nB, rr = f / 12, cc = f % 12;
+                    if (cc < 11) v = Sin[(long long)rr * ld + cc];
+                }
+                buf[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < kTrips; ++u) {
+                const int e = tid - 64 + 192 * u;
+                if (e < nA) sSbJ[e / kTile][e % kTile] = buf[u];
+                else if (e < nA + nB) sSIb[(e - nA) / 12][(e - nA) % 12] = buf[u];
+                else if (e < nAll) sSbb[(e - nA - nB) / 12][(e - nA - nB) % 12] = buf[u];
+            }
+        }
+        if (blockValid) {
+            const T* src = Sin + (long long)(kLm0 + 3 * BI) * ld + kLm0 + 3 * BJ;
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) S[3 * rr + cc] = src[(long long)rr * ld + cc];
+        }
+    };
     if (isLmWg) {
         // ---- group step Q_i <- Q_i * lift_i of 64 landmarks (VIOGroup.cpp:230-240 / :188-196, :105-107)
         const int i = (rel - 2 - 2 * a.NT) * 64 + ln;
@@ -336,6 +392,24 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
             if (bad && a.errflag) atomicOr(a.errflag, 1);
         }
         return;
+    }
+    if (!PRE && wv == 1 && riccati && ln < 32 && !isExtra && !isState) {
+        // ---- wave 1: the Lw blocks of the tile's landmarks -- they need nothing of the linearisation but T, so they are
+        // built beside wave 0's chain instead of at its end
+        const int i = (ln < 16) ? I0 + ln : J0 + ln - 16;
+        m33 Lw;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Lw.a[k] = 0.0;
+        if (i < N) {
+            m33 RICt;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) RICt.a[k] = a.prm.RICt[k];
+            const quat Qq = quat{Qin[i], Qin[cap + i], Qin[2 * cap + i], Qin[3 * cap + i]};
+            Lw = buildLw(G.accTime + dt0, RICt, mk3(a.prm.camx[0], a.prm.camx[1], a.prm.camx[2]), Qq, Qin[4 * cap + i],
+                mk3(p0[i], p0[cap + i], p0[2 * cap + i]));
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sLw[ln][k] = (T)Lw.a[k];
     }
     if (isState) {
         // ---- scalar state.  Word-parallel copy in -> out, then one lane patches the changed fields
@@ -375,16 +449,16 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
             const int i = (ln < 16) ? I0 + ln : J0 + ln - 16;
             if (i < N) {
                 const quat Qq = quat{Qin[i], Qin[cap + i], Qin[2 * cap + i], Qin[3 * cap + i]};
-                const LmBlocks blk = buildBlocks(c, Qq, Qin[4 * cap + i], mk3(p0[i], p0[cap + i], p0[2 * cap + i]));
+                m33 D, Lv;
+                buildDLv(c, Qq, Qin[4 * cap + i], mk3(p0[i], p0[cap + i], p0[2 * cap + i]), &D, &Lv);
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
-                    sD[ln][k] = (T)blk.D.a[k];
-                    sLw[ln][k] = (T)blk.Lw.a[k];
-                    sLv[ln][k] = (T)blk.Lv.a[k];
+                    sD[ln][k] = (T)D.a[k];
+                    sLv[ln][k] = (T)Lv.a[k];
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < 9; ++k) sD[ln][k] = sLw[ln][k] = sLv[ln][k] = (T)0;
+                for (int k = 0; k < 9; ++k) sD[ln][k] = sLv[ln][k] = (T)0;
             }
         }
         if (ln == 32) {
@@ -429,35 +503,7 @@ __global__ __launch_bounds__(256) void k_propagate(PropArgs a) {
         return;
     }
 
-    // ---- waves 1..3 stage the base panels while wave 0 runs the scalar chain
-    if (tid >= 64) {
-        for (int e = tid - 64; e < 11 * kTile; e += 192) {
-            const int rr = e / kTile, cc = e % kTile;
-            const int Cc = kLm0 + 3 * J0 + cc;
-            sSbJ[rr][cc] = (Cc < kLm0 + 3 * N) ? Sin[(long long)rr * ld + Cc] : (T)0;
-        }
-        for (int e = tid - 64; e < kTile * 12; e += 192) {
-            const int rr = e / 12, cc = e % 12;
-            const int R = kLm0 + 3 * I0 + rr;
-            sSIb[rr][cc] = (R < kLm0 + 3 * N && cc < 11) ? Sin[(long long)R * ld + cc] : (T)0;
-        }
-        if (tid - 64 < 132) {
-            const int rr = (tid - 64) / 12, cc = (tid - 64) % 12;
-            sSbb[rr][cc] = (cc < 11) ? Sin[(long long)rr * ld + cc] : (T)0;
-        }
-    }
-    // this thread's own 3x3 block of Sigma: issue the loads before the barrier
-    const int bi = tid >> 4, bj = tid & 15;
-    const int BI = I0 + bi, BJ = J0 + bj;
-    const bool blockValid = !isExtra && !isTail && BI < N && BJ < N;
-    T S[9];
-    if (blockValid) {
-        const T* src = Sin + (long long)(kLm0 + 3 * BI) * ld + kLm0 + 3 * BJ;
-#pragma unroll
-        for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) S[3 * rr + cc] = src[(long long)rr * ld + cc];
-    }
+    stageAll();
     EQF_PSTAMP(1);
     __syncthreads();
     EQF_PSTAMP(2);

@@ -12,9 +12,10 @@ for kind, k in ev[:38]:
 fb.synchronize()
 out = (C.c_longlong * 1024)()
 hip.lib().eqf_debug_prop_stamps(out)
-a = np.array(out[:]).reshape(512, 2)[:187]
+a = np.array(out[:]).reshape(512, 2)[:201]
 d = a[:, 1] - a[:, 0]
 print("tiles   : median", int(np.median(d[:169])), "max", d[:169].max(), "at", int(d[:169].argmax()))
-print("extra   :", d[169])
-print("tails   :", d[170:183])
-print("landmark:", d[183:187])
+print("base blk:", d[169], " state:", d[170])
+print("row tails:", d[171:184])
+print("col tails:", d[184:197])
+print("landmark:", d[197:201])
