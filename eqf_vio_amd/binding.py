@@ -18,7 +18,7 @@ SKIPPED_NOT_INITIALISED = 3
 SKIPPED_NO_BEARINGS = 4
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSORTED, ERR_NUMERIC, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
 PRECISION_F64, PRECISION_F32 = 0, 1
-PROF_CLASSES = 8
+PROF_CLASSES = 9
 
 _ERR_NAMES = {
     -1: "EQF_ERR_INVALID", -2: "EQF_ERR_NO_DEVICE", -3: "EQF_ERR_HIP", -4: "EQF_ERR_CAPACITY",
@@ -58,7 +58,7 @@ EXPORTED_SYMBOLS = [
     "eqf_settings_default", "eqf_create", "eqf_destroy", "eqf_reset", "eqf_process_imu", "eqf_process_vision",
     "eqf_stream_upload", "eqf_stream_imu", "eqf_stream_vision", "eqf_synchronize", "eqf_get_time", "eqf_num_landmarks",
     "eqf_get_ids", "eqf_get_state_estimate", "eqf_get_origin", "eqf_get_group", "eqf_get_bias", "eqf_get_sigma",
-    "eqf_set_sigma", "eqf_set_state", "eqf_set_camera_offset", "eqf_get_integrator", "eqf_get_last_update", "eqf_device_error", "eqf_set_dense_propagate", "eqf_profile_enable",
+    "eqf_set_sigma", "eqf_set_state", "eqf_set_camera_offset", "eqf_get_integrator", "eqf_get_last_update", "eqf_device_error", "eqf_set_dense_propagate", "eqf_set_imu_burst", "eqf_profile_enable",
     "eqf_profile_get", "eqf_profile_class_name", "eqf_version",
 ]
 
@@ -219,6 +219,11 @@ class FilterBatch:
     def set_dense_propagate(self, on=True):
         """Riccati step as dense F Sigma F^T on the matrix cores (BASELINE cfg 3 cross-check backend)."""
         _check(lib().eqf_set_dense_propagate(self._h, int(bool(on))), "eqf_set_dense_propagate")
+
+    def set_imu_burst(self, max_steps):
+        """IMU calls are queued and launched as bursts of up to `max_steps` steps (0: one launch per call); see
+        include/eqf_vio_amd.h."""
+        _check(lib().eqf_set_imu_burst(self._h, int(max_steps)), "eqf_set_imu_burst")
 
     def synchronize(self):
         _check(lib().eqf_synchronize(self._h), "eqf_synchronize")

@@ -16,6 +16,7 @@
 #include "eqf_dense.hpp"
 #include "eqf_device.hpp"
 #include "eqf_propagate.hpp"
+#include "eqf_burst.hpp"
 #include "eqf_chol64.hpp"
 #include "eqf_update.hpp"
 
@@ -117,6 +118,17 @@ struct eqf_filter {
     int* dMask = nullptr;        // [B]
     hipEvent_t evGate = nullptr;
     int gateSpeculative = 1;     // EQF_GATE_SPECULATIVE = 0: always wait for the gate's answer before the update
+    // IMU bursts (eqf_burst.hpp): processIMUData calls are queued on the host and launched together -- when the queue is
+    // full, when the vision call that follows them arrives (whose integrateUpToTime joins the burst), or when the host
+    // touches the handle in any other way.  burstMax = 0: every call launches at once through k_propagate.
+    int burstMax = kBurstMax;      // EQF_IMU_BURST / eqf_set_imu_burst
+    struct {
+        int kind = 0;              // 0 nothing pending, 1 records k0 .. k0+cnt-1 of the uploaded stream, 2 inline records (one filter)
+        int k0 = 0, cnt = 0;
+        ImuRec inl[kBurstMax];
+    } burst;
+    void *dColRec = nullptr, *dRowRec = nullptr;  // per step and landmark records of k_burst_build
+    BurstStep* dSteps = nullptr;
     int cholSplit = -1;            // -1 heuristic, 0 fused chain launches, 1 panel + update launches (EQF_CHOL_SPLIT)
     // profiling
     bool prof = false;
@@ -246,9 +258,13 @@ int initState(eqf_filter* f) {
 }
 
 int resolveGate(eqf_filter* f);
+int flushBurst(eqf_filter* f);
+// Every entry point that looks at (or changes) the filter first settles what the host has deferred: the speculative gate
+// of the last vision frame, then the queued IMU steps (in this order: they come after that frame).
 #define GATE(f)                          \
     do {                                 \
-        const int grc_ = resolveGate(f); \
+        int grc_ = resolveGate(f);       \
+        if (!grc_) grc_ = flushBurst(f); \
         if (grc_) return grc_;           \
     } while (0)
 
@@ -280,6 +296,8 @@ int releaseSlot(eqf_filter* f, int slot) {
     f->ringUsed[slot] = true;
     return EQF_OK;
 }
+
+void mirrorStep(eqf_filter* f, const double* stamps, bool isImu, int* status);
 
 // integrateUpToTime on the device + host mirror of its control flow.  devRecs == nullptr -> inline (B == 1).
 int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, const double* stamps, bool isImu, bool doRiccati,
@@ -369,7 +387,86 @@ int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, con
     HIPC(hipGetLastError());
     f->pG ^= 1;
     f->pS ^= 1;
-    // host mirror (VIOFilter.cpp:120-131, :146-152, :207)
+    mirrorStep(f, stamps, isImu, status);
+    return EQF_OK;
+}
+
+// K steps in two launches (eqf_burst.hpp).  Steps 0 .. K-1 read devRecs[s * recStride + b] (or inl[s], one filter); with
+// visionLast the last step is the vision call's integrateUpToTime, its record visRec[b] (or inl[K-1]).
+int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride, const ImuRec* inl, bool visionLast, const ImuRec* visRec) {
+    if (K <= 0) return EQF_OK;
+    BurstArgs a{};
+    a.gin = f->g[f->pG];
+    a.gout = f->g[f->pG ^ 1];
+    a.p0 = f->p0;
+    a.Qin = f->Q[f->pG];
+    a.Qout = f->Q[f->pG ^ 1];
+    a.Sin = f->Sigma[f->pS];
+    a.Sout = f->Sigma[f->pS ^ 1];
+    a.recs = devRecs;
+    a.recStride = recStride;
+    a.visRec = visRec;
+    if (inl) std::memcpy(a.inl, inl, sizeof(ImuRec) * K);
+    a.K = K;
+    a.visionLast = visionLast ? 1 : 0;
+    a.errflag = f->errflag;
+    a.sigmaStride = f->sigmaStride;
+    a.cap = f->cap;
+    a.ld = f->ld;
+    a.colRec = f->dColRec;
+    a.rowRec = f->dRowRec;
+    a.steps = f->dSteps;
+    a.prm = f->prm;
+    const int nmx = maxN(f);
+    const dim3 bgrid(std::max(1, (nmx + kBurstLm - 1) / kBurstLm), f->B);
+    // rows per wavefront of the block kernel: one while the launch cannot fill the chip anyway (latency), more once the
+    // column constants of a lane are worth sharing between several of its blocks
+    const long long waves1 = (long long)((nmx + 63) / 64) * nmx * f->B;
+    const int R = waves1 <= 4096 ? 1 : (waves1 <= 32768 ? 2 : 4);
+    const dim3 rgrid((nmx + 63) / 64, (nmx + 4 * R - 1) / (4 * R), f->B);
+    const int rc = profiled(f, EQF_PROF_BURST, [&] {
+        auto go = [&](auto zero) {
+            typedef decltype(zero) TT;
+            hipLaunchKernelGGL(k_burst_build<TT>, bgrid, dim3(kBuildThreads), 0, f->stream, a);
+            if (nmx > 0) {
+                if (R == 1) hipLaunchKernelGGL((k_burst_riccati<TT, 1>), rgrid, dim3(256), 0, f->stream, a);
+                else if (R == 2) hipLaunchKernelGGL((k_burst_riccati<TT, 2>), rgrid, dim3(256), 0, f->stream, a);
+                else hipLaunchKernelGGL((k_burst_riccati<TT, 4>), rgrid, dim3(256), 0, f->stream, a);
+            }
+        };
+        if (f->precision == EQF_PRECISION_F32) go(0.0f);
+        else go(0.0);
+    });
+    if (rc) return rc;
+    HIPC(hipGetLastError());
+    f->pG ^= 1;
+    f->pS ^= 1;
+    return EQF_OK;
+}
+
+bool burstEligible(const eqf_filter* f, bool isImu) {
+    return f->burstMax > 0 && !f->densePropagate && (!isImu || !f->set.fastRiccati);
+}
+
+// launch the queued IMU steps (optionally closed by the integrateUpToTime of a vision call)
+int flushBurstWith(eqf_filter* f, bool visionLast, const ImuRec* visDev, const ImuRec* visInl) {
+    auto& q = f->burst;
+    const int nImu = q.kind ? q.cnt : 0, K = nImu + (visionLast ? 1 : 0);
+    if (K == 0) return EQF_OK;
+    HIPC(hipSetDevice(f->device));
+    ImuRec inl[kBurstMax];
+    const ImuRec* dev = nullptr;
+    if (q.kind == 1) dev = f->sImu + (size_t)q.k0 * f->B;
+    else if (q.kind == 2) std::memcpy(inl, q.inl, sizeof(ImuRec) * nImu);
+    if (visionLast && !visDev) inl[K - 1] = *visInl;
+    q.kind = 0;
+    q.cnt = 0;
+    return launchBurst(f, K, dev, f->B, inl, visionLast, visDev);
+}
+int flushBurst(eqf_filter* f) { return f->burst.kind ? flushBurstWith(f, false, nullptr, nullptr) : EQF_OK; }
+
+// host mirror (VIOFilter.cpp:120-131, :146-152, :207)
+void mirrorStep(eqf_filter* f, const double* stamps, bool isImu, int* status) {
     for (int b = 0; b < f->B; ++b) {
         int st = EQF_OK;
         if (isImu) f->init[b] = 1;  // lazy initialisation happens on the first IMU sample (:122-124)
@@ -379,7 +476,6 @@ int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, con
         if (!isImu && st == EQF_OK && !f->init[b]) st = EQF_SKIPPED_NOT_INITIALISED;
         if (status) status[b] = st;
     }
-    return EQF_OK;
 }
 
 UpdArgs makeUpdArgs(eqf_filter* f, const double* bearings, long long bearStride, const int* perm) {
@@ -845,7 +941,7 @@ void freeAll(eqf_filter* f) {
     for (void* p : {(void*)f->p0, (void*)f->lmc, (void*)f->SA, (void*)f->SL, (void*)f->YW, (void*)f->YO, (void*)f->EA, (void*)f->EL, (void*)f->ZW,
              (void*)f->ZO, (void*)f->dbgDelta, (void*)f->dbgGamma, (void*)f->dbgGammaTot, (void*)f->red, (void*)f->errflag, (void*)f->dMap,
              (void*)f->dNewN, (void*)f->dPerm, (void*)f->dSrc, (void*)f->dChord, (void*)f->dDepth2, (void*)f->dDepthSel, (void*)f->dScratch, (void*)f->dMeas,
-             (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn, f->dBlk, (void*)f->dBlkCommon})
+             (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn, f->dBlk, (void*)f->dBlkCommon, f->dColRec, f->dRowRec, (void*)f->dSteps})
         hipFree(p);
     if (f->hGate) hipHostFree(f->hGate);
     if (f->dMask) hipFree(f->dMask);
@@ -983,6 +1079,10 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     chk(dmalloc(&f->dRing, (size_t)kRing * B));
     if (!rc && hipMalloc(&f->dBlk, f->esz * (size_t)kBlkRec * cap * B) != hipSuccess) rc = EQF_ERR_HIP;
     chk(dmalloc(&f->dBlkCommon, B));
+    if (!rc && hipMalloc(&f->dColRec, f->esz * (size_t)kBurstMax * kColRec * cap * B) != hipSuccess) rc = EQF_ERR_HIP;
+    if (!rc && hipMalloc(&f->dRowRec, f->esz * (size_t)kBurstMax * kBlkRec * cap * B) != hipSuccess) rc = EQF_ERR_HIP;
+    chk(dmalloc(&f->dSteps, (size_t)kBurstMax * B));
+    if (const char* e = std::getenv("EQF_IMU_BURST")) f->burstMax = std::max(0, std::min(kBurstMax, std::atoi(e)));
     if (const char* e = std::getenv("EQF_SPLIT_PROPAGATE")) f->splitPropagate = std::atoi(e);
     if (const char* e = std::getenv("EQF_STREAM_PROPAGATE")) f->streamPropagate = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_MODE")) f->cholMode = std::strcmp(e, "32inv") == 0 ? 33 : (std::strcmp(e, "32") == 0 ? 32 : 64);
@@ -1035,7 +1135,8 @@ int eqf_synchronize(eqf_filter* f) {
 
 int eqf_process_imu(eqf_filter* f, const double* stamps, const double* omega, const double* accel, int* status) {
     if (!f || !stamps || !omega || !accel) return EQF_ERR_INVALID;
-    GATE(f);
+    const bool burst = burstEligible(f, true);
+    if (!(burst && f->B == 1 && f->burst.kind != 1)) GATE(f);  // (a queued call settles nothing: it is only recorded)
     HIPC(hipSetDevice(f->device));
     std::vector<ImuRec> recs(f->B);
     for (int b = 0; b < f->B; ++b) {
@@ -1046,11 +1147,27 @@ int eqf_process_imu(eqf_filter* f, const double* stamps, const double* omega, co
         }
         recs[b].pad_ = 0;
     }
+    if (burst && f->B == 1) {
+        // one filter: queue the record; the burst is launched when it is full or when anything else touches the handle
+        auto& q = f->burst;
+        q.kind = 2;
+        q.inl[q.cnt++] = recs[0];
+        mirrorStep(f, stamps, true, status);
+        if (q.cnt >= std::min(f->burstMax, kBurstMax - 1)) {
+            GATE(f);
+        }
+        return EQF_OK;
+    }
     const ImuRec* dev = nullptr;
     int slot = -1;
     int rc = stageRecs(f, recs.data(), &dev, &slot);
     if (rc) return rc;
-    rc = launchPropagate(f, dev, recs[0], stamps, true, !f->set.fastRiccati, status);
+    if (burst) {
+        rc = launchBurst(f, 1, dev, 0, nullptr, false, nullptr);
+        if (!rc) mirrorStep(f, stamps, true, status);
+    } else {
+        rc = launchPropagate(f, dev, recs[0], stamps, true, !f->set.fastRiccati, status);
+    }
     if (rc) return rc;
     return releaseSlot(f, slot);
 }
@@ -1058,7 +1175,10 @@ int eqf_process_imu(eqf_filter* f, const double* stamps, const double* omega, co
 int eqf_process_vision(eqf_filter* f, const double* stamps, const int* nb, const int* ids, const double* bearings, int stride,
     int* status) {
     if (!f || !stamps || !nb || (!ids && stride > 0) || (!bearings && stride > 0)) return EQF_ERR_INVALID;
-    GATE(f);
+    {
+        const int grc = burstEligible(f, false) ? resolveGate(f) : (resolveGate(f) || flushBurst(f));
+        if (grc) return grc;
+    }
     HIPC(hipSetDevice(f->device));
     const int B = f->B, cap = f->cap;
     for (int b = 0; b < B; ++b) {
@@ -1078,7 +1198,12 @@ int eqf_process_vision(eqf_filter* f, const double* stamps, const int* nb, const
     int rc = stageRecs(f, recs.data(), &dev, &slot);
     if (rc) return rc;
     std::vector<int> st(B, EQF_OK);
-    rc = launchPropagate(f, dev, recs[0], stamps, false, true, st.data());
+    if (burstEligible(f, false)) {
+        rc = flushBurstWith(f, true, dev, &recs[0]);
+        if (!rc) mirrorStep(f, stamps, false, st.data());
+    } else {
+        rc = launchPropagate(f, dev, recs[0], stamps, false, true, st.data());
+    }
     if (rc) return rc;
     rc = releaseSlot(f, slot);
     if (rc) return rc;
@@ -1142,6 +1267,21 @@ int eqf_stream_upload(eqf_filter* f, int K, const double* imu, int F, const doub
 
 int eqf_stream_imu(eqf_filter* f, int k) {
     if (!f || k < 0 || k >= f->sK) return EQF_ERR_INVALID;
+    if (burstEligible(f, true)) {
+        auto& q = f->burst;
+        if (q.kind && !(q.kind == 1 && k == q.k0 + q.cnt)) GATE(f);  // not the record after the queued ones: launch those first
+        if (!q.kind) {
+            q.kind = 1;
+            q.k0 = k;
+            q.cnt = 0;
+        }
+        ++q.cnt;
+        mirrorStep(f, f->hImuStamp.data() + (size_t)k * f->B, true, nullptr);
+        if (q.cnt >= std::min(f->burstMax, kBurstMax - 1)) {
+            GATE(f);
+        }
+        return EQF_OK;
+    }
     GATE(f);
     ImuRec dummy{};
     return launchPropagate(f, f->sImu + (size_t)k * f->B, dummy, f->hImuStamp.data() + (size_t)k * f->B, true, !f->set.fastRiccati, nullptr);
@@ -1149,11 +1289,19 @@ int eqf_stream_imu(eqf_filter* f, int k) {
 
 int eqf_stream_vision(eqf_filter* f, int fr) {
     if (!f || fr < 0 || fr >= f->sF) return EQF_ERR_INVALID;
-    GATE(f);
     const int B = f->B;
     ImuRec dummy{};
     std::vector<int> st(B, EQF_OK);
-    int rc = launchPropagate(f, f->sVis + (size_t)fr * B, dummy, f->hVisStamp.data() + (size_t)fr * B, false, true, st.data());
+    int rc = resolveGate(f);
+    if (rc) return rc;
+    if (burstEligible(f, false)) {
+        // the queued IMU steps and this call's integrateUpToTime leave as one burst
+        rc = flushBurstWith(f, true, f->sVis + (size_t)fr * B, nullptr);
+        if (!rc) mirrorStep(f, f->hVisStamp.data() + (size_t)fr * B, false, st.data());
+    } else {
+        rc = flushBurst(f);
+        if (!rc) rc = launchPropagate(f, f->sVis + (size_t)fr * B, dummy, f->hVisStamp.data() + (size_t)fr * B, false, true, st.data());
+    }
     if (rc) return rc;
     std::vector<const int*> mids(B, f->sIds.data());
     std::vector<int> nbv(B, f->sNb);
@@ -1388,12 +1536,19 @@ int eqf_get_last_update(eqf_filter* f, int b, double* delta, double* gamma, doub
 
 int eqf_device_error(eqf_filter* f) {
     if (!f) return EQF_ERR_INVALID;
-    if (resolveGate(f)) return EQF_ERR_HIP;
+    if (resolveGate(f) || flushBurst(f)) return EQF_ERR_HIP;
     if (hipSetDevice(f->device) != hipSuccess) return EQF_ERR_HIP;
     if (hipStreamSynchronize(f->stream) != hipSuccess) return EQF_ERR_HIP;
     int e = 0;
     if (hipMemcpy(&e, f->errflag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return EQF_ERR_HIP;
     return e;
+}
+
+int eqf_set_imu_burst(eqf_filter* f, int max_steps) {
+    if (!f || max_steps < 0) return EQF_ERR_INVALID;
+    GATE(f);
+    f->burstMax = std::min(max_steps, kBurstMax);
+    return EQF_OK;
 }
 
 int eqf_set_dense_propagate(eqf_filter* f, int on) {
@@ -1472,7 +1627,7 @@ int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_m
 
 const char* eqf_profile_class_name(int cls) {
     static const char* names[EQF_PROF_CLASSES] = {"k_propagate", "k_update_prep", "k_chol_step", "k_update_reduce", "k_update_finish",
-        "k_downdate", "churn", "k_dense_riccati"};
+        "k_downdate", "churn", "k_dense_riccati", "k_imu_burst"};
     return (cls >= 0 && cls < EQF_PROF_CLASSES) ? names[cls] : "?";
 }
 

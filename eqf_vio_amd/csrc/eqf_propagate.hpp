@@ -85,7 +85,9 @@ EQF_DI void poseConstants(quat P0q, double* eta0, double* cDiff, double* cInv, i
 //   kPartLift  Ad(T_IC^-1)(w_cur, vhat), SE3Exp(-dt U_C)            (the landmark group step)
 constexpr int kPartBase = 1, kPartRicc = 2, kPartLift = 4;
 // G is the (read-only) current state; for a vision call only r.stamp is used.
-EQF_DI void stepCommon(const Glob& G, const ImuRec& r, const PropArgs& a, StepCommon& c, int parts, int* bad) {
+// (A: anything with the members prm, isImu, doRiccati -- PropArgs, or the per-step view of the burst kernels)
+template <class Args>
+EQF_DI void stepCommon(const Glob& G, const ImuRec& r, const Args& a, StepCommon& c, int parts, int* bad) {
     const Params& p = a.prm;
     c.dt = r.stamp - G.curTime;
     c.step = (G.curTime >= 0) && (c.dt > 0);  // VIOFilter.cpp:147-152
@@ -188,7 +190,8 @@ EQF_DI LmBlocks buildBlocks(const StepCommon& c, quat Qq, double Qa, d3 p0) {
 }
 
 // Group step of one landmark: Q_i <- Q_i * lift_i   (VIOGroup.cpp:230-240 / :188-196 + SOT3Exp; :105-107)
-EQF_DI void stepLandmark(const StepCommon& c, const PropArgs& a, quat Qq, double Qa, d3 p0, quat* Qo, double* ao, int* bad) {
+template <class Args>
+EQF_DI void stepLandmark(const StepCommon& c, const Args& a, quat Qq, double Qa, d3 p0, quat* Qo, double* ao, int* bad) {
     const d3 qhat = scl(1.0 / Qa, qrot(qinv(Qq), p0));
     quat lq;
     double la;
@@ -210,7 +213,8 @@ EQF_DI void stepLandmark(const StepCommon& c, const PropArgs& a, quat Qq, double
 // Scalar part of the step, one lane per filter: lazy initialisation, X.A, X.w, ZOH bookkeeping.
 // `out` already holds a copy of G (made word-parallel by the calling wave); only changed fields are written, so no
 // private Glob copy (which hipcc would place in scratch) is needed.
-EQF_DI void stepGlobal(const Glob& G, Glob* out, const ImuRec& r, const PropArgs& a, const StepCommon& c, int* bad) {
+template <class Args>
+EQF_DI void stepGlobal(const Glob& G, Glob* out, const ImuRec& r, const Args& a, const StepCommon& c, int* bad) {
     d3 unbW = mk3(0, 0, 0), unbA = mk3(0, 0, 0);
     if (a.isImu) {  // VIOFilter.cpp:121-124
         unbW = mk3(r.w[0] - G.bias[0], r.w[1] - G.bias[1], r.w[2] - G.bias[2]);

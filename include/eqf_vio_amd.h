@@ -141,6 +141,15 @@ int eqf_get_last_update(eqf_filter* f, int b, double* delta, double* gamma, doub
 /* Sticky device-side error flag (NaN / antipodal), 0 if none. */
 int eqf_device_error(eqf_filter* f);
 
+/* IMU bursts.  processIMUData calls (VIOFilter.cpp:120-131) only depend on each other and on the state, so the library
+ * queues them on the host and launches up to 15 of them -- plus the integrateUpToTime of the processVisionData call
+ * that follows (VIOFilter.cpp:233) -- as ONE pair of kernels that reads and writes Sigma once (csrc/eqf_burst.hpp).
+ * Each step is the reference's step, in order; the result does not depend on where the bursts are cut.  A queued call
+ * is launched when the queue is full, when the next vision call arrives, or when any other entry point of the handle
+ * is called (getters, eqf_synchronize, ...): the deferral is invisible apart from timing.  max_steps = 0 launches
+ * every call at once through the single-step kernel (k_propagate); default 15 (environment: EQF_IMU_BURST). */
+int eqf_set_imu_burst(eqf_filter* f, int max_steps);
+
 /* Propagate backend: 0 = block-structured HBM-bound kernel (default, product path),
  * 1 = dense F Sigma F^T on MFMA (what the reference executes; BASELINE cfg 3 cross-check). */
 int eqf_set_dense_propagate(eqf_filter* f, int on);
@@ -155,7 +164,8 @@ int eqf_set_dense_propagate(eqf_filter* f, int on);
 #define EQF_PROF_DOWNDATE 5
 #define EQF_PROF_CHURN 6
 #define EQF_PROF_DENSE 7 /* k_dense_build + the two k_dense_gemm launches of the dense Riccati backend */
-#define EQF_PROF_CLASSES 8
+#define EQF_PROF_BURST 8 /* k_burst_build + k_burst_riccati: one bracket per burst of integrateUpToTime steps */
+#define EQF_PROF_CLASSES 9
 int eqf_profile_enable(eqf_filter* f, int on);
 int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_ms);
 const char* eqf_profile_class_name(int cls);
