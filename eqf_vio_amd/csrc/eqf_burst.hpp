@@ -61,50 +61,199 @@ struct StepView {
     int isImu, doRiccati;
 };
 
+// LDS-only synchronisation.  __syncthreads() / a release fence also drain the wave's GLOBAL stores (s_waitcnt vmcnt(0):
+// ~6 k cycles until the records written in a tick are acknowledged), which nobody in this launch reads.
 EQF_DI void waveSync() {
 #ifdef __HIP_DEVICE_COMPILE__
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS operations of one wave are performed in order
+#endif
+}
+EQF_DI void ldsBarrier() {
+#ifdef __HIP_DEVICE_COMPILE__
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 }
 
-template <typename T>
-struct BurstLds {
-    Glob glob[2];
-    StepCommon com[3];
-    int ricc[3];
-    T F[3][11][12];   // F_bb
-    T Nb[3][11][4];   // gyro columns of B, base rows
-    T RA[3][9];
-    T Tt[3];
-    double Q[2][kBurstLm][5];
-    T blk[2][kBurstLm][28];  // D, Lw, Lv
-    T Sbb[3][11][12];
-    T Tb[11][12];
-    T P[4][12][12];   // Sigma_Ib of the panel wave's 4 landmarks (12 rows x 11 columns)
-    T Gs[4][12][12];  // G_I = L_I Sigma_bb + D_I Sigma_Ib
-    ImuRec rec[kBurstMax];
+#ifdef EQF_BURST_STAMPS
+__device__ long long g_burstStamps[8][20][4];  // [wave][tick]: work begins / ends (workgroup 0)
+#define EQF_BSTAMP(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && t < 20) g_burstStamps[wv][t][k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define EQF_BSTAMP(k) do { } while (0)
+#endif
+
+// State-independent part of a step: functions of the IMU samples and the stamps alone.  All steps of a burst are done at
+// once, one lane per step, so that the serial chain over the steps carries only what really depends on the state.
+struct StepPre {
+    double dt, T;
+    int step, pad_;
+    d3 wcur, acur;   // the zero-order-hold sample the step integrates (currentVelocity)
+    quat lAq;        // se3Exp(dt w_cur, v) = {lAq, VA v}
+    m33 VA;
+    d3 vCpre;        // x_CI^ (R_CI wbar)            (linear part of Ad(T_IC^-1)(wbar, .))
+    d3 oCcur;        // R_CI w_cur
+    d3 vCcurPre;     // x_CI^ (R_CI w_cur)
+    quat camq;       // se3Exp(-dt oCcur, v) = {camq, Vc v}
+    m33 Vc;
 };
 
+template <typename T>
+struct BurstLds {
+    Glob glob[2];       // generic schedule: the scalar state before / after the step of the tick
+    StepCommon com[4];  // rings of 4 (step u in slot u & 3): written in tick u, last read in tick u + 2
+    int ricc[4];
+    T F[4][11][12];     // F_bb
+    T Nb[4][11][4];     // gyro columns of B, base rows
+    T RA[4][9];
+    T Tt[4];
+    T swT[4];           // sigma_w^2 / T
+    double Q[2][kBurstLm][5];
+    T blk[2][kBurstLm][28];  // D, Lw, Lv
+    T Sbb[4][11][12];   // Sigma_bb ENTERING step u in slot u & 3
+    T Tb[11][12];
+    T Gs[4][4][3][12];  // [panel wave][landmark][row]: G_I = L_I Sigma_bb + D_I Sigma_Ib, exchanged between the column lanes
+    ImuRec rec[kBurstMax];
+    StepPre pre[kBurstMax];
+    unsigned stepMask;
+};
+
+// The two 11 x 11 pieces every step needs of its common values: F_bb = I + T [[0,0,0,0],[-B_g^w,0,0,0],[-B_v^w,-R_A,A_vg,0]]
+// (VIOFilter.cpp:178-183) and the gyro columns of B on the base rows.  One wavefront; every lane owns up to three entries
+// of the 11 x 12 arrays, and where an entry comes from (which double of the step's StepCommon, with which sign) is worked
+// out once per launch: per step an entry costs one LDS read and a multiply.
+struct FMap {
+    int off[3];   // index (in doubles, from the start of StepCommon) of the source value, -1: none
+    int sgn[3];   // F = diag + sgn * T * src
+    int nOff[3];  // Nb = src (or 0 if -1), entries with column < 4 only
+    int diag[3];
+};
+EQF_DI FMap burstFMap(int lane) {
+    FMap m;
+    constexpr int oBg = offsetof(StepCommon, Bg) / 8, oBvw = offsetof(StepCommon, Bvw) / 8, oRA = offsetof(StepCommon, RA) / 8,
+                  oAvg = offsetof(StepCommon, Avg) / 8;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int e = lane + 64 * u, rr = e / 12, cc = e % 12;
+        int off = -1, sg = 0, no = -1;
+        if (e < 132) {
+            if (rr >= 6 && rr < 8 && cc < 3) { off = oBg + 3 * (rr - 6) + cc; sg = -1; no = off; }
+            if (rr >= 8) {
+                if (cc < 3) { off = oBvw + 3 * (rr - 8) + cc; sg = -1; no = off; }
+                else if (cc < 6) { off = oRA + 3 * (rr - 8) + cc - 3; sg = -1; }
+                else if (cc < 8) { off = oAvg + 2 * (rr - 8) + cc - 6; sg = 1; }
+            }
+        }
+        m.off[u] = off;
+        m.sgn[u] = sg;
+        m.nOff[u] = no;
+        m.diag[u] = (e < 132 && rr == cc && cc < 11) ? 1 : 0;
+    }
+    return m;
+}
+template <typename T>
+EQF_DI void burstBuildF(BurstLds<T>& s, int sl, int lane, const FMap& m) {
+    const double* src = reinterpret_cast<const double*>(&s.com[sl]);
+    const double Tt = s.com[sl].T;
+    T* Fd = &s.F[sl][0][0];
+    T* Nd = &s.Nb[sl][0][0];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int e = lane + 64 * u;
+        if (e < 132) {
+            const double v = m.off[u] >= 0 ? src[m.off[u]] : 0.0;
+            Fd[e] = (T)((double)m.diag[u] + (double)m.sgn[u] * Tt * v);
+            const int rr = e / 12, cc = e - 12 * rr;
+            if (cc < 4) Nd[4 * rr + cc] = (T)(m.nOff[u] >= 0 ? v : 0.0);
+        }
+    }
+    if (lane < 9) s.RA[sl][lane] = (T)s.com[sl].RA.a[lane];
+}
+
+// Sigma_bb after step u (slot (u + 1) & 3) from Sigma_bb entering it:  F_bb Sigma_bb F_bb^T + T (P_bb + B_b R B_b^T); one
+// wavefront, lane = (row, column mod 4): a row of F_bb (then of F_bb Sigma_bb) stays in registers for the lane's three columns
+template <typename T>
+EQF_DI void burstStepSbb(BurstLds<T>& s, int u, int lane, const Params& p) {
+    const int sl = u & 3, nx = (u + 1) & 3;
+    if (!s.ricc[sl]) {
+        for (int e = lane; e < 132; e += 64) s.Sbb[nx][e / 12][e % 12] = s.Sbb[sl][e / 12][e % 12];
+        return;
+    }
+    const int rr = min(lane >> 2, 10), c0 = lane & 3;
+    const bool act = lane < 44;
+    const T sw2 = (T)p.velOmegaVariance, sa2 = (T)p.velAccelVariance;
+    T fr[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) fr[k] = s.F[sl][rr][k];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int cc = c0 + 4 * j;  // column 11 is the structural pad: F_bb Sigma_bb is zero there
+        T acc = fr[0] * s.Sbb[sl][0][cc];
+#pragma unroll
+        for (int k = 1; k < 11; ++k) acc = fma(fr[k], s.Sbb[sl][k][cc], acc);
+        if (act) s.Tb[rr][cc] = acc;
+    }
+    waveSync();
+    T tr[11], nr[3];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) tr[k] = s.Tb[rr][k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) nr[k] = sw2 * s.Nb[sl][rr][k];
+    const T Tt = s.Tt[sl];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int cc = c0 + 4 * j, cq = min(cc, 10);
+        T acc = tr[0] * s.F[sl][cq][0];
+#pragma unroll
+        for (int k = 1; k < 11; ++k) acc = fma(tr[k], s.F[sl][cq][k], acc);
+        T nz = nr[0] * s.Nb[sl][cq][0];
+#pragma unroll
+        for (int k = 1; k < 3; ++k) nz = fma(nr[k], s.Nb[sl][cq][k], nz);
+        if (rr >= 8 && cc >= 8) {  // accel columns of B: rows 8:11 hold R_A
+#pragma unroll
+            for (int k = 0; k < 3; ++k) nz = fma(sa2 * s.RA[sl][3 * (rr - 8) + k], s.RA[sl][3 * (cq - 8) + k], nz);
+        }
+        if (rr == cc)
+            nz += (T)(rr < 3 ? p.biasOmegaProcessVariance
+                             : (rr < 6 ? p.biasAccelProcessVariance : (rr < 8 ? p.gravityProcessVariance : p.velocityProcessVariance)));
+        if (act) s.Sbb[nx][rr][cc] = cc < 11 ? fma(Tt, nz, acc) : (T)0;
+    }
+    waveSync();
+}
+
+// R(w), V(w) of SE3Exp (SE3.cpp:139-164) -- eqf_math.hpp's se3Exp in two halves: {m2q(R), V} here, V v by the caller
+EQF_DI void se3ExpParts(d3 w, quat* q, m33* V) {
+    double A, B, C;
+    expCoefficients(dot3(w, w), &A, &B, &C);
+    const m33 wx = skew3(w);
+    const m33 wx2 = mul33(wx, wx);
+    const m33 R = add33(eye3(), add33(scl33(A, wx), scl33(B, wx2)));
+    *V = add33(eye3(), add33(scl33(B, wx), scl33(C, wx2)));
+    *q = m2q(R);
+}
+
 // ------------------------------------------------------------------------------------------------
-// k_burst_build: grid = (max(1, ceil(N / 16)), B), block = 512 = 8 wavefronts in a software pipeline, one barrier per tick.
-// In tick t
-//   wave 4      scalar state of step t:            G_{t+1} = stepGlobal(G_t)                           (lane 0)
-//               then Sigma_bb after step t-1
-//   wave 5      common linearisation values, F_bb and the noise input rows of step t (from G_t)
+// k_burst_build: grid = (max(1, ceil(N / 16)), B), block = 512 = 8 wavefronts in a software pipeline, one LDS barrier per
+// tick.  A lone wavefront retires an fp64 instruction every ~6 cycles whatever the dependencies, so the serial chains are
+// laid side by side on different SIMDs; a tick costs its longest stage instead of their sum.
+//
+// FAST schedule (every filter of the handle initialised; the usual case).  Prologue: one lane per STEP computes what depends
+// on the IMU samples only (StepPre: dt, T, the rotation / V matrices of the two SE3 exponentials, ...).  Then, in tick t
+//   wave 4      state recurrence of step t on lane 0 with X.A, X.w in registers (R_A, vhat, etahat, the two group products)
+//               and the common linearisation values of the step
+//   wave 5      F_bb / noise rows of step t-1, then Sigma_bb after step t-2
 //   wave 6      group step of step t-1 for the 16 landmarks:  Q_t = Q_{t-1} * lift
 //   wave 7      blocks D, Lw, Lv of step t-1 (from Q_{t-1})
 //   waves 0..3  panels of step t-2, 4 landmarks each: G rows -> record, Sigma_Ib after the step
-// A lone wavefront retires an fp64 instruction every ~6 cycles whatever the dependencies, so the serial chains are laid
-// side by side on different SIMDs; the tick is the longest stage (~2.5 k cycles) instead of their sum.
+// Generic schedule (some filter still waits for its first IMU sample: lazy initialisation, VIOFilter.cpp:122-124, in the
+// chain): wave 4 runs stepGlobal on the LDS copy of the scalar state (+ Sigma_bb after step t-1), wave 5 stepCommon + F_bb
+// of step t -- the functions of eqf_propagate.hpp as they are.  Both schedules do the same arithmetic per step.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool FAST>
 __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int L0 = blockIdx.x * kBurstLm;
     __shared__ BurstLds<T> s;
-    const int N = a.gin[b].N, K = a.K, cap = a.cap, ld = a.ld;
+    const Glob& G0 = a.gin[b];
+    const int N = G0.N, K = a.K, cap = a.cap, ld = a.ld;
     const bool first = blockIdx.x == 0;
     const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
     T* Sout = static_cast<T*>(a.Sout) + (long long)b * a.sigmaStride;
@@ -119,24 +268,42 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
     const int li = L0 + lane;                   // waves 6, 7: lane = landmark
     const bool lmOk = lane < kBurstLm && li < N;
     d3 q0 = mk3(0, 0, 1);
-    // panel waves: lane -> (row r = (lane >> 4) + 4u of the wave's 12 panel rows, column c = lane & 15)
-    const int pc = lane & 15, pr0 = lane >> 4;
-    const int Lw0 = L0 + 4 * wv;  // first landmark of this panel wave
+    // panel waves: lane = 16 * (landmark of the wave, 0..3) + base column; the landmark's 3 x 11 panel Sigma_Ib lives in the
+    // registers of its 11 column lanes for the whole burst
+    const int pc = lane & 15, pi = lane >> 4;
+    const int plm = L0 + 4 * wv + pi;  // this lane's landmark
+    const bool pOk = wv < 4 && plm < N;
+    T pP[3] = {(T)0, (T)0, (T)0};
+    // wave 4, FAST: the state the recurrence carries, and the constants of the origin
+    quat rAq = quat{1, 0, 0, 0};
+    d3 rAx = mk3(0, 0, 0), rW = mk3(0, 0, 0), rV0 = mk3(0, 0, 0), rEta0 = mk3(0, 0, 1);
     if (wv < 4) {
+        if (pOk && pc < 11) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int r = pr0 + 4 * u, lm = Lw0 + r / 3;
-            T v = (T)0;
-            if (lm < N && pc < 11) v = Sin[(long long)(kLm0 + 3 * Lw0 + r) * ld + pc];
-            if (pc < 12) s.P[wv][r][pc] = v;
+            for (int rr = 0; rr < 3; ++rr) pP[rr] = Sin[(long long)(kLm0 + 3 * plm + rr) * ld + pc];
         }
     } else if (wv == 4) {
-        const double* src = reinterpret_cast<const double*>(a.gin + b);
-        double* dst = reinterpret_cast<double*>(&s.glob[0]);
-        if (lane < (int)(sizeof(Glob) / 8)) dst[lane] = src[lane];
-        for (int e = lane; e < 132; e += 64) {
-            const int rr = e / 12, cc = e % 12;
-            s.Sbb[0][rr][cc] = (cc < 11) ? Sin[(long long)rr * ld + cc] : (T)0;
+        if (FAST) {
+            rAq = quat{G0.Aq[0], G0.Aq[1], G0.Aq[2], G0.Aq[3]};
+            rAx = mk3(G0.Ax[0], G0.Ax[1], G0.Ax[2]);
+            rW = mk3(G0.w[0], G0.w[1], G0.w[2]);
+            rV0 = mk3(G0.v0[0], G0.v0[1], G0.v0[2]);
+            rEta0 = mk3(G0.eta0[0], G0.eta0[1], G0.eta0[2]);
+            if (lane < 4) {  // constants of the camera offset in every slot of the ring
+                StepCommon& c = s.com[lane];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    c.RIC.a[i] = a.prm.RIC[i];
+                    c.RICt.a[i] = a.prm.RICt[i];
+                }
+                c.xIC = mk3(a.prm.camx[0], a.prm.camx[1], a.prm.camx[2]);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) c.Avg[i] = -kGravity * G0.cInv[i];
+            }
+        } else {
+            const double* src = reinterpret_cast<const double*>(a.gin + b);
+            double* dst = reinterpret_cast<double*>(&s.glob[0]);
+            if (lane < (int)(sizeof(Glob) / 8)) dst[lane] = src[lane];
         }
     } else if (wv == 5) {
         for (int e = lane; e < K * 8; e += 64) {
@@ -144,6 +311,51 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
             const ImuRec* rp = (a.visionLast && st == K - 1) ? (a.visRec ? a.visRec + b : &a.inl[st])
                                                              : (a.recs ? a.recs + (long long)st * a.recStride + b : &a.inl[st]);
             reinterpret_cast<double*>(&s.rec[st])[j] = reinterpret_cast<const double*>(rp)[j];
+        }
+        for (int e = lane; e < 132; e += 64) {
+            const int rr = e / 12, cc = e % 12;
+            s.Sbb[0][rr][cc] = (cc < 11) ? Sin[(long long)rr * ld + cc] : (T)0;
+        }
+        if (FAST) {
+            // ---- one lane per step: the state-independent part of every step of the burst
+            waveSync();
+            const int st = lane < K ? lane : K - 1;
+            const ImuRec& r = s.rec[st];
+            // the sample and the time the step starts from: the previous call's (every step but the last is an IMU call)
+            double cv[6];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                cv[i] = st == 0 ? G0.curVel[i] : s.rec[st - (st > 0)].w[i] - G0.bias[i];
+                cv[3 + i] = st == 0 ? G0.curVel[3 + i] : s.rec[st - (st > 0)].a[i] - G0.bias[3 + i];
+            }
+            const double ct = st == 0 ? G0.curTime : s.rec[st - (st > 0)].stamp;
+            StepPre o;
+            o.dt = r.stamp - ct;
+            o.step = (ct >= 0) && (o.dt > 0);  // VIOFilter.cpp:147-152
+            const unsigned long long bal = __ballot(o.step && lane < K);
+            const unsigned mask = (unsigned)bal;
+            if (lane == 0) s.stepMask = mask;
+            // every step of a burst is a Riccati step: the accumulators restart after the first one (VIOFilter.cpp:192-193)
+            const bool fresh = (mask & ((1u << st) - 1u)) == 0;
+            o.T = (fresh ? G0.accTime : 0.0) + o.dt;  // :154
+            o.wcur = mk3(cv[0], cv[1], cv[2]);
+            o.acur = mk3(cv[3], cv[4], cv[5]);
+            o.pad_ = 0;
+            if (o.step) {
+                const double invT = 1.0 / o.T;
+                const d3 wbar = mk3(((fresh ? G0.accVel[0] : 0.0) + o.wcur.x * o.dt) * invT, ((fresh ? G0.accVel[1] : 0.0) + o.wcur.y * o.dt) * invT,
+                    ((fresh ? G0.accVel[2] : 0.0) + o.wcur.z * o.dt) * invT);
+                m33 RcI;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) RcI.a[i] = a.prm.RcamI[i];
+                const d3 xcI = mk3(a.prm.camIx[0], a.prm.camIx[1], a.prm.camIx[2]);
+                o.vCpre = crs(xcI, mv33(RcI, wbar));
+                o.oCcur = mv33(RcI, o.wcur);
+                o.vCcurPre = crs(xcI, o.oCcur);
+                se3ExpParts(scl(o.dt, o.wcur), &o.lAq, &o.VA);  // VIOGroup.cpp:214-217
+                if (a.prm.useDiscreteVelocityLift) se3ExpParts(scl(-o.dt, o.oCcur), &o.camq, &o.Vc);  // :226
+            }
+            if (lane < K) s.pre[lane] = o;
         }
     } else if (wv == 6 || wv == 7) {
         if (lmOk) {
@@ -156,75 +368,99 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
     }
     __syncthreads();
 
-    const T sw2 = (T)a.prm.velOmegaVariance, sa2 = (T)a.prm.velAccelVariance;
+    const T sw2 = (T)a.prm.velOmegaVariance;
     // One tick loop PER ROLE (the branch on the wave index is outside the loops): inside a common loop the compiler hoists the
     // loop invariants of every role at once and the kernel needs the sum of their registers instead of the maximum.  Every
     // wave passes the same number of barriers.
     if (wv == 4) {
         for (int t = 0; t < K + 2; ++t) {
-            if (t < K) {
-                const int cur = t & 1;
-                {
-                    const double* src = reinterpret_cast<const double*>(&s.glob[cur]);
-                    double* dst = reinterpret_cast<double*>(&s.glob[cur ^ 1]);
-                    if (lane < (int)(sizeof(Glob) / 8)) dst[lane] = src[lane];
-                }
-                waveSync();
-                if (lane == 0) {
-                    const StepView v{a.prm, (a.visionLast && t == K - 1) ? 0 : 1, 1};
-                    StepCommon c;
-                    c.step = 0;
-                    stepCommon(s.glob[cur], s.rec[t], v, c, kPartBase, &bad);
-                    stepGlobal(s.glob[cur], &s.glob[cur ^ 1], s.rec[t], v, c, &bad);
-                }
-            }
-            const int st = t - 1;
-            if (st >= 0 && st < K) {
-                const int sl = st % 3, nx = (st + 1) % 3;
-                if (!s.ricc[sl]) {
-                    for (int e = lane; e < 132; e += 64) s.Sbb[nx][e / 12][e % 12] = s.Sbb[sl][e / 12][e % 12];
-                } else {
-                    // Sigma'_bb = F_bb Sigma_bb F_bb^T + T (P_bb + B_b R B_b^T)
-                    for (int e = lane; e < 121; e += 64) {
-                        const int rr = e / 11, cc = e % 11;
-                        T acc = 0;
-#pragma unroll
-                        for (int k = 0; k < 11; ++k) acc += s.F[sl][rr][k] * s.Sbb[sl][k][cc];
-                        s.Tb[rr][cc] = acc;
+            EQF_BSTAMP(0);
+            if (FAST) {
+                if (t < K && lane == 0) {
+                    const StepPre& pr = s.pre[t];
+                    const int sl = t & 3;
+                    StepCommon& c = s.com[sl];
+                    const m33 RA = q2m(rAq);
+                    const d3 vhat = mtv33(RA, sub(rV0, rW));  // X.A.R().inverse() * (v - w)   (VIOGroup.cpp:26,49)
+                    const d3 etahat = mtv33(RA, rEta0);
+                    c.step = pr.step;
+                    s.ricc[sl] = pr.step;
+                    s.Tt[sl] = pr.step ? (T)pr.T : (T)0;
+                    s.swT[sl] = pr.step ? (T)(a.prm.velOmegaVariance / pr.T) : (T)0;
+                    if (first) {
+                        BurstStep bs;
+                        bs.riccati = pr.step;
+                        bs.pad_ = 0;
+                        bs.TtP = pr.step ? pr.T * a.prm.pointProcessVariance : 0.0;
+                        a.steps[b * kBurstMax + t] = bs;
                     }
-                    waveSync();
-                    const T Tt = s.Tt[sl];
-                    for (int e = lane; e < 132; e += 64) {
-                        const int rr = e / 12, cc = e % 12;
-                        T acc = 0;
-                        if (cc < 11) {
+                    if (pr.step) {
+                        // ---- common values (stepCommon's, from the precomputed halves)
+                        m33 RcI;
 #pragma unroll
-                            for (int k = 0; k < 11; ++k) acc += s.Tb[rr][k] * s.F[sl][cc][k];
-                            T nz = 0;
+                        for (int i = 0; i < 9; ++i) RcI.a[i] = a.prm.RcamI[i];
+                        const d3 Rv = mv33(RcI, vhat);
+                        c.dt = pr.dt;
+                        c.T = pr.T;
+                        c.RA = RA;
+                        c.vC = add(pr.vCpre, Rv);                 // EqFMatrices.cpp:302-304
+                        c.oCcur = pr.oCcur;
+                        c.vCcur = add(pr.vCcurPre, Rv);           // VIOGroup.cpp:225
+                        if (a.prm.useDiscreteVelocityLift) c.camInv = se3{pr.camq, mv33(pr.Vc, scl(-pr.dt, c.vCcur))};
+                        const m33 RAg = mul33(RA, skew3(etahat));
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) nz += sw2 * s.Nb[sl][rr][k] * s.Nb[sl][cc][k];
-                            if (rr >= 8 && cc >= 8) {  // accel columns of B: rows 8:11 hold R_A
+                        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                                for (int k = 0; k < 3; ++k) nz += sa2 * s.RA[sl][3 * (rr - 8) + k] * s.RA[sl][3 * (cc - 8) + k];
-                            }
-                            if (rr == cc) {
-                                const Params& p = a.prm;
-                                nz += (T)(rr < 3 ? p.biasOmegaProcessVariance
-                                                 : (rr < 6 ? p.biasAccelProcessVariance : (rr < 8 ? p.gravityProcessVariance : p.velocityProcessVariance)));
-                            }
-                            acc += Tt * nz;
+                            for (int j = 0; j < 3; ++j)
+                                c.Bg[3 * i + j] = G0.cDiff[3 * i] * RAg.a[j] + G0.cDiff[3 * i + 1] * RAg.a[3 + j] + G0.cDiff[3 * i + 2] * RAg.a[6 + j];
+                        c.Bvw = mul33(RA, skew3(vhat));
+                        // ---- the group step of the scalar state (stepGlobal's; VIOGroup.cpp:214-222 / :182-187, :95-96)
+                        const se3 lA = se3{pr.lAq, mv33(pr.VA, scl(pr.dt, vhat))};
+                        d3 lw;
+                        if (a.prm.useDiscreteVelocityLift) {
+                            const d3 inner = add(vhat, scl(pr.dt, add(add(neg(crs(pr.wcur, vhat)), pr.acur), scl(-kGravity, etahat))));
+                            lw = sub(vhat, qrot(lA.q, inner));
+                        } else {
+                            lw = scl(pr.dt, add(neg(pr.acur), scl(kGravity, etahat)));
                         }
-                        s.Sbb[nx][rr][cc] = acc;
+                        const se3 An = se3mul(se3{rAq, rAx}, lA);
+                        rW = add(rW, qrot(rAq, lw));
+                        rAq = An.q;
+                        rAx = An.x;
+                    }
+                }
+            } else {
+                if (t < K) {
+                    const int cur = t & 1;
+                    {
+                        const double* src = reinterpret_cast<const double*>(&s.glob[cur]);
+                        double* dst = reinterpret_cast<double*>(&s.glob[cur ^ 1]);
+                        if (lane < (int)(sizeof(Glob) / 8)) dst[lane] = src[lane];
                     }
                     waveSync();
+                    if (lane == 0) {
+                        const StepView v{a.prm, (a.visionLast && t == K - 1) ? 0 : 1, 1};
+                        StepCommon c;
+                        c.step = 0;
+                        stepCommon(s.glob[cur], s.rec[t], v, c, kPartBase, &bad);
+                        stepGlobal(s.glob[cur], &s.glob[cur ^ 1], s.rec[t], v, c, &bad);
+                    }
                 }
+                if (t >= 1 && t - 1 < K) burstStepSbb(s, t - 1, lane, a.prm);
             }
-            __syncthreads();
+            EQF_BSTAMP(1);
+            ldsBarrier();
         }
     } else if (wv == 5) {
+        const FMap fmap = burstFMap(lane);
         for (int t = 0; t < K + 2; ++t) {
-            if (t < K) {
-                const int sl = t % 3;
+            EQF_BSTAMP(0);
+            if (FAST) {
+                if (t >= 1 && t - 1 < K && s.ricc[(t - 1) & 3]) burstBuildF(s, (t - 1) & 3, lane, fmap);
+                waveSync();
+                if (t >= 2 && t - 2 < K) burstStepSbb(s, t - 2, lane, a.prm);
+            } else if (t < K) {
+                const int sl = t & 3;
                 if (lane == 0) {
                     const StepView v{a.prm, (a.visionLast && t == K - 1) ? 0 : 1, 1};
                     StepCommon c;
@@ -233,6 +469,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
                     s.com[sl] = c;
                     s.ricc[sl] = c.step;
                     s.Tt[sl] = c.step ? (T)c.T : (T)0;
+                    s.swT[sl] = c.step ? (T)(a.prm.velOmegaVariance / c.T) : (T)0;
                     if (first) {
                         BurstStep bs;
                         bs.riccati = c.step;
@@ -242,59 +479,42 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
                     }
                 }
                 waveSync();
-                if (s.ricc[sl]) {
-                    const StepCommon& c = s.com[sl];
-                    // F_bb = I + T * [[0,0,0,0],[-B_g^w,0,0,0],[-B_v^w,-R_A, A_vg, 0]]   (VIOFilter.cpp:178-183)
-                    for (int e = lane; e < 132; e += 64) {
-                        const int rr = e / 12, cc = e % 12;
-                        double f = (rr == cc) ? 1.0 : 0.0;
-                        if (rr >= 6 && rr < 8 && cc < 3) f = -c.T * c.Bg[3 * (rr - 6) + cc];
-                        if (rr >= 8) {
-                            if (cc < 3) f = -c.T * c.Bvw.a[3 * (rr - 8) + cc];
-                            else if (cc < 6) f = -c.T * c.RA.a[3 * (rr - 8) + cc - 3];
-                            else if (cc < 8) f = c.T * c.Avg[2 * (rr - 8) + cc - 6];
-                        }
-                        s.F[sl][rr][cc] = (cc < 11) ? (T)f : (T)0;
-                        if (cc < 4) {
-                            double nb = 0.0;
-                            if (cc < 3 && rr >= 6 && rr < 8) nb = c.Bg[3 * (rr - 6) + cc];
-                            if (cc < 3 && rr >= 8) nb = c.Bvw.a[3 * (rr - 8) + cc];
-                            s.Nb[sl][rr][cc] = (T)nb;
-                        }
-                    }
-                    if (lane < 9) s.RA[sl][lane] = (T)c.RA.a[lane];
-                }
+                if (s.ricc[sl]) burstBuildF(s, sl, lane, fmap);
             }
-            __syncthreads();
+            EQF_BSTAMP(1);
+            ldsBarrier();
         }
     } else if (wv == 6) {
         for (int t = 0; t < K + 2; ++t) {
+            EQF_BSTAMP(0);
             const int st = t - 1;
             if (st >= 0 && st < K && lane < kBurstLm) {
                 const int cur = st & 1;
                 quat Qq = quat{s.Q[cur][lane][0], s.Q[cur][lane][1], s.Q[cur][lane][2], s.Q[cur][lane][3]};
                 double Qa = s.Q[cur][lane][4];
-                if (lmOk && s.com[st % 3].step) {
+                if (lmOk && s.com[st & 3].step) {
                     const StepView v{a.prm, 1, 1};
                     quat Qo;
                     double ao;
-                    stepLandmark(s.com[st % 3], v, Qq, Qa, q0, &Qo, &ao, &bad);
+                    stepLandmark(s.com[st & 3], v, Qq, Qa, q0, &Qo, &ao, &bad);
                     Qq = Qo;
                     Qa = ao;
                 }
                 s.Q[cur ^ 1][lane][0] = Qq.w; s.Q[cur ^ 1][lane][1] = Qq.x; s.Q[cur ^ 1][lane][2] = Qq.y; s.Q[cur ^ 1][lane][3] = Qq.z;
                 s.Q[cur ^ 1][lane][4] = Qa;
             }
-            __syncthreads();
+            EQF_BSTAMP(1);
+            ldsBarrier();
         }
     } else if (wv == 7) {
         for (int t = 0; t < K + 2; ++t) {
+            EQF_BSTAMP(0);
             const int st = t - 1;
-            if (st >= 0 && st < K && lmOk && s.ricc[st % 3]) {
+            if (st >= 0 && st < K && lmOk && s.ricc[st & 3]) {
                 const int cur = st & 1;
                 const quat Qq = quat{s.Q[cur][lane][0], s.Q[cur][lane][1], s.Q[cur][lane][2], s.Q[cur][lane][3]};
                 const double Qa = s.Q[cur][lane][4];
-                const LmBlocks blk = buildBlocks(s.com[st % 3], Qq, Qa, q0);
+                const LmBlocks blk = buildBlocks(s.com[st & 3], Qq, Qa, q0);
                 T* cr = colRec + (long long)st * kColRec * cap + li;
                 T* rr = rowRec + ((long long)st * cap + li) * kBlkRec;
 #pragma unroll
@@ -311,92 +531,136 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
                     rr[18 + k] = lv;
                 }
             }
-            __syncthreads();
+            EQF_BSTAMP(1);
+            ldsBarrier();
         }
     } else {
         for (int t = 0; t < K + 2; ++t) {
+            EQF_BSTAMP(0);
             // ---- panel waves: step t-2
             const int st = t - 2;
-            if (st >= 0 && st < K && s.ricc[st % 3] && Lw0 < N) {
-                const int sl = st % 3, cur = st & 1;
-                T g[3];
-                T* cr = colRec + (long long)st * kColRec * cap;
+            if (st >= 0 && st < K && s.ricc[st & 3] && L0 + 4 * wv < N) {
+                const int sl = st & 3, cur = st & 1;
+                const T* bk = s.blk[cur][4 * wv + pi];  // D, Lw, Lv of the lane's landmark (the same address for its 16 lanes)
+                const int cq = pc < 11 ? pc : 0;
+                T sb[6], g[3];
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const int r = pr0 + 4 * u, jl = r / 3, rr = r - 3 * jl, lmL = 4 * wv + jl, lm = L0 + lmL;
-                    const T* bk = s.blk[cur][lmL];
-                    T acc = 0;
-                    if (pc < 11) {
+                for (int k = 0; k < 3; ++k) {
+                    sb[k] = s.Sbb[sl][k][cq];
+                    sb[3 + k] = s.Sbb[sl][8 + k][cq];
+                }
 #pragma unroll
-                        for (int k = 0; k < 3; ++k)
-                            acc += bk[9 + 3 * rr + k] * s.Sbb[sl][k][pc] + bk[18 + 3 * rr + k] * s.Sbb[sl][8 + k][pc] +
-                                   bk[3 * rr + k] * s.P[wv][3 * jl + k][pc];
-                    }
-                    g[u] = acc;
-                    if (pc < 12) s.Gs[wv][r][pc] = acc;
-                    // records: Gn / Gv for the row side, Sw / Sv (entering the step) for the column side
-                    if (lm < N && (pc < 3 || (pc >= 8 && pc < 11))) {
-                        const int cc = pc < 3 ? pc : pc - 8;
-                        const T gv = pc < 3 ? acc + (sw2 / s.Tt[sl]) * bk[9 + 3 * rr + cc] : acc;
+                for (int rr = 0; rr < 3; ++rr) {
+                    T acc = bk[9 + 3 * rr] * sb[0];
+                    acc = fma(bk[9 + 3 * rr + 1], sb[1], acc);
+                    acc = fma(bk[9 + 3 * rr + 2], sb[2], acc);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc = fma(bk[18 + 3 * rr + k], sb[3 + k], acc);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc = fma(bk[3 * rr + k], pP[k], acc);
+                    g[rr] = pc < 11 ? acc : (T)0;
+                    if (pc < 12) s.Gs[wv][pi][rr][pc] = g[rr];
+                }
+                // records: Gn / Gv for the row side, Sw / Sv (entering the step) for the column side
+                if (pOk && (pc < 3 || (pc >= 8 && pc < 11))) {
+                    const int cc = pc < 3 ? pc : pc - 8;
+                    T* cr = colRec + (long long)st * kColRec * cap + plm;
+                    T* rw = rowRec + ((long long)st * cap + plm) * kBlkRec;
+                    const T swT = s.swT[sl];
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr) {
+                        const T gv = pc < 3 ? fma(swT, bk[9 + 3 * rr + cc], g[rr]) : g[rr];
                         const int ko = (pc < 3 ? 27 : 36) + 3 * rr + cc;
-                        cr[(long long)ko * cap + lm] = gv;
-                        rowRec[((long long)st * cap + lm) * kBlkRec + ko] = gv;
-                        cr[(long long)((pc < 3 ? 45 : 54) + 3 * cc + rr) * cap + lm] = s.P[wv][r][pc];
+                        cr[(long long)ko * cap] = gv;
+                        rw[ko] = gv;
+                        cr[(long long)((pc < 3 ? 45 : 54) + 3 * cc + rr) * cap] = pP[rr];
                     }
                 }
                 waveSync();
                 // Sigma'_Ib = G_I F_bb^T - sigma_w^2 Lw_I Nb^T
+                T fr[11], nb[3];
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const int r = pr0 + 4 * u, jl = r / 3, rr = r - 3 * jl, lmL = 4 * wv + jl;
-                    const T* bk = s.blk[cur][lmL];
-                    if (pc < 11) {
-                        T acc = 0;
+                for (int k = 0; k < 11; ++k) fr[k] = s.F[sl][cq][k];
 #pragma unroll
-                        for (int k = 0; k < 11; ++k) acc += s.Gs[wv][r][k] * s.F[sl][pc][k];
+                for (int k = 0; k < 3; ++k) nb[k] = sw2 * s.Nb[sl][cq][k];
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) acc -= sw2 * bk[9 + 3 * rr + k] * s.Nb[sl][pc][k];
-                        g[u] = acc;
-                    }
+                for (int rr = 0; rr < 3; ++rr) {
+                    const T* gr = s.Gs[wv][pi][rr];
+                    T acc = gr[0] * fr[0];
+#pragma unroll
+                    for (int k = 1; k < 11; ++k) acc = fma(gr[k], fr[k], acc);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc = fma(-bk[9 + 3 * rr + k], nb[k], acc);
+                    pP[rr] = pc < 11 ? acc : (T)0;
                 }
-                waveSync();
-#pragma unroll
-                for (int u = 0; u < 3; ++u)
-                    if (pc < 11) s.P[wv][pr0 + 4 * u][pc] = g[u];
+                waveSync();  // (Gs is rewritten in the next tick)
             }
-            __syncthreads();
+            EQF_BSTAMP(1);
+            ldsBarrier();
         }
     }
 
     // ---- epilogue
     if (wv < 4) {
+        if (pOk && pc < 12) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int r = pr0 + 4 * u, lm = Lw0 + r / 3;
-            if (lm < N && pc < 12) {
-                const T v = pc < 11 ? s.P[wv][r][pc] : (T)0;
-                Sout[(long long)(kLm0 + 3 * Lw0 + r) * ld + pc] = v;   // Sigma_Ib
-                Sout[(long long)pc * ld + kLm0 + 3 * Lw0 + r] = v;     // Sigma_bI: its transpose
+            for (int rr = 0; rr < 3; ++rr) {
+                const T v = pc < 11 ? pP[rr] : (T)0;
+                Sout[(long long)(kLm0 + 3 * plm + rr) * ld + pc] = v;   // Sigma_Ib
+                Sout[(long long)pc * ld + kLm0 + 3 * plm + rr] = v;     // Sigma_bI: its transpose
             }
         }
     } else if (wv == 4) {
         if (first) {
-            const double* src = reinterpret_cast<const double*>(&s.glob[K & 1]);
             double* dst = reinterpret_cast<double*>(a.gout + b);
-            if (lane < (int)(sizeof(Glob) / 8)) dst[lane] = src[lane];
+            if (FAST) {
+                // the scalar state after the burst: a copy of G0 with what the K calls changed (stepGlobal, field by field)
+                const double* src = reinterpret_cast<const double*>(a.gin + b);
+                if (lane < (int)(sizeof(Glob) / 8)) dst[lane] = src[lane];
+                waveSync();
+                if (lane == 0) {
+                    Glob* out = a.gout + b;
+                    const unsigned mask = s.stepMask;
+                    const int nImu = K - (a.visionLast ? 1 : 0);
+                    out->Aq[0] = rAq.w; out->Aq[1] = rAq.x; out->Aq[2] = rAq.y; out->Aq[3] = rAq.z;
+                    out->Ax[0] = rAx.x; out->Ax[1] = rAx.y; out->Ax[2] = rAx.z;
+                    out->w[0] = rW.x; out->w[1] = rW.y; out->w[2] = rW.z;
+                    if (mask) {  // VIOFilter.cpp:192-193 (every step of a burst is a Riccati step)
+                        out->accTime = 0.0;
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) out->accVel[i] = 0.0;
+                    }
+                    if (nImu > 0) {  // VIOFilter.cpp:129-130
+                        const ImuRec& r = s.rec[nImu - 1];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            out->curVel[i] = r.w[i] - G0.bias[i];
+                            out->curVel[3 + i] = r.a[i] - G0.bias[3 + i];
+                        }
+                        out->curTime = r.stamp;
+                    }
+                    if (a.visionLast) {
+                        const int ok = (mask >> (K - 1)) & 1;
+                        if (ok) out->curTime = s.rec[K - 1].stamp;  // :207
+                        out->updateOk = (ok && G0.initialised) ? 1 : 0;  // :234-236
+                    }
+                }
+            } else {
+                const double* src = reinterpret_cast<const double*>(&s.glob[K & 1]);
+                if (lane < (int)(sizeof(Glob) / 8)) dst[lane] = src[lane];
+            }
         }
+    } else if (wv == 5) {
+        if (first)
+            for (int e = lane; e < 144; e += 64) {
+                const int rr = e / 12, cc = e % 12;
+                Sout[(long long)rr * ld + cc] = (rr < 11 && cc < 11) ? s.Sbb[K & 3][rr][cc] : (T)0;
+            }
     } else if (wv == 6) {
         if (lmOk) {
 #pragma unroll
             for (int k = 0; k < 5; ++k) Qout[k * cap + li] = s.Q[K & 1][lane][k];
         }
-    }
-    if (wv == 4) {
-        if (first)
-            for (int e = lane; e < 144; e += 64) {
-                const int rr = e / 12, cc = e % 12;
-                Sout[(long long)rr * ld + cc] = (rr < 11 && cc < 11) ? s.Sbb[K % 3][rr][cc] : (T)0;
-            }
     }
     if (bad && a.errflag) atomicOr(a.errflag, 1);
 }
@@ -425,7 +689,7 @@ __global__ __launch_bounds__(256) void k_burst_riccati(BurstArgs a) {
     const T* rowRec = static_cast<const T*>(a.rowRec) + (long long)b * kBurstMax * cap * kBlkRec + (long long)I0 * kBlkRec;
     const BurstStep* steps = a.steps + b * kBurstMax;
     constexpr int kRowVals = R * kBlkRec, kRowTrips = (kRowVals + 63) / 64;
-    __shared__ T sRow[4][2][kRowVals];
+    __shared__ T sRow[4][kRowVals];
 
     T S[R][9];
 #pragma unroll
@@ -437,41 +701,50 @@ __global__ __launch_bounds__(256) void k_burst_riccati(BurstArgs a) {
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc) S[i][3 * rr + cc] = src[(long long)rr * ld + cc];
     }
-    T cA[kBlkRec], cB[kBlkRec], rA[kRowTrips], rB[kRowTrips];
-    auto fetch = [&](int st, T* c, T* rv) {
+    // which steps touch Sigma (bit s), fetched once
+    unsigned todo = 0;
+    for (int st = 0; st < K; ++st) todo |= steps[st].riccati ? (1u << st) : 0u;
+    constexpr int kC = kBlkRec + 1;  // column constants + T p of the step
+    T cA[kC], cB[kC], rA[kRowTrips], rB[kRowTrips];
+    auto fetch = [&](int st, T* c, T* rv) __attribute__((always_inline)) {
         const T* cp = colRec + (long long)st * kColRec * cap;
 #pragma unroll
         for (int k = 0; k < 27; ++k) c[k] = cp[(long long)k * cap];
 #pragma unroll
         for (int k = 0; k < 18; ++k) c[27 + k] = cp[(long long)(45 + k) * cap];
+        c[kBlkRec] = (T)steps[st].TtP;
         const T* rp = rowRec + (long long)st * cap * kBlkRec;
 #pragma unroll
         for (int u = 0; u < kRowTrips; ++u) {
-            const int e = lane + 64 * u;
-            rv[u] = (e < nI * kBlkRec) ? rp[e] : (T)0;
+            const int e = min(lane + 64 * u, nI * kBlkRec - 1);
+            rv[u] = rp[e];
         }
     };
-    auto body = [&](int st, const T* c, const T* rv) {
-        T* row = sRow[wv][st & 1];
+    // row constants of the step -> wave-private LDS (they arrived with the column constants of the same step)
+    auto stage = [&](const T* rv) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < kRowTrips; ++u) {
             const int e = lane + 64 * u;
-            if (e < kRowVals) row[e] = rv[u];
+            if (e < kRowVals) sRow[wv][e] = rv[u];
         }
         waveSync();
-        const T TtP = (T)steps[st].TtP;
+    };
+    auto math = [&](const T* c) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const T* rc = row + i * kBlkRec;  // wave-uniform: LDS broadcast reads
+            const T* rc = sRow[wv] + i * kBlkRec;  // wave-uniform: LDS broadcast reads
             T H[9];
 #pragma unroll
             for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
                 for (int cc = 0; cc < 3; ++cc) {
-                    T acc = 0;
+                    T acc = rc[3 * rr] * S[i][cc];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k)
-                        acc += rc[3 * rr + k] * S[i][3 * k + cc] + rc[9 + 3 * rr + k] * c[27 + 3 * k + cc] + rc[18 + 3 * rr + k] * c[36 + 3 * k + cc];
+                    for (int k = 1; k < 3; ++k) acc = fma(rc[3 * rr + k], S[i][3 * k + cc], acc);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc = fma(rc[9 + 3 * rr + k], c[27 + 3 * k + cc], acc);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc = fma(rc[18 + 3 * rr + k], c[36 + 3 * k + cc], acc);
                     H[3 * rr + cc] = acc;
                 }
             const bool diag = (I0 + i) == J;
@@ -479,30 +752,39 @@ __global__ __launch_bounds__(256) void k_burst_riccati(BurstArgs a) {
             for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
                 for (int cc = 0; cc < 3; ++cc) {
-                    T acc = (diag && rr == cc) ? TtP : (T)0;
+                    T acc = (diag && rr == cc) ? c[kBlkRec] : (T)0;
 #pragma unroll
-                    for (int k = 0; k < 3; ++k)
-                        acc += H[3 * rr + k] * c[3 * cc + k] + rc[27 + 3 * rr + k] * c[9 + 3 * cc + k] + rc[36 + 3 * rr + k] * c[18 + 3 * cc + k];
+                    for (int k = 0; k < 3; ++k) acc = fma(H[3 * rr + k], c[3 * cc + k], acc);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc = fma(rc[27 + 3 * rr + k], c[9 + 3 * cc + k], acc);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc = fma(rc[36 + 3 * rr + k], c[18 + 3 * cc + k], acc);
                     S[i][3 * rr + cc] = acc;
                 }
+            waveSync();  // (the next stage() overwrites the rows)
         }
     };
-    // first step that touches Sigma, then ping-pong between the two register sets
-    int st = 0;
-    while (st < K && !steps[st].riccati) ++st;
-    if (st < K) fetch(st, cA, rA);
-    while (st < K) {
-        int nx = st + 1;
-        while (nx < K && !steps[nx].riccati) ++nx;
-        if (nx < K) fetch(nx, cB, rB);
-        body(st, cA, rA);
-        st = nx;
-        if (st >= K) break;
-        nx = st + 1;
-        while (nx < K && !steps[nx].riccati) ++nx;
-        if (nx < K) fetch(nx, cA, rA);
-        body(st, cB, rB);
-        st = nx;
+    // ping-pong between the two register sets: the fetch of the next step is issued after this step's constants have
+    // arrived (they are all needed at once) and flies during its arithmetic
+    auto next = [&]() __attribute__((always_inline)) {
+        const int st = todo ? __builtin_ctz(todo) : -1;
+        todo &= todo - 1;
+        return st;
+    };
+    // (the fetch is unconditional -- after the last step it re-reads that step -- so that the compiler's wait counters know
+    // that the loads it waits for are older than a full set of newer ones, instead of draining the queue)
+    int st = next();
+    if (st >= 0) fetch(st, cA, rA);
+    while (st >= 0) {
+        stage(rA);
+        int nx = next();
+        fetch(nx >= 0 ? nx : st, cB, rB);
+        math(cA);
+        if (nx < 0) break;
+        stage(rB);
+        st = next();
+        fetch(st >= 0 ? st : nx, cA, rA);
+        math(cB);
     }
     if (validJ) {
 #pragma unroll

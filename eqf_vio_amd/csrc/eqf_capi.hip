@@ -95,6 +95,7 @@ struct eqf_filter {
     std::vector<std::vector<int>> ids;
     std::vector<double> curTime;
     std::vector<char> init;
+    std::vector<char> devInit;  // the filter's lazy initialisation has been LAUNCHED (init is set when the call is queued)
     int densePropagate = 0;
     void *dF = nullptr, *dG = nullptr, *dBn = nullptr;  // dense backend: F, G = F Sigma, Bn (n x 6)
     void* dBlk = nullptr;          // split propagate path: per-landmark records [B][cap][kBlkRec] (T)
@@ -254,6 +255,7 @@ int initState(eqf_filter* f) {
     f->ids.assign(B, {});
     f->curTime.assign(B, -1.0);
     f->init.assign(B, 0);
+    f->devInit.assign(B, 0);
     return EQF_OK;
 }
 
@@ -387,6 +389,7 @@ int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, con
     HIPC(hipGetLastError());
     f->pG ^= 1;
     f->pS ^= 1;
+    if (isImu) std::fill(f->devInit.begin(), f->devInit.end(), 1);
     mirrorStep(f, stamps, isImu, status);
     return EQF_OK;
 }
@@ -424,10 +427,14 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     const long long waves1 = (long long)((nmx + 63) / 64) * nmx * f->B;
     const int R = waves1 <= 4096 ? 1 : (waves1 <= 32768 ? 2 : 4);
     const dim3 rgrid((nmx + 63) / 64, (nmx + 4 * R - 1) / (4 * R), f->B);
+    // every filter past its lazy initialisation (VIOFilter.cpp:122-124): the schedule with the precomputed step halves
+    bool fast = true;
+    for (int b = 0; b < f->B; ++b) fast = fast && f->devInit[b];
     const int rc = profiled(f, EQF_PROF_BURST, [&] {
         auto go = [&](auto zero) {
             typedef decltype(zero) TT;
-            hipLaunchKernelGGL(k_burst_build<TT>, bgrid, dim3(kBuildThreads), 0, f->stream, a);
+            if (fast) hipLaunchKernelGGL((k_burst_build<TT, true>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
+            else hipLaunchKernelGGL((k_burst_build<TT, false>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
             if (nmx > 0) {
                 if (R == 1) hipLaunchKernelGGL((k_burst_riccati<TT, 1>), rgrid, dim3(256), 0, f->stream, a);
                 else if (R == 2) hipLaunchKernelGGL((k_burst_riccati<TT, 2>), rgrid, dim3(256), 0, f->stream, a);
@@ -441,6 +448,7 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     HIPC(hipGetLastError());
     f->pG ^= 1;
     f->pS ^= 1;
+    if (K - (visionLast ? 1 : 0) > 0) std::fill(f->devInit.begin(), f->devInit.end(), 1);
     return EQF_OK;
 }
 
@@ -973,6 +981,11 @@ extern "C" int eqf_debug_prop_stamps(long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_propStamps), sizeof(long long) * 32) == hipSuccess ? 0 : -1;
 }
 #endif
+#ifdef EQF_BURST_STAMPS
+extern "C" int eqf_debug_burst_stamps(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_burstStamps), sizeof(long long) * 8 * 20 * 4) == hipSuccess ? 0 : -1;
+}
+#endif
 const char* eqf_version(void) { return "eqf_vio_amd 0.1 (gfx950)"; }
 
 void eqf_settings_default(eqf_settings* s) {  // VIOFilterSettings.h:29-50
@@ -1497,6 +1510,7 @@ int eqf_set_state(eqf_filter* f, int b, int N, const int* ids, const double* pos
     f->ids[b].assign(ids, ids + N);
     f->curTime[b] = currentTime;
     f->init[b] = initialised ? 1 : 0;
+    f->devInit[b] = f->init[b];
     hipLaunchKernelGGL(k_restore_constants, dim3((N + 127) / 128 + 1), dim3(128), 0, f->stream, f->g[f->pG], b, f->p0, f->lmc, cap, f->errflag);
     HIPC(hipGetLastError());
     return eqf_set_sigma(f, b, sigma, ld);

@@ -1,0 +1,26 @@
+"""Per-wave, per-tick cycle stamps of k_burst_build (library built with -DEQF_BURST_STAMPS): where a tick's time goes."""
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from eqf_vio_amd import binding as hip, synth
+N = 200
+st = synth.make_stream(N, duration=0.3)
+fb = hip.FilterBatch(synth.template_settings_dict(), capacity=N, batch=1)
+fb.stream_upload(st.imu, st.vision_stamps, st.ids, st.bearings)
+ev = list(st.events())
+for kind, k in ev[:50]:
+    (fb.stream_imu if kind == "imu" else fb.stream_vision)(k)
+fb.synchronize()
+out = (C.c_longlong * 640)()
+hip.lib().eqf_debug_burst_stamps(out)
+a = np.array(out[:]).reshape(8, 20, 4)
+t0 = a[:, 0, 0].min()
+names = ["panel0", "panel1", "panel2", "panel3", "glob+Sbb", "common+F", "lift", "blocks"]
+print("tick:      " + " ".join("%6d" % t for t in range(14)))
+for w in range(8):
+    print("%-9s b " % names[w] + " ".join("%6d" % (a[w, t, 0] - t0) for t in range(14)))
+    print("%-9s d " % names[w] + " ".join("%6d" % (a[w, t, 1] - a[w, t, 0]) for t in range(14)))
+for w in range(4):
+    print("%-9s G " % names[w] + " ".join("%6d" % (a[w, t, 2] - a[w, t, 0]) for t in range(2, 13)))
+    print("%-9s R " % names[w] + " ".join("%6d" % (a[w, t, 3] - a[w, t, 2]) for t in range(2, 13)))
+    print("%-9s P " % names[w] + " ".join("%6d" % (a[w, t, 1] - a[w, t, 3]) for t in range(2, 13)))
