@@ -666,6 +666,138 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_burst_riccati_ring: the landmark x landmark blocks of a SMALL problem (the launch cannot fill the chip, every wave is
+// bound by latency).  The records were written by k_burst_build on other XCDs, so the first touch of every step's
+// constants is a ~2 us miss: a one-step register prefetch cannot cover it.  Here the four wavefronts of a workgroup share
+// their 64 column landmarks (one row landmark each): each wave fetches a QUARTER of a step's 45 x 64 column constants, TWO
+// steps ahead (two register sets of 13 values), and passes them on through a two-slot LDS ring one step before they are
+// used -- loads have two full steps to arrive.  grid = (ceil(N / 64), ceil(N / 4), B), block = 256.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRingTrips = 12;  // column-constant rows per wave and step: 45 rows over 4 waves
+template <typename T>
+__global__ __launch_bounds__(256) void k_burst_riccati_ring(BurstArgs a) {
+    const int b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int N = a.gin[b].N, K = a.K, cap = a.cap, ld = a.ld;
+    const int J = blockIdx.x * 64 + lane;
+    const int Iraw = blockIdx.y * 4 + wv;
+    const bool rowOk = Iraw < N, validJ = J < N;
+    const int I = rowOk ? Iraw : N - 1, Jc = validJ ? J : 0;
+    const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
+    T* Sout = static_cast<T*>(a.Sout) + (long long)b * a.sigmaStride;
+    const T* colRec = static_cast<const T*>(a.colRec) + (long long)b * kBurstMax * kColRec * cap + Jc;
+    const T* rowRec = static_cast<const T*>(a.rowRec) + (long long)b * kBurstMax * cap * kBlkRec + (long long)I * kBlkRec;
+    const BurstStep* steps = a.steps + b * kBurstMax;
+    __shared__ T sCol[2][kBlkRec][64];
+    __shared__ T sRow[4][2][kBlkRec + 3];
+    __shared__ T sTtP[kBurstMax];
+    __shared__ int sRicc[kBurstMax];
+
+    T S[9];
+    {
+        const T* src = Sin + (long long)(kLm0 + 3 * I) * ld + kLm0 + 3 * Jc;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) S[3 * rr + cc] = src[(long long)rr * ld + cc];
+    }
+    if (tid < K) {
+        sTtP[tid] = (T)steps[tid].TtP;
+        sRicc[tid] = steps[tid].riccati;
+    }
+    // this wave's share of a step's column constants: ring rows q = wv + 4 j  (source row q, or q + 18 for Sw / Sv)
+    T xA[kRingTrips + 1], xB[kRingTrips + 1];
+    auto fetch = [&](int st, T* x) __attribute__((always_inline)) {
+        const int sc = min(st, K - 1);  // (past the end: re-read the last step, nobody uses it)
+        const T* cp = colRec + (long long)sc * kColRec * cap;
+#pragma unroll
+        for (int j = 0; j < kRingTrips; ++j) {
+            const int q = min(wv + 4 * j, kBlkRec - 1);
+            x[j] = cp[(long long)(q < 27 ? q : q + 18) * cap];
+        }
+        x[kRingTrips] = rowRec[(long long)sc * cap * kBlkRec + min(lane, kBlkRec - 1)];
+    };
+    auto pass = [&](int st, const T* x) __attribute__((always_inline)) {
+        const int sl = st & 1;
+#pragma unroll
+        for (int j = 0; j < kRingTrips; ++j) {
+            const int q = wv + 4 * j;
+            if (q < kBlkRec) sCol[sl][q][lane] = x[j];
+        }
+        if (lane < kBlkRec) sRow[wv][sl][lane] = x[kRingTrips];
+    };
+    auto math = [&](int st) __attribute__((always_inline)) {
+        const int sl = st & 1;
+        const T* rc = sRow[wv][sl];  // wave-uniform: LDS broadcast reads
+        T Sw[9], Sv[9], H[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            Sw[k] = sCol[sl][27 + k][lane];
+            Sv[k] = sCol[sl][36 + k][lane];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                T acc = rc[3 * rr] * S[cc];
+#pragma unroll
+                for (int k = 1; k < 3; ++k) acc = fma(rc[3 * rr + k], S[3 * k + cc], acc);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc = fma(rc[9 + 3 * rr + k], Sw[3 * k + cc], acc);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc = fma(rc[18 + 3 * rr + k], Sv[3 * k + cc], acc);
+                H[3 * rr + cc] = acc;
+            }
+        T c[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) c[k] = sCol[sl][k][lane];
+        const T TtP = sTtP[st];
+        const bool diag = Iraw == J;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                T acc = (diag && rr == cc) ? TtP : (T)0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc = fma(H[3 * rr + k], c[3 * cc + k], acc);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc = fma(rc[27 + 3 * rr + k], c[9 + 3 * cc + k], acc);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc = fma(rc[36 + 3 * rr + k], c[18 + 3 * cc + k], acc);
+                S[3 * rr + cc] = acc;
+            }
+    };
+    // prologue: steps 0 and 1 in flight, step 0 handed to the ring, step 2 issued
+    fetch(0, xA);
+    fetch(1, xB);
+    __builtin_amdgcn_sched_barrier(0);
+    pass(0, xA);
+    fetch(2, xA);
+    __builtin_amdgcn_sched_barrier(0);
+    ldsBarrier();
+    for (int st = 0; st < K; st += 2) {
+        // even step: its constants are in the ring; xB holds step st+1 (issued two steps ago), xA step st+2
+        if (sRicc[st]) math(st);
+        pass(st + 1, xB);
+        fetch(st + 3, xB);
+        __builtin_amdgcn_sched_barrier(0);
+        ldsBarrier();  // (LDS only: __syncthreads() would also drain the prefetches, loads and stores share vmcnt)
+        if (st + 1 >= K) break;
+        if (sRicc[st + 1]) math(st + 1);
+        pass(st + 2, xA);
+        fetch(st + 4, xA);
+        __builtin_amdgcn_sched_barrier(0);
+        ldsBarrier();  // (LDS only: __syncthreads() would also drain the prefetches, loads and stores share vmcnt)
+    }
+    if (validJ && rowOk) {
+        T* dst = Sout + (long long)(kLm0 + 3 * I) * ld + kLm0 + 3 * J;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) dst[(long long)rr * ld + cc] = S[3 * rr + cc];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_burst_riccati: the landmark x landmark blocks, all K steps in registers.
 //   Sigma'_IJ = (D_I Sigma_IJ + Lw_I Sw_J + Lv_I Sv_J) D_J^T + Gn_I Lw_J^T + Gv_I Lv_J^T  (+ T p I on the diagonal)
 // grid = (ceil(N / 64), ceil(N / (4 R)), B), block = 256: lane = column landmark J, each wavefront owns R row landmarks.
@@ -779,11 +911,13 @@ __global__ __launch_bounds__(256) void k_burst_riccati(BurstArgs a) {
         stage(rA);
         int nx = next();
         fetch(nx >= 0 ? nx : st, cB, rB);
+        __builtin_amdgcn_sched_barrier(0);  // (keep the loads here: the scheduler would sink them behind the arithmetic)
         math(cA);
         if (nx < 0) break;
         stage(rB);
         st = next();
         fetch(st >= 0 ? st : nx, cA, rA);
+        __builtin_amdgcn_sched_barrier(0);
         math(cB);
     }
     if (validJ) {

@@ -123,6 +123,7 @@ struct eqf_filter {
     // full, when the vision call that follows them arrives (whose integrateUpToTime joins the burst), or when the host
     // touches the handle in any other way.  burstMax = 0: every call launches at once through k_propagate.
     int burstMax = kBurstMax;      // EQF_IMU_BURST / eqf_set_imu_burst
+    int burstRing = 1;             // small problems: k_burst_riccati_ring (EQF_BURST_RING = 0: k_burst_riccati<1>)
     struct {
         int kind = 0;              // 0 nothing pending, 1 records k0 .. k0+cnt-1 of the uploaded stream, 2 inline records (one filter)
         int k0 = 0, cnt = 0;
@@ -436,7 +437,8 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
             if (fast) hipLaunchKernelGGL((k_burst_build<TT, true>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
             else hipLaunchKernelGGL((k_burst_build<TT, false>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
             if (nmx > 0) {
-                if (R == 1) hipLaunchKernelGGL((k_burst_riccati<TT, 1>), rgrid, dim3(256), 0, f->stream, a);
+                if (R == 1 && f->burstRing) hipLaunchKernelGGL(k_burst_riccati_ring<TT>, rgrid, dim3(256), 0, f->stream, a);
+                else if (R == 1) hipLaunchKernelGGL((k_burst_riccati<TT, 1>), rgrid, dim3(256), 0, f->stream, a);
                 else if (R == 2) hipLaunchKernelGGL((k_burst_riccati<TT, 2>), rgrid, dim3(256), 0, f->stream, a);
                 else hipLaunchKernelGGL((k_burst_riccati<TT, 4>), rgrid, dim3(256), 0, f->stream, a);
             }
@@ -1095,6 +1097,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (!rc && hipMalloc(&f->dColRec, f->esz * (size_t)kBurstMax * kColRec * cap * B) != hipSuccess) rc = EQF_ERR_HIP;
     if (!rc && hipMalloc(&f->dRowRec, f->esz * (size_t)kBurstMax * kBlkRec * cap * B) != hipSuccess) rc = EQF_ERR_HIP;
     chk(dmalloc(&f->dSteps, (size_t)kBurstMax * B));
+    if (const char* e = std::getenv("EQF_BURST_RING")) f->burstRing = std::atoi(e);
     if (const char* e = std::getenv("EQF_IMU_BURST")) f->burstMax = std::max(0, std::min(kBurstMax, std::atoi(e)));
     if (const char* e = std::getenv("EQF_SPLIT_PROPAGATE")) f->splitPropagate = std::atoi(e);
     if (const char* e = std::getenv("EQF_STREAM_PROPAGATE")) f->streamPropagate = std::atoi(e);
