@@ -99,6 +99,7 @@ def lib():
         L.eqf_get_integrator.argtypes = [vp, C.c_int, _dp, _dp, _dp, _ip]
         L.eqf_device_error.argtypes = [vp]
         L.eqf_set_dense_propagate.argtypes = [vp, C.c_int]
+        L.eqf_set_imu_burst.argtypes = [vp, C.c_int]
         L.eqf_profile_enable.argtypes = [vp, C.c_int]
         L.eqf_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_longlong), _dp]
         L.eqf_profile_class_name.argtypes = [C.c_int]

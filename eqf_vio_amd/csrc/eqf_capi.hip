@@ -395,6 +395,15 @@ int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, con
     return EQF_OK;
 }
 
+// Until every filter has seen its first IMU sample (lazy initialisation, VIOFilter.cpp:122-124) calls are not queued: the
+// generic schedule of the builder then only ever runs single steps, and everything after it is the fast schedule -- so
+// the arithmetic of a step never depends on where the bursts are cut.
+bool allDevInit(const eqf_filter* f) {
+    for (char c : f->devInit)
+        if (!c) return false;
+    return true;
+}
+
 // K steps in two launches (eqf_burst.hpp).  Steps 0 .. K-1 read devRecs[s * recStride + b] (or inl[s], one filter); with
 // visionLast the last step is the vision call's integrateUpToTime, its record visRec[b] (or inl[K-1]).
 int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride, const ImuRec* inl, bool visionLast, const ImuRec* visRec) {
@@ -429,8 +438,7 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     const int R = waves1 <= 4096 ? 1 : (waves1 <= 32768 ? 2 : 4);
     const dim3 rgrid((nmx + 63) / 64, (nmx + 4 * R - 1) / (4 * R), f->B);
     // every filter past its lazy initialisation (VIOFilter.cpp:122-124): the schedule with the precomputed step halves
-    bool fast = true;
-    for (int b = 0; b < f->B; ++b) fast = fast && f->devInit[b];
+    const bool fast = allDevInit(f);
     const int rc = profiled(f, EQF_PROF_BURST, [&] {
         auto go = [&](auto zero) {
             typedef decltype(zero) TT;
@@ -1169,7 +1177,7 @@ int eqf_process_imu(eqf_filter* f, const double* stamps, const double* omega, co
         q.kind = 2;
         q.inl[q.cnt++] = recs[0];
         mirrorStep(f, stamps, true, status);
-        if (q.cnt >= std::min(f->burstMax, kBurstMax - 1)) {
+        if (q.cnt >= std::min(f->burstMax, kBurstMax - 1) || !allDevInit(f)) {
             GATE(f);
         }
         return EQF_OK;
@@ -1293,7 +1301,7 @@ int eqf_stream_imu(eqf_filter* f, int k) {
         }
         ++q.cnt;
         mirrorStep(f, f->hImuStamp.data() + (size_t)k * f->B, true, nullptr);
-        if (q.cnt >= std::min(f->burstMax, kBurstMax - 1)) {
+        if (q.cnt >= std::min(f->burstMax, kBurstMax - 1) || !allDevInit(f)) {
             GATE(f);
         }
         return EQF_OK;

@@ -440,6 +440,7 @@ def test_split_propagate_path_equals_fused(hip, monkeypatch):
     st = synth.make_stream(N, duration=0.5)
     d = synth.template_settings_dict()
     out = []
+    monkeypatch.setenv("EQF_IMU_BURST", "0")  # one launch per call: these are the single-step kernels
     for mode, stream in (("0", "1"), ("1", "1"), ("1", "0")):  # fused / builder + streaming kernel / builder + tile kernel
         monkeypatch.setenv("EQF_SPLIT_PROPAGATE", mode)
         monkeypatch.setenv("EQF_STREAM_PROPAGATE", stream)
@@ -466,6 +467,7 @@ def test_split_path_in_fp32_mode_and_under_the_dense_backend(hip, monkeypatch):
     d = synth.template_settings_dict()
 
     def run(split, precision, dense):
+        monkeypatch.setenv("EQF_IMU_BURST", "0")
         monkeypatch.setenv("EQF_SPLIT_PROPAGATE", split)
         f = hip.FilterBatch(d, capacity=N, batch=1, precision=precision)
         if dense:
@@ -646,3 +648,82 @@ def test_cpp_facade_auxiliary_start_matches_the_oracle():
     assert np.abs(np.array(pos) - e.pose.x).max() < 2e-6  # printed with 6 decimals
     assert np.abs(np.array(q) - e.pose.q).max() < 2e-6
     assert abs(fro - np.linalg.norm(fo.stateCovariance())) < 1e-5 * fro
+
+
+def _run_bursts(hip, st, N, burst, peek=False, per_call=False, precision=0, ring=None, monkeypatch=None):
+    from eqf_vio_amd import synth
+
+    if ring is not None:
+        monkeypatch.setenv("EQF_BURST_RING", ring)
+    f = hip.FilterBatch(synth.template_settings_dict(), capacity=N, batch=1, precision=precision)
+    f.set_imu_burst(burst)
+    if not per_call:
+        f.stream_upload(st.imu, st.vision_stamps, st.ids, st.bearings)
+    for n, (kind, k) in enumerate(st.events()):
+        if per_call:
+            if kind == "imu":
+                f.process_imu([st.imu[k, 0]], st.imu[k, 1:4][None], st.imu[k, 4:7][None])
+            else:
+                f.process_vision([st.vision_stamps[k]], st.ids, st.bearings[k])
+        else:
+            (f.stream_imu if kind == "imu" else f.stream_vision)(k)
+        if peek and n % 7 == 3:
+            f.state_estimate()  # any getter launches what is queued: the bursts are cut somewhere else
+    assert f.device_error() == 0
+    return f.sigma(), f.state_estimate(), f.bias(), f.group(0)
+
+
+@pytest.mark.parametrize("N", [5, 37, 70])
+def test_imu_bursts_equal_single_step_launches(hip, N, monkeypatch):
+    """Queued IMU calls leave as bursts (csrc/eqf_burst.hpp): K reference steps in two launches.  The result must not depend
+    on where the bursts are cut -- bitwise -- and must agree with one launch per call (k_propagate) to rounding."""
+    from eqf_vio_amd import synth
+
+    st = synth.make_stream(N, duration=0.5)
+    ref = _run_bursts(hip, st, N, 0)           # every call at once, single-step kernels
+    full = _run_bursts(hip, st, N, 15)         # a frame's IMU calls + the vision call's integrateUpToTime as one burst
+    for burst, peek, per_call, ring in ((1, False, False, None), (4, False, False, None), (15, True, False, None), (15, False, True, None),
+                                        (7, True, True, None), (15, False, False, "0")):
+        o = _run_bursts(hip, st, N, burst, peek=peek, per_call=per_call, ring=ring, monkeypatch=monkeypatch)
+        if ring is None:
+            assert np.array_equal(o[0], full[0]), (burst, peek, per_call)
+            assert all(np.array_equal(o[1][k], full[1][k]) for k in full[1])
+            assert np.array_equal(o[2], full[2])
+        else:  # the other block kernel: the same formulas in another order
+            assert rel_fro(o[0], full[0]) < 1e-9
+    # against the single-step kernels: the same formulas, differently compiled; rounding amplified by cond(Sigma) ~ 1e7
+    assert rel_fro(full[0], ref[0]) < 1e-9
+    assert all(np.abs(full[1][k] - ref[1][k]).max() < 1e-9 for k in ref[1])
+    assert np.abs(full[2] - ref[2]).max() < 1e-9
+
+
+def test_imu_bursts_with_irregular_stamps_and_fp32(hip):
+    """Steps that do not integrate (repeated / decreasing stamps) inside a burst leave Sigma and the state alone, exactly as
+    one call at a time; and the fp32 mode runs the same burst kernels."""
+    from eqf_vio_amd import synth
+
+    N = 12
+    st = synth.make_stream(N, duration=0.4)
+    imu = st.imu.copy()
+    imu[17, 0] = imu[16, 0]          # dt = 0
+    imu[30, 0] = imu[28, 0] - 1e-3   # dt < 0
+    d = synth.template_settings_dict()
+    out = []
+    for burst in (0, 15, 3):
+        f = hip.FilterBatch(d, capacity=N, batch=1)
+        f.set_imu_burst(burst)
+        f.stream_upload(imu, st.vision_stamps, st.ids, st.bearings)
+        for kind, k in st.events():
+            (f.stream_imu if kind == "imu" else f.stream_vision)(k)
+        assert f.device_error() == 0
+        d0 = f.dump_state()
+        out.append((f.sigma(), f.state_estimate(), {k: np.asarray(d0[k], dtype=np.float64) for k in ("currentVelocity", "accumulatedVelocity", "accumulatedTime", "time")}))
+    assert np.array_equal(out[1][0], out[2][0])
+    assert rel_fro(out[1][0], out[0][0]) < 1e-9
+    assert all(np.abs(out[1][1][k] - out[0][1][k]).max() < 1e-9 for k in out[0][1])
+    for key in out[0][2]:
+        assert np.allclose(out[1][2][key], out[0][2][key], rtol=0, atol=1e-12), key
+    a = _run_bursts(hip, st, N, 0, precision=hip.PRECISION_F32)
+    b = _run_bursts(hip, st, N, 15, precision=hip.PRECISION_F32)
+    assert rel_fro(b[0], a[0]) < 5e-2  # the documented bound of the fp32 mode (see the split-path test above)
+    assert np.abs(a[1]["x"] - b[1]["x"]).max() < 5e-2
