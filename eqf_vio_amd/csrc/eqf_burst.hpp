@@ -85,6 +85,7 @@ __device__ long long g_burstStamps[8][20][4];  // [wave][tick]: work begins / en
 // once, one lane per step, so that the serial chain over the steps carries only what really depends on the state.
 struct StepPre {
     double dt, T;
+    double swT;      // sigma_w^2 / T
     int step, pad_;
     d3 wcur, acur;   // the zero-order-hold sample the step integrates (currentVelocity)
     quat lAq;        // se3Exp(dt w_cur, v) = {lAq, VA v}
@@ -169,9 +170,11 @@ EQF_DI void burstBuildF(BurstLds<T>& s, int sl, int lane, const FMap& m) {
 }
 
 // Sigma_bb after step u (slot (u + 1) & 3) from Sigma_bb entering it:  F_bb Sigma_bb F_bb^T + T (P_bb + B_b R B_b^T); one
-// wavefront, lane = (row, column mod 4): a row of F_bb (then of F_bb Sigma_bb) stays in registers for the lane's three columns
+// wavefront, lane = (row, column mod 4): a row of F_bb (then of F_bb Sigma_bb) stays in registers for the lane's three columns.
+// diagVar: the process variance of the lane's row (a lane-dependent pick from the kernel arguments inside the tick loop
+// becomes a vector load from the argument buffer, a microsecond each)
 template <typename T>
-EQF_DI void burstStepSbb(BurstLds<T>& s, int u, int lane, const Params& p) {
+EQF_DI void burstStepSbb(BurstLds<T>& s, int u, int lane, T sw2, T sa2, T diagVar) {
     const int sl = u & 3, nx = (u + 1) & 3;
     if (!s.ricc[sl]) {
         for (int e = lane; e < 132; e += 64) s.Sbb[nx][e / 12][e % 12] = s.Sbb[sl][e / 12][e % 12];
@@ -179,7 +182,6 @@ EQF_DI void burstStepSbb(BurstLds<T>& s, int u, int lane, const Params& p) {
     }
     const int rr = min(lane >> 2, 10), c0 = lane & 3;
     const bool act = lane < 44;
-    const T sw2 = (T)p.velOmegaVariance, sa2 = (T)p.velAccelVariance;
     T fr[11];
 #pragma unroll
     for (int k = 0; k < 11; ++k) fr[k] = s.F[sl][rr][k];
@@ -211,9 +213,7 @@ EQF_DI void burstStepSbb(BurstLds<T>& s, int u, int lane, const Params& p) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) nz = fma(sa2 * s.RA[sl][3 * (rr - 8) + k], s.RA[sl][3 * (cq - 8) + k], nz);
         }
-        if (rr == cc)
-            nz += (T)(rr < 3 ? p.biasOmegaProcessVariance
-                             : (rr < 6 ? p.biasAccelProcessVariance : (rr < 8 ? p.gravityProcessVariance : p.velocityProcessVariance)));
+        if (rr == cc) nz += diagVar;
         if (act) s.Sbb[nx][rr][cc] = cc < 11 ? fma(Tt, nz, acc) : (T)0;
     }
     waveSync();
@@ -277,6 +277,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
     // wave 4, FAST: the state the recurrence carries, and the constants of the origin
     quat rAq = quat{1, 0, 0, 0};
     d3 rAx = mk3(0, 0, 0), rW = mk3(0, 0, 0), rV0 = mk3(0, 0, 0), rEta0 = mk3(0, 0, 1);
+    double rCd[6] = {0, 0, 0, 0, 0, 0};
     if (wv < 4) {
         if (pOk && pc < 11) {
 #pragma unroll
@@ -289,6 +290,8 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
             rW = mk3(G0.w[0], G0.w[1], G0.w[2]);
             rV0 = mk3(G0.v0[0], G0.v0[1], G0.v0[2]);
             rEta0 = mk3(G0.eta0[0], G0.eta0[1], G0.eta0[2]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) rCd[i] = G0.cDiff[i];
             if (lane < 4) {  // constants of the camera offset in every slot of the ring
                 StepCommon& c = s.com[lane];
 #pragma unroll
@@ -341,8 +344,17 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
             o.wcur = mk3(cv[0], cv[1], cv[2]);
             o.acur = mk3(cv[3], cv[4], cv[5]);
             o.pad_ = 0;
+            o.swT = 0.0;
+            if (first && lane < K) {
+                BurstStep bs;
+                bs.riccati = o.step;
+                bs.pad_ = 0;
+                bs.TtP = o.step ? o.T * a.prm.pointProcessVariance : 0.0;
+                a.steps[b * kBurstMax + lane] = bs;
+            }
             if (o.step) {
                 const double invT = 1.0 / o.T;
+                o.swT = a.prm.velOmegaVariance * invT;
                 const d3 wbar = mk3(((fresh ? G0.accVel[0] : 0.0) + o.wcur.x * o.dt) * invT, ((fresh ? G0.accVel[1] : 0.0) + o.wcur.y * o.dt) * invT,
                     ((fresh ? G0.accVel[2] : 0.0) + o.wcur.z * o.dt) * invT);
                 m33 RcI;
@@ -368,7 +380,14 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
     }
     __syncthreads();
 
-    const T sw2 = (T)a.prm.velOmegaVariance;
+    const T sw2 = (T)a.prm.velOmegaVariance, sa2 = (T)a.prm.velAccelVariance;
+    T diagVar;  // process variance of base row lane >> 2 (burstStepSbb)
+    {
+        const int rr = lane >> 2;
+        const double v03 = a.prm.biasOmegaProcessVariance, v36 = a.prm.biasAccelProcessVariance, v68 = a.prm.gravityProcessVariance,
+                     v8 = a.prm.velocityProcessVariance;
+        diagVar = (T)(rr < 3 ? v03 : (rr < 6 ? v36 : (rr < 8 ? v68 : v8)));
+    }
     // One tick loop PER ROLE (the branch on the wave index is outside the loops): inside a common loop the compiler hoists the
     // loop invariants of every role at once and the kernel needs the sum of their registers instead of the maximum.  Every
     // wave passes the same number of barriers.
@@ -386,14 +405,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
                     c.step = pr.step;
                     s.ricc[sl] = pr.step;
                     s.Tt[sl] = pr.step ? (T)pr.T : (T)0;
-                    s.swT[sl] = pr.step ? (T)(a.prm.velOmegaVariance / pr.T) : (T)0;
-                    if (first) {
-                        BurstStep bs;
-                        bs.riccati = pr.step;
-                        bs.pad_ = 0;
-                        bs.TtP = pr.step ? pr.T * a.prm.pointProcessVariance : 0.0;
-                        a.steps[b * kBurstMax + t] = bs;
-                    }
+                    s.swT[sl] = (T)pr.swT;
                     if (pr.step) {
                         // ---- common values (stepCommon's, from the precomputed halves)
                         m33 RcI;
@@ -412,8 +424,9 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
                         for (int i = 0; i < 2; ++i)
 #pragma unroll
                             for (int j = 0; j < 3; ++j)
-                                c.Bg[3 * i + j] = G0.cDiff[3 * i] * RAg.a[j] + G0.cDiff[3 * i + 1] * RAg.a[3 + j] + G0.cDiff[3 * i + 2] * RAg.a[6 + j];
+                                c.Bg[3 * i + j] = rCd[3 * i] * RAg.a[j] + rCd[3 * i + 1] * RAg.a[3 + j] + rCd[3 * i + 2] * RAg.a[6 + j];
                         c.Bvw = mul33(RA, skew3(vhat));
+                        EQF_BSTAMP(2);
                         // ---- the group step of the scalar state (stepGlobal's; VIOGroup.cpp:214-222 / :182-187, :95-96)
                         const se3 lA = se3{pr.lAq, mv33(pr.VA, scl(pr.dt, vhat))};
                         d3 lw;
@@ -446,7 +459,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
                         stepGlobal(s.glob[cur], &s.glob[cur ^ 1], s.rec[t], v, c, &bad);
                     }
                 }
-                if (t >= 1 && t - 1 < K) burstStepSbb(s, t - 1, lane, a.prm);
+                if (t >= 1 && t - 1 < K) burstStepSbb(s, t - 1, lane, sw2, sa2, diagVar);
             }
             EQF_BSTAMP(1);
             ldsBarrier();
@@ -458,7 +471,8 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
             if (FAST) {
                 if (t >= 1 && t - 1 < K && s.ricc[(t - 1) & 3]) burstBuildF(s, (t - 1) & 3, lane, fmap);
                 waveSync();
-                if (t >= 2 && t - 2 < K) burstStepSbb(s, t - 2, lane, a.prm);
+                EQF_BSTAMP(2);
+                if (t >= 2 && t - 2 < K) burstStepSbb(s, t - 2, lane, sw2, sa2, diagVar);
             } else if (t < K) {
                 const int sl = t & 3;
                 if (lane == 0) {

@@ -20,7 +20,5 @@ print("tick:      " + " ".join("%6d" % t for t in range(14)))
 for w in range(8):
     print("%-9s b " % names[w] + " ".join("%6d" % (a[w, t, 0] - t0) for t in range(14)))
     print("%-9s d " % names[w] + " ".join("%6d" % (a[w, t, 1] - a[w, t, 0]) for t in range(14)))
-for w in range(4):
-    print("%-9s G " % names[w] + " ".join("%6d" % (a[w, t, 2] - a[w, t, 0]) for t in range(2, 13)))
-    print("%-9s R " % names[w] + " ".join("%6d" % (a[w, t, 3] - a[w, t, 2]) for t in range(2, 13)))
-    print("%-9s P " % names[w] + " ".join("%6d" % (a[w, t, 1] - a[w, t, 3]) for t in range(2, 13)))
+for w in (4, 5):
+    print("%-9s first part " % names[w] + " ".join("%6d" % (a[w, t, 2] - a[w, t, 0]) for t in range(2, 12)))
