@@ -90,6 +90,9 @@ def roofline(fb, events, N, B, precision):
     run_events(fb, events)
     prof = fb.profile()
     fb.profile_enable(False)
+    # integrateUpToTime steps per burst (IMU calls + the vision call's own step leave together, csrc/eqf_burst.hpp)
+    n_bursts = max(prof.get("k_imu_burst", (0, 0.0))[0], 1)
+    steps_per_burst = len(events) / n_bursts
     n = 11 + 3 * N
     m = 2 * N
     ne = 6 + 3 * N
@@ -104,6 +107,9 @@ def roofline(fb, events, N, B, precision):
     algo = {
         # propagate = read Sigma once + write Sigma once
         "k_propagate": ("hbm", 2.0 * n * n * esz * B),
+        # a burst of K steps: SURVEY.md 8(d)'s per-step figure (read + write Sigma once per STEP) x K.  The burst kernels
+        # keep Sigma in registers across the steps, so this "effective" rate may exceed what HBM could deliver step by step.
+        "k_imu_burst": ("hbm", 2.0 * n * n * esz * B * steps_per_burst),
         # Cholesky of S + forward solves of n+7 rhs + Cholesky of Sigma_e + 11 rhs (+ Sigma - Y^T Y when it rides along),
         # spread over the chain launches of one update
         "k_chol_step": ("mfma", (chain_flops + (downdate_flops if embedded else 0.0)) * B / chol_launches_per_update),
@@ -132,6 +138,8 @@ def roofline(fb, events, N, B, precision):
                 pk = MFMA_PEAK_TF["f64"]  # factorisation is always fp64
                 if name in ("k_downdate", "k_dense_riccati"):
                     pk = MFMA_PEAK_TF[precision]
+                if name == "k_imu_burst":
+                    row["steps_per_burst"] = round(steps_per_burst, 2)
                 if name == "k_chol_step":
                     row["launches_per_update"] = round(chol_launches_per_update, 2)
                     row["downdate_embedded"] = embedded
@@ -299,7 +307,7 @@ def main():
         t = {r["kernel"]: (r["total_ms"], r["launches"]) for r in rows}
         n_imu_vis = len(timed)
         n_upd = max(t.get("k_update_prep", (0, 1))[1], 1)
-        prop_ms = t.get("k_propagate", (0, 0))[0] + t.get("k_dense_riccati", (0, 0))[0]
+        prop_ms = t.get("k_propagate", (0, 0))[0] + t.get("k_dense_riccati", (0, 0))[0] + t.get("k_imu_burst", (0, 0))[0]
         upd_ms = sum(t.get(k, (0, 0))[0] for k in ("k_update_prep", "k_chol_step", "k_update_reduce", "k_update_finish", "k_downdate"))
         line["per_call"] = {
             "propagate_us": round(prop_ms * 1e3 / max(n_imu_vis, 1), 3),

@@ -991,6 +991,11 @@ extern "C" int eqf_debug_prop_stamps(long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_propStamps), sizeof(long long) * 32) == hipSuccess ? 0 : -1;
 }
 #endif
+#ifdef EQF_PREP_STAMPS
+extern "C" int eqf_debug_prep_stamps(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_prepStamps), sizeof(long long) * 1024) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef EQF_BURST_STAMPS
 extern "C" int eqf_debug_burst_stamps(long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_burstStamps), sizeof(long long) * 8 * 20 * 4) == hipSuccess ? 0 : -1;

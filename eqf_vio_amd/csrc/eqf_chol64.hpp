@@ -290,33 +290,41 @@ EQF_DI void factorFirstFromSigma(const UpdArgs& a, const ChainArgs& ch, int b, c
     if (!g.updateOk || g.N == 0) return;
     const int N = g.N, cap = a.cap, ld = a.ld, tid = threadIdx.x;
     const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
+    // (every global read of a role is issued before the first use: the block was written by the previous launch on other
+    // XCDs, a read-use-read-use loop would pay the ~2 us first-touch miss once per trip)
     if (ch.kind == 0) {
         const double* lmc = a.lmc + (long long)b * 15 * cap;
-        for (int e = tid; e < 32 * 32; e += 256) {
-            const int i = e >> 5, j = e & 31;
+        const double mv = a.prm.measurementVariance;
+        double Ci[4][6], Cj[4][6], v[4][9];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u, i = min(e >> 5, N - 1), j = min(e & 31, N - 1);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                Ci[u][q] = lmc[(long long)q * cap + i];
+                Cj[u][q] = lmc[(long long)q * cap + j];
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[u][3 * q + c] = (double)Sin[(long long)(kLm0 + 3 * i + q) * ld + kLm0 + 3 * j + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u, i = e >> 5, j = e & 31;
             double o[4] = {0.0, 0.0, 0.0, 0.0};
             if (i < N && j < N) {
-                double Ci[6], Cj[6], v[9];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    Ci[q] = lmc[(long long)q * cap + i];
-                    Cj[q] = lmc[(long long)q * cap + j];
-                }
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) v[3 * q + c] = (double)Sin[(long long)(kLm0 + 3 * i + q) * ld + kLm0 + 3 * j + c];
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     double cs[3];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) cs[c] = Ci[3 * r] * v[c] + Ci[3 * r + 1] * v[3 + c] + Ci[3 * r + 2] * v[6 + c];
+                    for (int c = 0; c < 3; ++c) cs[c] = Ci[u][3 * r] * v[u][c] + Ci[u][3 * r + 1] * v[u][3 + c] + Ci[u][3 * r + 2] * v[u][6 + c];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) o[2 * r + q] = cs[0] * Cj[3 * q] + cs[1] * Cj[3 * q + 1] + cs[2] * Cj[3 * q + 2];
+                    for (int q = 0; q < 2; ++q) o[2 * r + q] = cs[0] * Cj[u][3 * q] + cs[1] * Cj[u][3 * q + 1] + cs[2] * Cj[u][3 * q + 2];
                 }
                 if (i == j) {
-                    o[0] += a.prm.measurementVariance;
-                    o[3] += a.prm.measurementVariance;
+                    o[0] += mv;
+                    o[3] += mv;
                 }
             } else if (i == j) {
                 o[0] = o[3] = 1.0;
@@ -326,9 +334,18 @@ EQF_DI void factorFirstFromSigma(const UpdArgs& a, const ChainArgs& ch, int b, c
         }
     } else {
         const int ne = eDim(N);
-        for (int e = tid; e < kSB * kSB; e += 256) {
-            const int rr = e >> 6, cc = e & 63;
-            s.L[rr][cc] = (rr < ne && cc < ne && rr != 5 && cc != 5) ? (double)Sin[(long long)(6 + rr) * ld + 6 + cc] : (rr == cc ? 1.0 : 0.0);
+        T v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + 256 * u, rr = e >> 6, cc = e & 63;
+            const bool in = rr < ne && cc < ne && rr != 5 && cc != 5;
+            v[u] = Sin[(long long)(6 + (in ? rr : 0)) * ld + 6 + (in ? cc : 0)];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + 256 * u, rr = e >> 6, cc = e & 63;
+            const bool in = rr < ne && cc < ne && rr != 5 && cc != 5;
+            s.L[rr][cc] = in ? (double)v[u] : (rr == cc ? 1.0 : 0.0);
         }
     }
     __syncthreads();
@@ -337,17 +354,28 @@ EQF_DI void factorFirstFromSigma(const UpdArgs& a, const ChainArgs& ch, int b, c
     factor64(s, tid, bad, [](int) {}, ch.D + (long long)b * ch.strideD);
 }
 // k_update_prep + the two first-block workgroups (grid.x = lmBlocks + eBlocks + 2)
+#ifdef EQF_PREP_STAMPS
+__device__ long long g_prepStamps[512][2];  // per workgroup: first / last cycle
+#define EQF_PREPSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 512 && blockIdx.y == 0) g_prepStamps[blockIdx.x][k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define EQF_PREPSTAMP(k) do { } while (0)
+#endif
 template <typename T>
 __global__ __launch_bounds__(256) void k_update_prep64(UpdArgs a, ChainArgs cS, ChainArgs cE, int lmBlocks, int eBlocks, int wpb, int nvPad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
     const int role = (int)blockIdx.x - (lmBlocks + eBlocks);
+    EQF_PREPSTAMP(0);
     if (role < 0) {
         updatePrepBody<T>(a, lmBlocks, wpb, nvPad, reinterpret_cast<double*>(smem64));
+        __syncthreads();
+        EQF_PREPSTAMP(1);
         return;
     }
     int bad = 0;
     factorFirstFromSigma<T>(a, role == 0 ? cS : cE, blockIdx.y, ldsFull(smem64), &bad);
     if (bad && a.errflag && threadIdx.x == 0) atomicOr(a.errflag, 4);
+    __syncthreads();
+    EQF_PREPSTAMP(1);
 }
 // The two first-block workgroups as a launch of their own (grid = (2, B)): used when the prep launch has more workgroups
 // than the chip has CUs -- there the 119 KB of LDS these two need would cost every prep workgroup its occupancy.

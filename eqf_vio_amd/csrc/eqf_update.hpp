@@ -157,25 +157,35 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, d
         if (r0 >= nep) return;
         double* EA = a.EA + (long long)b * a.strideE;
         double* ZW = a.ZW + (long long)b * a.strideZ;
-        // one row per wave at a time, lanes stride the columns, 4 column groups per trip (independent loads in flight)
+        // Four rows per wave and trip, lanes stride the columns, ten column groups (all columns up to N = 211): 40 independent
+        // loads in flight.  Sigma was written by the previous launch on other XCDs -- a row-by-row, group-by-group copy pays
+        // the ~2 us first-touch miss two dozen times in a row and made these workgroups the longest of the launch.
         const int nw = (int)blockDim.x >> 6;
-        for (int rl = wv; rl < kNB; rl += nw) {
-            const int rr = r0 + rl;
-            for (int cc = lane; cc < nep; cc += 256) {
+        constexpr int kRowsTrip = 4, kColGroups = 10;
+        for (int rb = wv; rb < kNB; rb += nw * kRowsTrip) {
+            for (int c0 = lane; c0 < nep; c0 += 64 * kColGroups) {
                 // raw loads first, conversion afterwards: with T = float a convert right behind each load makes hipcc wait
-                // for every load separately (a chain of cold misses instead of one)
-                T v[4];
+                // for every load separately
+                T v[kRowsTrip][kColGroups];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int c2 = cc + 64 * u;
-                    const bool in = rr < ne && c2 < ne && rr != 5 && c2 != 5;
-                    v[u] = Sin[in ? (long long)(6 + rr) * ld + 6 + c2 : 0];
+                for (int q = 0; q < kRowsTrip; ++q) {
+                    const int rr = r0 + rb + q * nw;
+#pragma unroll
+                    for (int u = 0; u < kColGroups; ++u) {
+                        const int c2 = c0 + 64 * u;
+                        const bool in = rb + q * nw < kNB && rr < ne && c2 < ne && rr != 5 && c2 != 5;
+                        v[q][u] = Sin[in ? (long long)(6 + rr) * ld + 6 + c2 : 0];
+                    }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int c2 = cc + 64 * u;
-                    const bool in = rr < ne && c2 < ne && rr != 5 && c2 != 5;
-                    if (c2 < nep) EA[(long long)rr * a.ldE + c2] = in ? (double)v[u] : ((rr == c2) ? 1.0 : 0.0);
+                for (int q = 0; q < kRowsTrip; ++q) {
+                    const int rr = r0 + rb + q * nw;
+#pragma unroll
+                    for (int u = 0; u < kColGroups; ++u) {
+                        const int c2 = c0 + 64 * u;
+                        const bool in = rr < ne && c2 < ne && rr != 5 && c2 != 5;
+                        if (rb + q * nw < kNB && c2 < nep) EA[(long long)rr * a.ldE + c2] = in ? (double)v[q][u] : ((rr == c2) ? 1.0 : 0.0);
+                    }
                 }
             }
         }
@@ -215,6 +225,21 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, d
     for (int k = 0; k < 12; ++k) V[k] = 0.0;
     const bool valid = i < N;
     const double* lmc = a.lmc + (long long)b * 15 * cap;
+    const T* s0 = Sin + (long long)(kLm0 + 3 * (valid ? i : 0)) * ld;
+    // The landmark's three Sigma rows: the first kPrepGroups * 64 columns (all of them up to N = 209) are requested before
+    // anything else -- Sigma was written by the previous launch on other XCDs, every access is a ~2 us miss, and the
+    // scalar chain below (residual, chart, lift rows) runs in its shadow.
+    constexpr int kPrepGroups = 10;
+    T vr[kPrepGroups][3];
+    {
+        const int colHi0 = kLm0 + 3 * min(N, kPrepLmChunk);
+#pragma unroll
+        for (int u = 0; u < kPrepGroups; ++u) {
+            const int cc = min(lane + 64 * u, colHi0 - 1);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) vr[u][q] = s0[(long long)q * ld + cc];
+        }
+    }
     if (valid) {
         const quat Qq = quat{Q[i], Q[cap + i], Q[2 * cap + i], Q[3 * cap + i]};
         const double Qa = Q[4 * cap + i];
@@ -239,7 +264,6 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, d
 #pragma unroll
             for (int c = 0; c < 6; ++c) V[6 * r + c] = C[3 * r] * Z[c] + C[3 * r + 1] * Z[6 + c] + C[3 * r + 2] * Z[12 + c];
     }
-    const T* s0 = Sin + (long long)(kLm0 + 3 * (valid ? i : 0)) * ld;
     for (int q0 = 0; q0 < N; q0 += kPrepLmChunk) {
         const int q1 = min(N, q0 + kPrepLmChunk);
         const int colLo = (q0 == 0) ? 0 : kLm0 + 3 * q0, colHi = kLm0 + 3 * q1;
@@ -247,16 +271,19 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, d
             // rows 2i, 2i+1 of C*Sigma for this column chunk: lanes stride the columns (coalesced 3-row reads)
             // (4 column groups per trip: 12 independent loads in flight -- Sigma was written by the previous launch on
             // other XCDs, every access is a ~2 us miss)
-            for (int col = colLo + lane; col < colHi; col += 256) {
-                T vr[4][3];  // raw loads first (clamped column, always in bounds), conversion afterwards -- see above
+            for (int col = colLo + lane; col < colHi; col += 64 * kPrepGroups) {
+                // raw loads first (clamped column, always in bounds), conversion afterwards -- see above; the very first
+                // trip is already in flight
+                if (!(q0 == 0 && col == lane)) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int cc = min(col + 64 * u, colHi - 1);
+                    for (int u = 0; u < kPrepGroups; ++u) {
+                        const int cc = min(col + 64 * u, colHi - 1);
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) vr[u][q] = s0[(long long)q * ld + cc];
+                        for (int q = 0; q < 3; ++q) vr[u][q] = s0[(long long)q * ld + cc];
+                    }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < kPrepGroups; ++u) {
                     const int cc = col + 64 * u;
                     if (cc < colHi) {
                         const double v0 = (double)vr[u][0], v1 = (double)vr[u][1], v2 = (double)vr[u][2];

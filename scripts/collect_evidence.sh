@@ -39,6 +39,8 @@ timeout 900 $PY $ROOT/bench.py > "$OUT/${TAG}_bench_N200.json" 2> "$OUT/${TAG}_b
 stats bench_N200
 pmc bench_N200 FETCH_SIZE --steps 220 --warmup 110
 pmc bench_N200 WRITE_SIZE --steps 220 --warmup 110
+# 1b. the same workload with one launch per call (no IMU bursts): what the single-step kernel k_propagate does
+EQF_IMU_BURST=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-traffic > "$OUT/${TAG}_bench_N200_noburst.json" 2>/dev/null
 # 2. a batch of 64 filters on one GPU (cfg 4's filters, all on one device)
 timeout 900 $PY $ROOT/bench.py --filters-per-gpu 64 --steps 440 --warmup 110 --no-cpu-baseline --no-traffic > "$OUT/${TAG}_bench_batch64.json" 2>/dev/null
 stats bench_N200_batch64 --filters-per-gpu 64 --steps 220 --warmup 110
