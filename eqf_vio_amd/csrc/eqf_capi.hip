@@ -991,6 +991,12 @@ extern "C" int eqf_debug_prop_stamps(long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_propStamps), sizeof(long long) * 32) == hipSuccess ? 0 : -1;
 }
 #endif
+#ifdef EQF_CHOL_WG_STAMPS
+extern "C" int eqf_debug_chol_wg(long long* t, int* info) {
+    if (hipMemcpyFromSymbol(t, HIP_SYMBOL(eqf::g_cholWg), sizeof(long long) * 16 * 256 * 2) != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(info, HIP_SYMBOL(eqf::g_cholWgInfo), sizeof(int) * 16 * 256 * 4) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef EQF_PREP_STAMPS
 extern "C" int eqf_debug_prep_stamps(long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_prepStamps), sizeof(long long) * 1024) == hipSuccess ? 0 : -1;

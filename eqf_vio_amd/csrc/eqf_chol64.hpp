@@ -207,10 +207,14 @@ EQF_DI void storeDiagColumns(const Lds64& s, double* Dn, int j, int t, int nthr)
 // zeroed) and form s.Wd.  All 256 threads.  `pre` is extra work for waves 2 and 3 during the first stage (the diagonal
 // workgroup's remaining trailing-update tiles): pre(wave).
 template <typename Pre>
-EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn = nullptr, long long* st = nullptr) {
+EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn = nullptr, long long* st = nullptr, int nStages = 4) {
     const int lane = tid & 63, wv = tid >> 6;
+    // nStages: 16-column stages that hold a real column.  The rest of the block is the identity padding of the chain's
+    // last block (off-diagonal zero): its L_jj = I stands as it is, W_jj = I is set here, and the pivot chain stops early.
+    for (int j = nStages; j < 4; ++j)
+        if (tid < kQB * kQB) s.Wd[j][tid >> 4][tid & 15] = ((tid >> 4) == (tid & 15)) ? 1.0 : 0.0;
 #pragma unroll 1
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < nStages; ++j) {
         const int base = kQB * j;
         // ---- phase P: the next 16 columns (wave 0; wave 1 carries the identity rows at stage 0, where wave 0 has no idle
         // lanes) while waves 2, 3 apply the deferred updates of stage j-1 to the columns >= j+1
@@ -224,7 +228,7 @@ EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn = nu
                 if (Dn) storeDiagColumns(s, Dn, j - 1, tid - 128, 128);
                 int t = 0;
 #pragma unroll 1
-                for (int c = j + 1; c < 4; ++c)
+                for (int c = j + 1; c < nStages; ++c)
 #pragma unroll 1
                     for (int r = c; r < 4; ++r, ++t) {
                         if ((t & 1) != (wv & 1)) continue;
@@ -239,7 +243,7 @@ EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn = nu
 #endif
         __syncthreads();
         // ---- phase U: the tiles of column j+1 (needed by the next stage), one per wave:  T_r,j+1 -= L_rj L_j+1,j^T
-        if (j < 3 && wv < 3 - j) {
+        if (j + 1 < nStages && wv < 3 - j) {
             const int r = j + 1 + wv;
             f64x4 acc = ldTile(&s.L[0][0], kSP, kQB * r, base + kQB, lane);
             acc = mmTile<true, kQB>(acc, &s.L[0][base], kSP, kQB * r, &s.L[0][base], kSP, base + kQB, lane, -1.0);
@@ -250,8 +254,11 @@ EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn = nu
 #endif
         __syncthreads();
     }
-    if (Dn) storeDiagColumns(s, Dn, 3, tid, 256);
+    if (Dn)
+        for (int j = nStages - 1; j < 4; ++j) storeDiagColumns(s, Dn, j, tid, 256);
 }
+// stages of the 64-wide block starting at column c0 of a chain of real order n that hold a real column
+EQF_DI int realStages(int n, int c0) { return max(1, min(4, (min(kSB, n - c0) + kQB - 1) / kQB)); }
 
 // Panel solve of one 16-wide strip of M in place, four 16x16 stages chained through the accumulators:
 //   TR = true : the strip is rows x0..x0+15,    M <- M L^-T   (held transposed:  X_j^T = W_jj (A_j^T - sum L_ji X_i^T))
@@ -351,7 +358,7 @@ EQF_DI void factorFirstFromSigma(const UpdArgs& a, const ChainArgs& ch, int b, c
     __syncthreads();
     if (tid < kQB * kQB) s.D0[tid >> 4][tid & 15] = s.L[tid >> 4][tid & 15];
     __syncthreads();
-    factor64(s, tid, bad, [](int) {}, ch.D + (long long)b * ch.strideD);
+    factor64(s, tid, bad, [](int) {}, ch.D + (long long)b * ch.strideD, nullptr, realStages(ch.kind == 0 ? sDim(N) : eDim(N), 0));
 }
 // k_update_prep + the two first-block workgroups (grid.x = lmBlocks + eBlocks + 2)
 #ifdef EQF_PREP_STAMPS
@@ -420,9 +427,26 @@ __global__ __launch_bounds__(256) void k_factor_first64(ChainArgs c0, ChainArgs 
 // PHASE 1 + PHASE 2: the split chain for throughput (many tiles per launch): a panel launch solves every block of column
 //          K ONCE, in place (A_RK <- L_RK, Y_K -> WO), an update launch then only multiplies: no redundant solves
 //          (2.25x fewer MFMAs per tile) and the 77 KB LDS layout lets two workgroups share a CU.
+#ifdef EQF_CHOL_WG_STAMPS
+__device__ long long g_cholWg[16][256][2];  // [launch K][workgroup]: first / last cycle
+__device__ int g_cholWgInfo[16][256][4];    // second chain?, isW, R, C
+struct CholWgStamp {
+    int K;
+    __device__ CholWgStamp(int k) : K(k) {
+        if (threadIdx.x == 0 && blockIdx.y == 0 && K < 16 && blockIdx.x < 256) g_cholWg[K][blockIdx.x][0] = __builtin_readcyclecounter();
+    }
+    __device__ ~CholWgStamp() {
+        __syncthreads();
+        if (threadIdx.x == 0 && blockIdx.y == 0 && K < 16 && blockIdx.x < 256) g_cholWg[K][blockIdx.x][1] = __builtin_readcyclecounter();
+    }
+};
+#endif
 template <typename T, int PHASE>
 __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1, UpdArgs a, int K, int ddNt, int ddSmall,
     int embedFinish, int* errflag) {
+#ifdef EQF_CHOL_WG_STAMPS
+    CholWgStamp wgStamp(K);
+#endif
     const int b = blockIdx.y;
     const int n0 = chainBlocks64(c0.nbMax, c0.wtMax, K, PHASE);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
@@ -478,6 +502,14 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
 
     const Lds64 s = PHASE == 2 ? ldsUpdate(smem64) : ldsFull(smem64);
     int bad = 0;
+#ifdef EQF_CHOL_WG_STAMPS
+    if (threadIdx.x == 0 && blockIdx.y == 0 && K < 16 && blockIdx.x < 256) {
+        g_cholWgInfo[K][blockIdx.x][0] = second;
+        g_cholWgInfo[K][blockIdx.x][1] = isW;
+        g_cholWgInfo[K][blockIdx.x][2] = R;
+        g_cholWgInfo[K][blockIdx.x][3] = C;
+    }
+#endif
     const bool diagNext = PHASE != 1 && !isW && R == C && C == K + 1;
     const bool needQ = C > K;
     const bool needP = isW || R != C;
@@ -634,9 +666,9 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
                 }
             };
 #ifdef EQF_STEP64_STAMPS
-            factor64(s, tid, &bad, pre, D + (long long)(K + 1) * kDRec, !second ? &g_stamps[K][8] : nullptr);
+            factor64(s, tid, &bad, pre, D + (long long)(K + 1) * kDRec, !second ? &g_stamps[K][8] : nullptr, realStages(ch.kind == 0 ? sDim(g.N) : eDim(g.N), kSB * (K + 1)));
 #else
-            factor64(s, tid, &bad, pre, D + (long long)(K + 1) * kDRec);
+            factor64(s, tid, &bad, pre, D + (long long)(K + 1) * kDRec, nullptr, realStages(ch.kind == 0 ? sDim(g.N) : eDim(g.N), kSB * (K + 1)));
 #endif
             EQF_STAMP(4);
             EQF_STAMP(5);
