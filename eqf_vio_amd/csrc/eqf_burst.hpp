@@ -687,6 +687,12 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
 // steps ahead (two register sets of 13 values), and passes them on through a two-slot LDS ring one step before they are
 // used -- loads have two full steps to arrive.  grid = (ceil(N / 64), ceil(N / 4), B), block = 256.
 // ------------------------------------------------------------------------------------------------
+#ifdef EQF_BURST_STAMPS
+__device__ long long g_ringStamps[4][64];
+#define EQF_RSTAMP(i) do { if (blockIdx.x == 1 && blockIdx.y == 7 && blockIdx.z == 0 && lane == 0 && (i) < 64) g_ringStamps[wv][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define EQF_RSTAMP(i) do { } while (0)
+#endif
 constexpr int kRingTrips = 12;  // column-constant rows per wave and step: 45 rows over 4 waves
 template <typename T>
 __global__ __launch_bounds__(256) void k_burst_riccati_ring(BurstArgs a) {
@@ -706,6 +712,7 @@ __global__ __launch_bounds__(256) void k_burst_riccati_ring(BurstArgs a) {
     __shared__ T sTtP[kBurstMax];
     __shared__ int sRicc[kBurstMax];
 
+    EQF_RSTAMP(63);
     T S[9];
     {
         const T* src = Sin + (long long)(kLm0 + 3 * I) * ld + kLm0 + 3 * Jc;
@@ -787,20 +794,28 @@ __global__ __launch_bounds__(256) void k_burst_riccati_ring(BurstArgs a) {
     pass(0, xA);
     fetch(2, xA);
     __builtin_amdgcn_sched_barrier(0);
+    EQF_RSTAMP(0);
     ldsBarrier();
+    EQF_RSTAMP(1);
     for (int st = 0; st < K; st += 2) {
         // even step: its constants are in the ring; xB holds step st+1 (issued two steps ago), xA step st+2
         if (sRicc[st]) math(st);
+        EQF_RSTAMP(2 + 3 * st);
         pass(st + 1, xB);
+        EQF_RSTAMP(3 + 3 * st);
         fetch(st + 3, xB);
         __builtin_amdgcn_sched_barrier(0);
-        ldsBarrier();  // (LDS only: __syncthreads() would also drain the prefetches, loads and stores share vmcnt)
+        ldsBarrier();
+        EQF_RSTAMP(4 + 3 * st);  // (LDS only: __syncthreads() would also drain the prefetches, loads and stores share vmcnt)
         if (st + 1 >= K) break;
         if (sRicc[st + 1]) math(st + 1);
+        EQF_RSTAMP(2 + 3 * (st + 1));
         pass(st + 2, xA);
+        EQF_RSTAMP(3 + 3 * (st + 1));
         fetch(st + 4, xA);
         __builtin_amdgcn_sched_barrier(0);
-        ldsBarrier();  // (LDS only: __syncthreads() would also drain the prefetches, loads and stores share vmcnt)
+        ldsBarrier();
+        EQF_RSTAMP(4 + 3 * (st + 1));  // (LDS only: __syncthreads() would also drain the prefetches, loads and stores share vmcnt)
     }
     if (validJ && rowOk) {
         T* dst = Sout + (long long)(kLm0 + 3 * I) * ld + kLm0 + 3 * J;

@@ -1003,6 +1003,9 @@ extern "C" int eqf_debug_prep_stamps(long long* out) {
 }
 #endif
 #ifdef EQF_BURST_STAMPS
+extern "C" int eqf_debug_ring_stamps(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_ringStamps), sizeof(long long) * 256) == hipSuccess ? 0 : -1;
+}
 extern "C" int eqf_debug_burst_stamps(long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_burstStamps), sizeof(long long) * 8 * 20 * 4) == hipSuccess ? 0 : -1;
 }

@@ -22,3 +22,11 @@ for w in range(8):
     print("%-9s d " % names[w] + " ".join("%6d" % (a[w, t, 1] - a[w, t, 0]) for t in range(14)))
 for w in (4, 5):
     print("%-9s first part " % names[w] + " ".join("%6d" % (a[w, t, 2] - a[w, t, 0]) for t in range(2, 12)))
+# the block kernel (k_burst_riccati_ring), one workgroup: per wave and step  math | hand-over | wait at the barrier
+r = (C.c_longlong * 256)()
+hip.lib().eqf_debug_ring_stamps(r)
+r = np.array(r[:]).reshape(4, 64)
+for w in range(4):
+    t0 = r[w, 63]
+    print("ring wave %d: prologue %d (+barrier %d)" % (w, r[w, 0] - t0, r[w, 1] - r[w, 0]), " steps:",
+          " ".join("%d|%d|%d" % (r[w, 2 + 3 * s] - (r[w, 1] if s == 0 else r[w, 4 + 3 * (s - 1)]), r[w, 3 + 3 * s] - r[w, 2 + 3 * s], r[w, 4 + 3 * s] - r[w, 3 + 3 * s]) for s in range(12)))
