@@ -991,6 +991,11 @@ extern "C" int eqf_debug_prop_stamps(long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_propStamps), sizeof(long long) * 32) == hipSuccess ? 0 : -1;
 }
 #endif
+#ifdef EQF_STEP64_STAMPS
+extern "C" int eqf_debug_step64_stamps(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_stamps), sizeof(long long) * 64 * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef EQF_CHOL_WG_STAMPS
 extern "C" int eqf_debug_chol_wg(long long* t, int* info) {
     if (hipMemcpyFromSymbol(t, HIP_SYMBOL(eqf::g_cholWg), sizeof(long long) * 16 * 256 * 2) != hipSuccess) return -1;
