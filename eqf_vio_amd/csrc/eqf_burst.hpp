@@ -20,9 +20,10 @@
 namespace eqf {
 
 constexpr int kBurstMax = 16;  // steps per burst
-constexpr int kBurstLm = 16;   // landmarks per builder workgroup (4 per panel wave)
+constexpr int kBurstLmMax = 16;  // landmarks per builder workgroup: LM = 16 (throughput) or 4 (latency), see k_burst_build
 // per step and landmark (element type T): D, Lw, Lv, Gn, Gv (the row constants, kBlkRec = 45 as in k_build_blocks) and
 // Sw = Sigma[0:3, J], Sv = Sigma[8:11, J] (entering the step) for the column side
+constexpr int kLwWave = 1, kSbbWave = 2;  // k_burst_build<.., 4>: waves 1..3 carry no panel and take over two of the stages
 constexpr int kColRec = 63;
 constexpr int kBuildThreads = 512;  // 8 wavefronts, see k_burst_build (a ninth would cap every wave at 168 VGPRs: spills)
 
@@ -107,8 +108,8 @@ struct BurstLds {
     T RA[4][9];
     T Tt[4];
     T swT[4];           // sigma_w^2 / T
-    double Q[2][kBurstLm][5];
-    T blk[2][kBurstLm][28];  // D, Lw, Lv
+    double Q[2][kBurstLmMax][5];
+    T blk[2][kBurstLmMax][28];  // D, Lw, Lv
     T Sbb[4][11][12];   // Sigma_bb ENTERING step u in slot u & 3
     T Tb[11][12];
     T Gs[4][4][3][12];  // [panel wave][landmark][row]: G_I = L_I Sigma_bb + D_I Sigma_Ib, exchanged between the column lanes
@@ -247,10 +248,12 @@ EQF_DI void se3ExpParts(d3 w, quat* q, m33* V) {
 // chain): wave 4 runs stepGlobal on the LDS copy of the scalar state (+ Sigma_bb after step t-1), wave 5 stepCommon + F_bb
 // of step t -- the functions of eqf_propagate.hpp as they are.  Both schedules do the same arithmetic per step.
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool FAST>
+template <typename T, bool FAST, int LM>
 __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
+    static_assert(LM == 4 || LM == 16, "role tables exist for 4 and 16 landmarks per workgroup");
+    constexpr bool kSpread = LM == 4;  // one panel wave: the Lw blocks and Sigma_bb get wavefronts of their own
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int L0 = blockIdx.x * kBurstLm;
+    const int L0 = blockIdx.x * LM;
     __shared__ BurstLds<T> s;
     const Glob& G0 = a.gin[b];
     const int N = G0.N, K = a.K, cap = a.cap, ld = a.ld;
@@ -266,13 +269,13 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
 
     // ---- prologue: everything this workgroup reads of the state, issued together
     const int li = L0 + lane;                   // waves 6, 7: lane = landmark
-    const bool lmOk = lane < kBurstLm && li < N;
+    const bool lmOk = lane < LM && li < N;
     d3 q0 = mk3(0, 0, 1);
     // panel waves: lane = 16 * (landmark of the wave, 0..3) + base column; the landmark's 3 x 11 panel Sigma_Ib lives in the
     // registers of its 11 column lanes for the whole burst
     const int pc = lane & 15, pi = lane >> 4;
     const int plm = L0 + 4 * wv + pi;  // this lane's landmark
-    const bool pOk = wv < 4 && plm < N;
+    const bool pOk = 4 * wv < LM && plm < N;
     T pP[3] = {(T)0, (T)0, (T)0};
     // wave 4, FAST: the state the recurrence carries, and the constants of the origin
     quat rAq = quat{1, 0, 0, 0};
@@ -283,6 +286,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
 #pragma unroll
             for (int rr = 0; rr < 3; ++rr) pP[rr] = Sin[(long long)(kLm0 + 3 * plm + rr) * ld + pc];
         }
+        if (kSpread && wv == kLwWave && lmOk) q0 = mk3(p0[li], p0[cap + li], p0[2 * cap + li]);
     } else if (wv == 4) {
         if (FAST) {
             rAq = quat{G0.Aq[0], G0.Aq[1], G0.Aq[2], G0.Aq[3]};
@@ -290,8 +294,6 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
             rW = mk3(G0.w[0], G0.w[1], G0.w[2]);
             rV0 = mk3(G0.v0[0], G0.v0[1], G0.v0[2]);
             rEta0 = mk3(G0.eta0[0], G0.eta0[1], G0.eta0[2]);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) rCd[i] = G0.cDiff[i];
             if (lane < 4) {  // constants of the camera offset in every slot of the ring
                 StepCommon& c = s.com[lane];
 #pragma unroll
@@ -320,6 +322,8 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
             s.Sbb[0][rr][cc] = (cc < 11) ? Sin[(long long)rr * ld + cc] : (T)0;
         }
         if (FAST) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) rCd[i] = G0.cDiff[i];
             // ---- one lane per step: the state-independent part of every step of the burst
             waveSync();
             const int st = lane < K ? lane : K - 1;
@@ -419,13 +423,8 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
                         c.oCcur = pr.oCcur;
                         c.vCcur = add(pr.vCcurPre, Rv);           // VIOGroup.cpp:225
                         if (a.prm.useDiscreteVelocityLift) c.camInv = se3{pr.camq, mv33(pr.Vc, scl(-pr.dt, c.vCcur))};
-                        const m33 RAg = mul33(RA, skew3(etahat));
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int j = 0; j < 3; ++j)
-                                c.Bg[3 * i + j] = rCd[3 * i] * RAg.a[j] + rCd[3 * i + 1] * RAg.a[3 + j] + rCd[3 * i + 2] * RAg.a[6 + j];
-                        c.Bvw = mul33(RA, skew3(vhat));
+                        c.vhat = vhat;      // (the input blocks B_g^w, B_v^w of F_bb are formed from these by wave 5, one tick later)
+                        c.etahat = etahat;
                         EQF_BSTAMP(2);
                         // ---- the group step of the scalar state (stepGlobal's; VIOGroup.cpp:214-222 / :182-187, :95-96)
                         const se3 lA = se3{pr.lAq, mv33(pr.VA, scl(pr.dt, vhat))};
@@ -459,7 +458,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
                         stepGlobal(s.glob[cur], &s.glob[cur ^ 1], s.rec[t], v, c, &bad);
                     }
                 }
-                if (t >= 1 && t - 1 < K) burstStepSbb(s, t - 1, lane, sw2, sa2, diagVar);
+                if (!kSpread && t >= 1 && t - 1 < K) burstStepSbb(s, t - 1, lane, sw2, sa2, diagVar);
             }
             EQF_BSTAMP(1);
             ldsBarrier();
@@ -469,10 +468,26 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
         for (int t = 0; t < K + 2; ++t) {
             EQF_BSTAMP(0);
             if (FAST) {
-                if (t >= 1 && t - 1 < K && s.ricc[(t - 1) & 3]) burstBuildF(s, (t - 1) & 3, lane, fmap);
-                waveSync();
+                if (t >= 1 && t - 1 < K && s.ricc[(t - 1) & 3]) {
+                    if (lane == 0) {  // B[0:2,0:3] and B[2:5,0:3] of the step  (EqFMatrices.cpp:364-367)
+                        StepCommon& c = s.com[(t - 1) & 3];
+                        const m33 RA = c.RA;
+                        const m33 RAg = mul33(RA, skew3(c.etahat));
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 3; ++j)
+                                c.Bg[3 * i + j] = rCd[3 * i] * RAg.a[j] + rCd[3 * i + 1] * RAg.a[3 + j] + rCd[3 * i + 2] * RAg.a[6 + j];
+                        c.Bvw = mul33(RA, skew3(c.vhat));
+                    }
+                    waveSync();
+                    burstBuildF(s, (t - 1) & 3, lane, fmap);
+                }
                 EQF_BSTAMP(2);
-                if (t >= 2 && t - 2 < K) burstStepSbb(s, t - 2, lane, sw2, sa2, diagVar);
+                if (!kSpread) {
+                    waveSync();
+                    if (t >= 2 && t - 2 < K) burstStepSbb(s, t - 2, lane, sw2, sa2, diagVar);
+                }
             } else if (t < K) {
                 const int sl = t & 3;
                 if (lane == 0) {
@@ -502,7 +517,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
         for (int t = 0; t < K + 2; ++t) {
             EQF_BSTAMP(0);
             const int st = t - 1;
-            if (st >= 0 && st < K && lane < kBurstLm) {
+            if (st >= 0 && st < K && lane < LM) {
                 const int cur = st & 1;
                 quat Qq = quat{s.Q[cur][lane][0], s.Q[cur][lane][1], s.Q[cur][lane][2], s.Q[cur][lane][3]};
                 double Qa = s.Q[cur][lane][4];
@@ -528,23 +543,65 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
                 const int cur = st & 1;
                 const quat Qq = quat{s.Q[cur][lane][0], s.Q[cur][lane][1], s.Q[cur][lane][2], s.Q[cur][lane][3]};
                 const double Qa = s.Q[cur][lane][4];
-                const LmBlocks blk = buildBlocks(s.com[st & 3], Qq, Qa, q0);
+                m33 Dm, Lvm;
+                buildDLv(s.com[st & 3], Qq, Qa, q0, &Dm, &Lvm);
                 T* cr = colRec + (long long)st * kColRec * cap + li;
                 T* rr = rowRec + ((long long)st * cap + li) * kBlkRec;
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
-                    const T d = (T)blk.D.a[k], lw = (T)blk.Lw.a[k], lv = (T)blk.Lv.a[k];
+                    const T d = (T)Dm.a[k], lv = (T)Lvm.a[k];
                     s.blk[cur][lane][k] = d;
-                    s.blk[cur][lane][9 + k] = lw;
                     s.blk[cur][lane][18 + k] = lv;
                     cr[(long long)k * cap] = d;
-                    cr[(long long)(9 + k) * cap] = lw;
                     cr[(long long)(18 + k) * cap] = lv;
                     rr[k] = d;
-                    rr[9 + k] = lw;
                     rr[18 + k] = lv;
                 }
+                if (!kSpread) {  // (LM = 16: no wavefront to spare for Lw)
+                    const StepCommon& c = s.com[st & 3];
+                    const m33 Lwm = buildLw(c.T, c.RICt, c.xIC, Qq, Qa, q0);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        const T lw = (T)Lwm.a[k];
+                        s.blk[cur][lane][9 + k] = lw;
+                        cr[(long long)(9 + k) * cap] = lw;
+                        rr[9 + k] = lw;
+                    }
+                }
             }
+            EQF_BSTAMP(1);
+            ldsBarrier();
+        }
+    } else if (kSpread && wv == kLwWave) {
+        // ---- Lw = -T B_i of step t-1: needs nothing of the state but T and the landmark's group element
+        for (int t = 0; t < K + 2; ++t) {
+            EQF_BSTAMP(0);
+            const int st = t - 1;
+            if (st >= 0 && st < K && lmOk && s.ricc[st & 3]) {
+                const int cur = st & 1;
+                const quat Qq = quat{s.Q[cur][lane][0], s.Q[cur][lane][1], s.Q[cur][lane][2], s.Q[cur][lane][3]};
+                const double Qa = s.Q[cur][lane][4];
+                const StepCommon& c = s.com[st & 3];
+                const m33 Lwm = buildLw(c.T, c.RICt, c.xIC, Qq, Qa, q0);
+                T* cr = colRec + (long long)st * kColRec * cap + li;
+                T* rr = rowRec + ((long long)st * cap + li) * kBlkRec;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const T lw = (T)Lwm.a[k];
+                    s.blk[cur][lane][9 + k] = lw;
+                    cr[(long long)(9 + k) * cap] = lw;
+                    rr[9 + k] = lw;
+                }
+            }
+            EQF_BSTAMP(1);
+            ldsBarrier();
+        }
+    } else if (kSpread && wv == kSbbWave) {
+        // ---- Sigma_bb: after step t-1 (generic schedule) / t-2 (fast schedule: F_bb of a step is built one tick later)
+        for (int t = 0; t < K + 2; ++t) {
+            EQF_BSTAMP(0);
+            const int u = FAST ? t - 2 : t - 1;
+            if (u >= 0 && u < K) burstStepSbb(s, u, lane, sw2, sa2, diagVar);
             EQF_BSTAMP(1);
             ldsBarrier();
         }
@@ -553,7 +610,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
             EQF_BSTAMP(0);
             // ---- panel waves: step t-2
             const int st = t - 2;
-            if (st >= 0 && st < K && s.ricc[st & 3] && L0 + 4 * wv < N) {
+            if (st >= 0 && st < K && s.ricc[st & 3] && 4 * wv < LM && L0 + 4 * wv < N) {
                 const int sl = st & 3, cur = st & 1;
                 const T* bk = s.blk[cur][4 * wv + pi];  // D, Lw, Lv of the lane's landmark (the same address for its 16 lanes)
                 const int cq = pc < 11 ? pc : 0;

@@ -123,6 +123,7 @@ struct eqf_filter {
     // full, when the vision call that follows them arrives (whose integrateUpToTime joins the burst), or when the host
     // touches the handle in any other way.  burstMax = 0: every call launches at once through k_propagate.
     int burstMax = kBurstMax;      // EQF_IMU_BURST / eqf_set_imu_burst
+    int burstLm = 0;               // builder: landmarks per workgroup, 0 = by launch size (EQF_BURST_LM = 4 | 16)
     int burstRing = 1;             // small problems: k_burst_riccati_ring (EQF_BURST_RING = 0: k_burst_riccati<1>)
     struct {
         int kind = 0;              // 0 nothing pending, 1 records k0 .. k0+cnt-1 of the uploaded stream, 2 inline records (one filter)
@@ -431,7 +432,10 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     a.steps = f->dSteps;
     a.prm = f->prm;
     const int nmx = maxN(f);
-    const dim3 bgrid(std::max(1, (nmx + kBurstLm - 1) / kBurstLm), f->B);
+    // builder: 4 landmarks per workgroup (its eight stages on eight wavefronts, shortest tick) while that launch fits the chip,
+    // 16 per workgroup (four panel waves, full lanes) otherwise
+    const int lm = f->burstLm ? f->burstLm : ((long long)((nmx + 3) / 4) * f->B <= 256 ? 4 : 16);
+    const dim3 bgrid(std::max(1, (nmx + lm - 1) / lm), f->B);
     // rows per wavefront of the block kernel: one while the launch cannot fill the chip anyway (latency), more once the
     // column constants of a lane are worth sharing between several of its blocks
     const long long waves1 = (long long)((nmx + 63) / 64) * nmx * f->B;
@@ -442,8 +446,10 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     const int rc = profiled(f, EQF_PROF_BURST, [&] {
         auto go = [&](auto zero) {
             typedef decltype(zero) TT;
-            if (fast) hipLaunchKernelGGL((k_burst_build<TT, true>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
-            else hipLaunchKernelGGL((k_burst_build<TT, false>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
+            if (fast && lm == 4) hipLaunchKernelGGL((k_burst_build<TT, true, 4>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
+            else if (fast) hipLaunchKernelGGL((k_burst_build<TT, true, 16>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
+            else if (lm == 4) hipLaunchKernelGGL((k_burst_build<TT, false, 4>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
+            else hipLaunchKernelGGL((k_burst_build<TT, false, 16>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
             if (nmx > 0) {
                 if (R == 1 && f->burstRing) hipLaunchKernelGGL(k_burst_riccati_ring<TT>, rgrid, dim3(256), 0, f->stream, a);
                 else if (R == 1) hipLaunchKernelGGL((k_burst_riccati<TT, 1>), rgrid, dim3(256), 0, f->stream, a);
@@ -1125,6 +1131,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (!rc && hipMalloc(&f->dRowRec, f->esz * (size_t)kBurstMax * kBlkRec * cap * B) != hipSuccess) rc = EQF_ERR_HIP;
     chk(dmalloc(&f->dSteps, (size_t)kBurstMax * B));
     if (const char* e = std::getenv("EQF_BURST_RING")) f->burstRing = std::atoi(e);
+    if (const char* e = std::getenv("EQF_BURST_LM")) f->burstLm = std::atoi(e) == 16 ? 16 : (std::atoi(e) == 4 ? 4 : 0);
     if (const char* e = std::getenv("EQF_IMU_BURST")) f->burstMax = std::max(0, std::min(kBurstMax, std::atoi(e)));
     if (const char* e = std::getenv("EQF_SPLIT_PROPAGATE")) f->splitPropagate = std::atoi(e);
     if (const char* e = std::getenv("EQF_STREAM_PROPAGATE")) f->streamPropagate = std::atoi(e);

@@ -691,6 +691,14 @@ def test_imu_bursts_equal_single_step_launches(hip, N, monkeypatch):
             assert np.array_equal(o[2], full[2])
         else:  # the other block kernel: the same formulas in another order
             assert rel_fro(o[0], full[0]) < 1e-9
+    # the builder's two role tables (4 / 16 landmarks per workgroup; chosen by launch size): the same formulas
+    outs = []
+    for lm in ("4", "16"):
+        monkeypatch.setenv("EQF_BURST_LM", lm)
+        outs.append(_run_bursts(hip, st, N, 15))
+    monkeypatch.delenv("EQF_BURST_LM")
+    assert rel_fro(outs[0][0], outs[1][0]) < 1e-9 and rel_fro(outs[0][0], full[0]) < 1e-9
+    assert all(np.abs(outs[0][1][k] - outs[1][1][k]).max() < 1e-9 for k in outs[0][1])
     # against the single-step kernels: the same formulas, differently compiled; rounding amplified by cond(Sigma) ~ 1e7
     assert rel_fro(full[0], ref[0]) < 1e-9
     assert all(np.abs(full[1][k] - ref[1][k]).max() < 1e-9 for k in ref[1])
