@@ -116,6 +116,7 @@ struct BurstLds {
     ImuRec rec[kBurstMax];
     StepPre pre[kBurstMax];
     unsigned stepMask;
+    volatile int handStep;  // LM = 4: wave 4 has published R_A / vhat / etahat of this step (wave 3 polls it inside the tick)
 };
 
 // The two 11 x 11 pieces every step needs of its common values: F_bb = I + T [[0,0,0,0],[-B_g^w,0,0,0],[-B_v^w,-R_A,A_vg,0]]
@@ -231,6 +232,19 @@ EQF_DI void se3ExpParts(d3 w, quat* q, m33* V) {
     *q = m2q(R);
 }
 
+// The camera-frame part of a step's common values (stepCommon's, from the precomputed halves): v_C, U_C of the current
+// sample, SE3Exp(-dt U_C).  One lane.
+EQF_DI void burstCommonCam(StepCommon& c, const StepPre& pr, const Params& p) {
+    m33 RcI;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) RcI.a[i] = p.RcamI[i];
+    const d3 Rv = mv33(RcI, c.vhat);
+    c.vC = add(pr.vCpre, Rv);        // EqFMatrices.cpp:302-304
+    c.oCcur = pr.oCcur;
+    c.vCcur = add(pr.vCcurPre, Rv);  // VIOGroup.cpp:225
+    if (p.useDiscreteVelocityLift) c.camInv = se3{pr.camq, mv33(pr.Vc, scl(-pr.dt, c.vCcur))};
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_burst_build: grid = (max(1, ceil(N / 16)), B), block = 512 = 8 wavefronts in a software pipeline, one LDS barrier per
 // tick.  A lone wavefront retires an fp64 instruction every ~6 cycles whatever the dependencies, so the serial chains are
@@ -294,6 +308,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
             rW = mk3(G0.w[0], G0.w[1], G0.w[2]);
             rV0 = mk3(G0.v0[0], G0.v0[1], G0.v0[2]);
             rEta0 = mk3(G0.eta0[0], G0.eta0[1], G0.eta0[2]);
+            if (lane == 0) s.handStep = -1;
             if (lane < 4) {  // constants of the camera offset in every slot of the ring
                 StepCommon& c = s.com[lane];
 #pragma unroll
@@ -411,20 +426,19 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
                     s.Tt[sl] = pr.step ? (T)pr.T : (T)0;
                     s.swT[sl] = (T)pr.swT;
                     if (pr.step) {
-                        // ---- common values (stepCommon's, from the precomputed halves)
-                        m33 RcI;
-#pragma unroll
-                        for (int i = 0; i < 9; ++i) RcI.a[i] = a.prm.RcamI[i];
-                        const d3 Rv = mv33(RcI, vhat);
                         c.dt = pr.dt;
                         c.T = pr.T;
                         c.RA = RA;
-                        c.vC = add(pr.vCpre, Rv);                 // EqFMatrices.cpp:302-304
-                        c.oCcur = pr.oCcur;
-                        c.vCcur = add(pr.vCcurPre, Rv);           // VIOGroup.cpp:225
-                        if (a.prm.useDiscreteVelocityLift) c.camInv = se3{pr.camq, mv33(pr.Vc, scl(-pr.dt, c.vCcur))};
                         c.vhat = vhat;      // (the input blocks B_g^w, B_v^w of F_bb are formed from these by wave 5, one tick later)
                         c.etahat = etahat;
+                    }
+                    if (kSpread) {
+                        // the camera-frame velocities of the step are wave 3's (it has no other work): hand R_A, vhat over now
+                        waveSync();
+                        s.handStep = t;
+                    }
+                    if (pr.step) {
+                        if (!kSpread) burstCommonCam(c, pr, a.prm);
                         EQF_BSTAMP(2);
                         // ---- the group step of the scalar state (stepGlobal's; VIOGroup.cpp:214-222 / :182-187, :95-96)
                         const se3 lA = se3{pr.lAq, mv33(pr.VA, scl(pr.dt, vhat))};
@@ -568,6 +582,18 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
                         rr[9 + k] = lw;
                     }
                 }
+            }
+            EQF_BSTAMP(1);
+            ldsBarrier();
+        }
+    } else if (kSpread && FAST && wv == 3) {
+        // ---- the camera-frame common values of step t, inside the tick, as soon as wave 4 has handed R_A / vhat over
+        for (int t = 0; t < K + 2; ++t) {
+            EQF_BSTAMP(0);
+            if (t < K) {
+                while (s.handStep < t) __builtin_amdgcn_s_sleep(2);
+                waveSync();
+                if (lane == 0 && s.pre[t].step) burstCommonCam(s.com[t & 3], s.pre[t], a.prm);
             }
             EQF_BSTAMP(1);
             ldsBarrier();
