@@ -137,8 +137,10 @@ EQF_DI void stTile(const f64x4& v, double* M, int ld, int r0, int c0, int lane) 
 #ifdef EQF_STEP64_STAMPS
 __device__ long long g_stamps[64][16];
 #define EQF_STAMP(i) do { if (diagNext && tid == 0 && !second) g_stamps[K][i] = __builtin_readcyclecounter(); } while (0)
+#define EQF_FSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.y == 0) g_stamps[40][i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define EQF_STAMP(i) do { } while (0)
+#define EQF_FSTAMP(i) do { } while (0)
 #endif
 
 // Right-looking Cholesky of 16 columns of a 64-row panel by one wave, one row per lane.  The rows are ROTATED so that
@@ -534,6 +536,7 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
     }
 
     EQF_STAMP(0);
+    if (second && isW && C == K && K == nb - 1) EQF_FSTAMP(0);
     // ---- every global read of the launch is issued up front (the data was written by the previous launch on other
     // XCDs: each access is a ~2 us miss, so they must all be in flight together)
     double* Ct = isW ? (W + (long long)(C * kSB) * ldW + R * kSB) : (A + (long long)(R * kSB) * ldA + C * kSB);
@@ -593,6 +596,7 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
     }
     __syncthreads();
     EQF_STAMP(1);
+    if (second && isW && C == K && K == nb - 1) EQF_FSTAMP(1);
     // ---- panel blocks: each wave solves its 16-row strip of P and of Q (16-column strip of the rhs block)
     if (PHASE != 2) {
         if (needP) {
@@ -604,6 +608,7 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
         __syncthreads();
     }
     EQF_STAMP(2);
+    if (second && isW && C == K && K == nb - 1) EQF_FSTAMP(2);
 
     if (panelA) {
         for (int e = tid; e < kSB * kSB; e += 256) A[(long long)(R * kSB + (e >> 6)) * ldA + K * kSB + (e & 63)] = s.P[e >> 6][e & 63];
@@ -634,7 +639,10 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
             }
             if (last) {
                 __syncthreads();
+                EQF_FSTAMP(3);
                 updateFinishBody(a, b, s.redL);
+                __syncthreads();
+                EQF_FSTAMP(4);
             }
         }
     } else {

@@ -20,3 +20,5 @@ for K in range(6):
     print("K=%d  loads %d  solves %d  upd0 %d  | stages (P,U): %s | end %d  total %d" % (
         K, r[1] - r[0], r[2] - r[1], r[3] - r[2], " ".join("%d,%d" % (r[8 + 2 * j] - (r[3] if j == 0 else r[8 + 2 * j - 1]), r[9 + 2 * j] - r[8 + 2 * j]) for j in range(4)),
         r[4] - r[15], r[4] - r[0]))
+r = a[40]
+print("last rhs workgroup (K = nb-1): loads %d  solve %d  stores+reductions %d  innovation lift %d  total %d" % (r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[4] - r[0]))
