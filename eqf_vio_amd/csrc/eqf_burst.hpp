@@ -8,9 +8,9 @@
 //     Sigma'_bb = F_bb Sigma_bb F_bb^T + ...                          needs Sigma_bb only
 //     Sigma'_Ib = (L_I Sigma_bb + D_I Sigma_Ib) F_bb^T + ...          needs Sigma_bb and landmark I's own 3 x 11 panel
 //     Sigma'_IJ = (D_I Sigma_IJ + L_I Sigma_bJ) D_J^T + G_I L_J^T     needs its own block and the panels of I and J
-// so the 11-wide base panels evolve on their own (k_burst_build, one workgroup per 16 landmarks, which also runs the
+// so the 11-wide base panels evolve on their own (k_burst_build, one workgroup per 4 or 16 landmarks, which also runs the
 // scalar state chain and the landmark group steps and leaves, per step and landmark, a 63-value record), and each 3x3
-// landmark block then runs all K steps in registers from those records (k_burst_riccati).
+// landmark block then runs all K steps in registers from those records (k_burst_riccati / k_burst_riccati_ring).
 //
 // The per-step arithmetic does not depend on how the calls are cut into bursts: a filter replayed with other burst
 // boundaries (e.g. after eqf_dump / restore) produces the same bits.
@@ -21,9 +21,9 @@ namespace eqf {
 
 constexpr int kBurstMax = 16;  // steps per burst
 constexpr int kBurstLmMax = 16;  // landmarks per builder workgroup: LM = 16 (throughput) or 4 (latency), see k_burst_build
+constexpr int kLwWave = 1, kSbbWave = 2;  // k_burst_build<.., 4>: waves 1..3 carry no panel and take over three of the stages
 // per step and landmark (element type T): D, Lw, Lv, Gn, Gv (the row constants, kBlkRec = 45 as in k_build_blocks) and
 // Sw = Sigma[0:3, J], Sv = Sigma[8:11, J] (entering the step) for the column side
-constexpr int kLwWave = 1, kSbbWave = 2;  // k_burst_build<.., 4>: waves 1..3 carry no panel and take over two of the stages
 constexpr int kColRec = 63;
 constexpr int kBuildThreads = 512;  // 8 wavefronts, see k_burst_build (a ninth would cap every wave at 168 VGPRs: spills)
 
@@ -246,21 +246,29 @@ EQF_DI void burstCommonCam(StepCommon& c, const StepPre& pr, const Params& p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_burst_build: grid = (max(1, ceil(N / 16)), B), block = 512 = 8 wavefronts in a software pipeline, one LDS barrier per
-// tick.  A lone wavefront retires an fp64 instruction every ~6 cycles whatever the dependencies, so the serial chains are
-// laid side by side on different SIMDs; a tick costs its longest stage instead of their sum.
+// k_burst_build<T, FAST, LM>: grid = (max(1, ceil(N / LM)), B), block = 512 = 8 wavefronts in a software pipeline, one LDS
+// barrier per tick.  A lone wavefront retires an fp64 instruction every ~6 cycles whatever the dependencies, so the serial
+// chains are laid side by side on different SIMDs; a tick costs its longest stage instead of their sum.
 //
 // FAST schedule (every filter of the handle initialised; the usual case).  Prologue: one lane per STEP computes what depends
 // on the IMU samples only (StepPre: dt, T, the rotation / V matrices of the two SE3 exponentials, ...).  Then, in tick t
-//   wave 4      state recurrence of step t on lane 0 with X.A, X.w in registers (R_A, vhat, etahat, the two group products)
-//               and the common linearisation values of the step
-//   wave 5      F_bb / noise rows of step t-1, then Sigma_bb after step t-2
-//   wave 6      group step of step t-1 for the 16 landmarks:  Q_t = Q_{t-1} * lift
-//   wave 7      blocks D, Lw, Lv of step t-1 (from Q_{t-1})
-//   waves 0..3  panels of step t-2, 4 landmarks each: G rows -> record, Sigma_Ib after the step
+//                LM = 16 (throughput: batches, large N)                  LM = 4 (latency: the launch fits the chip)
+//   wave 4       state recurrence of step t on lane 0 with X.A, X.w      the same; R_A, vhat, etahat are handed to wave 3
+//                in registers + the camera-frame common values           INSIDE the tick (LDS flag; wave 4 never waits)
+//   wave 3       panels                                                  camera-frame common values of step t
+//   wave 5       B_g^w, B_v^w, F_bb / noise rows of step t-1,             B_g^w, B_v^w, F_bb / noise rows of step t-1
+//                then Sigma_bb after step t-2
+//   wave 2       panels                                                  Sigma_bb after step t-2
+//   wave 6       group step of step t-1 (lane = landmark):  Q_t = Q_{t-1} * lift
+//   wave 7       blocks D, Lv, Lw of step t-1 (from Q_{t-1})              blocks D, Lv
+//   wave 1       panels                                                  blocks Lw
+//   wave 0       panels of step t-2, 4 landmarks per panel wave (lane = (landmark, base column), the 3 x 11 panel in
+//                registers): G rows -> record, Sigma_Ib after the step
+// With 16 landmarks per workgroup eight busy waves share four SIMDs and every stage runs ~1.3x slower than with the stages
+// spread over the otherwise idle waves of a 4-landmark workgroup (N = 200, one filter: 51 -> 43 us per burst).
 // Generic schedule (some filter still waits for its first IMU sample: lazy initialisation, VIOFilter.cpp:122-124, in the
-// chain): wave 4 runs stepGlobal on the LDS copy of the scalar state (+ Sigma_bb after step t-1), wave 5 stepCommon + F_bb
-// of step t -- the functions of eqf_propagate.hpp as they are.  Both schedules do the same arithmetic per step.
+// chain): wave 4 runs stepGlobal on the LDS copy of the scalar state, wave 5 stepCommon + F_bb of step t -- the functions of
+// eqf_propagate.hpp as they are (Sigma_bb after step t-1 by wave 4 / wave 2).  Both schedules do the same arithmetic per step.
 // ------------------------------------------------------------------------------------------------
 template <typename T, bool FAST, int LM>
 __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
