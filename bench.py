@@ -292,6 +292,8 @@ def main():
             "landmarks": N,
             "events": {"imu": sum(1 for k, _ in timed if k == "imu"), "vision": sum(1 for k, _ in timed if k == "vision")},
             "parallelism": "independent filters sharded over %d GPU(s), RCCL scatter/gather only" % world,
+            "imu_burst": "IMU calls between two vision frames + the vision call's integrateUpToTime leave as one burst of <= 16 steps "
+                         "(2 launches, Sigma read/written once; every step is the reference's step); EQF_IMU_BURST=0: one launch per call",
         },
         "device_error_flag": err,
         "sigma_fro_filter0": float(res[0, 7]) if res is not None else None,
