@@ -123,6 +123,7 @@ struct eqf_filter {
     // full, when the vision call that follows them arrives (whose integrateUpToTime joins the burst), or when the host
     // touches the handle in any other way.  burstMax = 0: every call launches at once through k_propagate.
     int burstMax = kBurstMax;      // EQF_IMU_BURST / eqf_set_imu_burst
+    int burstRows = 0;             // block kernel: row landmarks per wavefront, 0 = by launch size (EQF_BURST_ROWS = 1 | 2 | 4)
     int burstLm = 0;               // builder: landmarks per workgroup, 0 = by launch size (EQF_BURST_LM = 4 | 16)
     int burstRing = 1;             // small problems: k_burst_riccati_ring (EQF_BURST_RING = 0: k_burst_riccati<1>)
     struct {
@@ -439,7 +440,7 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     // rows per wavefront of the block kernel: one while the launch cannot fill the chip anyway (latency), more once the
     // column constants of a lane are worth sharing between several of its blocks
     const long long waves1 = (long long)((nmx + 63) / 64) * nmx * f->B;
-    const int R = waves1 <= 4096 ? 1 : (waves1 <= 32768 ? 2 : 4);
+    const int R = f->burstRows ? f->burstRows : (waves1 <= 4096 ? 1 : (waves1 <= 32768 ? 2 : 4));
     const dim3 rgrid((nmx + 63) / 64, (nmx + 4 * R - 1) / (4 * R), f->B);
     // every filter past its lazy initialisation (VIOFilter.cpp:122-124): the schedule with the precomputed step halves
     const bool fast = allDevInit(f);
@@ -1131,6 +1132,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (!rc && hipMalloc(&f->dRowRec, f->esz * (size_t)kBurstMax * kBlkRec * cap * B) != hipSuccess) rc = EQF_ERR_HIP;
     chk(dmalloc(&f->dSteps, (size_t)kBurstMax * B));
     if (const char* e = std::getenv("EQF_BURST_RING")) f->burstRing = std::atoi(e);
+    if (const char* e = std::getenv("EQF_BURST_ROWS")) f->burstRows = (std::atoi(e) == 1 || std::atoi(e) == 2 || std::atoi(e) == 4) ? std::atoi(e) : 0;
     if (const char* e = std::getenv("EQF_BURST_LM")) f->burstLm = std::atoi(e) == 16 ? 16 : (std::atoi(e) == 4 ? 4 : 0);
     if (const char* e = std::getenv("EQF_IMU_BURST")) f->burstMax = std::max(0, std::min(kBurstMax, std::atoi(e)));
     if (const char* e = std::getenv("EQF_SPLIT_PROPAGATE")) f->splitPropagate = std::atoi(e);

@@ -691,6 +691,13 @@ def test_imu_bursts_equal_single_step_launches(hip, N, monkeypatch):
             assert np.array_equal(o[2], full[2])
         else:  # the other block kernel: the same formulas in another order
             assert rel_fro(o[0], full[0]) < 1e-9
+    # the block kernel with 2 and 4 row landmarks per wavefront (large problems; EQF_BURST_ROWS forces it here)
+    for rows in ("2", "4"):
+        monkeypatch.setenv("EQF_BURST_ROWS", rows)
+        o = _run_bursts(hip, st, N, 15)
+        assert rel_fro(o[0], full[0]) < 1e-9, rows
+        assert all(np.abs(o[1][k] - full[1][k]).max() < 1e-9 for k in full[1])
+    monkeypatch.delenv("EQF_BURST_ROWS")
     # the builder's two role tables (4 / 16 landmarks per workgroup; chosen by launch size): the same formulas
     outs = []
     for lm in ("4", "16"):
