@@ -71,6 +71,7 @@ def lib():
         L.oracle_create.restype = C.c_void_p
         L.oracle_create.argtypes = [C.POINTER(OracleSettings)]
         L.oracle_destroy.argtypes = [C.c_void_p]
+        L.oracle_set_structured.argtypes = [C.c_void_p, C.c_int]
         L.oracle_process_imu.argtypes = [C.c_void_p, C.c_double, dp, dp]
         L.oracle_process_vision.argtypes = [C.c_void_p, C.c_double, C.c_int, ip, dp]
         L.oracle_num_landmarks.argtypes = [C.c_void_p]
@@ -92,11 +93,18 @@ def _dp(a):
 
 
 class OracleFilter:
-    """The reference's VIOFilter API on the C++ fp64 oracle."""
+    """The reference's VIOFilter API on the C++ fp64 oracle.
 
-    def __init__(self, settings_dict):
+    structured=False: the reference's dense operation sequence (the parity anchor and the "cpu_baseline").
+    structured=True:  the same equations without the structural-zero work and with Cholesky-form S^-1 / Sigma_e^-1
+                      ("cpu_structured"); pinned against the dense form by tests/test_oracle_structured.py."""
+
+    def __init__(self, settings_dict, structured=False):
         self._s = make_settings(settings_dict)
         self._h = C.c_void_p(lib().oracle_create(C.byref(self._s)))
+        self.structured = bool(structured)
+        if structured:
+            lib().oracle_set_structured(self._h, 1)
 
     def __del__(self):
         if getattr(self, "_h", None):

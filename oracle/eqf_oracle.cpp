@@ -324,30 +324,31 @@ inline void setBlock(Mat& A, int i0, int j0, const M3& b, double s = 1.0) {
 // the timed CPU baseline is not handicapped by a naive triple loop.
 typedef double v4d __attribute__((vector_size(32), aligned(8)));
 
-Mat gemm(const Mat& A, const Mat& Bin, bool transB = false) {
-    const int M = A.r, K = A.c, N = transB ? Bin.r : Bin.c;
-    Mat C(M, N);
-    if (M == 0 || N == 0 || K == 0) return C;
+// C (M x N, row-major, leading dimension ldc) += alpha * A (M x K, lda) * op(B), op(B) = B (K x N, ldb) or, with
+// transB, B^T for B stored N x K.
+void gemmCore(int M, int N, int K, const double* A, int lda, const double* B, int ldb, bool transB, double* C, int ldc,
+    double alpha) {
+    if (M == 0 || N == 0 || K == 0) return;
     constexpr int KB = 256, NR = 8, MR = 6;
     const int NP = (N + NR - 1) / NR;  // number of 8-wide column panels
     std::vector<double> Bp(size_t(NP) * KB * NR);
     for (int k0 = 0; k0 < K; k0 += KB) {
         const int kb = std::min(KB, K - k0);
-        // pack B[k0:k0+kb, :] into panels [panel][k][8], zero padded
+        // pack op(B)[k0:k0+kb, :] into panels [panel][k][8], zero padded
         for (int pn = 0; pn < NP; ++pn) {
             double* dst = &Bp[size_t(pn) * KB * NR];
             for (int k = 0; k < kb; ++k)
                 for (int j = 0; j < NR; ++j) {
                     const int col = pn * NR + j;
                     double v = 0.0;
-                    if (col < N) v = transB ? Bin(col, k0 + k) : Bin(k0 + k, col);
+                    if (col < N) v = transB ? B[size_t(col) * ldb + k0 + k] : B[size_t(k0 + k) * ldb + col];
                     dst[k * NR + j] = v;
                 }
         }
         for (int i0 = 0; i0 < M; i0 += MR) {
             const int mr = std::min(MR, M - i0);
             const double* a[MR];
-            for (int r = 0; r < MR; ++r) a[r] = &A.d[size_t(std::min(i0 + r, M - 1)) * K + k0];
+            for (int r = 0; r < MR; ++r) a[r] = &A[size_t(std::min(i0 + r, M - 1)) * lda + k0];
             for (int pn = 0; pn < NP; ++pn) {
                 const double* b = &Bp[size_t(pn) * KB * NR];
                 v4d c[MR][2];
@@ -364,12 +365,18 @@ Mat gemm(const Mat& A, const Mat& Bin, bool transB = false) {
                 }
                 const int nc = std::min(NR, N - pn * NR);
                 for (int r = 0; r < mr; ++r) {
-                    double* crow = &C.d[size_t(i0 + r) * N + pn * NR];
-                    for (int j = 0; j < nc; ++j) crow[j] += (j < 4 ? c[r][0][j] : c[r][1][j - 4]);
+                    double* crow = &C[size_t(i0 + r) * ldc + pn * NR];
+                    for (int j = 0; j < nc; ++j) crow[j] += alpha * (j < 4 ? c[r][0][j] : c[r][1][j - 4]);
                 }
             }
         }
     }
+}
+
+Mat gemm(const Mat& A, const Mat& Bin, bool transB = false) {
+    const int M = A.r, K = A.c, N = transB ? Bin.r : Bin.c;
+    Mat C(M, N);
+    gemmCore(M, N, K, A.d.data(), A.c, Bin.d.data(), Bin.c, transB, C.d.data(), N, 1.0);
     return C;
 }
 }  // namespace
@@ -461,6 +468,122 @@ void qrSolve(int n, std::vector<double> A, std::vector<double> b, double* x) {
         double s = b[i];
         for (int j = i + 1; j < n; ++j) s -= A[i * n + j] * x[j];
         x[i] = s / A[i * n + i];
+    }
+}
+
+// ------------------------------------------------------------------ structured backend ("cpu_structured")
+// The same filter equations evaluated without the reference's structural-zero work: F = I + T*A_b and C_b as sparse row
+// lists, S^-1 / Sigma_e^-1 through Cholesky factors and forward substitutions instead of explicit inverses.  Exact-
+// arithmetic identities only (K*delta = Y^T L^-1 delta, K C Sigma = Y^T Y with S = L L^T, Y = L^-1 C Sigma); it differs
+// from the dense evaluation by rounding.  tests/test_oracle_structured.py holds it against the dense backend; it exists
+// so that N >= 1000 parity tests are affordable and so that bench.py can report the algorithmic share of the speed-up.
+struct SparseRows {  // row i: entries [start[i], start[i+1]) of (col, val)
+    int rows = 0;
+    std::vector<int> start, col;
+    std::vector<double> val;
+    SparseRows() : start(1, 0) {}
+    void push(int c, double v) {
+        col.push_back(c);
+        val.push_back(v);
+    }
+    void endRow() {
+        start.push_back(int(col.size()));
+        ++rows;
+    }
+};
+// out (A.rows x B.c) = A * B for dense row-major B; `out` is reshaped and overwritten (caller-owned scratch: no allocation
+// once it has the size).
+void sparseTimesDense(const SparseRows& A, const Mat& B, Mat& out) {
+    out.r = A.rows;
+    out.c = B.c;
+    out.d.resize(size_t(A.rows) * B.c);
+    for (int i = 0; i < A.rows; ++i) {
+        double* o = &out.d[size_t(i) * B.c];
+        std::fill(o, o + B.c, 0.0);
+        for (int e = A.start[i]; e < A.start[i + 1]; ++e) {
+            const double v = A.val[e];
+            const double* b = &B.d[size_t(A.col[e]) * B.c];
+            for (int j = 0; j < B.c; ++j) o[j] += v * b[j];
+        }
+    }
+}
+void transposeInto(const Mat& A, Mat& T) {
+    T.r = A.c;
+    T.c = A.r;
+    T.d.resize(A.d.size());
+    constexpr int TB = 16;
+    for (int i0 = 0; i0 < A.r; i0 += TB)
+        for (int j0 = 0; j0 < A.c; j0 += TB) {
+            const int i1 = std::min(A.r, i0 + TB), j1 = std::min(A.c, j0 + TB);
+            for (int j = j0; j < j1; ++j)
+                for (int i = i0; i < i1; ++i) T.d[size_t(j) * A.r + i] = A.d[size_t(i) * A.c + j];
+        }
+}
+// C (n x n, ldc) -= A A^T for A (n x k, lda): lower block triangle by gemmCore, then mirrored (the result is symmetric).
+void syrkLowerMinus(int n, int k, const double* A, int lda, double* C, int ldc) {
+    constexpr int RB = 96;
+    for (int i0 = 0; i0 < n; i0 += RB) {
+        const int ib = std::min(RB, n - i0);
+        gemmCore(ib, i0 + ib, k, &A[size_t(i0) * lda], lda, A, lda, true, &C[size_t(i0) * ldc], ldc, -1.0);
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j) C[size_t(i) * ldc + j] = C[size_t(j) * ldc + i];
+}
+// In-place lower Cholesky A = L L^T of the leading n x n block (row-major, leading dimension ld), blocked right-looking;
+// the strict upper triangle is neither read nor kept meaningful.  Returns false if a pivot <= 0.
+bool choleskyBlocked(double* A, int n, int ld) {
+    constexpr int NB = 64;
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        const int kb = std::min(NB, n - k0);
+        for (int j = k0; j < k0 + kb; ++j) {  // unblocked factorisation of the diagonal block
+            double d = A[size_t(j) * ld + j];
+            for (int k = k0; k < j; ++k) d -= A[size_t(j) * ld + k] * A[size_t(j) * ld + k];
+            if (!(d > 0)) return false;
+            d = std::sqrt(d);
+            A[size_t(j) * ld + j] = d;
+            for (int i = j + 1; i < k0 + kb; ++i) {
+                double v = A[size_t(i) * ld + j];
+                for (int k = k0; k < j; ++k) v -= A[size_t(i) * ld + k] * A[size_t(j) * ld + k];
+                A[size_t(i) * ld + j] = v / d;
+            }
+        }
+        const int r0 = k0 + kb, rest = n - r0;
+        if (rest <= 0) break;
+        for (int i = r0; i < n; ++i) {  // panel: L_ik = A_ik L_kk^-T, row by row
+            double* a = &A[size_t(i) * ld + k0];
+            for (int j = 0; j < kb; ++j) {
+                const double* l = &A[size_t(k0 + j) * ld + k0];
+                double v = a[j];
+                for (int k = 0; k < j; ++k) v -= a[k] * l[k];
+                a[j] = v / l[j];
+            }
+        }
+        // trailing block -= panel * panel^T, lower block triangle only (the upper half is never read)
+        constexpr int RB = 96;
+        for (int i0 = 0; i0 < rest; i0 += RB) {
+            const int ib = std::min(RB, rest - i0);
+            gemmCore(ib, i0 + ib, kb, &A[size_t(r0 + i0) * ld + k0], ld, &A[size_t(r0) * ld + k0], ld, true,
+                &A[size_t(r0 + i0) * ld + r0], ld, -1.0);
+        }
+    }
+    return true;
+}
+// W (n x r, leading dimension ldw) <- L^-1 W for the lower factor L (n x n, ld), blocked forward substitution.
+void forwardSolve(const double* L, int n, int ld, double* W, int r, int ldw) {
+    constexpr int NB = 64;
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        const int kb = std::min(NB, n - k0);
+        if (k0 > 0) gemmCore(kb, r, k0, &L[size_t(k0) * ld], ld, W, ldw, false, &W[size_t(k0) * ldw], ldw, -1.0);
+        for (int i = k0; i < k0 + kb; ++i) {
+            double* wi = &W[size_t(i) * ldw];
+            for (int k = k0; k < i; ++k) {
+                const double l = L[size_t(i) * ld + k];
+                const double* wk = &W[size_t(k) * ldw];
+                for (int j = 0; j < r; ++j) wi[j] -= l * wk[j];
+            }
+            const double inv = 1.0 / L[size_t(i) * ld + i];
+            for (int j = 0; j < r; ++j) wi[j] *= inv;
+        }
     }
 }
 
@@ -651,7 +774,8 @@ Mat EqFInputMatrixB(const Group& X, const Manifold& xi0) {  // :346-382
     return Bt;
 }
 
-std::vector<double> bundleLift(const std::vector<double>& base, const State& xi0, const Group& X, const Mat& Sigma) {  // :173-252
+std::vector<double> bundleLift(const std::vector<double>& base, const State& xi0, const Group& X, const Mat& Sigma,
+    bool structured = false) {  // :173-252
     const State xiHat = stateGroupAction(X, xi0);
     const int N = int(xi0.p.size());
     const V3 eta0 = normalized(projectToManifold(xi0).gravityDir);
@@ -714,18 +838,49 @@ std::vector<double> bundleLift(const std::vector<double>& base, const State& xi0
         }
         setBlock(D, 5 + 3 * i, 3 * i, X.Q[i].asMatrix3() * R_CT);
     }
-    // weightMat = D^T * Sigma^-1 * D   (:239, explicit dense inverse, evaluated left to right)
-    Mat Dt(D.c, D.r);
-    for (int i = 0; i < D.r; ++i)
-        for (int j = 0; j < D.c; ++j) Dt(j, i) = D(i, j);
-    const Mat W = gemm(gemm(Dt, inverseLU(Sigma)), D);
-    // (coeff^T W coeff) x = coeff^T W obs
-    Mat coeffT(4, 3 * N);
-    for (int i = 0; i < 3 * N; ++i)
-        for (int j = 0; j < 4; ++j) coeffT(j, i) = coeff(i, j);
-    const Mat cTW = gemm(coeffT, W);
-    const Mat lhs = gemm(cTW, coeff);
-    const Mat rhs = gemm(cTW, obs);
+    Mat lhs(4, 4), rhs(4, 1);
+    bool done = false;
+    if (structured) {
+        // coeff^T (D^T Sigma^-1 D) [coeff | obs] = (L^-1 D coeff)^T (L^-1 D [coeff | obs]) with Sigma = L L^T
+        const int ne = 5 + 3 * N;
+        Mat Z(ne, 5);
+        for (int i = 0; i < N; ++i)
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 5; ++c) {
+                    double acc = 0;
+                    for (int k = 0; k < 3; ++k) acc += D(5 + 3 * i + r, 3 * i + k) * (c < 4 ? coeff(3 * i + k, c) : obs(3 * i + k, 0));
+                    Z(5 + 3 * i + r, c) = acc;
+                }
+        Mat L = Sigma;
+        if (choleskyBlocked(L.d.data(), ne, ne)) {
+            forwardSolve(L.d.data(), ne, ne, Z.d.data(), 5, 5);
+            for (int a = 0; a < 4; ++a) {
+                for (int b = 0; b < 4; ++b) {
+                    double acc = 0;
+                    for (int i = 0; i < ne; ++i) acc += Z(i, a) * Z(i, b);
+                    lhs(a, b) = acc;
+                }
+                double acc = 0;
+                for (int i = 0; i < ne; ++i) acc += Z(i, a) * Z(i, 4);
+                rhs(a, 0) = acc;
+            }
+            done = true;
+        }
+    }
+    if (!done) {
+        // weightMat = D^T * Sigma^-1 * D   (:239, explicit dense inverse, evaluated left to right)
+        Mat Dt(D.c, D.r);
+        for (int i = 0; i < D.r; ++i)
+            for (int j = 0; j < D.c; ++j) Dt(j, i) = D(i, j);
+        const Mat W = gemm(gemm(Dt, inverseLU(Sigma)), D);
+        // (coeff^T W coeff) x = coeff^T W obs
+        Mat coeffT(4, 3 * N);
+        for (int i = 0; i < 3 * N; ++i)
+            for (int j = 0; j < 4; ++j) coeffT(j, i) = coeff(i, j);
+        const Mat cTW = gemm(coeffT, W);
+        lhs = gemm(cTW, coeff);
+        rhs = gemm(cTW, obs);
+    }
     double sol[4];
     qrSolve(4, lhs.d, rhs.d, sol);
     std::vector<double> lifted(9 + 3 * N);
@@ -796,6 +951,8 @@ struct Filter {
     // internals of the last update (for kernel-level parity tests)
     std::vector<double> lastDelta, lastGamma, lastGammaTotal;
     Mat lastS;
+    bool structured = false;  // cpu_structured backend (same equations, no structural-zero work, Cholesky-form update)
+    Mat scrFS, scrFSt, scrG;  // scratch of riccatiStructured (kept between calls)
 
     explicit Filter(const Settings& st) : s(st) {  // VIOFilter.cpp:60-73
         Sigma = Mat::Identity(SIGMA_BASE_SIZE);
@@ -837,7 +994,11 @@ struct Filter {
         accumulatedVelocity = imuAdd(accumulatedVelocity, imuScale(currentVelocity, dt));
         const int N = int(xi0.p.size());
         const State currentState = stateEstimate();
-        if (doRiccati) {
+        if (doRiccati && structured) {
+            riccatiStructured(N);
+            accumulatedVelocity = IMU{};
+            accumulatedTime = 0.0;
+        } else if (doRiccati) {
             const int n = Sigma.r;
             Mat PMat = Mat::Identity(n);
             for (int i = 0; i < 3; ++i) {
@@ -880,6 +1041,53 @@ struct Filter {
             X = groupMul(X, liftVelocityExp(cur, currentVelocity, dt));
         currentTime = newTime;
         return true;
+    }
+
+    // VIOFilter.cpp:160-194 with F = I + T*A_b as sparse rows (9 non-zeros per landmark row): Sigma <- T(P + B R B^T) +
+    // F Sigma F^T evaluated as (F (F Sigma)^T)^T, the rank-6 input noise term from the 6 columns of B.
+    void riccatiStructured(int N) {
+        const int n = Sigma.r;
+        const double T = accumulatedTime;
+        const Manifold xi0m = projectToManifold(xi0);
+        const Mat A0t = EqFStateMatrixA(X, xi0m, imuScale(accumulatedVelocity, 1.0 / accumulatedTime));
+        const Mat Bt = EqFInputMatrixB(X, xi0m);
+        SparseRows F;
+        for (int i = 0; i < 6; ++i) {
+            F.push(i, 1.0);
+            F.endRow();
+        }
+        for (int i = 0; i < A0t.r; ++i) {
+            for (int j = 0; j < 6; ++j)
+                if (Bt(i, j) != 0.0) F.push(j, -Bt(i, j) * T);
+            for (int j = 0; j < A0t.c; ++j) {
+                const double v = (i == j ? 1.0 : 0.0) + A0t(i, j) * T;
+                if (v != 0.0) F.push(6 + j, v);
+            }
+            F.endRow();
+        }
+        sparseTimesDense(F, Sigma, scrFS);
+        transposeInto(scrFS, scrFSt);  // = Sigma F^T (Sigma is symmetric to rounding; the reference multiplies F Sigma first too)
+        sparseTimesDense(F, scrFSt, scrG);  // = (F Sigma) F^T transposed
+        const Mat& G = scrG;
+        const double Rw = s.velOmegaVariance, Ra = s.velAccelVariance;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                double q = 0;
+                if (i >= 6 && j >= 6) {
+                    const double* bi = &Bt.d[size_t(i - 6) * 6];
+                    const double* bj = &Bt.d[size_t(j - 6) * 6];
+                    q = Rw * (bi[0] * bj[0] + bi[1] * bj[1] + bi[2] * bj[2]) + Ra * (bi[3] * bj[3] + bi[4] * bj[4] + bi[5] * bj[5]);
+                }
+                if (i == j) {
+                    q += i < 3 ? s.biasOmegaProcessVariance
+                       : i < 6 ? s.biasAccelProcessVariance
+                       : i < 8 ? s.gravityProcessVariance
+                       : i < 11 ? s.velocityProcessVariance
+                                : s.pointProcessVariance;
+                }
+                Sigma(i, j) = T * q + G(j, i);
+            }
+        (void)N;
     }
 
     void removeLandmarkAtIndex(int idx) {  // :421-427
@@ -976,14 +1184,55 @@ struct Filter {
         Mat Cb(m, n);
         for (int i = 0; i < m; ++i)
             for (int j = 0; j < C0.c; ++j) Cb(i, 6 + j) = C0(i, j);
-        Mat S = gemm(gemm(Cb, Sigma), Cb, true);
-        for (int i = 0; i < m; ++i) S(i, i) += s.measurementVariance;
-        const Mat K = gemm(gemm(Sigma, Cb, true), inverseLU(S));
+        Mat S, K, Yt;  // Yt (structured only): (L^-1 C Sigma)^T, n x m
         std::vector<double> gam(n, 0.0);
-        for (int i = 0; i < n; ++i) {
-            double acc = 0;
-            for (int j = 0; j < m; ++j) acc += K(i, j) * delta[j];
-            gam[i] = acc;
+        bool chol = false;
+        if (structured) {
+            SparseRows Cs;
+            for (int i = 0; i < m; ++i) {
+                for (int j = 0; j < C0.c; ++j)
+                    if (C0(i, j) != 0.0) Cs.push(6 + j, C0(i, j));
+                Cs.endRow();
+            }
+            Mat CS;
+            sparseTimesDense(Cs, Sigma, CS);
+            S = Mat(m, m);
+            for (int i = 0; i < m; ++i) {
+                for (int j = 0; j < m; ++j) {
+                    double acc = 0;
+                    for (int e = Cs.start[j]; e < Cs.start[j + 1]; ++e) acc += CS(i, Cs.col[e]) * Cs.val[e];
+                    S(i, j) = acc;
+                }
+                S(i, i) += s.measurementVariance;
+            }
+            Mat L = S;
+            if (choleskyBlocked(L.d.data(), m, m)) {
+                Mat W(m, n + 1);  // [C Sigma | delta]
+                for (int i = 0; i < m; ++i) {
+                    std::copy(&CS.d[size_t(i) * n], &CS.d[size_t(i) * n] + n, &W.d[size_t(i) * (n + 1)]);
+                    W(i, n) = delta[i];
+                }
+                forwardSolve(L.d.data(), m, m, W.d.data(), n + 1, n + 1);
+                for (int r = 0; r < m; ++r) {
+                    const double z = W(r, n);
+                    const double* y = &W.d[size_t(r) * (n + 1)];
+                    for (int i = 0; i < n; ++i) gam[i] += y[i] * z;  // K delta = Y^T (L^-1 delta)
+                }
+                Yt = Mat(n, m);
+                for (int r = 0; r < m; ++r)
+                    for (int i = 0; i < n; ++i) Yt(i, r) = W(r, i);
+                chol = true;
+            }
+        }
+        if (!chol) {
+            S = gemm(gemm(Cb, Sigma), Cb, true);
+            for (int i = 0; i < m; ++i) S(i, i) += s.measurementVariance;
+            K = gemm(gemm(Sigma, Cb, true), inverseLU(S));
+            for (int i = 0; i < n; ++i) {
+                double acc = 0;
+                for (int j = 0; j < m; ++j) acc += K(i, j) * delta[j];
+                gam[i] = acc;
+            }
         }
         std::vector<double> gE(gam.begin() + 6, gam.end());
         Group Delta;
@@ -991,7 +1240,7 @@ struct Filter {
             Mat Se(n - 6, n - 6);
             for (int i = 0; i < n - 6; ++i)
                 for (int j = 0; j < n - 6; ++j) Se(i, j) = Sigma(6 + i, 6 + j);
-            const std::vector<double> G = bundleLift(gE, xi0, X, Se);
+            const std::vector<double> G = bundleLift(gE, xi0, X, Se, structured);
             lastGammaTotal = G;
             if (s.useDiscreteInnovationLift) {
                 Delta = liftTotalSpaceInnovationDiscrete(G, xi0);
@@ -1015,8 +1264,12 @@ struct Filter {
         lastS = S;
         for (int i = 0; i < 6; ++i) inputBias[i] += gam[i];
         X = groupMul(Delta, X);
-        const Mat KCS = gemm(gemm(K, Cb), Sigma);
-        for (size_t k = 0; k < Sigma.d.size(); ++k) Sigma.d[k] -= KCS.d[k];
+        if (chol) {  // K C Sigma = Y^T Y
+            syrkLowerMinus(n, m, Yt.d.data(), m, Sigma.d.data(), n);
+        } else {
+            const Mat KCS = gemm(gemm(K, Cb), Sigma);
+            for (size_t k = 0; k < Sigma.d.size(); ++k) Sigma.d[k] -= KCS.d[k];
+        }
     }
 };
 
@@ -1096,6 +1349,8 @@ static Settings toSettings(const oracle_settings* o) {
 
 void* oracle_create(const oracle_settings* o) { return new Filter(toSettings(o)); }
 void oracle_destroy(void* h) { delete static_cast<Filter*>(h); }
+// 0 = dense reference operation sequence (default), 1 = structured backend (same equations, see "structured backend")
+void oracle_set_structured(void* h, int on) { static_cast<Filter*>(h)->structured = on != 0; }
 // returns 0 ok, -1 antipodal domain_error (libs/core/src/SO3.cpp:160-161)
 int oracle_process_imu(void* h, double stamp, const double* w, const double* a) {
     try {

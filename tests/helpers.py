@@ -33,9 +33,9 @@ def frame_record(q, x, v, bias, S, n):
     return np.concatenate([q, x, v, bias, [np.linalg.norm(S), n]])
 
 
-def run_oracle_on_golden(ob, d, settings, capture=()):
+def run_oracle_on_golden(ob, d, settings, capture=(), structured=False):
     """C++ oracle over a golden fixture -> per-frame records, final filter, captured internals."""
-    f = ob.OracleFilter(settings)
+    f = ob.OracleFilter(settings, structured=structured)
     frames, internals = [], {}
     for kind, k in events_of(d["imu"], d["vision_stamps"]):
         if kind == "imu":
@@ -70,3 +70,17 @@ def run_hip_on_golden(binding, d, settings, capacity, capture=(), precision=0):
 
 def rel_fro(A, B):
     return np.linalg.norm(A - B) / np.linalg.norm(B)
+
+
+def drive_pair(stream, a_imu, a_vis, b_imu, b_vis, on_frame=None):
+    """Feed one synthetic stream to two filters (callables taking the event's arrays); on_frame(k) after each vision call."""
+    for kind, k in stream.events():
+        if kind == "imu":
+            r = stream.imu[k]
+            a_imu(r[0], r[1:4], r[4:7])
+            b_imu(r[0], r[1:4], r[4:7])
+        else:
+            a_vis(stream.vision_stamps[k], stream.ids, stream.bearings[k])
+            b_vis(stream.vision_stamps[k], stream.ids, stream.bearings[k])
+            if on_frame is not None:
+                on_frame(k)
