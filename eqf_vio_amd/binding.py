@@ -18,7 +18,7 @@ SKIPPED_NOT_INITIALISED = 3
 SKIPPED_NO_BEARINGS = 4
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSORTED, ERR_NUMERIC, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
 PRECISION_F64, PRECISION_F32 = 0, 1
-PROF_CLASSES = 9
+PROF_CLASSES = 10
 
 _ERR_NAMES = {
     -1: "EQF_ERR_INVALID", -2: "EQF_ERR_NO_DEVICE", -3: "EQF_ERR_HIP", -4: "EQF_ERR_CAPACITY",
@@ -58,7 +58,7 @@ EXPORTED_SYMBOLS = [
     "eqf_settings_default", "eqf_create", "eqf_destroy", "eqf_reset", "eqf_process_imu", "eqf_process_vision",
     "eqf_stream_upload", "eqf_stream_imu", "eqf_stream_vision", "eqf_synchronize", "eqf_get_time", "eqf_num_landmarks",
     "eqf_get_ids", "eqf_get_state_estimate", "eqf_get_origin", "eqf_get_group", "eqf_get_bias", "eqf_get_sigma",
-    "eqf_set_sigma", "eqf_set_state", "eqf_set_camera_offset", "eqf_get_integrator", "eqf_get_last_update", "eqf_device_error", "eqf_set_dense_propagate", "eqf_set_imu_burst", "eqf_profile_enable",
+    "eqf_set_sigma", "eqf_set_state", "eqf_set_camera_offset", "eqf_get_integrator", "eqf_get_last_update", "eqf_debug_get_blocks", "eqf_device_error", "eqf_set_dense_propagate", "eqf_set_imu_burst", "eqf_profile_enable",
     "eqf_profile_get", "eqf_profile_class_name", "eqf_version",
 ]
 
@@ -97,6 +97,7 @@ def lib():
         L.eqf_get_last_update.argtypes = [vp, C.c_int, _dp, _dp, _dp]
         L.eqf_set_state.argtypes = [vp, C.c_int, C.c_int, _ip] + [_dp] * 11 + [C.c_int, C.c_double, _dp, _dp, C.c_double, C.c_int]
         L.eqf_get_integrator.argtypes = [vp, C.c_int, _dp, _dp, _dp, _ip]
+        L.eqf_debug_get_blocks.argtypes = [vp, C.c_int, _dp, _dp, _dp]
         L.eqf_device_error.argtypes = [vp]
         L.eqf_set_dense_propagate.argtypes = [vp, C.c_int]
         L.eqf_set_imu_burst.argtypes = [vp, C.c_int]
@@ -322,6 +323,15 @@ class FilterBatch:
         delta, gamma, Gamma = np.zeros(max(2 * N, 1)), np.zeros(11 + 3 * N), np.zeros(9 + 3 * N)
         _check(lib().eqf_get_last_update(self._h, b, _p(delta), _p(gamma), _p(Gamma)), "eqf_get_last_update")
         return dict(delta=delta[: 2 * N], gamma=gamma, Gamma=Gamma)
+
+    def debug_blocks(self, b=0):
+        """Linearisation blocks of the last single-step split-path launch + the C0i blocks (include/eqf_vio_amd.h)."""
+        N = self.num_landmarks(b)
+        common, rec, c0 = np.zeros(31), np.zeros((max(N, 1), 27)), np.zeros((max(N, 1), 6))
+        _check(lib().eqf_debug_get_blocks(self._h, b, _p(common), _p(rec), _p(c0)), "eqf_debug_get_blocks")
+        return dict(T=common[0], Bg=common[1:7].reshape(2, 3), Bvw=common[7:16].reshape(3, 3), RA=common[16:25].reshape(3, 3),
+                    Avg=common[25:31].reshape(3, 2), D=rec[:N, 0:9].reshape(N, 3, 3), Lw=rec[:N, 9:18].reshape(N, 3, 3),
+                    Lv=rec[:N, 18:27].reshape(N, 3, 3), C0=c0[:N].reshape(N, 2, 3))
 
     def device_error(self):
         return lib().eqf_device_error(self._h)

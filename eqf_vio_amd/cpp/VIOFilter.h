@@ -7,6 +7,7 @@
 // the HIP kernels behind include/eqf_vio_amd.h; this header is plumbing only and has no CPU fallback.
 #pragma once
 #include <array>
+#include <cmath>
 #include <memory>
 #include <ostream>
 #include <stdexcept>
@@ -117,6 +118,19 @@ class VIOFilter {
     VIOFilter& operator=(VIOFilter&&) = default;  // eqf_vio_ros_node.cpp:59 move-assigns
 
     void reset() { check(eqf_reset(handle_.get()), "eqf_reset"); }  // VIOFilter.cpp:84-91
+
+    // VIOFilter.cpp:133-144: origin pose = identity position + the attitude that takes the measured specific-force
+    // direction to e3, zero origin velocity, initialised.  processIMUData does this lazily on the device at the first
+    // sample (with the bias-corrected sample); this member is the explicit form of the reference's public method and takes
+    // the velocity as given.  Throws std::domain_error like SO3FromVectors (SO3.cpp:160-161) for accel = -|accel| e3.
+    void initialiseFromIMUData(const IMUVelocity& imuVelocity) {
+        Snapshot st = dump();
+        st.pq = so3FromVectors(imuVelocity.accel, {0, 0, 1});
+        st.px = {0, 0, 0};
+        st.v = {0, 0, 0};
+        st.initialised = 1;
+        restore(st);
+    }
 
     // VIOFilter.cpp:120-131
     void processIMUData(const IMUVelocity& imuVelocity) {
@@ -284,6 +298,49 @@ class VIOFilter {
     static std::array<double, 4> qmul(const std::array<double, 4>& a, const std::array<double, 4>& b) {
         return {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
             a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3], a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1]};
+    }
+    // SO3::SO3FromVectors (libs/core/src/SO3.cpp:155-167): R = I + v^ + v^ v^ / (1 + c) for the normalised inputs, stored as
+    // a quaternion the way Eigen converts a rotation matrix (SO3.cpp:100).
+    static std::array<double, 4> so3FromVectors(const Vector3d& origin, const Vector3d& dest) {
+        auto unit = [](const Vector3d& a) {
+            const double n = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+            return Vector3d{a[0] / n, a[1] / n, a[2] / n};
+        };
+        const Vector3d o = unit(origin), d = unit(dest);
+        const Vector3d v = {o[1] * d[2] - o[2] * d[1], o[2] * d[0] - o[0] * d[2], o[0] * d[1] - o[1] * d[0]};
+        const double c = o[0] * d[0] + o[1] * d[1] + o[2] * d[2];
+        if (std::fabs(1 + c) <= 1e-8) throw std::domain_error("The vectors cannot be exactly opposing.");
+        const double k = 1 / (1 + c);
+        double m[3][3];
+        const double vx[3][3] = {{0, -v[2], v[1]}, {v[2], 0, -v[0]}, {-v[1], v[0], 0}};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double sq = 0;
+                for (int l = 0; l < 3; ++l) sq += vx[i][l] * vx[l][j];
+                m[i][j] = (i == j ? 1.0 : 0.0) + vx[i][j] + k * sq;
+            }
+        std::array<double, 4> q{};
+        double t = m[0][0] + m[1][1] + m[2][2];
+        if (t > 0) {
+            t = std::sqrt(t + 1.0);
+            q[0] = 0.5 * t;
+            t = 0.5 / t;
+            q[1] = (m[2][1] - m[1][2]) * t;
+            q[2] = (m[0][2] - m[2][0]) * t;
+            q[3] = (m[1][0] - m[0][1]) * t;
+        } else {
+            int i = 0;
+            if (m[1][1] > m[0][0]) i = 1;
+            if (m[2][2] > m[i][i]) i = 2;
+            const int j = (i + 1) % 3, l = (j + 1) % 3;
+            t = std::sqrt(m[i][i] - m[j][j] - m[l][l] + 1.0);
+            q[1 + i] = 0.5 * t;
+            t = 0.5 / t;
+            q[0] = (m[l][j] - m[j][l]) * t;
+            q[1 + j] = (m[j][i] + m[i][j]) * t;
+            q[1 + l] = (m[l][i] + m[i][l]) * t;
+        }
+        return q;
     }
     static Vector3d qrot(const std::array<double, 4>& q, const Vector3d& v) {
         const Vector3d u = {q[1], q[2], q[3]};

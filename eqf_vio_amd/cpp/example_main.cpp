@@ -1,8 +1,11 @@
 // Minimal C++ caller of the facade, shaped like the reference's offline runner (eqf_vio/src/main.cpp:111-170):
 // events are interleaved by "imu.stamp < meas.stamp", the state is read after every vision call.
-// Usage: eqf_example <N landmarks> <frames> [aux]  -- runs a small synthetic sequence and prints the final pose and
-// |Sigma|_F.  With "aux" the filter starts from AuxiliaryFilterData + setInertialPoints (VIOFilter.cpp:51-58, 74-118)
-// instead of the gravity alignment at the first IMU sample.
+// Usage: eqf_example <N landmarks> <frames> [aux | level | init]  -- runs a small synthetic sequence and prints the final
+// pose and |Sigma|_F.  With "aux" the filter starts from AuxiliaryFilterData + setInertialPoints (VIOFilter.cpp:51-58,
+// 74-118) instead of the gravity alignment at the first IMU sample; with "init" from an explicit initialiseFromIMUData
+// call (VIOFilter.cpp:133-144; same result as the lazy one).  With "level" the vehicle rests level: the reference's gravity
+// chart is then singular and its first Riccati step throws std::domain_error (SO3.cpp:160-161) -- here the device raises
+// its sticky flag and the facade throws the same exception; the example reports it and exits with status 3.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +24,8 @@ int main(int argc, char** argv) {
     s.velOmegaVariance = s.velAccelVariance = 1e-4;
     s.outlierThreshold = 1e9;
     const bool aux = argc > 3 && std::string(argv[3]) == "aux";
+    const bool level = argc > 3 && std::string(argv[3]) == "level";
+    const bool init = argc > 3 && std::string(argv[3]) == "init";
     std::vector<Vector3d> lm(N);
     for (int i = 0; i < N; ++i) lm[i] = {2 * std::sin(1.3 * i), 2 * std::cos(0.7 * i), 5 + std::sin(0.37 * i)};
     AuxiliaryFilterData ad;
@@ -49,7 +54,10 @@ int main(int argc, char** argv) {
     // vehicle at rest, tilted so that body x is "up" (a level start makes the reference's gravity chart singular)
     IMUVelocity imu;
     imu.accel = {GRAVITY_CONSTANT, 0, 0};
+    if (level) imu.accel = {0, 0, GRAVITY_CONSTANT};
+    if (init) filter.initialiseFromIMUData(imu);
     int k = 0;
+    try {
     for (int f = 0; f < frames; ++f) {
         VisionMeasurement meas;
         meas.stamp = 0.05 * f + 0.0025;
@@ -74,6 +82,10 @@ int main(int argc, char** argv) {
                 est.bodyLandmarks.size(), est.pose.x[0], est.pose.x[1], est.pose.x[2], est.pose.R.w, est.pose.R.x, est.pose.R.y,
                 est.pose.R.z, std::sqrt(fro));
         }
+    }
+    } catch (const std::domain_error& e) {
+        std::printf("std::domain_error: %s\n", e.what());
+        return 3;
     }
     return 0;
 }

@@ -140,7 +140,7 @@ struct eqf_filter {
     std::vector<hipEvent_t> evPool;
     long long profCount[EQF_PROF_CLASSES] = {};
     double profMs[EQF_PROF_CLASSES] = {};
-    std::vector<float> profSamples[EQF_PROF_CLASSES];  // per-bracket times: outliers (a box hiccup) are clipped in eqf_profile_get
+    std::vector<float> profSamples[EQF_PROF_CLASSES];  // per-bracket times
     double profOverheadMs = 0.0;  // elapsed time of an EMPTY event bracket (calibrated when profiling is switched on)
 };
 
@@ -266,11 +266,12 @@ int resolveGate(eqf_filter* f);
 int flushBurst(eqf_filter* f);
 // Every entry point that looks at (or changes) the filter first settles what the host has deferred: the speculative gate
 // of the last vision frame, then the queued IMU steps (in this order: they come after that frame).
-#define GATE(f)                          \
-    do {                                 \
-        int grc_ = resolveGate(f);       \
-        if (!grc_) grc_ = flushBurst(f); \
-        if (grc_) return grc_;           \
+#define GATE(f)                                                        \
+    do {                                                               \
+        if (hipSetDevice((f)->device) != hipSuccess) return EQF_ERR_HIP; \
+        int grc_ = resolveGate(f);                                     \
+        if (!grc_) grc_ = flushBurst(f);                               \
+        if (grc_) return grc_;                                         \
     } while (0)
 
 int maxN(const eqf_filter* f) {
@@ -618,14 +619,14 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         for (int k = 0; k < steps; ++k) {
             if (!splitChain) {
                 const int dd = (embed && k == nb64S) ? ddTiles : 0;
-                rc = profiled(f, EQF_PROF_CHOL_STEP, [&] {
+                rc = profiled(f, dd ? EQF_PROF_CHOL_DD : EQF_PROF_CHOL_STEP, [&] {
                     hipLaunchKernelGGL((k_chol_step64<T, 0>), dim3(blocks(k, 0) + dd, B), dim3(256), sizeof(Step64Lds), f->stream, cS, cE, a, k,
                         dd ? ddNt : 0, small ? 1 : 0, embed ? 1 : 0, f->errflag);
                 });
             } else {
                 // the S-chain's right-hand sides are complete after panel launch nb64S - 1: the downdate joins that update launch
                 const int dd = (embed && k == nb64S - 1) ? ddTiles : 0;
-                rc = profiled(f, EQF_PROF_CHOL_STEP, [&] {
+                rc = profiled(f, dd ? EQF_PROF_CHOL_DD : EQF_PROF_CHOL_STEP, [&] {
                     hipLaunchKernelGGL((k_chol_step64<T, 1>), dim3(blocks(k, 1), B), dim3(256), sizeof(Step64Lds), f->stream, cS, cE, a, k, 0, 0,
                         embed ? 1 : 0, f->errflag);
                     if (k + 1 < steps)
@@ -862,6 +863,7 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
             if (std::find(f->ids[b].begin(), f->ids[b].end(), measIds[b][k]) == f->ids[b].end()) fresh[b].push_back(k);
         }
         if (!fresh[b].empty()) {
+            // (cannot happen: every entry point checks nb <= capacity and strictly ascending ids before any effect)
             if (f->ids[b].size() + fresh[b].size() > (size_t)cap) return EQF_ERR_CAPACITY;
             if (!f->ids[b].empty()) needDepth = true;
         }
@@ -1227,17 +1229,22 @@ int eqf_process_imu(eqf_filter* f, const double* stamps, const double* omega, co
 int eqf_process_vision(eqf_filter* f, const double* stamps, const int* nb, const int* ids, const double* bearings, int stride,
     int* status) {
     if (!f || !stamps || !nb || (!ids && stride > 0) || (!bearings && stride > 0)) return EQF_ERR_INVALID;
-    {
-        const int grc = burstEligible(f, false) ? resolveGate(f) : (resolveGate(f) || flushBurst(f));
-        if (grc) return grc;
-    }
     HIPC(hipSetDevice(f->device));
     const int B = f->B, cap = f->cap;
+    // Argument errors are reported before ANY effect (nothing enqueued, no time advanced).  After removeOldLandmarks the
+    // state's ids are a subset of the measurement's and addNewLandmarks appends the rest, so nb <= capacity is the whole
+    // capacity condition of the call (the reference grows Sigma on demand instead, VIOFilter.cpp:386).  Ids must be strictly
+    // ascending: the reference asserts is_sorted (VIOFilter.cpp:239-240) and a duplicate id would map two bearings to one
+    // landmark / append one landmark twice.
     for (int b = 0; b < B; ++b) {
         if (nb[b] < 0 || nb[b] > stride) return EQF_ERR_INVALID;
         if (nb[b] > cap) return EQF_ERR_CAPACITY;
         for (int k = 1; k < nb[b]; ++k)
-            if (ids[(size_t)b * stride + k] < ids[(size_t)b * stride + k - 1]) return EQF_ERR_UNSORTED;  // VIOFilter.cpp:239-240
+            if (ids[(size_t)b * stride + k] <= ids[(size_t)b * stride + k - 1]) return EQF_ERR_UNSORTED;
+    }
+    {
+        const int grc = burstEligible(f, false) ? resolveGate(f) : (resolveGate(f) || flushBurst(f));
+        if (grc) return grc;
     }
     // integrateUpToTime(measurement.stamp) (VIOFilter.cpp:234)
     std::vector<ImuRec> recs(B);
@@ -1256,6 +1263,7 @@ int eqf_process_vision(eqf_filter* f, const double* stamps, const int* nb, const
     } else {
         rc = launchPropagate(f, dev, recs[0], stamps, false, true, st.data());
     }
+    if (status) std::copy(st.begin(), st.end(), status);
     if (rc) return rc;
     rc = releaseSlot(f, slot);
     if (rc) return rc;
@@ -1284,7 +1292,7 @@ int eqf_stream_upload(eqf_filter* f, int K, const double* imu, int F, const doub
     HIPC(hipStreamSynchronize(f->stream));
     const int B = f->B;
     for (int k = 1; k < nbear; ++k)
-        if (ids[k] < ids[k - 1]) return EQF_ERR_UNSORTED;
+        if (ids[k] <= ids[k - 1]) return EQF_ERR_UNSORTED;  // strictly ascending, as in eqf_process_vision
     hipFree(f->sImu); hipFree(f->sVis); hipFree(f->sBear);
     f->sImu = nullptr; f->sVis = nullptr; f->sBear = nullptr;
     std::vector<ImuRec> ri((size_t)K * B), rv((size_t)F * B);
@@ -1344,6 +1352,7 @@ int eqf_stream_vision(eqf_filter* f, int fr) {
     const int B = f->B;
     ImuRec dummy{};
     std::vector<int> st(B, EQF_OK);
+    HIPC(hipSetDevice(f->device));
     int rc = resolveGate(f);
     if (rc) return rc;
     if (burstEligible(f, false)) {
@@ -1587,6 +1596,36 @@ int eqf_get_last_update(eqf_filter* f, int b, double* delta, double* gamma, doub
     return EQF_OK;
 }
 
+int eqf_debug_get_blocks(eqf_filter* f, int b, double* common, double* rec, double* c0) {
+    if (!f || b < 0 || b >= f->B) return EQF_ERR_INVALID;
+    if (f->precision != EQF_PRECISION_F64) return EQF_ERR_UNSUPPORTED;
+    GATE(f);
+    HIPC(hipStreamSynchronize(f->stream));
+    const int N = int(f->ids[b].size()), cap = f->cap;
+    if (common) {
+        CommonLds c;
+        HIPC(hipMemcpy(&c, f->dBlkCommon + b, sizeof(CommonLds), hipMemcpyDeviceToHost));
+        common[0] = c.T;
+        std::copy(c.Bg, c.Bg + 6, common + 1);
+        std::copy(c.Bvw, c.Bvw + 9, common + 7);
+        std::copy(c.RA, c.RA + 9, common + 16);
+        std::copy(c.Avg, c.Avg + 6, common + 25);
+    }
+    if (rec && N > 0) {
+        std::vector<double> tmp((size_t)kBlkRec * N);
+        HIPC(hipMemcpy(tmp.data(), static_cast<const double*>(f->dBlk) + (size_t)b * cap * kBlkRec, sizeof(double) * tmp.size(),
+            hipMemcpyDeviceToHost));
+        for (int i = 0; i < N; ++i) std::copy(&tmp[(size_t)i * kBlkRec], &tmp[(size_t)i * kBlkRec] + 27, rec + (size_t)27 * i);
+    }
+    if (c0 && N > 0) {
+        std::vector<double> tmp((size_t)15 * cap);
+        HIPC(hipMemcpy(tmp.data(), f->lmc + (size_t)b * 15 * cap, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < N; ++i)
+            for (int q = 0; q < 6; ++q) c0[(size_t)6 * i + q] = tmp[(size_t)q * cap + i];
+    }
+    return EQF_OK;
+}
+
 int eqf_device_error(eqf_filter* f) {
     if (!f) return EQF_ERR_INVALID;
     if (resolveGate(f) || flushBurst(f)) return EQF_ERR_HIP;
@@ -1663,16 +1702,11 @@ int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_m
     if (rc) return rc;
     if (launches) *launches = f->profCount[cls];
     if (total_ms) {
-        // sum of the brackets, with isolated outliers (> 8x the class median: a page fault, a clock change -- one such
-        // bracket of tens of milliseconds was seen to dominate a class total) replaced by the median
-        std::vector<float> v = f->profSamples[cls];
+        // plain sum of the brackets (no outlier clipping: launches of one class differ legitimately by far more than any
+        // hiccup -- the chain launch that carries the covariance downdate is a class of its own for that reason);
+        // bench.py cross-checks the class totals against the wall time of the profiled pass
         double sum = 0.0;
-        if (!v.empty()) {
-            std::vector<float> sorted = v;
-            std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2, sorted.end());
-            const float med = sorted[sorted.size() / 2];
-            for (float x : v) sum += (x > 8.0f * med) ? med : x;
-        }
+        for (float x : f->profSamples[cls]) sum += x;
         *total_ms = std::max(0.0, sum - f->profOverheadMs * f->profCount[cls]);
     }
     return EQF_OK;
@@ -1680,7 +1714,7 @@ int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_m
 
 const char* eqf_profile_class_name(int cls) {
     static const char* names[EQF_PROF_CLASSES] = {"k_propagate", "k_update_prep", "k_chol_step", "k_update_reduce", "k_update_finish",
-        "k_downdate", "churn", "k_dense_riccati", "k_imu_burst"};
+        "k_downdate", "churn", "k_dense_riccati", "k_imu_burst", "k_chol_step_dd"};
     return (cls >= 0 && cls < EQF_PROF_CLASSES) ? names[cls] : "?";
 }
 

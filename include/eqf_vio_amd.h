@@ -85,7 +85,9 @@ int eqf_reset(eqf_filter* f);
 int eqf_process_imu(eqf_filter* f, const double* stamps, const double* omega, const double* accel, int* status);
 
 /* VIOFilter::processVisionData (VIOFilter.cpp:232-302).  For filter b: nb[b] bearings with ids
- * ids[b*stride + k] (ascending) and unit vectors bearings[(b*stride + k)*3 + c]. */
+ * ids[b*stride + k] (STRICTLY ascending) and unit vectors bearings[(b*stride + k)*3 + c].
+ * EQF_ERR_INVALID / EQF_ERR_CAPACITY (nb[b] > capacity) / EQF_ERR_UNSORTED are returned before any effect: the
+ * filters are exactly as before the call.  status[] is written whenever the call got past those checks. */
 int eqf_process_vision(eqf_filter* f, const double* stamps, const int* nb, const int* ids, const double* bearings,
     int stride, int* status);
 
@@ -138,6 +140,13 @@ int eqf_get_integrator(eqf_filter* f, int b, double* currentVelocity6, double* a
 
 /* Internals of the most recent update of filter b: delta[2N], gamma[11+3N] (K*delta), Gamma[9+3N]. */
 int eqf_get_last_update(eqf_filter* f, int b, double* delta, double* gamma, double* Gamma);
+/* Test hook for block-level parity (A0 / B / C0 blocks): the linearisation blocks of filter b as the most
+ * recent single-step launch of the split propagate path (k_build_blocks: EQF_IMU_BURST=0, EQF_SPLIT_PROPAGATE=1) left
+ * them, and the per-landmark output blocks.  common[31] = T, B[0:2,0:3] (6), B[2:5,0:3] (9), R_A = B[2:5,3:6] (9),
+ * A0[2:5,0:2] (6), row-major (EqFMatrices.cpp:288-289, :364-368).  rec[N][27] per landmark: D = I + T A0[ii] (9),
+ * Lw = -T B[5+3i.., 0:3] (9), Lv = T A0[5+3i.., 2:5] (9) (EqFMatrices.cpp:294-314, :370-380).  c0[N][6] = C0i, the 2 x 3
+ * block of EqFOutputMatrixC (EqFMatrices.cpp:319-344).  Any pointer may be NULL.  fp64 handles only. */
+int eqf_debug_get_blocks(eqf_filter* f, int b, double* common, double* rec, double* c0);
 /* Sticky device-side error flag (NaN / antipodal), 0 if none. */
 int eqf_device_error(eqf_filter* f);
 
@@ -165,7 +174,8 @@ int eqf_set_dense_propagate(eqf_filter* f, int on);
 #define EQF_PROF_CHURN 6
 #define EQF_PROF_DENSE 7 /* k_dense_build + the two k_dense_gemm launches of the dense Riccati backend */
 #define EQF_PROF_BURST 8 /* k_burst_build + k_burst_riccati: one bracket per burst of integrateUpToTime steps */
-#define EQF_PROF_CLASSES 9
+#define EQF_PROF_CHOL_DD 9 /* the one k_chol_step64 launch per update that also carries Sigma - Y^T Y (64-wide path) */
+#define EQF_PROF_CLASSES 10
 int eqf_profile_enable(eqf_filter* f, int on);
 int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_ms);
 const char* eqf_profile_class_name(int cls);

@@ -81,6 +81,7 @@ def lib():
         for f in ("oracle_get_sigma", "oracle_get_bias", "oracle_get_xi0", "oracle_get_estimate", "oracle_get_group"):
             getattr(L, f).argtypes = [C.c_void_p, dp]
         L.oracle_set_sigma.argtypes = [C.c_void_p, dp]
+        L.oracle_set_state.argtypes = [C.c_void_p, C.c_int, ip, dp, dp, dp, dp, C.c_double, dp, dp, C.c_double, C.c_int]
         L.oracle_get_last.argtypes = [C.c_void_p, dp, dp, dp]
         L.oracle_matrices.argtypes = [C.c_int, dp, dp, dp, dp, dp, dp, dp, dp]
         L.oracle_bundle_lift.argtypes = [C.c_int, dp, dp, dp, dp, dp, dp, dp]
@@ -147,6 +148,17 @@ class OracleFilter:
         S = np.ascontiguousarray(S, dtype=np.float64)
         assert S.shape == (11 + 3 * self.N,) * 2
         lib().oracle_set_sigma(self._h, _dp(S))
+
+    def set_state(self, st):
+        """Inject a snapshot in the format of eqf_vio_amd.binding.FilterBatch.dump_state (kernel-level parity tests)."""
+        ids = np.ascontiguousarray(st["ids"], dtype=np.int32)
+        o, g = st["origin"], st["group"]
+        state = np.ascontiguousarray(pack_state(o["q"], o["x"], o["v"], o["p"]))
+        group = np.ascontiguousarray(pack_group(g["Aq"], g["Ax"], g["w"], g["Qq"], g["Qa"]))
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (st["bias"], st["sigma"], st["currentVelocity"], st["accumulatedVelocity"])]
+        lib().oracle_set_state(self._h, len(ids), ids.ctypes.data_as(C.POINTER(C.c_int)), _dp(state), _dp(group), _dp(arrs[0]),
+                               _dp(arrs[1]), float(st["time"]), _dp(arrs[2]), _dp(arrs[3]), float(st["accumulatedTime"]),
+                               int(st["initialised"]))
 
     def bias(self):
         out = np.zeros(6)

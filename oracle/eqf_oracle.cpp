@@ -1382,6 +1382,26 @@ void oracle_set_sigma(void* h, const double* in) {
     auto* f = static_cast<Filter*>(h);
     std::copy(in, in + f->Sigma.d.size(), f->Sigma.d.begin());
 }
+// State injection for single-step (kernel-level) parity tests: overwrites the whole filter with N landmarks `ids`, origin
+// state / group element packed as packState / packGroup, bias, Sigma ((11+3N)^2 row-major) and the integrator scalars.
+void oracle_set_state(void* h, int N, const int* ids, const double* state, const double* group, const double* bias6,
+    const double* sigma, double currentTime, const double* curVel6, const double* accVel6, double accumulatedTime, int initialised) {
+    auto* f = static_cast<Filter*>(h);
+    const SE3 cam = f->xi0.cameraOffset;
+    const double camq[4] = {cam.q.w, cam.q.x, cam.q.y, cam.q.z}, camx[3] = {cam.x.x, cam.x.y, cam.x.z};
+    f->xi0 = unpackState(state, N, camq, camx);
+    f->X = unpackGroup(group, N);
+    for (int i = 0; i < N; ++i) f->xi0.id[i] = f->X.id[i] = ids[i];
+    std::memcpy(f->inputBias, bias6, 6 * sizeof(double));
+    const int n = SIGMA_BASE_SIZE + 3 * N;
+    f->Sigma = Mat(n, n);
+    std::copy(sigma, sigma + size_t(n) * n, f->Sigma.d.begin());
+    f->currentTime = currentTime;
+    f->currentVelocity = IMU{0, {curVel6[0], curVel6[1], curVel6[2]}, {curVel6[3], curVel6[4], curVel6[5]}};
+    f->accumulatedVelocity = IMU{0, {accVel6[0], accVel6[1], accVel6[2]}, {accVel6[3], accVel6[4], accVel6[5]}};
+    f->accumulatedTime = accumulatedTime;
+    f->initialised = initialised != 0;
+}
 void oracle_get_bias(void* h, double* out) { std::memcpy(out, static_cast<Filter*>(h)->inputBias, 6 * sizeof(double)); }
 void oracle_get_xi0(void* h, double* out) { packState(static_cast<Filter*>(h)->xi0, out); }
 void oracle_get_estimate(void* h, double* out) { packState(static_cast<Filter*>(h)->stateEstimate(), out); }

@@ -1,0 +1,325 @@
+"""BASELINE.json's configurations AT SIZE on the MI355X, through the C ABI, against the CPU oracle -- plus the kernel-level
+gates of SURVEY.md 8(d) (linearisation blocks, one propagate, one update) and the device-raised error path.
+
+The checker at these sizes is the STRUCTURED fp64 oracle (oracle/eqf_oracle.cpp, structured=True): the dense restatement
+of the reference's operation sequence needs ~10 s per call at N = 1000.  tests/test_oracle_structured.py pins the
+structured form against the dense one (<= 2e-9 on Sigma); here the dense oracle is run beside it wherever it is affordable
+(filter 0 of the 64-filter batch, the first second of the N = 200 run).
+Default launch-shape selection everywhere (no EQF_* forcing) except where a test says otherwise.
+"""
+import os
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from helpers import rel_fro
+
+pytestmark = pytest.mark.gpu
+
+SIGMA_TOL = 1e-7
+POSE_TOL = 1e-8
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from eqf_vio_amd import binding
+
+    return binding
+
+
+def _oracle_frames(ob, settings, st, structured=True, keep_sigma=True, frames=None):
+    """Run one oracle over a stream; per vision frame: (Sigma or its norm, estimate, bias)."""
+    fo = ob.OracleFilter(settings, structured=structured)
+    out = []
+    for kind, k in st.events():
+        if kind == "imu":
+            r = st.imu[k]
+            fo.processIMUData(r[0], r[1:4], r[4:7])
+        else:
+            fo.processVisionData(st.vision_stamps[k], st.ids, st.bearings[k])
+            S = fo.stateCovariance()
+            out.append(dict(S=S if keep_sigma else None, fro=np.linalg.norm(S), est=fo.stateEstimate(), bias=fo.bias()))
+            if frames is not None and len(out) >= frames:
+                break
+    return out
+
+
+def _check_frame(fg, b, ref, what):
+    eg = fg.state_estimate(b)
+    assert np.abs(eg["x"] - ref["est"]["x"]).max() < POSE_TOL and np.abs(eg["q"] - ref["est"]["q"]).max() < POSE_TOL, what
+    assert np.abs(eg["v"] - ref["est"]["v"]).max() < POSE_TOL and np.abs(fg.bias(b) - ref["bias"]).max() < POSE_TOL, what
+    assert np.abs(eg["p"] - ref["est"]["p"]).max() < 1e-6, what
+    S = fg.sigma(b)
+    if ref["S"] is not None:
+        rel = rel_fro(S, ref["S"])
+        assert rel < SIGMA_TOL, (what, rel)
+        return rel
+    assert abs(np.linalg.norm(S) / ref["fro"] - 1) < SIGMA_TOL, what
+    return None
+
+
+def test_cfg3_N1000_structured_and_dense_mfma_riccati(oracle_lib, hip):
+    """BASELINE configs[2]: N = 1000 (Sigma 3011 x 3011), three vision updates, (a) the block-structured product path (split
+    chain, 16-landmark burst builder, multi-row block kernel -- whatever the defaults select at this size) and (b) the dense
+    MFMA Riccati backend (F Sigma F^T as two GEMMs on v_mfma_f64_16x16x4_f64), each against the structured oracle after every
+    vision frame."""
+    from eqf_vio_amd import synth
+
+    N = 1000
+    st = synth.make_stream(N, duration=0.16)
+    d = synth.template_settings_dict()
+    ref = _oracle_frames(oracle_lib, d, st)
+    assert len(ref) == 3
+    worst = {}
+    for backend in ("structured", "dense"):
+        fg = hip.FilterBatch(d, capacity=N, batch=1)
+        if backend == "dense":
+            fg.set_dense_propagate(True)
+        fg.stream_upload(st.imu, st.vision_stamps, st.ids, st.bearings)
+        fr = 0
+        rels = []
+        for kind, k in st.events():
+            if kind == "imu":
+                fg.stream_imu(k)
+            else:
+                fg.stream_vision(k)
+                assert fg.num_landmarks() == N
+                rels.append(_check_frame(fg, 0, ref[fr], (backend, fr)))
+                fr += 1
+        assert fr == 3 and fg.device_error() == 0
+        worst[backend] = max(rels)
+        fg.close()
+    print("cfg3 N=1000 worst relS:", worst)
+
+
+def test_cfg4_batch_of_64_filters_N200(oracle_lib, hip):
+    """BASELINE configs[3] on one GPU: 64 independent filters of N = 200 in one handle, each on its own stream (seed 1234 + b),
+    three vision updates.  Every filter's pose / velocity / bias / landmarks and |Sigma|_F against its own structured oracle;
+    the full Sigma of filters 0, 21, 42, 63 after every frame; filter 0 also against the DENSE oracle."""
+    from eqf_vio_amd import synth
+
+    N, B = 200, 64
+    sts = [synth.make_stream(N, seed=1234 + b, duration=0.16) for b in range(B)]
+    d = synth.template_settings_dict()
+    full = (0, 21, 42, 63)
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:  # ctypes calls release the GIL
+        refs = list(ex.map(lambda b: _oracle_frames(oracle_lib, d, sts[b], keep_sigma=b in full), range(B)))
+        dense0 = ex.submit(_oracle_frames, oracle_lib, d, sts[0], False).result()
+    fg = hip.FilterBatch(d, capacity=N, batch=B)
+    fg.stream_upload(np.stack([s.imu for s in sts], axis=1), np.stack([s.vision_stamps for s in sts], axis=1), sts[0].ids,
+                     np.stack([s.bearings for s in sts], axis=1))
+    fr = 0
+    for kind, k in sts[0].events():
+        if kind == "imu":
+            fg.stream_imu(k)
+        else:
+            fg.stream_vision(k)
+            for b in range(B):
+                _check_frame(fg, b, refs[b][fr], (b, fr))
+            assert rel_fro(fg.sigma(0), dense0[fr]["S"]) < SIGMA_TOL
+            fr += 1
+    assert fr == 3 and fg.device_error() == 0
+    assert rel_fro(fg.sigma(0), fg.sigma(1)) > 1e-3  # the filters really are different
+
+
+def test_cfg2_N200_two_seconds_worst_frame(oracle_lib, hip):
+    """BASELINE configs[1] over 2 s (400 IMU + 40 vision calls, per-call API, IMU bursts): Sigma and pose after EVERY vision
+    update against the structured oracle, worst frame reported; the first second also against the dense oracle."""
+    from eqf_vio_amd import synth
+
+    N = 200
+    st = synth.make_stream(N, duration=2.01)
+    d = synth.template_settings_dict()
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        fs = ex.submit(_oracle_frames, oracle_lib, d, st)
+        fd = ex.submit(_oracle_frames, oracle_lib, d, st, False, True, 20)
+        ref, refd = fs.result(), fd.result()
+    assert len(ref) == 40
+    fg = hip.FilterBatch(d, capacity=N, batch=1)
+    fr, worst, at = 0, 0.0, -1
+    for kind, k in st.events():
+        if kind == "imu":
+            r = st.imu[k]
+            fg.process_imu([r[0]], r[1:4], r[4:7])
+        else:
+            fg.process_vision([st.vision_stamps[k]], st.ids, st.bearings[k])
+            rel = _check_frame(fg, 0, ref[fr], fr)
+            if rel > worst:
+                worst, at = rel, fr
+            if fr < len(refd):
+                assert rel_fro(fg.sigma(), refd[fr]["S"]) < SIGMA_TOL, fr
+            fr += 1
+    assert fr == 40 and fg.device_error() == 0
+    assert worst < SIGMA_TOL
+    print(f"cfg2 N=200, 2 s: worst relS {worst:.3e} at vision frame {at}")
+
+
+def test_level_start_raises_the_device_flag_and_the_facade_throws(hip):
+    """A perfectly level first accelerometer sample makes the reference's gravity chart singular: SO3FromVectors(-e3, e3)
+    throws std::domain_error (libs/core/src/SO3.cpp:160-161) at the first Riccati step.  On the device the same condition
+    raises the sticky error flag (EQF_ERR_NUMERIC at the boundary); the C++ facade turns it back into std::domain_error."""
+    fg = hip.FilterBatch({}, capacity=4, batch=1)
+    assert fg.device_error() == 0
+    fg.process_imu([0.0], [0, 0, 0], [0, 0, 9.81])
+    fg.process_imu([0.005], [0, 0, 0], [0, 0, 9.81])
+    assert fg.device_error() != 0
+    fg.process_imu([0.010], [0, 0, 0], [9.81, 0, 0])
+    assert fg.device_error() != 0  # sticky
+    fg.reset()
+    assert fg.device_error() == 0  # a reset handle starts clean
+    # a tilted start on the same handle is fine
+    fg.process_imu([0.0], [0, 0, 0], [9.81, 0, 0])
+    fg.process_imu([0.005], [0, 0, 0], [9.81, 0, 0])
+    assert fg.device_error() == 0
+    exe = os.path.join(ROOT, "eqf_vio_amd", "cpp", "eqf_example")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    r = subprocess.run([exe, "6", "2", "level"], capture_output=True, text=True)
+    assert r.returncode == 3 and "std::domain_error" in r.stdout and "opposing" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    ok = subprocess.run([exe, "6", "2"], capture_output=True, text=True)
+    assert ok.returncode == 0 and "domain_error" not in ok.stdout
+
+
+def test_explicit_initialiseFromIMUData_equals_the_lazy_one():
+    """VIOFilter::initialiseFromIMUData (VIOFilter.cpp:133-144) called explicitly through the C++ facade gives the run the
+    lazy initialisation at the first IMU sample gives (zero initial bias: the two see the same sample)."""
+    exe = os.path.join(ROOT, "eqf_vio_amd", "cpp", "eqf_example")
+    a = subprocess.run([exe, "12", "4"], capture_output=True, text=True, check=True).stdout
+    b = subprocess.run([exe, "12", "4", "init"], capture_output=True, text=True, check=True).stdout
+    assert a == b and "pos=" in a
+
+
+def test_argument_errors_leave_the_filter_untouched(oracle_lib, hip):
+    """EQF_ERR_CAPACITY / EQF_ERR_UNSORTED (incl. a DUPLICATE id) are reported before any effect: time, landmarks and Sigma
+    are as before the call, and the stream continues in step with the oracle."""
+    from eqf_vio_amd import synth
+
+    N = 8
+    st = synth.make_stream(N, duration=0.3)
+    big = synth.make_stream(N + 3, duration=0.2)
+    d = synth.template_settings_dict()
+    fo = oracle_lib.OracleFilter(d)
+    fg = hip.FilterBatch(d, capacity=N, batch=1)
+    ev = list(st.events())
+    for kind, k in ev:
+        if kind == "imu":
+            r = st.imu[k]
+            fo.processIMUData(r[0], r[1:4], r[4:7])
+            fg.process_imu([r[0]], r[1:4], r[4:7])
+        else:
+            if k == 2:
+                t0, n0, S0 = fg.get_time()[0], fg.num_landmarks(), fg.sigma()
+                with pytest.raises(hip.EqfError) as ei:
+                    fg.process_vision([st.vision_stamps[k]], big.ids, big.bearings[0])
+                assert ei.value.code == hip.ERR_CAPACITY
+                dup = st.ids.copy()
+                dup[3] = dup[2]
+                with pytest.raises(hip.EqfError) as ei:
+                    fg.process_vision([st.vision_stamps[k]], dup, st.bearings[k])
+                assert ei.value.code == hip.ERR_UNSORTED
+                assert fg.get_time()[0] == t0 and fg.num_landmarks() == n0 and np.array_equal(fg.sigma(), S0)
+            fo.processVisionData(st.vision_stamps[k], st.ids, st.bearings[k])
+            fg.process_vision([st.vision_stamps[k]], st.ids, st.bearings[k])
+            assert rel_fro(fg.sigma(), fo.stateCovariance()) < SIGMA_TOL
+    assert fg.get_time()[0] == fo.getTime() and fg.device_error() == 0
+
+
+def test_linearisation_blocks_against_the_oracle_matrices(oracle_lib, hip, monkeypatch):
+    """Kernel-level gate of SURVEY.md 8(d): the per-landmark blocks of A0 (EqFStateMatrixA), B (EqFInputMatrixB) and C0
+    (EqFOutputMatrixC) as the device builds them (one wavefront lane per landmark, k_build_blocks / k_append) against the
+    oracle's dense matrices at the same state.  Gate 1e-6 relative; held to 1e-9."""
+    from eqf_vio_amd import synth
+
+    monkeypatch.setenv("EQF_IMU_BURST", "0")        # one launch per call ...
+    monkeypatch.setenv("EQF_SPLIT_PROPAGATE", "1")  # ... through the builder kernel that leaves its blocks in HBM
+    N = 24
+    st = synth.make_stream(N, duration=0.3)
+    d = synth.template_settings_dict()
+    fg = hip.FilterBatch(d, capacity=N, batch=1)
+    ev = list(st.events())
+    stop = [i for i, (kind, k) in enumerate(ev) if kind == "vision"][3] + 3  # a few IMU steps after the 4th vision frame
+    for kind, k in ev[:stop]:
+        if kind == "imu":
+            r = st.imu[k]
+            fg.process_imu([r[0]], r[1:4], r[4:7])
+        else:
+            fg.process_vision([st.vision_stamps[k]], st.ids, st.bearings[k])
+    snap = fg.dump_state()
+    kind, k = ev[stop]
+    assert kind == "imu"
+    r = st.imu[k]
+    fg.process_imu([r[0]], r[1:4], r[4:7])
+    blk = fg.debug_blocks()
+    o, g = snap["origin"], snap["group"]
+    A0, Bm, C0 = oracle_lib.matrices(oracle_lib.pack_group(g["Aq"], g["Ax"], g["w"], g["Qq"], g["Qa"]),
+                                     oracle_lib.pack_state(o["q"], o["x"], o["v"], o["p"]), d["cameraOffset_q"], d["cameraOffset_x"],
+                                     snap["currentVelocity"][:3])
+    T = r[0] - snap["time"]
+    assert abs(blk["T"] - T) < 1e-15 and T > 0
+
+    def close(a, b, what):
+        assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max()), (what, np.abs(a - b).max())
+
+    close(blk["Bg"], Bm[0:2, 0:3], "B gravity rows")
+    close(blk["Bvw"], Bm[2:5, 0:3], "B velocity rows (omega)")
+    close(blk["RA"], Bm[2:5, 3:6], "B velocity rows (accel) = R_A")
+    close(blk["Avg"], A0[2:5, 0:2], "A0 gravity -> velocity")
+    for i in range(N):
+        rows = slice(5 + 3 * i, 8 + 3 * i)
+        close((blk["D"][i] - np.eye(3)) / T, A0[rows, rows], ("A0 landmark block", i))
+        close(blk["Lv"][i] / T, A0[rows, 2:5], ("A0 velocity -> landmark", i))
+        close(-blk["Lw"][i] / T, Bm[rows, 0:3], ("B landmark block", i))
+        close(blk["C0"][i], C0[2 * i:2 * i + 2, rows], ("C0 block", i))
+
+
+def test_single_propagate_and_single_update_from_an_injected_state(oracle_lib, hip):
+    """Kernel-level gates of SURVEY.md 8(d) (one propagate <= 1e-6, one update <= 1e-5): the state of a running device filter
+    is injected into a fresh DENSE oracle, then ONE processIMUData and, ten IMU calls later, ONE processVisionData are compared
+    -- no accumulated history between the two implementations."""
+    from eqf_vio_amd import synth
+
+    N = 40
+    st = synth.make_stream(N, duration=0.5)
+    d = synth.template_settings_dict()
+    fg = hip.FilterBatch(d, capacity=N, batch=1)
+    ev = list(st.events())
+    stop = [i for i, (kind, k) in enumerate(ev) if kind == "vision"][5] + 1
+    for kind, k in ev[:stop]:
+        if kind == "imu":
+            r = st.imu[k]
+            fg.process_imu([r[0]], r[1:4], r[4:7])
+        else:
+            fg.process_vision([st.vision_stamps[k]], st.ids, st.bearings[k])
+    snap = fg.dump_state()
+    fo = oracle_lib.OracleFilter(d)
+    fo.set_state(snap)
+    assert np.array_equal(fo.stateCovariance(), snap["sigma"]) and np.array_equal(fo.ids(), snap["ids"])
+    kind, k = ev[stop]
+    assert kind == "imu"
+    r = st.imu[k]
+    fo.processIMUData(r[0], r[1:4], r[4:7])
+    fg.process_imu([r[0]], r[1:4], r[4:7])
+    one_prop = rel_fro(fg.sigma(), fo.stateCovariance())
+    eo, eg = fo.stateEstimate(), fg.state_estimate()
+    assert one_prop < 1e-12, one_prop
+    assert np.abs(eo["x"] - eg["x"]).max() < 1e-13 and np.abs(eo["q"] - eg["q"]).max() < 1e-13 and np.abs(eo["p"] - eg["p"]).max() < 1e-12
+    i = stop + 1
+    while ev[i][0] == "imu":
+        r = st.imu[ev[i][1]]
+        fo.processIMUData(r[0], r[1:4], r[4:7])
+        fg.process_imu([r[0]], r[1:4], r[4:7])
+        i += 1
+    before = rel_fro(fg.sigma(), fo.stateCovariance())
+    k = ev[i][1]
+    fo.processVisionData(st.vision_stamps[k], st.ids, st.bearings[k])
+    fg.process_vision([st.vision_stamps[k]], st.ids, st.bearings[k])
+    one_upd = rel_fro(fg.sigma(), fo.stateCovariance())
+    lo, lg = fo.last_update(), fg.last_update()
+    assert np.abs(lo["delta"] - lg["delta"]).max() < 1e-12
+    assert np.abs(lo["gamma"] - lg["gamma"]).max() < 1e-9 * max(1.0, np.abs(lo["gamma"]).max())
+    assert np.abs(lo["Gamma"] - lg["Gamma"]).max() < 1e-9 * max(1.0, np.abs(lo["Gamma"]).max())
+    assert before < 1e-11 and one_upd < 2e-9, (before, one_upd)
+    assert fg.device_error() == 0
+    print(f"one propagate {one_prop:.2e}, eleven propagates {before:.2e}, one update {one_upd:.2e}")
