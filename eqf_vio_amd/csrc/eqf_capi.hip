@@ -35,8 +35,12 @@ namespace {
 constexpr int kRing = 64;
 
 struct ProfPair {
-    int cls;
+    int cls, key;
     hipEvent_t a, b;
+};
+struct ProfSample {
+    int key;  // launch shape within the class (chain step index, burst length, ...): launches of one key do identical work
+    float ms;
 };
 }  // namespace
 
@@ -140,14 +144,14 @@ struct eqf_filter {
     std::vector<hipEvent_t> evPool;
     long long profCount[EQF_PROF_CLASSES] = {};
     double profMs[EQF_PROF_CLASSES] = {};
-    std::vector<float> profSamples[EQF_PROF_CLASSES];  // per-bracket times
+    std::vector<ProfSample> profSamples[EQF_PROF_CLASSES];  // per-bracket times with their launch shape
     double profOverheadMs = 0.0;  // elapsed time of an EMPTY event bracket (calibrated when profiling is switched on)
 };
 
 namespace {
 
 template <typename F>
-int profiled(eqf_filter* f, int cls, F&& launch) {
+int profiled(eqf_filter* f, int cls, F&& launch, int key = 0) {
     if (!f->prof) {
         launch();
         return EQF_OK;
@@ -164,7 +168,7 @@ int profiled(eqf_filter* f, int cls, F&& launch) {
     HIPC(hipEventRecord(a, f->stream));
     launch();
     HIPC(hipEventRecord(b, f->stream));
-    f->profPairs.push_back({cls, a, b});
+    f->profPairs.push_back({cls, key, a, b});
     return EQF_OK;
 }
 
@@ -175,7 +179,7 @@ int profDrain(eqf_filter* f) {
         HIPC(hipEventElapsedTime(&ms, p.a, p.b));
         f->profCount[p.cls]++;
         f->profMs[p.cls] += ms;
-        f->profSamples[p.cls].push_back(ms);
+        f->profSamples[p.cls].push_back({p.key, ms});
         f->evPool.push_back(p.a);
         f->evPool.push_back(p.b);
     }
@@ -461,7 +465,7 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
         };
         if (f->precision == EQF_PRECISION_F32) go(0.0f);
         else go(0.0);
-    });
+    }, K);
     if (rc) return rc;
     HIPC(hipGetLastError());
     f->pG ^= 1;
@@ -622,7 +626,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
                 rc = profiled(f, dd ? EQF_PROF_CHOL_DD : EQF_PROF_CHOL_STEP, [&] {
                     hipLaunchKernelGGL((k_chol_step64<T, 0>), dim3(blocks(k, 0) + dd, B), dim3(256), sizeof(Step64Lds), f->stream, cS, cE, a, k,
                         dd ? ddNt : 0, small ? 1 : 0, embed ? 1 : 0, f->errflag);
-                });
+                }, k);
             } else {
                 // the S-chain's right-hand sides are complete after panel launch nb64S - 1: the downdate joins that update launch
                 const int dd = (embed && k == nb64S - 1) ? ddTiles : 0;
@@ -632,7 +636,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
                     if (k + 1 < steps)
                         hipLaunchKernelGGL((k_chol_step64<T, 2>), dim3(blocks(k, 2) + dd, B), dim3(256), kLdsUpdateBytes, f->stream, cS, cE, a, k,
                             dd ? ddNt : 0, small ? 1 : 0, embed ? 1 : 0, f->errflag);
-                });
+                }, k);
             }
             if (rc) return rc;
         }
@@ -649,7 +653,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             rc = profiled(f, EQF_PROF_CHOL_STEP, [&] {
                 if (inverse) hipLaunchKernelGGL(k_chol_step<true>, dim3(nblk, B), dim3(256), 0, f->stream, cS, cE, k, f->errflag);
                 else hipLaunchKernelGGL(k_chol_step<false>, dim3(nblk, B), dim3(256), 0, f->stream, cS, cE, k, f->errflag);
-            });
+            }, k);
             if (rc) return rc;
         }
     }
@@ -1702,11 +1706,20 @@ int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_m
     if (rc) return rc;
     if (launches) *launches = f->profCount[cls];
     if (total_ms) {
-        // plain sum of the brackets (no outlier clipping: launches of one class differ legitimately by far more than any
-        // hiccup -- the chain launch that carries the covariance downdate is a class of its own for that reason);
-        // bench.py cross-checks the class totals against the wall time of the profiled pass
+        // An event bracket measures kernel time PLUS whatever the stream waited for the host between the two records (the
+        // profiled pass triples the API calls per launch, so a small problem is host-bound in it: brackets of one and the
+        // same launch then read 13 us or 40 us by chance).  Launches of one class and one shape key do identical work, so
+        // each shape is charged its MEDIAN bracket times its launch count; different shapes (chain step 0 vs step 9, the
+        // launch that carries the downdate) are never compared with each other.
+        std::vector<ProfSample> v = f->profSamples[cls];
+        std::sort(v.begin(), v.end(), [](const ProfSample& x, const ProfSample& y) { return x.key != y.key ? x.key < y.key : x.ms < y.ms; });
         double sum = 0.0;
-        for (float x : f->profSamples[cls]) sum += x;
+        for (size_t i = 0; i < v.size();) {
+            size_t j = i;
+            while (j < v.size() && v[j].key == v[i].key) ++j;
+            sum += double(v[i + (j - i) / 2].ms) * double(j - i);
+            i = j;
+        }
         *total_ms = std::max(0.0, sum - f->profOverheadMs * f->profCount[cls]);
     }
     return EQF_OK;

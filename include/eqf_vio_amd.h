@@ -164,7 +164,9 @@ int eqf_set_imu_burst(eqf_filter* f, int max_steps);
 int eqf_set_dense_propagate(eqf_filter* f, int on);
 
 /* Per-kernel-class timing with HIP events on the handle's stream (bench.py roofline leg).
- * eqf_profile_get: for class c in [0, EQF_PROF_CLASSES) -> launches and total milliseconds. */
+ * eqf_profile_get: for class c in [0, EQF_PROF_CLASSES) -> launches and total milliseconds.  The total is, per launch shape
+ * within the class (chain step index, burst length), the median bracket times the number of launches of that shape, minus
+ * the calibrated cost of an empty bracket: an event bracket also contains the time the stream waited for the host. */
 #define EQF_PROF_PROPAGATE 0
 #define EQF_PROF_UPDATE_PREP 1
 #define EQF_PROF_CHOL_STEP 2
