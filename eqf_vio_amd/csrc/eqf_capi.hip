@@ -138,6 +138,10 @@ struct eqf_filter {
     void *dColRec = nullptr, *dRowRec = nullptr;  // per step and landmark records of k_burst_build
     BurstStep* dSteps = nullptr;
     int cholSplit = -1;            // -1 heuristic, 0 fused chain launches, 1 panel + update launches (EQF_CHOL_SPLIT)
+    int cholTail = 1;              // split chain: update launches also solve the next block column (EQF_CHOL_TAIL = 0: panel + update launches)
+    int* dFlags = nullptr;         // [B][2][flagStride]: epoch flags of the in-launch hand-off of the diagonal-factor records
+    int flagStride = 0;
+    int updateEpoch = 0;           // one per launchUpdate
     // profiling
     bool prof = false;
     std::vector<ProfPair> profPairs;
@@ -569,6 +573,8 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<float, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsUpdateBytes));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsUpdateBytes));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<float, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTailBytes));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTailBytes));
         attrSet = true;
     }
     // chains
@@ -579,6 +585,9 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     cE.g = a.g; cE.A = f->EA; cE.D = f->EL; cE.W = f->ZW; cE.WO = f->ZO;
     cE.ldA = f->ldE; cE.ldW = f->ldZ; cE.strideA = f->strideE; cE.strideD = f->strideDE; cE.strideW = f->strideZ;
     cE.kind = 1;
+    f->updateEpoch = f->updateEpoch == 0x7fffffff ? 1 : f->updateEpoch + 1;
+    cS.flags = f->dFlags; cS.strideF = 2 * f->flagStride; cS.epoch = f->updateEpoch;
+    cE.flags = f->dFlags + f->flagStride; cE.strideF = 2 * f->flagStride; cE.epoch = f->updateEpoch;
     if (!attrSet64) {
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -620,6 +629,27 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         auto blocks = [&](int k, int phase) {
             return chainBlocks64(cS.nbMax, cS.wtMax, k, phase) + chainBlocks64(cE.nbMax, cE.wtMax, k, phase);
         };
+        if (splitChain && f->cholTail) {
+            // one launch per block column: the panel launch of column 0, then update launches that also solve column k+1
+            // (k_chol_step64<T, 3>); the S-chain's right-hand sides are complete after launch nb64S - 2, the downdate joins
+            // launch nb64S - 1 (or runs on its own below when there is none)
+            rc = profiled(f, EQF_PROF_CHOL_STEP, [&] {
+                hipLaunchKernelGGL((k_chol_step64<T, 1>), dim3(blocks(0, 1), B), dim3(256), sizeof(Step64Lds), f->stream, cS, cE, a, 0, 0, 0,
+                    embed ? 1 : 0, f->errflag);
+            }, 1000);
+            if (rc) return rc;
+            bool ddDone = false;
+            for (int k = 0; k + 1 < steps; ++k) {
+                const int dd = (embed && k == nb64S - 1) ? ddTiles : 0;
+                if (dd) ddDone = true;
+                rc = profiled(f, dd ? EQF_PROF_CHOL_DD : EQF_PROF_CHOL_STEP, [&] {
+                    hipLaunchKernelGGL((k_chol_step64<T, 3>), dim3(blocks(k, 3) + dd, B), dim3(256), kLdsTailBytes, f->stream, cS, cE, a, k,
+                        dd ? ddNt : 0, small ? 1 : 0, embed ? 1 : 0, f->errflag);
+                }, k);
+                if (rc) return rc;
+            }
+            if (embed && !ddDone) embed = false;  // (cannot happen while nb64S < nb64E: kept for safety -> tail launch below)
+        } else
         for (int k = 0; k < steps; ++k) {
             if (!splitChain) {
                 const int dd = (embed && k == nb64S) ? ddTiles : 0;
@@ -972,7 +1002,7 @@ void freeAll(eqf_filter* f) {
     for (void* p : {(void*)f->p0, (void*)f->lmc, (void*)f->SA, (void*)f->SL, (void*)f->YW, (void*)f->YO, (void*)f->EA, (void*)f->EL, (void*)f->ZW,
              (void*)f->ZO, (void*)f->dbgDelta, (void*)f->dbgGamma, (void*)f->dbgGammaTot, (void*)f->red, (void*)f->errflag, (void*)f->dMap,
              (void*)f->dNewN, (void*)f->dPerm, (void*)f->dSrc, (void*)f->dChord, (void*)f->dDepth2, (void*)f->dDepthSel, (void*)f->dScratch, (void*)f->dMeas,
-             (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn, f->dBlk, (void*)f->dBlkCommon, f->dColRec, f->dRowRec, (void*)f->dSteps})
+             (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn, f->dBlk, (void*)f->dBlkCommon, f->dColRec, f->dRowRec, (void*)f->dSteps, (void*)f->dFlags})
         hipFree(p);
     if (f->hGate) hipHostFree(f->hGate);
     if (f->dMask) hipFree(f->dMask);
@@ -1146,6 +1176,10 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (const char* e = std::getenv("EQF_CHOL_MODE")) f->cholMode = std::strcmp(e, "32inv") == 0 ? 33 : (std::strcmp(e, "32") == 0 ? 32 : 64);
     if (const char* e = std::getenv("EQF_CHOL_EMBED")) f->cholEmbed = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_SPLIT")) f->cholSplit = std::atoi(e);
+    if (const char* e = std::getenv("EQF_CHOL_TAIL")) f->cholTail = std::atoi(e);
+    f->flagStride = std::max(mpC, nepC) / kSB + 1;
+    chk(dmalloc(&f->dFlags, (size_t)2 * f->flagStride * B));
+    if (!rc && hipMemset(f->dFlags, 0, sizeof(int) * 2 * f->flagStride * B) != hipSuccess) rc = EQF_ERR_HIP;
     if (const char* e = std::getenv("EQF_GATE_SPECULATIVE")) f->gateSpeculative = std::atoi(e);
     chk(stageInit(f->stMap, (size_t)cap * B + B)); chk(stageInit(f->stPerm, (size_t)cap * B)); chk(stageInit(f->stSrc, cap));
     chk(hmalloc(&f->hChord, (size_t)cap * B)); chk(dmalloc(&f->dDepthSel, B));

@@ -25,6 +25,7 @@
 // [Zt | Et] = Le^-1 [Z_P | E_top], replacing S.inverse() / Sigma_e.inverse() of VIOFilter.cpp:276-277 and
 // EqFMatrices.cpp:239); chain dimensions are padded to multiples of 64 with identity (UpdArgs::pad = 64).
 #pragma once
+#include "eqf_handoff.hpp"
 #include "eqf_update.hpp"
 
 namespace eqf {
@@ -58,11 +59,12 @@ struct Lds64 {
     double (*D0)[kWP];
     double (*Zs)[kWP];
     double* redL;
+    double* zv;  // tail layout only: [0, 64) the innovation column of this block row, [64, 128) z of the previous block row
 };
 constexpr int kLdsUpdateBytes = int(sizeof(double)) * (2 * kSB * kSP + 4 * kQB * kWP + kQB * kWP);
 EQF_DI Lds64 ldsFull(unsigned char* smem) {
     Step64Lds* f = reinterpret_cast<Step64Lds*>(smem);
-    return Lds64{f->P, f->Q, f->L, f->Wd, f->D0, f->Zs, f->redL};
+    return Lds64{f->P, f->Q, f->L, f->Wd, f->D0, f->Zs, f->redL, nullptr};
 }
 EQF_DI Lds64 ldsUpdate(unsigned char* smem) {
     double* d = reinterpret_cast<double*>(smem);
@@ -70,7 +72,16 @@ EQF_DI Lds64 ldsUpdate(unsigned char* smem) {
     double (*P)[kSP] = reinterpret_cast<double (*)[kSP]>(d + kSB * kSP);
     double (*Wd)[kQB][kWP] = reinterpret_cast<double (*)[kQB][kWP]>(d + 2 * kSB * kSP);
     double (*D0)[kWP] = reinterpret_cast<double (*)[kWP]>(d + 2 * kSB * kSP + 4 * kQB * kWP);
-    return Lds64{P, Q, P, Wd, D0, nullptr, nullptr};
+    return Lds64{P, Q, P, Wd, D0, nullptr, nullptr, nullptr};
+}
+// tail (update launches that also solve the next block column, PHASE 3): the update layout + zv + redL  (80.5 KB, 2 / CU)
+constexpr int kLdsTailBytes = kLdsUpdateBytes + int(sizeof(double)) * (128 + 256);
+EQF_DI Lds64 ldsTail(unsigned char* smem) {
+    Lds64 s = ldsUpdate(smem);
+    double* d = reinterpret_cast<double*>(smem) + kLdsUpdateBytes / int(sizeof(double));
+    s.zv = d;
+    s.redL = d + 128;
+    return s;
 }
 
 EQF_DI void chainDims64(const ChainArgs& ch, int N, int* nb, int* wt) {
@@ -88,6 +99,7 @@ EQF_DI void chainDims64(const ChainArgs& ch, int N, int* nb, int* wt) {
 //   phase 0 (fused):  rem x rem A tiles (lower triangle used) + wt x (rem + 1) rhs tiles (column K solves, K+1.. update)
 //   phase 1 (panel):  rem A blocks (R, K)                    + wt rhs tiles (column K)
 //   phase 2 (update): rem x rem A tiles                      + wt x rem rhs tiles
+//   phase 3 (update + solve of block column K+1 in the same launch): as phase 2
 __host__ __device__ inline int chainBlocks64(int nbMax, int wtMax, int K, int phase) {
     const int rem = nbMax - K - 1;
     if (rem < 0) return 0;
@@ -289,6 +301,33 @@ EQF_DI void solveStrip(double* M, int ld, const Lds64& s, int x0, int lane) {
         }
 }
 
+// z <- L^-1 z for one 64-vector in LDS, by ONE wave (lanes 0..15 carry a 16-block), with the inverse diagonal blocks:
+//   z_j = W_jj (z_j - sum_{k < 16 j} L[16 j + r][k] z_k).  LDS traffic of one wave is ordered; the asm statements keep the
+// compiler from moving loads across the in-place stores.
+EQF_DI void solveVec64(double* z, const Lds64& s, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EQF_LDS_ORDER() __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define EQF_LDS_ORDER() do { } while (0)
+#endif
+    const int r = lane & 15;
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+        double t = z[kQB * j + r];
+        for (int k = 0; k < kQB * j; ++k) t = fma(-s.L[kQB * j + r][k], z[k], t);
+        EQF_LDS_ORDER();
+        if (lane < kQB) z[kQB * j + r] = t;
+        EQF_LDS_ORDER();
+        double zz = 0.0;
+#pragma unroll
+        for (int c = 0; c < kQB; ++c) zz = fma(s.Wd[j][r][c], z[kQB * j + c], zz);
+        EQF_LDS_ORDER();
+        if (lane < kQB) z[kQB * j + r] = zz;
+        EQF_LDS_ORDER();
+    }
+#undef EQF_LDS_ORDER
+}
+
 // The first diagonal blocks of the two chains, formed straight from Sigma and factored INSIDE the prep launch (two extra
 // workgroups per filter that finish in the shadow of the landmark waves), so that the first chain launch is an ordinary
 // one:   kind 0:  S_00 = C Sigma C^T + R for the first 32 landmarks   (same expression order as k_update_prep)
@@ -429,6 +468,11 @@ __global__ __launch_bounds__(256) void k_factor_first64(ChainArgs c0, ChainArgs 
 // PHASE 1 + PHASE 2: the split chain for throughput (many tiles per launch): a panel launch solves every block of column
 //          K ONCE, in place (A_RK <- L_RK, Y_K -> WO), an update launch then only multiplies: no redundant solves
 //          (2.25x fewer MFMAs per tile) and the 77 KB LDS layout lets two workgroups share a CU.
+// PHASE 3: an update launch that ALSO solves block column K+1 (the next panel launch folded in: one launch per block column
+//          instead of two).  The workgroups of column K+1 keep their freshly updated tile in registers, wait INSIDE the
+//          launch for the diagonal workgroup to publish D[K+1] (eqf_handoff.hpp: write-through record + epoch flag, 2.6 us
+//          for the 40 KB record), then solve in place.  Only those (nb - K - 2 + wt) workgroups per chain wait, and the
+//          diagonal workgroup they wait for has the lowest block index of its filter's chain, so it is dispatched first.
 #ifdef EQF_CHOL_WG_STAMPS
 __device__ long long g_cholWg[16][256][2];  // [launch K][workgroup]: first / last cycle
 __device__ int g_cholWgInfo[16][256][4];    // second chain?, isW, R, C
@@ -444,7 +488,7 @@ struct CholWgStamp {
 };
 #endif
 template <typename T, int PHASE>
-__global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1, UpdArgs a, int K, int ddNt, int ddSmall,
+__global__ __launch_bounds__(256, (PHASE == 2 || PHASE == 3) ? 2 : 1) void k_chol_step64(ChainArgs c0, ChainArgs c1, UpdArgs a, int K, int ddNt, int ddSmall,
     int embedFinish, int* errflag) {
 #ifdef EQF_CHOL_WG_STAMPS
     CholWgStamp wgStamp(K);
@@ -502,7 +546,8 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
     const int ldA = ch.ldA, ldW = ch.ldW;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-    const Lds64 s = PHASE == 2 ? ldsUpdate(smem64) : ldsFull(smem64);
+    constexpr bool UPD = PHASE == 2 || PHASE == 3;  // update launches of the split chain: panel blocks arrive solved
+    const Lds64 s = PHASE == 3 ? ldsTail(smem64) : (PHASE == 2 ? ldsUpdate(smem64) : ldsFull(smem64));
     int bad = 0;
 #ifdef EQF_CHOL_WG_STAMPS
     if (threadIdx.x == 0 && blockIdx.y == 0 && K < 16 && blockIdx.x < 256) {
@@ -517,6 +562,8 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
     const bool needP = isW || R != C;
     const bool solveOnly = isW && C == K;
     const bool panelA = PHASE == 1 && !isW;  // solve in place, no update
+    // PHASE 3: this workgroup's tile belongs to block column K+1 (rhs: block row K+1): it is solved in this launch
+    const bool tail = PHASE == 3 && C == K + 1 && !diagNext;
 
     // ---- which 16x16 tiles of the 64x64 output tile this wave owns: its 16-row strip (tiles (wv, 0..3)); the diagonal
     // workgroup needs the lower triangle only and the first column first: slot 0 = (wv, 0), then the other tiles spread
@@ -550,7 +597,9 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
     // running sums of the reductions (rhs workgroups): previous value of this thread's entry, fetched with everything else
     double prevSum = 0.0;
     double* sumPtr = nullptr;
-    if (solveOnly) {
+    const bool rhsSolve = solveOnly || (tail && isW);  // this workgroup solves a block row of right-hand sides ...
+    const int Kp = tail ? K + 1 : K;                   // ... namely block row Kp
+    if (rhsSolve) {
         const int nvv = kLm0 + 3 * g.N;
         if (ch.kind == 0) {
             const int col = R * kSB + tid;
@@ -559,37 +608,42 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
         } else if (tid < 121) {
             sumPtr = a.red + (long long)b * 256 + 8 + tid;
         }
-        if (sumPtr && K) prevSum = *sumPtr;
+        if (sumPtr && Kp) prevSum = *sumPtr;
     }
     const double* Dk = D + (long long)K * kDRec;
     // (update launches of the split chain read the SOLVED blocks: Y_K from WO, L_RK / L_CK in place in A)
-    const double* Pg = isW ? ((PHASE == 2 ? WO : W) + (long long)(K * kSB) * ldW + R * kSB) : (A + (long long)(R * kSB) * ldA + K * kSB);
+    const double* Pg = isW ? ((UPD ? WO : W) + (long long)(K * kSB) * ldW + R * kSB) : (A + (long long)(R * kSB) * ldA + K * kSB);
     const double* Qg = A + (long long)(C * kSB) * ldA + K * kSB;
     const int ldp = isW ? ldW : ldA;
     double rL[16], rW[4], rP[16], rQ[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
         const int e = tid + 256 * u, rr = e >> 6, cc = e & 63;
-        rL[u] = PHASE == 2 ? 0.0 : Dk[e];
+        rL[u] = UPD ? 0.0 : Dk[e];
         rP[u] = needP ? Pg[(long long)rr * ldp + cc] : 0.0;
         rQ[u] = needQ ? Qg[(long long)rr * ldA + cc] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) rW[u] = PHASE == 2 ? 0.0 : Dk[kSB * kSB + tid + 256 * u];
+    for (int u = 0; u < 4; ++u) rW[u] = UPD ? 0.0 : Dk[kSB * kSB + tid + 256 * u];
+    // PHASE 3, S-chain rhs tails: the innovation column of block row K+1 (through K-1) and z_K of block row K
+    double rZ = 0.0;
+    if (tail && isW && ch.kind == 0 && tid < 2 * kSB)
+        rZ = tid < kSB ? W[(long long)((K + 1) * kSB + tid) * ldW + 11] : WO[(long long)(K * kSB + tid - kSB) * ldW + 11];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
         const int e = tid + 256 * u, rr = e >> 6, cc = e & 63;
-        if (PHASE != 2) s.L[rr][cc] = rL[u];
+        if (!UPD) s.L[rr][cc] = rL[u];
         s.P[rr][cc] = rP[u];
         s.Q[rr][cc] = rQ[u];
     }
-    if (PHASE != 2) {
+    if (!UPD) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = tid + 256 * u;
             s.Wd[e >> 8][(e >> 4) & 15][e & 15] = rW[u];
         }
     }
+    if (tail && isW && ch.kind == 0 && tid < 2 * kSB) s.zv[tid] = rZ;
     if (solveOnly && ch.kind == 0) {  // the innovation column: rows of this block row, column 11 of the right-hand sides
         for (int e = tid; e < kSB * kQB; e += 256)
             s.Zs[e >> 4][e & 15] = ((e & 15) == 0) ? W[(long long)(K * kSB + (e >> 4)) * ldW + 11] : 0.0;
@@ -598,7 +652,7 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
     EQF_STAMP(1);
     if (second && isW && C == K && K == nb - 1) EQF_FSTAMP(1);
     // ---- panel blocks: each wave solves its 16-row strip of P and of Q (16-column strip of the rhs block)
-    if (PHASE != 2) {
+    if (!UPD) {
         if (needP) {
             if (isW) solveStrip<false>(&s.P[0][0], kSP, s, kQB * wv, lane);
             else solveStrip<true>(&s.P[0][0], kSP, s, kQB * wv, lane);
@@ -610,22 +664,22 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
     EQF_STAMP(2);
     if (second && isW && C == K && K == nb - 1) EQF_FSTAMP(2);
 
-    if (panelA) {
-        for (int e = tid; e < kSB * kSB; e += 256) A[(long long)(R * kSB + (e >> 6)) * ldA + K * kSB + (e & 63)] = s.P[e >> 6][e & 63];
-    } else if (solveOnly) {
-        for (int e = tid; e < kSB * kSB; e += 256) WO[(long long)(K * kSB + (e >> 6)) * ldW + R * kSB + (e & 63)] = s.P[e >> 6][e & 63];
+    // Epilogue of a solved block row of right-hand sides (s.P = Y_Kp tile R): store it, add its share of the reductions, and
+    // -- last block row of the E-chain -- run the innovation lift.  z = L_KpKp^-1 delta_Kp, element r at z[r * zs].
+    auto rhsEpilogue = [&](const double* z, int zs) {
+        for (int e = tid; e < kSB * kSB; e += 256) WO[(long long)(Kp * kSB + (e >> 6)) * ldW + R * kSB + (e & 63)] = s.P[e >> 6][e & 63];
         const double* red = a.red + (long long)b * 256;
         if (ch.kind == 0) {
             // gamma[col] += Y_K[:, col] . z_K ; the six columns after nv are hV ; column 11 is z itself (gamma[11] = 0)
             if (sumPtr) {
                 double v = 0.0;
 #pragma unroll 8
-                for (int r = 0; r < kSB; ++r) v = fma(s.P[r][tid], s.Zs[r][0], v);
+                for (int r = 0; r < kSB; ++r) v = fma(s.P[r][tid], z[r * zs], v);
                 *sumPtr = (R * kSB + tid == 11) ? 0.0 : prevSum + v;
             }
         } else {
             // G11 += [Zt|Et]_K^T [Zt|Et]_K ; in the chain's last step the totals go straight to the innovation lift
-            const bool last = embedFinish && K == nb - 1;
+            const bool last = embedFinish && Kp == nb - 1;
             if (sumPtr) {
                 const int q0 = tid / 11, q1 = tid % 11;
                 double v = 0.0;
@@ -645,6 +699,11 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
                 EQF_FSTAMP(4);
             }
         }
+    };
+    if (panelA) {
+        for (int e = tid; e < kSB * kSB; e += 256) A[(long long)(R * kSB + (e >> 6)) * ldA + K * kSB + (e & 63)] = s.P[e >> 6][e & 63];
+    } else if (solveOnly) {
+        rhsEpilogue(PHASE == 3 ? nullptr : &s.Zs[0][0], kWP);
     } else {
         // ---- trailing update of this tile: A_RC -= L_RK L_CK^T  /  R_C -= L_CK Y_K
         const double (*Am)[kSP] = isW ? s.Q : (needP ? s.P : s.Q);
@@ -652,13 +711,59 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
             if (isW) acc[i] = mmTile<false, kSB>(acc[i], &Am[0][0], kSP, kQB * tr[i], &s.P[0][0], kSP, kQB * tc[i], lane, -1.0);
             else acc[i] = mmTile<true, kSB>(acc[i], &Am[0][0], kSP, kQB * tr[i], &s.Q[0][0], kSP, kQB * tc[i], lane, -1.0);
         };
-        if (!diagNext) {
+        if (!diagNext && !tail) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) upd(i);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) Ct[(long long)(kQB * tr[i] + (lane >> 4) + 4 * q) * ldc + kQB * tc[i] + (lane & 15)] = acc[i][q];
+        } else if (!diagNext) {
+            // ---- PHASE 3, block column K+1: update, then solve in this launch as soon as D[K+1] is published
+            if (isW && ch.kind == 0 && wv == 1) {
+                // innovation column of this block row through K:  delta' = delta - L_{K+1,K} z_K   (L_{K+1,K} = s.Q)
+                double t = s.zv[lane];
+#pragma unroll 8
+                for (int k = 0; k < kSB; ++k) t = fma(-s.Q[lane][k], s.zv[kSB + k], t);
+                s.zv[lane] = t;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) upd(i);
+            __syncthreads();  // every wave is done with s.P / s.Q as operands
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stTile(acc[i], &s.P[0][0], kSP, kQB * tr[i], kQB * tc[i], lane);
+            const double* Dn = D + (long long)(K + 1) * kDRec;
+            if (tid == 0 && !hoWait(ch.flags + (long long)b * ch.strideF + K + 1, ch.epoch)) bad = 8;  // (timed out: flagged, no hang)
+            __syncthreads();
+            Lds64 sT = s;
+            sT.L = s.Q;  // the factor of the diagonal block goes where L_CK was
+            {
+                v4i32 v[10];
+                hoLoad16x10(reinterpret_cast<const char*>(Dn) + 16 * tid, v);
+#pragma unroll
+                for (int u = 0; u < 10; ++u) {
+                    const int e = 2 * (tid + 256 * u);
+                    if (e < kSB * kSB) {
+                        sT.L[e >> 6][e & 63] = hoLo(v[u]);
+                        sT.L[e >> 6][(e & 63) + 1] = hoHi(v[u]);
+                    } else {
+                        const int q = e - kSB * kSB;
+                        s.Wd[q >> 8][(q >> 4) & 15][q & 15] = hoLo(v[u]);
+                        s.Wd[q >> 8][(q >> 4) & 15][(q & 15) + 1] = hoHi(v[u]);
+                    }
+                }
+            }
+            __syncthreads();
+            if (isW) {
+                solveStrip<false>(&s.P[0][0], kSP, sT, kQB * wv, lane);
+                if (ch.kind == 0 && wv == 3) solveVec64(s.zv, sT, lane);
+                __syncthreads();
+                rhsEpilogue(s.zv, 1);
+            } else {
+                solveStrip<true>(&s.P[0][0], kSP, sT, kQB * wv, lane);
+                __syncthreads();
+                for (int e = tid; e < kSB * kSB; e += 256) A[(long long)(R * kSB + (e >> 6)) * ldA + (K + 1) * kSB + (e & 63)] = s.P[e >> 6][e & 63];
+            }
         } else {
             // ---- look-ahead: factor the freshly updated diagonal block for launch K + 1 in s.L (nobody reads it any more)
             upd(0);
@@ -673,16 +778,38 @@ __global__ __launch_bounds__(256) void k_chol_step64(ChainArgs c0, ChainArgs c1,
                     stTile(acc[i], &s.L[0][0], kSP, kQB * tr[i], kQB * tc[i], lane);
                 }
             };
+            // (PHASE 3 publishes the whole record at the end, write-through, instead of plain stores along the way)
+            double* Dnext = D + (long long)(K + 1) * kDRec;
 #ifdef EQF_STEP64_STAMPS
-            factor64(s, tid, &bad, pre, D + (long long)(K + 1) * kDRec, !second ? &g_stamps[K][8] : nullptr, realStages(ch.kind == 0 ? sDim(g.N) : eDim(g.N), kSB * (K + 1)));
+            factor64(s, tid, &bad, pre, PHASE == 3 ? nullptr : Dnext, !second ? &g_stamps[K][8] : nullptr, realStages(ch.kind == 0 ? sDim(g.N) : eDim(g.N), kSB * (K + 1)));
 #else
-            factor64(s, tid, &bad, pre, D + (long long)(K + 1) * kDRec, nullptr, realStages(ch.kind == 0 ? sDim(g.N) : eDim(g.N), kSB * (K + 1)));
+            factor64(s, tid, &bad, pre, PHASE == 3 ? nullptr : Dnext, nullptr, realStages(ch.kind == 0 ? sDim(g.N) : eDim(g.N), kSB * (K + 1)));
 #endif
             EQF_STAMP(4);
+            if (PHASE == 3) {
+                // hand D[K+1] to the workgroups of block column K+1 of THIS launch (eqf_handoff.hpp)
+#pragma unroll
+                for (int u = 0; u < 10; ++u) {
+                    const int e = 2 * (tid + 256 * u);
+                    double v0, v1;
+                    if (e < kSB * kSB) {
+                        v0 = s.L[e >> 6][e & 63];
+                        v1 = s.L[e >> 6][(e & 63) + 1];
+                    } else {
+                        const int q = e - kSB * kSB;
+                        v0 = s.Wd[q >> 8][(q >> 4) & 15][q & 15];
+                        v1 = s.Wd[q >> 8][(q >> 4) & 15][(q & 15) + 1];
+                    }
+                    hoStore16(Dnext + e, v0, v1);
+                }
+                hoDrain();
+                __syncthreads();
+                if (tid == 0) hoPublish(ch.flags + (long long)b * ch.strideF + K + 1, ch.epoch);
+            }
             EQF_STAMP(5);
         }
     }
-    if (bad && errflag && tid == 0) atomicOr(errflag, 4);
+    if (bad && errflag && tid == 0) atomicOr(errflag, bad == 8 ? 8 : 4);
 }
 
 }  // namespace eqf

@@ -1,0 +1,59 @@
+// Inter-workgroup hand-off INSIDE one launch (gfx950): a producer workgroup publishes a record and a flag, consumer
+// workgroups of the same launch wait for the flag and read the record.
+//
+// Protocol (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility", valid form
+// "{sc0 sc1 stores and loads both sides}" with a drained flag): the per-XCD L2s are not coherent and a CU's L1 is never
+// refreshed by another CU's stores, so
+//   producer:  payload as 16-byte global_store_dwordx4 sc0 sc1 (write-through) -> s_waitcnt vmcnt(0) by every storing
+//              thread -> workgroup barrier -> ONE relaxed agent-scope atomic store of the flag;
+//   consumer:  one lane polls the flag with relaxed agent-scope loads (s_sleep between polls, bounded by a timeout) ->
+//              workgroup barrier -> payload as 16-byte global_load_dwordx4 sc0 sc1 (never served from L1 / a stale line).
+// Measured on MI355X with scripts/micro/handoff.hip (one producer, 163 consumer workgroups, every word checked over 200
+// rounds): 32 KB from flag store to the LAST consumer holding the whole payload 2.6 us, no stale word; the same with 8-byte
+// agent atomics 6.6 us, with plain stores + agent release / acquire fences 7.5 us.
+// Flags carry an EPOCH (the update counter of the handle): nothing has to be reset between updates.
+#pragma once
+#include "eqf_device.hpp"
+
+namespace eqf {
+
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+#define EQF_DEV __device__ __forceinline__
+EQF_DEV void hoStore16(void* p, double a, double b) {
+    v4i32 v;
+    v.x = __double2loint(a); v.y = __double2hiint(a); v.z = __double2loint(b); v.w = __double2hiint(b);
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+EQF_DEV void hoDrain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// one thread, after the barrier that follows every storing thread's hoDrain()
+EQF_DEV void hoPublish(int* flag, int epoch) { __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one lane; false = timed out (the producer never came: the caller raises the error flag instead of hanging the GPU)
+EQF_DEV bool hoWait(const int* flag, int epoch) {
+    const long long t0 = wall_clock64();  // 100 MHz
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > 5000000LL) return false;  // 50 ms
+    }
+    return true;
+}
+// Ten 16-byte sc0 sc1 loads at p + 4096 k (k = 0..9: 40 KB per 256-thread workgroup, one diagonal-factor record), all in
+// flight together and COMPLETE on return: the s_waitcnt sits inside the same asm statement because the compiler does not
+// track the asynchronous register write of an inline-asm load and could otherwise copy a result register too early.
+EQF_DEV void hoLoad16x10(const char* p, v4i32 (&v)[10]) {
+    const char *p0 = p, *p1 = p + 4096, *p2 = p + 2 * 4096, *p3 = p + 3 * 4096, *p4 = p + 4 * 4096, *p5 = p + 5 * 4096,
+               *p6 = p + 6 * 4096, *p7 = p + 7 * 4096, *p8 = p + 8 * 4096, *p9 = p + 9 * 4096;
+    asm volatile(
+        "global_load_dwordx4 %0, %10, off sc0 sc1\n\tglobal_load_dwordx4 %1, %11, off sc0 sc1\n\t"
+        "global_load_dwordx4 %2, %12, off sc0 sc1\n\tglobal_load_dwordx4 %3, %13, off sc0 sc1\n\t"
+        "global_load_dwordx4 %4, %14, off sc0 sc1\n\tglobal_load_dwordx4 %5, %15, off sc0 sc1\n\t"
+        "global_load_dwordx4 %6, %16, off sc0 sc1\n\tglobal_load_dwordx4 %7, %17, off sc0 sc1\n\t"
+        "global_load_dwordx4 %8, %18, off sc0 sc1\n\tglobal_load_dwordx4 %9, %19, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]), "=&v"(v[9])
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7), "v"(p8), "v"(p9)
+        : "memory");
+}
+EQF_DEV double hoLo(const v4i32& v) { return __hiloint2double(v.y, v.x); }
+EQF_DEV double hoHi(const v4i32& v) { return __hiloint2double(v.w, v.z); }
+
+}  // namespace eqf

@@ -462,6 +462,11 @@ struct ChainArgs {
     int kind;     // 0: S-chain, 1: E-chain
     int nbMax;    // tiles per edge launched for A
     int wtMax;    // right-hand-side column tiles launched
+    // in-launch hand-off of the diagonal-factor records (k_chol_step64<T, 3>, eqf_handoff.hpp): flags[b * strideF + K] == epoch
+    // once D[K] of this update has been published
+    int* flags;
+    long long strideF;
+    int epoch;
 };
 
 // per-filter chain sizes

@@ -488,15 +488,19 @@ def test_split_path_in_fp32_mode_and_under_the_dense_backend(hip, monkeypatch):
     assert all(np.abs(c[1][k] - e[1][k]).max() < 1e-9 for k in c[1])
 
 
-@pytest.mark.parametrize("mode,embed,split", [("32", "1", "0"), ("32inv", "1", "0"), ("64", "0", "0"), ("64", "1", "1"), ("64", "0", "1")])
-def test_alternative_factorisation_kernels_agree(hip, monkeypatch, mode, embed, split):
+@pytest.mark.parametrize("mode,embed,split,tail", [("32", "1", "0", "1"), ("32inv", "1", "0", "1"), ("64", "0", "0", "1"), ("64", "1", "1", "1"),
+                                                   ("64", "0", "1", "1"), ("64", "1", "1", "0"), ("64", "0", "1", "0")])
+def test_alternative_factorisation_kernels_agree(hip, monkeypatch, mode, embed, split, tail):
     """The update has three interchangeable factorisation paths: k_chol_step64 (default; reductions, downdate and
     innovation lift riding along in the chain launches), the same with downdate / lift as a launch of their own, the split
     chain (panel + update launches, the throughput variant), and the older 32-wide kernels (forward substitution or
-    explicit block inverses).  They must agree to rounding."""
+    explicit block inverses).  The split chain itself comes as one launch per block column (update launches that also solve
+    the next column after an in-launch hand-off of the diagonal factor, EQF_CHOL_TAIL=1, default) or as panel + update
+    launches (EQF_CHOL_TAIL=0).  They must agree to rounding."""
     from eqf_vio_amd import synth
 
     N = 70  # S-chain 3 and E-chain 4 block columns of 64; 5 and 7 of 32
+    monkeypatch.setenv("EQF_CHOL_TAIL", tail)
     st = synth.make_stream(N, duration=0.5)
     d = synth.template_settings_dict()
     out = []
@@ -544,6 +548,44 @@ def test_large_filter_split_chain_agrees_with_the_32_wide_kernels(hip, monkeypat
         assert rel_fro(o[0], out[0][0]) < 1e-8
         assert np.abs(o[1]["x"] - out[0][1]["x"]).max() < 1e-9
         assert np.abs(o[2]["gamma"] - out[0][2]["gamma"]).max() < 1e-8
+
+
+def test_in_launch_handoff_on_a_ragged_batch(oracle_lib, hip, monkeypatch):
+    """The one-launch-per-column split chain (k_chol_step64<T, 3>: the workgroups of block column K+1 wait inside the launch for
+    the diagonal workgroup's record) forced onto a batch of five filters with DIFFERENT chain lengths (1 .. 5 block columns),
+    over enough frames that a stale or torn record would show: every filter against its own oracle after every frame."""
+    from eqf_vio_amd import synth
+
+    monkeypatch.setenv("EQF_CHOL_SPLIT", "1")
+    monkeypatch.setenv("EQF_CHOL_TAIL", "1")
+    Ns = [9, 30, 50, 75, 100]
+    B = len(Ns)
+    sts = [synth.make_stream(Ns[b], seed=900 + b, duration=1.0) for b in range(B)]
+    d = synth.template_settings_dict()
+    fos = [oracle_lib.OracleFilter(d) for _ in range(B)]
+    fg = hip.FilterBatch(d, capacity=max(Ns), batch=B)
+    stride = max(Ns)
+    nf = 0
+    for kind, k in sts[0].events():
+        if kind == "imu":
+            for b in range(B):
+                r = sts[b].imu[k]
+                fos[b].processIMUData(r[0], r[1:4], r[4:7])
+            fg.process_imu([s_.imu[k, 0] for s_ in sts], [s_.imu[k, 1:4] for s_ in sts], [s_.imu[k, 4:7] for s_ in sts])
+        else:
+            ids = np.zeros((B, stride), dtype=np.int32)
+            y = np.zeros((B, stride, 3))
+            for b in range(B):
+                fos[b].processVisionData(sts[b].vision_stamps[k], sts[b].ids, sts[b].bearings[k])
+                ids[b, : Ns[b]] = sts[b].ids
+                y[b, : Ns[b]] = sts[b].bearings[k]
+            fg.process_vision([s_.vision_stamps[k] for s_ in sts], ids, y, nb=np.array(Ns, dtype=np.int32))
+            nf += 1
+            for b in range(B):
+                assert rel_fro(fg.sigma(b), fos[b].stateCovariance()) < SIGMA_TOL, (k, b)
+                eo, eg = fos[b].stateEstimate(), fg.state_estimate(b)
+                assert np.abs(eo["x"] - eg["x"]).max() < POSE_TOL and np.abs(eo["q"] - eg["q"]).max() < POSE_TOL, (k, b)
+    assert nf >= 19 and fg.device_error() == 0
 
 
 def test_small_filters_with_equal_chain_lengths(oracle_lib, hip):
