@@ -18,7 +18,7 @@ SKIPPED_NOT_INITIALISED = 3
 SKIPPED_NO_BEARINGS = 4
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSORTED, ERR_NUMERIC, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
 PRECISION_F64, PRECISION_F32 = 0, 1
-PROF_CLASSES = 10
+PROF_CLASSES = 11
 
 _ERR_NAMES = {
     -1: "EQF_ERR_INVALID", -2: "EQF_ERR_NO_DEVICE", -3: "EQF_ERR_HIP", -4: "EQF_ERR_CAPACITY",

@@ -18,6 +18,7 @@
 #include "eqf_propagate.hpp"
 #include "eqf_burst.hpp"
 #include "eqf_chol64.hpp"
+#include "eqf_resident.hpp"
 #include "eqf_update.hpp"
 
 using namespace eqf;
@@ -142,6 +143,14 @@ struct eqf_filter {
     int* dFlags = nullptr;         // [B][2][flagStride]: epoch flags of the in-launch hand-off of the diagonal-factor records
     int flagStride = 0;
     int updateEpoch = 0;           // one per launchUpdate
+    // k_chol_resident (one launch per update while the grid fits the chip): EQF_CHOL_RESIDENT = 0 switches it off
+    int cholResident = 1;
+    int numCUs = 0;
+    int nbCap = 0, wtCap = 0;
+    int *dReadyA = nullptr, *dReadyY = nullptr, *dResCounters = nullptr;
+    double *dGammaPart = nullptr, *dG11Part = nullptr;
+    ResRole* dRoles = nullptr;
+    int rolesN = -1, rolesCount = 0;  // chain shape (nbS, nbE, wtS) the role table was built for
     // profiling
     bool prof = false;
     std::vector<ProfPair> profPairs;
@@ -535,8 +544,35 @@ UpdArgs makeUpdArgs(eqf_filter* f, const double* bearings, long long bearStride,
     a.dbgGammaTot = f->dbgGammaTot;
     a.red = f->red;
     a.errflag = f->errflag;
+    a.resCounters = f->dResCounters;
     a.prm = f->prm;
     return a;
+}
+
+// Role table of k_chol_resident for chains of nbS / nbE block columns (wtS right-hand-side column tiles in the S-chain):
+// block index = dependency order -- group s holds the workgroups whose last step consumes D[s]; they only wait for groups < s.
+int buildRoles(eqf_filter* f, int Nmax) {
+    const int nbS = roundUp(sDim(Nmax), kSB) / kSB, nbE = roundUp(eDim(Nmax), kSB) / kSB, wtS = roundUp(yCols(Nmax), kSB) / kSB;
+    const int key = (nbS << 20) | (nbE << 10) | wtS;  // the table only changes when a chain crosses a 64-block boundary
+    if (f->rolesN == key) return EQF_OK;
+    std::vector<ResRole> r;
+    for (int s = 0; s < std::max(nbS, nbE); ++s)
+        for (int kind = 1; kind >= 0; --kind) {  // the E-chain (the longer one) first
+            const int nb = kind ? nbE : nbS, wt = kind ? 1 : wtS;
+            if (s >= nb) continue;
+            if (s + 1 < nb) r.push_back({kind, 0, s + 1, 0});
+            for (int R = s + 2; R < nb; ++R) r.push_back({kind, 1, R, s});
+            for (int t = 0; t < wt; ++t) r.push_back({kind, 2, t, s});
+        }
+    HIPC(hipStreamSynchronize(f->stream));
+    hipFree(f->dRoles);
+    f->dRoles = nullptr;
+    int rc = dmalloc(&f->dRoles, r.size());
+    if (rc) return rc;
+    HIPC(hipMemcpy(f->dRoles, r.data(), sizeof(ResRole) * r.size(), hipMemcpyHostToDevice));
+    f->rolesN = key;
+    f->rolesCount = int(r.size());
+    return EQF_OK;
 }
 
 template <typename T>
@@ -573,6 +609,8 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<float, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsUpdateBytes));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsUpdateBytes));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<float>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<float, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTailBytes));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTailBytes));
         attrSet = true;
@@ -629,7 +667,30 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         auto blocks = [&](int k, int phase) {
             return chainBlocks64(cS.nbMax, cS.wtMax, k, phase) + chainBlocks64(cE.nbMax, cE.wtMax, k, phase);
         };
-        if (splitChain && f->cholTail) {
+        // ONE launch for the whole factorisation part while its grid fits the chip (every workgroup resident: one small
+        // filter, the latency case); the role table's block order keeps it deadlock-free even when it does not
+        bool resident = false;
+        if (embed && f->cholResident && f->cholSplit <= 0 && f->dReadyA) {
+            rc = buildRoles(f, Nmax);
+            if (rc) return rc;
+            resident = (long long)f->rolesCount * B <= f->numCUs;
+        }
+        if (resident) {
+            ResArgs ra{};
+            ra.c0 = cS; ra.c1 = cE; ra.a = a;
+            ra.roles = f->dRoles;
+            ra.readyA = f->dReadyA; ra.readyY = f->dReadyY; ra.counters = f->dResCounters;
+            ra.gammaPart = f->dGammaPart; ra.g11Part = f->dG11Part;
+            ra.nbCap = f->nbCap; ra.wtCap = f->wtCap;
+            // 64 x 64 downdate tiles: a tile costs the same 14 dependent chunk fetches whatever its size, and there are enough
+            // finished workgroups to take one each
+            ra.ddNt = nt64; ra.ddSmall = 0;
+            ra.errflag = f->errflag;
+            rc = profiled(f, EQF_PROF_CHOL_RESIDENT, [&] {
+                hipLaunchKernelGGL(k_chol_resident<T>, dim3(f->rolesCount, B), dim3(256), sizeof(Step64Lds), f->stream, ra);
+            });
+            if (rc) return rc;
+        } else if (splitChain && f->cholTail) {
             // one launch per block column: the panel launch of column 0, then update launches that also solve column k+1
             // (k_chol_step64<T, 3>); the S-chain's right-hand sides are complete after launch nb64S - 2, the downdate joins
             // launch nb64S - 1 (or runs on its own below when there is none)
@@ -1002,7 +1063,8 @@ void freeAll(eqf_filter* f) {
     for (void* p : {(void*)f->p0, (void*)f->lmc, (void*)f->SA, (void*)f->SL, (void*)f->YW, (void*)f->YO, (void*)f->EA, (void*)f->EL, (void*)f->ZW,
              (void*)f->ZO, (void*)f->dbgDelta, (void*)f->dbgGamma, (void*)f->dbgGammaTot, (void*)f->red, (void*)f->errflag, (void*)f->dMap,
              (void*)f->dNewN, (void*)f->dPerm, (void*)f->dSrc, (void*)f->dChord, (void*)f->dDepth2, (void*)f->dDepthSel, (void*)f->dScratch, (void*)f->dMeas,
-             (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn, f->dBlk, (void*)f->dBlkCommon, f->dColRec, f->dRowRec, (void*)f->dSteps, (void*)f->dFlags})
+             (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn, f->dBlk, (void*)f->dBlkCommon, f->dColRec, f->dRowRec, (void*)f->dSteps, (void*)f->dFlags, (void*)f->dReadyA, (void*)f->dReadyY, (void*)f->dResCounters, (void*)f->dGammaPart,
+             (void*)f->dG11Part, (void*)f->dRoles})
         hipFree(p);
     if (f->hGate) hipHostFree(f->hGate);
     if (f->dMask) hipFree(f->dMask);
@@ -1043,6 +1105,11 @@ extern "C" int eqf_debug_step64_stamps(long long* out) {
 extern "C" int eqf_debug_chol_wg(long long* t, int* info) {
     if (hipMemcpyFromSymbol(t, HIP_SYMBOL(eqf::g_cholWg), sizeof(long long) * 16 * 256 * 2) != hipSuccess) return -1;
     return hipMemcpyFromSymbol(info, HIP_SYMBOL(eqf::g_cholWgInfo), sizeof(int) * 16 * 256 * 4) == hipSuccess ? 0 : -1;
+}
+#endif
+#ifdef EQF_RES_STAMPS
+extern "C" int eqf_debug_res_stamps(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_resStamps), sizeof(long long) * 2 * 16 * 12) == hipSuccess ? 0 : -1;
 }
 #endif
 #ifdef EQF_PREP_STAMPS
@@ -1177,6 +1244,27 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (const char* e = std::getenv("EQF_CHOL_EMBED")) f->cholEmbed = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_SPLIT")) f->cholSplit = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_TAIL")) f->cholTail = std::atoi(e);
+    if (const char* e = std::getenv("EQF_CHOL_RESIDENT")) f->cholResident = std::atoi(e);
+    {
+        hipDeviceProp_t prop;
+        if (!rc && hipGetDeviceProperties(&prop, device) != hipSuccess) rc = EQF_ERR_HIP;
+        if (!rc) f->numCUs = prop.multiProcessorCount;
+        f->nbCap = std::max(mpC, nepC) / kSB;
+        f->wtCap = ycC / kSB;
+        // the resident kernel only ever runs on grids that fit the chip: its buffers are only allocated for such handles
+        const long long maxRoles = (long long)(f->nbCap + 1) * f->nbCap + (long long)f->wtCap * f->nbCap;
+        if (!rc && maxRoles * B <= 4LL * std::max(f->numCUs, 1)) {
+            chk(dmalloc(&f->dReadyA, (size_t)2 * f->nbCap * f->nbCap * B));
+            chk(dmalloc(&f->dReadyY, (size_t)2 * f->nbCap * f->wtCap * B));
+            chk(dmalloc(&f->dResCounters, (size_t)4 * B));
+            chk(dmalloc(&f->dGammaPart, (size_t)f->nbCap * ycC * B));
+            chk(dmalloc(&f->dG11Part, (size_t)f->nbCap * 128 * B));
+            if (!rc && (hipMemset(f->dReadyA, 0, sizeof(int) * 2 * f->nbCap * f->nbCap * B) != hipSuccess ||
+                        hipMemset(f->dReadyY, 0, sizeof(int) * 2 * f->nbCap * f->wtCap * B) != hipSuccess ||
+                        hipMemset(f->dResCounters, 0, sizeof(int) * 4 * B) != hipSuccess))
+                rc = EQF_ERR_HIP;
+        }
+    }
     f->flagStride = std::max(mpC, nepC) / kSB + 1;
     chk(dmalloc(&f->dFlags, (size_t)2 * f->flagStride * B));
     if (!rc && hipMemset(f->dFlags, 0, sizeof(int) * 2 * f->flagStride * B) != hipSuccess) rc = EQF_ERR_HIP;
@@ -1761,7 +1849,7 @@ int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_m
 
 const char* eqf_profile_class_name(int cls) {
     static const char* names[EQF_PROF_CLASSES] = {"k_propagate", "k_update_prep", "k_chol_step", "k_update_reduce", "k_update_finish",
-        "k_downdate", "churn", "k_dense_riccati", "k_imu_burst", "k_chol_step_dd"};
+        "k_downdate", "churn", "k_dense_riccati", "k_imu_burst", "k_chol_step_dd", "k_chol_resident"};
     return (cls >= 0 && cls < EQF_PROF_CLASSES) ? names[cls] : "?";
 }
 

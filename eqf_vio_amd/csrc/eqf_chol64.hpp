@@ -212,16 +212,30 @@ EQF_DI void potrf16(double (*T)[kSP], const double* src, int srcLd, double (*Wj)
 }
 
 // Columns [16 j, 16 j + 16) of s.L and the inverse block Wd[j] -> diagonal-factor record Dn, by threads t = 0..nthr-1
+// (WT: write-through 8-byte stores for a record that is handed over inside the launch, eqf_handoff.hpp)
+template <bool WT = false>
 EQF_DI void storeDiagColumns(const Lds64& s, double* Dn, int j, int t, int nthr) {
-    for (int e = t; e < kSB * kQB; e += nthr) Dn[(e >> 4) * kSB + kQB * j + (e & 15)] = s.L[e >> 4][kQB * j + (e & 15)];
-    for (int e = t; e < kQB * kQB; e += nthr) Dn[kSB * kSB + kQB * kQB * j + e] = s.Wd[j][e >> 4][e & 15];
+    for (int e = t; e < kSB * kQB; e += nthr) {
+        double* p = Dn + (e >> 4) * kSB + kQB * j + (e & 15);
+        const double v = s.L[e >> 4][kQB * j + (e & 15)];
+        if (WT) hoStore8(p, v);
+        else *p = v;
+    }
+    for (int e = t; e < kQB * kQB; e += nthr) {
+        double* p = Dn + kSB * kSB + kQB * kQB * j + e;
+        const double v = s.Wd[j][e >> 4][e & 15];
+        if (WT) hoStore8(p, v);
+        else *p = v;
+    }
 }
 
 // Factor the 64x64 symmetric block in s.L in place (lower block triangle; the upper triangles of the diagonal blocks are
 // zeroed) and form s.Wd.  All 256 threads.  `pre` is extra work for waves 2 and 3 during the first stage (the diagonal
 // workgroup's remaining trailing-update tiles): pre(wave).
-template <typename Pre>
-EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn = nullptr, long long* st = nullptr, int nStages = 4) {
+// `mid` (all threads) runs once, right after the first stage's two barriers: a place to finish something asynchronous that
+// was started before the call (k_chol_resident drains and publishes the write-through stores of the solved block there).
+template <bool WT = false, typename Pre, typename Mid>
+EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn, long long* st, int nStages, Mid mid) {
     const int lane = tid & 63, wv = tid >> 6;
     // nStages: 16-column stages that hold a real column.  The rest of the block is the identity padding of the chain's
     // last block (off-diagonal zero): its L_jj = I stands as it is, W_jj = I is set here, and the pivot chain stops early.
@@ -239,7 +253,7 @@ EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn = nu
             else {
                 // the 16 columns finished in the previous stage (and their inverse block) go to the record in global memory
                 // now, in the shadow of wave 0's pivot chain, instead of all at the end of the launch
-                if (Dn) storeDiagColumns(s, Dn, j - 1, tid - 128, 128);
+                if (Dn) storeDiagColumns<WT>(s, Dn, j - 1, tid - 128, 128);
                 int t = 0;
 #pragma unroll 1
                 for (int c = j + 1; c < nStages; ++c)
@@ -267,9 +281,14 @@ EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn = nu
         if (st && tid == 0) st[2 * j + 1] = __builtin_readcyclecounter();
 #endif
         __syncthreads();
+        if (j == 0) mid();
     }
     if (Dn)
-        for (int j = nStages - 1; j < 4; ++j) storeDiagColumns(s, Dn, j, tid, 256);
+        for (int j = nStages - 1; j < 4; ++j) storeDiagColumns<WT>(s, Dn, j, tid, 256);
+}
+template <typename Pre>
+EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn = nullptr, long long* st = nullptr, int nStages = 4) {
+    factor64<false>(s, tid, bad, pre, Dn, st, nStages, [] {});
 }
 // stages of the 64-wide block starting at column c0 of a chain of real order n that hold a real column
 EQF_DI int realStages(int n, int c0) { return max(1, min(4, (min(kSB, n - c0) + kQB - 1) / kQB)); }
@@ -335,6 +354,7 @@ EQF_DI void solveVec64(double* z, const Lds64& s, int lane) {
 template <typename T>
 EQF_DI void factorFirstFromSigma(const UpdArgs& a, const ChainArgs& ch, int b, const Lds64& s, int* bad) {
     const Glob& g = a.g[b];
+    if (ch.kind == 0 && a.resCounters && threadIdx.x < 4) a.resCounters[4 * b + threadIdx.x] = 0;  // (k_chol_resident's work counters)
     if (!g.updateOk || g.N == 0) return;
     const int N = g.N, cap = a.cap, ld = a.ld, tid = threadIdx.x;
     const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;

@@ -23,7 +23,11 @@ typedef int v4i32 __attribute__((ext_vector_type(4)));
 EQF_DEV void hoStore16(void* p, double a, double b) {
     v4i32 v;
     v.x = __double2loint(a); v.y = __double2hiint(a); v.z = __double2loint(b); v.w = __double2hiint(b);
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    // The trailing s_nop covers the "VMEM store of more than 64 bits -> VALU write of its data VGPRs" hazard: the store reads
+    // its data registers a few cycles after issue, and the compiler's hazard recogniser does not look inside inline asm.
+    // (Seen without it: the low dword of some stored doubles replaced by whatever the next instruction put in the register --
+    // relative errors of 2^-20 in a handful of entries.)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 3" ::"v"(p), "v"(v) : "memory");
 }
 EQF_DEV void hoDrain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // one thread, after the barrier that follows every storing thread's hoDrain()
@@ -53,6 +57,8 @@ EQF_DEV void hoLoad16x10(const char* p, v4i32 (&v)[10]) {
         : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7), "v"(p8), "v"(p9)
         : "memory");
 }
+EQF_DEV double hoLoad8(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+EQF_DEV void hoStore8(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 EQF_DEV double hoLo(const v4i32& v) { return __hiloint2double(v.y, v.x); }
 EQF_DEV double hoHi(const v4i32& v) { return __hiloint2double(v.w, v.z); }
 

@@ -1,0 +1,443 @@
+// k_chol_resident: the WHOLE factorisation part of one vision update -- both Cholesky chains with their right-hand
+// sides, the reductions, the covariance downdate and the innovation lift -- as ONE launch (gfx950, fp64).
+//
+// Same mathematics and the same building blocks as k_chol_step64 (eqf_chol64.hpp: 64-wide block columns, register-chained
+// MFMA panel solves, the staged 16-column diagonal factorisation); what changes is WHERE the data lives and how the steps
+// are ordered.  k_chol_step64 is one launch per block column: every launch re-reads and re-writes all trailing tiles
+// through global memory (8.5 MB per launch, 85 MB per update at N = 200) and every block column pays a kernel boundary.
+// Here every 64x64 tile of the two chain matrices has ONE workgroup that keeps it in registers from the first to the last
+// update that touches it; only SOLVED blocks (L_RK, Y_Kt) and the diagonal-factor records D[K] travel, once each, through
+// global memory with the in-launch hand-off of eqf_handoff.hpp (write-through stores + epoch flags).
+//
+// Roles (per chain; S-chain: nb block rows, wt right-hand-side column tiles; E-chain: wt = 1):
+//   H(R), R = 1..nb-1   "row head": tiles (R, R-1) and (R, R).  Applies the panels K < R-1 to both, then -- the only serial
+//                       part -- waits for D[R-1], solves L_{R,R-1}, publishes it, updates and factors the diagonal tile,
+//                       publishes D[R].  One hand-off per block column on the critical path.
+//   T(R,C), C <= R-2    interior tile: applies the panels K < C, solves with D[C], publishes L_RC.
+//   W(t,C)              right-hand-side tile (block row C, column tile t): applies K < C, solves with D[C], publishes
+//                       Y_Ct; S-chain tiles also carry the innovation column z along and leave their share of
+//                       gamma = Y^T z; the E-chain's leave their share of G11 = [Zt|Et]^T [Zt|Et].
+//   The last right-hand-side workgroup of the E-chain waits for every share, sums them IN BLOCK-ROW ORDER (deterministic)
+//   and runs the innovation lift.  S-chain workgroups that finish late take the downdate tiles Sigma - Y^T Y from a
+//   counter once every Y tile is out.
+// Deadlock freedom: block indices follow the dependency order (a workgroup only ever waits for workgroups with a lower
+// block index), so whatever part of the grid is resident contains a workgroup that can run; every wait is bounded
+// (eqf_handoff.hpp) and raises the device error flag instead of hanging.  The host uses this kernel when the grid fits the
+// chip (one small filter -- the latency case); larger problems keep the per-column launches, which are bandwidth-bound.
+#pragma once
+#include "eqf_chol64.hpp"
+
+namespace eqf {
+
+struct ResRole {
+    int kind;  // 0 S-chain, 1 E-chain
+    int role;  // 0 H, 1 T, 2 W
+    int R, C;  // H: R ; T: (R, C) ; W: R = column tile t, C = block row
+};
+
+struct ResArgs {
+    ChainArgs c0, c1;      // flags = D-record flags (epoch valued)
+    UpdArgs a;
+    const ResRole* roles;  // [gridDim.x]
+    int* readyA;           // [B][2][nbCap * nbCap]  panel block (R, K) of chain c solved     (epoch valued)
+    int* readyY;           // [B][2][nbCap * wtCap]  right-hand-side tile (block row C, tile t) solved
+    int* counters;         // [B][4]: 0 = S-chain Y tiles out, 1 = next downdate tile (zeroed by the prep launch)
+    double* gammaPart;     // [B][nbCap][ldY]   share of block row C in gamma / hV
+    double* g11Part;       // [B][nbCap][128]   share of block row C in G11
+    int nbCap, wtCap;
+    int ddNt, ddSmall;
+    int* errflag;
+};
+
+// ---- 64x64 block <-> LDS through write-through / L1-bypassing 16-byte accesses.  Thread t handles row t / 4, 16 doubles
+// starting at column 16 (t % 4): one address register per block and immediate offsets (the asm operand limit).
+EQF_DEV void hoLoadBlocks2(const double* srcA, int ldA, double (*dstA)[kSP], const double* srcB, int ldB, double (*dstB)[kSP], int tid) {
+    const int r = tid >> 2, c = (tid & 3) * 16;
+    const char* pa = reinterpret_cast<const char*>(srcA + (long long)r * ldA + c);
+    const char* pb = reinterpret_cast<const char*>(srcB + (long long)r * ldB + c);
+    v4i32 a[8], b[8];
+    asm volatile(
+        "global_load_dwordx4 %0, %16, off sc0 sc1\n\tglobal_load_dwordx4 %1, %16, off offset:16 sc0 sc1\n\t"
+        "global_load_dwordx4 %2, %16, off offset:32 sc0 sc1\n\tglobal_load_dwordx4 %3, %16, off offset:48 sc0 sc1\n\t"
+        "global_load_dwordx4 %4, %16, off offset:64 sc0 sc1\n\tglobal_load_dwordx4 %5, %16, off offset:80 sc0 sc1\n\t"
+        "global_load_dwordx4 %6, %16, off offset:96 sc0 sc1\n\tglobal_load_dwordx4 %7, %16, off offset:112 sc0 sc1\n\t"
+        "global_load_dwordx4 %8, %17, off sc0 sc1\n\tglobal_load_dwordx4 %9, %17, off offset:16 sc0 sc1\n\t"
+        "global_load_dwordx4 %10, %17, off offset:32 sc0 sc1\n\tglobal_load_dwordx4 %11, %17, off offset:48 sc0 sc1\n\t"
+        "global_load_dwordx4 %12, %17, off offset:64 sc0 sc1\n\tglobal_load_dwordx4 %13, %17, off offset:80 sc0 sc1\n\t"
+        "global_load_dwordx4 %14, %17, off offset:96 sc0 sc1\n\tglobal_load_dwordx4 %15, %17, off offset:112 sc0 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7]), "=&v"(b[0]), "=&v"(b[1]),
+          "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7])
+        : "v"(pa), "v"(pb)
+        : "memory");
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        dstA[r][c + 2 * u] = hoLo(a[u]);
+        dstA[r][c + 2 * u + 1] = hoHi(a[u]);
+        dstB[r][c + 2 * u] = hoLo(b[u]);
+        dstB[r][c + 2 * u + 1] = hoHi(b[u]);
+    }
+}
+EQF_DEV void hoLoadBlock(const double* src, int ld, double (*dst)[kSP], int tid) {
+    const int r = tid >> 2, c = (tid & 3) * 16;
+    const char* pa = reinterpret_cast<const char*>(src + (long long)r * ld + c);
+    v4i32 a[8];
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off sc0 sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc0 sc1\n\t"
+        "global_load_dwordx4 %2, %8, off offset:32 sc0 sc1\n\tglobal_load_dwordx4 %3, %8, off offset:48 sc0 sc1\n\t"
+        "global_load_dwordx4 %4, %8, off offset:64 sc0 sc1\n\tglobal_load_dwordx4 %5, %8, off offset:80 sc0 sc1\n\t"
+        "global_load_dwordx4 %6, %8, off offset:96 sc0 sc1\n\tglobal_load_dwordx4 %7, %8, off offset:112 sc0 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7])
+        : "v"(pa)
+        : "memory");
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        dst[r][c + 2 * u] = hoLo(a[u]);
+        dst[r][c + 2 * u + 1] = hoHi(a[u]);
+    }
+}
+// LDS block -> global, write-through; the caller drains, synchronises and publishes the flag
+// (coalesced: 32 consecutive lanes cover one 512-byte row)
+EQF_DEV void hoStoreBlock(double* dst, int ld, const double (*src)[kSP], int tid) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int p = tid + 256 * u, r = p >> 5, c = 2 * (p & 31);
+        hoStore16(dst + (long long)r * ld + c, src[r][c], src[r][c + 1]);
+    }
+}
+// diagonal-factor record (L_KK 64x64 + four inverse 16x16 blocks) global -> s.L / s.Wd
+EQF_DEV void hoLoadRecord(const double* Dk, const Lds64& s, int tid) {
+    v4i32 v[10];
+    hoLoad16x10(reinterpret_cast<const char*>(Dk) + 16 * tid, v);
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+        const int e = 2 * (tid + 256 * u);
+        if (e < kSB * kSB) {
+            s.L[e >> 6][e & 63] = hoLo(v[u]);
+            s.L[e >> 6][(e & 63) + 1] = hoHi(v[u]);
+        } else {
+            const int q = e - kSB * kSB;
+            s.Wd[q >> 8][(q >> 4) & 15][q & 15] = hoLo(v[u]);
+            s.Wd[q >> 8][(q >> 4) & 15][(q & 15) + 1] = hoHi(v[u]);
+        }
+    }
+}
+EQF_DEV void hoStoreRecord(double* Dk, const Lds64& s, int tid) {
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+        const int e = 2 * (tid + 256 * u);
+        double v0, v1;
+        if (e < kSB * kSB) {
+            v0 = s.L[e >> 6][e & 63];
+            v1 = s.L[e >> 6][(e & 63) + 1];
+        } else {
+            const int q = e - kSB * kSB;
+            v0 = s.Wd[q >> 8][(q >> 4) & 15][q & 15];
+            v1 = s.Wd[q >> 8][(q >> 4) & 15][(q & 15) + 1];
+        }
+        hoStore16(Dk + e, v0, v1);
+    }
+}
+
+// Thread 0 waits for up to three flags (nullptr = none).  Returns through `bad` (8 = timed out).
+EQF_DEV void hoWait3(const int* f0, const int* f1, const int* f2, int epoch, int tid, int* bad) {
+    if (tid == 0) {
+        if (f0 && !hoWait(f0, epoch)) *bad = 8;
+        if (f1 && !hoWait(f1, epoch)) *bad = 8;
+        if (f2 && !hoWait(f2, epoch)) *bad = 8;
+    }
+    __syncthreads();
+}
+
+#ifdef EQF_RES_STAMPS
+__device__ long long g_resStamps[2][16][12];  // [chain][R][phase] wall-clock (100 MHz) stamps of the row heads, filter 0
+#define EQF_RSTAMP(i) do { if (tid == 0 && b == 0 && R < 16) g_resStamps[role.kind][R][i] = wall_clock64(); } while (0)
+#define EQF_WSTAMP(i) do { if (tid == 0 && b == 0 && !isS && C == nb - 1) g_resStamps[1][15][i] = wall_clock64(); } while (0)
+#else
+#define EQF_RSTAMP(i) do { } while (0)
+#define EQF_WSTAMP(i) do { } while (0)
+#endif
+template <typename T>
+__global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemR[];
+    const ResRole role = ra.roles[blockIdx.x];
+    const int b = blockIdx.y;
+    const ChainArgs& ch = role.kind ? ra.c1 : ra.c0;
+    const UpdArgs& a = ra.a;
+    const Glob& g = ch.g[b];
+    // a filter whose update is switched off (speculative outlier gate) or that has no landmarks: no factorisation work, but its
+    // Sigma still has to reach the other ping-pong buffer -- the downdate loop below copies it
+    const bool active = g.updateOk && g.N != 0;
+    if (!active && !(ra.ddNt > 0 && role.kind == 0)) return;  // (inactive filter: the S-chain's workgroups copy Sigma below)
+    int nb, wt;
+    chainDims64(ch, g.N, &nb, &wt);
+    int nbS, wtS, nbE, wtE;
+    chainDims64(ra.c0, g.N, &nbS, &wtS);
+    chainDims64(ra.c1, g.N, &nbE, &wtE);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int epoch = ch.epoch;
+    const Lds64 s = ldsFull(smemR);
+    double* A = ch.A + (long long)b * ch.strideA;
+    double* D = ch.D + (long long)b * ch.strideD;
+    double* W = ch.W + (long long)b * ch.strideW;
+    double* WO = ch.WO + (long long)b * ch.strideW;
+    const int ldA = ch.ldA, ldW = ch.ldW;
+    const int nbCap = ra.nbCap, wtCap = ra.wtCap;
+    int* readyA = ra.readyA + ((long long)b * 2 + role.kind) * nbCap * nbCap;
+    int* readyY = ra.readyY + ((long long)b * 2 + role.kind) * nbCap * wtCap;
+    const int* flagD = ch.flags + (long long)b * ch.strideF;
+    int* counters = ra.counters + (long long)b * 4;
+    int bad = 0;
+    int finishStep = 0;  // the block column at which this workgroup's own work ends
+
+    if (!active) {
+        finishStep = 1 << 20;
+    } else if (role.role == 0) {
+        // =========================================================================================== H(R)
+        const int R = role.R;
+        if (R >= nb) return;
+        finishStep = R - 1;
+        // tile (R, R-1): wave wv owns the 16-row strip (tiles (wv, 0..3)); tile (R, R): the lower triangle in the
+        // diagonal-workgroup layout of k_chol_step64 (slot 0 = (wv, 0), the deferred tiles on waves 2, 3)
+        int tr[4], tc[4], nt;
+        nt = wv >= 2 ? 4 : 1;
+        tr[0] = wv; tc[0] = 0;
+        tr[1] = wv == 2 ? 1 : 2; tc[1] = 1;
+        tr[2] = wv == 2 ? 3 : 2; tc[2] = wv == 2 ? 1 : 2;
+        tr[3] = 3;               tc[3] = wv == 2 ? 2 : 3;
+        const double* T1 = A + (long long)(R * kSB) * ldA + (R - 1) * kSB;
+        const double* T2 = A + (long long)(R * kSB) * ldA + R * kSB;
+        f64x4 a1[4], a2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a1[i][q] = T1[(long long)(kQB * wv + (lane >> 4) + 4 * q) * ldA + kQB * i + (lane & 15)];
+                a2[i][q] = i < nt ? T2[(long long)(kQB * tr[i] + (lane >> 4) + 4 * q) * ldA + kQB * tc[i] + (lane & 15)] : 0.0;
+            }
+        EQF_RSTAMP(0);
+        // (A dry run of the serial part during the idle time before the panels arrive -- to take the instruction-cache misses of
+        // code a workgroup executes exactly once off the critical path -- was tried and measured: no gain.)
+        for (int K = 0; K + 1 < R; ++K) {
+            hoWait3(readyA + R * nbCap + K, readyA + (R - 1) * nbCap + K, nullptr, epoch, tid, &bad);
+            hoLoadBlocks2(A + (long long)(R * kSB) * ldA + K * kSB, ldA, s.P, A + (long long)((R - 1) * kSB) * ldA + K * kSB, ldA, s.Q, tid);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a1[i] = mmTile<true, kSB>(a1[i], &s.P[0][0], kSP, kQB * wv, &s.Q[0][0], kSP, kQB * i, lane, -1.0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nt) a2[i] = mmTile<true, kSB>(a2[i], &s.P[0][0], kSP, kQB * tr[i], &s.P[0][0], kSP, kQB * tc[i], lane, -1.0);
+            __syncthreads();
+        }
+        // ---- the serial part: D[R-1] -> L_{R,R-1} -> diagonal tile -> D[R]
+        EQF_RSTAMP(1);
+        hoWait3(R - 1 > 0 ? flagD + (R - 1) : nullptr, nullptr, nullptr, epoch, tid, &bad);
+        EQF_RSTAMP(2);
+        hoLoadRecord(D + (long long)(R - 1) * kDRec, s, tid);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stTile(a1[i], &s.P[0][0], kSP, kQB * wv, kQB * i, lane);
+        __syncthreads();
+        EQF_RSTAMP(3);
+        solveStrip<true>(&s.P[0][0], kSP, s, kQB * wv, lane);
+        __syncthreads();
+        EQF_RSTAMP(4);
+        // first column of the diagonal tile, then the factorisation with the other tiles deferred to waves 2, 3; the solved
+        // block leaves for the other workgroups meanwhile (stores are asynchronous)
+        hoStoreBlock(A + (long long)(R * kSB) * ldA + (R - 1) * kSB, ldA, s.P, tid);
+        a2[0] = mmTile<true, kSB>(a2[0], &s.P[0][0], kSP, kQB * tr[0], &s.P[0][0], kSP, kQB * tc[0], lane, -1.0);
+        __syncthreads();  // (every wave has finished reading s.L / s.Wd of D[R-1])
+        EQF_RSTAMP(5);
+        stTile(a2[0], &s.L[0][0], kSP, kQB * tr[0], kQB * tc[0], lane);
+        if (wv == 0) stTile(a2[0], &s.D0[0][0], kWP, 0, 0, lane);
+        __syncthreads();
+        auto pre = [&](int) {
+#pragma unroll
+            for (int i = 1; i < 4; ++i) {
+                a2[i] = mmTile<true, kSB>(a2[i], &s.P[0][0], kSP, kQB * tr[i], &s.P[0][0], kSP, kQB * tc[i], lane, -1.0);
+                stTile(a2[i], &s.L[0][0], kSP, kQB * tr[i], kQB * tc[i], lane);
+            }
+        };
+        EQF_RSTAMP(6);
+        // the solved block's stores drain in the shadow of the first 16 pivots; it is published right after them
+        auto mid = [&] {
+            hoDrain();
+            __syncthreads();
+            if (tid == 0) hoPublish(readyA + R * nbCap + (R - 1), epoch);
+        };
+        factor64<true>(s, tid, &bad, pre, D + (long long)R * kDRec, nullptr, realStages(ch.kind == 0 ? sDim(g.N) : eDim(g.N), kSB * R), mid);
+        EQF_RSTAMP(7);
+        hoDrain();
+        __syncthreads();
+        if (tid == 0) hoPublish(ch.flags + (long long)b * ch.strideF + R, epoch);
+        EQF_RSTAMP(8);
+    } else if (role.role == 1) {
+        // =========================================================================================== T(R, C)
+        const int R = role.R, C = role.C;
+        if (R >= nb) return;
+        finishStep = C;
+        const double* Tg = A + (long long)(R * kSB) * ldA + C * kSB;
+        f64x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][q] = Tg[(long long)(kQB * wv + (lane >> 4) + 4 * q) * ldA + kQB * i + (lane & 15)];
+        for (int K = 0; K < C; ++K) {
+            hoWait3(readyA + R * nbCap + K, readyA + C * nbCap + K, nullptr, epoch, tid, &bad);
+            hoLoadBlocks2(A + (long long)(R * kSB) * ldA + K * kSB, ldA, s.P, A + (long long)(C * kSB) * ldA + K * kSB, ldA, s.Q, tid);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = mmTile<true, kSB>(acc[i], &s.P[0][0], kSP, kQB * wv, &s.Q[0][0], kSP, kQB * i, lane, -1.0);
+            __syncthreads();
+        }
+        hoWait3(C > 0 ? flagD + C : nullptr, nullptr, nullptr, epoch, tid, &bad);
+        hoLoadRecord(D + (long long)C * kDRec, s, tid);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stTile(acc[i], &s.P[0][0], kSP, kQB * wv, kQB * i, lane);
+        __syncthreads();
+        solveStrip<true>(&s.P[0][0], kSP, s, kQB * wv, lane);
+        __syncthreads();
+        hoStoreBlock(A + (long long)(R * kSB) * ldA + C * kSB, ldA, s.P, tid);
+        hoDrain();
+        __syncthreads();
+        if (tid == 0) hoPublish(readyA + R * nbCap + C, epoch);
+    } else {
+        // =========================================================================================== W(t, C)
+        const int t = role.R, C = role.C;
+        if (t >= wt || C >= nb) return;
+        finishStep = C;
+        const double* Tg = W + (long long)(C * kSB) * ldW + t * kSB;
+        f64x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][q] = Tg[(long long)(kQB * wv + (lane >> 4) + 4 * q) * ldW + kQB * i + (lane & 15)];
+        const bool isS = ch.kind == 0;
+        double* zv = s.redL;  // [0, 64) the innovation column delta of this block row, [64, 128) z of block row K
+        if (isS && tid < kSB) zv[tid] = W[(long long)(C * kSB + tid) * ldW + 11];
+        for (int K = 0; K < C; ++K) {
+            hoWait3(readyA + C * nbCap + K, readyY + K * wtCap + t, isS ? readyY + K * wtCap : nullptr, epoch, tid, &bad);
+            hoLoadBlocks2(A + (long long)(C * kSB) * ldA + K * kSB, ldA, s.Q, WO + (long long)(K * kSB) * ldW + t * kSB, ldW, s.P, tid);
+            if (isS && tid < kSB) zv[kSB + tid] = hoLoad8(WO + (long long)(K * kSB + tid) * ldW + 11);
+            __syncthreads();
+            if (isS && wv == 1) {  // delta -= L_CK z_K
+                double d = zv[lane];
+#pragma unroll 8
+                for (int k = 0; k < kSB; ++k) d = fma(-s.Q[lane][k], zv[kSB + k], d);
+                zv[lane] = d;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = mmTile<false, kSB>(acc[i], &s.Q[0][0], kSP, kQB * wv, &s.P[0][0], kSP, kQB * i, lane, -1.0);
+            __syncthreads();
+        }
+        EQF_WSTAMP(0);
+        hoWait3(C > 0 ? flagD + C : nullptr, nullptr, nullptr, epoch, tid, &bad);
+        EQF_WSTAMP(1);
+        hoLoadRecord(D + (long long)C * kDRec, s, tid);
+        // running sums of the reductions: block row C adds its share to what block row C-1 of the same column tile left
+        // (published together with that tile, which this workgroup has already waited for): a fixed summation order
+        const int nvv = kLm0 + 3 * g.N;
+        double prevSum = 0.0;
+        if (C > 0) {
+            if (isS && tid < kSB && t * kSB + tid < nvv + 6) prevSum = hoLoad8(ra.gammaPart + ((long long)b * nbCap + C - 1) * ldW + t * kSB + tid);
+            if (!isS && tid < 121) prevSum = hoLoad8(ra.g11Part + ((long long)b * nbCap + C - 1) * 128 + tid);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stTile(acc[i], &s.P[0][0], kSP, kQB * wv, kQB * i, lane);
+        __syncthreads();
+        solveStrip<false>(&s.P[0][0], kSP, s, kQB * wv, lane);
+        if (isS && wv == 3) solveVec64(zv, s, lane);
+        __syncthreads();
+        EQF_WSTAMP(2);
+        hoStoreBlock(WO + (long long)(C * kSB) * ldW + t * kSB, ldW, s.P, tid);
+        double g11Tot = 0.0;
+        if (isS) {
+            // gamma[col] = sum_C Y_C[:, col] . z_C (columns nvv .. nvv+5: hV), through block row C
+            const int col = t * kSB + tid;
+            if (tid < kSB && col < nvv + 6) {
+                double v = 0.0;
+#pragma unroll 8
+                for (int r = 0; r < kSB; ++r) v = fma(s.P[r][tid], zv[r], v);
+                hoStore8(ra.gammaPart + ((long long)b * nbCap + C) * ldW + col, prevSum + v);
+            }
+        } else if (tid < 121) {
+            const int q0 = tid / 11, q1 = tid % 11;
+            double v = 0.0;
+#pragma unroll 8
+            for (int r = 0; r < kSB; ++r) v = fma(s.P[r][q0], s.P[r][q1], v);
+            g11Tot = prevSum + v;
+            hoStore8(ra.g11Part + ((long long)b * nbCap + C) * 128 + tid, g11Tot);
+        }
+        hoDrain();
+        __syncthreads();
+        if (tid == 0) {
+            hoPublish(readyY + C * wtCap + t, epoch);
+            if (isS) __hip_atomic_fetch_add(counters + 0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        EQF_WSTAMP(3);
+        if (!isS && C == nb - 1) {
+            // ---- the last right-hand-side workgroup of the E-chain: collect every share (block-row order), innovation lift
+            // the S-chain's last block row carries the complete sums: wait for its tiles only
+            const int* ryS = ra.readyY + ((long long)b * 2 + 0) * nbCap * wtCap;
+            if (tid < wtS && !hoWait(ryS + (nbS - 1) * wtCap + tid, epoch)) bad = 8;
+            __syncthreads();
+            double* gam = a.dbgGamma + (long long)b * (kLm0 + 3 * a.cap);
+            const int ldY = ra.c0.ldW;
+            double gv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int col = tid + 256 * u;
+                gv[u] = col < nvv + 6 ? hoLoad8(ra.gammaPart + ((long long)b * nbCap + nbS - 1) * ldY + col) : 0.0;
+            }
+            for (int col = tid + 1024; col < nvv + 6; col += 256) {  // (more than 1024 columns: N > 335, not a resident size)
+                const double v = hoLoad8(ra.gammaPart + ((long long)b * nbCap + nbS - 1) * ldY + col);
+                if (col < nvv) gam[col] = v;
+                else s.redL[col - nvv] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int col = tid + 256 * u;
+                if (col < nvv) gam[col] = col == 11 ? 0.0 : gv[u];
+                else if (col < nvv + 6) s.redL[col - nvv] = gv[u];
+            }
+            if (tid < 121) s.redL[8 + tid] = g11Tot;
+            __syncthreads();
+            EQF_WSTAMP(4);
+            updateFinishBody(a, b, s.redL);
+            __syncthreads();
+            EQF_WSTAMP(5);
+        }
+    }
+    if (bad && ra.errflag && tid == 0) atomicOr(ra.errflag, bad == 8 ? 8 : 4);
+
+    // ---- covariance downdate Sigma - Y^T Y: every workgroup that is done with its role takes tiles from a counter once every Y
+    // tile of this filter is out (a tile is latency-bound -- 14 dependent chunk fetches -- so it wants many workgroups, one
+    // tile each; workgroups that finish later find the counter exhausted and leave)
+    if (ra.ddNt > 0 && (active || role.kind == 0)) {
+        __shared__ int sTile;
+        if (tid == 0 && active) {
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(counters + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nbS * wtS) {
+                __builtin_amdgcn_s_sleep(32);
+                if (wall_clock64() - t0 > 5000000LL) {
+                    if (ra.errflag) atomicOr(ra.errflag, 8);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        const int ddTiles = ra.ddNt * (ra.ddNt + 1) / 2;
+        for (;;) {
+            if (tid == 0) sTile = __hip_atomic_fetch_add(counters + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const int tile = sTile;
+            __syncthreads();
+            if (tile >= ddTiles) break;
+            if (ra.ddSmall) downdateTile<T, 32>(a, ra.ddNt, b, tile, reinterpret_cast<T*>(smemR));
+            else downdateTile<T, 64>(a, ra.ddNt, b, tile, reinterpret_cast<T*>(smemR));
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace eqf

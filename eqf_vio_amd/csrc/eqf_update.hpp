@@ -63,6 +63,7 @@ struct UpdArgs {
     double* dbgGammaTot;  // [B][9+3*cap]
     double* red;          // [B][256]: hV (6) at 0, G11 = [Zt|Et]^T [Zt|Et] (11x11) at 8
     int* errflag;
+    int* resCounters;     // [B][4] work counters of k_chol_resident (zeroed by the prep launch), or nullptr
     int pad;              // chain dimensions are padded (with identity) to multiples of this: 32 (k_chol_step) or 64 (k_chol_step64)
     Params prm;
 };

@@ -177,7 +177,8 @@ int eqf_set_dense_propagate(eqf_filter* f, int on);
 #define EQF_PROF_DENSE 7 /* k_dense_build + the two k_dense_gemm launches of the dense Riccati backend */
 #define EQF_PROF_BURST 8 /* k_burst_build + k_burst_riccati: one bracket per burst of integrateUpToTime steps */
 #define EQF_PROF_CHOL_DD 9 /* the one k_chol_step64 launch per update that also carries Sigma - Y^T Y (64-wide path) */
-#define EQF_PROF_CLASSES 10
+#define EQF_PROF_CHOL_RESIDENT 10 /* k_chol_resident: the whole factorisation part of an update as one launch */
+#define EQF_PROF_CLASSES 11
 int eqf_profile_enable(eqf_filter* f, int on);
 int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_ms);
 const char* eqf_profile_class_name(int cls);

@@ -1,0 +1,36 @@
+"""Phases of the row-head workgroups of k_chol_resident (library built with -DEQF_RES_STAMPS): wall-clock stamps (100 MHz) of
+the E-chain and S-chain row heads of the LAST update of a short N = 200 run, relative to the first stamp."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from eqf_vio_amd import binding, synth
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+st = synth.make_stream(N, duration=0.3)
+fb = binding.FilterBatch(synth.template_settings_dict(), capacity=N, batch=1)
+fb.stream_upload(st.imu, st.vision_stamps, st.ids, st.bearings)
+for kind, k in st.events():
+    (fb.stream_imu if kind == "imu" else fb.stream_vision)(k)
+fb.synchronize()
+out = (C.c_longlong * (2 * 16 * 12))()
+assert binding.lib().eqf_debug_res_stamps(out) == 0
+t = np.array(out, dtype=np.int64).reshape(2, 16, 12)
+names = ["tiles loaded", "panels applied", "D flag seen", "D loaded + tile in LDS", "solved", "L published", "first column in LDS", "factored", "D published"]
+for ch, nm in ((1, "E-chain"), (0, "S-chain")):
+    rows = [R for R in range(1, 16) if t[ch, R, 8] > 0]
+    if not rows:
+        continue
+    t0 = t[ch, rows[0], 0]
+    print(nm, "(us since the first row head started; phases:", ", ".join(names), ")")
+    for R in rows:
+        print(f"  H({R:2d})", " ".join(f"{(t[ch, R, i] - t0) / 100.0:7.2f}" for i in range(9)))
+
+w = t[1, 15]
+if w[5] > 0:
+    t0 = t[1, [R for R in range(1, 15) if t[1, R, 8] > 0][0], 0]
+    print("last right-hand-side workgroup of the E-chain (lift): ready, D flag seen, solved, published, sums collected, lift done")
+    print("   ", " ".join(f"{(w[i] - t0) / 100.0:7.2f}" for i in range(6)))

@@ -588,6 +588,55 @@ def test_in_launch_handoff_on_a_ragged_batch(oracle_lib, hip, monkeypatch):
     assert nf >= 19 and fg.device_error() == 0
 
 
+@pytest.mark.parametrize("Ns", [(70,), (200,), (30, 70), (9, 64, 21)])
+def test_resident_update_kernel_equals_the_per_column_launches(oracle_lib, hip, monkeypatch, Ns):
+    """k_chol_resident (the whole factorisation part of an update as ONE launch: tiles resident in registers, solved blocks and
+    diagonal factors handed over inside the launch) against the per-column launches of k_chol_step64 (EQF_CHOL_RESIDENT=0) and
+    against the oracle, single filters and ragged batches (chains of different lengths inside one launch)."""
+    from eqf_vio_amd import synth
+
+    B = len(Ns)
+    dur = 0.36 if max(Ns) >= 200 else 0.8
+    sts = [synth.make_stream(Ns[b], seed=300 + b, duration=dur) for b in range(B)]
+    d = synth.template_settings_dict()
+    stride = max(Ns)
+    out = []
+    for res in ("1", "0"):
+        monkeypatch.setenv("EQF_CHOL_RESIDENT", res)
+        fos = [oracle_lib.OracleFilter(d) for _ in range(B)] if res == "1" else None
+        fg = hip.FilterBatch(d, capacity=stride, batch=B)
+        for kind, k in sts[0].events():
+            if kind == "imu":
+                if fos:
+                    for b in range(B):
+                        r = sts[b].imu[k]
+                        fos[b].processIMUData(r[0], r[1:4], r[4:7])
+                fg.process_imu([s_.imu[k, 0] for s_ in sts], [s_.imu[k, 1:4] for s_ in sts], [s_.imu[k, 4:7] for s_ in sts])
+            else:
+                ids = np.zeros((B, stride), dtype=np.int32)
+                y = np.zeros((B, stride, 3))
+                for b in range(B):
+                    if fos:
+                        fos[b].processVisionData(sts[b].vision_stamps[k], sts[b].ids, sts[b].bearings[k])
+                    ids[b, : Ns[b]] = sts[b].ids
+                    y[b, : Ns[b]] = sts[b].bearings[k]
+                fg.process_vision([s_.vision_stamps[k] for s_ in sts], ids, y, nb=np.array(Ns, dtype=np.int32))
+                if fos:
+                    for b in range(B):
+                        assert rel_fro(fg.sigma(b), fos[b].stateCovariance()) < SIGMA_TOL, (k, b)
+                        eo, eg = fos[b].stateEstimate(), fg.state_estimate(b)
+                        assert np.abs(eo["x"] - eg["x"]).max() < POSE_TOL and np.abs(eo["q"] - eg["q"]).max() < POSE_TOL, (k, b)
+        assert fg.device_error() == 0
+        out.append([(fg.sigma(b), fg.state_estimate(b), fg.bias(b), fg.last_update(b)) for b in range(B)])
+    for b in range(B):
+        r1, r0 = out[0][b], out[1][b]
+        assert rel_fro(r1[0], r0[0]) < 1e-9
+        assert all(np.abs(r1[1][k] - r0[1][k]).max() < 1e-9 for k in r1[1])
+        assert np.abs(r1[2] - r0[2]).max() < 1e-9
+        assert np.abs(r1[3]["gamma"] - r0[3]["gamma"]).max() < 1e-9 * max(1.0, np.abs(r0[3]["gamma"]).max())
+        assert np.abs(r1[3]["Gamma"] - r0[3]["Gamma"]).max() < 1e-9 * max(1.0, np.abs(r0[3]["Gamma"]).max())
+
+
 def test_small_filters_with_equal_chain_lengths(oracle_lib, hip):
     """N <= 19: both chains are one 64-block long, so downdate and innovation lift cannot ride along (fallback launch)."""
     from eqf_vio_amd import synth
