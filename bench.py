@@ -180,6 +180,8 @@ def roofline(fb, events, N, B, precision):
         # every chain launch does ~1/L of the two factorisations; the one that carries the downdate does that on top
         "k_chol_step": ("mfma", chain_flops * B / max(chol_launches_per_update, 1)),
         "k_chol_step_dd": ("mfma", (downdate_flops + chain_flops / max(chol_launches_per_update, 1)) * B),
+        # the whole factorisation part of an update in ONE launch (csrc/eqf_resident.hpp)
+        "k_chol_resident": ("mfma", update_flops * B),
         "k_downdate": ("mfma", downdate_flops * B),
         # dense backend (cfg 3): build F + two n^3 GEMMs = 4 n^3 flops per Riccati step (SURVEY.md 8d "mfma_dense_equiv")
         "k_dense_riccati": ("mfma", 4.0 * n**3 * B),
@@ -216,7 +218,13 @@ def roofline(fb, events, N, B, precision):
     out = None
     chol_ms, chol_cnt = ms_plain + ms_dd, c_plain + c_dd
     top = next((r for r in rows if "bound" in r), None)
-    if chol_cnt and top is not None and top["kernel"].startswith("k_chol_step"):
+    if top is not None and top["kernel"] == "k_chol_resident":
+        # dominant kernel = k_chol_resident: one launch per update carries SURVEY 8(d)'s update flops
+        out = {k: top[k] for k in ("bound", "achieved", "peak", "unit", "frac")}
+        out.update(traffic=None, kernel="k_chol_resident", avg_us=top["avg_us"], launches_per_update=1.0,
+                   algorithmic_flops_per_update=update_flops * B, executed_flops_per_update=executed_flops * B,
+                   achieved_executed=round(executed_flops * B / (top["avg_us"] * 1e-6) / 1e12, 4), us_per_update=top["avg_us"])
+    elif chol_cnt and top is not None and top["kernel"].startswith("k_chol_step"):
         # dominant kernel = k_chol_step64 (all its launches of an update, the downdate-carrying one included): SURVEY 8(d)'s
         # update flops per update / launches per update / average launch duration
         avg_us = chol_ms * 1e3 / chol_cnt
@@ -397,8 +405,8 @@ def main():
         n_imu_vis = len(timed)
         n_upd = max(t.get("k_update_prep", (0, 1))[1], 1)
         prop_ms = t.get("k_propagate", (0, 0))[0] + t.get("k_dense_riccati", (0, 0))[0] + t.get("k_imu_burst", (0, 0))[0]
-        upd_ms = sum(t.get(k, (0, 0))[0] for k in ("k_update_prep", "k_chol_step", "k_chol_step_dd", "k_update_reduce", "k_update_finish",
-                                                   "k_downdate"))
+        upd_ms = sum(t.get(k, (0, 0))[0] for k in ("k_update_prep", "k_chol_step", "k_chol_step_dd", "k_chol_resident", "k_update_reduce",
+                                                   "k_update_finish", "k_downdate"))
         line["per_call"] = {
             "propagate_us": round(prop_ms * 1e3 / max(n_imu_vis, 1), 3),
             "update_us": round(upd_ms * 1e3 / n_upd, 3),
