@@ -28,7 +28,7 @@ bundleLift's weights (EqFMatrices.cpp:239, Sigma_e = Sigma[6:, 6:]) come from th
 coordinates of Sigma_e have been eliminated locally (a Schur complement every rank can form from the replicated panel).
 
 Status: design + exchange schedule + tile-local mathematics in torch (rocBLAS fp64 on the GPU box); validated on CPU with gloo
-against the single-process oracle (tests/test_tiled.py).  The hand-written tile kernels (the tile-local forms of k_riccati_stream
+against the single-process fp64 reference filter (tests/test_tiled.py).  The hand-written tile kernels (the tile-local forms of k_riccati_stream
 / k_chol_step64 / downdateTile behind eqf_tile_* entry points) and a measured 8-GPU run are the next step -- no 8-GPU node has
 been available to this build.
 """
