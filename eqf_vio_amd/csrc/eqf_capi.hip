@@ -699,6 +699,9 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
                     embed ? 1 : 0, f->errflag);
             }, 1000);
             if (rc) return rc;
+            // (A downdate with 128 x 128 tiles -- half the Y traffic per flop -- as a launch of its own was tried here and measured
+            // SLOWER: 788 vs 516 us for 64 filters, 48 vs 29.5 ms at N = 4000; 352 registers leave one wave per SIMD.  The 64-wide
+            // tiles are not bandwidth-bound: they run at half the fp64 MFMA peak in executed flops.)
             bool ddDone = false;
             for (int k = 0; k + 1 < steps; ++k) {
                 const int dd = (embed && k == nb64S - 1) ? ddTiles : 0;
@@ -757,8 +760,8 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     if (tailLaunch) {
         // the last workgroup of the launch runs the (independent) innovation-lift / group-update part
         rc = profiled(f, EQF_PROF_DOWNDATE, [&] {
-            if (small) hipLaunchKernelGGL((k_downdate<T, 32>), dim3(ddTiles + 1, B), dim3(256), 0, f->stream, a, nt32);
-            else hipLaunchKernelGGL((k_downdate<T, 64>), dim3(ddTiles + 1, B), dim3(256), 0, f->stream, a, nt64);
+            if (small) hipLaunchKernelGGL((k_downdate<T, 32>), dim3(ddTiles + 1, B), dim3(256), (downdateLdsBytes<T, 32>()), f->stream, a, nt32, 1);
+            else hipLaunchKernelGGL((k_downdate<T, 64>), dim3(ddTiles + 1, B), dim3(256), (downdateLdsBytes<T, 64>()), f->stream, a, nt64, 1);
         });
         if (rc) return rc;
     }

@@ -1025,17 +1025,20 @@ EQF_DI void downdateTile(const UpdArgs& a, int nt, int b, int tileIdx, T* lds) {
             }
 }
 
+// withFinish = 0: no innovation-lift workgroup (it ran in the E-chain's last launch).
 template <typename T, int TS>
-__global__ __launch_bounds__(256) void k_downdate(UpdArgs a, int nt) {
+__global__ __launch_bounds__(256) void k_downdate(UpdArgs a, int nt, int withFinish = 1) {
     const int b = blockIdx.y;
-    if (blockIdx.x == gridDim.x - 1) {
+    if (withFinish && blockIdx.x == gridDim.x - 1) {
         // the innovation lift / X <- Delta X / bias update is independent of the downdate: one extra workgroup of this
         // launch does it (saves a kernel boundary; both only need gamma and the reduced products)
         updateFinishBody(a, b, a.red + (long long)b * 256);
         return;
     }
-    __shared__ T sBuf[2 * 32 * (TS + 1)];
-    downdateTile<T, TS>(a, nt, b, (int)blockIdx.x, sBuf);
+    extern __shared__ __attribute__((aligned(16))) unsigned char sBufDd[];
+    downdateTile<T, TS>(a, nt, b, (int)blockIdx.x, reinterpret_cast<T*>(sBufDd));
 }
+template <typename T, int TS>
+constexpr int downdateLdsBytes() { return int(sizeof(T)) * 2 * 32 * (TS + 1); }
 
 }  // namespace eqf
