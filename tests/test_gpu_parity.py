@@ -2,7 +2,7 @@
 
 Tolerances (stated by BASELINE.json's north_star: Sigma within 1e-4 relative Frobenius, pose to an fp32-class
 tolerance): the default fp64 path is held to 1e-7 on Sigma and 1e-8 on the pose -- three orders tighter than
-required; the fp32 mode is held to its own documented bound ("fp32 mode").
+required; the fp32 mode is held to its own MEASURED bound (profiles/r02_fp32_study.txt).
 """
 import numpy as np
 import pytest
@@ -364,8 +364,10 @@ def test_trace_decreases_on_update(oracle_lib, hip):
 
 
 def test_fp32_mode_runs_and_is_bounded(oracle_lib, hip):
-    """EQF_PRECISION_F32 (Sigma stored / propagated / downdated in fp32, factorisations in fp64): not parity grade,
-    documented in DESIGN.md; here only its documented bound is enforced."""
+    """EQF_PRECISION_F32 (Sigma stored / propagated / downdated in fp32, factorisations in fp64): not parity grade.  Measured on
+    the MI355X at N = 200 over 10 s (profiles/r02_fp32_study.txt): worst relS 2.8e-2 -- 280x the north-star tolerance, and
+    neither fp32 storage with fp64 arithmetic (3.8e-3) nor hi+lo storage with a 3-product fp32 downdate (1.7e-2) meets it
+    either.  Here only the measured bound (with a margin) is enforced."""
     worst, _, _ = _drive(oracle_lib, hip, 25, 1.0, precision=1)
     assert worst["sigma"] < 5e-2, worst
     assert worst["pos"] < 5e-2, worst
