@@ -152,6 +152,125 @@ __device__ __forceinline__ void variantGrp(double (*T)[kSP], int base, int lane,
         for (int c = 0; c < kQB; ++c) T[lane][base + c] = (lane - base >= c) ? row[c] : 0.0;
     }
 }
+// MODE 7 (round 2, measured SLOWER: 4530 vs 3749 cycles): TWO waves, static column split.  Wave A (columns 0..7) runs the pivot chain of its columns and publishes every finished
+// pivot column through LDS (column, then a flag: LDS operations of one wave are performed in order); wave B (columns 8..15)
+// applies those eight pivots to its columns as they arrive -- off A's instruction stream -- and then runs the pivot chain of its
+// own columns.  The serial chain is unchanged (16 pivots); what leaves it is the issue-bound bulk of rank-1 updates.
+__device__ __forceinline__ void twoWaveA(double (*T)[kSP], double (*cb)[kSP], volatile int* flg, int tag, int base, int lane, int* bad) {
+    double row[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) row[c] = T[lane][base + c];
+    double ljPrev = 0.0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const double d = readlane64(row[c], base + c);
+        if (!(d > 0.0)) *bad = 1;
+        const double rd = rsqrtPivot(d);
+        if (c >= 1) {
+            double bc[8];
+#pragma unroll
+            for (int c2 = c + 1; c2 < 8; ++c2) bc[c2] = readlane64(ljPrev, base + c2);
+#pragma unroll
+            for (int c2 = c + 1; c2 < 8; ++c2) __asm__ volatile("" : "+s"(bc[c2]));
+#pragma unroll
+            for (int c2 = c + 1; c2 < 8; ++c2) row[c2] = fma(-ljPrev, bc[c2], row[c2]);
+        }
+        const double lj = row[c] * rd;
+        cb[c][lane] = lj;
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) flg[c] = tag;
+        if (c + 1 < 8) row[c + 1] = fma(-lj, readlane64(lj, base + c + 1), row[c + 1]);
+        row[c] = lj;
+        ljPrev = lj;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 8; ++c2) __asm__ volatile("" : "+v"(row[c2]));
+    }
+    if (lane >= base) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) T[lane][base + c] = (lane - base >= c) ? row[c] : 0.0;
+    }
+}
+__device__ __forceinline__ void twoWaveB(double (*T)[kSP], double (*cb)[kSP], volatile int* flg, int tag, int base, int lane, int* bad) {
+    double row[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) row[c] = T[lane][base + 8 + c];
+    // pivots 0..7 of wave A, as they arrive
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        while (flg[c] != tag) __builtin_amdgcn_s_sleep(0);
+        __asm__ volatile("" ::: "memory");
+        const double lj = cb[c][lane];
+        double bc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bc[k] = cb[c][base + 8 + k];  // uniform address: LDS broadcast
+#pragma unroll
+        for (int k = 0; k < 8; ++k) row[k] = fma(-lj, bc[k], row[k]);
+    }
+    // own pivot chain, columns 8..15
+    double ljPrev = 0.0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const double d = readlane64(row[c], base + 8 + c);
+        if (!(d > 0.0)) *bad = 1;
+        const double rd = rsqrtPivot(d);
+        if (c >= 1) {
+            double bc[8];
+#pragma unroll
+            for (int c2 = c + 1; c2 < 8; ++c2) bc[c2] = readlane64(ljPrev, base + 8 + c2);
+#pragma unroll
+            for (int c2 = c + 1; c2 < 8; ++c2) __asm__ volatile("" : "+s"(bc[c2]));
+#pragma unroll
+            for (int c2 = c + 1; c2 < 8; ++c2) row[c2] = fma(-ljPrev, bc[c2], row[c2]);
+        }
+        const double lj = row[c] * rd;
+        if (c + 1 < 8) row[c + 1] = fma(-lj, readlane64(lj, base + 8 + c + 1), row[c + 1]);
+        row[c] = lj;
+        ljPrev = lj;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 8; ++c2) __asm__ volatile("" : "+v"(row[c2]));
+    }
+    if (lane >= base) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) T[lane][base + 8 + c] = (lane - base >= 8 + c) ? row[c] : 0.0;
+    }
+}
+__global__ __launch_bounds__(256) void k_bench2(double* out, int reps) {
+    __shared__ double T[kSB][kSP];
+    __shared__ double T0[kSB][kSP];
+    __shared__ double cb[8][kSP];
+    __shared__ volatile int flg[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int e = tid; e < kSB * kSB; e += blockDim.x) {
+        const int r = e / kSB, c = e % kSB;
+        T0[r][c] = (r == c ? 40.0 : 0.0) + 1.0 / (1 + r + c);
+    }
+    if (tid < 16) flg[tid] = 0;
+    __syncthreads();
+    int bad = 0;
+    if (wv < 2) {
+        if (wv == 0) for (int c = 0; c < kSB; ++c) T[lane][c] = T0[lane][c];
+    }
+    __syncthreads();
+    long long t0 = __builtin_readcyclecounter();
+    if (wv == 0) twoWaveA(T, cb, flg, 1, 16, lane, &bad);
+    else if (wv == 1) twoWaveB(T, cb, flg, 1, 16, lane, &bad);
+    __syncthreads();
+    long long t1 = __builtin_readcyclecounter();
+    for (int i = 0; i < reps; ++i) {
+        if (wv == 0) for (int c = 0; c < kQB; ++c) T[lane][16 + c] = T0[lane][16 + c];
+        __syncthreads();
+        if (wv == 0) twoWaveA(T, cb, flg, 2 + i, 16, lane, &bad);
+        else if (wv == 1) twoWaveB(T, cb, flg, 2 + i, 16, lane, &bad);
+        __syncthreads();
+    }
+    long long t2 = __builtin_readcyclecounter();
+    if (tid == 0) {
+        out[0] = double(t1 - t0);
+        out[1] = double(t2 - t1) / reps;
+        out[2] = T[40][20] + bad;
+    }
+}
+
 template <int MODE>
 __device__ __forceinline__ void dispatch(double (*T)[kSP], double (*colS)[kQB + 2], int base, int lane, int* bad) {
     if (MODE == 4) variantLdl(T, base, lane, bad);
@@ -207,5 +326,12 @@ int main() {
     run<5>("hand-interleaved + sched_barrier", o);
     run<6>("grouped broadcasts", o);
     run<0>("readlane bulk again", o);
+    {
+        double h[3];
+        hipLaunchKernelGGL(k_bench2, dim3(1), dim3(256), 0, 0, o, 100);
+        hipMemcpy(h, o, 24, hipMemcpyDeviceToHost);
+        printf("%-28s cold %6.0f cycles   warm %6.0f cycles (%.2f us)   check %.9f   (incl. the copy + 2 barriers per repetition)\n",
+               "two waves, column split", h[0], h[1], h[1] / 2400.0, h[2]);
+    }
     return 0;
 }
