@@ -59,7 +59,7 @@ EXPORTED_SYMBOLS = [
     "eqf_stream_upload", "eqf_stream_imu", "eqf_stream_vision", "eqf_synchronize", "eqf_get_time", "eqf_num_landmarks",
     "eqf_get_ids", "eqf_get_state_estimate", "eqf_get_origin", "eqf_get_group", "eqf_get_bias", "eqf_get_sigma",
     "eqf_set_sigma", "eqf_set_state", "eqf_set_camera_offset", "eqf_get_integrator", "eqf_get_last_update", "eqf_debug_get_blocks", "eqf_device_error", "eqf_set_dense_propagate", "eqf_set_imu_burst", "eqf_profile_enable",
-    "eqf_profile_get", "eqf_profile_class_name", "eqf_version",
+    "eqf_profile_get", "eqf_profile_class_name", "eqf_version", "eqf_tile_propagate", "eqf_tile_downdate",
 ]
 
 
@@ -106,6 +106,10 @@ def lib():
         L.eqf_profile_class_name.argtypes = [C.c_int]
         L.eqf_profile_class_name.restype = C.c_char_p
         L.eqf_version.restype = C.c_char_p
+        vpp = C.c_void_p
+        L.eqf_tile_propagate.argtypes = [C.c_int, vpp, vpp, vpp, C.c_int, C.c_int, C.c_int, vpp, vpp, vpp, vpp, vpp, vpp, C.c_int, vpp, C.c_int,
+                                         vpp, vpp, _dp, C.c_double, C.c_double, C.c_int]
+        L.eqf_tile_downdate.argtypes = [C.c_int, vpp, vpp, C.c_int, C.c_int, C.c_int, vpp, C.c_int, vpp, C.c_int, C.c_int]
         _lib = L
     return _lib
 

@@ -27,19 +27,66 @@ Update (VIOFilter.cpp:264-297) in the Cholesky form the single-GPU path uses (cs
 bundleLift's weights (EqFMatrices.cpp:239, Sigma_e = Sigma[6:, 6:]) come from the same distributed solver after the five base
 coordinates of Sigma_e have been eliminated locally (a Schur complement every rank can form from the replicated panel).
 
-Status: design + exchange schedule + tile-local mathematics in torch (rocBLAS fp64 on the GPU box); validated on CPU with gloo
-against the single-process fp64 reference filter (tests/test_tiled.py).  The hand-written tile kernels (the tile-local forms of k_riccati_stream
-/ k_chol_step64 / downdateTile behind eqf_tile_* entry points) and a measured 8-GPU run are the next step -- no 8-GPU node has
-been available to this build.
+Status: design + exchange schedule validated on CPU with gloo against the single-process fp64 reference filter
+(tests/test_tiled.py, tile-local mathematics in torch).  On a GPU the two operations that touch every tile every step -- the
+Riccati step and the downdate -- run in hand-written tile kernels behind the C ABI (eqf_tile_propagate, eqf_tile_downdate:
+csrc/eqf_tile.hpp, called on the torch tensors' device pointers; ProcessGrid(..., kernels=TileKernels(dev))), checked on the
+MI355X against the torch path (tests/test_gpu_tiled.py); the panel operations of the distributed Cholesky (potrf / trsm of
+2bl x 2bl blocks) are still torch (rocBLAS / rocSOLVER).  A measured 8-GPU run is outstanding: no 8-GPU node has been available
+to this build.
 """
+import ctypes
+
 import torch
+
+
+class TileKernels:
+    """The tile kernels of csrc/eqf_tile.hpp through the C ABI, on torch CUDA tensors (their device pointers) and torch's
+    current stream, so that they order with the torch operations around them."""
+
+    def __init__(self, device_index=0):
+        from . import binding
+
+        self.lib = binding.lib()
+        self.dev = int(device_index)
+        self._dp = ctypes.POINTER(ctypes.c_double)
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    @staticmethod
+    def _p(t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    def propagate(self, inp, nI, nJ, D_I, L_I, D_J, L_J, Sbb, SbI, ldbI, SbJ, ldbJ, BnI, BnJ, R6, T, diag_noise, is_diag):
+        out = torch.empty_like(inp)
+        r6 = (ctypes.c_double * 6)(*[float(x) for x in R6])
+        rc = self.lib.eqf_tile_propagate(self.dev, self._stream(), self._p(out), self._p(inp), inp.stride(0), nI, nJ, self._p(D_I), self._p(L_I),
+                                         self._p(D_J), self._p(L_J), self._p(Sbb), self._p(SbI), ldbI, self._p(SbJ), ldbJ, self._p(BnI),
+                                         self._p(BnJ), ctypes.cast(r6, self._dp), float(T), float(diag_noise), int(is_diag))
+        if rc:
+            raise RuntimeError(f"eqf_tile_propagate failed with status {rc}")
+        return out
+
+    def downdate(self, C, A, B):
+        """C -= A^T B in place (C m x n, A k x m, B k x n; row-major, unit column stride)."""
+        if A.stride(1) != 1:
+            A = A.contiguous()  # (LAPACK-backed torch solves hand back column-major strides)
+        if B.stride(1) != 1:
+            B = B.contiguous()
+        assert C.stride(1) == 1
+        rc = self.lib.eqf_tile_downdate(self.dev, self._stream(), self._p(C), C.stride(0), C.shape[0], C.shape[1], self._p(A), A.stride(0),
+                                        self._p(B), B.stride(0), A.shape[0])
+        if rc:
+            raise RuntimeError(f"eqf_tile_downdate failed with status {rc}")
 
 
 class ProcessGrid:
     """Pr x Pc process grid over a torch.distributed group; tile (I, J) -> rank (I mod Pr) * Pc + (J mod Pc)."""
 
-    def __init__(self, dist, Pr, Pc, device="cpu"):
+    def __init__(self, dist, Pr, Pc, device="cpu", kernels=None):
         self.dist, self.Pr, self.Pc = dist, Pr, Pc
+        self.kernels = kernels  # TileKernels (GPU) or None (tile mathematics in torch)
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
         assert self.world == Pr * Pc
@@ -139,7 +186,14 @@ def propagate(ts, Fbb, L, D, Qbb, Bn, Rdiag, T, point_var):
     BR = Bn * Rdiag  # (n x 6) columns scaled
     Sbb, Sb = ts.Sbb, ts.Sb
     new = {}
-    for (I, J), S_IJ in ts.t.items():
+    kern = ts.g.kernels
+    if kern is not None:
+        Dc, Lc, Bc, Sbbc, Sbc = D.contiguous(), L.contiguous(), Bn.contiguous(), Sbb.contiguous(), Sb.contiguous()
+        for (I, J), S_IJ in ts.t.items():
+            new[(I, J)] = kern.propagate(S_IJ.contiguous(), bl, bl, Dc[I * bl:], Lc[I * w:], Dc[J * bl:], Lc[J * w:], Sbbc, Sbc[:, I * w:],
+                                         Sbc.stride(0), Sbc[:, J * w:], Sbc.stride(0), Bc[11 + I * w:], Bc[11 + J * w:], Rdiag.tolist(), T,
+                                         T * point_var, I == J)
+    for (I, J), S_IJ in ([] if kern is not None else ts.t.items()):
         SIb = Sb[:, ts.cols(I)].T  # Sigma_Ib = Sigma_bI^T
         G_I = Lr[I] @ Sbb + Dm[I] @ SIb
         Q_IJ = T * (BR[11 + I * w:11 + (I + 1) * w] @ Bn[11 + J * w:11 + (J + 1) * w].T)
@@ -234,7 +288,10 @@ def update(ts, C, delta, meas_var):
             gamma[11 + J * w:11 + (J + 1) * w] += Yw[J].T @ z
             Sb_dd[:, ts.cols(J)] += Yb.T @ Yw[J]
         for (I, J) in ts.t:
-            ts.t[(I, J)] -= Yw[I].T @ Yw[J]
+            if g.kernels is not None:
+                g.kernels.downdate(ts.t[(I, J)], Yw[I], Yw[J])
+            else:
+                ts.t[(I, J)] -= Yw[I].T @ Yw[J]
 
     dist_chol_solve(g, nb, A, Wt, Wn, bs, w, on_row)
     ts.Sb = ts.Sb - Sb_dd

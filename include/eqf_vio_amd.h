@@ -183,6 +183,26 @@ int eqf_profile_enable(eqf_filter* f, int on);
 int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_ms);
 const char* eqf_profile_class_name(int cls);
 
+/* ---- Tile-local kernels for Sigma 2-D block-partitioned over a process grid (BASELINE configs[4]: N = 4000 over 8 GPUs).
+ * They work on CALLER-OWNED device memory (plain device pointers, e.g. torch tensors) of HIP device `device`, enqueue on
+ * `stream` (a hipStream_t, NULL = the default stream) and return without synchronising.  The exchange schedule above them
+ * (which rank owns which tile, the RCCL all-gathers of the panels) is eqf_vio_amd/tiled.py.  fp64.
+ *
+ * eqf_tile_propagate: one structured Riccati step of the (3 nI x 3 nJ) tile (I, J) of the landmark-landmark part of Sigma
+ * (VIOFilter.cpp:188-189 with F = I + T A_b = [[F_bb, 0], [L, D]]):
+ *     out = (D_I in + L_I Sigma_bJ) D_J^T + (L_I Sigma_bb + D_I Sigma_Ib) L_J^T + T (B_I R B_J^T) [+ diag_noise I on a diagonal tile]
+ *   D_I [nI][9] / D_J [nJ][9]: the 3x3 diagonal blocks of F; L_I [3 nI][11] / L_J: the rows of F below the base block;
+ *   Sbb [11][11]; SbI [11][ldbI], SbJ [11][ldbJ]: the base panel columns of the row / column landmarks (Sigma_Ib = SbI^T);
+ *   BnI [3 nI][6], BnJ: rows of the input matrix B (EqFMatrices.cpp:346-382); R[6] = diag(velOmega x3, velAccel x3);
+ *   diag_noise = T * pointProcessVariance, is_diag = 1 for tiles with I == J.  in / out: row-major, leading dimension ld.
+ * eqf_tile_downdate: C (m x n, ldc) -= A^T B for A (k x m, lda), B (k x n, ldb): the tile's share of Sigma - K C Sigma =
+ * Sigma - Y^T Y (VIOFilter.cpp:297) from solved block rows Y. */
+int eqf_tile_propagate(int device, void* stream, double* out, const double* in, int ld, int nI, int nJ, const double* D_I,
+    const double* L_I, const double* D_J, const double* L_J, const double* Sbb, const double* SbI, int ldbI, const double* SbJ,
+    int ldbJ, const double* BnI, const double* BnJ, const double* R6, double T, double diag_noise, int is_diag);
+int eqf_tile_downdate(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb,
+    int k);
+
 const char* eqf_version(void);
 
 #ifdef __cplusplus
