@@ -146,6 +146,8 @@ struct eqf_filter {
     int updateEpoch = 0;           // one per launchUpdate
     // k_chol_resident (one launch per update while the grid fits the chip): EQF_CHOL_RESIDENT = 0 switches it off
     int cholResident = 1;
+    int cholOrder = -1;            // order of the workgroup classes in an update launch, -1 = by launch size (EQF_CHOL_ORDER = 0 | 1 | 2)
+    int cholStreams = 0;           // stream workgroups per filter of an update launch, 0 = by launch size (EQF_CHOL_STREAMS)
     int numCUs = 0;
     int nbCap = 0, wtCap = 0;
     int *dReadyA = nullptr, *dReadyY = nullptr, *dResCounters = nullptr;
@@ -456,10 +458,11 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     // 16 per workgroup (four panel waves, full lanes) otherwise
     const int lm = f->burstLm ? f->burstLm : ((long long)((nmx + 3) / 4) * f->B <= 256 ? 4 : 16);
     const dim3 bgrid(std::max(1, (nmx + lm - 1) / lm), f->B);
-    // rows per wavefront of the block kernel: one while the launch cannot fill the chip anyway (latency), more once the
-    // column constants of a lane are worth sharing between several of its blocks
+    // rows per wavefront of the block kernel: one while the launch cannot fill the chip anyway (latency), four once the
+    // column constants of a lane are worth sharing between several of its blocks.  (Two rows: 286 VGPRs, one wave per SIMD
+    // like four rows but half their reuse -- measured slower than both at every size, N = 200 x 2..64 filters, N = 400..4000.)
     const long long waves1 = (long long)((nmx + 63) / 64) * nmx * f->B;
-    const int R = f->burstRows ? f->burstRows : (waves1 <= 4096 ? 1 : (waves1 <= 32768 ? 2 : 4));
+    const int R = f->burstRows ? f->burstRows : (waves1 <= 2800 ? 1 : 4);
     const dim3 rgrid((nmx + 63) / 64, (nmx + 4 * R - 1) / (4 * R), f->B);
     // every filter past its lazy initialisation (VIOFilter.cpp:122-124): the schedule with the precomputed step halves
     const bool fast = allDevInit(f);
@@ -674,7 +677,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         if (embed && f->cholResident && f->cholSplit <= 0 && f->dReadyA) {
             rc = buildRoles(f, Nmax);
             if (rc) return rc;
-            resident = (long long)f->rolesCount * B <= f->numCUs;
+            resident = f->cholResident >= 2 || (long long)f->rolesCount * B <= f->numCUs;
         }
         if (resident) {
             ResArgs ra{};
@@ -707,9 +710,17 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             for (int k = 0; k + 1 < steps; ++k) {
                 const int dd = (embed && k == nb64S - 1) ? ddTiles : 0;
                 if (dd) ddDone = true;
+                // workgroups per filter: 2 diagonal + the tails of block column k+1 + nStream streams over the pure updates
+                // (about two per CU over the whole launch) + the downdate tiles; see step3Counts
+                int tS, uS, tE, uE;
+                step3Counts(cS.nbMax, cS.wtMax, k, &tS, &uS);
+                step3Counts(cE.nbMax, cE.wtMax, k, &tE, &uE);
+                const int nStream = f->cholStreams > 0 ? std::min(f->cholStreams, std::max(uS + uE, 1))
+                                                       : std::min(uS + uE, std::max(1, (2 * f->numCUs + B - 1) / B));
+                const int tailsLast = f->cholOrder >= 0 ? f->cholOrder : 1;
                 rc = profiled(f, dd ? EQF_PROF_CHOL_DD : EQF_PROF_CHOL_STEP, [&] {
-                    hipLaunchKernelGGL((k_chol_step64<T, 3>), dim3(blocks(k, 3) + dd, B), dim3(256), kLdsTailBytes, f->stream, cS, cE, a, k,
-                        dd ? ddNt : 0, small ? 1 : 0, embed ? 1 : 0, f->errflag);
+                    hipLaunchKernelGGL((k_chol_step64<T, 3>), dim3(2 + tS + tE + nStream + dd, B), dim3(256), kLdsTailBytes, f->stream, cS, cE, a,
+                        k, dd ? ddNt : 0, small ? 1 : 0, embed ? 1 : 0, f->errflag, nStream, tailsLast);
                 }, k);
                 if (rc) return rc;
             }
@@ -1249,6 +1260,8 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (const char* e = std::getenv("EQF_CHOL_SPLIT")) f->cholSplit = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_TAIL")) f->cholTail = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_RESIDENT")) f->cholResident = std::atoi(e);
+    if (const char* e = std::getenv("EQF_CHOL_ORDER")) f->cholOrder = std::atoi(e);
+    if (const char* e = std::getenv("EQF_CHOL_STREAMS")) f->cholStreams = std::max(0, std::atoi(e));
     {
         hipDeviceProp_t prop;
         if (!rc && hipGetDeviceProperties(&prop, device) != hipSuccess) rc = EQF_ERR_HIP;

@@ -493,6 +493,180 @@ __global__ __launch_bounds__(256) void k_factor_first64(ChainArgs c0, ChainArgs 
 //          launch for the diagonal workgroup to publish D[K+1] (eqf_handoff.hpp: write-through record + epoch flag, 2.6 us
 //          for the 40 KB record), then solve in place.  Only those (nb - K - 2 + wt) workgroups per chain wait, and the
 //          diagonal workgroup they wait for has the lowest block index of its filter's chain, so it is dispatched first.
+// ---- PHASE 3 (update + solve of block column K+1 in one launch): how a launch's workgroups are laid out.
+// Per filter and chain with rem = nbMax - K - 1 block rows left and m = rem - 1:
+//   1 diagonal workgroup  (tile (K+1, K+1): update, factor, publish D[K+1])
+//   m + wt tails          (tiles (R, K+1), R > K+1, and the rhs tiles of block row K+1: update, wait for D[K+1], solve)
+//   m (m + 1) / 2 + wt m  pure updates -- NOT one workgroup each: nStream workgroups per filter walk the list with the
+//                         operands of the next tile in flight while the matrix cores work on the current one.
+// A pure update is 128 KB of traffic for 1.7 us of matrix-core time; as one workgroup per tile (load everything, then
+// compute, then store, two workgroups per CU) a tile cost 8.4 CU-microseconds -- a batch of 64 filters ran its chain
+// launches at 19 % of the fp64 MFMA rate whether its data sat in HBM or in the MALL.
+__host__ __device__ inline void step3Counts(int nbMax, int wtMax, int K, int* nTail, int* nUpd) {
+    const int rem = nbMax - K - 1, m = rem > 1 ? rem - 1 : 0;
+    *nTail = rem >= 1 ? m + wtMax : 0;
+    *nUpd = m * (m + 1) / 2 + wtMax * m;
+}
+
+// Element x of a workgroup class that starts at linear workgroup index o (per filters of `per` workgroups each) -> filter b and
+// index i within the filter, such that all workgroups of a filter share (o + x) % 8: observed, for speed only, workgroup L of a
+// launch runs on XCD L % 8 -- a filter's panel blocks (and, in the downdate, its Y) are then fetched into ONE 4 MB L2 and
+// reused there instead of crossing the fabric once per tile.  Any placement is correct.
+EQF_DI void xcdSplit(long long o, long long x, int per, int Bn, int* b, int* i) {
+    if ((Bn & 7) == 0) {
+        const int r = int((o + x) & 7);
+        const long long q = x >> 3;
+        *b = r + 8 * int(q / per);
+        *i = int(q % per);
+    } else {
+        *b = int(x / per);
+        *i = int(x % per);
+    }
+}
+
+struct StreamTile {
+    double* Ct;
+    const double* Pg;
+    const double* Qg;
+    int ldcp, ldq;  // leading dimension of Ct and Pg (the same matrix family), of Qg
+    int isW;
+};
+
+// update tiles first, first + stride, ... of filter b in launch K (see step3Counts); 256 threads, LDS: s.P, s.Q
+EQF_DI void streamUpdates64(const ChainArgs& c0, const ChainArgs& c1, int b, int K, int first, int stride, const Lds64& s) {
+    const Glob& g = c0.g[b];
+    if (!g.updateOk || g.N == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int nbS, wtS, nbE, wtE;
+    chainDims64(c0, g.N, &nbS, &wtS);
+    chainDims64(c1, g.N, &nbE, &wtE);
+    const int mS = max(c0.nbMax - K - 2, 0), mE = max(c1.nbMax - K - 2, 0);
+    const int nAS = mS * (mS + 1) / 2, nS = nAS + c0.wtMax * mS, nAE = mE * (mE + 1) / 2, total = nS + nAE + c1.wtMax * mE;
+    // (field-by-field selects: a reference picked between the two argument structs at run time makes the compiler copy both to
+    // scratch memory)
+    double* const AS = c0.A + (long long)b * c0.strideA;
+    double* const AE = c1.A + (long long)b * c1.strideA;
+    double* const WS = c0.W + (long long)b * c0.strideW;
+    double* const WE = c1.W + (long long)b * c1.strideW;
+    const double* const YS = c0.WO + (long long)b * c0.strideW;
+    const double* const YE = c1.WO + (long long)b * c1.strideW;
+    const int ldAS = c0.ldA, ldAE = c1.ldA, ldWS = c0.ldW, ldWE = c1.ldW;
+    auto decode = [&](int u, StreamTile& t) -> bool {
+        const bool second = u >= nS;
+        const int nb = second ? nbE : nbS, wt = second ? wtE : wtS, m = second ? mE : mS, nA = second ? nAE : nAS;
+        int v = second ? u - nS : u;
+        double* A = second ? AE : AS;
+        const int ldA = second ? ldAE : ldAS, ldW = second ? ldWE : ldWS;
+        const bool isA = v < nA;
+        // A tile (R, C) of the lower triangle, R, C >= K + 2  |  rhs tile: column tile tt of block row C
+        int R = 0, C = 0, tt = 0;
+        if (isA) {
+            int r = 0;
+            while (v >= r + 1) {
+                v -= r + 1;
+                ++r;
+            }
+            R = K + 2 + r;
+            C = K + 2 + v;
+        } else {
+            v -= nA;
+            tt = v / max(m, 1);
+            C = K + 2 + v % max(m, 1);
+        }
+        // (every field assigned once, from values: fields written in the two arms of a branch end up in scratch memory)
+        const int ldcp = isA ? ldA : ldW;
+        double* Cb = isA ? A : (second ? WE : WS);
+        const double* Pb = isA ? A : (second ? YE : YS);
+        t.Ct = Cb + (long long)((isA ? R : C) * kSB) * ldcp + (isA ? C : tt) * kSB;
+        t.Pg = Pb + (long long)((isA ? R : K) * kSB) * ldcp + (isA ? K : tt) * kSB;  // (R == C: the same block as Qg, read twice)
+        t.Qg = A + (long long)(C * kSB) * ldA + K * kSB;
+        t.ldcp = ldcp;
+        t.ldq = ldA;
+        t.isW = isA ? 0 : 1;
+        return isA ? R < nb : (tt < wt && C < nb);
+    };
+    // a contiguous chunk of the list per workgroup: consecutive tiles share their P operand (A tiles of one block row: L_RK;
+    // rhs tiles of one column tile: Y_Kt), which then stays in LDS
+    const int chunk = (total + stride - 1) / stride, uEnd = min(total, (first + 1) * chunk);
+    StreamTile cur, nxt;
+    int u = first * chunk;
+    bool have = false;
+    while (u < uEnd && !(have = decode(u, nxt))) ++u;
+    if (!have) return;
+    // operands as 16-byte pairs: thread -> rows (tid >> 5) + 8 q, columns 2 (tid & 31), 2 (tid & 31) + 1
+    const int pr = tid >> 5, pc = 2 * (tid & 31);
+    f64x4 nAcc[4];
+    f64x2 nP[8], nQ[8];
+    auto issue = [&](const StreamTile& t, bool withP) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) nQ[q] = *reinterpret_cast<const f64x2*>(t.Qg + (long long)(pr + 8 * q) * t.ldq + pc);
+        if (withP) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) nP[q] = *reinterpret_cast<const f64x2*>(t.Pg + (long long)(pr + 8 * q) * t.ldcp + pc);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nAcc[i][q] = t.Ct[(long long)(kQB * wv + (lane >> 4) + 4 * q) * t.ldcp + kQB * i + (lane & 15)];
+    };
+    issue(nxt, true);
+    bool newP = true;  // the tile in flight brings its own P block (otherwise the one in LDS is its P too)
+    // Order inside an iteration: [operands of tile i -> LDS] [result of tile i-1 -> memory] [fetch of tile i+1] [arithmetic of
+    // tile i].  The wait counter retires in order: with the stores issued BEFORE the next fetch, waiting for that fetch at the
+    // top of the next iteration only has stores in front of it that are a whole tile's arithmetic old.
+    f64x4 res[4];
+    double* resPtr = nullptr;
+    int resLd = 0;
+    for (;;) {
+        cur = nxt;
+        f64x4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            s.Q[pr + 8 * q][pc] = nQ[q][0];
+            s.Q[pr + 8 * q][pc + 1] = nQ[q][1];
+        }
+        if (newP) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                s.P[pr + 8 * q][pc] = nP[q][0];
+                s.P[pr + 8 * q][pc + 1] = nP[q][1];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = nAcc[i];
+        __syncthreads();
+        if (resPtr) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) resPtr[(long long)(kQB * wv + (lane >> 4) + 4 * q) * resLd + kQB * i + (lane & 15)] = res[i][q];
+        }
+        ++u;
+        have = false;
+        while (u < uEnd && !(have = decode(u, nxt))) ++u;
+        newP = have && nxt.Pg != cur.Pg;
+        if (have) issue(nxt, newP);
+        __builtin_amdgcn_sched_barrier(0);  // (the next tile's loads stay ahead of this tile's arithmetic)
+        if (cur.isW) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = mmTile<false, kSB>(acc[i], &s.Q[0][0], kSP, kQB * wv, &s.P[0][0], kSP, kQB * i, lane, -1.0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = mmTile<true, kSB>(acc[i], &s.P[0][0], kSP, kQB * wv, &s.Q[0][0], kSP, kQB * i, lane, -1.0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) res[i] = acc[i];
+        resPtr = cur.Ct;
+        resLd = cur.ldcp;
+        if (!have) break;
+        __syncthreads();  // every wave is done with s.P / s.Q
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) resPtr[(long long)(kQB * wv + (lane >> 4) + 4 * q) * resLd + kQB * i + (lane & 15)] = res[i][q];
+}
+
 #ifdef EQF_CHOL_WG_STAMPS
 __device__ long long g_cholWg[16][256][2];  // [launch K][workgroup]: first / last cycle
 __device__ int g_cholWgInfo[16][256][4];    // second chain?, isW, R, C
@@ -509,55 +683,136 @@ struct CholWgStamp {
 #endif
 template <typename T, int PHASE>
 __global__ __launch_bounds__(256, (PHASE == 2 || PHASE == 3) ? 2 : 1) void k_chol_step64(ChainArgs c0, ChainArgs c1, UpdArgs a, int K, int ddNt, int ddSmall,
-    int embedFinish, int* errflag) {
+    int embedFinish, int* errflag, int nStream = 0, int tailsLast = 0) {
 #ifdef EQF_CHOL_WG_STAMPS
     CholWgStamp wgStamp(K);
 #endif
-    const int b = blockIdx.y;
-    const int n0 = chainBlocks64(c0.nbMax, c0.wtMax, K, PHASE);
+    int b = blockIdx.y;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
-    {
+    bool second = false, isW = false;
+    int R = 0, C = 0;  // A tile (R,C) or rhs tile (t = R, C)
+    if (PHASE == 3) {
+        // dispatch order = linear workgroup index: [diagonal workgroups of every filter | tails | streams | downdate tiles]
+        // tailsLast = 0: as written; 1: streams before tails; 2: filter-major, see below
+        const int Bn = gridDim.y;
+        long long x = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+        int tS, uS, tE, uE;
+        step3Counts(c0.nbMax, c0.wtMax, K, &tS, &uS);
+        step3Counts(c1.nbMax, c1.wtMax, K, &tE, &uE);
+        const int nT = tS + tE;
+        const long long nDiag = 2LL * Bn, nTail = (long long)nT * Bn, nStr = (long long)nStream * Bn;
+        int cls = 0;  // 0 diagonal, 1 tail, 2 stream, 3 downdate
+        int bx = 0;   // filter, classes 1 and 2
+        if (x >= nDiag) {
+            x -= nDiag;
+            if (tailsLast == 2) {
+                // filter-major: [streams of filter 0 | tails of filter 0 | streams of filter 1 | ...] -- the latency-bound tails of one
+                // filter share the chip with the bandwidth-bound streams of its neighbours, and all but the first few filters' tails
+                // find D[K+1] published when they start
+                const int per = nStream + nT;
+                if (x < (long long)per * Bn) {
+                    bx = int(x / per);
+                    x %= per;
+                    if (x < nStream) cls = 2;
+                    else { x -= nStream; cls = 1; }
+                } else { x -= (long long)per * Bn; cls = 3; }
+            } else {
+                const long long nFirst = tailsLast ? nStr : nTail, nSecond = tailsLast ? nTail : nStr;
+                long long o = nDiag;
+                if (x < nFirst) cls = tailsLast ? 2 : 1;
+                else if (x - nFirst < nSecond) { x -= nFirst; o += nFirst; cls = tailsLast ? 1 : 2; }
+                else { x -= nFirst + nSecond; o += nFirst + nSecond; cls = 3; }
+                int ix = 0;
+                if (cls == 1) xcdSplit(o, x, max(nT, 1), Bn, &bx, &ix);
+                if (cls == 2) xcdSplit(o, x, max(nStream, 1), Bn, &bx, &ix);
+                if (cls == 3) {
+                    const int ddTiles = ddNt * (ddNt + 1) / 2;
+                    if (ddTiles == 0) return;
+                    xcdSplit(o, x, ddTiles, Bn, &bx, &ix);
+                    if (bx >= Bn) return;
+                    if (ddSmall) downdateTile<T, 32>(a, ddNt, bx, ix, reinterpret_cast<T*>(smem64));
+                    else downdateTile<T, 64>(a, ddNt, bx, ix, reinterpret_cast<T*>(smem64));
+                    return;
+                }
+                x = ix;
+            }
+        }
+        if (cls == 3) {
+            const int ddTiles = ddNt * (ddNt + 1) / 2;
+            if (ddTiles == 0) return;
+            b = int(x / ddTiles);
+            if (b >= Bn) return;
+            if (ddSmall) downdateTile<T, 32>(a, ddNt, b, int(x % ddTiles), reinterpret_cast<T*>(smem64));
+            else downdateTile<T, 64>(a, ddNt, b, int(x % ddTiles), reinterpret_cast<T*>(smem64));
+            return;
+        }
+        if (cls == 2) {
+            streamUpdates64(c0, c1, bx, K, int(x), nStream, ldsTail(smem64));
+            return;
+        }
+        if (cls == 0) {
+            b = int(x >> 1);
+            second = (x & 1) != 0;
+            R = C = K + 1;
+        } else {
+            b = bx;
+            int i = int(x);
+            second = i >= tS;
+            if (second) i -= tS;
+            const int m = max(pickValue(second, c0.nbMax, c1.nbMax) - K - 2, 0);
+            C = K + 1;
+            if (i < m) R = K + 2 + i;
+            else {
+                isW = true;
+                R = i - m;
+            }
+        }
+    } else {
+        const int n0 = chainBlocks64(c0.nbMax, c0.wtMax, K, PHASE);
         const int nChain = n0 + chainBlocks64(c1.nbMax, c1.wtMax, K, PHASE);
         if ((int)blockIdx.x >= nChain) {  // covariance downdate tile
             if (ddSmall) downdateTile<T, 32>(a, ddNt, b, (int)blockIdx.x - nChain, reinterpret_cast<T*>(smem64));
             else downdateTile<T, 64>(a, ddNt, b, (int)blockIdx.x - nChain, reinterpret_cast<T*>(smem64));
             return;
         }
+        second = (int)blockIdx.x >= n0;
     }
-    const bool second = (int)blockIdx.x >= n0;
-    const ChainArgs& ch = second ? c1 : c0;
-    int idx = second ? (int)blockIdx.x - n0 : (int)blockIdx.x;
+    const ChainArgs ch = pickChain(second, c0, c1);
     const Glob& g = ch.g[b];
     if (!g.updateOk || g.N == 0) return;
     int nb, wt;
     chainDims64(ch, g.N, &nb, &wt);
     if (K >= nb) return;
-    bool isW = false;
-    int R, C;  // A tile (R,C) or rhs tile (t = R, C)
     const int rem = ch.nbMax - K - 1;
     if (rem < 0) return;
-    if (PHASE == 1) {
-        if (idx < rem) {  // panel launch: the blocks (R, K) below the diagonal
-            R = K + 1 + idx;
-            C = K;
-            if (R >= nb) return;
-        } else {
-            isW = true;
-            R = idx - rem;
-            C = K;
-            if (R >= wt) return;
-        }
-    } else if (idx < rem * rem) {
-        R = K + 1 + idx / rem;
-        C = K + 1 + idx % rem;
-        if (R >= nb || C > R) return;
+    if (PHASE == 3) {
+        if (rem < 1) return;
+        if (isW ? (R >= wt || C >= nb) : (R >= nb)) return;
     } else {
-        idx -= rem * rem;
-        isW = true;
-        const int cols = PHASE == 0 ? rem + 1 : rem;  // block rows of the right-hand sides still in play
-        R = idx / cols;
-        C = (PHASE == 0 ? K : K + 1) + idx % cols;
-        if (R >= wt || C >= nb) return;
+        int idx = second ? (int)blockIdx.x - chainBlocks64(c0.nbMax, c0.wtMax, K, PHASE) : (int)blockIdx.x;
+        if (PHASE == 1) {
+            if (idx < rem) {  // panel launch: the blocks (R, K) below the diagonal
+                R = K + 1 + idx;
+                C = K;
+                if (R >= nb) return;
+            } else {
+                isW = true;
+                R = idx - rem;
+                C = K;
+                if (R >= wt) return;
+            }
+        } else if (idx < rem * rem) {
+            R = K + 1 + idx / rem;
+            C = K + 1 + idx % rem;
+            if (R >= nb || C > R) return;
+        } else {
+            idx -= rem * rem;
+            isW = true;
+            const int cols = PHASE == 0 ? rem + 1 : rem;  // block rows of the right-hand sides still in play
+            R = idx / cols;
+            C = (PHASE == 0 ? K : K + 1) + idx % cols;
+            if (R >= wt || C >= nb) return;
+        }
     }
     double* A = ch.A + (long long)b * ch.strideA;
     double* D = ch.D + (long long)b * ch.strideD;

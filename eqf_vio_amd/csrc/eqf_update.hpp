@@ -28,6 +28,7 @@
 namespace eqf {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ inline int roundUp(int x, int m) { return (x + m - 1) / m * m; }
@@ -469,6 +470,34 @@ struct ChainArgs {
     long long strideF;
     int epoch;
 };
+
+// One of two argument blocks by a run-time flag, FIELD BY FIELD on values.  (`second ? c1 : c0` on the structs -- or on a member
+// of them, an lvalue -- is compiled as a select between two ADDRESSES: both structs are copied to scratch memory at kernel
+// entry and every later use is a scratch load.)
+template <typename V>
+EQF_DI V pickValue(bool second, V v0, V v1) {
+    return second ? v1 : v0;
+}
+EQF_DI ChainArgs pickChain(bool second, const ChainArgs& c0, const ChainArgs& c1) {
+    ChainArgs ch;
+    ch.g = pickValue(second, c0.g, c1.g);
+    ch.A = pickValue(second, c0.A, c1.A);
+    ch.D = pickValue(second, c0.D, c1.D);
+    ch.W = pickValue(second, c0.W, c1.W);
+    ch.WO = pickValue(second, c0.WO, c1.WO);
+    ch.ldA = pickValue(second, c0.ldA, c1.ldA);
+    ch.ldW = pickValue(second, c0.ldW, c1.ldW);
+    ch.strideA = pickValue(second, c0.strideA, c1.strideA);
+    ch.strideD = pickValue(second, c0.strideD, c1.strideD);
+    ch.strideW = pickValue(second, c0.strideW, c1.strideW);
+    ch.kind = pickValue(second, c0.kind, c1.kind);
+    ch.nbMax = pickValue(second, c0.nbMax, c1.nbMax);
+    ch.wtMax = pickValue(second, c0.wtMax, c1.wtMax);
+    ch.flags = pickValue(second, c0.flags, c1.flags);
+    ch.strideF = pickValue(second, c0.strideF, c1.strideF);
+    ch.epoch = pickValue(second, c0.epoch, c1.epoch);
+    return ch;
+}
 
 // per-filter chain sizes
 EQF_DI void chainDims(const ChainArgs& ch, int N, int* nb, int* wt) {
@@ -1010,6 +1039,11 @@ EQF_DI void downdateTile(const UpdArgs& a, int nt, int b, int tileIdx, T* lds) {
                 for (int v = 0; v < WM; ++v) acc[u][v] = MF::mfma(av[u], bv[v], acc[u][v]);
         }
     }
+    // ---- epilogue.  Every read of Sigma_in is issued before the first write of Sigma_out (a load the compiler cannot prove
+    // independent of the previous store waits for that store's acknowledgement: 32 dependent round trips per thread), and
+    // the mirror tile goes through LDS so that its rows are read and written as rows (512 contiguous bytes per wavefront
+    // instead of 64 lines).
+    T sv[WM][WM][4];
 #pragma unroll
     for (int u = 0; u < WM; ++u)
 #pragma unroll
@@ -1018,11 +1052,44 @@ EQF_DI void downdateTile(const UpdArgs& a, int nt, int b, int tileIdx, T* lds) {
             for (int q = 0; q < 4; ++q) {
                 const int R = I0 + 16 * WM * qi + 16 * u + MF::row(lane, q);
                 const int Cc = J0 + 16 * WM * qj + 16 * v + lr;
-                if (R < nv && Cc < nv) {
-                    Sout[(long long)R * ld + Cc] = Sin[(long long)R * ld + Cc] - acc[u][v][q];
-                    if (ti != tj) Sout[(long long)Cc * ld + R] = Sin[(long long)Cc * ld + R] - acc[u][v][q];
-                }
+                sv[u][v][q] = (R < nv && Cc < nv) ? Sin[(long long)R * ld + Cc] : (T)0;
             }
+    constexpr int MT = TS * TS / 256;  // mirror-tile elements per thread
+    T mv[MT];
+    if (ti != tj) {
+#pragma unroll
+        for (int w = 0; w < MT; ++w) {
+            const int e = tid + 256 * w, mr = J0 + e / TS, mc = I0 + e % TS;  // mirror element (row in J, column in I)
+            mv[w] = (mr < nv && mc < nv) ? Sin[(long long)mr * ld + mc] : (T)0;
+        }
+        __syncthreads();  // (the last chunk's operands have been read)
+        T (*sM)[TS + 1] = reinterpret_cast<T (*)[TS + 1]>(lds);  // sM[c][r] = acc(r, c)   (TS x (TS + 1) <= 2 * KC * (TS + 1))
+#pragma unroll
+        for (int u = 0; u < WM; ++u)
+#pragma unroll
+            for (int v = 0; v < WM; ++v)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sM[16 * WM * qj + 16 * v + lr][16 * WM * qi + 16 * u + MF::row(lane, q)] = acc[u][v][q];
+    }
+#pragma unroll
+    for (int u = 0; u < WM; ++u)
+#pragma unroll
+        for (int v = 0; v < WM; ++v)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int R = I0 + 16 * WM * qi + 16 * u + MF::row(lane, q);
+                const int Cc = J0 + 16 * WM * qj + 16 * v + lr;
+                if (R < nv && Cc < nv) Sout[(long long)R * ld + Cc] = sv[u][v][q] - acc[u][v][q];
+            }
+    if (ti != tj) {
+        __syncthreads();
+        const T (*sM)[TS + 1] = reinterpret_cast<const T (*)[TS + 1]>(lds);
+#pragma unroll
+        for (int w = 0; w < MT; ++w) {
+            const int e = tid + 256 * w, mr = J0 + e / TS, mc = I0 + e % TS;
+            if (mr < nv && mc < nv) Sout[(long long)mr * ld + mc] = mv[w] - sM[e / TS][e % TS];
+        }
+    }
 }
 
 // withFinish = 0: no innovation-lift workgroup (it ran in the E-chain's last launch).
