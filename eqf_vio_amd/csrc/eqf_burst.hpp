@@ -785,39 +785,48 @@ __device__ long long g_ringStamps[4][64];
 #define EQF_RSTAMP(i) do { } while (0)
 #endif
 constexpr int kRingTrips = 12;  // column-constant rows per wave and step: 45 rows over 4 waves
-template <typename T>
-__global__ __launch_bounds__(256) void k_burst_riccati_ring(BurstArgs a) {
+// R = row landmarks per wavefront: 1 for the small launches described above; 4 for launches that fill the chip -- there the point
+// of the ring is that the 45 x 64 column constants of a step are fetched ONCE per workgroup (16 row landmarks) instead of once per
+// wavefront, and that a lane holds 13 + 3 prefetched values per register set instead of 46: 2 wavefronts per SIMD instead of 1.
+// grid = (ceil(N / 64), ceil(N / (4 R)), B).
+template <typename T, int R = 1>
+__global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(BurstArgs a) {
     const int b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int N = a.gin[b].N, K = a.K, cap = a.cap, ld = a.ld;
     const int J = blockIdx.x * 64 + lane;
-    const int Iraw = blockIdx.y * 4 + wv;
-    const bool rowOk = Iraw < N, validJ = J < N;
-    const int I = rowOk ? Iraw : N - 1, Jc = validJ ? J : 0;
+    const int I0raw = (blockIdx.y * 4 + wv) * R;
+    const bool validJ = J < N;
+    const int I0 = min(I0raw, max(N - 1, 0)), Jc = validJ ? J : 0;  // (rows past N: the wave works on a copy of the last row, stores nothing)
+    const int nI = max(min(R, N - I0), 1);
     const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
     T* Sout = static_cast<T*>(a.Sout) + (long long)b * a.sigmaStride;
     const T* colRec = static_cast<const T*>(a.colRec) + (long long)b * kBurstMax * kColRec * cap + Jc;
-    const T* rowRec = static_cast<const T*>(a.rowRec) + (long long)b * kBurstMax * cap * kBlkRec + (long long)I * kBlkRec;
+    const T* rowRec = static_cast<const T*>(a.rowRec) + (long long)b * kBurstMax * cap * kBlkRec + (long long)I0 * kBlkRec;
     const BurstStep* steps = a.steps + b * kBurstMax;
+    constexpr int kRowVals = R * kBlkRec, kRowTrips = (kRowVals + 63) / 64;
     __shared__ T sCol[2][kBlkRec][64];
-    __shared__ T sRow[4][2][kBlkRec + 3];
+    __shared__ T sRow[4][2][kRowVals + 3];
     __shared__ T sTtP[kBurstMax];
     __shared__ int sRicc[kBurstMax];
 
     EQF_RSTAMP(63);
-    T S[9];
-    {
+    T S[R][9];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int I = min(I0 + i, max(N - 1, 0));
         const T* src = Sin + (long long)(kLm0 + 3 * I) * ld + kLm0 + 3 * Jc;
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-            for (int cc = 0; cc < 3; ++cc) S[3 * rr + cc] = src[(long long)rr * ld + cc];
+            for (int cc = 0; cc < 3; ++cc) S[i][3 * rr + cc] = src[(long long)rr * ld + cc];
     }
     if (tid < K) {
         sTtP[tid] = (T)steps[tid].TtP;
         sRicc[tid] = steps[tid].riccati;
     }
-    // this wave's share of a step's column constants: ring rows q = wv + 4 j  (source row q, or q + 18 for Sw / Sv)
-    T xA[kRingTrips + 1], xB[kRingTrips + 1];
+    // this wave's share of a step's column constants: ring rows q = wv + 4 j  (source row q, or q + 18 for Sw / Sv), and the
+    // row constants of its own R landmarks
+    T xA[kRingTrips + kRowTrips], xB[kRingTrips + kRowTrips];
     auto fetch = [&](int st, T* x) __attribute__((always_inline)) {
         const int sc = min(st, K - 1);  // (past the end: re-read the last step, nobody uses it)
         const T* cp = colRec + (long long)sc * kColRec * cap;
@@ -826,7 +835,9 @@ __global__ __launch_bounds__(256) void k_burst_riccati_ring(BurstArgs a) {
             const int q = min(wv + 4 * j, kBlkRec - 1);
             x[j] = cp[(long long)(q < 27 ? q : q + 18) * cap];
         }
-        x[kRingTrips] = rowRec[(long long)sc * cap * kBlkRec + min(lane, kBlkRec - 1)];
+        const T* rp = rowRec + (long long)sc * cap * kBlkRec;
+#pragma unroll
+        for (int u = 0; u < kRowTrips; ++u) x[kRingTrips + u] = rp[min(lane + 64 * u, nI * kBlkRec - 1)];
     };
     auto pass = [&](int st, const T* x) __attribute__((always_inline)) {
         const int sl = st & 1;
@@ -835,49 +846,104 @@ __global__ __launch_bounds__(256) void k_burst_riccati_ring(BurstArgs a) {
             const int q = wv + 4 * j;
             if (q < kBlkRec) sCol[sl][q][lane] = x[j];
         }
-        if (lane < kBlkRec) sRow[wv][sl][lane] = x[kRingTrips];
+#pragma unroll
+        for (int u = 0; u < kRowTrips; ++u) {
+            const int e = lane + 64 * u;
+            if (e < kRowVals) sRow[wv][sl][e] = x[kRingTrips + u];
+        }
     };
     auto math = [&](int st) __attribute__((always_inline)) {
         const int sl = st & 1;
-        const T* rc = sRow[wv][sl];  // wave-uniform: LDS broadcast reads
-        T Sw[9], Sv[9], H[9];
+        // two passes over the wave's rows so that only one group of column constants is live at a time (Sw / Sv, then D^T / Lw /
+        // Lv): H_i = D_i S_i + Lw_i Sw + Lv_i Sv takes the place of S_i, then S_i' = H_i D^T + Gn_i Lw^T + Gv_i Lv^T
+        {
+            T Sw[9], Sv[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            Sw[k] = sCol[sl][27 + k][lane];
-            Sv[k] = sCol[sl][36 + k][lane];
+            for (int k = 0; k < 9; ++k) {
+                Sw[k] = sCol[sl][27 + k][lane];
+                Sv[k] = sCol[sl][36 + k][lane];
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const T* rc = sRow[wv][sl] + i * kBlkRec;  // wave-uniform: LDS broadcast reads
+                T H[9];
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        T acc = rc[3 * rr] * S[i][cc];
+#pragma unroll
+                        for (int k = 1; k < 3; ++k) acc = fma(rc[3 * rr + k], S[i][3 * k + cc], acc);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) acc = fma(rc[9 + 3 * rr + k], Sw[3 * k + cc], acc);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) acc = fma(rc[18 + 3 * rr + k], Sv[3 * k + cc], acc);
+                        H[3 * rr + cc] = acc;
+                    }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) S[i][k] = H[k];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const T TtP = sTtP[st];
+        {
+            T c[9];  // D_J^T
+#pragma unroll
+            for (int k = 0; k < 9; ++k) c[k] = sCol[sl][k][lane];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const bool diag = (I0raw + i) == J;
+                T O[9];
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        T acc = (diag && rr == cc) ? TtP : (T)0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) acc = fma(S[i][3 * rr + k], c[3 * cc + k], acc);
+                        O[3 * rr + cc] = acc;
+                    }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) S[i][k] = O[k];
+            }
         }
 #pragma unroll
-        for (int rr = 0; rr < 3; ++rr)
+        for (int grp = 1; grp < 3; ++grp) {  // + Gn_i Lw_J^T, then + Gv_i Lv_J^T (the same summation order as one pass)
+            __builtin_amdgcn_sched_barrier(0);
+            T c[9];
 #pragma unroll
-            for (int cc = 0; cc < 3; ++cc) {
-                T acc = rc[3 * rr] * S[cc];
+            for (int k = 0; k < 9; ++k) c[k] = sCol[sl][9 * grp + k][lane];
 #pragma unroll
-                for (int k = 1; k < 3; ++k) acc = fma(rc[3 * rr + k], S[3 * k + cc], acc);
+            for (int i = 0; i < R; ++i) {
+                const T* rc = sRow[wv][sl] + i * kBlkRec + 18 + 9 * grp;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) acc = fma(rc[9 + 3 * rr + k], Sw[3 * k + cc], acc);
+                for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) acc = fma(rc[18 + 3 * rr + k], Sv[3 * k + cc], acc);
-                H[3 * rr + cc] = acc;
+                    for (int cc = 0; cc < 3; ++cc) {
+                        T acc = S[i][3 * rr + cc];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) acc = fma(rc[3 * rr + k], c[3 * cc + k], acc);
+                        S[i][3 * rr + cc] = acc;
+                    }
             }
-        T c[27];
-#pragma unroll
-        for (int k = 0; k < 27; ++k) c[k] = sCol[sl][k][lane];
-        const T TtP = sTtP[st];
-        const bool diag = Iraw == J;
-#pragma unroll
-        for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) {
-                T acc = (diag && rr == cc) ? TtP : (T)0;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) acc = fma(H[3 * rr + k], c[3 * cc + k], acc);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) acc = fma(rc[27 + 3 * rr + k], c[9 + 3 * cc + k], acc);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) acc = fma(rc[36 + 3 * rr + k], c[18 + 3 * cc + k], acc);
-                S[3 * rr + cc] = acc;
-            }
+        }
     };
+    if (R > 1) {
+        // throughput variant: one register set, constants fetched one step ahead (the other wavefront of the SIMD covers the wait)
+        fetch(0, xA);
+        __builtin_amdgcn_sched_barrier(0);
+        pass(0, xA);
+        fetch(1, xA);
+        __builtin_amdgcn_sched_barrier(0);
+        ldsBarrier();
+        for (int st = 0; st < K; ++st) {
+            if (sRicc[st]) math(st);
+            pass(st + 1, xA);
+            fetch(st + 2, xA);
+            __builtin_amdgcn_sched_barrier(0);
+            ldsBarrier();
+        }
+    } else {
     // prologue: steps 0 and 1 in flight, step 0 handed to the ring, step 2 issued
     fetch(0, xA);
     fetch(1, xB);
@@ -908,12 +974,18 @@ __global__ __launch_bounds__(256) void k_burst_riccati_ring(BurstArgs a) {
         ldsBarrier();
         EQF_RSTAMP(4 + 3 * (st + 1));  // (LDS only: __syncthreads() would also drain the prefetches, loads and stores share vmcnt)
     }
-    if (validJ && rowOk) {
-        T* dst = Sout + (long long)(kLm0 + 3 * I) * ld + kLm0 + 3 * J;
+    }
+    if (validJ) {
 #pragma unroll
-        for (int rr = 0; rr < 3; ++rr)
+        for (int i = 0; i < R; ++i) {
+            if (I0raw + i < N) {
+                T* dst = Sout + (long long)(kLm0 + 3 * (I0raw + i)) * ld + kLm0 + 3 * J;
 #pragma unroll
-            for (int cc = 0; cc < 3; ++cc) dst[(long long)rr * ld + cc] = S[3 * rr + cc];
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) dst[(long long)rr * ld + cc] = S[i][3 * rr + cc];
+            }
+        }
     }
 }
 

@@ -474,9 +474,12 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
             else if (lm == 4) hipLaunchKernelGGL((k_burst_build<TT, false, 4>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
             else hipLaunchKernelGGL((k_burst_build<TT, false, 16>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
             if (nmx > 0) {
-                if (R == 1 && f->burstRing) hipLaunchKernelGGL(k_burst_riccati_ring<TT>, rgrid, dim3(256), 0, f->stream, a);
+                // (ring: the four wavefronts of a workgroup share a step's column constants through LDS; EQF_BURST_RING=0: every
+                // wavefront fetches its own)
+                if (R == 1 && f->burstRing) hipLaunchKernelGGL((k_burst_riccati_ring<TT, 1>), rgrid, dim3(256), 0, f->stream, a);
                 else if (R == 1) hipLaunchKernelGGL((k_burst_riccati<TT, 1>), rgrid, dim3(256), 0, f->stream, a);
                 else if (R == 2) hipLaunchKernelGGL((k_burst_riccati<TT, 2>), rgrid, dim3(256), 0, f->stream, a);
+                else if (f->burstRing) hipLaunchKernelGGL((k_burst_riccati_ring<TT, 4>), rgrid, dim3(256), 0, f->stream, a);
                 else hipLaunchKernelGGL((k_burst_riccati<TT, 4>), rgrid, dim3(256), 0, f->stream, a);
             }
         };

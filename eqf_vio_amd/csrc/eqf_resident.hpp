@@ -152,10 +152,10 @@ EQF_DEV void hoWait3(const int* f0, const int* f1, const int* f2, int epoch, int
 
 #ifdef EQF_RES_STAMPS
 __device__ long long g_resStamps[2][16][12];  // [chain][R][phase] wall-clock (100 MHz) stamps of the row heads, filter 0
-#define EQF_RSTAMP(i) do { if (tid == 0 && b == 0 && R < 16) g_resStamps[role.kind][R][i] = wall_clock64(); } while (0)
+#define EQF_HSTAMP(i) do { if (tid == 0 && b == 0 && R < 16) g_resStamps[role.kind][R][i] = wall_clock64(); } while (0)
 #define EQF_WSTAMP(i) do { if (tid == 0 && b == 0 && !isS && C == nb - 1) g_resStamps[1][15][i] = wall_clock64(); } while (0)
 #else
-#define EQF_RSTAMP(i) do { } while (0)
+#define EQF_HSTAMP(i) do { } while (0)
 #define EQF_WSTAMP(i) do { } while (0)
 #endif
 template <typename T>
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
                 a1[i][q] = T1[(long long)(kQB * wv + (lane >> 4) + 4 * q) * ldA + kQB * i + (lane & 15)];
                 a2[i][q] = i < nt ? T2[(long long)(kQB * tr[i] + (lane >> 4) + 4 * q) * ldA + kQB * tc[i] + (lane & 15)] : 0.0;
             }
-        EQF_RSTAMP(0);
+        EQF_HSTAMP(0);
         // (A dry run of the serial part during the idle time before the panels arrive -- to take the instruction-cache misses of
         // code a workgroup executes exactly once off the critical path -- was tried and measured: no gain.)
         for (int K = 0; K + 1 < R; ++K) {
@@ -231,23 +231,23 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
             __syncthreads();
         }
         // ---- the serial part: D[R-1] -> L_{R,R-1} -> diagonal tile -> D[R]
-        EQF_RSTAMP(1);
+        EQF_HSTAMP(1);
         hoWait3(R - 1 > 0 ? flagD + (R - 1) : nullptr, nullptr, nullptr, epoch, tid, &bad);
-        EQF_RSTAMP(2);
+        EQF_HSTAMP(2);
         hoLoadRecord(D + (long long)(R - 1) * kDRec, s, tid);
 #pragma unroll
         for (int i = 0; i < 4; ++i) stTile(a1[i], &s.P[0][0], kSP, kQB * wv, kQB * i, lane);
         __syncthreads();
-        EQF_RSTAMP(3);
+        EQF_HSTAMP(3);
         solveStrip<true>(&s.P[0][0], kSP, s, kQB * wv, lane);
         __syncthreads();
-        EQF_RSTAMP(4);
+        EQF_HSTAMP(4);
         // first column of the diagonal tile, then the factorisation with the other tiles deferred to waves 2, 3; the solved
         // block leaves for the other workgroups meanwhile (stores are asynchronous)
         hoStoreBlock(A + (long long)(R * kSB) * ldA + (R - 1) * kSB, ldA, s.P, tid);
         a2[0] = mmTile<true, kSB>(a2[0], &s.P[0][0], kSP, kQB * tr[0], &s.P[0][0], kSP, kQB * tc[0], lane, -1.0);
         __syncthreads();  // (every wave has finished reading s.L / s.Wd of D[R-1])
-        EQF_RSTAMP(5);
+        EQF_HSTAMP(5);
         stTile(a2[0], &s.L[0][0], kSP, kQB * tr[0], kQB * tc[0], lane);
         if (wv == 0) stTile(a2[0], &s.D0[0][0], kWP, 0, 0, lane);
         __syncthreads();
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
                 stTile(a2[i], &s.L[0][0], kSP, kQB * tr[i], kQB * tc[i], lane);
             }
         };
-        EQF_RSTAMP(6);
+        EQF_HSTAMP(6);
         // the solved block's stores drain in the shadow of the first 16 pivots; it is published right after them
         auto mid = [&] {
             hoDrain();
@@ -266,11 +266,11 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
             if (tid == 0) hoPublish(readyA + R * nbCap + (R - 1), epoch);
         };
         factor64<true>(s, tid, &bad, pre, D + (long long)R * kDRec, nullptr, realStages(ch.kind == 0 ? sDim(g.N) : eDim(g.N), kSB * R), mid);
-        EQF_RSTAMP(7);
+        EQF_HSTAMP(7);
         hoDrain();
         __syncthreads();
         if (tid == 0) hoPublish(ch.flags + (long long)b * ch.strideF + R, epoch);
-        EQF_RSTAMP(8);
+        EQF_HSTAMP(8);
     } else if (role.role == 1) {
         // =========================================================================================== T(R, C)
         const int R = role.R, C = role.C;

@@ -8,9 +8,14 @@ d=json.load(open("/tmp/b.json"))
 print("B="+sys.argv[1], sys.argv[2], round(d["value"]), d["device_error_flag"], [(r["kernel"], r["launches"], r["avg_us"]) for r in d["kernels"]])
 PY
 }
-for B in 1 2 4 8 16 64; do
+run 1 X=1
+run 1 X=1
+for B in 4 8 16 64; do
 run $B X=1
+run $B EQF_BURST_RING=0
 done
-timeout 600 python bench.py --landmarks 1000 --steps 110 --warmup 22 --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-prewarm 2>/dev/null | python -c "
+for r in 1 0; do
+EQF_BURST_RING=$r timeout 600 python bench.py --landmarks 1000 --steps 110 --warmup 22 --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-prewarm 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('N=1000', round(d['value'],1), [(r['kernel'], r['launches'], r['avg_us']) for r in d['kernels']])"
+done
