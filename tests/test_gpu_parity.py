@@ -590,6 +590,48 @@ def test_in_launch_handoff_on_a_ragged_batch(oracle_lib, hip, monkeypatch):
     assert nf >= 19 and fg.device_error() == 0
 
 
+def test_update_launch_layouts_give_the_same_bits(hip, monkeypatch):
+    """k_chol_step64<T, 3>: the pure trailing updates of a launch are walked by persistent stream workgroups; how many of them
+    there are (EQF_CHOL_STREAMS), in which order the workgroup classes are dispatched (EQF_CHOL_ORDER) and on which XCD a
+    filter's workgroups land (batch a multiple of 8: the XCD-aware split; otherwise the plain one) must not change a single
+    bit -- every tile sees the same operands in the same order.  Ragged batches of 8 and 3 filters, split chain forced."""
+    from eqf_vio_amd import synth
+
+    monkeypatch.setenv("EQF_CHOL_SPLIT", "1")
+    monkeypatch.setenv("EQF_CHOL_TAIL", "1")
+    d = synth.template_settings_dict()
+    for Ns in ([100, 9, 75, 30, 50, 100, 64, 21], [140, 70, 33]):
+        B = len(Ns)
+        stride = max(Ns)
+        sts = [synth.make_stream(Ns[b], seed=300 + b, duration=0.26) for b in range(B)]
+
+        def run():
+            fg = hip.FilterBatch(d, capacity=stride, batch=B)
+            for kind, k in sts[0].events():
+                if kind == "imu":
+                    fg.process_imu([s_.imu[k, 0] for s_ in sts], [s_.imu[k, 1:4] for s_ in sts], [s_.imu[k, 4:7] for s_ in sts])
+                else:
+                    ids = np.zeros((B, stride), dtype=np.int32)
+                    y = np.zeros((B, stride, 3))
+                    for b in range(B):
+                        ids[b, : Ns[b]] = sts[b].ids
+                        y[b, : Ns[b]] = sts[b].bearings[k]
+                    fg.process_vision([s_.vision_stamps[k] for s_ in sts], ids, y, nb=np.array(Ns, dtype=np.int32))
+            assert fg.device_error() == 0
+            return [fg.sigma(b) for b in range(B)], [fg.state_estimate(b) for b in range(B)]
+
+        ref = run()
+        for order, streams in (("0", "0"), ("2", "0"), ("1", "1"), ("1", "3"), ("0", "1000")):
+            monkeypatch.setenv("EQF_CHOL_ORDER", order)
+            monkeypatch.setenv("EQF_CHOL_STREAMS", streams)
+            o = run()
+            for b in range(B):
+                assert np.array_equal(o[0][b], ref[0][b]), (Ns, order, streams, b)
+                assert all(np.array_equal(o[1][b][k], ref[1][b][k]) for k in ref[1][b])
+        monkeypatch.delenv("EQF_CHOL_ORDER")
+        monkeypatch.delenv("EQF_CHOL_STREAMS")
+
+
 @pytest.mark.parametrize("Ns", [(70,), (200,), (30, 70), (9, 64, 21)])
 def test_resident_update_kernel_equals_the_per_column_launches(oracle_lib, hip, monkeypatch, Ns):
     """k_chol_resident (the whole factorisation part of an update as ONE launch: tiles resident in registers, solved blocks and
@@ -785,9 +827,13 @@ def test_imu_bursts_equal_single_step_launches(hip, N, monkeypatch):
         else:  # the other block kernel: the same formulas in another order
             assert rel_fro(o[0], full[0]) < 1e-9
     # the block kernel with 2 and 4 row landmarks per wavefront (large problems; EQF_BURST_ROWS forces it here)
-    for rows in ("2", "4"):
+    for rows, ring in (("2", None), ("4", None), ("4", "0")):
         monkeypatch.setenv("EQF_BURST_ROWS", rows)
-        o = _run_bursts(hip, st, N, 15)
+        o = _run_bursts(hip, st, N, 15, ring=ring, monkeypatch=monkeypatch)
+        monkeypatch.delenv("EQF_BURST_RING", raising=False)
+        if rows == "4" and ring is None:
+            # the ring kernel with four rows per wavefront: the arithmetic of the one-row ring kernel, block by block
+            assert np.array_equal(o[0], full[0])
         assert rel_fro(o[0], full[0]) < 1e-9, rows
         assert all(np.abs(o[1][k] - full[1][k]).max() < 1e-9 for k in full[1])
     monkeypatch.delenv("EQF_BURST_ROWS")
