@@ -146,6 +146,7 @@ struct eqf_filter {
     int updateEpoch = 0;           // one per launchUpdate
     // k_chol_resident (one launch per update while the grid fits the chip): EQF_CHOL_RESIDENT = 0 switches it off
     int cholResident = 1;
+    int prepFuseMax = 1 << 30;     // prep + first diagonal factors as one launch up to this many workgroups (EQF_PREP_FUSE_MAX; measured: one launch is never slower, 4..64 filters)
     int cholOrder = -1;            // order of the workgroup classes in an update launch, -1 = by launch size (EQF_CHOL_ORDER = 0 | 1 | 2)
     int cholStreams = 0;           // stream workgroups per filter of an update launch, 0 = by launch size (EQF_CHOL_STREAMS)
     int numCUs = 0;
@@ -642,7 +643,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     }
     int rc = profiled(f, EQF_PROF_UPDATE_PREP, [&] {
         // 64-wide path: two more workgroups per filter factor the first diagonal block of each chain straight from Sigma
-        if (use64 && wpb == 4 && (long long)(lmBlocks + eBlocks + 2) * B <= 512)
+        if (use64 && wpb == 4 && (long long)(lmBlocks + eBlocks + 2) * B <= f->prepFuseMax)
             hipLaunchKernelGGL(k_update_prep64<T>, dim3(lmBlocks + eBlocks + 2, B), dim3(256), std::max(lds, sizeof(Step64Lds)), f->stream, a, cS,
                 cE, lmBlocks, eBlocks, wpb, nvPad);
         else {
@@ -1263,6 +1264,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (const char* e = std::getenv("EQF_CHOL_SPLIT")) f->cholSplit = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_TAIL")) f->cholTail = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_RESIDENT")) f->cholResident = std::atoi(e);
+    if (const char* e = std::getenv("EQF_PREP_FUSE_MAX")) f->prepFuseMax = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_ORDER")) f->cholOrder = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_STREAMS")) f->cholStreams = std::max(0, std::atoi(e));
     {
