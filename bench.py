@@ -23,7 +23,13 @@ import os
 import sys
 import time
 
-import numpy as np
+# The GPU hosts run this under a cgroup CPU quota (16 CPUs on a 256-core machine).  numpy's OpenBLAS starts 64 threads that keep
+# spinning after every call; that burns the quota and the kernel throttles the whole process for tens of milliseconds -- seen as
+# random 45-65 ms stalls in the timed region (late launches, a late return from the final wait).  Nothing here needs threaded BLAS.
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
