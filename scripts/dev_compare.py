@@ -8,9 +8,10 @@ from oracle import binding as ob
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 dur = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
 prec = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+structured = len(sys.argv) > 4 and sys.argv[4] == "structured"  # the structured CPU backend: affordable at N >= 1000
 st = synth.make_stream(N, duration=dur)
 d = synth.template_settings_dict()
-fo = ob.OracleFilter(d)
+fo = ob.OracleFilter(d, structured=structured)
 fg = binding.FilterBatch(d, capacity=max(N, 16), batch=1, precision=prec)
 print(binding.lib().eqf_version().decode())
 nev = 0
