@@ -1,7 +1,12 @@
 import os
 import sys
 
-import pytest
+# (one BLAS thread: numpy's 64 spinning OpenBLAS workers exhaust the test hosts' cgroup CPU quota, and a throttled process sees
+# random stalls of tens of milliseconds -- bench.py does the same)
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
