@@ -59,7 +59,7 @@ EXPORTED_SYMBOLS = [
     "eqf_stream_upload", "eqf_stream_imu", "eqf_stream_vision", "eqf_synchronize", "eqf_get_time", "eqf_num_landmarks",
     "eqf_get_ids", "eqf_get_state_estimate", "eqf_get_origin", "eqf_get_group", "eqf_get_bias", "eqf_get_sigma",
     "eqf_set_sigma", "eqf_set_state", "eqf_set_camera_offset", "eqf_get_integrator", "eqf_get_last_update", "eqf_debug_get_blocks", "eqf_device_error", "eqf_set_dense_propagate", "eqf_set_imu_burst", "eqf_profile_enable",
-    "eqf_profile_get", "eqf_profile_class_name", "eqf_version", "eqf_tile_propagate", "eqf_tile_downdate",
+    "eqf_profile_get", "eqf_profile_class_name", "eqf_version", "eqf_tile_propagate", "eqf_tile_downdate", "eqf_tile_potrf", "eqf_tile_trsm",
 ]
 
 
@@ -110,6 +110,8 @@ def lib():
         L.eqf_tile_propagate.argtypes = [C.c_int, vpp, vpp, vpp, C.c_int, C.c_int, C.c_int, vpp, vpp, vpp, vpp, vpp, vpp, C.c_int, vpp, C.c_int,
                                          vpp, vpp, _dp, C.c_double, C.c_double, C.c_int]
         L.eqf_tile_downdate.argtypes = [C.c_int, vpp, vpp, C.c_int, C.c_int, C.c_int, vpp, C.c_int, vpp, C.c_int, C.c_int]
+        L.eqf_tile_potrf.argtypes = [C.c_int, vpp, vpp, C.c_int, C.c_int, vpp, vpp]
+        L.eqf_tile_trsm.argtypes = [C.c_int, vpp, vpp, C.c_int, C.c_int, vpp, vpp, C.c_int, C.c_int, C.c_int]
         _lib = L
     return _lib
 

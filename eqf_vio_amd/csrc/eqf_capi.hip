@@ -1897,6 +1897,34 @@ int eqf_tile_downdate(int device, void* stream, double* C, int ldc, int m, int n
     return EQF_OK;
 }
 
+int eqf_tile_potrf(int device, void* stream, double* A, int ld, int n, double* drec, int* info) {
+    if (!A || !drec || n < 1 || ld < n) return EQF_ERR_INVALID;
+    HIPC(hipSetDevice(device));
+    static bool attr[64] = {};
+    if (device >= 0 && device < 64 && !attr[device]) {
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_potrf), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        attr[device] = true;
+    }
+    hipLaunchKernelGGL(k_tile_potrf, dim3(1), dim3(256), sizeof(Step64Lds), static_cast<hipStream_t>(stream), A, ld, n, drec, info);
+    HIPC(hipGetLastError());
+    return EQF_OK;
+}
+
+int eqf_tile_trsm(int device, void* stream, const double* A, int ld, int n, const double* drec, double* B, int ldb, int m, int right) {
+    if (!A || !drec || !B || n < 1 || m < 1 || ld < n || ldb < (right ? n : m)) return EQF_ERR_INVALID;
+    HIPC(hipSetDevice(device));
+    static bool attr[64] = {};
+    if (device >= 0 && device < 64 && !attr[device]) {
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        attr[device] = true;
+    }
+    hipLaunchKernelGGL(k_tile_trsm, dim3((m + kSB - 1) / kSB), dim3(256), sizeof(Step64Lds), static_cast<hipStream_t>(stream), A, ld, n, drec, B, ldb,
+        m, right ? 1 : 0);
+    HIPC(hipGetLastError());
+    return EQF_OK;
+}
+
 const char* eqf_profile_class_name(int cls) {
     static const char* names[EQF_PROF_CLASSES] = {"k_propagate", "k_update_prep", "k_chol_step", "k_update_reduce", "k_update_finish",
         "k_downdate", "churn", "k_dense_riccati", "k_imu_burst", "k_chol_step_dd", "k_chol_resident"};

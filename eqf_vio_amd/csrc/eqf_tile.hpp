@@ -10,8 +10,17 @@
 //   k_tile_downdate    C -= A^T B for A (k x m), B (k x n) row-major: the tile's share of Sigma - K C Sigma = Sigma - Y^T Y
 //                      (VIOFilter.cpp:297) from the solved block rows Y_k that the update's all-gather delivers; 64 x 64 outputs per
 //                      workgroup on v_mfma_f64_16x16x4_f64, operands staged through LDS in chunks of 32 rows.
+//   k_tile_potrf       Cholesky of ONE n x n diagonal block of the distributed factorisation (S_kk / the Schur complement of
+//                      Sigma_e, VIOFilter.cpp:276, EqFMatrices.cpp:239), in place, by one workgroup in 64-wide block columns with the
+//                      building blocks of the single-GPU path (eqf_chol64.hpp: factor64, solveStrip, mmTile).  Leaves, per 64-wide
+//                      block column, the diagonal-factor record the panel solves use (L_jj + the inverses of its four 16 x 16
+//                      diagonal blocks, kDRec doubles).  The diagonal block is the serial part of a block column of the distributed
+//                      algorithm: one workgroup is what it offers.
+//   k_tile_trsm        the panel blocks and the block row of right-hand sides against that factor:  B <- B L^-T (right; B is m x n)
+//                      or B <- L^-1 B (left; B is n x m); one workgroup per 64 rows (columns) of B, register-chained MFMA
+//                      substitution per 64 x 64 block, the earlier blocks of the strip applied first.
 #pragma once
-#include "eqf_update.hpp"
+#include "eqf_chol64.hpp"
 
 namespace eqf {
 
@@ -162,6 +171,141 @@ __global__ __launch_bounds__(256) void k_tile_downdate(double* C, int ldc, int m
                 const int R = I0 + 32 * qi + 16 * u + (lane >> 4) + 4 * q, Cc = J0 + 32 * qj + 16 * v + lr;
                 if (R < m && Cc < n) C[(long long)R * ldc + Cc] -= acc[u][v][q];
             }
+}
+
+
+// ---- n x n block, lower triangle, row-major with leading dimension ld: A <- L (A = L L^T); drec[ceil(n / 64)][kDRec].
+// One workgroup of 256 threads, LDS = Step64Lds.  info: or-ed with 1 if a pivot is not positive.
+__global__ __launch_bounds__(256) void k_tile_potrf(double* A, int ld, int n, double* drec, int* info) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemT[];
+    const Lds64 s = ldsFull(smemT);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nb = (n + kSB - 1) / kSB;
+    int bad = 0;
+    // block (rb, cb) of A <-> LDS; rows / columns past n read as the identity (diagonal blocks) or zero
+    auto loadBlock = [&](double (*dst)[kSP], int rb, int cb, bool diag) {
+        for (int e = tid; e < kSB * kSB; e += 256) {
+            const int r = e >> 6, c = e & 63, gr = kSB * rb + r, gc = kSB * cb + c;
+            double v = 0.0;
+            if (gr < n && gc < n) v = (!diag || c <= r) ? A[(long long)gr * ld + gc] : 0.0;
+            else if (diag && r == c) v = 1.0;
+            dst[r][c] = v;
+        }
+    };
+    auto storeBlock = [&](const double (*src)[kSP], int rb, int cb, bool diag) {
+        for (int e = tid; e < kSB * kSB; e += 256) {
+            const int r = e >> 6, c = e & 63, gr = kSB * rb + r, gc = kSB * cb + c;
+            if (gr < n && gc < n && (!diag || c <= r)) A[(long long)gr * ld + gc] = src[r][c];
+        }
+    };
+    for (int kb = 0; kb < nb; ++kb) {
+        loadBlock(s.L, kb, kb, true);
+        __syncthreads();
+        if (tid < kQB * kQB) s.D0[tid >> 4][tid & 15] = s.L[tid >> 4][tid & 15];
+        __syncthreads();
+        factor64(s, tid, &bad, [](int) {}, drec + (long long)kb * kDRec, nullptr, realStages(n, kSB * kb));
+        __syncthreads();
+        storeBlock(s.L, kb, kb, true);
+        // panel: A_rb,kb <- A_rb,kb L_kk^-T
+        for (int rb = kb + 1; rb < nb; ++rb) {
+            loadBlock(s.P, rb, kb, false);
+            __syncthreads();
+            solveStrip<true>(&s.P[0][0], kSP, s, kQB * wv, lane);
+            __syncthreads();
+            storeBlock(s.P, rb, kb, false);
+            __syncthreads();
+        }
+        __threadfence_block();  // (the panel is read back below by other threads of this workgroup)
+        __syncthreads();
+        // trailing update of the lower triangle: A_rb,cb -= L_rb,kb L_cb,kb^T
+        for (int rb = kb + 1; rb < nb; ++rb) {
+            loadBlock(s.P, rb, kb, false);
+            for (int cb = kb + 1; cb <= rb; ++cb) {
+                loadBlock(s.Q, cb, kb, false);
+                __syncthreads();
+                f64x4 acc[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int gr = kSB * rb + kQB * wv + (lane >> 4) + 4 * q, gc = kSB * cb + kQB * i + (lane & 15);
+                        acc[i][q] = (gr < n && gc < n) ? A[(long long)gr * ld + gc] : 0.0;
+                    }
+                    acc[i] = mmTile<true, kSB>(acc[i], &s.P[0][0], kSP, kQB * wv, &s.Q[0][0], kSP, kQB * i, lane, -1.0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int gr = kSB * rb + kQB * wv + (lane >> 4) + 4 * q, gc = kSB * cb + kQB * i + (lane & 15);
+                        if (gr < n && gc < n && gc <= gr) A[(long long)gr * ld + gc] = acc[i][q];  // (lower triangle only)
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (bad && info && tid == 0) atomicOr(info, 1);
+}
+
+// ---- B <- B L^-T (right = 1: B is m x n, a workgroup owns 64 rows) or B <- L^-1 B (right = 0: B is n x m, a workgroup owns 64
+// columns), L = lower triangle of A with the records of k_tile_potrf.  grid = ceil(m / 64), block = 256, LDS = Step64Lds.
+__global__ __launch_bounds__(256) void k_tile_trsm(const double* A, int ld, int n, const double* drec, double* B, int ldb, int m, int right) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemT[];
+    const Lds64 s = ldsFull(smemT);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nb = (n + kSB - 1) / kSB, s0 = blockIdx.x * kSB;  // first row (right) / column (left) of the strip
+    // strip block kb <-> (row, column) of B: right: rows s0.., columns 64 kb.. ; left: rows 64 kb.., columns s0..
+    auto bAt = [&](int kb, int r, int c, long long* idx) -> bool {
+        const int gr = right ? s0 + r : kSB * kb + r, gc = right ? kSB * kb + c : s0 + c;
+        *idx = (long long)gr * ldb + gc;
+        return right ? (gr < m && gc < n) : (gr < n && gc < m);
+    };
+    for (int kb = 0; kb < nb; ++kb) {
+        // the strip's block kb in the accumulator layout (wave wv: rows 16 wv.., four 16-column tiles)
+        f64x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                long long idx;
+                acc[i][q] = bAt(kb, kQB * wv + (lane >> 4) + 4 * q, kQB * i + (lane & 15), &idx) ? B[idx] : 0.0;
+            }
+        for (int j = 0; j < kb; ++j) {
+            // P <- the strip's solved block j (written by this workgroup) ; Q <- L_kb,j
+            for (int e = tid; e < kSB * kSB; e += 256) {
+                const int r = e >> 6, c = e & 63;
+                long long idx;
+                s.P[r][c] = bAt(j, r, c, &idx) ? B[idx] : 0.0;
+                const int gr = kSB * kb + r, gc = kSB * j + c;
+                s.Q[r][c] = (gr < n && gc < n) ? A[(long long)gr * ld + gc] : 0.0;
+            }
+            __syncthreads();
+            if (right) {  // X_kb -= X_j L_kb,j^T
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = mmTile<true, kSB>(acc[i], &s.P[0][0], kSP, kQB * wv, &s.Q[0][0], kSP, kQB * i, lane, -1.0);
+            } else {  // Y_kb -= L_kb,j Y_j
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = mmTile<false, kSB>(acc[i], &s.Q[0][0], kSP, kQB * wv, &s.P[0][0], kSP, kQB * i, lane, -1.0);
+            }
+            __syncthreads();
+        }
+        // L_kb,kb and its inverse blocks
+        const double* Dk = drec + (long long)kb * kDRec;
+        for (int e = tid; e < kSB * kSB; e += 256) s.L[e >> 6][e & 63] = Dk[e];
+        for (int e = tid; e < 4 * kQB * kQB; e += 256) s.Wd[e >> 8][(e >> 4) & 15][e & 15] = Dk[kSB * kSB + e];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stTile(acc[i], &s.P[0][0], kSP, kQB * wv, kQB * i, lane);
+        __syncthreads();
+        if (right) solveStrip<true>(&s.P[0][0], kSP, s, kQB * wv, lane);
+        else solveStrip<false>(&s.P[0][0], kSP, s, kQB * wv, lane);
+        __syncthreads();
+        for (int e = tid; e < kSB * kSB; e += 256) {
+            long long idx;
+            if (bAt(kb, e >> 6, e & 63, &idx)) B[idx] = s.P[e >> 6][e & 63];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 
 }  // namespace eqf

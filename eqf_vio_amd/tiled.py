@@ -81,6 +81,32 @@ class TileKernels:
             raise RuntimeError(f"eqf_tile_downdate failed with status {rc}")
 
 
+    DREC = 64 * 64 + 4 * 16 * 16  # doubles per 64-wide block column: L_jj and the inverses of its four 16 x 16 diagonal blocks
+
+    def potrf(self, A):
+        """Cholesky of the n x n block A (lower triangle read): returns (L, drec); L = the lower-triangular factor (fresh tensor),
+        drec = the diagonal-factor records trsm() multiplies with."""
+        n = A.shape[0]
+        L = torch.tril(A).contiguous()
+        drec = torch.empty(((n + 63) // 64) * self.DREC, dtype=torch.float64, device=A.device)
+        info = torch.zeros(1, dtype=torch.int32, device=A.device)
+        rc = self.lib.eqf_tile_potrf(self.dev, self._stream(), self._p(L), L.stride(0), n, self._p(drec), self._p(info))
+        if rc:
+            raise RuntimeError(f"eqf_tile_potrf failed with status {rc}")
+        self._info = info  # checked by the caller when it synchronises anyway (dist_chol_solve: after the broadcast)
+        return L, drec
+
+    def trsm(self, L, drec, B, right):
+        """right: B (m x n) <- B L^-T ; left: B (n x m) <- L^-1 B.  Returns the solved block (B is copied first)."""
+        X = B.contiguous().clone()
+        m = X.shape[0] if right else X.shape[1]
+        rc = self.lib.eqf_tile_trsm(self.dev, self._stream(), self._p(L), L.stride(0), L.shape[0], self._p(drec), self._p(X), X.stride(0), m,
+                                    1 if right else 0)
+        if rc:
+            raise RuntimeError(f"eqf_tile_trsm failed with status {rc}")
+        return X
+
+
 class ProcessGrid:
     """Pr x Pc process grid over a torch.distributed group; tile (I, J) -> rank (I mod Pr) * Pc + (J mod Pc)."""
 
@@ -218,22 +244,36 @@ def dist_chol_solve(grid, nb, A, Wt, Wn, bs, wt, on_row=None):
     if grid.dist is not None and grid.world > 1:
         grid.dist.all_reduce(nn_all, op=grid.dist.ReduceOp.MAX)
     nn = int(nn_all.item())
+    kern = grid.kernels
     for k in range(nb):
-        # 1. diagonal block
+        # 1. diagonal block (GPU: hand-written k_tile_potrf, which also leaves the records the panel solves multiply with)
         Lkk = torch.empty((bs, bs), dtype=torch.float64, device=grid.device)
+        drec = torch.empty(((bs + 63) // 64) * TileKernels.DREC, dtype=torch.float64, device=grid.device) if kern is not None else None
         if grid.mine(k, k):
-            Lkk = torch.linalg.cholesky(A.pop((k, k))).contiguous()  # (LAPACK hands back column-major strides)
+            if kern is not None:
+                Lkk, drec = kern.potrf(A.pop((k, k)))
+            else:
+                Lkk = torch.linalg.cholesky(A.pop((k, k))).contiguous()  # (LAPACK hands back column-major strides)
         grid.bcast(Lkk, grid.owner(k, k))
+        if kern is not None:
+            grid.bcast(drec, grid.owner(k, k))
+
+        def solve_right(Bm):  # B Lkk^-T
+            return kern.trsm(Lkk, drec, Bm, True) if kern is not None else torch.linalg.solve_triangular(Lkk, Bm.T, upper=False).T
+
+        def solve_left(Bm):  # Lkk^-1 B
+            return kern.trsm(Lkk, drec, Bm, False) if kern is not None else torch.linalg.solve_triangular(Lkk, Bm, upper=False)
+
         # 2. panel blocks and this block row of right-hand sides, on their owners
         pan = {}
         for (i, j) in [key for key in A if key[1] == k]:
-            pan[(i, k)] = torch.linalg.solve_triangular(Lkk, A.pop((i, j)).T, upper=False).T  # A_ik Lkk^-T
+            pan[(i, k)] = solve_right(A.pop((i, j)))
         yw = {}
         for (i, t) in [key for key in Wt if key[0] == k]:
-            yw[(k, t)] = torch.linalg.solve_triangular(Lkk, Wt.pop((i, t)), upper=False)
+            yw[(k, t)] = solve_left(Wt.pop((i, t)))
         yn = {}
         if (k, 0) in Wn:
-            yn[(k, 0)] = torch.linalg.solve_triangular(Lkk, Wn.pop((k, 0)), upper=False)
+            yn[(k, 0)] = solve_left(Wn.pop((k, 0)))
         # 3. everybody gets the panel column and the block row
         pan = grid.allgather_blocks(pan, (bs, bs))
         yw = grid.allgather_blocks(yw, (bs, wt))

@@ -196,12 +196,20 @@ const char* eqf_profile_class_name(int cls);
  *   BnI [3 nI][6], BnJ: rows of the input matrix B (EqFMatrices.cpp:346-382); R[6] = diag(velOmega x3, velAccel x3);
  *   diag_noise = T * pointProcessVariance, is_diag = 1 for tiles with I == J.  in / out: row-major, leading dimension ld.
  * eqf_tile_downdate: C (m x n, ldc) -= A^T B for A (k x m, lda), B (k x n, ldb): the tile's share of Sigma - K C Sigma =
- * Sigma - Y^T Y (VIOFilter.cpp:297) from solved block rows Y. */
+ * Sigma - Y^T Y (VIOFilter.cpp:297) from solved block rows Y.
+ * eqf_tile_potrf: A (n x n, ld, lower triangle) <- L with A = L L^T: the diagonal block S_kk (or of Sigma_e's Schur complement) of
+ * a block column of the distributed factorisation that replaces S.inverse() / Sigma_e.inverse() (VIOFilter.cpp:276-277,
+ * EqFMatrices.cpp:239); drec [ceil(n / 64)][5120] receives, per 64-wide block column, L_jj and the inverses of its four 16 x 16
+ * diagonal blocks (what eqf_tile_trsm multiplies with); info (device int, may be NULL) is or-ed with 1 if a pivot is not positive.
+ * eqf_tile_trsm: right = 1: B (m x n, ldb) <- B L^-T (the panel blocks A_ik L_kk^-T); right = 0: B (n x m, ldb) <- L^-1 B (the block
+ * row of right-hand sides Y_k = L_kk^-1 [C Sigma | delta]_k).  A, drec as left by eqf_tile_potrf. */
 int eqf_tile_propagate(int device, void* stream, double* out, const double* in, int ld, int nI, int nJ, const double* D_I,
     const double* L_I, const double* D_J, const double* L_J, const double* Sbb, const double* SbI, int ldbI, const double* SbJ,
     int ldbJ, const double* BnI, const double* BnJ, const double* R6, double T, double diag_noise, int is_diag);
 int eqf_tile_downdate(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb,
     int k);
+int eqf_tile_potrf(int device, void* stream, double* A, int ld, int n, double* drec, int* info);
+int eqf_tile_trsm(int device, void* stream, const double* A, int ld, int n, const double* drec, double* B, int ldb, int m, int right);
 
 const char* eqf_version(void);
 

@@ -1,4 +1,4 @@
-"""The tile kernels of cfg 5 (csrc/eqf_tile.hpp: eqf_tile_propagate, eqf_tile_downdate) on the MI355X, through the C ABI on torch
+"""The tile kernels of cfg 5 (csrc/eqf_tile.hpp: eqf_tile_propagate, eqf_tile_downdate, eqf_tile_potrf, eqf_tile_trsm) on the MI355X, through the C ABI on torch
 tensors: against dense formulas on random tiles, and end to end -- the tiled Sigma of eqf_vio_amd/tiled.py on the GPU with
 these kernels, driven by the oracle's linearisation blocks, against the oracle's Sigma after every call (the multi-rank exchange
 schedule itself is validated on CPU with gloo, tests/test_tiled.py)."""
@@ -50,8 +50,46 @@ def test_tile_propagate_and_downdate_against_dense_formulas():
         assert np.abs(Cd.cpu().numpy() - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (m, n2, kk)
 
 
+@pytest.mark.parametrize("n", [16, 64, 96, 200, 384])
+def test_tile_potrf_and_trsm_against_lapack(n):
+    """eqf_tile_potrf / eqf_tile_trsm (the panel operations of the distributed factorisation, csrc/eqf_tile.hpp) against numpy's
+    Cholesky and triangular solves: block sizes below, at and between multiples of the 64-wide block column."""
+    import torch
+
+    from eqf_vio_amd import tiled
+
+    dev = torch.device("cuda", 0)
+    k = tiled.TileKernels(0)
+    rng = np.random.default_rng(100 + n)
+    M = rng.standard_normal((n, n))
+    A = M @ M.T + n * np.eye(n)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    L, drec = k.potrf(t(A))
+    torch.cuda.synchronize()
+    assert int(k._info.item()) == 0
+    Lref = np.linalg.cholesky(A)
+    Lg = L.cpu().numpy()
+    assert np.abs(np.triu(Lg, 1)).max() == 0.0
+    assert np.abs(Lg - Lref).max() <= 1e-12 * np.abs(Lref).max()
+    for m in (1, 64, 70, 150):
+        B = rng.standard_normal((m, n))
+        X = k.trsm(L, drec, t(B), True).cpu().numpy()          # B L^-T
+        want = np.linalg.solve(Lref, B.T).T
+        assert np.abs(X - want).max() <= 1e-11 * max(1.0, np.abs(want).max()), (n, m, "right")
+        B2 = rng.standard_normal((n, m))
+        Y = k.trsm(L, drec, t(B2), False).cpu().numpy()        # L^-1 B
+        want = np.linalg.solve(Lref, B2)
+        assert np.abs(Y - want).max() <= 1e-11 * max(1.0, np.abs(want).max()), (n, m, "left")
+    # a matrix that is not positive definite raises the flag instead of producing NaNs silently
+    Abad = A.copy()
+    Abad[n // 2, n // 2] = -1.0
+    k.potrf(t(Abad))
+    torch.cuda.synchronize()
+    assert int(k._info.item()) == 1
+
+
 def test_tiled_sigma_on_the_gpu_with_the_tile_kernels(oracle_lib):
-    """One rank (1 x 1 grid) on the GPU: Riccati steps and downdates through eqf_tile_*, the panel operations in torch; Sigma
+    """One rank (1 x 1 grid) on the GPU: Riccati steps, downdates and the panel operations (diagonal-block Cholesky, triangular solves) through eqf_tile_*; Sigma
     against the oracle after every IMU / vision call of a short stream, open loop as in tests/test_tiled.py."""
     import torch
 
