@@ -308,6 +308,45 @@ __global__ __launch_bounds__(256) void k_bench(double* out, int reps) {
         }
     }
 }
+// EXEC restricted to the first LIM lanes: does the hardware skip the 16-lane passes of a wave64 VALU instruction whose EXEC bits
+// are all zero?  (The later stages of factor64 only have 48 / 32 live rows.)
+template <int LIM>
+__global__ __launch_bounds__(256) void k_bench_lim(double* out, int reps) {
+    __shared__ double T[kSB][kSP];
+    __shared__ double T0[kSB][kSP];
+    __shared__ __attribute__((aligned(16))) double colS[kQB][kQB + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int e = tid; e < kSB * kSB; e += blockDim.x) {
+        const int r = e / kSB, c = e % kSB;
+        T0[r][c] = (r == c ? 40.0 : 0.0) + 1.0 / (1 + r + c);
+    }
+    __syncthreads();
+    int bad = 0;
+    if (wv == 0) {
+        for (int c = 0; c < kSB; ++c) T[lane][c] = T0[lane][c];
+        long long t1 = __builtin_readcyclecounter();
+        if (lane < LIM) {
+            for (int i = 0; i < reps; ++i) {
+                for (int c = 0; c < kQB; ++c) T[lane][16 + c] = T0[lane][16 + c];
+                variantGrp(T, 16, lane, &bad);
+            }
+        }
+        long long t2 = __builtin_readcyclecounter();
+        if (lane == 0) {
+            out[0] = 0;
+            out[1] = double(t2 - t1) / reps;
+            out[2] = T[20][20] + bad;
+        }
+    }
+}
+template <int LIM>
+void runLim(double* o) {
+    double h[3];
+    hipLaunchKernelGGL(k_bench_lim<LIM>, dim3(1), dim3(256), 0, 0, o, 100);
+    hipMemcpy(h, o, 24, hipMemcpyDeviceToHost);
+    printf("grouped broadcasts, EXEC = first %2d lanes   warm %6.0f cycles (%.2f us)   check %.9f\n", LIM, h[1], h[1] / 2400.0, h[2]);
+}
+
 template <int MODE>
 void run(const char* name, double* o) {
     double h[3];
@@ -326,6 +365,9 @@ int main() {
     run<5>("hand-interleaved + sched_barrier", o);
     run<6>("grouped broadcasts", o);
     run<0>("readlane bulk again", o);
+    runLim<64>(o);
+    runLim<48>(o);
+    runLim<32>(o);
     {
         double h[3];
         hipLaunchKernelGGL(k_bench2, dim3(1), dim3(256), 0, 0, o, 100);
