@@ -152,6 +152,69 @@ __device__ __forceinline__ void variantGrp(double (*T)[kSP], int base, int lane,
         for (int c = 0; c < kQB; ++c) T[lane][base + c] = (lane - base >= c) ? row[c] : 0.0;
     }
 }
+// MODE 9: 2 x 2 BLOCK pivots.  The trailing update A' = A - P D^-1 P^T of a two-column panel P with pivot block D = [[a,b],[b,d]]
+// needs ONE reciprocal (of det D) on the dependent chain instead of two dependent reciprocal square roots; the Cholesky
+// columns L = P chol(D)^-T are formed off the chain.  Same mathematics as two rank-1 steps.
+__device__ __forceinline__ double rcpNewton(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+__device__ __forceinline__ void variantBlk2(double (*T)[kSP], int base, int lane, int* bad) {
+    double row[kQB];
+#pragma unroll
+    for (int c = 0; c < kQB; ++c) row[c] = T[lane][base + c];
+    double T1 = 0.0, T2 = 0.0, U1 = 0.0, U2 = 0.0;  // previous block: its bulk update (columns >= c + 2) runs one iteration later
+#pragma unroll
+    for (int c = 0; c < kQB; c += 2) {
+        const double u1 = row[c], u2 = row[c + 1];
+        const double a = readlane64(u1, base + c), b = readlane64(u1, base + c + 1), d = readlane64(u2, base + c + 1);
+        // broadcasts this block's immediate update needs (independent of the reciprocal)
+        double b1n[2], b2n[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (c + 2 + q < kQB) {
+                b1n[q] = readlane64(u1, base + c + 2 + q);
+                b2n[q] = readlane64(u2, base + c + 2 + q);
+            }
+        const double det = fma(a, d, -b * b);
+        if (!(a > 0.0) || !(det > 0.0)) *bad = 1;
+        const double rdet = rcpNewton(det);
+        // deferred bulk of the previous block, in the shadow of the reciprocal
+        if (c >= 2) {
+            double bc1[kQB], bc2[kQB];
+#pragma unroll
+            for (int c2 = c + 2; c2 < kQB; ++c2) {
+                bc1[c2] = readlane64(U1, base + c2);
+                bc2[c2] = readlane64(U2, base + c2);
+            }
+#pragma unroll
+            for (int c2 = c + 2; c2 < kQB; ++c2) __asm__ volatile("" : "+s"(bc1[c2]), "+s"(bc2[c2]));
+#pragma unroll
+            for (int c2 = c + 2; c2 < kQB; ++c2) row[c2] = fma(-T2, bc2[c2], fma(-T1, bc1[c2], row[c2]));
+        }
+        const double n1 = fma(u1, d, -u2 * b), n2 = fma(u2, a, -u1 * b);
+        const double t1 = n1 * rdet, t2 = n2 * rdet;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (c + 2 + q < kQB) row[c + 2 + q] = fma(-t2, b2n[q], fma(-t1, b1n[q], row[c + 2 + q]));
+        // Cholesky columns of the panel (off the chain)
+        const double r11 = rsqrtPivot(a);
+        const double l21 = b * r11;
+        const double r22 = rsqrtPivot(fma(-l21, l21, d));
+        const double l1 = u1 * r11;
+        row[c] = l1;
+        row[c + 1] = fma(-l1, l21, u2) * r22;
+        T1 = t1; T2 = t2; U1 = u1; U2 = u2;
+#pragma unroll
+        for (int c2 = c + 2; c2 < kQB; ++c2) __asm__ volatile("" : "+v"(row[c2]));
+    }
+    if (lane >= base) {
+#pragma unroll
+        for (int c = 0; c < kQB; ++c) T[lane][base + c] = (lane - base >= c) ? row[c] : 0.0;
+    }
+}
 // MODE 7 (round 2, measured SLOWER: 4530 vs 3749 cycles): TWO waves, static column split.  Wave A (columns 0..7) runs the pivot chain of its columns and publishes every finished
 // pivot column through LDS (column, then a flag: LDS operations of one wave are performed in order); wave B (columns 8..15)
 // applies those eight pivots to its columns as they arrive -- off A's instruction stream -- and then runs the pivot chain of its
@@ -276,6 +339,7 @@ __device__ __forceinline__ void dispatch(double (*T)[kSP], double (*colS)[kQB + 
     if (MODE == 4) variantLdl(T, base, lane, bad);
     else if (MODE == 5) variantIl(T, base, lane, bad);
     else if (MODE == 6) variantGrp(T, base, lane, bad);
+    else if (MODE == 9) variantBlk2(T, base, lane, bad);
     else variant<MODE>(T, colS, base, lane, bad);
 }
 
@@ -364,6 +428,7 @@ int main() {
     run<4>("LDL^T chain (rcp on chain)", o);
     run<5>("hand-interleaved + sched_barrier", o);
     run<6>("grouped broadcasts", o);
+    run<9>("2x2 block pivots", o);
     run<0>("readlane bulk again", o);
     runLim<64>(o);
     runLim<48>(o);
