@@ -147,6 +147,7 @@ struct eqf_filter {
     // k_chol_resident (one launch per update while the grid fits the chip): EQF_CHOL_RESIDENT = 0 switches it off
     int cholResident = 1;
     int prepFuseMax = 1 << 30;     // prep + first diagonal factors as one launch up to this many workgroups (EQF_PREP_FUSE_MAX; measured: one launch is never slower, 4..64 filters)
+    int eFromSigma = 1;            // split chain: block column 0 of the E-chain read straight from Sigma (EQF_E_FROM_SIGMA=0: copied by prep)
     int cholOrder = -1;            // order of the workgroup classes in an update launch, -1 = by launch size (EQF_CHOL_ORDER = 0 | 1 | 2)
     int cholStreams = 0;           // stream workgroups per filter of an update launch, 0 = by launch size (EQF_CHOL_STREAMS)
     int numCUs = 0;
@@ -641,7 +642,24 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_first_sigma<double>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         attrSet64 = true;
     }
-    int rc = profiled(f, EQF_PROF_UPDATE_PREP, [&] {
+    // ---- which shape the factorisation launches will have (decided here: the prep launch needs to know whether anybody reads EA's
+    // block column 0)
+    bool embed = nb64S < nb64E;
+    for (int b = 0; b < B && embed; ++b) {
+        const int Nb = int(f->ids[b].size());
+        if (Nb > 0 && roundUp(sDim(Nb), kSB) >= roundUp(eDim(Nb), kSB)) embed = false;
+    }
+    if (!f->cholEmbed) embed = false;
+    const bool splitChain = f->cholSplit >= 0 ? f->cholSplit != 0 : (long long)nblk64 * B >= 1500;  // measured: N = 200 from 8 filters on, N >= ~600
+    bool resident = false;
+    int rc = EQF_OK;
+    if (use64 && embed && f->cholResident && f->cholSplit <= 0 && f->dReadyA) {
+        rc = buildRoles(f, Nmax);
+        if (rc) return rc;
+        resident = f->cholResident >= 2 || (long long)f->rolesCount * B <= f->numCUs;
+    }
+    a.eFromSigma = (use64 && !resident && splitChain && f->cholTail && f->eFromSigma && f->precision != EQF_PRECISION_F32) ? 1 : 0;
+    rc = profiled(f, EQF_PROF_UPDATE_PREP, [&] {
         // 64-wide path: two more workgroups per filter factor the first diagonal block of each chain straight from Sigma
         if (use64 && wpb == 4 && (long long)(lmBlocks + eBlocks + 2) * B <= f->prepFuseMax)
             hipLaunchKernelGGL(k_update_prep64<T>, dim3(lmBlocks + eBlocks + 2, B), dim3(256), std::max(lds, sizeof(Step64Lds)), f->stream, a, cS,
@@ -662,27 +680,15 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         cE.nbMax = nb64E; cE.wtMax = 1;
         const int steps = std::max(nb64S, nb64E);
         // The reductions ride along in the rhs workgroups; the downdate and the innovation lift ride along too when
-        // every filter's S-chain is shorter than its E-chain (always, except for a handful of landmarks).
-        bool embed = nb64S < nb64E;
-        for (int b = 0; b < B && embed; ++b) {
-            const int Nb = int(f->ids[b].size());
-            if (Nb > 0 && roundUp(sDim(Nb), kSB) >= roundUp(eDim(Nb), kSB)) embed = false;
-        }
-        if (!f->cholEmbed) embed = false;
+        // every filter's S-chain is shorter than its E-chain (always, except for a handful of landmarks): `embed`, above.
         // Fused launches (each tile solves its own panel blocks) while a launch is bound by the serial diagonal chain;
-        // panel + update launches (every panel block solved once, 2 workgroups per CU) once it is bound by throughput.
-        const bool splitChain = f->cholSplit >= 0 ? f->cholSplit != 0 : (long long)nblk64 * B >= 1500;  // measured: N = 200 from 8 filters on, N >= ~600
+        // panel + update launches (every panel block solved once, 2 workgroups per CU) once it is bound by throughput:
+        // `splitChain`, above.
         auto blocks = [&](int k, int phase) {
             return chainBlocks64(cS.nbMax, cS.wtMax, k, phase) + chainBlocks64(cE.nbMax, cE.wtMax, k, phase);
         };
         // ONE launch for the whole factorisation part while its grid fits the chip (every workgroup resident: one small
-        // filter, the latency case); the role table's block order keeps it deadlock-free even when it does not
-        bool resident = false;
-        if (embed && f->cholResident && f->cholSplit <= 0 && f->dReadyA) {
-            rc = buildRoles(f, Nmax);
-            if (rc) return rc;
-            resident = f->cholResident >= 2 || (long long)f->rolesCount * B <= f->numCUs;
-        }
+        // filter, the latency case); the role table's block order keeps it deadlock-free even when it does not: `resident`, above.
         if (resident) {
             ResArgs ra{};
             ra.c0 = cS; ra.c1 = cE; ra.a = a;
@@ -1265,6 +1271,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (const char* e = std::getenv("EQF_CHOL_TAIL")) f->cholTail = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_RESIDENT")) f->cholResident = std::atoi(e);
     if (const char* e = std::getenv("EQF_PREP_FUSE_MAX")) f->prepFuseMax = std::atoi(e);
+    if (const char* e = std::getenv("EQF_E_FROM_SIGMA")) f->eFromSigma = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_ORDER")) f->cholOrder = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_STREAMS")) f->cholStreams = std::max(0, std::atoi(e));
     {

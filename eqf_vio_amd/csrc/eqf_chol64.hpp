@@ -530,10 +530,12 @@ struct StreamTile {
     const double* Qg;
     int ldcp, ldq;  // leading dimension of Ct and Pg (the same matrix family), of Qg
     int isW;
+    const double* CtL;  // where the tile's current value is READ: Ct, or -- block column 0 of the E-chain, UpdArgs::eFromSigma -- Sigma
+    int ldL;
 };
 
 // update tiles first, first + stride, ... of filter b in launch K (see step3Counts); 256 threads, LDS: s.P, s.Q
-EQF_DI void streamUpdates64(const ChainArgs& c0, const ChainArgs& c1, int b, int K, int first, int stride, const Lds64& s) {
+EQF_DI void streamUpdates64(const ChainArgs& c0, const ChainArgs& c1, const UpdArgs& a, int b, int K, int first, int stride, const Lds64& s) {
     const Glob& g = c0.g[b];
     if (!g.updateOk || g.N == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -551,6 +553,10 @@ EQF_DI void streamUpdates64(const ChainArgs& c0, const ChainArgs& c1, int b, int
     const double* const YS = c0.WO + (long long)b * c0.strideW;
     const double* const YE = c1.WO + (long long)b * c1.strideW;
     const int ldAS = c0.ldA, ldAE = c1.ldA, ldWS = c0.ldW, ldWE = c1.ldW;
+    // E-chain A tiles in launch 0: their values are still Sigma's (fp64 only; the last block row comes from EA: identity padding)
+    const bool eSrc = a.eFromSigma && K == 0;
+    const double* Se = static_cast<const double*>(a.Sin) + (long long)b * a.sigmaStride + 6LL * a.ld + 6;
+    const int ldSg = a.ld;
     auto decode = [&](int u, StreamTile& t) -> bool {
         const bool second = u >= nS;
         const int nb = second ? nbE : nbS, wt = second ? wtE : wtS, m = second ? mE : mS, nA = second ? nAE : nAS;
@@ -583,6 +589,9 @@ EQF_DI void streamUpdates64(const ChainArgs& c0, const ChainArgs& c1, int b, int
         t.ldcp = ldcp;
         t.ldq = ldA;
         t.isW = isA ? 0 : 1;
+        const bool fromS = eSrc && second && isA && R < nb - 1;
+        t.CtL = fromS ? Se + (long long)(R * kSB) * ldSg + C * kSB : t.Ct;
+        t.ldL = fromS ? ldSg : ldcp;
         return isA ? R < nb : (tt < wt && C < nb);
     };
     // a contiguous chunk of the list per workgroup: consecutive tiles share their P operand (A tiles of one block row: L_RK;
@@ -607,7 +616,7 @@ EQF_DI void streamUpdates64(const ChainArgs& c0, const ChainArgs& c1, int b, int
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) nAcc[i][q] = t.Ct[(long long)(kQB * wv + (lane >> 4) + 4 * q) * t.ldcp + kQB * i + (lane & 15)];
+            for (int q = 0; q < 4; ++q) nAcc[i][q] = t.CtL[(long long)(kQB * wv + (lane >> 4) + 4 * q) * t.ldL + kQB * i + (lane & 15)];
     };
     issue(nxt, true);
     bool newP = true;  // the tile in flight brings its own P block (otherwise the one in LDS is its P too)
@@ -747,7 +756,7 @@ __global__ __launch_bounds__(256, (PHASE == 2 || PHASE == 3) ? 2 : 1) void k_cho
             return;
         }
         if (cls == 2) {
-            streamUpdates64(c0, c1, bx, K, int(x), nStream, ldsTail(smem64));
+            streamUpdates64(c0, c1, a, bx, K, int(x), nStream, ldsTail(smem64));
             return;
         }
         if (cls == 0) {
@@ -863,12 +872,18 @@ __global__ __launch_bounds__(256, (PHASE == 2 || PHASE == 3) ? 2 : 1) void k_cho
     // XCDs: each access is a ~2 us miss, so they must all be in flight together)
     double* Ct = isW ? (W + (long long)(C * kSB) * ldW + R * kSB) : (A + (long long)(R * kSB) * ldA + C * kSB);
     const int ldc = isW ? ldW : ldA;
+    // (UpdArgs::eFromSigma: in launch 0 the E-chain's A tiles still hold Sigma's values and are read there -- EA = Sigma[6:, 6:] is a
+    // plain offset; the last block row, which holds the identity padding, comes from EA as ever)
+    const bool eSrc = a.eFromSigma && K == 0 && second && !isW && R < nb - 1 && (PHASE == 1 || PHASE == 3);
+    const double* Se = static_cast<const double*>(a.Sin) + (long long)b * a.sigmaStride + 6LL * a.ld + 6;
+    const double* CtL = eSrc ? Se + (long long)(R * kSB) * a.ld + C * kSB : Ct;
+    const int ldcL = eSrc ? a.ld : ldc;
     f64x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            acc[i][q] = (solveOnly || panelA || i >= nt) ? 0.0 : Ct[(long long)(kQB * tr[i] + (lane >> 4) + 4 * q) * ldc + kQB * tc[i] + (lane & 15)];
+            acc[i][q] = (solveOnly || panelA || i >= nt) ? 0.0 : CtL[(long long)(kQB * tr[i] + (lane >> 4) + 4 * q) * ldcL + kQB * tc[i] + (lane & 15)];
     // running sums of the reductions (rhs workgroups): previous value of this thread's entry, fetched with everything else
     double prevSum = 0.0;
     double* sumPtr = nullptr;
@@ -887,9 +902,10 @@ __global__ __launch_bounds__(256, (PHASE == 2 || PHASE == 3) ? 2 : 1) void k_cho
     }
     const double* Dk = D + (long long)K * kDRec;
     // (update launches of the split chain read the SOLVED blocks: Y_K from WO, L_RK / L_CK in place in A)
-    const double* Pg = isW ? ((UPD ? WO : W) + (long long)(K * kSB) * ldW + R * kSB) : (A + (long long)(R * kSB) * ldA + K * kSB);
+    const double* Pg = isW ? ((UPD ? WO : W) + (long long)(K * kSB) * ldW + R * kSB)
+                           : ((eSrc && panelA) ? Se + (long long)(R * kSB) * a.ld + K * kSB : A + (long long)(R * kSB) * ldA + K * kSB);
     const double* Qg = A + (long long)(C * kSB) * ldA + K * kSB;
-    const int ldp = isW ? ldW : ldA;
+    const int ldp = isW ? ldW : ((eSrc && panelA) ? a.ld : ldA);
     double rL[16], rW[4], rP[16], rQ[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {

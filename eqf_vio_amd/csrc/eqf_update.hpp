@@ -66,6 +66,8 @@ struct UpdArgs {
     int* errflag;
     int* resCounters;     // [B][4] work counters of k_chol_resident (zeroed by the prep launch), or nullptr
     int pad;              // chain dimensions are padded (with identity) to multiples of this: 32 (k_chol_step) or 64 (k_chol_step64)
+    int eFromSigma;       // split 64-wide chain, fp64: the E-chain's tiles are first read straight from Sigma (EA = Sigma[6:, 6:] is a plain
+                          // offset there) -- prep only copies the LAST block row, the one that holds the identity padding
     Params prm;
 };
 
@@ -164,7 +166,9 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, d
         // the ~2 us first-touch miss two dozen times in a row and made these workgroups the longest of the launch.
         const int nw = (int)blockDim.x >> 6;
         constexpr int kRowsTrip = 4, kColGroups = 10;
-        for (int rb = wv; rb < kNB; rb += nw * kRowsTrip) {
+        // (a.eFromSigma: only the last 64-row block row is copied, 6 MB less traffic per filter and update at N = 200)
+        const bool copyRows = !a.eFromSigma || r0 + kNB > nep - 64;
+        for (int rb = wv; rb < (copyRows ? kNB : 0); rb += nw * kRowsTrip) {
             for (int c0 = lane; c0 < nep; c0 += 64 * kColGroups) {
                 // raw loads first, conversion afterwards: with T = float a convert right behind each load makes hipcc wait
                 // for every load separately

@@ -630,6 +630,12 @@ def test_update_launch_layouts_give_the_same_bits(hip, monkeypatch):
                 assert all(np.array_equal(o[1][b][k], ref[1][b][k]) for k in ref[1][b])
         monkeypatch.delenv("EQF_CHOL_ORDER")
         monkeypatch.delenv("EQF_CHOL_STREAMS")
+        # the E-chain's tiles first read straight from Sigma (default) or from the copy the prep launch makes: the same values
+        monkeypatch.setenv("EQF_E_FROM_SIGMA", "0")
+        o = run()
+        monkeypatch.delenv("EQF_E_FROM_SIGMA")
+        for b in range(B):
+            assert np.array_equal(o[0][b], ref[0][b]), (Ns, "copy", b)
 
 
 @pytest.mark.parametrize("Ns", [(70,), (200,), (30, 70), (9, 64, 21)])
