@@ -373,6 +373,28 @@ def test_fp32_mode_runs_and_is_bounded(oracle_lib, hip):
     assert worst["pos"] < 5e-2, worst
 
 
+def test_fp32_mode_on_the_per_column_launches(hip, monkeypatch):
+    """EQF_PRECISION_F32 on the split chain (one launch per block column, streamed trailing updates): Sigma is fp32 there, so the
+    E-chain's first read goes through the converting copy of the prep launch, not through Sigma itself.  Must agree with the
+    fused fp32 launches to fp32 rounding amplified by the conditioning (measured 3e-4 on Sigma)."""
+    from eqf_vio_amd import synth
+
+    N = 70
+    st = synth.make_stream(N, duration=0.4)
+    d = synth.template_settings_dict()
+    out = []
+    for sp in ("0", "1"):
+        monkeypatch.setenv("EQF_CHOL_SPLIT", sp)
+        f = hip.FilterBatch(d, capacity=N, batch=1, precision=1)
+        f.stream_upload(st.imu, st.vision_stamps, st.ids, st.bearings)
+        for kind, k in st.events():
+            (f.stream_imu if kind == "imu" else f.stream_vision)(k)
+        assert f.device_error() == 0
+        out.append((f.sigma(), f.state_estimate()))
+    assert rel_fro(out[1][0], out[0][0]) < 5e-3
+    assert np.abs(out[1][1]["x"] - out[0][1]["x"]).max() < 1e-3
+
+
 def test_cpp_facade_matches_the_oracle(oracle_lib):
     """The C++ host facade (eqf_vio_amd/cpp/VIOFilter.h, the reference's class interface) driven by the example
     runner reproduces the oracle on the same inputs."""
