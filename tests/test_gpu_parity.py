@@ -375,8 +375,8 @@ def test_fp32_mode_runs_and_is_bounded(oracle_lib, hip):
 
 def test_fp32_mode_on_the_per_column_launches(hip, monkeypatch):
     """EQF_PRECISION_F32 on the split chain (one launch per block column, streamed trailing updates): Sigma is fp32 there, so the
-    E-chain's first read goes through the converting copy of the prep launch, not through Sigma itself.  Must agree with the
-    fused fp32 launches to fp32 rounding amplified by the conditioning (measured 3e-4 on Sigma)."""
+    E-chain's first read goes through the converting copy of the prep launch, not through Sigma itself.  Against the default for
+    one small filter (the resident update kernel): the same factorisation arithmetic tile by tile -- bitwise equal in fp32 too."""
     from eqf_vio_amd import synth
 
     N = 70
@@ -391,8 +391,8 @@ def test_fp32_mode_on_the_per_column_launches(hip, monkeypatch):
             (f.stream_imu if kind == "imu" else f.stream_vision)(k)
         assert f.device_error() == 0
         out.append((f.sigma(), f.state_estimate()))
-    assert rel_fro(out[1][0], out[0][0]) < 5e-3
-    assert np.abs(out[1][1]["x"] - out[0][1]["x"]).max() < 1e-3
+    assert np.array_equal(out[1][0], out[0][0])
+    assert np.array_equal(out[1][1]["x"], out[0][1]["x"])
 
 
 def test_cpp_facade_matches_the_oracle(oracle_lib):
