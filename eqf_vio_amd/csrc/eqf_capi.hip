@@ -146,6 +146,7 @@ struct eqf_filter {
     int updateEpoch = 0;           // one per launchUpdate
     // k_chol_resident (one launch per update while the grid fits the chip): EQF_CHOL_RESIDENT = 0 switches it off
     int cholResident = 1;
+    int residentPerCU = -1;        // hipOccupancyMaxActiveBlocksPerMultiprocessor of k_chol_resident on this device (lazily queried)
     int prepFuseMax = 1 << 30;     // prep + first diagonal factors as one launch up to this many workgroups (EQF_PREP_FUSE_MAX; measured: one launch is never slower, 4..64 filters)
     int eFromSigma = 1;            // split chain: block column 0 of the E-chain read straight from Sigma (EQF_E_FROM_SIGMA=0: copied by prep)
     int cholOrder = -1;            // order of the workgroup classes in an update launch, -1 = by launch size (EQF_CHOL_ORDER = 0 | 1 | 2)
@@ -651,12 +652,20 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     }
     if (!f->cholEmbed) embed = false;
     const bool splitChain = f->cholSplit >= 0 ? f->cholSplit != 0 : (long long)nblk64 * B >= 1500;  // measured: N = 200 from 8 filters on, N >= ~600
-    bool resident = false;
+    bool resident = false, residentFits = false;
     int rc = EQF_OK;
     if (use64 && embed && f->cholResident && f->cholSplit <= 0 && f->dReadyA) {
         rc = buildRoles(f, Nmax);
         if (rc) return rc;
-        resident = f->cholResident >= 2 || (long long)f->rolesCount * B <= f->numCUs;
+        // co-residency of the whole grid by the occupancy calculation (one workgroup per CU with the 119 KB LDS image), not by
+        // the CU count alone: the in-kernel downdate waits for workgroups with HIGHER block indices while holding its CU
+        if (f->residentPerCU < 0) {
+            int nblk = 0;
+            HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(&k_chol_resident<T>), 256, sizeof(Step64Lds)));
+            f->residentPerCU = std::max(nblk, 0);
+        }
+        residentFits = (long long)f->rolesCount * B <= (long long)f->residentPerCU * f->numCUs;
+        resident = f->cholResident >= 2 || residentFits;
     }
     a.eFromSigma = (use64 && !resident && splitChain && f->cholTail && f->eFromSigma && f->precision != EQF_PRECISION_F32) ? 1 : 0;
     rc = profiled(f, EQF_PROF_UPDATE_PREP, [&] {
@@ -688,7 +697,8 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             return chainBlocks64(cS.nbMax, cS.wtMax, k, phase) + chainBlocks64(cE.nbMax, cE.wtMax, k, phase);
         };
         // ONE launch for the whole factorisation part while its grid fits the chip (every workgroup resident: one small
-        // filter, the latency case); the role table's block order keeps it deadlock-free even when it does not: `resident`, above.
+        // filter, the latency case); the role table's block order keeps the ROLES deadlock-free even when it does not, and the
+        // downdate -- the one wait for later workgroups -- then runs as a launch of its own: `resident` / `residentFits`, above.
         if (resident) {
             ResArgs ra{};
             ra.c0 = cS; ra.c1 = cE; ra.a = a;
@@ -698,12 +708,20 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             ra.nbCap = f->nbCap; ra.wtCap = f->wtCap;
             // 64 x 64 downdate tiles: a tile costs the same 14 dependent chunk fetches whatever its size, and there are enough
             // finished workgroups to take one each
-            ra.ddNt = nt64; ra.ddSmall = 0;
+            // (a grid forced beyond what is co-resident -- EQF_CHOL_RESIDENT=2 -- must not wait for later workgroups while holding
+            // CUs: its downdate is the follow-up launch below)
+            ra.ddNt = residentFits ? nt64 : 0; ra.ddSmall = 0;
             ra.errflag = f->errflag;
             rc = profiled(f, EQF_PROF_CHOL_RESIDENT, [&] {
                 hipLaunchKernelGGL(k_chol_resident<T>, dim3(f->rolesCount, B), dim3(256), sizeof(Step64Lds), f->stream, ra);
             });
             if (rc) return rc;
+            if (!residentFits) {
+                rc = profiled(f, EQF_PROF_DOWNDATE, [&] {
+                    hipLaunchKernelGGL((k_downdate<T, 64>), dim3(nt64 * (nt64 + 1) / 2, B), dim3(256), (downdateLdsBytes<T, 64>()), f->stream, a, nt64, 0);
+                });
+                if (rc) return rc;
+            }
         } else if (splitChain && f->cholTail) {
             // one launch per block column: the panel launch of column 0, then update launches that also solve column k+1
             // (k_chol_step64<T, 3>); the S-chain's right-hand sides are complete after launch nb64S - 2, the downdate joins

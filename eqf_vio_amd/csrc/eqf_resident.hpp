@@ -20,10 +20,15 @@
 //   The last right-hand-side workgroup of the E-chain waits for every share, sums them IN BLOCK-ROW ORDER (deterministic)
 //   and runs the innovation lift.  S-chain workgroups that finish late take the downdate tiles Sigma - Y^T Y from a
 //   counter once every Y tile is out.
-// Deadlock freedom: block indices follow the dependency order (a workgroup only ever waits for workgroups with a lower
-// block index), so whatever part of the grid is resident contains a workgroup that can run; every wait is bounded
-// (eqf_handoff.hpp) and raises the device error flag instead of hanging.  The host uses this kernel when the grid fits the
-// chip (one small filter -- the latency case); larger problems keep the per-column launches, which are bandwidth-bound.
+// Deadlock freedom: in the ROLES, block indices follow the dependency order (a workgroup only ever waits for workgroups with a
+// lower block index), so whatever part of the grid is resident contains a workgroup that can run.  The one exception is the
+// in-kernel downdate: workgroups that are done wait -- holding their CU -- until ALL Y tiles are out, i.e. also for higher block
+// indices.  That is only safe when the whole grid is co-resident, so the host compiles the downdate into this launch
+// (ResArgs::ddNt > 0) only when hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs covers the grid; a grid forced onto a larger
+// size (EQF_CHOL_RESIDENT=2) gets the downdate as a follow-up launch.  Every wait is bounded (eqf_handoff.hpp, 50 ms): a
+// timeout raises the sticky device error flag (bit 8 -> EQF_ERR_NUMERIC from eqf_device_error) and the workgroup that saw it
+// takes no downdate tiles -- Sigma_out is never overwritten from stale operands.  The host uses this kernel when the grid fits
+// the chip (one small filter -- the latency case); larger problems keep the per-column launches, which are bandwidth-bound.
 #pragma once
 #include "eqf_chol64.hpp"
 
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
             // the S-chain's last block row carries the complete sums: wait for its tiles only
             const int* ryS = ra.readyY + ((long long)b * 2 + 0) * nbCap * wtCap;
             if (tid < wtS && !hoWait(ryS + (nbS - 1) * wtCap + tid, epoch)) bad = 8;
-            __syncthreads();
+            bad = __syncthreads_or(bad) ? 8 : 0;  // (a timeout seen by ANY of the polling threads is reported below by thread 0)
             double* gam = a.dbgGamma + (long long)b * (kLm0 + 3 * a.cap);
             const int ldY = ra.c0.ldW;
             double gv[4];
@@ -409,23 +414,33 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
         }
     }
     if (bad && ra.errflag && tid == 0) atomicOr(ra.errflag, bad == 8 ? 8 : 4);
+    // A hand-off that timed out left this workgroup with stale operands: everything it published is wrong, and so would be a
+    // downdate from it.  The sticky flag (bit 8, include/eqf_vio_amd.h) makes the host report EQF_ERR_NUMERIC; this workgroup takes no
+    // downdate tiles, so Sigma_out is not overwritten with a plausible-looking wrong matrix.
+    if (__syncthreads_or(bad == 8)) return;
 
     // ---- covariance downdate Sigma - Y^T Y: every workgroup that is done with its role takes tiles from a counter once every Y
     // tile of this filter is out (a tile is latency-bound -- 14 dependent chunk fetches -- so it wants many workgroups, one
-    // tile each; workgroups that finish later find the counter exhausted and leave)
+    // tile each; workgroups that finish later find the counter exhausted and leave).
+    // This is the ONE wait of the kernel for workgroups with a HIGHER block index, made while holding a CU: it is only compiled into
+    // launches whose whole grid is co-resident by the occupancy calculation (ra.ddNt > 0 <=> the host checked; otherwise the downdate
+    // is a follow-up launch).  If the chip is shared with other work the late workgroups arrive as soon as that work retires; a wait
+    // that still times out skips the downdate (Sigma_out is left untouched) and raises the sticky flag.
     if (ra.ddNt > 0 && (active || role.kind == 0)) {
         __shared__ int sTile;
+        int late = 0;
         if (tid == 0 && active) {
             const long long t0 = wall_clock64();
             while (__hip_atomic_load(counters + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nbS * wtS) {
                 __builtin_amdgcn_s_sleep(32);
                 if (wall_clock64() - t0 > 5000000LL) {
                     if (ra.errflag) atomicOr(ra.errflag, 8);
+                    late = 1;
                     break;
                 }
             }
         }
-        __syncthreads();
+        if (__syncthreads_or(late)) return;
         const int ddTiles = ra.ddNt * (ra.ddNt + 1) / 2;
         for (;;) {
             if (tid == 0) sTile = __hip_atomic_fetch_add(counters + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -147,7 +147,11 @@ int eqf_get_last_update(eqf_filter* f, int b, double* delta, double* gamma, doub
  * Lw = -T B[5+3i.., 0:3] (9), Lv = T A0[5+3i.., 2:5] (9) (EqFMatrices.cpp:294-314, :370-380).  c0[N][6] = C0i, the 2 x 3
  * block of EqFOutputMatrixC (EqFMatrices.cpp:319-344).  Any pointer may be NULL.  fp64 handles only. */
 int eqf_debug_get_blocks(eqf_filter* f, int b, double* common, double* rec, double* c0);
-/* Sticky device-side error flag (NaN / antipodal), 0 if none. */
+/* Sticky device-side error flag, 0 if none; a bit mask (any bit -> the C++ facade throws std::domain_error, like the reference's
+ * SO3FromVectors, SO3.cpp:160): 1 antipodal vectors / singular gravity chart in a propagate step; 2 the same while building the residual
+ * or C0i; 4 a pivot of S or Sigma_e not positive; 8 antipodal vectors in the innovation lift, OR an in-launch hand-off of k_chol_resident
+ * timed out (50 ms: the chip was shared beyond what the kernel's co-residency allows) -- that update's Sigma was NOT written and the
+ * filter must be reset or restored; 16 / 32 a new / restored landmark on the chart pole. */
 int eqf_device_error(eqf_filter* f);
 
 /* IMU bursts.  processIMUData calls (VIOFilter.cpp:120-131) only depend on each other and on the state, so the library
