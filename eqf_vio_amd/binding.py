@@ -59,7 +59,11 @@ EXPORTED_SYMBOLS = [
     "eqf_stream_upload", "eqf_stream_imu", "eqf_stream_vision", "eqf_synchronize", "eqf_get_time", "eqf_num_landmarks",
     "eqf_get_ids", "eqf_get_state_estimate", "eqf_get_origin", "eqf_get_group", "eqf_get_bias", "eqf_get_sigma",
     "eqf_set_sigma", "eqf_set_state", "eqf_set_camera_offset", "eqf_get_integrator", "eqf_get_last_update", "eqf_debug_get_blocks", "eqf_device_error", "eqf_set_dense_propagate", "eqf_set_imu_burst", "eqf_profile_enable",
-    "eqf_profile_get", "eqf_profile_class_name", "eqf_version", "eqf_tile_propagate", "eqf_tile_downdate", "eqf_tile_potrf", "eqf_tile_trsm",
+    "eqf_profile_get", "eqf_profile_class_name", "eqf_version", "eqf_tile_propagate", "eqf_tile_downdate", "eqf_tile_potrf", "eqf_tile_trsm", "eqf_tile_gemm_tn",
+    "eqf_tiled_create", "eqf_tiled_destroy", "eqf_tiled_set_stream", "eqf_tiled_set_geometry", "eqf_tiled_propagate", "eqf_tiled_add_landmarks",
+    "eqf_tiled_update_prep", "eqf_tiled_update_finish", "eqf_tiled_synchronize", "eqf_tiled_num_landmarks", "eqf_tiled_get_time",
+    "eqf_tiled_device_error", "eqf_tiled_get_state_estimate", "eqf_tiled_get_origin", "eqf_tiled_get_group", "eqf_tiled_get_bias",
+    "eqf_tiled_get_last_update", "eqf_tiled_get_integrator", "eqf_tiled_get_base", "eqf_tiled_set_state",
 ]
 
 
@@ -112,6 +116,29 @@ def lib():
         L.eqf_tile_downdate.argtypes = [C.c_int, vpp, vpp, C.c_int, C.c_int, C.c_int, vpp, C.c_int, vpp, C.c_int, C.c_int]
         L.eqf_tile_potrf.argtypes = [C.c_int, vpp, vpp, C.c_int, C.c_int, vpp, vpp]
         L.eqf_tile_trsm.argtypes = [C.c_int, vpp, vpp, C.c_int, C.c_int, vpp, vpp, C.c_int, C.c_int, C.c_int]
+        L.eqf_tile_gemm_tn.argtypes = [C.c_int, vpp, vpp, C.c_int, C.c_int, C.c_int, vpp, C.c_int, vpp, C.c_int, C.c_int, C.c_double] + [C.c_int] * 8
+        # the 2-D block-partitioned filter (BASELINE configs[4]); device buffers are plain pointers (torch tensors' data_ptr)
+        L.eqf_tiled_create.argtypes = [C.POINTER(Settings), C.c_int, C.c_int, C.POINTER(vp)]
+        L.eqf_tiled_destroy.argtypes = [vp]
+        L.eqf_tiled_destroy.restype = None
+        L.eqf_tiled_set_stream.argtypes = [vp, vpp]
+        L.eqf_tiled_set_geometry.argtypes = [vp, C.c_int, _ip, C.c_int, _ip]
+        L.eqf_tiled_propagate.argtypes = [vp, C.c_double, _dp, _dp, C.c_int, vpp, C.c_int]
+        L.eqf_tiled_add_landmarks.argtypes = [vp, C.c_int, _dp, vpp, C.c_int]
+        L.eqf_tiled_update_prep.argtypes = [vp, _dp, vpp, C.c_int, vpp, C.c_int, vpp, C.c_int, vpp]
+        L.eqf_tiled_update_finish.argtypes = [vp, vpp, C.c_int, vpp, vpp]
+        L.eqf_tiled_synchronize.argtypes = [vp]
+        L.eqf_tiled_num_landmarks.argtypes = [vp]
+        L.eqf_tiled_get_time.argtypes = [vp, _dp]
+        L.eqf_tiled_device_error.argtypes = [vp]
+        L.eqf_tiled_get_state_estimate.argtypes = [vp, _dp, _dp, _dp, _dp]
+        L.eqf_tiled_get_origin.argtypes = [vp, _dp, _dp, _dp, _dp]
+        L.eqf_tiled_get_group.argtypes = [vp, _dp, _dp, _dp, _dp, _dp]
+        L.eqf_tiled_get_bias.argtypes = [vp, _dp]
+        L.eqf_tiled_get_last_update.argtypes = [vp, _dp, _dp, _dp]
+        L.eqf_tiled_get_integrator.argtypes = [vp, _dp, _dp, _dp, _ip]
+        L.eqf_tiled_get_base.argtypes = [vp, _dp, C.c_int]
+        L.eqf_tiled_set_state.argtypes = [vp, C.c_int] + [_dp] * 11 + [C.c_int, C.c_double, _dp, _dp, C.c_double, C.c_int]
         _lib = L
     return _lib
 

@@ -19,7 +19,6 @@
 #include "eqf_burst.hpp"
 #include "eqf_chol64.hpp"
 #include "eqf_resident.hpp"
-#include "eqf_tile.hpp"
 #include "eqf_update.hpp"
 
 using namespace eqf;
@@ -1891,62 +1890,6 @@ int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_m
         }
         *total_ms = std::max(0.0, sum - f->profOverheadMs * f->profCount[cls]);
     }
-    return EQF_OK;
-}
-
-int eqf_tile_propagate(int device, void* stream, double* out, const double* in, int ld, int nI, int nJ, const double* D_I,
-    const double* L_I, const double* D_J, const double* L_J, const double* Sbb, const double* SbI, int ldbI, const double* SbJ,
-    int ldbJ, const double* BnI, const double* BnJ, const double* R6, double T, double diag_noise, int is_diag) {
-    if (!out || !in || !D_I || !L_I || !D_J || !L_J || !Sbb || !SbI || !SbJ || !BnI || !BnJ || !R6 || nI < 1 || nJ < 1 || ld < 3 * nJ)
-        return EQF_ERR_INVALID;
-    HIPC(hipSetDevice(device));
-    TilePropArgs a{};
-    a.out = out; a.in = in; a.ld = ld; a.nI = nI; a.nJ = nJ;
-    a.DI = D_I; a.LI = L_I; a.DJ = D_J; a.LJ = L_J;
-    a.Sbb = Sbb; a.SbI = SbI; a.SbJ = SbJ; a.ldbI = ldbI; a.ldbJ = ldbJ;
-    a.BnI = BnI; a.BnJ = BnJ;
-    std::copy(R6, R6 + 6, a.R);
-    a.T = T; a.diagNoise = diag_noise; a.isDiag = is_diag ? 1 : 0;
-    hipLaunchKernelGGL(k_tile_propagate, dim3((nJ + 15) / 16, (nI + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), a);
-    HIPC(hipGetLastError());
-    return EQF_OK;
-}
-
-int eqf_tile_downdate(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb,
-    int k) {
-    if (!C || !A || !B || m < 1 || n < 1 || k < 1 || ldc < n || lda < m || ldb < n) return EQF_ERR_INVALID;
-    HIPC(hipSetDevice(device));
-    hipLaunchKernelGGL(k_tile_downdate, dim3((n + 63) / 64, (m + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), C, ldc, m, n, A, lda, B,
-        ldb, k);
-    HIPC(hipGetLastError());
-    return EQF_OK;
-}
-
-int eqf_tile_potrf(int device, void* stream, double* A, int ld, int n, double* drec, int* info) {
-    if (!A || !drec || n < 1 || ld < n) return EQF_ERR_INVALID;
-    HIPC(hipSetDevice(device));
-    static bool attr[64] = {};
-    if (device >= 0 && device < 64 && !attr[device]) {
-        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_potrf), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
-        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
-        attr[device] = true;
-    }
-    hipLaunchKernelGGL(k_tile_potrf, dim3(1), dim3(256), sizeof(Step64Lds), static_cast<hipStream_t>(stream), A, ld, n, drec, info);
-    HIPC(hipGetLastError());
-    return EQF_OK;
-}
-
-int eqf_tile_trsm(int device, void* stream, const double* A, int ld, int n, const double* drec, double* B, int ldb, int m, int right) {
-    if (!A || !drec || !B || n < 1 || m < 1 || ld < n || ldb < (right ? n : m)) return EQF_ERR_INVALID;
-    HIPC(hipSetDevice(device));
-    static bool attr[64] = {};
-    if (device >= 0 && device < 64 && !attr[device]) {
-        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
-        attr[device] = true;
-    }
-    hipLaunchKernelGGL(k_tile_trsm, dim3((m + kSB - 1) / kSB), dim3(256), sizeof(Step64Lds), static_cast<hipStream_t>(stream), A, ld, n, drec, B, ldb,
-        m, right ? 1 : 0);
-    HIPC(hipGetLastError());
     return EQF_OK;
 }
 

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void k_factor_first_sigma(UpdArgs a, ChainArgs
     if (bad && a.errflag && threadIdx.x == 0) atomicOr(a.errflag, 4);
 }
 // Stand-alone variant (tests / microbenchmarks without a prep launch): factor A_00 of each chain from ChainArgs::A.
-__global__ __launch_bounds__(256) void k_factor_first64(ChainArgs c0, ChainArgs c1, int* errflag) {
+inline __global__ __launch_bounds__(256) void k_factor_first64(ChainArgs c0, ChainArgs c1, int* errflag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
     const Lds64 s = ldsFull(smem64);
     const ChainArgs& ch = blockIdx.x ? c1 : c0;

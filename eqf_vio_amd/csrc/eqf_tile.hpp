@@ -7,9 +7,10 @@
 //                      one thread per 3x3 block, a workgroup = 16 x 16 landmark pairs; the rows G_i = L_i Sigma_bb + D_i Sigma_ib of
 //                      its 16 row landmarks are formed once per workgroup in LDS.  Needs nothing from any other rank: the
 //                      11 x n base panel and the per-landmark blocks are replicated.
-//   k_tile_downdate    C -= A^T B for A (k x m), B (k x n) row-major: the tile's share of Sigma - K C Sigma = Sigma - Y^T Y
-//                      (VIOFilter.cpp:297) from the solved block rows Y_k that the update's all-gather delivers; 64 x 64 outputs per
-//                      workgroup on v_mfma_f64_16x16x4_f64, operands staged through LDS in chunks of 32 rows.
+//   k_tile_gemm_tn     C += alpha A^T B for A (k x m), B (k x n) row-major: every dense product of the distributed update -- the trailing
+//                      updates of the two factorisations, the right-hand sides, the downdate Sigma - K C Sigma = Sigma - Y^T Y
+//                      (VIOFilter.cpp:297) and the reductions -- 128 x 128 outputs per workgroup on v_mfma_f64_16x16x4_f64, operands
+//                      double-buffered through LDS in chunks of 16 rows, XCD-contiguous tile order.
 //   k_tile_potrf       Cholesky of ONE n x n diagonal block of the distributed factorisation (S_kk / the Schur complement of
 //                      Sigma_e, VIOFilter.cpp:276, EqFMatrices.cpp:239), in place, by one workgroup in 64-wide block columns with the
 //                      building blocks of the single-GPU path (eqf_chol64.hpp: factor64, solveStrip, mmTile).  Leaves, per 64-wide
@@ -111,65 +112,123 @@ __global__ __launch_bounds__(256) void k_tile_propagate(TilePropArgs a) {
         }
 }
 
-// C (m x n, ldc) -= A^T B with A (k x m, lda), B (k x n, ldb), all row-major; k a multiple of 4 is NOT required (tail rows are
-// zero-filled).  grid = (ceil(n / 64), ceil(m / 64)), block = 256: each wave a 32 x 32 quadrant as 2 x 2 MFMA tiles.
-__global__ __launch_bounds__(256) void k_tile_downdate(double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k) {
-    constexpr int TS = 64, KC = 32;
-    __shared__ double sA[KC][TS + 1];
-    __shared__ double sB[KC][TS + 1];
+// ---- C (m x n, ldc) += alpha A^T B with A (k x m, lda), B (k x n, ldb), all row-major (every dense product of the distributed
+// update has this form once the factorisation keeps block ROWS: trailing updates U_ki^T U_kj, right-hand sides U_ki^T Y_kt, the
+// downdate Y_kI^T Y_kJ, the reductions Yn_k^T [Y_k | Yn_k]).  fp64 on v_mfma_f64_16x16x4_f64.
+// A 16x16x4 f64 MFMA occupies a SIMD's matrix pipe for 64 cycles (78.6 TFLOP/s over 1024 SIMDs), so the kernel is laid out for the
+// MEMORY side: a 64 x 64 output tile asks for 8 flop per staged operand byte = 9.8 TB/s of L2 traffic at peak -- more than the
+// fabric delivers; a 128 x 128 tile halves that.  One workgroup = 128 x 128 outputs, 4 waves of 64 x 64 (4 x 4 MFMA tiles, 128
+// accumulator registers), K in chunks of 16 rows: the next chunk's 32 KB travel global -> registers while the 64 MFMAs of the
+// current one (4096 matrix-pipe cycles per wave) run from LDS, one barrier per chunk (double-buffered LDS, row pitch 144 doubles:
+// rows 128 B apart modulo the 256 B bank window, so the four k rows of an operand fetch fall on disjoint banks).
+// Tile order: the linear workgroup index is dealt to the 8 XCDs round-robin by the hardware (L % 8); it is remapped so that each XCD
+// walks a CONTIGUOUS range of tiles in a grouped order (8 tile rows at a time, column by column): the panels of A and B a XCD's 32
+// resident workgroups read at any time are a handful of 128-column slices that stay in its 4 MB L2.
+// mask (rb > 0): C is the A-part of a block-cyclic local matrix whose strictly-lower blocks are never read (upper block rows of a
+// Cholesky): tiles whose rows all lie in blocks I > the blocks J of all their columns are skipped; row r belongs to global block
+// (rblk0 + r / rb) * Pr + pr, column c to (cblk0 + c / cb) * Pc + pc.
+struct GemmMask {
+    int rb, cb;          // rows / columns per block (0 = no mask)
+    int rblk0, Pr, pr;   // local row block index of C's first row, process grid rows, this rank's grid row
+    int cblk0, Pc, pc;
+};
+constexpr int kGemmTile = 128, kGemmKC = 16, kGemmPitch = 144;
+constexpr int kGemmLdsBytes = 2 * 2 * kGemmKC * kGemmPitch * 8;
+__global__ __launch_bounds__(256, 2) void k_tile_gemm_tn(double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k,
+    double alpha, GemmMask mk, int tm, int tn) {
+    extern __shared__ __attribute__((aligned(16))) double sGemm[];  // [2][2][KC][pitch]: buffer, operand
+    // ---- tile of this workgroup (XCD-contiguous grouped order)
+    const int T = tm * tn, per = (T + 7) / 8;
+    const int L = blockIdx.x, id = (L & 7) * per + (L >> 3);
+    if ((L >> 3) >= per || id >= T) return;
+    constexpr int G = 8;
+    const int grp = id / (G * tn), first = grp * G, gsz = min(tm - first, G);
+    const int ti = first + (id % (G * tn)) % gsz, tj = (id % (G * tn)) / gsz;
+    const int I0 = ti * kGemmTile, J0 = tj * kGemmTile;
+    if (mk.rb > 0) {
+        const int Ilo = (mk.rblk0 + I0 / mk.rb) * mk.Pr + mk.pr;
+        const int Jhi = (mk.cblk0 + (min(J0 + kGemmTile, n) - 1) / mk.cb) * mk.Pc + mk.pc;
+        if (Ilo > Jhi) return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int I0 = blockIdx.y * TS, J0 = blockIdx.x * TS;
-    const int qi = wv >> 1, qj = wv & 1, lr = lane & 15, lk = lane >> 4;
-    f64x4 acc[2][2];
+    const int wi = wv >> 1, wj = wv & 1, lr = lane & 15, lk = lane >> 4;
+    // 16-row / 16-column sub-tiles of this wave that hold anything (ragged edges, narrow products)
+    const int mu = max(0, min(4, (m - I0 - 64 * wi + 15) / 16)), nv = max(0, min(4, (n - J0 - 64 * wj + 15) / 16));
+    f64x4 acc[4][4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int v = 0; v < 4; ++v)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[u][v][q] = 0.0;
-    const int sr = tid >> 3, sc = (tid & 7) * 8;  // staging: row tid / 8 of the chunk, 8 consecutive columns
+    // staging: thread -> row tid / 16 of the chunk, 8 consecutive columns
+    const int sr = tid >> 4, sc = (tid & 15) * 8;
+    const bool fullA = I0 + kGemmTile <= m, fullB = J0 + kGemmTile <= n;
     double pa[8], pb[8];
     auto fetch = [&](int k0) {
         const int row = k0 + sr;
+        const double* ar = A + (long long)row * lda + I0 + sc;
+        const double* br = B + (long long)row * ldb + J0 + sc;
+        if (row < k && fullA) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int ca = I0 + sc + q, cb = J0 + sc + q;
-            pa[q] = (row < k && ca < m) ? A[(long long)row * lda + ca] : 0.0;
-            pb[q] = (row < k && cb < n) ? B[(long long)row * ldb + cb] : 0.0;
+            for (int q = 0; q < 8; ++q) pa[q] = ar[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pa[q] = (row < k && I0 + sc + q < m) ? ar[q] : 0.0;
+        }
+        if (row < k && fullB) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pb[q] = br[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pb[q] = (row < k && J0 + sc + q < n) ? br[q] : 0.0;
+        }
+    };
+    auto stage = [&](int buf) {
+        double* da = sGemm + ((buf * 2 + 0) * kGemmKC + sr) * kGemmPitch + sc;
+        double* db = sGemm + ((buf * 2 + 1) * kGemmKC + sr) * kGemmPitch + sc;
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+            *reinterpret_cast<f64x2*>(da + q) = f64x2{pa[q], pa[q + 1]};
+            *reinterpret_cast<f64x2*>(db + q) = f64x2{pb[q], pb[q + 1]};
         }
     };
     fetch(0);
-    for (int k0 = 0; k0 < k; k0 += KC) {
-        __syncthreads();
+    stage(0);
+    __syncthreads();
+    const int nc = (k + kGemmKC - 1) / kGemmKC;
+    for (int c = 0; c < nc; ++c) {
+        if (c + 1 < nc) fetch((c + 1) * kGemmKC);  // in flight during this chunk's MFMAs
+        const double* sa = sGemm + ((c & 1) * 2 + 0) * kGemmKC * kGemmPitch + 64 * wi + lr;
+        const double* sb = sGemm + ((c & 1) * 2 + 1) * kGemmKC * kGemmPitch + 64 * wj + lr;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            sA[sr][sc + q] = pa[q];
-            sB[sr][sc + q] = pb[q];
-        }
-        __syncthreads();
-        if (k0 + KC < k) fetch(k0 + KC);
+        for (int s = 0; s < kGemmKC / 4; ++s) {
+            double av[4], bv[4];
 #pragma unroll
-        for (int s = 0; s < KC / 4; ++s) {
-            double av[2], bv[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                av[u] = sA[4 * s + lk][32 * qi + 16 * u + lr];
-                bv[u] = sB[4 * s + lk][32 * qj + 16 * u + lr];
+            for (int u = 0; u < 4; ++u) {
+                av[u] = sa[(4 * s + lk) * kGemmPitch + 16 * u];
+                bv[u] = sb[(4 * s + lk) * kGemmPitch + 16 * u];
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int v = 0; v < 2; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[v], acc[u][v], 0, 0, 0);
+                for (int v = 0; v < 4; ++v)
+                    if (u < mu && v < nv) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[v], acc[u][v], 0, 0, 0);
         }
+        if (c + 1 < nc) stage((c + 1) & 1);
+        __syncthreads();
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int v = 0; v < 4; ++v)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int R = I0 + 32 * qi + 16 * u + (lane >> 4) + 4 * q, Cc = J0 + 32 * qj + 16 * v + lr;
-                if (R < m && Cc < n) C[(long long)R * ldc + Cc] -= acc[u][v][q];
+                const int R = I0 + 64 * wi + 16 * u + lk + 4 * q, Cc = J0 + 64 * wj + 16 * v + lr;
+                if (R < m && Cc < n) {
+                    double* cp = C + (long long)R * ldc + Cc;
+                    *cp = fma(alpha, acc[u][v][q], *cp);
+                }
             }
 }
 

@@ -1,0 +1,645 @@
+// C ABI of the 2-D block-partitioned filter (include/eqf_vio_amd.h, "eqf_tiled_*" and "eqf_tile_*"): the per-rank device side of
+// BASELINE configs[4].  Second translation unit of libeqf_vio_amd.so; kernels in eqf_tiled.hpp (replicated O(N) state, base panel,
+// local blocks) and eqf_tile.hpp (dense tile kernels of the distributed factorisations).  No CPU fallback: without a GPU
+// eqf_tiled_create fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/eqf_vio_amd.h"
+#include "eqf_tile.hpp"
+#include "eqf_tiled.hpp"
+
+using namespace eqf;
+
+#define HIPC(expr)                                                                              \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            std::fprintf(stderr, "eqf_vio_amd: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return EQF_ERR_HIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+
+namespace {
+// the caller's (torch's) current device is restored when an entry point returns
+struct DeviceScope {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceScope(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceScope() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) hipSetDevice(prev);
+    }
+};
+// > 64 KB of dynamic LDS needs the function attribute once per device
+int tileAttributes(int device) {
+    static std::mutex mu;
+    static std::vector<char> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (device < 0) return EQF_ERR_INVALID;
+    if ((int)done.size() <= device) done.resize(device + 1, 0);
+    if (done[device]) return EQF_OK;
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_potrf), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_gemm_tn), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLdsBytes));
+    done[device] = 1;
+    return EQF_OK;
+}
+template <typename T>
+int dmallocT(T** p, size_t count) {
+    HIPC(hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T)));
+    return EQF_OK;
+}
+}  // namespace
+
+struct eqf_tiled {
+    int cap = 0, device = 0, N = 0;
+    eqf_settings set{};
+    Params prm{};
+    hipStream_t stream = nullptr;
+    Glob* g[2] = {nullptr, nullptr};
+    double* Q[2] = {nullptr, nullptr};
+    double* Sb[2] = {nullptr, nullptr};
+    int pG = 0, pB = 0, ldb = 0;
+    double *p0 = nullptr, *lmc = nullptr, *blk = nullptr;
+    CommonLds* blkCommon = nullptr;
+    double *delta = nullptr, *Zrows = nullptr, *Vrows = nullptr, *Pg = nullptr, *Lgi = nullptr, *gamma = nullptr, *gammaTot = nullptr, *dBear = nullptr,
+           *dOut = nullptr;
+    int ldp = 0;
+    int* errflag = nullptr;
+    int *rowMap = nullptr, *colMap = nullptr;
+    int nlr = 0, nlc = 0;
+    // host mirror of the control flow (VIOFilter.cpp:120-131, :146-152, :234-236)
+    double curTime = -1.0;
+    bool init = false;
+};
+
+namespace {
+void freeTiled(eqf_tiled* t) {
+    if (!t) return;
+    for (int q = 0; q < 2; ++q) {
+        hipFree(t->g[q]);
+        hipFree(t->Q[q]);
+        hipFree(t->Sb[q]);
+    }
+    for (void* p : {(void*)t->p0, (void*)t->lmc, (void*)t->blk, (void*)t->blkCommon, (void*)t->delta, (void*)t->Zrows, (void*)t->Vrows, (void*)t->Pg,
+             (void*)t->Lgi, (void*)t->gamma, (void*)t->gammaTot, (void*)t->dBear, (void*)t->dOut, (void*)t->errflag, (void*)t->rowMap, (void*)t->colMap})
+        hipFree(p);
+    delete t;
+}
+// camera-offset constants, same formulas as on the device (and as eqf_create)
+void cameraConstants(Params& p) {
+    const quat cq = quat{p.camq[0], p.camq[1], p.camq[2], p.camq[3]};
+    const se3 camI = se3inv(se3{cq, mk3(p.camx[0], p.camx[1], p.camx[2])});
+    const m33 RIC = q2m(cq), RICt = q2m(qinv(cq)), RcI = q2m(camI.q);
+    for (int i = 0; i < 9; ++i) {
+        p.RIC[i] = RIC.a[i];
+        p.RICt[i] = RICt.a[i];
+        p.RcamI[i] = RcI.a[i];
+    }
+    p.camIq[0] = camI.q.w; p.camIq[1] = camI.q.x; p.camIq[2] = camI.q.y; p.camIq[3] = camI.q.z;
+    p.camIx[0] = camI.x.x; p.camIx[1] = camI.x.y; p.camIx[2] = camI.x.z;
+}
+int initTiledState(eqf_tiled* t) {
+    Glob g0;
+    std::memset(&g0, 0, sizeof(Glob));
+    g0.P0q[0] = 1.0;
+    g0.Aq[0] = 1.0;
+    for (int i = 0; i < 3; ++i) {
+        g0.bias[i] = t->set.initialOmegaBias[i];
+        g0.bias[3 + i] = t->set.initialAccelBias[i];
+    }
+    g0.curTime = -1.0;
+    std::vector<double> base((size_t)12 * t->ldb, 0.0);
+    for (int i = 0; i < 3; ++i) {
+        base[(size_t)i * t->ldb + i] = t->set.initialBiasOmegaVariance;
+        base[(size_t)(3 + i) * t->ldb + 3 + i] = t->set.initialBiasAccelVariance;
+        base[(size_t)(8 + i) * t->ldb + 8 + i] = t->set.initialVelocityVariance;
+    }
+    base[(size_t)6 * t->ldb + 6] = base[(size_t)7 * t->ldb + 7] = t->set.initialGravityVariance;
+    for (int q = 0; q < 2; ++q) {
+        HIPC(hipMemcpy(t->g[q], &g0, sizeof(Glob), hipMemcpyHostToDevice));
+        HIPC(hipMemset(t->Q[q], 0, sizeof(double) * 5 * t->cap));
+        HIPC(hipMemcpy(t->Sb[q], base.data(), sizeof(double) * 12 * t->ldb, hipMemcpyHostToDevice));
+    }
+    HIPC(hipMemset(t->p0, 0, sizeof(double) * 3 * t->cap));
+    HIPC(hipMemset(t->errflag, 0, sizeof(int)));
+    t->pG = t->pB = 0;
+    t->N = 0;
+    t->curTime = -1.0;
+    t->init = false;
+    return EQF_OK;
+}
+TlArgs propArgs(eqf_tiled* t, const ImuRec& r, int isImu, double* Sll, int ldl) {
+    TlArgs a{};
+    a.gin = t->g[t->pG];
+    a.gout = t->g[t->pG ^ 1];
+    a.p0 = t->p0;
+    a.Qin = t->Q[t->pG];
+    a.Qout = t->Q[t->pG ^ 1];
+    a.SbIn = t->Sb[t->pB];
+    a.SbOut = t->Sb[t->pB ^ 1];
+    a.ldb = t->ldb;
+    a.cap = t->cap;
+    a.inl = r;
+    a.isImu = isImu;
+    a.doRiccati = isImu ? (t->set.fastRiccati ? 0 : 1) : 1;  // VIOFilter.cpp:127, :233
+    a.blk = t->blk;
+    a.blkCommon = t->blkCommon;
+    a.errflag = t->errflag;
+    a.prm = t->prm;
+    a.Sll = Sll;
+    a.ldl = ldl;
+    a.nlr = t->nlr;
+    a.nlc = t->nlc;
+    a.rowMap = t->rowMap;
+    a.colMap = t->colMap;
+    return a;
+}
+}  // namespace
+
+extern "C" {
+
+int eqf_tiled_create(const eqf_settings* settings, int capacity_landmarks, int device, eqf_tiled** out) {
+    if (!settings || !out || capacity_landmarks < 1) return EQF_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return EQF_ERR_NO_DEVICE;
+    DeviceScope ds(device);
+    if (!ds.ok) return EQF_ERR_HIP;
+    eqf_tiled* t = new eqf_tiled();
+    t->cap = capacity_landmarks;
+    t->device = device;
+    t->set = *settings;
+    Params& p = t->prm;
+    p.biasOmegaProcessVariance = settings->biasOmegaProcessVariance;
+    p.biasAccelProcessVariance = settings->biasAccelProcessVariance;
+    p.gravityProcessVariance = settings->gravityProcessVariance;
+    p.velocityProcessVariance = settings->velocityProcessVariance;
+    p.pointProcessVariance = settings->pointProcessVariance;
+    p.velOmegaVariance = settings->velOmegaVariance;
+    p.velAccelVariance = settings->velAccelVariance;
+    p.measurementVariance = settings->measurementVariance;
+    p.initialPointVariance = settings->initialPointVariance;
+    std::memcpy(p.camq, settings->cameraOffset_q, sizeof(p.camq));
+    std::memcpy(p.camx, settings->cameraOffset_x, sizeof(p.camx));
+    p.useInnovationLift = settings->useInnovationLift;
+    p.useDiscreteInnovationLift = settings->useDiscreteInnovationLift;
+    p.useDiscreteVelocityLift = settings->useDiscreteVelocityLift;
+    cameraConstants(p);
+    const int cap = t->cap;
+    t->ldb = roundUp(kLm0 + 3 * cap, 16);
+    t->ldp = roundUp(3 * cap, 16);
+    int rc = EQF_OK;
+    auto chk = [&](int r) { if (r && !rc) rc = r; };
+    for (int q = 0; q < 2; ++q) {
+        chk(dmallocT(&t->g[q], 1));
+        chk(dmallocT(&t->Q[q], (size_t)5 * cap));
+        chk(dmallocT(&t->Sb[q], (size_t)12 * t->ldb));
+    }
+    chk(dmallocT(&t->p0, (size_t)3 * cap));
+    chk(dmallocT(&t->lmc, (size_t)15 * cap));
+    chk(dmallocT(&t->blk, (size_t)kBlkRec * cap));
+    chk(dmallocT(&t->blkCommon, 1));
+    chk(dmallocT(&t->delta, (size_t)2 * cap));
+    chk(dmallocT(&t->Zrows, (size_t)18 * cap));
+    chk(dmallocT(&t->Vrows, (size_t)12 * cap));
+    chk(dmallocT(&t->Pg, (size_t)5 * t->ldp));
+    chk(dmallocT(&t->Lgi, 32));
+    chk(dmallocT(&t->gamma, (size_t)kLm0 + 3 * cap));
+    chk(dmallocT(&t->gammaTot, (size_t)9 + 3 * cap));
+    chk(dmallocT(&t->dBear, (size_t)3 * cap));
+    chk(dmallocT(&t->dOut, (size_t)16 + 3 * cap));
+    chk(dmallocT(&t->errflag, 1));
+    chk(dmallocT(&t->rowMap, cap));
+    chk(dmallocT(&t->colMap, cap));
+    if (!rc) rc = initTiledState(t);
+    if (!rc) rc = tileAttributes(device);
+    if (rc) {
+        freeTiled(t);
+        return rc;
+    }
+    *out = t;
+    return EQF_OK;
+}
+
+void eqf_tiled_destroy(eqf_tiled* t) {
+    if (!t) return;
+    DeviceScope ds(t->device);
+    hipStreamSynchronize(t->stream);
+    freeTiled(t);
+}
+
+int eqf_tiled_set_stream(eqf_tiled* t, void* stream) {
+    if (!t) return EQF_ERR_INVALID;
+    DeviceScope ds(t->device);
+    HIPC(hipStreamSynchronize(t->stream));
+    t->stream = static_cast<hipStream_t>(stream);
+    return EQF_OK;
+}
+
+int eqf_tiled_set_geometry(eqf_tiled* t, int nlr, const int* rowMap, int nlc, const int* colMap) {
+    if (!t || nlr < 0 || nlc < 0 || nlr > t->cap || nlc > t->cap || (nlr && !rowMap) || (nlc && !colMap)) return EQF_ERR_INVALID;
+    for (int i = 0; i < nlr; ++i)
+        if (rowMap[i] < 0 || rowMap[i] >= t->cap) return EQF_ERR_INVALID;
+    for (int i = 0; i < nlc; ++i)
+        if (colMap[i] < 0 || colMap[i] >= t->cap) return EQF_ERR_INVALID;
+    DeviceScope ds(t->device);
+    HIPC(hipStreamSynchronize(t->stream));
+    if (nlr) HIPC(hipMemcpy(t->rowMap, rowMap, sizeof(int) * nlr, hipMemcpyHostToDevice));
+    if (nlc) HIPC(hipMemcpy(t->colMap, colMap, sizeof(int) * nlc, hipMemcpyHostToDevice));
+    t->nlr = nlr;
+    t->nlc = nlc;
+    return EQF_OK;
+}
+
+int eqf_tiled_propagate(eqf_tiled* t, double stamp, const double* omega, const double* accel, int is_imu, double* Sll, int ldl) {
+    if (!t || (is_imu && (!omega || !accel))) return EQF_ERR_INVALID;
+    if (t->N > 0 && t->nlr > 0 && t->nlc > 0 && (!Sll || ldl < 3 * t->nlc)) return EQF_ERR_INVALID;
+    DeviceScope ds(t->device);
+    if (!ds.ok) return EQF_ERR_HIP;
+    ImuRec r{};
+    r.stamp = stamp;
+    if (is_imu)
+        for (int i = 0; i < 3; ++i) {
+            r.w[i] = omega[i];
+            r.a[i] = accel[i];
+        }
+    // host mirror of the control flow (VIOFilter.cpp:120-131, :146-152, :207, :234-236)
+    int st = EQF_OK;
+    if (t->curTime < 0) st = EQF_SKIPPED_BEFORE_FIRST_IMU;
+    else if (!(stamp - t->curTime > 0)) st = EQF_SKIPPED_NONPOSITIVE_DT;
+    const bool step = st == EQF_OK;
+    const TlArgs a = propArgs(t, r, is_imu ? 1 : 0, Sll, ldl);
+    const int N = t->N;
+    hipLaunchKernelGGL(k_tl_build, dim3((std::max(N, 1) + 63) / 64 + 1), dim3(128), 0, t->stream, a);
+    hipLaunchKernelGGL(k_tl_base, dim3(std::max(1, (N + 255) / 256)), dim3(256), 0, t->stream, a);
+    if (step && a.doRiccati && N > 0 && t->nlr > 0 && t->nlc > 0)
+        hipLaunchKernelGGL(k_tl_riccati, dim3((t->nlc + 255) / 256, (t->nlr + kStreamRows - 1) / kStreamRows), dim3(256), 0, t->stream, a);
+    HIPC(hipGetLastError());
+    t->pG ^= 1;
+    t->pB ^= 1;
+    if (is_imu) t->init = true;
+    if (step || is_imu) t->curTime = stamp;
+    if (!is_imu && st == EQF_OK && !t->init) st = EQF_SKIPPED_NOT_INITIALISED;
+    return st;
+}
+
+int eqf_tiled_add_landmarks(eqf_tiled* t, int n, const double* bearings, double* Sll, int ldl) {
+    if (!t || n < 1 || !bearings) return EQF_ERR_INVALID;
+    if (n > t->cap) return EQF_ERR_CAPACITY;
+    if (t->N != 0) return EQF_ERR_UNSUPPORTED;
+    if (t->nlr > 0 && t->nlc > 0 && (!Sll || ldl < 3 * t->nlc)) return EQF_ERR_INVALID;
+    DeviceScope ds(t->device);
+    if (!ds.ok) return EQF_ERR_HIP;
+    HIPC(hipMemcpyAsync(t->dBear, bearings, sizeof(double) * 3 * n, hipMemcpyHostToDevice, t->stream));
+    hipLaunchKernelGGL(k_tl_append, dim3((n + 127) / 128), dim3(128), 0, t->stream, t->g[0], t->g[1], n, t->set.initialSceneDepth, t->cap, t->dBear, t->p0,
+        t->Q[0], t->Q[1], t->lmc, t->Sb[0], t->Sb[1], t->ldb, t->errflag);
+    if (t->nlr > 0 && t->nlc > 0)
+        hipLaunchKernelGGL(k_tl_init_local, dim3((t->nlc + 127) / 128, t->nlr), dim3(128), 0, t->stream, Sll, ldl, t->nlr, t->nlc, t->rowMap, t->colMap,
+            t->set.initialPointVariance);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(t->stream));  // (bearings is pageable host memory)
+    t->N = n;
+    return EQF_OK;
+}
+
+int eqf_tiled_update_prep(eqf_tiled* t, const double* bearings, const double* Sll, int ldl, double* M, int ldm, double* E, int lde, double* G11) {
+    if (!t || !bearings || !G11 || t->N < 1) return EQF_ERR_INVALID;
+    const bool local = t->nlr > 0 && t->nlc > 0;
+    if (local && (!Sll || !M || !E || ldl < 3 * t->nlc || ldm < 5 * t->nlc + kTlNarrowS || lde < 3 * t->nlc + kTlNarrowE)) return EQF_ERR_INVALID;
+    DeviceScope ds(t->device);
+    if (!ds.ok) return EQF_ERR_HIP;
+    const int N = t->N;
+    HIPC(hipMemcpyAsync(t->dBear, bearings, sizeof(double) * 3 * N, hipMemcpyHostToDevice, t->stream));
+    TlUpdArgs a{};
+    a.g = t->g[t->pG];
+    a.p0 = t->p0;
+    a.lmc = t->lmc;
+    a.Q = t->Q[t->pG];
+    a.Sb = t->Sb[t->pB];
+    a.ldb = t->ldb;
+    a.cap = t->cap;
+    a.bearings = t->dBear;
+    a.delta = t->delta;
+    a.Zrows = t->Zrows;
+    a.Vrows = t->Vrows;
+    a.Pg = t->Pg;
+    a.Lgi = t->Lgi;
+    a.ldp = t->ldp;
+    a.errflag = t->errflag;
+    a.prm = t->prm;
+    a.Sll = Sll;
+    a.ldl = ldl;
+    a.nlr = t->nlr;
+    a.nlc = t->nlc;
+    a.rowMap = t->rowMap;
+    a.colMap = t->colMap;
+    a.M = M;
+    a.ldm = ldm;
+    a.E = E;
+    a.lde = lde;
+    a.G11 = G11;
+    hipLaunchKernelGGL(k_tl_prep, dim3((N + 63) / 64), dim3(64), 0, t->stream, a);
+    hipLaunchKernelGGL(k_tl_eprep, dim3((3 * N + 255) / 256), dim3(256), 0, t->stream, a);
+    if (local) {
+        const dim3 grid((t->nlc + 255) / 256 + 1, (t->nlr + kStreamRows - 1) / kStreamRows);
+        hipLaunchKernelGGL(k_tl_form_s, grid, dim3(256), 0, t->stream, a);
+        hipLaunchKernelGGL(k_tl_form_e, grid, dim3(256), 0, t->stream, a);
+    }
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(t->stream));  // (bearings is pageable host memory)
+    return EQF_OK;
+}
+
+int eqf_tiled_update_finish(eqf_tiled* t, const double* acc, int ldacc, const double* Gnn, const double* G11) {
+    if (!t || !acc || !Gnn || !G11 || t->N < 1 || ldacc < 3 * t->N) return EQF_ERR_INVALID;
+    DeviceScope ds(t->device);
+    if (!ds.ok) return EQF_ERR_HIP;
+    TlFinArgs a{};
+    a.u.g = t->g[t->pG];
+    a.u.p0 = t->p0;
+    a.u.lmc = t->lmc;
+    a.u.Q = t->Q[t->pG];
+    a.u.cap = t->cap;
+    a.u.dbgDelta = t->delta;
+    a.u.dbgGamma = t->gamma;
+    a.u.dbgGammaTot = t->gammaTot;
+    a.u.errflag = t->errflag;
+    a.u.prm = t->prm;
+    a.acc = acc;
+    a.ldacc = ldacc;
+    a.Gnn = Gnn;
+    a.G11 = G11;
+    a.Sb = t->Sb[t->pB];
+    a.ldb = t->ldb;
+    hipLaunchKernelGGL(k_tl_finish, dim3(1), dim3(256), 0, t->stream, a);
+    HIPC(hipGetLastError());
+    return EQF_OK;
+}
+
+int eqf_tiled_synchronize(eqf_tiled* t) {
+    if (!t) return EQF_ERR_INVALID;
+    DeviceScope ds(t->device);
+    HIPC(hipStreamSynchronize(t->stream));
+    return EQF_OK;
+}
+int eqf_tiled_num_landmarks(eqf_tiled* t) { return t ? t->N : EQF_ERR_INVALID; }
+int eqf_tiled_get_time(eqf_tiled* t, double* time) {
+    if (!t || !time) return EQF_ERR_INVALID;
+    *time = t->curTime;
+    return EQF_OK;
+}
+int eqf_tiled_device_error(eqf_tiled* t) {
+    if (!t) return EQF_ERR_INVALID;
+    DeviceScope ds(t->device);
+    HIPC(hipStreamSynchronize(t->stream));
+    int e = 0;
+    HIPC(hipMemcpy(&e, t->errflag, sizeof(int), hipMemcpyDeviceToHost));
+    return e;
+}
+
+static int fetchGlob(eqf_tiled* t, Glob* g) {
+    HIPC(hipStreamSynchronize(t->stream));
+    HIPC(hipMemcpy(g, t->g[t->pG], sizeof(Glob), hipMemcpyDeviceToHost));
+    return EQF_OK;
+}
+
+int eqf_tiled_get_state_estimate(eqf_tiled* t, double* pose_q, double* pose_x, double* velocity, double* p) {
+    if (!t) return EQF_ERR_INVALID;
+    DeviceScope ds(t->device);
+    const int N = t->N;
+    hipLaunchKernelGGL(k_tl_state_estimate, dim3(std::max(1, (N + 127) / 128)), dim3(128), 0, t->stream, t->g[t->pG], t->p0, t->Q[t->pG], t->cap, t->dOut);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(t->stream));
+    std::vector<double> h((size_t)10 + 3 * N);
+    HIPC(hipMemcpy(h.data(), t->dOut, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    if (pose_q) std::copy(h.begin(), h.begin() + 4, pose_q);
+    if (pose_x) std::copy(h.begin() + 4, h.begin() + 7, pose_x);
+    if (velocity) std::copy(h.begin() + 7, h.begin() + 10, velocity);
+    if (p) std::copy(h.begin() + 10, h.end(), p);
+    return EQF_OK;
+}
+
+static int fetchSoA(eqf_tiled* t, const double* src, int rows, double* dst /* [N][rows] */) {
+    const int N = t->N, cap = t->cap;
+    std::vector<double> h((size_t)rows * cap);
+    HIPC(hipMemcpy(h.data(), src, sizeof(double) * rows * cap, hipMemcpyDeviceToHost));
+    for (int i = 0; i < N; ++i)
+        for (int c = 0; c < rows; ++c) dst[(size_t)i * rows + c] = h[(size_t)c * cap + i];
+    return EQF_OK;
+}
+
+int eqf_tiled_get_origin(eqf_tiled* t, double* pose_q, double* pose_x, double* velocity, double* p) {
+    if (!t) return EQF_ERR_INVALID;
+    DeviceScope ds(t->device);
+    Glob g;
+    int rc = fetchGlob(t, &g);
+    if (rc) return rc;
+    if (pose_q) std::copy(g.P0q, g.P0q + 4, pose_q);
+    if (pose_x) std::copy(g.P0x, g.P0x + 3, pose_x);
+    if (velocity) std::copy(g.v0, g.v0 + 3, velocity);
+    if (p) return fetchSoA(t, t->p0, 3, p);
+    return EQF_OK;
+}
+
+int eqf_tiled_get_group(eqf_tiled* t, double* A_q, double* A_x, double* w, double* Q_q, double* Q_a) {
+    if (!t) return EQF_ERR_INVALID;
+    DeviceScope ds(t->device);
+    Glob g;
+    int rc = fetchGlob(t, &g);
+    if (rc) return rc;
+    if (A_q) std::copy(g.Aq, g.Aq + 4, A_q);
+    if (A_x) std::copy(g.Ax, g.Ax + 3, A_x);
+    if (w) std::copy(g.w, g.w + 3, w);
+    if (Q_q || Q_a) {
+        std::vector<double> q5((size_t)5 * std::max(t->N, 1));
+        rc = fetchSoA(t, t->Q[t->pG], 5, q5.data());
+        if (rc) return rc;
+        for (int i = 0; i < t->N; ++i) {
+            if (Q_q) std::copy(q5.begin() + 5 * i, q5.begin() + 5 * i + 4, Q_q + 4 * i);
+            if (Q_a) Q_a[i] = q5[5 * i + 4];
+        }
+    }
+    return EQF_OK;
+}
+
+int eqf_tiled_get_bias(eqf_tiled* t, double* bias6) {
+    if (!t || !bias6) return EQF_ERR_INVALID;
+    DeviceScope ds(t->device);
+    Glob g;
+    int rc = fetchGlob(t, &g);
+    if (rc) return rc;
+    std::copy(g.bias, g.bias + 6, bias6);
+    return EQF_OK;
+}
+
+int eqf_tiled_get_integrator(eqf_tiled* t, double* currentVelocity6, double* accumulatedVelocity6, double* accumulatedTime, int* initialised) {
+    if (!t) return EQF_ERR_INVALID;
+    DeviceScope ds(t->device);
+    Glob g;
+    int rc = fetchGlob(t, &g);
+    if (rc) return rc;
+    if (currentVelocity6) std::copy(g.curVel, g.curVel + 6, currentVelocity6);
+    if (accumulatedVelocity6) std::copy(g.accVel, g.accVel + 6, accumulatedVelocity6);
+    if (accumulatedTime) *accumulatedTime = g.accTime;
+    if (initialised) *initialised = g.initialised;
+    return EQF_OK;
+}
+
+int eqf_tiled_get_last_update(eqf_tiled* t, double* delta, double* gamma, double* Gamma) {
+    if (!t) return EQF_ERR_INVALID;
+    DeviceScope ds(t->device);
+    HIPC(hipStreamSynchronize(t->stream));
+    const int N = t->N;
+    if (delta) HIPC(hipMemcpy(delta, t->delta, sizeof(double) * 2 * N, hipMemcpyDeviceToHost));
+    if (gamma) {
+        std::vector<double> h((size_t)kLm0 + 3 * N);
+        HIPC(hipMemcpy(h.data(), t->gamma, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+        std::copy(h.begin(), h.begin() + 11, gamma);
+        std::copy(h.begin() + kLm0, h.end(), gamma + 11);
+    }
+    if (Gamma) HIPC(hipMemcpy(Gamma, t->gammaTot, sizeof(double) * (9 + 3 * N), hipMemcpyDeviceToHost));
+    return EQF_OK;
+}
+
+int eqf_tiled_get_base(eqf_tiled* t, double* dst, int ld) {
+    if (!t || !dst || ld < 11 + 3 * t->N) return EQF_ERR_INVALID;
+    DeviceScope ds(t->device);
+    HIPC(hipStreamSynchronize(t->stream));
+    const int N = t->N;
+    std::vector<double> h((size_t)12 * t->ldb);
+    HIPC(hipMemcpy(h.data(), t->Sb[t->pB], sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    for (int r = 0; r < 11; ++r) {
+        for (int c = 0; c < 11; ++c) dst[(size_t)r * ld + c] = h[(size_t)r * t->ldb + c];
+        for (int c = 0; c < 3 * N; ++c) dst[(size_t)r * ld + 11 + c] = h[(size_t)r * t->ldb + kLm0 + c];
+    }
+    return EQF_OK;
+}
+
+int eqf_tiled_set_state(eqf_tiled* t, int N, const double* pose_q, const double* pose_x, const double* velocity, const double* p0,
+    const double* A_q, const double* A_x, const double* w, const double* Q_q, const double* Q_a, const double* bias6, const double* sigma_base,
+    int ld, double currentTime, const double* currentVelocity6, const double* accumulatedVelocity6, double accumulatedTime, int initialised) {
+    if (!t || N < 0 || !pose_q || !pose_x || !velocity || !A_q || !A_x || !w || !bias6 || !sigma_base || ld < 11 + 3 * N) return EQF_ERR_INVALID;
+    if (N > 0 && (!p0 || !Q_q || !Q_a)) return EQF_ERR_INVALID;
+    if (N > t->cap) return EQF_ERR_CAPACITY;
+    DeviceScope ds(t->device);
+    HIPC(hipStreamSynchronize(t->stream));
+    const int cap = t->cap;
+    Glob g;
+    std::memset(&g, 0, sizeof(Glob));
+    std::copy(pose_q, pose_q + 4, g.P0q);
+    std::copy(pose_x, pose_x + 3, g.P0x);
+    std::copy(velocity, velocity + 3, g.v0);
+    std::copy(A_q, A_q + 4, g.Aq);
+    std::copy(A_x, A_x + 3, g.Ax);
+    std::copy(w, w + 3, g.w);
+    std::copy(bias6, bias6 + 6, g.bias);
+    if (currentVelocity6) std::copy(currentVelocity6, currentVelocity6 + 6, g.curVel);
+    if (accumulatedVelocity6) std::copy(accumulatedVelocity6, accumulatedVelocity6 + 6, g.accVel);
+    g.accTime = accumulatedTime;
+    g.curTime = currentTime;
+    g.initialised = initialised ? 1 : 0;
+    g.N = N;
+    std::vector<double> hp((size_t)3 * cap, 0.0), hq((size_t)5 * cap, 0.0), hb((size_t)12 * t->ldb, 0.0);
+    for (int i = 0; i < N; ++i) {
+        for (int c = 0; c < 3; ++c) hp[(size_t)c * cap + i] = p0[3 * i + c];
+        for (int c = 0; c < 4; ++c) hq[(size_t)c * cap + i] = Q_q[4 * i + c];
+        hq[(size_t)4 * cap + i] = Q_a[i];
+    }
+    for (int r = 0; r < 11; ++r) {
+        for (int c = 0; c < 11; ++c) hb[(size_t)r * t->ldb + c] = sigma_base[(size_t)r * ld + c];
+        for (int c = 0; c < 3 * N; ++c) hb[(size_t)r * t->ldb + kLm0 + c] = sigma_base[(size_t)r * ld + 11 + c];
+    }
+    for (int q = 0; q < 2; ++q) {
+        HIPC(hipMemcpy(t->g[q], &g, sizeof(Glob), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(t->Q[q], hq.data(), sizeof(double) * hq.size(), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(t->Sb[q], hb.data(), sizeof(double) * hb.size(), hipMemcpyHostToDevice));
+    }
+    HIPC(hipMemcpy(t->p0, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice));
+    for (int q = 0; q < 2; ++q) {
+        hipLaunchKernelGGL(k_tl_restore, dim3(std::max(1, (N + 127) / 128)), dim3(128), 0, t->stream, t->g[q], t->p0, t->lmc, cap, t->errflag);
+    }
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(t->stream));
+    t->N = N;
+    t->curTime = currentTime;
+    t->init = initialised != 0;
+    return EQF_OK;
+}
+
+// ---- dense tile kernels ------------------------------------------------------------------------------------------------------
+int eqf_tile_gemm_tn(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k,
+    double alpha, int mask_rb, int mask_cb, int rblk0, int Pr, int pr, int cblk0, int Pc, int pc) {
+    if (!C || !A || !B || m < 1 || n < 1 || k < 1 || ldc < n || lda < m || ldb < n) return EQF_ERR_INVALID;
+    if (mask_rb < 0 || mask_cb < 0 || ((mask_rb > 0) != (mask_cb > 0)) || (mask_rb > 0 && (Pr < 1 || Pc < 1))) return EQF_ERR_INVALID;
+    DeviceScope ds(device);
+    if (!ds.ok) return EQF_ERR_HIP;
+    int rc = tileAttributes(device);
+    if (rc) return rc;
+    GemmMask mk{mask_rb, mask_cb, rblk0, Pr, pr, cblk0, Pc, pc};
+    const int tm = (m + kGemmTile - 1) / kGemmTile, tn = (n + kGemmTile - 1) / kGemmTile;
+    const long long T = (long long)tm * tn;
+    const int grid = int(8 * ((T + 7) / 8));
+    hipLaunchKernelGGL(k_tile_gemm_tn, dim3(grid), dim3(256), kGemmLdsBytes, static_cast<hipStream_t>(stream), C, ldc, m, n, A, lda, B, ldb, k, alpha, mk, tm,
+        tn);
+    HIPC(hipGetLastError());
+    return EQF_OK;
+}
+
+int eqf_tile_downdate(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k) {
+    return eqf_tile_gemm_tn(device, stream, C, ldc, m, n, A, lda, B, ldb, k, -1.0, 0, 0, 0, 1, 0, 0, 1, 0);
+}
+
+int eqf_tile_propagate(int device, void* stream, double* out, const double* in, int ld, int nI, int nJ, const double* D_I,
+    const double* L_I, const double* D_J, const double* L_J, const double* Sbb, const double* SbI, int ldbI, const double* SbJ,
+    int ldbJ, const double* BnI, const double* BnJ, const double* R6, double T, double diag_noise, int is_diag) {
+    if (!out || !in || !D_I || !L_I || !D_J || !L_J || !Sbb || !SbI || !SbJ || !BnI || !BnJ || !R6 || nI < 1 || nJ < 1 || ld < 3 * nJ ||
+        ldbI < 3 * nI || ldbJ < 3 * nJ)
+        return EQF_ERR_INVALID;
+    DeviceScope ds(device);
+    if (!ds.ok) return EQF_ERR_HIP;
+    TilePropArgs a{};
+    a.out = out; a.in = in; a.ld = ld; a.nI = nI; a.nJ = nJ;
+    a.DI = D_I; a.LI = L_I; a.DJ = D_J; a.LJ = L_J;
+    a.Sbb = Sbb; a.SbI = SbI; a.SbJ = SbJ; a.ldbI = ldbI; a.ldbJ = ldbJ;
+    a.BnI = BnI; a.BnJ = BnJ;
+    std::copy(R6, R6 + 6, a.R);
+    a.T = T; a.diagNoise = diag_noise; a.isDiag = is_diag ? 1 : 0;
+    hipLaunchKernelGGL(k_tile_propagate, dim3((nJ + 15) / 16, (nI + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    HIPC(hipGetLastError());
+    return EQF_OK;
+}
+
+int eqf_tile_potrf(int device, void* stream, double* A, int ld, int n, double* drec, int* info) {
+    if (!A || !drec || n < 1 || ld < n) return EQF_ERR_INVALID;
+    DeviceScope ds(device);
+    if (!ds.ok) return EQF_ERR_HIP;
+    int rc = tileAttributes(device);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tile_potrf, dim3(1), dim3(256), sizeof(Step64Lds), static_cast<hipStream_t>(stream), A, ld, n, drec, info);
+    HIPC(hipGetLastError());
+    return EQF_OK;
+}
+
+int eqf_tile_trsm(int device, void* stream, const double* A, int ld, int n, const double* drec, double* B, int ldb, int m, int right) {
+    if (!A || !drec || !B || n < 1 || m < 1 || ld < n || ldb < (right ? n : m)) return EQF_ERR_INVALID;
+    DeviceScope ds(device);
+    if (!ds.ok) return EQF_ERR_HIP;
+    int rc = tileAttributes(device);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tile_trsm, dim3((m + kSB - 1) / kSB), dim3(256), sizeof(Step64Lds), static_cast<hipStream_t>(stream), A, ld, n, drec, B, ldb,
+        m, right ? 1 : 0);
+    HIPC(hipGetLastError());
+    return EQF_OK;
+}
+
+}  // extern "C"

@@ -718,7 +718,7 @@ __global__ __launch_bounds__(256) void k_chol_step(ChainArgs c0, ChainArgs c1, i
 //   gamma[col] = sum_r Y[r][col] z[r]  (z = Y[:, 11]),  hV = (L^-1 V)^T z,  G11 = [Zt | Et]^T [Zt | Et].
 // grid.x = colBlocks (64 columns of Y each) + 1 (the E-chain block), grid.y = B, block = 256.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_update_reduce(UpdArgs a, int colBlocks) {
+inline __global__ __launch_bounds__(1024) void k_update_reduce(UpdArgs a, int colBlocks) {
     const int b = blockIdx.y;
     const Glob& g = a.g[b];
     if (!g.updateOk || g.N == 0) return;

@@ -1,368 +1,537 @@
-"""Sigma 2-D block-partitioned over a process grid (BASELINE configs[4]: N = 4000 landmarks, Sigma = 1.15 GB fp64, SURVEY.md
-8(e) row 2) -- the exchange schedule and the tile-local mathematics, one process per GPU over torch.distributed (backend
-"nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+"""One EqF filter with Sigma 2-D block-partitioned over a process grid -- BASELINE configs[4] (N = 4000 landmarks, Sigma = 1.15 GB
+fp64), SURVEY.md 8(e) row 2.  One process per GPU over torch.distributed (backend "nccl" = RCCL over xGMI on a GPU node, "gloo" in
+the CPU tests); the host side of eqf_vio/include/eqf_vio/VIOFilter.h:41-88 for this configuration: `TiledFilter.processIMUData`,
+`processVisionData`, `stateEstimate`, `stateCovariance`.
 
 What is partitioned.  Sigma in the reference's index map (eqf_vio/src/VIOFilter.cpp:54-57): 11 base coordinates, then 3 per
-landmark.  Landmarks are cut into blocks of `bl`; the landmark-landmark part of Sigma is an nb x nb grid of (3 bl x 3 bl) tiles
-dealt block-cyclically over a Pr x Pc process grid (tile (I, J) lives on process (I mod Pr, J mod Pc); 2 x 4 for one 8-GPU
-node).  The 11 x n base panel (88 KB per 1000 landmarks) is REPLICATED on every rank, and so is the O(N) filter state.
+landmark.  Landmarks are cut into blocks of `bl`; process (pr, pc) of the Pr x Pc grid owns the landmark blocks I = pr, pr + Pr, ...
+as rows and J = pc, pc + Pc, ... as columns of ONE dense local matrix Sll (3 nlr x 3 nlc, ScaLAPACK's block-cyclic local storage), so
+every step is a handful of launches over the whole local matrix.  The 11-row base panel Sigma[0:11, :] (88 KB per 1000 landmarks) and
+the O(N) filter state are REPLICATED: every rank advances its own identical copy (csrc/eqf_tiled.hpp, the device functions of the
+single-GPU path).  Pr must divide Pc (1 x 1, 1 x 2, 2 x 2, 2 x 4 for one 8-GPU node, 1 x 8).
 
 Riccati propagate (VIOFilter.cpp:160-194), F = I + T A_b = [[F_bb, 0], [L, D]] with D block-diagonal:
-    Sigma'_IJ = (D_I Sigma_IJ + L_I Sigma_bJ) D_J^T + (L_I Sigma_bb + D_I Sigma_Ib) L_J^T + Q_IJ      tile-local
+    Sigma'_IJ = (D_I Sigma_IJ + L_I Sigma_bJ) D_J^T + (L_I Sigma_bb + D_I Sigma_Ib) L_J^T + Q_IJ      local, in place
     Sigma'_bJ = F_bb (Sigma_bb L_J^T + Sigma_bJ D_J^T) + Q_bJ ,  Sigma'_bb = F_bb Sigma_bb F_bb^T + Q_bb   replicated
-  -> NO communication: every rank advances its own tiles and its copy of the base panel.
+  -> NO communication.
 
-Update (VIOFilter.cpp:264-297) in the Cholesky form the single-GPU path uses (csrc/eqf_update.hpp):
-    S_IJ = C_I Sigma_IJ C_J^T (+ R)          tile-local (C is block diagonal, EqFMatrices.cpp:319-344)
-    S = L L^T, Y = L^-1 [C Sigma | delta]    blocked right-looking Cholesky over the process grid, block column k:
-        1. the owner of S_kk factors it and broadcasts L_kk                                   (one broadcast, 2bl x 2bl)
-        2. the owners solve their panel blocks L_ik = S_ik L_kk^-T and right-hand-side tiles Y_kt = L_kk^-1 W_kt
-        3. the panel column and the block row Y_k are gathered to every rank                  (one all-gather each)
-        4. every rank updates its own trailing tiles S_ij -= L_ik L_jk^T, W_it -= L_ik Y_kt, and -- with Y_k at hand --
-           its share of the downdate Sigma_IJ -= Y_kI^T Y_kJ and of gamma = K delta = sum_k Y_k^T z_k   (no further traffic)
-    the base panel is downdated from the same Y_k on every rank (replicated, identical arithmetic).
-  Per update every rank receives the lower half of L once (m^2/2 values) and Y once (m n values): at N = 4000 that is
-  0.26 + 0.77 GB against 4.6e12 flops / 8 -- communication-bound on xGMI unless panels are restricted to the process rows /
-  columns that need them (SUMMA); the schedule below gathers to all ranks because that is the simplest correct one.
-bundleLift's weights (EqFMatrices.cpp:239, Sigma_e = Sigma[6:, 6:]) come from the same distributed solver after the five base
-coordinates of Sigma_e have been eliminated locally (a Schur complement every rank can form from the replicated panel).
+Update (VIOFilter.cpp:264-297) in the Cholesky form of the single-GPU path (csrc/eqf_update.hpp): S = U^T U, Y = U^-T [C Sigma | C
+Sigma_b, delta, V], gamma = Y^T z, Sigma <- Sigma - Y^T Y; bundleLift's weights (EqFMatrices.cpp:239) from a second factorisation, of
+the Schur complement of Sigma_e = Sigma[6:, 6:] after its five base coordinates.  Both run through `_chain`: a right-looking blocked
+Cholesky that keeps block ROWS (upper factor), so that every dense product has the one form C += alpha A^T B (eqf_tile_gemm_tn).
+Per block row k (owner process row k mod Pr):
+    1. the owner of the diagonal block factors it (eqf_tile_potrf) and broadcasts L_kk ALONG ITS PROCESS ROW;
+    2. that process row solves its pieces of block row k in place:  [U_k,k+1.. | Y_k] = L_kk^-1 [A_k,k+1.. | W_k]  (eqf_tile_trsm);
+    3. every rank of the row broadcasts its solved piece DOWN ITS PROCESS COLUMN  (-> the "B operand" of every product);
+    4. the ranks (pr, c) with c = pr mod Pr re-broadcast the piece they just received ALONG THEIR PROCESS ROW; interleaved these give
+       the "A operand": the blocks U_ki / Y_kI of the rank's own ROW blocks (this needs Pr | Pc);
+    5. trailing updates of the local matrix, the rank's share of the downdate Sigma_IJ -= Y_kI^T Y_kJ and of the reductions -- no
+       further traffic.
+  A rank receives (1/Pr + 1/Pc) of every block row instead of all of it (SUMMA-restricted; the round-2 prototype gathered every panel
+  to every rank): at N = 4000 on 2 x 4 that is 0.75 x (0.26 + 0.77) GB per update.
 
-Status: design + exchange schedule validated on CPU with gloo against the single-process fp64 reference filter
-(tests/test_tiled.py, tile-local mathematics in torch).  On a GPU the two operations that touch every tile every step -- the
-Riccati step and the downdate -- run in hand-written tile kernels behind the C ABI (eqf_tile_propagate, eqf_tile_downdate:
-csrc/eqf_tile.hpp, called on the torch tensors' device pointers; ProcessGrid(..., kernels=TileKernels(dev))), checked on the
-MI355X against the torch path (tests/test_gpu_tiled.py); the panel operations of the distributed Cholesky (potrf / trsm of
-2bl x 2bl blocks) are still torch (rocBLAS / rocSOLVER).  A measured 8-GPU run is outstanding: no 8-GPU node has been available
-to this build.
+The tile mathematics is NOT here: `HipBackend` calls the HIP kernels through the C ABI (include/eqf_vio_amd.h, eqf_tiled_* /
+eqf_tile_*) on torch CUDA tensors' device pointers, and fails loudly without the library or a GPU.  The CPU tests drive the same
+schedule with a test double of the backend (tests/tiled_double.py) over gloo.
 """
 import ctypes
 
+import numpy as np
 import torch
 
+NARROW_S = 18  # (C Sigma)_Ib (11) | delta | V (6)
+NARROW_E = 11  # Z_P (6) | E_top (5)
 
-class TileKernels:
-    """The tile kernels of csrc/eqf_tile.hpp through the C ABI, on torch CUDA tensors (their device pointers) and torch's
-    current stream, so that they order with the torch operations around them."""
 
-    def __init__(self, device_index=0):
-        from . import binding
+class BlockCyclic:
+    """Geometry of the partition: N landmarks in blocks of bl, block I on process row I mod Pr, block J on process column J mod Pc."""
 
-        self.lib = binding.lib()
-        self.dev = int(device_index)
-        self._dp = ctypes.POINTER(ctypes.c_double)
+    def __init__(self, N, bl, Pr, Pc, pr, pc):
+        assert N >= 1 and bl >= 1 and Pc % Pr == 0, "the process grid needs Pr | Pc"
+        self.N, self.bl, self.Pr, self.Pc, self.pr, self.pc = N, bl, Pr, Pc, pr, pc
+        self.nb = (N + bl - 1) // bl
+        self.row_blocks = list(range(pr, self.nb, Pr))
+        self.col_blocks = list(range(pc, self.nb, Pc))
+        self.rowMap = self.landmarks_of(self.row_blocks)
+        self.colMap = self.landmarks_of(self.col_blocks)
+        self.nlr, self.nlc = len(self.rowMap), len(self.colMap)
 
-    def _stream(self):
-        return ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+    def block_size(self, b):
+        return min(self.bl, self.N - b * self.bl)
+
+    def landmarks_of(self, blocks):
+        out = [np.arange(b * self.bl, b * self.bl + self.block_size(b), dtype=np.int32) for b in blocks]
+        return np.concatenate(out) if out else np.zeros(0, dtype=np.int32)
+
+    def ncols_of(self, c):
+        """landmarks in the local columns of process column c"""
+        return sum(self.block_size(b) for b in range(c, self.nb, self.Pc))
 
     @staticmethod
-    def _p(t):
-        return ctypes.c_void_p(t.data_ptr())
-
-    def propagate(self, inp, nI, nJ, D_I, L_I, D_J, L_J, Sbb, SbI, ldbI, SbJ, ldbJ, BnI, BnJ, R6, T, diag_noise, is_diag):
-        out = torch.empty_like(inp)
-        r6 = (ctypes.c_double * 6)(*[float(x) for x in R6])
-        rc = self.lib.eqf_tile_propagate(self.dev, self._stream(), self._p(out), self._p(inp), inp.stride(0), nI, nJ, self._p(D_I), self._p(L_I),
-                                         self._p(D_J), self._p(L_J), self._p(Sbb), self._p(SbI), ldbI, self._p(SbJ), ldbJ, self._p(BnI),
-                                         self._p(BnJ), ctypes.cast(r6, self._dp), float(T), float(diag_noise), int(is_diag))
-        if rc:
-            raise RuntimeError(f"eqf_tile_propagate failed with status {rc}")
-        return out
-
-    def downdate(self, C, A, B):
-        """C -= A^T B in place (C m x n, A k x m, B k x n; row-major, unit column stride)."""
-        if A.stride(1) != 1:
-            A = A.contiguous()  # (LAPACK-backed torch solves hand back column-major strides)
-        if B.stride(1) != 1:
-            B = B.contiguous()
-        assert C.stride(1) == 1
-        rc = self.lib.eqf_tile_downdate(self.dev, self._stream(), self._p(C), C.stride(0), C.shape[0], C.shape[1], self._p(A), A.stride(0),
-                                        self._p(B), B.stride(0), A.shape[0])
-        if rc:
-            raise RuntimeError(f"eqf_tile_downdate failed with status {rc}")
-
-
-    DREC = 64 * 64 + 4 * 16 * 16  # doubles per 64-wide block column: L_jj and the inverses of its four 16 x 16 diagonal blocks
-
-    def potrf(self, A):
-        """Cholesky of the n x n block A (lower triangle read): returns (L, drec); L = the lower-triangular factor (fresh tensor),
-        drec = the diagonal-factor records trsm() multiplies with."""
-        n = A.shape[0]
-        L = torch.tril(A).contiguous()
-        drec = torch.empty(((n + 63) // 64) * self.DREC, dtype=torch.float64, device=A.device)
-        info = torch.zeros(1, dtype=torch.int32, device=A.device)
-        rc = self.lib.eqf_tile_potrf(self.dev, self._stream(), self._p(L), L.stride(0), n, self._p(drec), self._p(info))
-        if rc:
-            raise RuntimeError(f"eqf_tile_potrf failed with status {rc}")
-        self._info = info  # checked by the caller when it synchronises anyway (dist_chol_solve: after the broadcast)
-        return L, drec
-
-    def trsm(self, L, drec, B, right):
-        """right: B (m x n) <- B L^-T ; left: B (n x m) <- L^-1 B.  Returns the solved block (B is copied first)."""
-        X = B.contiguous().clone()
-        m = X.shape[0] if right else X.shape[1]
-        rc = self.lib.eqf_tile_trsm(self.dev, self._stream(), self._p(L), L.stride(0), L.shape[0], self._p(drec), self._p(X), X.stride(0), m,
-                                    1 if right else 0)
-        if rc:
-            raise RuntimeError(f"eqf_tile_trsm failed with status {rc}")
-        return X
+    def blocks_upto(k, p, P):
+        """number of blocks b <= k with b mod P == p"""
+        return (k - p) // P + 1 if k >= p else 0
 
 
 class ProcessGrid:
-    """Pr x Pc process grid over a torch.distributed group; tile (I, J) -> rank (I mod Pr) * Pc + (J mod Pc)."""
+    """Pr x Pc process grid over a torch.distributed group, rank = pr * Pc + pc, with one sub-group per process row / column."""
 
-    def __init__(self, dist, Pr, Pc, device="cpu", kernels=None):
-        self.dist, self.Pr, self.Pc = dist, Pr, Pc
-        self.kernels = kernels  # TileKernels (GPU) or None (tile mathematics in torch)
+    def __init__(self, dist, Pr, Pc, device="cpu"):
+        self.dist, self.Pr, self.Pc, self.device = dist, Pr, Pc, device
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
-        assert self.world == Pr * Pc
+        assert self.world == Pr * Pc and Pc % Pr == 0
         self.pr, self.pc = divmod(self.rank, Pc)
-        self.device = device
+        self.row_group = self.col_group = None
+        if dist is not None and self.world > 1:
+            # (new_group is collective over the whole job: every rank creates every group, in the same order)
+            for r in range(Pr):
+                grp = dist.new_group([r * Pc + c for c in range(Pc)])
+                if r == self.pr:
+                    self.row_group = grp
+            for c in range(Pc):
+                grp = dist.new_group([r * Pc + c for r in range(Pr)])
+                if c == self.pc:
+                    self.col_group = grp
 
-    def owner(self, I, J):
-        return (I % self.Pr) * self.Pc + (J % self.Pc)
-
-    def mine(self, I, J):
-        return self.owner(I, J) == self.rank
-
-    def bcast(self, t, src):
-        if self.dist is not None and self.world > 1:
-            self.dist.broadcast(t, src=src)
+    def bcast_row(self, t, root_pc):
+        if self.Pc > 1:
+            self.dist.broadcast(t, src=self.pr * self.Pc + root_pc, group=self.row_group)
         return t
 
-    def allgather_blocks(self, mine, shape):
-        """mine: {key: tensor(shape)} of the blocks this rank contributes; returns {key: tensor} of everybody's.  One
-        all-gather of a padded [slots, *shape] buffer + an int key table (ragged counts per rank)."""
-        if self.dist is None or self.world == 1:
-            return dict(mine)
-        cnt = torch.tensor([len(mine)], dtype=torch.int64, device=self.device)
-        cnts = [torch.zeros_like(cnt) for _ in range(self.world)]
-        self.dist.all_gather(cnts, cnt)
-        slots = max(int(c.item()) for c in cnts)
-        if slots == 0:
-            return {}
-        buf = torch.zeros((slots,) + tuple(shape), dtype=torch.float64, device=self.device)
-        keys = torch.full((slots, 2), -1, dtype=torch.int64, device=self.device)
-        for s, (k, v) in enumerate(sorted(mine.items())):
-            buf[s] = v
-            keys[s, 0], keys[s, 1] = k
-        bufs = [torch.empty_like(buf) for _ in range(self.world)]
-        keyss = [torch.empty_like(keys) for _ in range(self.world)]
-        self.dist.all_gather(bufs, buf)
-        self.dist.all_gather(keyss, keys)
-        out = {}
-        for r in range(self.world):
-            for s in range(int(cnts[r].item())):
-                out[(int(keyss[r][s, 0]), int(keyss[r][s, 1]))] = bufs[r][s]
+    def bcast_col(self, t, root_pr):
+        if self.Pr > 1:
+            self.dist.broadcast(t, src=root_pr * self.Pc + self.pc, group=self.col_group)
+        return t
+
+    def allgather_row(self, t):
+        if self.Pc == 1:
+            return [t]
+        out = [torch.empty_like(t) for _ in range(self.Pc)]
+        self.dist.all_gather(out, t, group=self.row_group)
+        return out
+
+    def allgather_all(self, t):
+        if self.world == 1:
+            return [t]
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
         return out
 
 
-class TiledSigma:
-    """The rank's share of Sigma: owned landmark tiles {(I, J): (3bl x 3bl)}, replicated base block Sbb (11 x 11) and base panel
-    Sb (11 x 3N)."""
+class HipBackend:
+    """The per-rank device side through the C ABI: an eqf_tiled handle (replicated state + base panel) and the dense tile kernels, on
+    torch CUDA tensors of `device_index` and torch's current stream."""
 
-    def __init__(self, grid, N, bl):
-        assert N % bl == 0, "the prototype wants whole landmark blocks"
-        self.g, self.N, self.bl, self.nb = grid, N, bl, N // bl
-        self.t = {}
-        self.Sbb = None
-        self.Sb = None
+    DREC = 64 * 64 + 4 * 16 * 16  # doubles per 64-wide block column of a diagonal-factor record
 
-    @classmethod
-    def from_dense(cls, grid, Sigma, bl):
-        """Scatter by slicing a dense Sigma every rank holds (test set-up / restart from a single-GPU snapshot)."""
-        S = torch.as_tensor(Sigma, dtype=torch.float64, device=grid.device)
-        N = (S.shape[0] - 11) // 3
-        ts = cls(grid, N, bl)
-        ts.Sbb = S[:11, :11].clone()
-        ts.Sb = S[:11, 11:].clone()
-        w = 3 * bl
-        for I in range(ts.nb):
-            for J in range(ts.nb):
-                if grid.mine(I, J):
-                    ts.t[(I, J)] = S[11 + I * w:11 + (I + 1) * w, 11 + J * w:11 + (J + 1) * w].clone()
-        return ts
+    def __init__(self, settings, capacity, device_index=0):
+        from . import binding
 
-    def to_dense(self):
-        """Gather to a dense Sigma on every rank (tests, snapshots)."""
-        w = 3 * self.bl
-        allt = self.g.allgather_blocks(self.t, (w, w))
-        n = 11 + 3 * self.N
-        S = torch.zeros((n, n), dtype=torch.float64, device=self.g.device)
-        S[:11, :11] = self.Sbb
-        S[:11, 11:] = self.Sb
-        S[11:, :11] = self.Sb.T
-        for (I, J), v in allt.items():
-            S[11 + I * w:11 + (I + 1) * w, 11 + J * w:11 + (J + 1) * w] = v
+        self.b = binding
+        self.lib = binding.lib()  # raises when libeqf_vio_amd.so is missing: there is no CPU fallback
+        if isinstance(settings, dict):
+            settings = binding.settings_from_dict(settings)
+        self.settings = settings
+        self.dev = int(device_index)
+        self.device = torch.device("cuda", self.dev)
+        self.cap = int(capacity)
+        self._h = ctypes.c_void_p()
+        binding._check(self.lib.eqf_tiled_create(ctypes.byref(settings), self.cap, self.dev, ctypes.byref(self._h)), "eqf_tiled_create")
+        self._stream = None
+        self._info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._sync_stream()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.eqf_tiled_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- plumbing
+    def _sync_stream(self):
+        s = torch.cuda.current_stream(self.dev).cuda_stream
+        if s != self._stream:
+            self.b._check(self.lib.eqf_tiled_set_stream(self._h, ctypes.c_void_p(s)), "eqf_tiled_set_stream")
+            self._stream = s
+        return ctypes.c_void_p(s)
+
+    @staticmethod
+    def _p(t):
+        return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()
+
+    @staticmethod
+    def _dp(a):
+        return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float64, device=self.device)
+
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float64, device=self.device)
+
+    # ---- replicated state + local blocks
+    def set_geometry(self, geo):
+        rm, cm = np.ascontiguousarray(geo.rowMap, dtype=np.int32), np.ascontiguousarray(geo.colMap, dtype=np.int32)
+        ip = ctypes.POINTER(ctypes.c_int)
+        self.b._check(self.lib.eqf_tiled_set_geometry(self._h, len(rm), rm.ctypes.data_as(ip), len(cm), cm.ctypes.data_as(ip)), "eqf_tiled_set_geometry")
+
+    def propagate(self, stamp, omega, accel, is_imu, Sll):
+        self._sync_stream()
+        w = np.ascontiguousarray(omega if omega is not None else np.zeros(3), dtype=np.float64)
+        a = np.ascontiguousarray(accel if accel is not None else np.zeros(3), dtype=np.float64)
+        ld = Sll.stride(0) if Sll is not None else 0
+        return self.b._check(self.lib.eqf_tiled_propagate(self._h, float(stamp), self._dp(w), self._dp(a), int(bool(is_imu)), self._p(Sll), ld),
+                             "eqf_tiled_propagate")
+
+    def add_landmarks(self, bearings, Sll):
+        self._sync_stream()
+        y = np.ascontiguousarray(bearings, dtype=np.float64).reshape(-1, 3)
+        self.b._check(self.lib.eqf_tiled_add_landmarks(self._h, len(y), self._dp(y), self._p(Sll), Sll.stride(0) if Sll is not None else 0),
+                      "eqf_tiled_add_landmarks")
+
+    def update_prep(self, bearings, Sll, M, E, G11):
+        self._sync_stream()
+        y = np.ascontiguousarray(bearings, dtype=np.float64).reshape(-1, 3)
+        self.b._check(self.lib.eqf_tiled_update_prep(self._h, self._dp(y), self._p(Sll), Sll.stride(0), self._p(M), M.stride(0), self._p(E),
+                                                     E.stride(0), self._p(G11)), "eqf_tiled_update_prep")
+
+    def update_finish(self, acc, Gnn, G11):
+        self._sync_stream()
+        assert acc.stride(1) == 1 and Gnn.is_contiguous() and G11.is_contiguous()
+        self.b._check(self.lib.eqf_tiled_update_finish(self._h, self._p(acc), acc.stride(0), self._p(Gnn), self._p(G11)), "eqf_tiled_update_finish")
+
+    # ---- dense tile kernels (csrc/eqf_tile.hpp)
+    def potrf(self, Akk):
+        """In place: lower triangle of the (n x n) view Akk <- L.  Returns the diagonal-factor records trsm() multiplies with."""
+        n = Akk.shape[0]
+        drec = torch.empty(((n + 63) // 64) * self.DREC, dtype=torch.float64, device=self.device)
+        self.b._check(self.lib.eqf_tile_potrf(self.dev, self._sync_stream(), self._p(Akk), Akk.stride(0), n, self._p(drec), self._p(self._info)),
+                      "eqf_tile_potrf")
+        return drec
+
+    def trsm_left(self, L, drec, Bm):
+        """In place: Bm (n x m view) <- L^-1 Bm."""
+        self.b._check(self.lib.eqf_tile_trsm(self.dev, self._sync_stream(), self._p(L), L.stride(0), L.shape[0], self._p(drec), self._p(Bm),
+                                             Bm.stride(0), Bm.shape[1], 0), "eqf_tile_trsm")
+
+    def gemm_tn(self, Cm, A, B, alpha, mask=None):
+        """Cm (m x n view) += alpha A^T B; A (k x m), B (k x n) views with unit column stride.  mask = (rb, cb, rblk0, Pr, pr, cblk0, Pc,
+        pc): skip tiles entirely below the block diagonal of a block-cyclic local matrix."""
+        m, n = Cm.shape
+        k = A.shape[0]
+        if m == 0 or n == 0 or k == 0:
+            return
+        assert A.shape[1] == m and B.shape == (k, n) and Cm.stride(1) == 1 and A.stride(1) == 1 and B.stride(1) == 1
+        mk = mask if mask is not None else (0, 0, 0, 1, 0, 0, 1, 0)
+        self.b._check(self.lib.eqf_tile_gemm_tn(self.dev, self._sync_stream(), self._p(Cm), Cm.stride(0), m, n, self._p(A), A.stride(0), self._p(B),
+                                                B.stride(0), k, float(alpha), *[int(x) for x in mk]), "eqf_tile_gemm_tn")
+
+    def factor_info(self):
+        """non-zero if a pivot of any diagonal block since the last call was not positive (synchronises)"""
+        v = int(self._info.item())
+        self._info.zero_()
+        return v
+
+    # ---- getters (synchronise)
+    def num_landmarks(self):
+        return self.lib.eqf_tiled_num_landmarks(self._h)
+
+    def time(self):
+        t = ctypes.c_double()
+        self.lib.eqf_tiled_get_time(self._h, ctypes.byref(t))
+        return t.value
+
+    def device_error(self):
+        return self.lib.eqf_tiled_device_error(self._h)
+
+    def state_estimate(self):
+        N = self.num_landmarks()
+        q, x, v, p = np.zeros(4), np.zeros(3), np.zeros(3), np.zeros((max(N, 1), 3))
+        self.b._check(self.lib.eqf_tiled_get_state_estimate(self._h, self._dp(q), self._dp(x), self._dp(v), self._dp(p)), "eqf_tiled_get_state_estimate")
+        return {"q": q, "x": x, "v": v, "p": p[:N]}
+
+    def origin(self):
+        N = self.num_landmarks()
+        q, x, v, p = np.zeros(4), np.zeros(3), np.zeros(3), np.zeros((max(N, 1), 3))
+        self.b._check(self.lib.eqf_tiled_get_origin(self._h, self._dp(q), self._dp(x), self._dp(v), self._dp(p)), "eqf_tiled_get_origin")
+        return {"q": q, "x": x, "v": v, "p": p[:N]}
+
+    def group(self):
+        N = self.num_landmarks()
+        Aq, Ax, w, Qq, Qa = np.zeros(4), np.zeros(3), np.zeros(3), np.zeros((max(N, 1), 4)), np.zeros(max(N, 1))
+        self.b._check(self.lib.eqf_tiled_get_group(self._h, self._dp(Aq), self._dp(Ax), self._dp(w), self._dp(Qq), self._dp(Qa)), "eqf_tiled_get_group")
+        return {"Aq": Aq, "Ax": Ax, "w": w, "Qq": Qq[:N], "Qa": Qa[:N]}
+
+    def bias(self):
+        b6 = np.zeros(6)
+        self.b._check(self.lib.eqf_tiled_get_bias(self._h, self._dp(b6)), "eqf_tiled_get_bias")
+        return b6
+
+    def integrator(self):
+        cv, av, at, ini = np.zeros(6), np.zeros(6), ctypes.c_double(), ctypes.c_int()
+        self.b._check(self.lib.eqf_tiled_get_integrator(self._h, self._dp(cv), self._dp(av), ctypes.byref(at), ctypes.byref(ini)), "eqf_tiled_get_integrator")
+        return {"currentVelocity": cv, "accumulatedVelocity": av, "accumulatedTime": at.value, "initialised": bool(ini.value)}
+
+    def last_update(self):
+        N = self.num_landmarks()
+        d, g, G = np.zeros(2 * N), np.zeros(11 + 3 * N), np.zeros(9 + 3 * N)
+        self.b._check(self.lib.eqf_tiled_get_last_update(self._h, self._dp(d), self._dp(g), self._dp(G)), "eqf_tiled_get_last_update")
+        return {"delta": d, "gamma": g, "Gamma": G}
+
+    def base_rows(self):
+        N = self.num_landmarks()
+        out = np.zeros((11, 11 + 3 * N))
+        self.b._check(self.lib.eqf_tiled_get_base(self._h, self._dp(out), out.shape[1]), "eqf_tiled_get_base")
+        return out
+
+    def set_state(self, st):
+        """st: a snapshot as FilterBatch.dump_state() makes it (ids, origin, group, bias, sigma, time, currentVelocity, accumulatedVelocity,
+        accumulatedTime, initialised); only the first 11 rows of sigma are taken (the replicated base panel)."""
+        N = len(st["ids"])
+        o, g = st["origin"], st["group"]
+
+        def arr(a, shape):
+            out = np.zeros(shape)
+            if N:
+                out[...] = np.asarray(a, dtype=np.float64).reshape(shape)
+            return np.ascontiguousarray(out)
+
+        p0, Qq, Qa = arr(o["p"], (max(N, 1), 3)), arr(g["Qq"], (max(N, 1), 4)), arr(g["Qa"], (max(N, 1),))
+        sb = np.ascontiguousarray(np.asarray(st["sigma"], dtype=np.float64)[:11])
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        arrs = [f(x) for x in (o["q"], o["x"], o["v"], p0, g["Aq"], g["Ax"], g["w"], Qq, Qa, st["bias"], sb)]
+        cv, av = f(st["currentVelocity"]), f(st["accumulatedVelocity"])
+        self.b._check(self.lib.eqf_tiled_set_state(self._h, N, *[self._dp(a) for a in arrs], sb.shape[1], float(st["time"]), self._dp(cv),
+                                                   self._dp(av), float(st["accumulatedTime"]), int(st["initialised"])), "eqf_tiled_set_state")
+
+
+class TiledFilter:
+    """VIOFilter (VIOFilter.h:41-88) for one filter whose Sigma is partitioned over `grid`.  Every rank of the grid makes the same calls
+    with the same arguments.  `backend`: HipBackend (the product path), or the CPU test double."""
+
+    def __init__(self, grid, backend, block_landmarks):
+        self.g, self.be, self.bl = grid, backend, int(block_landmarks)
+        self.geo = None
+        self.Sll = self.M = self.E = None
+        self.ids = None
+
+    # ---- storage
+    def _alloc(self, N):
+        g, be = self.g, self.be
+        self.geo = geo = BlockCyclic(N, self.bl, g.Pr, g.Pc, g.pr, g.pc)
+        be.set_geometry(geo)
+        r16 = lambda x: (x + 15) // 16 * 16
+        self.Sll = be.zeros(max(3 * geo.nlr, 1), r16(max(3 * geo.nlc, 1)))[: 3 * geo.nlr, : 3 * geo.nlc]
+        self.M = be.empty(max(2 * geo.nlr, 1), r16(5 * geo.nlc + NARROW_S))[: 2 * geo.nlr, : 5 * geo.nlc + NARROW_S]
+        self.E = be.empty(max(3 * geo.nlr, 1), r16(3 * geo.nlc + NARROW_E))[: 3 * geo.nlr, : 3 * geo.nlc + NARROW_E]
+        self.G11 = be.zeros(11, 11)
+        # exchange buffers: a solved block row piece per process column of my row (B operand / contributions to the A operand)
+        bsmax = 3 * min(self.bl, N)
+        self._wmax = {c: 5 * geo.ncols_of(c) + NARROW_S for c in range(g.Pc)}
+        self._wmax_e = {c: 3 * geo.ncols_of(c) + NARROW_E for c in range(g.Pc)}
+        self._buf = {c: be.empty(bsmax * max(self._wmax[c], self._wmax_e[c])) for c in range(g.Pc) if c == g.pc or c % g.Pr == g.pr}
+        self._pack = be.empty(bsmax * bsmax + ((bsmax + 63) // 64) * HipBackend.DREC)
+        self._aopA = be.empty(bsmax, max(3 * geo.nlr, 1))
+        self._aopW = be.empty(bsmax, max(3 * geo.nlr, 1))
+        self._accS = be.zeros(NARROW_S, 3 * geo.nlc + NARROW_S)
+        self._accE = be.zeros(NARROW_E, NARROW_E)
+
+    # ---- VIOFilter::processIMUData (VIOFilter.cpp:120-131)
+    def processIMUData(self, stamp, omega, accel):
+        return self.be.propagate(stamp, omega, accel, True, self.Sll)
+
+    # ---- VIOFilter::processVisionData (VIOFilter.cpp:232-302) for a FIXED landmark set: the first frame defines it
+    def processVisionData(self, stamp, ids, bearings):
+        ids = np.asarray(ids, dtype=np.int64)
+        y = np.asarray(bearings, dtype=np.float64).reshape(-1, 3)
+        if len(ids) != len(y) or (len(ids) > 1 and not np.all(np.diff(ids) > 0)):
+            raise ValueError("bearings must come with strictly ascending ids (VIOFilter.cpp:239-240)")
+        if self.ids is not None and not np.array_equal(ids, self.ids):
+            raise NotImplementedError("the 2-D partitioned filter keeps the landmark set of its first frame (landmark churn lives in the "
+                                      "single-GPU path)")
+        st = self.be.propagate(stamp, None, None, False, self.Sll)  # :233 integrateUpToTime
+        if st != 0:
+            return st  # :234-236
+        if len(ids) == 0:
+            return 4  # EQF_SKIPPED_NO_BEARINGS, :258-259
+        if self.ids is None:
+            self._alloc(len(ids))  # addNewLandmarks on the empty state, :345-391
+            self.be.add_landmarks(y, self.Sll)
+            self.ids = ids.copy()
+        self._update(y)
+        return 0
+
+    def initialise_from(self, st):
+        """Restart from a single-GPU snapshot (FilterBatch.dump_state(); every rank holds the dense Sigma once, here)."""
+        N = len(st["ids"])
+        self._alloc(N)
+        S = torch.as_tensor(np.asarray(st["sigma"]), dtype=torch.float64)
+        rows = torch.as_tensor(np.repeat(3 * self.geo.rowMap.astype(np.int64), 3) + np.tile(np.arange(3), self.geo.nlr) + 11)
+        cols = torch.as_tensor(np.repeat(3 * self.geo.colMap.astype(np.int64), 3) + np.tile(np.arange(3), self.geo.nlc) + 11)
+        if self.geo.nlr and self.geo.nlc:
+            self.Sll.copy_(S[rows][:, cols].to(self.Sll.device))
+        self.be.set_state(st)
+        self.ids = np.asarray(st["ids"], dtype=np.int64)
+
+    # ---- the update
+    def _update(self, y):
+        be, geo = self.be, self.geo
+        be.update_prep(y, self.Sll, self.M, self.E, self.G11)  # E and M are formed from the PRE-update Sigma (VIOFilter.cpp:285 before :297)
+        nA = 2 * geo.nlc
+        self._accS.zero_()
+        self._accE.zero_()
+
+        def hook_s(k, bk, Bop, off, contributions):
+            # Bop[:, off:] = [Y_k (3 nlc) | Yn_k (18)] of my process column; the rank's share of the downdate and of the reductions
+            Yw = Bop[:, off: off + 3 * geo.nlc]
+            Yn = Bop[:, off + 3 * geo.nlc: off + 3 * geo.nlc + NARROW_S]
+            YI = self._rows_operand(contributions, 3, lambda c, wc: (wc - 3 * geo.ncols_of(c) - NARROW_S, 0), bk, self._aopW, all_blocks=True)
+            be.gemm_tn(self.Sll, YI, Yw, -1.0)                           # Sigma_IJ -= Y_kI^T Y_kJ    (VIOFilter.cpp:297)
+            be.gemm_tn(self._accS, Yn, Bop[:, off:], 1.0)               # [Sigma_b's downdate ; gamma_L ; .. | Gnn] += Yn_k^T [Y_k | Yn_k]
+
+        def hook_e(k, bk, Bop, off, contributions):
+            En = Bop[:, off: off + NARROW_E]
+            be.gemm_tn(self._accE, En, En, 1.0)
+
+        self._chain(self.M, 2, nA, hook_s, self._wmax)
+        self._chain(self.E, 3, 3 * geo.nlc, hook_e, self._wmax_e)
+        info = be.factor_info()
+        if info:
+            raise ArithmeticError("a pivot of S or Sigma_e was not positive (distributed factorisation)")
+        # gamma_L and the base panel's downdate live with the process COLUMNS: gather them along the process row, global landmark order
+        acc = self._gather_columns(self._accS[:, : 3 * geo.nlc])
+        Gnn = self._accS[:, 3 * geo.nlc:].contiguous()
+        G11 = (self.G11 + self._accE).contiguous()
+        be.update_finish(acc, Gnn, G11)
+
+    def _gather_columns(self, mine):
+        g, geo = self.g, self.geo
+        rows = mine.shape[0]
+        wmax = 3 * max(geo.ncols_of(c) for c in range(g.Pc))
+        pad = self.be.zeros(rows, wmax)
+        pad[:, : mine.shape[1]] = mine
+        parts = g.allgather_row(pad)
+        out = self.be.empty(rows, 3 * geo.N)
+        for c, part in enumerate(parts):
+            o = 0
+            for b in range(c, geo.nb, g.Pc):
+                w = 3 * geo.block_size(b)
+                out[:, 3 * b * geo.bl: 3 * b * geo.bl + w] = part[:, o: o + w]
+                o += w
+        return out
+
+    def _rows_operand(self, contributions, unit, part_of, bk, buf, all_blocks, k=None):
+        """The A operand of the products of block row k: for each of MY local row blocks (all of them, or the trailing ones i > k) the
+        (bk x unit * size) block of the solved block row -- found in the piece of the process column c = i mod Pc, which the rank (pr, c)
+        re-broadcast along the process row.  contributions: {c: (piece (bk x w_c), jl0_c)}; part_of(c, w_c) -> (column offset of the part
+        inside the piece, 1 if the part starts at local block jl0_c else 0)."""
+        g, geo = self.g, self.geo
+        q = g.Pc // g.Pr
+        bsF = unit * geo.bl
+        il0 = 0 if all_blocks else BlockCyclic.blocks_upto(k, g.pr, g.Pr)
+        ncol = unit * geo.nlr - il0 * bsF
+        if ncol <= 0:
+            return None
+        if q == 1:
+            # one contributor, c = pr: its local column blocks ARE my local row blocks, in order -> a view, no copy
+            piece, jl0 = contributions[g.pr]
+            off, trailing = part_of(g.pr, piece.shape[1])
+            start = off + ((il0 - jl0) * bsF if trailing else il0 * bsF)
+            return piece[:, start: start + ncol]
+        out = buf[:bk, : unit * geo.nlr]
+        for s in range(q):
+            c = g.pr + g.Pr * s
+            piece, jl0 = contributions[c]
+            off, trailing = part_of(c, piece.shape[1])
+            # my local row block ilb = s + t q  <->  local column block t of process column c
+            for ilb in range(s, len(geo.row_blocks), q):
+                if ilb < il0:
+                    continue
+                t = (ilb - s) // q
+                w = unit * geo.block_size(geo.row_blocks[ilb])
+                src = off + ((t - jl0) if trailing else t) * bsF
+                out[:, ilb * bsF: ilb * bsF + w] = piece[:, src: src + w]
+        return out[:, il0 * bsF:]
+
+    def _chain(self, X, unit, nA, hook, wmax):
+        """Blocked right-looking Cholesky by block ROWS of the SPD matrix in X[:, :nA] (upper blocks, block size unit * bl, block-cyclic
+        over the grid) with the right-hand sides X[:, nA:]; X is consumed.  hook(k, bk, Bop, off, contributions) runs on every rank once
+        block row k is solved: Bop[:, off:] holds the right-hand-side part of my process column."""
+        g, geo, be = self.g, self.geo, self.be
+        bsF = unit * geo.bl
+        W = X.shape[1]
+        for k in range(geo.nb):
+            prk, pck = k % g.Pr, k % g.Pc
+            bk = unit * geo.block_size(k)
+            klr, klc = k // g.Pr, k // g.Pc
+            jl0 = BlockCyclic.blocks_upto(k, g.pc, g.Pc)
+            c0 = min(jl0 * bsF, nA)
+            width = W - c0
+            Bop = self._buf[g.pc][: bk * width].view(bk, width)
+            if g.pr == prk:
+                # 1. the diagonal block, L_kk and its records along the process row
+                nrec = ((bk + 63) // 64) * HipBackend.DREC
+                pack = self._pack[: bk * bk + nrec]
+                Lkk, drec = pack[: bk * bk].view(bk, bk), pack[bk * bk:]
+                if g.pc == pck:
+                    Akk = X[klr * bsF: klr * bsF + bk, klc * bsF: klc * bsF + bk]
+                    drec.copy_(be.potrf(Akk))
+                    Lkk.copy_(Akk)
+                g.bcast_row(pack, pck)
+                # 2. my piece of block row k
+                R = X[klr * bsF: klr * bsF + bk, c0:]
+                be.trsm_left(Lkk, drec, R)
+                Bop.copy_(R)
+            # 3. down the process column
+            g.bcast_col(Bop, prk)
+            # 4. along the process row, from the ranks whose column blocks are this process row's row blocks
+            contributions = {}
+            for c in range(g.pr, g.Pc, g.Pr):
+                jl0c = BlockCyclic.blocks_upto(k, c, g.Pc)
+                wc = wmax[c] - min(jl0c * bsF, unit * geo.ncols_of(c))
+                piece = Bop if c == g.pc else self._buf[c][: bk * wc].view(bk, wc)
+                g.bcast_row(piece, c)
+                contributions[c] = (piece, jl0c)
+            # 5. trailing updates of what this rank owns: rows of blocks i > k, columns from block jl0 on
+            il0 = BlockCyclic.blocks_upto(k, g.pr, g.Pr)
+            if il0 * bsF < X.shape[0]:
+                Ua = self._rows_operand(contributions, unit, lambda c, wc: (0, 1), bk, self._aopA, all_blocks=False, k=k)
+                Ct = X[il0 * bsF:, c0:]
+                if nA - c0 > 0:
+                    be.gemm_tn(Ct[:, : nA - c0], Ua, Bop[:, : nA - c0], -1.0, mask=(bsF, bsF, il0, g.Pr, g.pr, jl0, g.Pc, g.pc))
+                be.gemm_tn(Ct[:, nA - c0:], Ua, Bop[:, nA - c0:], -1.0)
+            hook(k, bk, Bop, nA - c0, contributions)
+
+    # ---- getters
+    def getTime(self):
+        return self.be.time()
+
+    def stateEstimate(self):
+        return self.be.state_estimate()
+
+    def stateCovariance(self):
+        """Dense Sigma (reference index map) gathered to every rank -- tests and snapshots (VIOFilter::stateCovariance, :306-309)."""
+        g, geo = self.g, self.geo
+        N = geo.N
+        n = 11 + 3 * N
+        S = np.zeros((n, n))
+        base = self.be.base_rows()
+        S[:, :11] = base.T  # (only the base ROWS are kept: the columns are their transpose)
+        S[:11, :] = base
+        rmax = 3 * max(len(BlockCyclic(N, self.bl, g.Pr, g.Pc, r, 0).rowMap) for r in range(g.Pr))
+        cmax = 3 * max(geo.ncols_of(c) for c in range(g.Pc))
+        pad = self.be.zeros(rmax, cmax)
+        pad[: 3 * geo.nlr, : 3 * geo.nlc] = self.Sll
+        for rank, part in enumerate(g.allgather_all(pad)):
+            r, c = divmod(rank, g.Pc)
+            og = BlockCyclic(N, self.bl, g.Pr, g.Pc, r, c)
+            rows = (np.repeat(3 * og.rowMap.astype(np.int64), 3) + np.tile(np.arange(3), og.nlr)) + 11
+            cols = (np.repeat(3 * og.colMap.astype(np.int64), 3) + np.tile(np.arange(3), og.nlc)) + 11
+            S[np.ix_(rows, cols)] = part[: 3 * og.nlr, : 3 * og.nlc].cpu().numpy()
         return S
-
-    def cols(self, J):
-        w = 3 * self.bl
-        return slice(J * w, (J + 1) * w)
-
-
-def propagate(ts, Fbb, L, D, Qbb, Bn, Rdiag, T, point_var):
-    """One Riccati step, tile-local (no communication).  Fbb 11 x 11; L (3N x 11) = rows of F below the base block; D (N, 3, 3)
-    the diagonal blocks of F; process noise Q = T (P + Bn R Bn^T) with Bn = (n x 6) input matrix (first 6 rows zero), R = diag
-    (6,), P = diag(..., point_var on every landmark coordinate); Qbb = its 11 x 11 base block."""
-    bl, nb = ts.bl, ts.nb
-    w = 3 * bl
-    Dm = [torch.block_diag(*D[I * bl:(I + 1) * bl]) for I in range(nb)]
-    Lr = [L[I * w:(I + 1) * w] for I in range(nb)]
-    BR = Bn * Rdiag  # (n x 6) columns scaled
-    Sbb, Sb = ts.Sbb, ts.Sb
-    new = {}
-    kern = ts.g.kernels
-    if kern is not None:
-        Dc, Lc, Bc, Sbbc, Sbc = D.contiguous(), L.contiguous(), Bn.contiguous(), Sbb.contiguous(), Sb.contiguous()
-        for (I, J), S_IJ in ts.t.items():
-            new[(I, J)] = kern.propagate(S_IJ.contiguous(), bl, bl, Dc[I * bl:], Lc[I * w:], Dc[J * bl:], Lc[J * w:], Sbbc, Sbc[:, I * w:],
-                                         Sbc.stride(0), Sbc[:, J * w:], Sbc.stride(0), Bc[11 + I * w:], Bc[11 + J * w:], Rdiag.tolist(), T,
-                                         T * point_var, I == J)
-    for (I, J), S_IJ in ([] if kern is not None else ts.t.items()):
-        SIb = Sb[:, ts.cols(I)].T  # Sigma_Ib = Sigma_bI^T
-        G_I = Lr[I] @ Sbb + Dm[I] @ SIb
-        Q_IJ = T * (BR[11 + I * w:11 + (I + 1) * w] @ Bn[11 + J * w:11 + (J + 1) * w].T)
-        if I == J:
-            Q_IJ = Q_IJ + T * point_var * torch.eye(w, dtype=torch.float64, device=S_IJ.device)
-        new[(I, J)] = (Dm[I] @ S_IJ + Lr[I] @ Sb[:, ts.cols(J)]) @ Dm[J].T + G_I @ Lr[J].T + Q_IJ
-    Sb_new = torch.empty_like(Sb)
-    for J in range(nb):
-        Sb_new[:, ts.cols(J)] = Fbb @ (Sbb @ Lr[J].T + Sb[:, ts.cols(J)] @ Dm[J].T) + T * (BR[:11] @ Bn[11 + J * w:11 + (J + 1) * w].T)
-    ts.Sbb = Fbb @ Sbb @ Fbb.T + Qbb
-    ts.Sb = Sb_new
-    ts.t = new
-
-
-def dist_chol_solve(grid, nb, A, Wt, Wn, bs, wt, on_row=None):
-    """Blocked right-looking Cholesky of the SPD matrix A (nb x nb blocks of bs, lower blocks {(i, j), i >= j} on their owners)
-    with right-hand sides: wide tiles Wt {(i, t)} (bs x wt, owner (i mod Pr, t mod Pc)) and one narrow tile per block row Wn
-    {(i, 0)} (bs x nn, owner (i mod Pr, 0)).  A and W are consumed.  After block column k the solved block row is handed to
-    on_row(k, Yk_wide {t: bs x wt}, Yk_narrow) ON EVERY RANK (this is where the downdate and the reductions hang)."""
-    nn = next(iter(Wn.values())).shape[1] if Wn else 0
-    nn_all = torch.tensor([nn], dtype=torch.int64, device=grid.device)
-    if grid.dist is not None and grid.world > 1:
-        grid.dist.all_reduce(nn_all, op=grid.dist.ReduceOp.MAX)
-    nn = int(nn_all.item())
-    kern = grid.kernels
-    for k in range(nb):
-        # 1. diagonal block (GPU: hand-written k_tile_potrf, which also leaves the records the panel solves multiply with)
-        Lkk = torch.empty((bs, bs), dtype=torch.float64, device=grid.device)
-        drec = torch.empty(((bs + 63) // 64) * TileKernels.DREC, dtype=torch.float64, device=grid.device) if kern is not None else None
-        if grid.mine(k, k):
-            if kern is not None:
-                Lkk, drec = kern.potrf(A.pop((k, k)))
-            else:
-                Lkk = torch.linalg.cholesky(A.pop((k, k))).contiguous()  # (LAPACK hands back column-major strides)
-        grid.bcast(Lkk, grid.owner(k, k))
-        if kern is not None:
-            grid.bcast(drec, grid.owner(k, k))
-
-        def solve_right(Bm):  # B Lkk^-T
-            return kern.trsm(Lkk, drec, Bm, True) if kern is not None else torch.linalg.solve_triangular(Lkk, Bm.T, upper=False).T
-
-        def solve_left(Bm):  # Lkk^-1 B
-            return kern.trsm(Lkk, drec, Bm, False) if kern is not None else torch.linalg.solve_triangular(Lkk, Bm, upper=False)
-
-        # 2. panel blocks and this block row of right-hand sides, on their owners
-        pan = {}
-        for (i, j) in [key for key in A if key[1] == k]:
-            pan[(i, k)] = solve_right(A.pop((i, j)))
-        yw = {}
-        for (i, t) in [key for key in Wt if key[0] == k]:
-            yw[(k, t)] = solve_left(Wt.pop((i, t)))
-        yn = {}
-        if (k, 0) in Wn:
-            yn[(k, 0)] = solve_left(Wn.pop((k, 0)))
-        # 3. everybody gets the panel column and the block row
-        pan = grid.allgather_blocks(pan, (bs, bs))
-        yw = grid.allgather_blocks(yw, (bs, wt))
-        yn = grid.allgather_blocks(yn, (bs, nn)) if nn else {}
-        # 4. trailing updates of what this rank owns
-        for (i, j) in A:
-            if j > k:
-                A[(i, j)] -= pan[(i, k)] @ pan[(j, k)].T
-        for (i, t) in Wt:
-            if i > k:
-                Wt[(i, t)] -= pan[(i, k)] @ yw[(k, t)]
-        for (i, _) in Wn:
-            if i > k:
-                Wn[(i, 0)] -= pan[(i, k)] @ yn[(k, 0)]
-        if on_row is not None:
-            on_row(k, {t: v for (_, t), v in yw.items()}, yn.get((k, 0)))
-
-
-def update(ts, C, delta, meas_var):
-    """Sigma <- Sigma - K C Sigma and gamma = K delta (VIOFilter.cpp:276-297) over the process grid.  C (N, 2, 3): the blocks of
-    EqFOutputMatrixC (one per landmark, acting on its three coordinates); delta (2N,).  Returns gamma (11 + 3N,), the same on
-    every rank.  Sigma is downdated in place from the solved block rows as they arrive."""
-    g, bl, nb = ts.g, ts.bl, ts.nb
-    w, bs = 3 * bl, 2 * bl
-    dev = g.device
-    Cm = [torch.block_diag(*C[I * bl:(I + 1) * bl]) for I in range(nb)]  # (2bl x 3bl)
-    # S tiles (lower) and right-hand sides, all tile-local
-    A, Wt, Wn = {}, {}, {}
-    for (I, J), S_IJ in ts.t.items():
-        CS = Cm[I] @ S_IJ  # (C Sigma)_IJ
-        Wt[(I, J)] = CS
-        if I >= J:
-            Sij = CS @ Cm[J].T
-            if I == J:
-                Sij = Sij + meas_var * torch.eye(bs, dtype=torch.float64, device=dev)
-            A[(I, J)] = Sij
-    d = torch.as_tensor(delta, dtype=torch.float64, device=dev)
-    for I in range(nb):
-        if g.mine(I, 0):
-            Wn[(I, 0)] = torch.cat([Cm[I] @ ts.Sb[:, ts.cols(I)].T, d[I * bs:(I + 1) * bs, None]], dim=1)  # [(C Sigma)_Ib | delta_I]
-    n = 11 + 3 * ts.N
-    gamma = torch.zeros(n, dtype=torch.float64, device=dev)
-    Sb_dd = torch.zeros_like(ts.Sb)
-    Sbb_dd = torch.zeros_like(ts.Sbb)
-
-    def on_row(k, Yw, Yn):
-        z = Yn[:, 11]
-        Yb = Yn[:, :11]
-        gamma[:11] += Yb.T @ z
-        Sbb_dd.add_(Yb.T @ Yb)
-        for J in range(nb):
-            gamma[11 + J * w:11 + (J + 1) * w] += Yw[J].T @ z
-            Sb_dd[:, ts.cols(J)] += Yb.T @ Yw[J]
-        for (I, J) in ts.t:
-            if g.kernels is not None:
-                g.kernels.downdate(ts.t[(I, J)], Yw[I], Yw[J])
-            else:
-                ts.t[(I, J)] -= Yw[I].T @ Yw[J]
-
-    dist_chol_solve(g, nb, A, Wt, Wn, bs, w, on_row)
-    ts.Sb = ts.Sb - Sb_dd
-    ts.Sbb = ts.Sbb - Sbb_dd
-    return gamma
-
-
-def sigma_e_quadratic_form(ts, V):
-    """G = V^T Sigma_e^-1 V for Sigma_e = Sigma[6:, 6:] (bundleLift's weights, EqFMatrices.cpp:239) and V ((5 + 3N) x q) given
-    on every rank: the five base coordinates are eliminated locally from the replicated panel, the Schur complement of the
-    landmark tiles goes through the distributed solver, the q x q result is accumulated from the solved block rows."""
-    g, bl, nb = ts.g, ts.bl, ts.nb
-    w = 3 * bl
-    V = torch.as_tensor(V, dtype=torch.float64, device=g.device)
-    q = V.shape[1]
-    Sgg = ts.Sbb[6:, 6:]
-    Lg = torch.linalg.cholesky(Sgg)
-    Pg = torch.linalg.solve_triangular(Lg, ts.Sb[6:, :], upper=False)   # Lg^-1 Sigma_gL   (5 x 3N)
-    Vg = torch.linalg.solve_triangular(Lg, V[:5], upper=False)           # Lg^-1 V_g
-    G = Vg.T @ Vg
-    A, Wn = {}, {}
-    for (I, J), S_IJ in ts.t.items():
-        if I >= J:
-            A[(I, J)] = S_IJ - Pg[:, ts.cols(I)].T @ Pg[:, ts.cols(J)]
-    for I in range(nb):
-        if g.mine(I, 0):
-            Wn[(I, 0)] = V[5 + I * w:5 + (I + 1) * w] - Pg[:, ts.cols(I)].T @ Vg
-    acc = torch.zeros((q, q), dtype=torch.float64, device=g.device)
-
-    def on_row(k, Yw, Yn):
-        acc.add_(Yn.T @ Yn)
-
-    dist_chol_solve(g, nb, A, {}, Wn, w, w, on_row)
-    return G + acc

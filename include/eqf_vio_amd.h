@@ -187,26 +187,87 @@ int eqf_profile_enable(eqf_filter* f, int on);
 int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_ms);
 const char* eqf_profile_class_name(int cls);
 
-/* ---- Tile-local kernels for Sigma 2-D block-partitioned over a process grid (BASELINE configs[4]: N = 4000 over 8 GPUs).
- * They work on CALLER-OWNED device memory (plain device pointers, e.g. torch tensors) of HIP device `device`, enqueue on
- * `stream` (a hipStream_t, NULL = the default stream) and return without synchronising.  The exchange schedule above them
- * (which rank owns which tile, the RCCL all-gathers of the panels) is eqf_vio_amd/tiled.py.  fp64.
- *
- * eqf_tile_propagate: one structured Riccati step of the (3 nI x 3 nJ) tile (I, J) of the landmark-landmark part of Sigma
- * (VIOFilter.cpp:188-189 with F = I + T A_b = [[F_bb, 0], [L, D]]):
- *     out = (D_I in + L_I Sigma_bJ) D_J^T + (L_I Sigma_bb + D_I Sigma_Ib) L_J^T + T (B_I R B_J^T) [+ diag_noise I on a diagonal tile]
- *   D_I [nI][9] / D_J [nJ][9]: the 3x3 diagonal blocks of F; L_I [3 nI][11] / L_J: the rows of F below the base block;
- *   Sbb [11][11]; SbI [11][ldbI], SbJ [11][ldbJ]: the base panel columns of the row / column landmarks (Sigma_Ib = SbI^T);
- *   BnI [3 nI][6], BnJ: rows of the input matrix B (EqFMatrices.cpp:346-382); R[6] = diag(velOmega x3, velAccel x3);
- *   diag_noise = T * pointProcessVariance, is_diag = 1 for tiles with I == J.  in / out: row-major, leading dimension ld.
- * eqf_tile_downdate: C (m x n, ldc) -= A^T B for A (k x m, lda), B (k x n, ldb): the tile's share of Sigma - K C Sigma =
- * Sigma - Y^T Y (VIOFilter.cpp:297) from solved block rows Y.
- * eqf_tile_potrf: A (n x n, ld, lower triangle) <- L with A = L L^T: the diagonal block S_kk (or of Sigma_e's Schur complement) of
- * a block column of the distributed factorisation that replaces S.inverse() / Sigma_e.inverse() (VIOFilter.cpp:276-277,
- * EqFMatrices.cpp:239); drec [ceil(n / 64)][5120] receives, per 64-wide block column, L_jj and the inverses of its four 16 x 16
- * diagonal blocks (what eqf_tile_trsm multiplies with); info (device int, may be NULL) is or-ed with 1 if a pivot is not positive.
- * eqf_tile_trsm: right = 1: B (m x n, ldb) <- B L^-T (the panel blocks A_ik L_kk^-T); right = 0: B (n x m, ldb) <- L^-1 B (the block
- * row of right-hand sides Y_k = L_kk^-1 [C Sigma | delta]_k).  A, drec as left by eqf_tile_potrf. */
+/* ================================================================================================================================
+ * BASELINE configs[4]: ONE filter with N = 4000 landmarks whose Sigma (1.15 GB) is 2-D block-partitioned over the GPUs of a node.
+ * One process per GPU; process (pr, pc) of a Pr x Pc grid owns the landmark blocks I = pr, pr + Pr, ... as rows and J = pc, pc + Pc,
+ * ... as columns of ONE dense local matrix Sll (3 nlr x 3 nlc doubles, row-major, CALLER-OWNED device memory, e.g. a torch tensor, so
+ * that torch.distributed can move pieces of it).  The O(N) filter state and the 11-row base panel Sigma[0:11, :] are REPLICATED: every
+ * rank advances its own identical copy inside its eqf_tiled handle, with the same device functions as the single-GPU path.  The
+ * exchange schedule (which block row is factored where, the RCCL broadcasts of the solved block rows) is eqf_vio_amd/tiled.py; the
+ * entry points below are what a rank runs between two exchanges.  They enqueue on the handle's stream (eqf_tiled_set_stream; NULL = the
+ * default stream) and return; getters synchronise.  fp64 only.  The landmark set is fixed by the first vision frame (or by
+ * eqf_tiled_set_state): landmark churn (VIOFilter.cpp:345-443) lives in the single-GPU path, this is the fixed-N throughput configuration.
+ * ================================================================================================================================ */
+typedef struct eqf_tiled eqf_tiled; /* opaque */
+
+/* VIOFilter(const Settings&) (VIOFilter.cpp:60-73) for the replicated part of one filter with room for capacity_landmarks. */
+int eqf_tiled_create(const eqf_settings* settings, int capacity_landmarks, int device, eqf_tiled** out);
+void eqf_tiled_destroy(eqf_tiled* t);
+int eqf_tiled_set_stream(eqf_tiled* t, void* stream);
+/* The rank's share: rowMap[nlr] / colMap[nlc] = global landmark index of every local row / column landmark (host arrays, copied). */
+int eqf_tiled_set_geometry(eqf_tiled* t, int nlr, const int* rowMap, int nlc, const int* colMap);
+
+/* VIOFilter::processIMUData (is_imu = 1, VIOFilter.cpp:120-131) or the integrateUpToTime of processVisionData (is_imu = 0, :233;
+ * omega / accel ignored): state, base panel and -- when the call does a Riccati step -- the local blocks Sll in place
+ * (VIOFilter.cpp:188-189, F = [[F_bb, 0], [L, D]]).  Sll may be NULL while there are no landmarks.  Returns EQF_OK or the
+ * EQF_SKIPPED_* code of the reference's silent early-outs. */
+int eqf_tiled_propagate(eqf_tiled* t, double stamp, const double* omega, const double* accel, int is_imu, double* Sll, int ldl);
+/* addNewLandmarks on an empty state (VIOFilter.cpp:345-391, :361-366): n landmarks p0 = y * initialSceneDepth, Q = identity;
+ * bearings[n][3] host memory.  Sll (geometry set for n landmarks) is initialised: initialPointVariance on the diagonal.
+ * EQF_ERR_UNSUPPORTED if the filter already has landmarks. */
+int eqf_tiled_add_landmarks(eqf_tiled* t, int n, const double* bearings, double* Sll, int ldl);
+/* First half of the update (VIOFilter.cpp:264-277, EqFMatrices.cpp:319-344, :221-235): residual, C0i, lift rows; then the operands of
+ * the two factorisations from the local blocks:
+ *   M (2 nlr x ldm): columns [0, 2 nlc) S_IJ = C_I Sigma_IJ C_J^T (+ measurementVariance on the global diagonal), [2 nlc, 5 nlc)
+ *     (C Sigma)_IJ, [5 nlc, 5 nlc + 18) the narrow right-hand sides [(C Sigma)_Ib (11) | delta_I | V_I = C_I Z_I (6)];
+ *   E (3 nlr x lde): columns [0, 3 nlc) Sigma_IJ - Pg_I^T Pg_J (Schur complement of Sigma_e = Sigma[6:, 6:] after its five base
+ *     coordinates, EqFMatrices.cpp:239), [3 nlc, 3 nlc + 11) [Z_I (6) | -Pg_I^T Lg^-1 (5)];  G11 (11 x 11): the base part of
+ *     [Zt | Et]^T [Zt | Et].
+ * bearings[N][3] host memory, in state order (ids ascending = insertion order for the fixed set). */
+int eqf_tiled_update_prep(eqf_tiled* t, const double* bearings, const double* Sll, int ldl, double* M, int ldm, double* E, int lde,
+    double* G11);
+/* Second half (VIOFilter.cpp:279-297, EqFMatrices.cpp:173-275): acc (18 x ldacc, columns = 3 N in GLOBAL landmark order) = sum_k
+ * Yn_k^T Y_k, Gnn (18 x 18) = sum_k Yn_k^T Yn_k, G11 (11 x 11) complete; gamma = K delta, bundleLift, Delta, X <- Delta X, bias +=
+ * gamma[0:6]; the base panel's share of Sigma - K C Sigma.  (The local blocks were downdated by eqf_tile_gemm_tn as the solved block
+ * rows arrived.) */
+int eqf_tiled_update_finish(eqf_tiled* t, const double* acc, int ldacc, const double* Gnn, const double* G11);
+
+int eqf_tiled_synchronize(eqf_tiled* t);
+int eqf_tiled_num_landmarks(eqf_tiled* t);
+int eqf_tiled_get_time(eqf_tiled* t, double* time);
+int eqf_tiled_device_error(eqf_tiled* t);
+/* as eqf_get_state_estimate / eqf_get_origin / eqf_get_group / eqf_get_bias / eqf_get_last_update / eqf_get_integrator */
+int eqf_tiled_get_state_estimate(eqf_tiled* t, double* pose_q, double* pose_x, double* velocity, double* p);
+int eqf_tiled_get_origin(eqf_tiled* t, double* pose_q, double* pose_x, double* velocity, double* p);
+int eqf_tiled_get_group(eqf_tiled* t, double* A_q, double* A_x, double* w, double* Q_q, double* Q_a);
+int eqf_tiled_get_bias(eqf_tiled* t, double* bias6);
+int eqf_tiled_get_last_update(eqf_tiled* t, double* delta, double* gamma, double* Gamma);
+int eqf_tiled_get_integrator(eqf_tiled* t, double* currentVelocity6, double* accumulatedVelocity6, double* accumulatedTime, int* initialised);
+/* The replicated base rows Sigma[0:11, 0:11+3N] in the reference's index map (11 x ld, host memory). */
+int eqf_tiled_get_base(eqf_tiled* t, double* dst, int ld);
+/* State injection (as eqf_set_state; sigma_base = the first 11 rows of Sigma, 11 x ld, reference index map).  The caller fills Sll. */
+int eqf_tiled_set_state(eqf_tiled* t, int N, const double* pose_q, const double* pose_x, const double* velocity, const double* p0,
+    const double* A_q, const double* A_x, const double* w, const double* Q_q, const double* Q_a, const double* bias6,
+    const double* sigma_base, int ld, double currentTime, const double* currentVelocity6, const double* accumulatedVelocity6,
+    double accumulatedTime, int initialised);
+
+/* ---- Dense tile kernels of the distributed factorisations, on CALLER-OWNED device memory of HIP device `device`, enqueued on
+ * `stream` (a hipStream_t, NULL = the default stream) without synchronising; the caller's current device is restored.
+ * eqf_tile_gemm_tn: C (m x n, ldc) += alpha A^T B for A (k x m, lda), B (k x n, ldb), row-major -- every O(n^3) product of the
+ *   distributed update in the block-ROW form of the factorisation: trailing updates U_ki^T U_kj and right-hand sides U_ki^T Y_kt
+ *   (VIOFilter.cpp:276-277, EqFMatrices.cpp:239), the downdate Sigma_IJ -= Y_kI^T Y_kJ (VIOFilter.cpp:297), the reductions.
+ *   mask_rb > 0: C is the matrix part of a block-cyclic local matrix whose strictly-lower blocks are never read; tiles entirely below
+ *   the block diagonal are skipped (row r is in global block (rblk0 + r / mask_rb) * Pr + pr, column c in (cblk0 + c / mask_cb) * Pc + pc).
+ * eqf_tile_downdate = eqf_tile_gemm_tn with alpha = -1 and no mask.
+ * eqf_tile_potrf: A (n x n, ld, lower triangle) <- L with A = L L^T: the diagonal block of a block row; drec [ceil(n / 64)][5120]
+ *   receives, per 64-wide block column, L_jj and the inverses of its four 16 x 16 diagonal blocks (what eqf_tile_trsm multiplies with);
+ *   info (device int, may be NULL) is or-ed with 1 if a pivot is not positive.
+ * eqf_tile_trsm: right = 1: B (m x n, ldb) <- B L^-T; right = 0: B (n x m, ldb) <- L^-1 B (the solved block row [U_k,k+1.. | Y_k]).
+ * eqf_tile_propagate: one structured Riccati step of a (3 nI x 3 nJ) tile from explicit block arrays (kept for the block-level tests;
+ *   the closed loop uses eqf_tiled_propagate):
+ *     out = (D_I in + L_I Sigma_bJ) D_J^T + (L_I Sigma_bb + D_I Sigma_Ib) L_J^T + T (B_I R B_J^T) [+ diag_noise I on a diagonal tile] */
+int eqf_tile_gemm_tn(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k,
+    double alpha, int mask_rb, int mask_cb, int rblk0, int Pr, int pr, int cblk0, int Pc, int pc);
 int eqf_tile_propagate(int device, void* stream, double* out, const double* in, int ld, int nI, int nJ, const double* D_I,
     const double* L_I, const double* D_J, const double* L_J, const double* Sbb, const double* SbI, int ldbI, const double* SbJ,
     int ldbJ, const double* BnI, const double* BnJ, const double* R6, double T, double diag_noise, int is_diag);

@@ -1,22 +1,79 @@
-"""The tile kernels of cfg 5 (csrc/eqf_tile.hpp: eqf_tile_propagate, eqf_tile_downdate, eqf_tile_potrf, eqf_tile_trsm) on the MI355X, through the C ABI on torch
-tensors: against dense formulas on random tiles, and end to end -- the tiled Sigma of eqf_vio_amd/tiled.py on the GPU with
-these kernels, driven by the oracle's linearisation blocks, against the oracle's Sigma after every call (the multi-rank exchange
-schedule itself is validated on CPU with gloo, tests/test_tiled.py)."""
+"""BASELINE configs[4] on the MI355X: the 2-D block-partitioned filter (eqf_vio_amd/tiled.py + csrc/eqf_tiled.hpp / eqf_tile.hpp) on a
+1 x 1 process grid -- CLOSED LOOP, nothing of the oracle inside the loop: processIMUData / processVisionData run the replicated state,
+the base panel, the local blocks and the two distributed factorisations through the C ABI; the oracle and the single-GPU product path
+are the checkers.  Plus the dense tile kernels against numpy.  (The multi-rank exchange schedule is validated on CPU with gloo,
+tests/test_tiled.py.)"""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-def test_tile_propagate_and_downdate_against_dense_formulas():
+def _t(dev):
+    import torch
+
+    return lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_tile_gemm_tn_against_numpy():
+    """C += alpha A^T B (eqf_tile_gemm_tn): ragged sizes around the 128 x 128 x 16 tiling, narrow products, views with leading
+    dimensions, both signs, and the block-upper mask of a block-cyclic local matrix."""
     import torch
 
     from eqf_vio_amd import tiled
 
     dev = torch.device("cuda", 0)
-    k = tiled.TileKernels(0)
+    be = tiled.HipBackend({}, capacity=8)
+    t = _t(dev)
     rng = np.random.default_rng(3)
-    N = 45  # rows 0..19 against columns 20..44: a rectangular tile with ragged 16-landmark workgroups
+    for (m, n, k, alpha) in ((128, 128, 16, -1.0), (75, 130, 50, -1.0), (12, 12, 7, 1.0), (200, 96, 448, -1.0), (18, 777, 100, 1.0),
+                             (300, 18, 33, 1.0), (257, 513, 129, -1.0)):
+        A, B, C = rng.standard_normal((k, m + 5)), rng.standard_normal((k, n + 3)), rng.standard_normal((m, n + 7))
+        Ad, Bd, Cd = t(A), t(B), t(C)
+        be.gemm_tn(Cd[:, 2: 2 + n], Ad[:, 1: 1 + m], Bd[:, 3: 3 + n], alpha)
+        want = C.copy()
+        want[:, 2: 2 + n] += alpha * A[:, 1: 1 + m].T @ B[:, 3: 3 + n]
+        assert np.abs(Cd.cpu().numpy() - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (m, n, k)
+    # downdate entry point (alpha = -1)
+    A, B, C = rng.standard_normal((40, 70)), rng.standard_normal((40, 90)), rng.standard_normal((70, 90))
+    Cd = t(C)
+    assert be.lib.eqf_tile_downdate(0, None, be._p(Cd), 90, 70, 90, be._p(t(A)), 70, be._p(t(B)), 90, 40) == 0
+    torch.cuda.synchronize()
+    assert np.abs(Cd.cpu().numpy() - (C - A.T @ B)).max() <= 1e-12 * 100
+    # mask: local matrix of process (pr, pc) = (1, 0) on a 2 x 2 grid, blocks of 100: rows are global blocks 1, 3, 5, columns 0, 2, 4;
+    # everything on or above the block diagonal must be exact, tiles strictly below may be skipped
+    rb, nbl = 100, 3
+    m = n = rb * nbl
+    k = 64
+    A, B, C = rng.standard_normal((k, m)), rng.standard_normal((k, n)), rng.standard_normal((m, n))
+    Cd = t(C)
+    be.gemm_tn(Cd, t(A), t(B), -1.0, mask=(rb, rb, 0, 2, 1, 0, 2, 0))
+    got, want = Cd.cpu().numpy(), C - A.T @ B
+    skipped = 0
+    for ib in range(nbl):
+        for jb in range(nbl):
+            I, J = ib * 2 + 1, jb * 2
+            blk = (slice(ib * rb, (ib + 1) * rb), slice(jb * rb, (jb + 1) * rb))
+            if I <= J:
+                assert np.abs(got[blk] - want[blk]).max() <= 1e-12 * 100, (I, J)
+            else:
+                skipped += int(np.array_equal(got[blk], C[blk]))
+    assert skipped >= 1  # (whole tiles below the diagonal really are skipped)
+
+
+def test_tile_propagate_against_dense_formula():
+    import torch
+
+    from eqf_vio_amd import binding
+
+    dev = torch.device("cuda", 0)
+    t = _t(dev)
+    lib = binding.lib()
+    import ctypes
+
+    p = lambda x: ctypes.c_void_p(x.data_ptr())
+    rng = np.random.default_rng(3)
+    N = 45
     n = 11 + 3 * N
     M = rng.standard_normal((n, n))
     S = M @ M.T + n * np.eye(n)
@@ -32,122 +89,211 @@ def test_tile_propagate_and_downdate_against_dense_formulas():
     T, pv = 0.005, 0.001
     P = np.concatenate([np.full(11, 0.01), np.full(3 * N, pv)])
     ref = F @ S @ F.T + T * (np.diag(P) + (Bn * R6) @ Bn.T)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     Sd, Dd, Ld, Bd = t(S), t(D), t(F[11:, :11]), t(Bn)
     Sbb, Sb = Sd[:11, :11].contiguous(), Sd[:11, 11:].contiguous()
-    for (i0, ni, j0, nj) in ((0, 20, 20, 25), (20, 25, 20, 25), (25, 20, 0, 25)):  # off-diagonal, diagonal, below the diagonal
+    r6 = (ctypes.c_double * 6)(*R6)
+    for (i0, ni, j0, nj) in ((0, 20, 20, 25), (20, 25, 20, 25), (25, 20, 0, 25)):
         tile = Sd[11 + 3 * i0:11 + 3 * (i0 + ni), 11 + 3 * j0:11 + 3 * (j0 + nj)].contiguous()
-        out = k.propagate(tile, ni, nj, Dd[i0:], Ld[3 * i0:], Dd[j0:], Ld[3 * j0:], Sbb, Sb[:, 3 * i0:], Sb.stride(0), Sb[:, 3 * j0:], Sb.stride(0),
-                          Bd[11 + 3 * i0:], Bd[11 + 3 * j0:], R6, T, T * pv, i0 == j0 and ni == nj)
+        out = torch.empty_like(tile)
+        rc = lib.eqf_tile_propagate(0, None, p(out), p(tile), tile.stride(0), ni, nj, p(Dd[i0:]), p(Ld[3 * i0:]), p(Dd[j0:]), p(Ld[3 * j0:]), p(Sbb),
+                                    p(Sb[:, 3 * i0:]), Sb.stride(0), p(Sb[:, 3 * j0:]), Sb.stride(0), p(Bd[11 + 3 * i0:]), p(Bd[11 + 3 * j0:]),
+                                    ctypes.cast(r6, ctypes.POINTER(ctypes.c_double)), T, T * pv, int(i0 == j0 and ni == nj))
+        assert rc == 0
         want = ref[11 + 3 * i0:11 + 3 * (i0 + ni), 11 + 3 * j0:11 + 3 * (j0 + nj)]
         assert np.abs(out.cpu().numpy() - want).max() <= 1e-12 * np.abs(want).max(), (i0, j0)
-    # downdate: sizes that are not multiples of the 64 x 64 x 32 tiling
-    for (m, n2, kk) in ((64, 64, 32), (75, 130, 50), (12, 12, 7), (200, 96, 448)):
-        A, B, C = rng.standard_normal((kk, m)), rng.standard_normal((kk, n2)), rng.standard_normal((m, n2))
-        Cd = t(C)
-        k.downdate(Cd, t(A), t(B))
-        want = C - A.T @ B
-        assert np.abs(Cd.cpu().numpy() - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (m, n2, kk)
 
 
-@pytest.mark.parametrize("n", [16, 64, 96, 200, 384])
+@pytest.mark.parametrize("n", [16, 64, 96, 200, 384, 500, 750])
 def test_tile_potrf_and_trsm_against_lapack(n):
-    """eqf_tile_potrf / eqf_tile_trsm (the panel operations of the distributed factorisation, csrc/eqf_tile.hpp) against numpy's
-    Cholesky and triangular solves: block sizes below, at and between multiples of the 64-wide block column."""
+    """eqf_tile_potrf / eqf_tile_trsm (the diagonal block and the block-row solve of the distributed factorisation) against numpy, in place
+    on views with a leading dimension: block sizes below, at and between multiples of the 64-wide block column, up to the 2 bl = 500 and
+    3 bl = 750 of the N = 4000 configuration."""
     import torch
 
     from eqf_vio_amd import tiled
 
     dev = torch.device("cuda", 0)
-    k = tiled.TileKernels(0)
+    be = tiled.HipBackend({}, capacity=8)
+    t = _t(dev)
     rng = np.random.default_rng(100 + n)
     M = rng.standard_normal((n, n))
     A = M @ M.T + n * np.eye(n)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    L, drec = k.potrf(t(A))
-    torch.cuda.synchronize()
-    assert int(k._info.item()) == 0
+    big = t(np.pad(A, ((3, 2), (5, 4))))
+    Ad = big[3: 3 + n, 5: 5 + n]
+    drec = be.potrf(Ad)
+    assert be.factor_info() == 0
     Lref = np.linalg.cholesky(A)
-    Lg = L.cpu().numpy()
-    assert np.abs(np.triu(Lg, 1)).max() == 0.0
+    Lg = np.tril(Ad.cpu().numpy())
     assert np.abs(Lg - Lref).max() <= 1e-12 * np.abs(Lref).max()
+    L = Ad.clone()
     for m in (1, 64, 70, 150):
-        B = rng.standard_normal((m, n))
-        X = k.trsm(L, drec, t(B), True).cpu().numpy()          # B L^-T
-        want = np.linalg.solve(Lref, B.T).T
-        assert np.abs(X - want).max() <= 1e-11 * max(1.0, np.abs(want).max()), (n, m, "right")
-        B2 = rng.standard_normal((n, m))
-        Y = k.trsm(L, drec, t(B2), False).cpu().numpy()        # L^-1 B
-        want = np.linalg.solve(Lref, B2)
-        assert np.abs(Y - want).max() <= 1e-11 * max(1.0, np.abs(want).max()), (n, m, "left")
-    # a matrix that is not positive definite raises the flag instead of producing NaNs silently
+        B2 = rng.standard_normal((n, m + 6))
+        Bd = t(B2)
+        be.trsm_left(L, drec, Bd[:, 4: 4 + m])  # L^-1 B on a view
+        want = B2.copy()
+        want[:, 4: 4 + m] = np.linalg.solve(Lref, B2[:, 4: 4 + m])
+        assert np.abs(Bd.cpu().numpy() - want).max() <= 1e-11 * max(1.0, np.abs(want).max()), (n, m)
     Abad = A.copy()
     Abad[n // 2, n // 2] = -1.0
-    k.potrf(t(Abad))
-    torch.cuda.synchronize()
-    assert int(k._info.item()) == 1
+    be.potrf(t(Abad))
+    assert be.factor_info() == 1  # a matrix that is not positive definite raises the flag instead of producing NaNs silently
 
 
-def test_tiled_sigma_on_the_gpu_with_the_tile_kernels(oracle_lib):
-    """One rank (1 x 1 grid) on the GPU: Riccati steps, downdates and the panel operations (diagonal-block Cholesky, triangular solves) through eqf_tile_*; Sigma
-    against the oracle after every IMU / vision call of a short stream, open loop as in tests/test_tiled.py."""
-    import torch
-
-    from eqf_vio_amd import synth, tiled
-
-    ob = oracle_lib
-    dev = torch.device("cuda", 0)
-    N, bl = 48, 16
-    grid = tiled.ProcessGrid(None, 1, 1, device=dev, kernels=tiled.TileKernels(0))
-    st = synth.make_stream(N, duration=0.21)
-    d = synth.template_settings_dict()
-    fo = ob.OracleFilter(d)
-    n = 11 + 3 * N
-    Rdiag = torch.tensor([d["velOmegaVariance"]] * 3 + [d["velAccelVariance"]] * 3, dtype=torch.float64, device=dev)
-    Pb = torch.tensor([d["biasOmegaProcessVariance"]] * 3 + [d["biasAccelProcessVariance"]] * 3 + [d["gravityProcessVariance"]] * 2
-                      + [d["velocityProcessVariance"]] * 3, dtype=torch.float64, device=dev)
-
-    def inputs(stamp, omega):
-        T = stamp - fo.getTime()
-        g_, x_ = fo.group(), fo.xi0()
-        A0, Bm, C0 = ob.matrices(ob.pack_group(g_["Aq"], g_["Ax"], g_["w"], g_["Qq"], g_["Qa"]), ob.pack_state(x_["q"], x_["x"], x_["v"], x_["p"]),
-                                 d["cameraOffset_q"], d["cameraOffset_x"], omega)
-        Ab = np.zeros((n, n))
-        Ab[6:, 6:] = A0
-        Ab[6:, :6] = -Bm
-        F = torch.from_numpy(np.eye(n) + T * Ab).to(dev)
-        Bn = torch.zeros((n, 6), dtype=torch.float64, device=dev)
-        Bn[6:] = torch.from_numpy(Bm).to(dev)
-        Dblk = torch.stack([F[11 + 3 * i:14 + 3 * i, 11 + 3 * i:14 + 3 * i] for i in range(N)]).contiguous()
-        Qbb = T * (torch.diag(Pb) + (Bn[:11] * Rdiag) @ Bn[:11].T)
-        Cblk = torch.stack([torch.from_numpy(C0[2 * i:2 * i + 2, 5 + 3 * i:8 + 3 * i].copy()) for i in range(N)]).to(dev)
-        return T, F[:11, :11].contiguous(), F[11:, :11].contiguous(), Dblk, Qbb, Bn, Cblk
-
+def _drive(tf, fo, fg, st, frames_checked, tolS):
+    """Same stream into the tiled filter `tf`, the oracle `fo` and (optionally) the single-GPU product path `fg`; after every vision
+    call: Sigma, pose, landmarks, bias against the oracle (and the product path)."""
     rel = lambda A, B: float(np.linalg.norm(A - B) / np.linalg.norm(B))
-    ts, cur_w, worst, n_upd = None, np.zeros(3), 0.0, 0
+    worst = {"S_oracle": 0.0, "S_product": 0.0, "pose": 0.0}
+    n_upd = 0
     for kind, k in st.events():
         if kind == "imu":
             r = st.imu[k]
-            if ts is not None:
-                T, Fbb, L, Dblk, Qbb, Bn, _ = inputs(r[0], cur_w)
-            bias = fo.bias()
-            fo.processIMUData(r[0], r[1:4], r[4:7])
-            cur_w = r[1:4] - bias[:3]
-            if ts is not None:
-                tiled.propagate(ts, Fbb, L, Dblk, Qbb, Bn, Rdiag, T, d["pointProcessVariance"])
-                worst = max(worst, rel(ts.to_dense().cpu().numpy(), fo.stateCovariance()))
+            tf.processIMUData(r[0], r[1:4], r[4:7])
+            if fo is not None:
+                fo.processIMUData(r[0], r[1:4], r[4:7])
+            if fg is not None:
+                fg.process_imu([r[0]], r[1:4], r[4:7])
         else:
             stamp = st.vision_stamps[k]
-            if ts is not None:
-                T, Fbb, L, Dblk, Qbb, Bn, Cblk = inputs(stamp, cur_w)
-            fo.processVisionData(stamp, st.ids, st.bearings[k])
-            if ts is None:
-                ts = tiled.TiledSigma.from_dense(grid, fo.stateCovariance(), bl)
-                continue
-            lu = fo.last_update()
-            tiled.propagate(ts, Fbb, L, Dblk, Qbb, Bn, Rdiag, T, d["pointProcessVariance"])
-            gamma = tiled.update(ts, Cblk, lu["delta"], d["measurementVariance"]).cpu().numpy()
-            assert np.abs(gamma - lu["gamma"]).max() < 1e-8 * max(1.0, np.abs(lu["gamma"]).max())
-            worst = max(worst, rel(ts.to_dense().cpu().numpy(), fo.stateCovariance()))
+            assert tf.processVisionData(stamp, st.ids, st.bearings[k]) == 0
+            if fo is not None:
+                fo.processVisionData(stamp, st.ids, st.bearings[k])
+            if fg is not None:
+                fg.process_vision([stamp], st.ids, st.bearings[k])
             n_upd += 1
-    assert n_upd >= 3 and worst < 1e-9, worst
+            if n_upd > frames_checked:
+                continue
+            St = tf.stateCovariance()
+            et = tf.stateEstimate()
+            assert np.abs(St - St.T).max() <= 1e-9 * np.abs(St).max()
+            if fo is not None:
+                worst["S_oracle"] = max(worst["S_oracle"], rel(St, fo.stateCovariance()))
+                eo = fo.stateEstimate()
+                worst["pose"] = max(worst["pose"], float(np.abs(eo["x"] - et["x"]).max()), float(np.abs(eo["q"] - et["q"]).max()),
+                                    float(np.abs(eo["p"] - et["p"]).max()), float(np.abs(fo.bias() - tf.be.bias()).max()))
+            if fg is not None:
+                worst["S_product"] = max(worst["S_product"], rel(St, fg.sigma()))
+                eg = fg.state_estimate()
+                worst["pose"] = max(worst["pose"], float(np.abs(eg["x"] - et["x"]).max()), float(np.abs(eg["q"] - et["q"]).max()))
+    assert tf.be.device_error() == 0
+    assert worst["S_oracle"] <= tolS and worst["S_product"] <= tolS and worst["pose"] <= 1e-8, worst
+    return worst, n_upd
+
+
+@pytest.mark.parametrize("N,bl", [(48, 16), (50, 16), (37, 8), (200, 64)])
+def test_tiled_filter_closed_loop_small(oracle_lib, N, bl):
+    """1 x 1 grid, whole blocks and a ragged last block: first frame (landmarks appended), IMU steps, updates -- against the dense oracle
+    and the single-GPU product path after every frame.  Also delta / gamma / Gamma of the last update against the oracle's."""
+    from eqf_vio_amd import binding, synth, tiled
+
+    d = synth.template_settings_dict()
+    st = synth.make_stream(N, duration=0.26)
+    be = tiled.HipBackend(d, capacity=N)
+    tf = tiled.TiledFilter(tiled.ProcessGrid(None, 1, 1, device=be.device), be, bl)
+    fo = oracle_lib.OracleFilter(d)
+    fg = binding.FilterBatch(d, capacity=N, batch=1)
+    worst, n_upd = _drive(tf, fo, fg, st, 99, 1e-9)
+    assert n_upd >= 5
+    lt, lo = be.last_update(), fo.last_update()
+    for key, tol in (("delta", 1e-10), ("gamma", 1e-8), ("Gamma", 1e-8)):
+        assert np.abs(lt[key] - lo[key]).max() <= tol * max(1.0, np.abs(lo[key]).max()), key
+
+
+def test_tiled_filter_restart_from_a_single_gpu_snapshot(oracle_lib):
+    """initialise_from(FilterBatch.dump_state()): the tiled filter continues a stream the product path started, and stays with it."""
+    from eqf_vio_amd import binding, synth, tiled
+
+    N, bl = 64, 16
+    d = synth.template_settings_dict()
+    st = synth.make_stream(N, duration=0.36)
+    fg = binding.FilterBatch(d, capacity=N, batch=1)
+    ev = list(st.events())
+    cut = next(i for i, (kind, k) in enumerate(ev) if kind == "vision" and k == 2) + 4
+    for kind, k in ev[:cut]:
+        if kind == "imu":
+            r = st.imu[k]
+            fg.process_imu([r[0]], r[1:4], r[4:7])
+        else:
+            fg.process_vision([st.vision_stamps[k]], st.ids, st.bearings[k])
+    be = tiled.HipBackend(d, capacity=N)
+    tf = tiled.TiledFilter(tiled.ProcessGrid(None, 1, 1, device=be.device), be, bl)
+    tf.initialise_from(fg.dump_state())
+    S0, Sg0 = tf.stateCovariance(), fg.sigma()
+    # bitwise the same rows and blocks; the tiled filter keeps only the base ROWS (the single-GPU path's base columns are its rows'
+    # transpose up to rounding when its fused tile kernel wrote them)
+    assert np.array_equal(S0[:11], Sg0[:11]) and np.array_equal(S0[11:, 11:], Sg0[11:, 11:])
+    assert np.abs(S0 - Sg0).max() <= 1e-12 * np.abs(Sg0).max()
+    rel = lambda A, B: float(np.linalg.norm(A - B) / np.linalg.norm(B))
+    for kind, k in ev[cut:]:
+        if kind == "imu":
+            r = st.imu[k]
+            fg.process_imu([r[0]], r[1:4], r[4:7])
+            tf.processIMUData(r[0], r[1:4], r[4:7])
+        else:
+            fg.process_vision([st.vision_stamps[k]], st.ids, st.bearings[k])
+            assert tf.processVisionData(st.vision_stamps[k], st.ids, st.bearings[k]) == 0
+            assert rel(tf.stateCovariance(), fg.sigma()) <= 1e-9
+    e1, e2 = tf.stateEstimate(), fg.state_estimate()
+    assert np.abs(e1["x"] - e2["x"]).max() <= 1e-9 and np.abs(e1["q"] - e2["q"]).max() <= 1e-9 and be.device_error() == 0
+
+
+def test_tiled_filter_N1000_against_the_structured_oracle(oracle_lib):
+    """BASELINE cfg 3's size on the partitioned path: N = 1000, blocks of 125 (8 x 8 blocks), three updates against the structured fp64
+    oracle (pinned to the dense one by tests/test_oracle_structured.py)."""
+    from eqf_vio_amd import synth, tiled
+
+    N, bl = 1000, 125
+    d = synth.template_settings_dict()
+    st = synth.make_stream(N, duration=0.16)
+    be = tiled.HipBackend(d, capacity=N)
+    tf = tiled.TiledFilter(tiled.ProcessGrid(None, 1, 1, device=be.device), be, bl)
+    fo = oracle_lib.OracleFilter(d, structured=True)
+    worst, n_upd = _drive(tf, fo, None, st, 99, 1e-7)
+    assert n_upd >= 3 and worst["S_oracle"] <= 1e-8, worst
+
+
+def test_tiled_filter_N4000_against_the_single_gpu_product_path():
+    """BASELINE configs[4] at its size: N = 4000 (Sigma 12011 x 12011, 1.15 GB), blocks of 250 (16 x 16 blocks of 750 x 750), on the 1 x 1
+    grid: the first frame (4000 landmarks appended + update), a burst of IMU steps, the second frame's update -- Sigma against the
+    single-GPU product path to 1e-9 (which profiles/r02_parity_large_N.txt ties to the structured oracle at this size), symmetry,
+    positive definiteness (Cholesky succeeds), and the trace going down in every update."""
+    import torch
+
+    from eqf_vio_amd import binding, synth, tiled
+
+    N, bl = 4000, 250
+    d = synth.template_settings_dict()
+    st = synth.make_stream(N, duration=0.11)
+    be = tiled.HipBackend(d, capacity=N)
+    tf = tiled.TiledFilter(tiled.ProcessGrid(None, 1, 1, device=be.device), be, bl)
+    fg = binding.FilterBatch(d, capacity=N, batch=1)
+    rel = lambda A, B: float(np.linalg.norm(A - B) / np.linalg.norm(B))
+    n_upd = 0
+    for kind, k in st.events():
+        if kind == "imu":
+            r = st.imu[k]
+            tf.processIMUData(r[0], r[1:4], r[4:7])
+            fg.process_imu([r[0]], r[1:4], r[4:7])
+        else:
+            stamp = st.vision_stamps[k]
+            fg.process_vision([stamp], st.ids, st.bearings[k])
+            n_upd += 1
+            if n_upd == 1:
+                assert tf.processVisionData(stamp, st.ids, st.bearings[k]) == 0
+                prior_tr = 11.0 + 3 * N * d["initialPointVariance"]  # (an upper bound of the prior's trace: the new landmarks' variance)
+            else:
+                # the two halves of processVisionData by hand, to see the prior: integrateUpToTime (VIOFilter.cpp:233), then the update
+                assert be.propagate(stamp, None, None, False, tf.Sll) == 0
+                prior_tr = float(np.trace(tf.stateCovariance()))
+                tf._update(np.asarray(st.bearings[k], dtype=np.float64))
+            St, Sg = tf.stateCovariance(), fg.sigma()
+            assert rel(St, Sg) <= 1e-9, (k, rel(St, Sg))
+            assert np.abs(St - St.T).max() <= 1e-9 * np.abs(St).max()
+            assert float(np.trace(St)) < prior_tr  # Sigma - K C Sigma takes a positive semi-definite matrix away
+            if n_upd == 2:
+                Sd = torch.from_numpy(St).to(be.device)
+                torch.linalg.cholesky(Sd)  # raises if Sigma is not positive definite
+                del Sd
+    assert n_upd >= 2 and be.device_error() == 0 and fg.device_error() == 0
+    et, eg = tf.stateEstimate(), fg.state_estimate()
+    assert np.abs(et["x"] - eg["x"]).max() <= 1e-9 and np.abs(et["q"] - eg["q"]).max() <= 1e-9 and np.abs(et["p"] - eg["p"]).max() <= 1e-8

@@ -1,9 +1,9 @@
-"""cfg 5 groundwork: Sigma 2-D block-partitioned over a process grid -- the exchange schedule of
-eqf_vio_amd/tiled.py (tile-local Riccati step; distributed Cholesky-form update with one panel all-gather and one block-row
-all-gather per block column; bundleLift's Sigma_e^-1 quadratic form) on CPU with gloo, 2 ranks (1 x 2 grid) and 4 ranks (2 x 2),
-against the single-process oracle on the same stream.  The filter STATE is replicated (every rank runs the same oracle filter
-for the O(N) part and takes the linearisation blocks from it); the distributed Sigma is advanced open-loop with those blocks and
-compared with the oracle's after every call."""
+"""BASELINE configs[4] / SURVEY.md 8(e) row 2 on CPU: the exchange schedule of eqf_vio_amd/tiled.py -- block-cyclic local matrices, the
+two distributed factorisations with their row / column-restricted broadcasts, the downdate and the reductions -- CLOSED LOOP over gloo on
+1 x 1, 1 x 2, 2 x 2 and 2 x 4 process grids (the grid of one 8-GPU node), whole and ragged landmark blocks.  Every rank runs
+TiledFilter.processIMUData / processVisionData; gamma, the innovation lift and the state come out of the distributed quantities (nothing
+is taken from a reference filter inside the loop).  The per-rank mathematics is the CPU test double of the HIP backend
+(tests/tiled_double.py); the checker is the single-process dense fp64 oracle on the same stream."""
 import os
 import socket
 import sys
@@ -25,99 +25,82 @@ def _free_port():
 
 def _worker(rank, world, port, Pr, Pc, N, bl, out_dir):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
     import torch.distributed as dist
 
     from eqf_vio_amd import synth, tiled
     from oracle import binding as ob
+    from tiled_double import NumpyBackend
 
     torch.set_num_threads(1)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    grid = tiled.ProcessGrid(dist, Pr, Pc)
+    dist_ = None
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist_ = dist
+    grid = tiled.ProcessGrid(dist_, Pr, Pc)
     st = synth.make_stream(N, duration=0.26)
     d = synth.template_settings_dict()
-    fo = ob.OracleFilter(d)
-    n = 11 + 3 * N
-    Rdiag = torch.tensor([d["velOmegaVariance"]] * 3 + [d["velAccelVariance"]] * 3, dtype=torch.float64)
-    Pb = torch.tensor([d["biasOmegaProcessVariance"]] * 3 + [d["biasAccelProcessVariance"]] * 3 + [d["gravityProcessVariance"]] * 2
-                      + [d["velocityProcessVariance"]] * 3, dtype=torch.float64)
-
-    def riccati_inputs(stamp, omega):
-        """F = I + T A_b and the noise terms at the oracle's CURRENT state (VIOFilter.cpp:160-189), cut into the pieces propagate()
-        takes; the oracle supplies A0, B (EqFMatrices.cpp:277-382)."""
-        T = stamp - fo.getTime()
-        g_, x_ = fo.group(), fo.xi0()
-        A0, Bm, C0 = ob.matrices(ob.pack_group(g_["Aq"], g_["Ax"], g_["w"], g_["Qq"], g_["Qa"]), ob.pack_state(x_["q"], x_["x"], x_["v"], x_["p"]),
-                                 d["cameraOffset_q"], d["cameraOffset_x"], omega)
-        Ab = np.zeros((n, n))
-        Ab[6:, 6:] = A0
-        Ab[6:, :6] = -Bm
-        F = torch.from_numpy(np.eye(n) + T * Ab)
-        Bn = torch.zeros((n, 6), dtype=torch.float64)
-        Bn[6:] = torch.from_numpy(Bm)
-        Dblk = torch.stack([F[11 + 3 * i:14 + 3 * i, 11 + 3 * i:14 + 3 * i] for i in range(N)])
-        Qbb = T * (torch.diag(Pb) + (Bn[:11] * Rdiag) @ Bn[:11].T)
-        Cblk = torch.stack([torch.from_numpy(C0[2 * i:2 * i + 2, 5 + 3 * i:8 + 3 * i].copy()) for i in range(N)])
-        return T, F[:11, :11].clone(), F[11:, :11].clone(), Dblk, Qbb, Bn, Cblk
-
-    ts = None
-    cur_w = np.zeros(3)
-    worst = dict(prop=0.0, upd=0.0, gamma=0.0, quad=0.0)
+    tf = tiled.TiledFilter(grid, NumpyBackend(d, N), bl)
+    fo = ob.OracleFilter(d)  # the checker: dense fp64, reference op order
+    worst = dict(S=0.0, pose=0.0, gamma=0.0, Gamma=0.0, delta=0.0)
     n_upd = 0
-
-    def rel(A, B):
-        return float(np.linalg.norm(A - B) / np.linalg.norm(B))
-
+    rel = lambda A, B: float(np.linalg.norm(A - B) / np.linalg.norm(B))
     for kind, k in st.events():
         if kind == "imu":
             r = st.imu[k]
-            if ts is not None:
-                T, Fbb, L, Dblk, Qbb, Bn, _ = riccati_inputs(r[0], cur_w)
-            bias = fo.bias()
             fo.processIMUData(r[0], r[1:4], r[4:7])
-            cur_w = r[1:4] - bias[:3]
-            if ts is not None:
-                tiled.propagate(ts, Fbb, L, Dblk, Qbb, Bn, Rdiag, T, d["pointProcessVariance"])
-                worst["prop"] = max(worst["prop"], rel(ts.to_dense().numpy(), fo.stateCovariance()))
+            tf.processIMUData(r[0], r[1:4], r[4:7])
         else:
             stamp = st.vision_stamps[k]
-            if ts is not None:
-                T, Fbb, L, Dblk, Qbb, Bn, Cblk = riccati_inputs(stamp, cur_w)
             fo.processVisionData(stamp, st.ids, st.bearings[k])
-            if ts is None:
-                ts = tiled.TiledSigma.from_dense(grid, fo.stateCovariance(), bl)  # landmarks exist from here on
-                assert rel(ts.to_dense().numpy(), fo.stateCovariance()) == 0.0
-                continue
-            lu = fo.last_update()
-            tiled.propagate(ts, Fbb, L, Dblk, Qbb, Bn, Rdiag, T, d["pointProcessVariance"])
-            # bundleLift's weights on the PRE-update Sigma (VIOFilter.cpp:285 precedes :297), random regressors
-            Sm = ts.to_dense().numpy()
-            V = np.random.default_rng(7 + k).standard_normal((5 + 3 * N, 11))
-            G = tiled.sigma_e_quadratic_form(ts, V).numpy()
-            Gref = V.T @ np.linalg.solve(Sm[6:, 6:], V)
-            worst["quad"] = max(worst["quad"], rel(G, Gref))
-            gamma = tiled.update(ts, Cblk, lu["delta"], d["measurementVariance"]).numpy()
-            worst["gamma"] = max(worst["gamma"], float(np.abs(gamma - lu["gamma"]).max() / max(1.0, np.abs(lu["gamma"]).max())))
-            worst["upd"] = max(worst["upd"], rel(ts.to_dense().numpy(), fo.stateCovariance()))
+            assert tf.processVisionData(stamp, st.ids, st.bearings[k]) == 0
             n_upd += 1
-    owned = len(ts.t)
-    np.save(os.path.join(out_dir, f"worst_{rank}.npy"), np.array([worst["prop"], worst["upd"], worst["gamma"], worst["quad"], n_upd, owned]))
-    dist.barrier()
-    dist.destroy_process_group()
+            worst["S"] = max(worst["S"], rel(tf.stateCovariance(), fo.stateCovariance()))
+            eo, et = fo.stateEstimate(), tf.stateEstimate()
+            worst["pose"] = max(worst["pose"], float(np.abs(eo["x"] - et["x"]).max()), float(np.abs(eo["q"] - et["q"]).max()),
+                                float(np.abs(eo["p"] - et["p"]).max()), float(np.abs(fo.bias() - tf.be.bias()).max()))
+            lo, lt = fo.last_update(), tf.be.last_update()
+            for key in ("delta", "gamma", "Gamma"):
+                worst[key] = max(worst[key], float(np.abs(lo[key] - lt[key]).max() / max(1.0, np.abs(lo[key]).max())))
+    owned = tf.geo.nlr * tf.geo.nlc
+    np.save(os.path.join(out_dir, f"worst_{rank}.npy"), np.array([worst["S"], worst["pose"], worst["gamma"], worst["Gamma"], worst["delta"], n_upd, owned]))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("Pr,Pc", [(1, 2), (2, 2)])
-def test_tiled_sigma_over_a_process_grid_matches_the_single_process_oracle(tmp_path, Pr, Pc):
-    world, N, bl = Pr * Pc, 24, 4  # 6 x 6 landmark tiles of 12 x 12, dealt block-cyclically
-    mp.spawn(_worker, args=(world, _free_port(), Pr, Pc, N, bl, str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("Pr,Pc,N,bl", [(1, 1, 26, 4), (1, 2, 24, 4), (2, 2, 26, 4), (2, 4, 34, 4)])
+def test_tiled_filter_closed_loop_over_a_process_grid_matches_the_single_process_oracle(tmp_path, Pr, Pc, N, bl):
+    world = Pr * Pc
+    if world == 1:
+        _worker(0, 1, 0, Pr, Pc, N, bl, str(tmp_path))
+    else:
+        mp.spawn(_worker, args=(world, _free_port(), Pr, Pc, N, bl, str(tmp_path)), nprocs=world, join=True)
     owned = 0
     for r in range(world):
-        prop, upd, gamma, quad, n_upd, own = np.load(tmp_path / f"worst_{r}.npy")
-        assert n_upd >= 4
-        # open-loop over 4 updates + 50 Riccati steps: rounding amplified by cond(Sigma) ~ 1e7, as between any two evaluations
-        assert prop < 1e-9 and upd < 1e-9, (r, prop, upd)
-        assert gamma < 1e-8 and quad < 1e-8, (r, gamma, quad)
+        S, pose, gamma, Gamma, delta, n_upd, own = np.load(tmp_path / f"worst_{r}.npy")
+        assert n_upd >= 5
+        # closed loop over 5 updates + 50 Riccati steps: rounding amplified by cond(Sigma) ~ 1e7, as between any two fp64 evaluations
+        assert S < 1e-9 and pose < 1e-9, (r, S, pose)
+        assert delta < 1e-11 and gamma < 1e-8 and Gamma < 1e-8, (r, delta, gamma, Gamma)
         owned += own
-    assert owned == (N // bl) ** 2  # every tile has exactly one owner
+    assert owned == N * N  # every landmark pair has exactly one owner
+
+
+def test_block_cyclic_geometry():
+    from eqf_vio_amd.tiled import BlockCyclic
+
+    N, bl, Pr, Pc = 34, 4, 2, 4
+    seen = np.zeros((N, N), dtype=int)
+    for pr in range(Pr):
+        for pc in range(Pc):
+            g = BlockCyclic(N, bl, Pr, Pc, pr, pc)
+            seen[np.ix_(g.rowMap, g.colMap)] += 1
+            assert g.nlc == g.ncols_of(pc)
+            # only the globally last block is ragged, and it is the last local block of whoever owns it
+            assert all(g.block_size(b) == bl for b in g.row_blocks[:-1]) and all(g.block_size(b) == bl for b in g.col_blocks[:-1])
+    assert (seen == 1).all()
+    assert [BlockCyclic.blocks_upto(k, 1, 4) for k in range(10)] == [0, 1, 1, 1, 1, 2, 2, 2, 2, 3]
