@@ -51,11 +51,12 @@ def parse():
     ap.add_argument("--no-batch64", action="store_true", help="skip the strong-scaling leg (64 filters in total over the GPUs)")
     ap.add_argument("--batch64-steps", type=int, default=440)
     ap.add_argument("--no-steady-state", action="store_true", help="skip the 2200-step leg that accompanies a short --steps run")
-    ap.add_argument("--tiled", action="store_true", help="add the cfg 5 leg: one N = --tiled-landmarks filter with Sigma 2-D block-partitioned "
-                    "over the ranks of the job (1 x 1 grid on one GPU), closed loop through eqf_vio_amd/tiled.py")
+    ap.add_argument("--no-tiled", action="store_true", help="skip the cfg 5 leg: one N = --tiled-landmarks filter with Sigma 2-D block-partitioned "
+                    "over the ranks of the job (1 x 1 grid on one GPU, 2 x 4 on eight), closed loop through eqf_vio_amd/tiled.py")
+    ap.add_argument("--tiled", action="store_true", help="(the cfg 5 leg is on by default; kept for explicitness)")
     ap.add_argument("--tiled-landmarks", type=int, default=4000)
     ap.add_argument("--tiled-block", type=int, default=250, help="landmarks per block of the 2-D partition")
-    ap.add_argument("--tiled-frames", type=int, default=2)
+    ap.add_argument("--tiled-frames", type=int, default=3, help="timed frames (a frame = 10 IMU calls + 1 vision call) after one warm-up frame")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle-checked prefix (parity block of the JSON line)")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed throw-away run that precedes the measured job")
     ap.add_argument("--no-roofline", action="store_true")
@@ -357,6 +358,94 @@ def timed_job(args, dist, rank, world, device, N, B, steps, warmup, dense=False)
     return fb, timed, dt, res
 
 
+GRIDS = {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (2, 4)}
+
+
+def tiled_leg(args, dist, rank, world, device):
+    """BASELINE configs[4]: ONE filter of N landmarks, Sigma 2-D block-partitioned over the ranks of the job (eqf_vio_amd/tiled.py), closed
+    loop, the same stream on every rank.  One warm-up frame (the first frame: landmarks appended + update), then `frames` timed frames of
+    10 IMU calls + 1 vision call, bracketed by barrier + synchronize, maximum over the ranks.  On one GPU the monolithic single-GPU path
+    runs the same events right after, for the number next to it."""
+    import torch
+
+    from eqf_vio_amd import binding, synth, tiled
+
+    N, bl, frames = args.tiled_landmarks, args.tiled_block, args.tiled_frames
+    Pr, Pc = GRIDS[world]
+    st = synth.make_stream(N, seed=1234, duration=(frames + 2) / 20.0 + 0.011)
+    ev = list(st.events())
+    first_vis = next(i for i, (kind, _) in enumerate(ev) if kind == "vision")
+    warm, timed = ev[: first_vis + 1], ev[first_vis + 1: first_vis + 1 + 11 * frames]
+    d = synth.template_settings_dict()
+    be = tiled.HipBackend(d, capacity=N, device_index=device)
+    tf = tiled.TiledFilter(tiled.ProcessGrid(dist if world > 1 else None, Pr, Pc, device=be.device), be, bl)
+
+    def run(f_imu, f_vis, events):
+        for kind, k in events:
+            if kind == "imu":
+                r = st.imu[k]
+                f_imu(r[0], r[1:4], r[4:7])
+            else:
+                f_vis(st.vision_stamps[k], st.ids, st.bearings[k])
+
+    def timed_run(f_imu, f_vis, sync):
+        run(f_imu, f_vis, warm)
+        sync()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(f_imu, f_vis, timed)
+        sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    tf.check_every = 0  # (the pivot flag is looked at once, after the timed region)
+    run(tf.processIMUData, tf.processVisionData, [])
+    tf.phase_ms = None
+    dt = timed_run(tf.processIMUData, tf.processVisionData, lambda: torch.cuda.synchronize())
+    tf.check()
+    # per-phase GPU time: a second pass over the next frames with event brackets (kept out of the timed region)
+    tf.phase_ms = {}
+    more = ev[first_vis + 1 + 11 * frames: first_vis + 1 + 11 * (frames + 1)]
+    run(tf.processIMUData, tf.processVisionData, more)
+    tf.collect_phases()
+    n_vis_ph = max(sum(1 for kind, _ in more if kind == "vision"), 1)
+    n = 11 + 3 * N
+    m, ne = 2 * N, 5 + 3 * N
+    n_vis = sum(1 for kind, _ in timed if kind == "vision")
+    update_flops = m**3 / 3.0 + 2.0 * m * m * n + 2.0 * n * n * m + ne**3 / 3.0  # SURVEY.md 8(d)
+    out = {
+        "metric": "EqF propagate+update steps/sec, ONE filter of N=%d landmarks, Sigma 2-D block-partitioned over %d GPU(s)" % (N, world),
+        "value": len(timed) / dt, "unit": "steps/s", "n_gpus": world, "grid": "%d x %d" % (Pr, Pc), "block_landmarks": bl, "steps": len(timed),
+        "ms_per_step": dt * 1e3 / len(timed), "ms_per_frame": dt * 1e3 / max(n_vis, 1), "scaling": "strong", "dtype": "f64",
+        "device_error_flag": be.device_error(),
+        "sigma_fro_local": float(torch.linalg.norm(tf.Sll).item()),
+        "phases_ms_per_frame": {k: round(v / n_vis_ph, 3) for k, v in tf.phase_ms.items()},
+        "update_algorithmic_tflops": round(update_flops * n_vis_ph / max(sum(v for k, v in tf.phase_ms.items() if k != "propagate"), 1e-9) / 1e9, 2)
+        if tf.phase_ms else None,
+        "note": "closed loop through the C ABI (eqf_tiled_* / eqf_tile_*), torch.distributed only moves solved block rows; "
+                + ("one rank: no exchange" if world == 1 else "RCCL broadcasts along process rows / columns"),
+    }
+    if world > 1:
+        out["note"] += "; UNMEASURED on more than one GPU until a node is available to the builder -- this line is then the first measurement"
+    del tf, be
+    if world == 1 and rank == 0:
+        fb = binding.FilterBatch(d, capacity=N, batch=1, device=device)
+        dtm = timed_run(lambda s_, w_, a_: fb.process_imu([s_], w_, a_), lambda s_, i_, y_: fb.process_vision([s_], i_, y_), fb.synchronize)
+        out["monolithic_single_gpu"] = {"value": len(timed) / dtm, "unit": "steps/s", "ms_per_frame": dtm * 1e3 / max(n_vis, 1),
+                                        "note": "the single-GPU product path (eqf_process_*) on the same events"}
+        del fb
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -473,6 +562,10 @@ def main():
             "device_error_flag": err2,
             "sigma_fro_min_max": [float(res2[:, 7].min()), float(res2[:, 7].max())] if res2 is not None else None,
         }
+
+    # ---- BASELINE configs[4]: one N = 4000 filter partitioned over the ranks of the job
+    if not args.no_tiled and world in GRIDS and not args.dense_propagate and not args.pmc_child:
+        line["tiled_cfg5"] = tiled_leg(args, dist, rank, world, device)
 
     if rank == 0 and world == 1:
         rl = line.get("roofline")

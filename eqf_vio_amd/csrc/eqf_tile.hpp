@@ -138,8 +138,10 @@ __global__ __launch_bounds__(256, 2) void k_tile_gemm_tn(double* C, int ldc, int
     double alpha, GemmMask mk, int tm, int tn) {
     extern __shared__ __attribute__((aligned(16))) double sGemm[];  // [2][2][KC][pitch]: buffer, operand
     // ---- tile of this workgroup (XCD-contiguous grouped order)
+    // (masked launches: round-robin instead -- a contiguous range per XCD would give the XCDs that hold the last tile rows, mostly below
+    // the block diagonal, almost nothing to do)
     const int T = tm * tn, per = (T + 7) / 8;
-    const int L = blockIdx.x, id = (L & 7) * per + (L >> 3);
+    const int L = blockIdx.x, id = mk.rb > 0 ? L : (L & 7) * per + (L >> 3);
     if ((L >> 3) >= per || id >= T) return;
     constexpr int G = 8;
     const int grp = id / (G * tn), first = grp * G, gsz = min(tm - first, G);
@@ -161,36 +163,41 @@ __global__ __launch_bounds__(256, 2) void k_tile_gemm_tn(double* C, int ldc, int
         for (int v = 0; v < 4; ++v)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[u][v][q] = 0.0;
-    // staging: thread -> row tid / 16 of the chunk, 8 consecutive columns
-    const int sr = tid >> 4, sc = (tid & 15) * 8;
+    // staging: wave wv takes rows wv, wv + 4, wv + 8, wv + 12 of the chunk, lane l the columns 2 l, 2 l + 1: one load instruction of a wave
+    // reads one whole 1 KB row of the operand slice (fully coalesced), and writes it to LDS as one conflict-free row
+    const int sc = 2 * lane;
     const bool fullA = I0 + kGemmTile <= m, fullB = J0 + kGemmTile <= n;
+    typedef double f64x2u __attribute__((ext_vector_type(2), aligned(8)));  // 8-byte aligned pair: views may start at odd columns
     double pa[8], pb[8];
     auto fetch = [&](int k0) {
-        const int row = k0 + sr;
-        const double* ar = A + (long long)row * lda + I0 + sc;
-        const double* br = B + (long long)row * ldb + J0 + sc;
-        if (row < k && fullA) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) pa[q] = ar[q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) pa[q] = (row < k && I0 + sc + q < m) ? ar[q] : 0.0;
-        }
-        if (row < k && fullB) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) pb[q] = br[q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) pb[q] = (row < k && J0 + sc + q < n) ? br[q] : 0.0;
+        for (int r = 0; r < 4; ++r) {
+            const int row = k0 + wv + 4 * r;
+            const double* ar = A + (long long)row * lda + I0 + sc;
+            const double* br = B + (long long)row * ldb + J0 + sc;
+            if (row < k && fullA) {
+                const f64x2u v = *reinterpret_cast<const f64x2u*>(ar);
+                pa[2 * r] = v.x; pa[2 * r + 1] = v.y;
+            } else {
+                pa[2 * r] = (row < k && I0 + sc < m) ? ar[0] : 0.0;
+                pa[2 * r + 1] = (row < k && I0 + sc + 1 < m) ? ar[1] : 0.0;
+            }
+            if (row < k && fullB) {
+                const f64x2u v = *reinterpret_cast<const f64x2u*>(br);
+                pb[2 * r] = v.x; pb[2 * r + 1] = v.y;
+            } else {
+                pb[2 * r] = (row < k && J0 + sc < n) ? br[0] : 0.0;
+                pb[2 * r + 1] = (row < k && J0 + sc + 1 < n) ? br[1] : 0.0;
+            }
         }
     };
     auto stage = [&](int buf) {
-        double* da = sGemm + ((buf * 2 + 0) * kGemmKC + sr) * kGemmPitch + sc;
-        double* db = sGemm + ((buf * 2 + 1) * kGemmKC + sr) * kGemmPitch + sc;
 #pragma unroll
-        for (int q = 0; q < 8; q += 2) {
-            *reinterpret_cast<f64x2*>(da + q) = f64x2{pa[q], pa[q + 1]};
-            *reinterpret_cast<f64x2*>(db + q) = f64x2{pb[q], pb[q + 1]};
+        for (int r = 0; r < 4; ++r) {
+            double* da = sGemm + ((buf * 2 + 0) * kGemmKC + wv + 4 * r) * kGemmPitch + sc;
+            double* db = sGemm + ((buf * 2 + 1) * kGemmKC + wv + 4 * r) * kGemmPitch + sc;
+            *reinterpret_cast<f64x2*>(da) = f64x2{pa[2 * r], pa[2 * r + 1]};
+            *reinterpret_cast<f64x2*>(db) = f64x2{pb[2 * r], pb[2 * r + 1]};
         }
     };
     fetch(0);
@@ -304,6 +311,48 @@ __global__ __launch_bounds__(256) void k_tile_potrf(double* A, int ld, int n, do
         __syncthreads();
     }
     if (bad && info && tid == 0) atomicOr(info, 1);
+}
+
+// ---- blocked potrf for larger diagonal blocks, one launch per phase of a 64-wide block column kb (eqf_tile_potrf drives them):
+//   k_tile_potrf on the 64 x 64 diagonal block (one workgroup)  ->  k_tile_trsm<right> on the panel below it (one workgroup per 64
+//   rows)  ->  k_tile_potrf_trail: the lower triangle of the trailing matrix, A_rb,cb -= L_rb,kb L_cb,kb^T, one workgroup per 64 x 64
+//   tile.  The single-workgroup kernel above spends its time in exactly this trailing update (n^3 / 3 flops on one CU: 2.2 ms at
+//   n = 750); spread over the chip a block column costs three short launches.  grid = t (t + 1) / 2 with t = nb - kb - 1.
+constexpr int kTrailLdsBytes = 2 * kSB * kSP * 8;
+__global__ __launch_bounds__(256) void k_tile_potrf_trail(double* A, int ld, int n, int kb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemTr[];  // two 64 x kSP blocks (66 KB: dynamic)
+    double (*sP)[kSP] = reinterpret_cast<double (*)[kSP]>(smemTr);
+    double (*sQ)[kSP] = sP + kSB;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // tile (r, c), r >= c, of the trailing lower triangle, row-major enumeration
+    int r = 0, idx = blockIdx.x;
+    while (idx >= r + 1) {
+        idx -= r + 1;
+        ++r;
+    }
+    const int rb = kb + 1 + r, cb = kb + 1 + idx;
+    for (int e = tid; e < kSB * kSB; e += 256) {
+        const int rr = e >> 6, cc = e & 63, gc = kSB * kb + cc;
+        const int gr = kSB * rb + rr, gq = kSB * cb + rr;
+        sP[rr][cc] = (gr < n && gc < n) ? A[(long long)gr * ld + gc] : 0.0;
+        sQ[rr][cc] = (gq < n && gc < n) ? A[(long long)gq * ld + gc] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f64x4 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int gr = kSB * rb + kQB * wv + (lane >> 4) + 4 * q, gc = kSB * cb + kQB * i + (lane & 15);
+            acc[q] = (gr < n && gc < n) ? A[(long long)gr * ld + gc] : 0.0;
+        }
+        acc = mmTile<true, kSB>(acc, &sP[0][0], kSP, kQB * wv, &sQ[0][0], kSP, kQB * i, lane, -1.0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int gr = kSB * rb + kQB * wv + (lane >> 4) + 4 * q, gc = kSB * cb + kQB * i + (lane & 15);
+            if (gr < n && gc < n && gc <= gr) A[(long long)gr * ld + gc] = acc[q];
+        }
+    }
 }
 
 // ---- B <- B L^-T (right = 1: B is m x n, a workgroup owns 64 rows) or B <- L^-1 B (right = 0: B is n x m, a workgroup owns 64

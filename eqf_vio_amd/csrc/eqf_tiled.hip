@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -51,6 +52,7 @@ int tileAttributes(int device) {
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_potrf), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_gemm_tn), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLdsBytes));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_potrf_trail), hipFuncAttributeMaxDynamicSharedMemorySize, kTrailLdsBytes));
     done[device] = 1;
     return EQF_OK;
 }
@@ -576,6 +578,35 @@ int eqf_tiled_set_state(eqf_tiled* t, int N, const double* pose_q, const double*
     return EQF_OK;
 }
 
+// ---- streams restricted to a set of CUs ---------------------------------------------------------------------------------
+int eqf_stream_create_masked(int device, int first_cu, int num_cus, int complement, void** out) {
+    if (!out || first_cu < 0 || num_cus < 1) return EQF_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return EQF_ERR_NO_DEVICE;
+    DeviceScope ds(device);
+    if (!ds.ok) return EQF_ERR_HIP;
+    hipDeviceProp_t prop;
+    HIPC(hipGetDeviceProperties(&prop, device));
+    const int cus = prop.multiProcessorCount;
+    if (first_cu + num_cus > cus || (complement && num_cus >= cus)) return EQF_ERR_INVALID;
+    std::vector<uint32_t> mask((cus + 31) / 32, 0u);
+    for (int c = 0; c < cus; ++c) {
+        const bool in = c >= first_cu && c < first_cu + num_cus;
+        if (in != (complement != 0)) mask[c / 32] |= 1u << (c % 32);
+    }
+    hipStream_t st = nullptr;
+    HIPC(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    *out = st;
+    return EQF_OK;
+}
+int eqf_stream_destroy(int device, void* stream) {
+    if (!stream) return EQF_OK;
+    DeviceScope ds(device);
+    HIPC(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    HIPC(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+    return EQF_OK;
+}
+
 // ---- dense tile kernels ------------------------------------------------------------------------------------------------------
 int eqf_tile_gemm_tn(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k,
     double alpha, int mask_rb, int mask_cb, int rblk0, int Pr, int pr, int cblk0, int Pc, int pc) {
@@ -625,7 +656,25 @@ int eqf_tile_potrf(int device, void* stream, double* A, int ld, int n, double* d
     if (!ds.ok) return EQF_ERR_HIP;
     int rc = tileAttributes(device);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tile_potrf, dim3(1), dim3(256), sizeof(Step64Lds), static_cast<hipStream_t>(stream), A, ld, n, drec, info);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nb = (n + kSB - 1) / kSB;
+    if (nb <= 2) {
+        hipLaunchKernelGGL(k_tile_potrf, dim3(1), dim3(256), sizeof(Step64Lds), st, A, ld, n, drec, info);
+    } else {
+        // blocked: per 64-wide block column the diagonal block (one workgroup), the panel below it (one workgroup per 64 rows), the
+        // trailing lower triangle (one workgroup per 64 x 64 tile) -- see k_tile_potrf_trail
+        for (int kb = 0; kb < nb; ++kb) {
+            double* Akk = A + (long long)kb * kSB * ld + kb * kSB;
+            const int nk = std::min(kSB, n - kb * kSB), below = n - (kb + 1) * kSB;
+            hipLaunchKernelGGL(k_tile_potrf, dim3(1), dim3(256), sizeof(Step64Lds), st, Akk, ld, nk, drec + (long long)kb * kDRec, info);
+            if (below > 0) {
+                hipLaunchKernelGGL(k_tile_trsm, dim3((below + kSB - 1) / kSB), dim3(256), sizeof(Step64Lds), st, Akk, ld, nk, drec + (long long)kb * kDRec,
+                    Akk + (long long)kSB * ld, ld, below, 1);
+                const int t = nb - kb - 1;
+                hipLaunchKernelGGL(k_tile_potrf_trail, dim3(t * (t + 1) / 2), dim3(256), kTrailLdsBytes, st, A, ld, n, kb);
+            }
+        }
+    }
     HIPC(hipGetLastError());
     return EQF_OK;
 }

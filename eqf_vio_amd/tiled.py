@@ -125,7 +125,7 @@ class HipBackend:
 
     DREC = 64 * 64 + 4 * 16 * 16  # doubles per 64-wide block column of a diagonal-factor record
 
-    def __init__(self, settings, capacity, device_index=0):
+    def __init__(self, settings, capacity, device_index=0, reserve_cus=None):
         from . import binding
 
         self.b = binding
@@ -140,12 +140,30 @@ class HipBackend:
         binding._check(self.lib.eqf_tiled_create(ctypes.byref(settings), self.cap, self.dev, ctypes.byref(self._h)), "eqf_tiled_create")
         self._stream = None
         self._info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # Two streams with disjoint CU sets: `reserve` CUs for the look-ahead factorisation of the next diagonal block (side()), all the
+        # others for everything else (main()).  EQF_TILED_RESERVE_CUS=0: no reservation -- main() is torch's current stream and the
+        # look-ahead only runs when the trailing update happens to leave room.
+        import os
+
+        self.reserve = int(os.environ.get("EQF_TILED_RESERVE_CUS", "8")) if reserve_cus is None else int(reserve_cus)
+        self._raw = []
+        self._main = self._side = None
+        if self.reserve > 0:
+            pm, ps = ctypes.c_void_p(), ctypes.c_void_p()
+            binding._check(self.lib.eqf_stream_create_masked(self.dev, 0, self.reserve, 1, ctypes.byref(pm)), "eqf_stream_create_masked")
+            binding._check(self.lib.eqf_stream_create_masked(self.dev, 0, self.reserve, 0, ctypes.byref(ps)), "eqf_stream_create_masked")
+            self._raw = [pm, ps]
+            self._main = torch.cuda.ExternalStream(pm.value, device=self.device)
+            self._side = torch.cuda.ExternalStream(ps.value, device=self.device)
         self._sync_stream()
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self.lib.eqf_tiled_destroy(self._h)
             self._h = ctypes.c_void_p()
+            for p in getattr(self, "_raw", []):
+                self.lib.eqf_stream_destroy(self.dev, p)
+            self._raw = []
 
     def __del__(self):
         try:
@@ -160,6 +178,32 @@ class HipBackend:
             self.b._check(self.lib.eqf_tiled_set_stream(self._h, ctypes.c_void_p(s)), "eqf_tiled_set_stream")
             self._stream = s
         return ctypes.c_void_p(s)
+
+    def _cur(self):
+        """torch's current stream, for the dense tile kernels (they take the stream as an argument; the handle's own stream -- the
+        state kernels -- only follows torch's stream outside side())"""
+        return ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    # ---- a second stream for the look-ahead factorisation of the next diagonal block (TiledFilter._chain)
+    def main(self):
+        """context: the stream every call of the filter runs on (all CUs but the reserved ones)"""
+        import contextlib
+
+        return torch.cuda.stream(self._main) if self._main is not None else contextlib.nullcontext()
+
+    def side(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return torch.cuda.stream(self._side)
+
+    def record(self):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        return ev
+
+    def wait(self, ev):
+        if ev is not None:
+            torch.cuda.current_stream(self.dev).wait_event(ev)
 
     @staticmethod
     def _p(t):
@@ -207,17 +251,18 @@ class HipBackend:
         self.b._check(self.lib.eqf_tiled_update_finish(self._h, self._p(acc), acc.stride(0), self._p(Gnn), self._p(G11)), "eqf_tiled_update_finish")
 
     # ---- dense tile kernels (csrc/eqf_tile.hpp)
-    def potrf(self, Akk):
-        """In place: lower triangle of the (n x n) view Akk <- L.  Returns the diagonal-factor records trsm() multiplies with."""
+    def potrf(self, Akk, drec=None):
+        """In place: lower triangle of the (n x n) view Akk <- L.  Returns (fills) the diagonal-factor records trsm() multiplies with."""
         n = Akk.shape[0]
-        drec = torch.empty(((n + 63) // 64) * self.DREC, dtype=torch.float64, device=self.device)
-        self.b._check(self.lib.eqf_tile_potrf(self.dev, self._sync_stream(), self._p(Akk), Akk.stride(0), n, self._p(drec), self._p(self._info)),
+        if drec is None:
+            drec = torch.empty(((n + 63) // 64) * self.DREC, dtype=torch.float64, device=self.device)
+        self.b._check(self.lib.eqf_tile_potrf(self.dev, self._cur(), self._p(Akk), Akk.stride(0), n, self._p(drec), self._p(self._info)),
                       "eqf_tile_potrf")
         return drec
 
     def trsm_left(self, L, drec, Bm):
         """In place: Bm (n x m view) <- L^-1 Bm."""
-        self.b._check(self.lib.eqf_tile_trsm(self.dev, self._sync_stream(), self._p(L), L.stride(0), L.shape[0], self._p(drec), self._p(Bm),
+        self.b._check(self.lib.eqf_tile_trsm(self.dev, self._cur(), self._p(L), L.stride(0), L.shape[0], self._p(drec), self._p(Bm),
                                              Bm.stride(0), Bm.shape[1], 0), "eqf_tile_trsm")
 
     def gemm_tn(self, Cm, A, B, alpha, mask=None):
@@ -229,7 +274,7 @@ class HipBackend:
             return
         assert A.shape[1] == m and B.shape == (k, n) and Cm.stride(1) == 1 and A.stride(1) == 1 and B.stride(1) == 1
         mk = mask if mask is not None else (0, 0, 0, 1, 0, 0, 1, 0)
-        self.b._check(self.lib.eqf_tile_gemm_tn(self.dev, self._sync_stream(), self._p(Cm), Cm.stride(0), m, n, self._p(A), A.stride(0), self._p(B),
+        self.b._check(self.lib.eqf_tile_gemm_tn(self.dev, self._cur(), self._p(Cm), Cm.stride(0), m, n, self._p(A), A.stride(0), self._p(B),
                                                 B.stride(0), k, float(alpha), *[int(x) for x in mk]), "eqf_tile_gemm_tn")
 
     def factor_info(self):
@@ -320,6 +365,34 @@ class TiledFilter:
         self.geo = None
         self.Sll = self.M = self.E = None
         self.ids = None
+        self.phase_ms = None  # set to a dict to collect GPU time per phase (bench.py): {"propagate": ms, "prep": ms, "chain_S": ...}
+        self._pending = []
+
+    class _Phase:
+        """torch.cuda event bracket around a phase of a call, summed into TiledFilter.phase_ms when the filter is asked for its timings
+        (no synchronisation inside the loop)."""
+
+        def __init__(self, tf, name):
+            self.tf, self.name = tf, name
+            self.on = tf.phase_ms is not None and getattr(tf.be, "device", None) is not None and tf.be.device.type == "cuda"
+
+        def __enter__(self):
+            if self.on:
+                self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self.a.record()
+
+        def __exit__(self, *exc):
+            if self.on:
+                self.b.record()
+                self.tf._pending.append((self.name, self.a, self.b))
+
+    def collect_phases(self):
+        if self._pending:
+            torch.cuda.synchronize()
+            for name, a, b in self._pending:
+                self.phase_ms[name] = self.phase_ms.get(name, 0.0) + a.elapsed_time(b)
+            self._pending = []
+        return self.phase_ms
 
     # ---- storage
     def _alloc(self, N):
@@ -336,7 +409,7 @@ class TiledFilter:
         self._wmax = {c: 5 * geo.ncols_of(c) + NARROW_S for c in range(g.Pc)}
         self._wmax_e = {c: 3 * geo.ncols_of(c) + NARROW_E for c in range(g.Pc)}
         self._buf = {c: be.empty(bsmax * max(self._wmax[c], self._wmax_e[c])) for c in range(g.Pc) if c == g.pc or c % g.Pr == g.pr}
-        self._pack = be.empty(bsmax * bsmax + ((bsmax + 63) // 64) * HipBackend.DREC)
+        self._pack = [be.empty(bsmax * bsmax + ((bsmax + 63) // 64) * HipBackend.DREC) for _ in range(2)]
         self._aopA = be.empty(bsmax, max(3 * geo.nlr, 1))
         self._aopW = be.empty(bsmax, max(3 * geo.nlr, 1))
         self._accS = be.zeros(NARROW_S, 3 * geo.nlc + NARROW_S)
@@ -344,10 +417,15 @@ class TiledFilter:
 
     # ---- VIOFilter::processIMUData (VIOFilter.cpp:120-131)
     def processIMUData(self, stamp, omega, accel):
-        return self.be.propagate(stamp, omega, accel, True, self.Sll)
+        with self.be.main(), self._Phase(self, "propagate"):
+            return self.be.propagate(stamp, omega, accel, True, self.Sll)
 
     # ---- VIOFilter::processVisionData (VIOFilter.cpp:232-302) for a FIXED landmark set: the first frame defines it
     def processVisionData(self, stamp, ids, bearings):
+        with self.be.main():
+            return self._process_vision(stamp, ids, bearings)
+
+    def _process_vision(self, stamp, ids, bearings):
         ids = np.asarray(ids, dtype=np.int64)
         y = np.asarray(bearings, dtype=np.float64).reshape(-1, 3)
         if len(ids) != len(y) or (len(ids) > 1 and not np.all(np.diff(ids) > 0)):
@@ -355,7 +433,8 @@ class TiledFilter:
         if self.ids is not None and not np.array_equal(ids, self.ids):
             raise NotImplementedError("the 2-D partitioned filter keeps the landmark set of its first frame (landmark churn lives in the "
                                       "single-GPU path)")
-        st = self.be.propagate(stamp, None, None, False, self.Sll)  # :233 integrateUpToTime
+        with self._Phase(self, "propagate"):
+            st = self.be.propagate(stamp, None, None, False, self.Sll)  # :233 integrateUpToTime
         if st != 0:
             return st  # :234-236
         if len(ids) == 0:
@@ -370,6 +449,10 @@ class TiledFilter:
     def initialise_from(self, st):
         """Restart from a single-GPU snapshot (FilterBatch.dump_state(); every rank holds the dense Sigma once, here)."""
         N = len(st["ids"])
+        with self.be.main():
+            self._initialise_from(st, N)
+
+    def _initialise_from(self, st, N):
         self._alloc(N)
         S = torch.as_tensor(np.asarray(st["sigma"]), dtype=torch.float64)
         rows = torch.as_tensor(np.repeat(3 * self.geo.rowMap.astype(np.int64), 3) + np.tile(np.arange(3), self.geo.nlr) + 11)
@@ -382,7 +465,8 @@ class TiledFilter:
     # ---- the update
     def _update(self, y):
         be, geo = self.be, self.geo
-        be.update_prep(y, self.Sll, self.M, self.E, self.G11)  # E and M are formed from the PRE-update Sigma (VIOFilter.cpp:285 before :297)
+        with self._Phase(self, "prep"):
+            be.update_prep(y, self.Sll, self.M, self.E, self.G11)  # E and M are formed from the PRE-update Sigma (VIOFilter.cpp:285 before :297)
         nA = 2 * geo.nlc
         self._accS.zero_()
         self._accE.zero_()
@@ -399,16 +483,27 @@ class TiledFilter:
             En = Bop[:, off: off + NARROW_E]
             be.gemm_tn(self._accE, En, En, 1.0)
 
-        self._chain(self.M, 2, nA, hook_s, self._wmax)
-        self._chain(self.E, 3, 3 * geo.nlc, hook_e, self._wmax_e)
-        info = be.factor_info()
-        if info:
+        with self._Phase(self, "chain_S"):
+            self._chain(self.M, 2, nA, hook_s, self._wmax)
+        with self._Phase(self, "chain_E"):
+            self._chain(self.E, 3, 3 * geo.nlc, hook_e, self._wmax_e)
+        with self._Phase(self, "finish"):
+            # gamma_L and the base panel's downdate live with the process COLUMNS: gather them along the process row, global landmark order
+            acc = self._gather_columns(self._accS[:, : 3 * geo.nlc])
+            Gnn = self._accS[:, 3 * geo.nlc:].contiguous()
+            G11 = (self.G11 + self._accE).contiguous()
+            be.update_finish(acc, Gnn, G11)
+        self._frames_since_check = getattr(self, "_frames_since_check", 0) + 1
+        if self.check_every and self._frames_since_check >= self.check_every:
+            self.check()
+
+    check_every = 1  # frames between two looks at the factorisations' pivot flag (a look synchronises the stream)
+
+    def check(self):
+        """Raises if a pivot of S or Sigma_e was not positive since the last look (synchronises)."""
+        self._frames_since_check = 0
+        if self.be.factor_info():
             raise ArithmeticError("a pivot of S or Sigma_e was not positive (distributed factorisation)")
-        # gamma_L and the base panel's downdate live with the process COLUMNS: gather them along the process row, global landmark order
-        acc = self._gather_columns(self._accS[:, : 3 * geo.nlc])
-        Gnn = self._accS[:, 3 * geo.nlc:].contiguous()
-        G11 = (self.G11 + self._accE).contiguous()
-        be.update_finish(acc, Gnn, G11)
 
     def _gather_columns(self, mine):
         g, geo = self.g, self.geo
@@ -462,10 +557,14 @@ class TiledFilter:
     def _chain(self, X, unit, nA, hook, wmax):
         """Blocked right-looking Cholesky by block ROWS of the SPD matrix in X[:, :nA] (upper blocks, block size unit * bl, block-cyclic
         over the grid) with the right-hand sides X[:, nA:]; X is consumed.  hook(k, bk, Bop, off, contributions) runs on every rank once
-        block row k is solved: Bop[:, off:] holds the right-hand-side part of my process column."""
+        block row k is solved: Bop[:, off:] holds the right-hand-side part of my process column.
+        Look-ahead: the diagonal block is the serial part (one workgroup, eqf_tile_potrf).  As soon as block row k is solved, the owner of
+        block (k+1, k+1) applies row k to a COPY of that block and factors the copy on a second stream, in the shadow of the trailing
+        update of step k; step k+1 then starts from the finished factor."""
         g, geo, be = self.g, self.geo, self.be
         bsF = unit * geo.bl
         W = X.shape[1]
+        ahead = None  # event: the look-ahead factor of the current block is in self._pack[k & 1]
         for k in range(geo.nb):
             prk, pck = k % g.Pr, k % g.Pc
             bk = unit * geo.block_size(k)
@@ -477,12 +576,15 @@ class TiledFilter:
             if g.pr == prk:
                 # 1. the diagonal block, L_kk and its records along the process row
                 nrec = ((bk + 63) // 64) * HipBackend.DREC
-                pack = self._pack[: bk * bk + nrec]
+                pack = self._pack[k & 1][: bk * bk + nrec]
                 Lkk, drec = pack[: bk * bk].view(bk, bk), pack[bk * bk:]
                 if g.pc == pck:
-                    Akk = X[klr * bsF: klr * bsF + bk, klc * bsF: klc * bsF + bk]
-                    drec.copy_(be.potrf(Akk))
-                    Lkk.copy_(Akk)
+                    if ahead is not None:
+                        be.wait(ahead)
+                        ahead = None
+                    else:
+                        Lkk.copy_(X[klr * bsF: klr * bsF + bk, klc * bsF: klc * bsF + bk])
+                        be.potrf(Lkk, drec)
                 g.bcast_row(pack, pck)
                 # 2. my piece of block row k
                 R = X[klr * bsF: klr * bsF + bk, c0:]
@@ -502,6 +604,19 @@ class TiledFilter:
             il0 = BlockCyclic.blocks_upto(k, g.pr, g.Pr)
             if il0 * bsF < X.shape[0]:
                 Ua = self._rows_operand(contributions, unit, lambda c, wc: (0, 1), bk, self._aopA, all_blocks=False, k=k)
+                if k + 1 < geo.nb and g.pr == (k + 1) % g.Pr and g.pc == (k + 1) % g.Pc:
+                    # look-ahead: block (k+1, k+1) is the first trailing block of my rows and of my columns
+                    b1 = unit * geo.block_size(k + 1)
+                    nrec1 = ((b1 + 63) // 64) * HipBackend.DREC
+                    pack1 = self._pack[(k + 1) & 1][: b1 * b1 + nrec1]
+                    L1, drec1 = pack1[: b1 * b1].view(b1, b1), pack1[b1 * b1:]
+                    L1.copy_(X[il0 * bsF: il0 * bsF + b1, c0: c0 + b1])
+                    ready = be.record()
+                    with be.side():
+                        be.wait(ready)
+                        be.gemm_tn(L1, Ua[:, :b1], Bop[:, :b1], -1.0)
+                        be.potrf(L1, drec1)
+                        ahead = be.record()
                 Ct = X[il0 * bsF:, c0:]
                 if nA - c0 > 0:
                     be.gemm_tn(Ct[:, : nA - c0], Ua, Bop[:, : nA - c0], -1.0, mask=(bsF, bsF, il0, g.Pr, g.pr, jl0, g.Pc, g.pc))
@@ -517,6 +632,10 @@ class TiledFilter:
 
     def stateCovariance(self):
         """Dense Sigma (reference index map) gathered to every rank -- tests and snapshots (VIOFilter::stateCovariance, :306-309)."""
+        with self.be.main():
+            return self._state_covariance()
+
+    def _state_covariance(self):
         g, geo = self.g, self.geo
         N = geo.N
         n = 11 + 3 * N

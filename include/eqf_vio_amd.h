@@ -266,6 +266,12 @@ int eqf_tiled_set_state(eqf_tiled* t, int N, const double* pose_q, const double*
  * eqf_tile_propagate: one structured Riccati step of a (3 nI x 3 nJ) tile from explicit block arrays (kept for the block-level tests;
  *   the closed loop uses eqf_tiled_propagate):
  *     out = (D_I in + L_I Sigma_bJ) D_J^T + (L_I Sigma_bb + D_I Sigma_Ib) L_J^T + T (B_I R B_J^T) [+ diag_noise I on a diagonal tile] */
+/* A HIP stream whose kernels only run on the CUs [first_cu, first_cu + num_cus) (complement = 0) or on all the others (complement = 1)
+ * (hipExtStreamCreateWithCUMask).  The look-ahead of the distributed factorisations factors the next diagonal block -- one workgroup
+ * with 119 KB of LDS -- on a few reserved CUs while the trailing update fills the rest of the chip; without the reservation the
+ * update's workgroups (two per CU, 147 KB of LDS) never leave room for it. */
+int eqf_stream_create_masked(int device, int first_cu, int num_cus, int complement, void** out);
+int eqf_stream_destroy(int device, void* stream);
 int eqf_tile_gemm_tn(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k,
     double alpha, int mask_rb, int mask_cb, int rblk0, int Pr, int pr, int cblk0, int Pc, int pc);
 int eqf_tile_propagate(int device, void* stream, double* out, const double* in, int ld, int nI, int nJ, const double* D_I,

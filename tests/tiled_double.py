@@ -221,7 +221,21 @@ class NumpyBackend:
         self.Sbb = self.Sbb - Gnn[:11, :11]
 
     # ---- dense tile operations
-    def potrf(self, Akk):
+    # (no second stream on the CPU: the look-ahead of TiledFilter._chain runs in program order)
+    def side(self):
+        import contextlib
+
+        return contextlib.nullcontext()
+
+    main = side
+
+    def record(self):
+        return True
+
+    def wait(self, ev):
+        pass
+
+    def potrf(self, Akk, drec=None):
         A = Akk.numpy()
         try:
             L = np.linalg.cholesky(np.tril(A) + np.tril(A, -1).T)
