@@ -145,6 +145,7 @@ struct eqf_filter {
     int updateEpoch = 0;           // one per launchUpdate
     // k_chol_resident (one launch per update while the grid fits the chip): EQF_CHOL_RESIDENT = 0 switches it off
     int cholResident = 1;
+    int resStaged = 1;             // row heads consume D[R-1] stage by stage (EQF_RES_STAGED = 0: whole record after its last pivot)
     int residentPerCU = -1;        // hipOccupancyMaxActiveBlocksPerMultiprocessor of k_chol_resident on this device (lazily queried)
     int prepFuseMax = 1 << 30;     // prep + first diagonal factors as one launch up to this many workgroups (EQF_PREP_FUSE_MAX; measured: one launch is never slower, 4..64 filters)
     int eFromSigma = 1;            // split chain: block column 0 of the E-chain read straight from Sigma (EQF_E_FROM_SIGMA=0: copied by prep)
@@ -152,7 +153,7 @@ struct eqf_filter {
     int cholStreams = 0;           // stream workgroups per filter of an update launch, 0 = by launch size (EQF_CHOL_STREAMS)
     int numCUs = 0;
     int nbCap = 0, wtCap = 0;
-    int *dReadyA = nullptr, *dReadyY = nullptr, *dResCounters = nullptr;
+    int *dReadyA = nullptr, *dReadyY = nullptr, *dResCounters = nullptr, *dStageFlags = nullptr;
     double *dGammaPart = nullptr, *dG11Part = nullptr;
     ResRole* dRoles = nullptr;
     int rolesN = -1, rolesCount = 0;  // chain shape (nbS, nbE, wtS) the role table was built for
@@ -705,6 +706,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             ra.readyA = f->dReadyA; ra.readyY = f->dReadyY; ra.counters = f->dResCounters;
             ra.gammaPart = f->dGammaPart; ra.g11Part = f->dG11Part;
             ra.nbCap = f->nbCap; ra.wtCap = f->wtCap;
+            ra.stageFlags = f->resStaged ? f->dStageFlags : nullptr;
             // 64 x 64 downdate tiles: a tile costs the same 14 dependent chunk fetches whatever its size, and there are enough
             // finished workgroups to take one each
             // (a grid forced beyond what is co-resident -- EQF_CHOL_RESIDENT=2 -- must not wait for later workgroups while holding
@@ -1105,7 +1107,7 @@ void freeAll(eqf_filter* f) {
     for (void* p : {(void*)f->p0, (void*)f->lmc, (void*)f->SA, (void*)f->SL, (void*)f->YW, (void*)f->YO, (void*)f->EA, (void*)f->EL, (void*)f->ZW,
              (void*)f->ZO, (void*)f->dbgDelta, (void*)f->dbgGamma, (void*)f->dbgGammaTot, (void*)f->red, (void*)f->errflag, (void*)f->dMap,
              (void*)f->dNewN, (void*)f->dPerm, (void*)f->dSrc, (void*)f->dChord, (void*)f->dDepth2, (void*)f->dDepthSel, (void*)f->dScratch, (void*)f->dMeas,
-             (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn, f->dBlk, (void*)f->dBlkCommon, f->dColRec, f->dRowRec, (void*)f->dSteps, (void*)f->dFlags, (void*)f->dReadyA, (void*)f->dReadyY, (void*)f->dResCounters, (void*)f->dGammaPart,
+             (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn, f->dBlk, (void*)f->dBlkCommon, f->dColRec, f->dRowRec, (void*)f->dSteps, (void*)f->dFlags, (void*)f->dReadyA, (void*)f->dReadyY, (void*)f->dResCounters, (void*)f->dStageFlags, (void*)f->dGammaPart,
              (void*)f->dG11Part, (void*)f->dRoles})
         hipFree(p);
     if (f->hGate) hipHostFree(f->hGate);
@@ -1287,6 +1289,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (const char* e = std::getenv("EQF_CHOL_SPLIT")) f->cholSplit = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_TAIL")) f->cholTail = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_RESIDENT")) f->cholResident = std::atoi(e);
+    if (const char* e = std::getenv("EQF_RES_STAGED")) f->resStaged = std::atoi(e);
     if (const char* e = std::getenv("EQF_PREP_FUSE_MAX")) f->prepFuseMax = std::atoi(e);
     if (const char* e = std::getenv("EQF_E_FROM_SIGMA")) f->eFromSigma = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_ORDER")) f->cholOrder = std::atoi(e);
@@ -1303,6 +1306,8 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
             chk(dmalloc(&f->dReadyA, (size_t)2 * f->nbCap * f->nbCap * B));
             chk(dmalloc(&f->dReadyY, (size_t)2 * f->nbCap * f->wtCap * B));
             chk(dmalloc(&f->dResCounters, (size_t)4 * B));
+            chk(dmalloc(&f->dStageFlags, (size_t)2 * f->nbCap * 4 * B));
+            if (!rc && hipMemset(f->dStageFlags, 0, sizeof(int) * 2 * f->nbCap * 4 * B) != hipSuccess) rc = EQF_ERR_HIP;
             chk(dmalloc(&f->dGammaPart, (size_t)f->nbCap * ycC * B));
             chk(dmalloc(&f->dG11Part, (size_t)f->nbCap * 128 * B));
             if (!rc && (hipMemset(f->dReadyA, 0, sizeof(int) * 2 * f->nbCap * f->nbCap * B) != hipSuccess ||

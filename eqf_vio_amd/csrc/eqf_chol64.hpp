@@ -234,9 +234,15 @@ EQF_DI void storeDiagColumns(const Lds64& s, double* Dn, int j, int t, int nthr)
 // workgroup's remaining trailing-update tiles): pre(wave).
 // `mid` (all threads) runs once, right after the first stage's two barriers: a place to finish something asynchronous that
 // was started before the call (k_chol_resident drains and publishes the write-through stores of the solved block there).
+// `stageFlag` (WT only; nullptr = none): stageFlag[j] <- epoch as soon as columns [16 j, 16 j + 16) of L and W_jj are in the record Dn,
+// j = 0..nStages-2 -- one stage behind the pivot chain, stored and drained by waves 2, 3 in its shadow.  A consumer that only needs the
+// record stage by stage (the row head of k_chol_resident's next block column) overlaps its own work with the rest of this factorisation.
 template <bool WT = false, typename Pre, typename Mid>
-EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn, long long* st, int nStages, Mid mid) {
+EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn, long long* st, int nStages, Mid mid, int* stageFlag = nullptr,
+    int epoch = 0) {
     const int lane = tid & 63, wv = tid >> 6;
+    int* const stageCnt = reinterpret_cast<int*>(&s.D0[kQB - 1][kQB]);  // (pad column of D0: nobody reads it)
+    if (WT && stageFlag && tid == 0) *stageCnt = 0;
     // nStages: 16-column stages that hold a real column.  The rest of the block is the identity padding of the chain's
     // last block (off-diagonal zero): its L_jj = I stands as it is, W_jj = I is set here, and the pivot chain stops early.
     for (int j = nStages; j < 4; ++j)
@@ -264,6 +270,15 @@ EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn, lon
                         acc = mmTile<true, kQB>(acc, &s.L[0][base - kQB], kSP, kQB * r, &s.L[0][base - kQB], kSP, kQB * c, lane, -1.0);
                         stTile(acc, &s.L[0][0], kSP, kQB * r, kQB * c, lane);
                     }
+                if (WT && stageFlag) {
+                    // stage j-1 of the record is out as soon as BOTH storing waves have drained: the second one to arrive publishes it
+                    // (an LDS counter in the pad column of D0) -- half a stage earlier than the barrier below would allow
+                    hoDrain();
+                    if (lane == 0) {
+                        const int old = __hip_atomic_fetch_add(stageCnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (old & 1) hoPublish(stageFlag + (j - 1), epoch);
+                    }
+                }
             }
         }
 #ifdef EQF_STEP64_STAMPS

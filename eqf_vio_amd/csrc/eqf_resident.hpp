@@ -52,6 +52,7 @@ struct ResArgs {
     int nbCap, wtCap;
     int ddNt, ddSmall;
     int* errflag;
+    int* stageFlags;       // [B][2][nbCap][4]  stage j of D[K] of chain c is in the record (epoch valued; factor64's stageFlag)
 };
 
 // ---- 64x64 block <-> LDS through write-through / L1-bypassing 16-byte accesses.  Thread t handles row t / 4, 16 doubles
@@ -126,6 +127,68 @@ EQF_DEV void hoLoadRecord(const double* Dk, const Lds64& s, int tid) {
             s.Wd[q >> 8][(q >> 4) & 15][q & 15] = hoLo(v[u]);
             s.Wd[q >> 8][(q >> 4) & 15][(q & 15) + 1] = hoHi(v[u]);
         }
+    }
+}
+// ONE 16-column stage of a diagonal-factor record: columns [16 j, 16 j + 16) of L_KK (64 rows, 8 KB) -> s.L, W_jj (2 KB) -> s.Wd[j].
+// Three 16-byte loads per thread, in flight together.
+EQF_DEV void hoLoadStage(const double* Dk, int j, const Lds64& s, int tid) {
+    const int w0 = tid, w1 = tid + 256;  // word (16 bytes) w: row w / 8, doubles 2 (w % 8) .. +1 of the column block
+    const char* p0 = reinterpret_cast<const char*>(Dk + (w0 >> 3) * kSB + kQB * j + 2 * (w0 & 7));
+    const char* p1 = reinterpret_cast<const char*>(Dk + (w1 >> 3) * kSB + kQB * j + 2 * (w1 & 7));
+    const char* p2 = reinterpret_cast<const char*>(Dk + kSB * kSB + kQB * kQB * j + 2 * (tid & 127));
+    v4i32 a, b, c;
+    asm volatile(
+        "global_load_dwordx4 %0, %3, off sc0 sc1\n\tglobal_load_dwordx4 %1, %4, off sc0 sc1\n\tglobal_load_dwordx4 %2, %5, off sc0 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(a), "=&v"(b), "=&v"(c)
+        : "v"(p0), "v"(p1), "v"(p2)
+        : "memory");
+    s.L[w0 >> 3][kQB * j + 2 * (w0 & 7)] = hoLo(a);
+    s.L[w0 >> 3][kQB * j + 2 * (w0 & 7) + 1] = hoHi(a);
+    s.L[w1 >> 3][kQB * j + 2 * (w1 & 7)] = hoLo(b);
+    s.L[w1 >> 3][kQB * j + 2 * (w1 & 7) + 1] = hoHi(b);
+    if (tid < 128) {
+        s.Wd[j][tid >> 3][2 * (tid & 7)] = hoLo(c);
+        s.Wd[j][tid >> 3][2 * (tid & 7) + 1] = hoHi(c);
+    }
+}
+// Stages 0, 1, 2 together (nine loads in flight: one round trip) and the inverse block of stage 3 on its own -- what the row head of the
+// next block column needs of D[K]: L_ji for i < j and the four W_jj.
+EQF_DEV void hoLoadStages012(const double* Dk, const Lds64& s, int tid) {
+    const int w0 = tid, w1 = tid + 256;
+    const char* pl0 = reinterpret_cast<const char*>(Dk + (w0 >> 3) * kSB + 2 * (w0 & 7));
+    const char* pl1 = reinterpret_cast<const char*>(Dk + (w1 >> 3) * kSB + 2 * (w1 & 7));
+    const char* pw = reinterpret_cast<const char*>(Dk + kSB * kSB + 2 * (tid & 127));
+    const char* pw2 = pw + 2 * kQB * kQB * 8;  // (W_22: beyond the 13-bit immediate offset)
+    v4i32 a[3], b[3], c[3];
+    asm volatile(
+        "global_load_dwordx4 %0, %9, off sc0 sc1\n\tglobal_load_dwordx4 %1, %9, off offset:128 sc0 sc1\n\t"
+        "global_load_dwordx4 %2, %9, off offset:256 sc0 sc1\n\tglobal_load_dwordx4 %3, %10, off sc0 sc1\n\t"
+        "global_load_dwordx4 %4, %10, off offset:128 sc0 sc1\n\tglobal_load_dwordx4 %5, %10, off offset:256 sc0 sc1\n\t"
+        "global_load_dwordx4 %6, %11, off sc0 sc1\n\tglobal_load_dwordx4 %7, %11, off offset:2048 sc0 sc1\n\t"
+        "global_load_dwordx4 %8, %12, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2])
+        : "v"(pl0), "v"(pl1), "v"(pw), "v"(pw2)
+        : "memory");
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        s.L[w0 >> 3][kQB * j + 2 * (w0 & 7)] = hoLo(a[j]);
+        s.L[w0 >> 3][kQB * j + 2 * (w0 & 7) + 1] = hoHi(a[j]);
+        s.L[w1 >> 3][kQB * j + 2 * (w1 & 7)] = hoLo(b[j]);
+        s.L[w1 >> 3][kQB * j + 2 * (w1 & 7) + 1] = hoHi(b[j]);
+        if (tid < 128) {
+            s.Wd[j][tid >> 3][2 * (tid & 7)] = hoLo(c[j]);
+            s.Wd[j][tid >> 3][2 * (tid & 7) + 1] = hoHi(c[j]);
+        }
+    }
+}
+EQF_DEV void hoLoadW3(const double* Dk, const Lds64& s, int tid) {
+    const char* pw = reinterpret_cast<const char*>(Dk + kSB * kSB + 3 * kQB * kQB + 2 * (tid & 127));
+    v4i32 c;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(c) : "v"(pw) : "memory");
+    if (tid < 128) {
+        s.Wd[3][tid >> 3][2 * (tid & 7)] = hoLo(c);
+        s.Wd[3][tid >> 3][2 * (tid & 7) + 1] = hoHi(c);
     }
 }
 EQF_DEV void hoStoreRecord(double* Dk, const Lds64& s, int tid) {
@@ -225,27 +288,92 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
         // (A dry run of the serial part during the idle time before the panels arrive -- to take the instruction-cache misses of
         // code a workgroup executes exactly once off the critical path -- was tried and measured: no gain.)
         for (int K = 0; K + 1 < R; ++K) {
-            hoWait3(readyA + R * nbCap + K, readyA + (R - 1) * nbCap + K, nullptr, epoch, tid, &bad);
-            hoLoadBlocks2(A + (long long)(R * kSB) * ldA + K * kSB, ldA, s.P, A + (long long)((R - 1) * kSB) * ldA + K * kSB, ldA, s.Q, tid);
-            __syncthreads();
+            if (K + 2 < R) {
+                hoWait3(readyA + R * nbCap + K, readyA + (R - 1) * nbCap + K, nullptr, epoch, tid, &bad);
+                hoLoadBlocks2(A + (long long)(R * kSB) * ldA + K * kSB, ldA, s.P, A + (long long)((R - 1) * kSB) * ldA + K * kSB, ldA, s.Q, tid);
+                __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a1[i] = mmTile<true, kSB>(a1[i], &s.P[0][0], kSP, kQB * wv, &s.Q[0][0], kSP, kQB * i, lane, -1.0);
+                for (int i = 0; i < 4; ++i) a1[i] = mmTile<true, kSB>(a1[i], &s.P[0][0], kSP, kQB * wv, &s.Q[0][0], kSP, kQB * i, lane, -1.0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < nt) a2[i] = mmTile<true, kSB>(a2[i], &s.P[0][0], kSP, kQB * tr[i], &s.P[0][0], kSP, kQB * tc[i], lane, -1.0);
-            __syncthreads();
+                for (int i = 0; i < 4; ++i)
+                    if (i < nt) a2[i] = mmTile<true, kSB>(a2[i], &s.P[0][0], kSP, kQB * tr[i], &s.P[0][0], kSP, kQB * tc[i], lane, -1.0);
+                __syncthreads();
+            } else {
+                // The last panel, K = R-2.  L_{R-1,R-2} is the block the PREVIOUS row head solved a moment ago: it is the last thing to
+                // arrive, and only the tile (R, R-1) needs it.  So this row's own block L_{R,R-2} (an interior tile, out long before) is
+                // applied to the diagonal tile first, and what is left behind the late block is one 64 x 64 x 64 product instead of two
+                // (measured: 7 us from that flag to "panels applied" before -- a second critical path as long as the pivot chain's).
+                EQF_HSTAMP(9);
+                hoWait3(readyA + R * nbCap + K, nullptr, nullptr, epoch, tid, &bad);
+                hoLoadBlock(A + (long long)(R * kSB) * ldA + K * kSB, ldA, s.P, tid);
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < nt) a2[i] = mmTile<true, kSB>(a2[i], &s.P[0][0], kSP, kQB * tr[i], &s.P[0][0], kSP, kQB * tc[i], lane, -1.0);
+                hoWait3(readyA + (R - 1) * nbCap + K, nullptr, nullptr, epoch, tid, &bad);
+                EQF_HSTAMP(10);
+                hoLoadBlock(A + (long long)((R - 1) * kSB) * ldA + K * kSB, ldA, s.Q, tid);
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a1[i] = mmTile<true, kSB>(a1[i], &s.P[0][0], kSP, kQB * wv, &s.Q[0][0], kSP, kQB * i, lane, -1.0);
+                __syncthreads();
+            }
         }
         // ---- the serial part: D[R-1] -> L_{R,R-1} -> diagonal tile -> D[R]
         EQF_HSTAMP(1);
-        hoWait3(R - 1 > 0 ? flagD + (R - 1) : nullptr, nullptr, nullptr, epoch, tid, &bad);
-        EQF_HSTAMP(2);
-        hoLoadRecord(D + (long long)(R - 1) * kDRec, s, tid);
+        int* const stageOut = ra.stageFlags ? ra.stageFlags + (((long long)b * 2 + role.kind) * nbCap + R) * 4 : nullptr;
+        if (R - 1 == 0 || !ra.stageFlags) {
+            // D[0] comes complete from the prep launch
+            hoWait3(R - 1 > 0 ? flagD + (R - 1) : nullptr, nullptr, nullptr, epoch, tid, &bad);
+            EQF_HSTAMP(2);
+            hoLoadRecord(D + (long long)(R - 1) * kDRec, s, tid);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) stTile(a1[i], &s.P[0][0], kSP, kQB * wv, kQB * i, lane);
-        __syncthreads();
-        EQF_HSTAMP(3);
-        solveStrip<true>(&s.P[0][0], kSP, s, kQB * wv, lane);
-        __syncthreads();
+            for (int i = 0; i < 4; ++i) stTile(a1[i], &s.P[0][0], kSP, kQB * wv, kQB * i, lane);
+            __syncthreads();
+            EQF_HSTAMP(3);
+            solveStrip<true>(&s.P[0][0], kSP, s, kQB * wv, lane);
+            __syncthreads();
+        } else {
+            // D[R-1] is being factored by the previous row head RIGHT NOW: its record arrives in four 16-column stages (factor64's
+            // stageFlag), and the panel solve X_j^T = W_jj (A_j^T - sum_{i<j} L_ji X_i^T) only needs stage j for its step j.  So the
+            // first three steps run in the shadow of the previous head's pivot chain; what is left on the critical path after its
+            // last pivot is one flag, 2 KB (W_33) and one 16 x 16 x 16 product -- not the whole 40 KB record and the whole solve.
+            // (Same operations in the same order as solveStrip<true>: bitwise the same L_{R,R-1}.)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stTile(a1[i], &s.P[0][0], kSP, kQB * wv, kQB * i, lane);
+            __syncthreads();
+            f64x4 Z[4], X[4];
+            const int lc = lane & 15, lg = lane >> 4, x0 = kQB * wv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Z[j][q] = s.P[x0 + lc][kQB * j + lg + 4 * q];
+            const int* stageIn = ra.stageFlags + (((long long)b * 2 + role.kind) * nbCap + (R - 1)) * 4;
+            // (A row head reaches this point about a microsecond before the previous one publishes D[R-1] -- its own last panel is the
+            // other critical path, see above -- so the first three stages are usually all out: one wait, one round trip for the three
+            // of them, then the last stage on its own.)
+            const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+            hoWait3(stageIn + 2, nullptr, nullptr, epoch, tid, &bad);
+            hoLoadStages012(D + (long long)(R - 1) * kDRec, s, tid);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                X[j] = mmRegB(zero, &s.Wd[j][0][0], kWP, 0, 0, Z[j], lane, 1.0);
+#pragma unroll
+                for (int j2 = j + 1; j2 < 4; ++j2) Z[j2] = mmRegB(Z[j2], &s.L[0][0], kSP, kQB * j2, kQB * j, X[j], lane, -1.0);
+            }
+            hoWait3(flagD + (R - 1), nullptr, nullptr, epoch, tid, &bad);
+            EQF_HSTAMP(2);
+            hoLoadW3(D + (long long)(R - 1) * kDRec, s, tid);
+            __syncthreads();
+            EQF_HSTAMP(3);
+            X[3] = mmRegB(zero, &s.Wd[3][0][0], kWP, 0, 0, Z[3], lane, 1.0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s.P[x0 + lc][kQB * j + lg + 4 * q] = X[j][q];
+            __syncthreads();
+        }
         EQF_HSTAMP(4);
         // first column of the diagonal tile, then the factorisation with the other tiles deferred to waves 2, 3; the solved
         // block leaves for the other workgroups meanwhile (stores are asynchronous)
@@ -264,13 +392,17 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
             }
         };
         EQF_HSTAMP(6);
-        // the solved block's stores drain in the shadow of the first 16 pivots; it is published right after them
+        // the solved block's stores drain in the shadow of the first 16 pivots; it is published right after them.  (Tried in round 3:
+        // waves 2, 3 alone store the block and the second of them to have drained publishes it right after its deferred tiles, 1.5 us
+        // earlier for the next row head -- 138 -> 142 us per update: sixteen write-through stores per thread and a drain in front of the
+        // first stage's barrier cost the pivot chain more than the next head gains.)
         auto mid = [&] {
             hoDrain();
             __syncthreads();
             if (tid == 0) hoPublish(readyA + R * nbCap + (R - 1), epoch);
         };
-        factor64<true>(s, tid, &bad, pre, D + (long long)R * kDRec, nullptr, realStages(ch.kind == 0 ? sDim(g.N) : eDim(g.N), kSB * R), mid);
+        factor64<true>(s, tid, &bad, pre, D + (long long)R * kDRec, nullptr, realStages(ch.kind == 0 ? sDim(g.N) : eDim(g.N), kSB * R), mid,
+            stageOut, epoch);
         EQF_HSTAMP(7);
         hoDrain();
         __syncthreads();
@@ -306,6 +438,7 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
         hoDrain();
         __syncthreads();
         if (tid == 0) hoPublish(readyA + R * nbCap + C, epoch);
+        if (C + 2 == R) EQF_HSTAMP(11);
     } else {
         // =========================================================================================== W(t, C)
         const int t = role.R, C = role.C;

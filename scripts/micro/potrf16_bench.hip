@@ -334,12 +334,71 @@ __global__ __launch_bounds__(256) void k_bench2(double* out, int reps) {
     }
 }
 
+
+// MODE 10..13: COMBINATION -- the dependent chain of the LDL^T form (reciprocal of the pivot, NEWTON Newton steps; the scaling of the
+// column and its square root are off the chain), the two columns next to the pivot updated through v_readlane, everything further away
+// through uniform-address LDS reads of the column published one iteration earlier (half the instructions of a readlane pair), and the
+// normalisation u_c / sqrt(d_c) either inline (NORM = 0: eight more instructions per column) or deferred to the end with the sixteen
+// reciprocal square roots computed side by side on lanes 0..15 (NORM = 1).
+template <int NEWTON, int NORM>
+__device__ __forceinline__ void variantCombo(double (*T)[kSP], double (*colS)[kQB + 2], int base, int lane, int* bad) {
+    double u[kQB], out[kQB];
+#pragma unroll
+    for (int c = 0; c < kQB; ++c) u[c] = T[lane][base + c];
+    const bool inDiag = lane >= base && lane < base + kQB;
+    double tPrev = 0.0, dmine = 1.0;
+#pragma unroll
+    for (int c = 0; c < kQB; ++c) {
+        double bc[kQB];
+        if (c >= 1) {
+#pragma unroll
+            for (int c2 = c + 2; c2 < kQB; ++c2) bc[c2] = colS[c - 1][c2];  // (uniform address: LDS broadcast; issued first, used last)
+        }
+        const double d = readlane64(u[c], base + c);
+        if (!(d > 0.0)) *bad = 1;
+        double r = __builtin_amdgcn_rcp(d);
+        r = fma(r, fma(-d, r, 1.0), r);
+        if (NEWTON == 2) r = fma(r, fma(-d, r, 1.0), r);
+        const double uc = u[c];
+        const double b1 = (c + 1 < kQB) ? readlane64(uc, base + c + 1) : 0.0;
+        const double b2 = (c + 2 < kQB) ? readlane64(uc, base + c + 2) : 0.0;
+        const double t = uc * r;
+        if (c + 1 < kQB) u[c + 1] = fma(-t, b1, u[c + 1]);
+        if (c + 2 < kQB) u[c + 2] = fma(-t, b2, u[c + 2]);
+        if (inDiag) colS[c][lane - base] = uc;
+        if (c >= 1) {
+#pragma unroll
+            for (int c2 = c + 2; c2 < kQB; ++c2) u[c2] = fma(-tPrev, bc[c2], u[c2]);
+        }
+        if (NORM == 0) out[c] = uc * rsqrtPivot(d);
+        else {
+            out[c] = uc;
+            if (lane == base + c) dmine = uc;
+        }
+        tPrev = t;
+#pragma unroll
+        for (int c2 = c + 1; c2 < kQB; ++c2) __asm__ volatile("" : "+v"(u[c2]));
+    }
+    if (NORM == 1) {
+        const double rs = rsqrtPivot(dmine);  // lane base + c: 1 / sqrt(d_c)
+#pragma unroll
+        for (int c = 0; c < kQB; ++c) out[c] *= readlane64(rs, base + c);
+    }
+    if (lane >= base) {
+#pragma unroll
+        for (int c = 0; c < kQB; ++c) T[lane][base + c] = (lane - base >= c) ? out[c] : 0.0;
+    }
+}
 template <int MODE>
 __device__ __forceinline__ void dispatch(double (*T)[kSP], double (*colS)[kQB + 2], int base, int lane, int* bad) {
     if (MODE == 4) variantLdl(T, base, lane, bad);
     else if (MODE == 5) variantIl(T, base, lane, bad);
     else if (MODE == 6) variantGrp(T, base, lane, bad);
     else if (MODE == 9) variantBlk2(T, base, lane, bad);
+    else if (MODE == 10) variantCombo<2, 0>(T, colS, base, lane, bad);
+    else if (MODE == 11) variantCombo<1, 0>(T, colS, base, lane, bad);
+    else if (MODE == 12) variantCombo<2, 1>(T, colS, base, lane, bad);
+    else if (MODE == 13) variantCombo<1, 1>(T, colS, base, lane, bad);
     else variant<MODE>(T, colS, base, lane, bad);
 }
 
@@ -368,7 +427,7 @@ __global__ __launch_bounds__(256) void k_bench(double* out, int reps) {
         if (lane == 0) {
             out[0] = double(t1 - t0);
             out[1] = double(t2 - t1) / reps;
-            out[2] = T[40][20] + bad;
+            out[2] = T[40][20] + bad + 1e3 * T[63][31] + 1e6 * T[20][18];
         }
     }
 }
@@ -429,6 +488,10 @@ int main() {
     run<5>("hand-interleaved + sched_barrier", o);
     run<6>("grouped broadcasts", o);
     run<9>("2x2 block pivots", o);
+    run<10>("combo: 2 Newton, inline norm", o);
+    run<11>("combo: 1 Newton, inline norm", o);
+    run<12>("combo: 2 Newton, deferred norm", o);
+    run<13>("combo: 1 Newton, deferred norm", o);
     run<0>("readlane bulk again", o);
     runLim<64>(o);
     runLim<48>(o);

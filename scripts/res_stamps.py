@@ -27,7 +27,9 @@ for ch, nm in ((1, "E-chain"), (0, "S-chain")):
     t0 = t[ch, rows[0], 0]
     print(nm, "(us since the first row head started; phases:", ", ".join(names), ")")
     for R in rows:
-        print(f"  H({R:2d})", " ".join(f"{(t[ch, R, i] - t0) / 100.0:7.2f}" for i in range(9)))
+        print(f"  H({R:2d})", " ".join(f"{(t[ch, R, i] - t0) / 100.0:7.2f}" for i in range(9)), "  | last panel wait: from",
+              " ".join(f"{(t[ch, R, i] - t0) / 100.0:7.2f}" if t[ch, R, i] > 0 else "      -" for i in (9, 10)), " T(R,R-2) published",
+              f"{(t[ch, R, 11] - t0) / 100.0:7.2f}" if t[ch, R, 11] > 0 else "-")
 
 w = t[1, 15]
 if w[5] > 0:
