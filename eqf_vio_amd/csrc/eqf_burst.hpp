@@ -989,141 +989,4 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_burst_riccati: the landmark x landmark blocks, all K steps in registers.
-//   Sigma'_IJ = (D_I Sigma_IJ + Lw_I Sw_J + Lv_I Sv_J) D_J^T + Gn_I Lw_J^T + Gv_I Lv_J^T  (+ T p I on the diagonal)
-// grid = (ceil(N / 64), ceil(N / (4 R)), B), block = 256: lane = column landmark J, each wavefront owns R row landmarks.
-// Per step a lane fetches its 45 column constants (coalesced; the fetch for step s+1 is issued before the arithmetic of
-// step s) and the wave its R x 45 row constants (staged in wave-private LDS, read back as broadcasts): no workgroup
-// barrier anywhere.  Per block and step 162 FMAs.
-// ------------------------------------------------------------------------------------------------
-template <typename T, int R>
-__global__ __launch_bounds__(256) void k_burst_riccati(BurstArgs a) {
-    const int b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int N = a.gin[b].N, K = a.K, cap = a.cap, ld = a.ld;
-    const int J = blockIdx.x * 64 + lane;
-    const int I0 = (blockIdx.y * 4 + wv) * R;
-    if (I0 >= N) return;  // wave-uniform; the kernel has no workgroup barrier
-    const int nI = min(R, N - I0);
-    const bool validJ = J < N;
-    const int Jc = validJ ? J : 0;
-    const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
-    T* Sout = static_cast<T*>(a.Sout) + (long long)b * a.sigmaStride;
-    const T* colRec = static_cast<const T*>(a.colRec) + (long long)b * kBurstMax * kColRec * cap + Jc;
-    const T* rowRec = static_cast<const T*>(a.rowRec) + (long long)b * kBurstMax * cap * kBlkRec + (long long)I0 * kBlkRec;
-    const BurstStep* steps = a.steps + b * kBurstMax;
-    constexpr int kRowVals = R * kBlkRec, kRowTrips = (kRowVals + 63) / 64;
-    __shared__ T sRow[4][kRowVals];
-
-    T S[R][9];
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const int I = min(I0 + i, N - 1);
-        const T* src = Sin + (long long)(kLm0 + 3 * I) * ld + kLm0 + 3 * Jc;
-#pragma unroll
-        for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) S[i][3 * rr + cc] = src[(long long)rr * ld + cc];
-    }
-    // which steps touch Sigma (bit s), fetched once
-    unsigned todo = 0;
-    for (int st = 0; st < K; ++st) todo |= steps[st].riccati ? (1u << st) : 0u;
-    constexpr int kC = kBlkRec + 1;  // column constants + T p of the step
-    T cA[kC], cB[kC], rA[kRowTrips], rB[kRowTrips];
-    auto fetch = [&](int st, T* c, T* rv) __attribute__((always_inline)) {
-        const T* cp = colRec + (long long)st * kColRec * cap;
-#pragma unroll
-        for (int k = 0; k < 27; ++k) c[k] = cp[(long long)k * cap];
-#pragma unroll
-        for (int k = 0; k < 18; ++k) c[27 + k] = cp[(long long)(45 + k) * cap];
-        c[kBlkRec] = (T)steps[st].TtP;
-        const T* rp = rowRec + (long long)st * cap * kBlkRec;
-#pragma unroll
-        for (int u = 0; u < kRowTrips; ++u) {
-            const int e = min(lane + 64 * u, nI * kBlkRec - 1);
-            rv[u] = rp[e];
-        }
-    };
-    // row constants of the step -> wave-private LDS (they arrived with the column constants of the same step)
-    auto stage = [&](const T* rv) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < kRowTrips; ++u) {
-            const int e = lane + 64 * u;
-            if (e < kRowVals) sRow[wv][e] = rv[u];
-        }
-        waveSync();
-    };
-    auto math = [&](const T* c) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const T* rc = sRow[wv] + i * kBlkRec;  // wave-uniform: LDS broadcast reads
-            T H[9];
-#pragma unroll
-            for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-                for (int cc = 0; cc < 3; ++cc) {
-                    T acc = rc[3 * rr] * S[i][cc];
-#pragma unroll
-                    for (int k = 1; k < 3; ++k) acc = fma(rc[3 * rr + k], S[i][3 * k + cc], acc);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) acc = fma(rc[9 + 3 * rr + k], c[27 + 3 * k + cc], acc);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) acc = fma(rc[18 + 3 * rr + k], c[36 + 3 * k + cc], acc);
-                    H[3 * rr + cc] = acc;
-                }
-            const bool diag = (I0 + i) == J;
-#pragma unroll
-            for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-                for (int cc = 0; cc < 3; ++cc) {
-                    T acc = (diag && rr == cc) ? c[kBlkRec] : (T)0;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) acc = fma(H[3 * rr + k], c[3 * cc + k], acc);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) acc = fma(rc[27 + 3 * rr + k], c[9 + 3 * cc + k], acc);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) acc = fma(rc[36 + 3 * rr + k], c[18 + 3 * cc + k], acc);
-                    S[i][3 * rr + cc] = acc;
-                }
-            waveSync();  // (the next stage() overwrites the rows)
-        }
-    };
-    // ping-pong between the two register sets: the fetch of the next step is issued after this step's constants have
-    // arrived (they are all needed at once) and flies during its arithmetic
-    auto next = [&]() __attribute__((always_inline)) {
-        const int st = todo ? __builtin_ctz(todo) : -1;
-        todo &= todo - 1;
-        return st;
-    };
-    // (the fetch is unconditional -- after the last step it re-reads that step -- so that the compiler's wait counters know
-    // that the loads it waits for are older than a full set of newer ones, instead of draining the queue)
-    int st = next();
-    if (st >= 0) fetch(st, cA, rA);
-    while (st >= 0) {
-        stage(rA);
-        int nx = next();
-        fetch(nx >= 0 ? nx : st, cB, rB);
-        __builtin_amdgcn_sched_barrier(0);  // (keep the loads here: the scheduler would sink them behind the arithmetic)
-        math(cA);
-        if (nx < 0) break;
-        stage(rB);
-        st = next();
-        fetch(st >= 0 ? st : nx, cA, rA);
-        __builtin_amdgcn_sched_barrier(0);
-        math(cB);
-    }
-    if (validJ) {
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            if (i < nI) {
-                T* dst = Sout + (long long)(kLm0 + 3 * (I0 + i)) * ld + kLm0 + 3 * J;
-#pragma unroll
-                for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-                    for (int cc = 0; cc < 3; ++cc) dst[(long long)rr * ld + cc] = S[i][3 * rr + cc];
-            }
-        }
-    }
-}
-
 }  // namespace eqf

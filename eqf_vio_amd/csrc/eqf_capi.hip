@@ -107,7 +107,6 @@ struct eqf_filter {
     CommonLds* dBlkCommon = nullptr;
     int streamPropagate = 1;       // split path: landmark blocks by k_riccati_stream (EQF_STREAM_PROPAGATE = 0: by the tile kernel)
     int splitPropagate = -1;       // -1 heuristic, 0 never, 1 always (EQF_SPLIT_PROPAGATE)
-    int cholMode = 64;             // 64: k_chol_step64 ; 32 / 33: k_chol_step<false> / <true> (EQF_CHOL_MODE = 64 | 32 | 32inv)
     int cholEmbed = 1;             // EQF_CHOL_EMBED = 0: downdate + innovation lift as a launch of their own
     bool ldsAttrSet[2] = {false, false};  // hipFuncAttributeMaxDynamicSharedMemorySize applied on this handle's device
     // speculative outlier gate: the frame whose gate answer the host has not looked at yet
@@ -128,9 +127,8 @@ struct eqf_filter {
     // full, when the vision call that follows them arrives (whose integrateUpToTime joins the burst), or when the host
     // touches the handle in any other way.  burstMax = 0: every call launches at once through k_propagate.
     int burstMax = kBurstMax;      // EQF_IMU_BURST / eqf_set_imu_burst
-    int burstRows = 0;             // block kernel: row landmarks per wavefront, 0 = by launch size (EQF_BURST_ROWS = 1 | 2 | 4)
+    int burstRows = 0;             // block kernel: row landmarks per wavefront, 0 = by launch size (EQF_BURST_ROWS = 1 | 4)
     int burstLm = 0;               // builder: landmarks per workgroup, 0 = by launch size (EQF_BURST_LM = 4 | 16)
-    int burstRing = 1;             // small problems: k_burst_riccati_ring (EQF_BURST_RING = 0: k_burst_riccati<1>)
     struct {
         int kind = 0;              // 0 nothing pending, 1 records k0 .. k0+cnt-1 of the uploaded stream, 2 inline records (one filter)
         int k0 = 0, cnt = 0;
@@ -147,7 +145,6 @@ struct eqf_filter {
     int cholResident = 1;
     int resStaged = 1;             // row heads consume D[R-1] stage by stage (EQF_RES_STAGED = 0: whole record after its last pivot)
     int residentPerCU = -1;        // hipOccupancyMaxActiveBlocksPerMultiprocessor of k_chol_resident on this device (lazily queried)
-    int prepFuseMax = 1 << 30;     // prep + first diagonal factors as one launch up to this many workgroups (EQF_PREP_FUSE_MAX; measured: one launch is never slower, 4..64 filters)
     int eFromSigma = 1;            // split chain: block column 0 of the E-chain read straight from Sigma (EQF_E_FROM_SIGMA=0: copied by prep)
     int cholOrder = -1;            // order of the workgroup classes in an update launch, -1 = by launch size (EQF_CHOL_ORDER = 0 | 1 | 2)
     int cholStreams = 0;           // stream workgroups per filter of an update launch, 0 = by launch size (EQF_CHOL_STREAMS)
@@ -388,7 +385,8 @@ int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, con
     a.blkCommon = f->dBlkCommon;
     // Split path (builder + lean streaming kernel) when there are enough tiles for occupancy to matter; a single small
     // filter keeps the fused single-launch kernel (one kernel boundary less per step).
-    const bool split = f->splitPropagate >= 0 ? f->splitPropagate != 0 : (long long)a.NT * a.NT * f->B >= 2500;  // measured cross-over at N = 200: 16 filters
+    // (measured cross-over on the 256-CU part: 2500 tiles = ten per CU -- 16 filters of N = 200, N >= 800)
+    const bool split = f->splitPropagate >= 0 ? f->splitPropagate != 0 : (long long)a.NT * a.NT * f->B >= 10LL * std::max(f->numCUs, 1);
     rc = profiled(f, EQF_PROF_PROPAGATE, [&] {
         if (split) {
             const dim3 bgrid((std::max(1, maxN(f)) + 63) / 64 + 1, f->B);  // landmark workgroups + the scalar-state workgroup
@@ -459,13 +457,15 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     const int nmx = maxN(f);
     // builder: 4 landmarks per workgroup (its eight stages on eight wavefronts, shortest tick) while that launch fits the chip,
     // 16 per workgroup (four panel waves, full lanes) otherwise
-    const int lm = f->burstLm ? f->burstLm : ((long long)((nmx + 3) / 4) * f->B <= 256 ? 4 : 16);
+    const int cus = std::max(f->numCUs, 1);
+    const int lm = f->burstLm ? f->burstLm : ((long long)((nmx + 3) / 4) * f->B <= cus ? 4 : 16);
     const dim3 bgrid(std::max(1, (nmx + lm - 1) / lm), f->B);
     // rows per wavefront of the block kernel: one while the launch cannot fill the chip anyway (latency), four once the
     // column constants of a lane are worth sharing between several of its blocks.  (Two rows: 286 VGPRs, one wave per SIMD
     // like four rows but half their reuse -- measured slower than both at every size, N = 200 x 2..64 filters, N = 400..4000.)
     const long long waves1 = (long long)((nmx + 63) / 64) * nmx * f->B;
-    const int R = f->burstRows ? f->burstRows : (waves1 <= 2800 ? 1 : 4);
+    // (cross-over measured on the 256-CU part at 2800 wave-blocks = 11 per CU: four filters of N = 200, N >= 400)
+    const int R = f->burstRows ? f->burstRows : (waves1 <= 11LL * cus ? 1 : 4);
     const dim3 rgrid((nmx + 63) / 64, (nmx + 4 * R - 1) / (4 * R), f->B);
     // every filter past its lazy initialisation (VIOFilter.cpp:122-124): the schedule with the precomputed step halves
     const bool fast = allDevInit(f);
@@ -477,13 +477,9 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
             else if (lm == 4) hipLaunchKernelGGL((k_burst_build<TT, false, 4>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
             else hipLaunchKernelGGL((k_burst_build<TT, false, 16>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
             if (nmx > 0) {
-                // (ring: the four wavefronts of a workgroup share a step's column constants through LDS; EQF_BURST_RING=0: every
-                // wavefront fetches its own)
-                if (R == 1 && f->burstRing) hipLaunchKernelGGL((k_burst_riccati_ring<TT, 1>), rgrid, dim3(256), 0, f->stream, a);
-                else if (R == 1) hipLaunchKernelGGL((k_burst_riccati<TT, 1>), rgrid, dim3(256), 0, f->stream, a);
-                else if (R == 2) hipLaunchKernelGGL((k_burst_riccati<TT, 2>), rgrid, dim3(256), 0, f->stream, a);
-                else if (f->burstRing) hipLaunchKernelGGL((k_burst_riccati_ring<TT, 4>), rgrid, dim3(256), 0, f->stream, a);
-                else hipLaunchKernelGGL((k_burst_riccati<TT, 4>), rgrid, dim3(256), 0, f->stream, a);
+                // (the four wavefronts of a workgroup share a step's column constants through an LDS ring)
+                if (R == 1) hipLaunchKernelGGL((k_burst_riccati_ring<TT, 1>), rgrid, dim3(256), 0, f->stream, a);
+                else hipLaunchKernelGGL((k_burst_riccati_ring<TT, 4>), rgrid, dim3(256), 0, f->stream, a);
             }
         };
         if (f->precision == EQF_PRECISION_F32) go(0.0f);
@@ -589,15 +585,14 @@ template <typename T>
 int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, const int* perm, int Nmax) {
     UpdArgs a = makeUpdArgs(f, bearings, bearStride, perm);
     const int B = f->B;
-    // Factorisation kernel: k_chol_step64 (64-wide block columns, register-chained MFMA panel solves) -- measured faster
-    // than the older 32-wide kernel at every size tried (N = 200: 1..64 filters; N = 1000, 4000).  The 32-wide kernels
-    // stay as an independent cross-check: EQF_CHOL_MODE = 32 (per-workgroup forward substitution) | 32inv (explicit block
-    // inverses + MFMA panels).
+    // Factorisation kernels: k_chol_step64 / k_chol_resident (64-wide block columns, register-chained MFMA panel solves).  (The 32-wide
+    // family of round 1 -- k_chol_step<INVERSE>, k_update_reduce, a separate prep launch -- was dominated at every size measured and has
+    // been removed in round 3; the cross-checks of a factorisation are now the other launch shapes of the same mathematics -- resident
+    // vs per-column launches bitwise, fused vs split chain to rounding -- and the oracle.)
     const int nb64S = roundUp(sDim(Nmax), kSB) / kSB, nb64E = roundUp(eDim(Nmax), kSB) / kSB;
     const int wt64 = roundUp(yCols(Nmax), kSB) / kSB;
     const int nblk64 = nb64S * nb64S + wt64 * nb64S + nb64E * nb64E + nb64E;
-    const bool use64 = f->cholMode == 64;
-    a.pad = use64 ? kSB : kNB;
+    a.pad = kSB;
     const int mp = roundUp(sDim(Nmax), a.pad), nep = roundUp(eDim(Nmax), a.pad);
     const int nv = kLm0 + 3 * Nmax;
     // prep
@@ -611,8 +606,6 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     bool& attrSet = f->ldsAttrSet[0];
     bool& attrSet64 = f->ldsAttrSet[1];
     if (!attrSet) {
-        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<float, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<float, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
@@ -639,8 +632,6 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     if (!attrSet64) {
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_first_sigma<float>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
-        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_first_sigma<double>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         attrSet64 = true;
     }
     // ---- which shape the factorisation launches will have (decided here: the prep launch needs to know whether anybody reads EA's
@@ -651,10 +642,11 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         if (Nb > 0 && roundUp(sDim(Nb), kSB) >= roundUp(eDim(Nb), kSB)) embed = false;
     }
     if (!f->cholEmbed) embed = false;
-    const bool splitChain = f->cholSplit >= 0 ? f->cholSplit != 0 : (long long)nblk64 * B >= 1500;  // measured: N = 200 from 8 filters on, N >= ~600
+    // (measured on the 256-CU part: 1500 workgroups = six per CU -- N = 200 from 8 filters on, N >= ~600)
+    const bool splitChain = f->cholSplit >= 0 ? f->cholSplit != 0 : (long long)nblk64 * B >= 6LL * std::max(f->numCUs, 1);
     bool resident = false, residentFits = false;
     int rc = EQF_OK;
-    if (use64 && embed && f->cholResident && f->cholSplit <= 0 && f->dReadyA) {
+    if (embed && f->cholResident && f->cholSplit <= 0 && f->dReadyA) {
         rc = buildRoles(f, Nmax);
         if (rc) return rc;
         // co-residency of the whole grid by the occupancy calculation (one workgroup per CU with the 119 KB LDS image), not by
@@ -667,24 +659,20 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         residentFits = (long long)f->rolesCount * B <= (long long)f->residentPerCU * f->numCUs;
         resident = f->cholResident >= 2 || residentFits;
     }
-    a.eFromSigma = (use64 && !resident && splitChain && f->cholTail && f->eFromSigma && f->precision != EQF_PRECISION_F32) ? 1 : 0;
+    a.eFromSigma = (!resident && splitChain && f->cholTail && f->eFromSigma && f->precision != EQF_PRECISION_F32) ? 1 : 0;
     rc = profiled(f, EQF_PROF_UPDATE_PREP, [&] {
-        // 64-wide path: two more workgroups per filter factor the first diagonal block of each chain straight from Sigma
-        if (use64 && wpb == 4 && (long long)(lmBlocks + eBlocks + 2) * B <= f->prepFuseMax)
-            hipLaunchKernelGGL(k_update_prep64<T>, dim3(lmBlocks + eBlocks + 2, B), dim3(256), std::max(lds, sizeof(Step64Lds)), f->stream, a, cS,
-                cE, lmBlocks, eBlocks, wpb, nvPad);
-        else {
-            hipLaunchKernelGGL(k_update_prep<T>, dim3(lmBlocks + eBlocks, B), dim3(64 * wpb), lds, f->stream, a, lmBlocks, wpb, nvPad);
-            if (use64) hipLaunchKernelGGL(k_factor_first_sigma<T>, dim3(2, B), dim3(256), sizeof(Step64Lds), f->stream, a, cS, cE);
-        }
+        // the landmark waves + E-chain operand + two more workgroups per filter that factor the first diagonal block of each chain
+        // straight from Sigma (one launch: measured never slower than a separate factor launch, 4..64 filters)
+        hipLaunchKernelGGL(k_update_prep64<T>, dim3(lmBlocks + eBlocks + 2, B), dim3(256), std::max(lds, sizeof(Step64Lds)), f->stream, a, cS, cE,
+            lmBlocks, eBlocks, wpb, nvPad);
     });
     if (rc) return rc;
     // downdate tiling: 64x64 tiles when they fill the chip, 32x32 tiles (4x the workgroups) for a single small filter
     const int nt64 = (nv + 63) / 64, nt32 = (nv + 31) / 32;
-    const bool small = (long long)nt64 * (nt64 + 1) / 2 * B < 512;
+    const bool small = (long long)nt64 * (nt64 + 1) / 2 * B < 2LL * std::max(f->numCUs, 1);
     const int ddNt = small ? nt32 : nt64, ddTiles = ddNt * (ddNt + 1) / 2;
-    bool tailLaunch = true;  // reduce / downdate / finish as launches of their own after the chains
-    if (use64) {
+    bool tailLaunch = true;  // downdate / finish as a launch of their own after the chains
+    {
         cS.nbMax = nb64S; cS.wtMax = wt64;
         cE.nbMax = nb64E; cE.wtMax = 1;
         const int steps = std::max(nb64S, nb64E);
@@ -776,27 +764,6 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             if (rc) return rc;
         }
         tailLaunch = !embed;
-    } else {
-        cS.nbMax = mp / kNB; cS.wtMax = roundUp(yCols(Nmax), kNB) / kNB;
-        cE.nbMax = nep / kNB; cE.wtMax = 1;
-        const int steps = std::max(cS.nbMax, cE.nbMax);
-        const int nblk = cS.nbMax * cS.nbMax + cS.wtMax * cS.nbMax + cE.nbMax * cE.nbMax + cE.wtMax * cE.nbMax;
-        // Panel blocks by explicit inverse + MFMA when the launch is throughput-bound (many tiles), by per-workgroup
-        // forward substitution otherwise: see k_chol_step.
-        const bool inverse = f->cholMode == 33;
-        for (int k = 0; k < steps; ++k) {
-            rc = profiled(f, EQF_PROF_CHOL_STEP, [&] {
-                if (inverse) hipLaunchKernelGGL(k_chol_step<true>, dim3(nblk, B), dim3(256), 0, f->stream, cS, cE, k, f->errflag);
-                else hipLaunchKernelGGL(k_chol_step<false>, dim3(nblk, B), dim3(256), 0, f->stream, cS, cE, k, f->errflag);
-            }, k);
-            if (rc) return rc;
-        }
-    }
-    if (!use64) {
-        const int colBlocks = (nv + 6 + 63) / 64;
-        rc = profiled(f, EQF_PROF_REDUCE,
-            [&] { hipLaunchKernelGGL(k_update_reduce, dim3(colBlocks + 1, B), dim3(1024), 0, f->stream, a, colBlocks); });
-        if (rc) return rc;
     }
     if (tailLaunch) {
         // the last workgroup of the launch runs the (independent) innovation-lift / group-update part
@@ -1278,19 +1245,16 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (!rc && hipMalloc(&f->dColRec, f->esz * (size_t)kBurstMax * kColRec * cap * B) != hipSuccess) rc = EQF_ERR_HIP;
     if (!rc && hipMalloc(&f->dRowRec, f->esz * (size_t)kBurstMax * kBlkRec * cap * B) != hipSuccess) rc = EQF_ERR_HIP;
     chk(dmalloc(&f->dSteps, (size_t)kBurstMax * B));
-    if (const char* e = std::getenv("EQF_BURST_RING")) f->burstRing = std::atoi(e);
-    if (const char* e = std::getenv("EQF_BURST_ROWS")) f->burstRows = (std::atoi(e) == 1 || std::atoi(e) == 2 || std::atoi(e) == 4) ? std::atoi(e) : 0;
+    if (const char* e = std::getenv("EQF_BURST_ROWS")) f->burstRows = (std::atoi(e) == 1 || std::atoi(e) == 4) ? std::atoi(e) : 0;
     if (const char* e = std::getenv("EQF_BURST_LM")) f->burstLm = std::atoi(e) == 16 ? 16 : (std::atoi(e) == 4 ? 4 : 0);
     if (const char* e = std::getenv("EQF_IMU_BURST")) f->burstMax = std::max(0, std::min(kBurstMax, std::atoi(e)));
     if (const char* e = std::getenv("EQF_SPLIT_PROPAGATE")) f->splitPropagate = std::atoi(e);
     if (const char* e = std::getenv("EQF_STREAM_PROPAGATE")) f->streamPropagate = std::atoi(e);
-    if (const char* e = std::getenv("EQF_CHOL_MODE")) f->cholMode = std::strcmp(e, "32inv") == 0 ? 33 : (std::strcmp(e, "32") == 0 ? 32 : 64);
     if (const char* e = std::getenv("EQF_CHOL_EMBED")) f->cholEmbed = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_SPLIT")) f->cholSplit = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_TAIL")) f->cholTail = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_RESIDENT")) f->cholResident = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_STAGED")) f->resStaged = std::atoi(e);
-    if (const char* e = std::getenv("EQF_PREP_FUSE_MAX")) f->prepFuseMax = std::atoi(e);
     if (const char* e = std::getenv("EQF_E_FROM_SIGMA")) f->eFromSigma = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_ORDER")) f->cholOrder = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_STREAMS")) f->cholStreams = std::max(0, std::atoi(e));

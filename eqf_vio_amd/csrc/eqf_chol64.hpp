@@ -462,13 +462,6 @@ __global__ __launch_bounds__(256) void k_update_prep64(UpdArgs a, ChainArgs cS, 
 }
 // The two first-block workgroups as a launch of their own (grid = (2, B)): used when the prep launch has more workgroups
 // than the chip has CUs -- there the 119 KB of LDS these two need would cost every prep workgroup its occupancy.
-template <typename T>
-__global__ __launch_bounds__(256) void k_factor_first_sigma(UpdArgs a, ChainArgs cS, ChainArgs cE) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
-    int bad = 0;
-    factorFirstFromSigma<T>(a, blockIdx.x == 0 ? cS : cE, blockIdx.y, ldsFull(smem64), &bad);
-    if (bad && a.errflag && threadIdx.x == 0) atomicOr(a.errflag, 4);
-}
 // Stand-alone variant (tests / microbenchmarks without a prep launch): factor A_00 of each chain from ChainArgs::A.
 inline __global__ __launch_bounds__(256) void k_factor_first64(ChainArgs c0, ChainArgs c1, int* errflag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];

@@ -355,24 +355,10 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, d
     }
     if (bad && a.errflag) atomicOr(a.errflag, 2);
 }
-template <typename T>
-__global__ __launch_bounds__(256) void k_update_prep(UpdArgs a, int lmBlocks, int wpb, int nvPad) {
-    extern __shared__ __attribute__((aligned(16))) double sPrepLds[];  // [wpb][2][nvPad]
-    updatePrepBody<T>(a, lmBlocks, wpb, nvPad, sPrepLds);
-}
 
 // ------------------------------------------------------------------------------------------------
-// Blocked right-looking Cholesky with right-hand sides, ONE launch per block column k, both chains in
-// the same launch.  Every workgroup re-derives L_kk (32x32 potrf, one wave) and the panel blocks it needs
-// (forward substitution, one lane per row), so a launch has no inter-workgroup dependency:
-//   tile (r,c), r >= c >= k of chain matrix A:   c == k: L_rk = A_rk L_kk^-T  -> L
-//                                                c  > k: A_rc -= L_rk L_ck^T   (in place)
-//   tile (t,c) of the right-hand sides W (n x wcols):
-//                                                c == k: Y_k = L_kk^-1 W_k     -> Wout
-//                                                c  > k: W_c -= L_ck Y_k       (in place)
+// Small helpers of the factorisation kernels (eqf_chol64.hpp)
 // ------------------------------------------------------------------------------------------------
-constexpr int kLdsP = kNB + 1;  // LDS row pitch (doubles): +1 breaks the power-of-two stride
-
 // Broadcast of a double held by lane `src` (compile-time constant after unrolling) through SGPRs.
 EQF_DI double readlane64(double v, int src) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -395,69 +381,6 @@ EQF_DI double rsqrtPivot(double d) {
     y = y * (1.5 - h * y * y);
     y = y * (1.5 - h * y * y);
     return y;
-}
-
-// 32x32 Cholesky by one wave, right-looking, row `lane & 31` of the block in registers.
-// Measured on gfx950 (scripts/micro/lat.hip): fp64 VALU op ~6 cycles, v_readlane ~15, LDS round trip ~110,
-// so only the pivot chain (and the next kLA columns it needs) uses SGPR broadcasts; the bulk of each rank-1
-// update reads the finished column from LDS one iteration later (wide uniform-address reads), off the chain.
-// Output: L^T in sLT (sLT[j][c] = L[c][j], c >= j) and the reciprocal diagonal in sRd.
-constexpr int kLtP = kNB + 2;  // even pitch: rows 16-byte aligned for ds_read_b128
-constexpr int kLA = 2;         // columns ahead of the pivot that are updated through v_readlane
-EQF_DI void potrf32(const double (*sA)[kLdsP], double (*sLT)[kLtP], double* sRd, int lane, int* bad) {
-    double row[kNB];
-    const int lr = lane & (kNB - 1);
-#pragma unroll
-    for (int c = 0; c < kNB; ++c) row[c] = sA[lr][c];
-    double ljPrev = 0.0;
-#pragma unroll
-    for (int j = 0; j < kNB; ++j) {
-        // (1) start fetching column j-1 (written to LDS one iteration ago) for its bulk update
-        double colPrev[kNB];
-        if (j >= 1) {
-#pragma unroll
-            for (int c = j + kLA; c < kNB; ++c) colPrev[c] = sLT[j - 1][c];
-        }
-        // (2) pivot chain of column j while those reads are in flight
-        const double d = readlane64(row[j], j);
-        if (!(d > 0.0)) *bad = 1;
-        const double rd = rsqrtPivot(d);
-        const double lj = row[j] * rd;  // lane j: sqrt(d); lanes > j: L[lane][j]
-#pragma unroll
-        for (int q = 1; q <= kLA; ++q)
-            if (j + q < kNB) row[j + q] = fma(-lj, readlane64(lj, j + q), row[j + q]);
-        // (3) bulk rank-1 update with column j-1
-        if (j >= 1) {
-#pragma unroll
-            for (int c = j + kLA; c < kNB; ++c) row[c] = fma(-ljPrev, colPrev[c], row[c]);
-        }
-        // (4) publish column j
-        if (lane < kNB) sLT[j][lane] = lj;
-        if (lane == j) sRd[j] = rd;
-        ljPrev = lj;
-#if defined(__HIP_DEVICE_COMPILE__)
-        // Pin the updated row here: hipcc otherwise sinks every rank-1 update to the point where the element is
-        // consumed, which re-creates one long dependent FMA chain in front of each pivot.
-#pragma unroll
-        for (int c = j + 1; c < kNB; ++c) __asm__ volatile("" : "+v"(row[c]));
-#endif
-    }
-}
-// Forward substitution with L^T in LDS (sLT[j][c] = L[c][j]) and sRd = 1/diag: solves L x = b for one vector per
-// lane (b in x[]), right-looking: the FMAs of one column are independent and read contiguous L values.
-// Used both for rows of A_rk (x L^T = a) and for columns of W_k (L y = w).
-EQF_DI void fwdsub32(const double (*sLT)[kLtP], const double* sRd, double* x) {
-#pragma unroll
-    for (int j = 0; j < kNB; ++j) {
-        const double xj = x[j] * sRd[j];
-        x[j] = xj;
-#pragma unroll
-        for (int c = j + 1; c < kNB; ++c) x[c] = fma(-xj, sLT[j][c], x[c]);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-        for (int c = j + 1; c < kNB; ++c) __asm__ volatile("" : "+v"(x[c]));
-#endif
-    }
 }
 
 struct ChainArgs {
@@ -501,274 +424,6 @@ EQF_DI ChainArgs pickChain(bool second, const ChainArgs& c0, const ChainArgs& c1
     ch.strideF = pickValue(second, c0.strideF, c1.strideF);
     ch.epoch = pickValue(second, c0.epoch, c1.epoch);
     return ch;
-}
-
-// per-filter chain sizes
-EQF_DI void chainDims(const ChainArgs& ch, int N, int* nb, int* wt) {
-    if (ch.kind == 0) {
-        *nb = roundUp(sDim(N), kNB) / kNB;
-        *wt = roundUp(yCols(N), kNB) / kNB;
-    } else {
-        *nb = roundUp(eDim(N), kNB) / kNB;
-        *wt = 1;
-    }
-}
-
-// 32x32x32 product on v_mfma_f64_16x16x4_f64, one 16x16 quadrant (tm, tn) per wave, operands in LDS.
-//   NT: acc += sgn * P Q^T      NN: acc += sgn * P Q
-template <bool NT>
-EQF_DI f64x4 mm32(f64x4 acc, const double (*P)[kLdsP], const double (*Q)[kLdsP], int tm, int tn, int lane, double sgn) {
-    const int lr = lane & 15, lk = lane >> 4;
-#pragma unroll
-    for (int s = 0; s < kNB / 4; ++s) {
-        const double av = sgn * P[16 * tm + lr][4 * s + lk];
-        const double bv = NT ? Q[16 * tn + lr][4 * s + lk] : Q[4 * s + lk][16 * tn + lr];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-    }
-    return acc;
-}
-// accumulator quadrant (C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg) <-> LDS / global
-EQF_DI void accToLds(const f64x4& acc, double (*M)[kLdsP], int tm, int tn, int lane) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) M[16 * tm + (lane >> 4) + 4 * q][16 * tn + (lane & 15)] = acc[q];
-}
-
-// Blocked right-looking Cholesky with right-hand sides and one-step look-ahead; one launch per block column k,
-// both chains in the same launch.  Entering launch k, D[k] holds the factor of the k-th diagonal block (from launch
-// k-1's diagonal workgroup; at k = 0 every workgroup derives it itself).  Only ONE workgroup per chain runs the serial
-// 32x32 factorisation, for the NEXT column:
-//   tile (r,c), r >= c > k :  A_rc -= L_rk L_ck^T ; if r == c == k+1: potrf of the updated tile -> D[k+1]
-//   rhs tile (t,c), c == k :  Y_k -> WO ;            c > k: R_c -= L_ck Y_k
-// Two ways to form the panel blocks L_rk = A_rk L_kk^-T, Y_k = L_kk^-1 R_k:
-//   INVERSE = true  (throughput: batches, large N): D[k] also holds W_k = L_kk^-1 and the panel blocks are products
-//                   on v_mfma_f64_16x16x4_f64; the diagonal workgroup pays the explicit inverse (+3.9 us on its chain).
-//   INVERSE = false (latency: one small filter): every workgroup solves its own panel blocks by forward substitution
-//                   (one lane per row / column) WHILE the diagonal workgroup factors the next block, so a launch
-//                   costs max(potrf, solve) instead of potrf + inverse.
-template <bool INVERSE>
-__global__ __launch_bounds__(256) void k_chol_step(ChainArgs c0, ChainArgs c1, int k, int* errflag) {
-    const int b = blockIdx.y;
-    const int n0 = c0.nbMax * c0.nbMax + c0.wtMax * c0.nbMax;
-    const bool second = (int)blockIdx.x >= n0;
-    const ChainArgs& ch = second ? c1 : c0;
-    int idx = second ? (int)blockIdx.x - n0 : (int)blockIdx.x;
-    const Glob& g = ch.g[b];
-    if (!g.updateOk || g.N == 0) return;
-    int nb, wt;
-    chainDims(ch, g.N, &nb, &wt);
-    if (k >= nb) return;
-    bool isW = false;
-    int r, c;  // A tile (r,c) or rhs tile (t = r, c)
-    if (idx < ch.nbMax * ch.nbMax) {
-        r = idx / ch.nbMax;
-        c = idx % ch.nbMax;
-        if (r >= nb || c > r || c <= k) return;  // the panel column itself needs no workgroup any more
-    } else {
-        idx -= ch.nbMax * ch.nbMax;
-        isW = true;
-        r = idx / ch.nbMax;  // column tile t
-        c = idx % ch.nbMax;
-        if (r >= wt || c >= nb || c < k) return;
-    }
-    double* A = ch.A + (long long)b * ch.strideA;
-    double* D = ch.D + (long long)b * ch.strideD;
-    double* W = ch.W + (long long)b * ch.strideW;
-    double* WO = ch.WO + (long long)b * ch.strideW;
-    const int ldA = ch.ldA, ldW = ch.ldW;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tm = wv >> 1, tn = wv & 1;
-
-    __shared__ double sWk[kNB][kLdsP];  // INVERSE: W_k = L_kk^-1 ; k = 0: A_00
-    __shared__ double sP[kNB][kLdsP];   // A_rk -> L_rk   (A tiles)   /  R_k -> Y_k (rhs tiles)
-    __shared__ double sQ[kNB][kLdsP];   // A_ck -> L_ck
-    __shared__ __attribute__((aligned(16))) double sLT[kNB][kLtP];  // L_kk^T
-    __shared__ double sRd[kNB];                                     // 1 / diag(L_kk)
-    int bad = 0;
-    const bool diagNext = !isW && r == c && c == k + 1;  // this workgroup factors the next diagonal block
-    const bool needQ = c > k;
-    const double* Dk = D + ((long long)k * 2) * kNB * kNB;  // [0]: L_kk^T (sLT image), [1]: W_k or (row 0) 1/diag
-
-    // ---- the tile this workgroup updates: fetched first, its (cold) miss overlaps the panel work below
-    const bool hasTile = !(isW && c == k);
-    double* Ct = isW ? (W + (long long)(c * kNB) * ldW + r * kNB) : (A + (long long)(r * kNB) * ldA + c * kNB);
-    const int ldc = isW ? ldW : ldA;
-    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-    if (hasTile) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = Ct[(long long)(16 * tm + (lane >> 4) + 4 * q) * ldc + 16 * tn + (lane & 15)];
-    }
-    // ---- operands
-#pragma unroll
-    for (int e = tid; e < kNB * kNB; e += 256) {
-        const int rr = e / kNB, cc = e % kNB;
-        if (k == 0) sWk[rr][cc] = A[(long long)rr * ldA + cc];  // A_00: factored below by every workgroup
-        else if (INVERSE) sWk[rr][cc] = Dk[kNB * kNB + rr * kNB + cc];
-        else sLT[rr][cc] = Dk[rr * kNB + cc];
-        if (isW) sP[rr][cc] = W[(long long)(k * kNB + rr) * ldW + r * kNB + cc];
-        else if (r != c) sP[rr][cc] = A[(long long)(r * kNB + rr) * ldA + k * kNB + cc];
-        if (needQ) sQ[rr][cc] = A[(long long)(c * kNB + rr) * ldA + k * kNB + cc];
-    }
-    if (!INVERSE && k > 0 && tid < kNB) sRd[tid] = Dk[kNB * kNB + tid];
-    __syncthreads();
-    if (k == 0) {
-        // first column: no look-ahead yet, every workgroup factors (and, INVERSE, inverts) A_00 itself
-        if (wv == 0) {
-            potrf32(sWk, sLT, sRd, lane, &bad);
-            if (INVERSE) {
-                double x[kNB];
-#pragma unroll
-                for (int j = 0; j < kNB; ++j) x[j] = ((lane & 31) == j) ? 1.0 : 0.0;
-                fwdsub32(sLT, sRd, x);  // column (lane & 31) of L^-1
-                if (lane < kNB) {
-#pragma unroll
-                    for (int j = 0; j < kNB; ++j) sWk[j][lane] = x[j];
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (INVERSE) {
-        // ---- panel blocks by MFMA: L_rk = A_rk W^T, L_ck = A_ck W^T, Y_k = W R_k   (in place, barrier in between)
-        f64x4 zero = {0.0, 0.0, 0.0, 0.0};
-        f64x4 pP = zero, pQ = zero;
-        if (isW) pP = mm32<false>(zero, sWk, sP, tm, tn, lane, 1.0);
-        else if (r != c) pP = mm32<true>(zero, sP, sWk, tm, tn, lane, 1.0);
-        if (needQ) pQ = mm32<true>(zero, sQ, sWk, tm, tn, lane, 1.0);
-        __syncthreads();
-        if (isW || r != c) accToLds(pP, sP, tm, tn, lane);
-        if (needQ) accToLds(pQ, sQ, tm, tn, lane);
-        __syncthreads();
-    } else {
-        // ---- panel blocks by forward substitution, one lane per vector: wave 0, lanes 0..31 -> sP, lanes 32..63 -> sQ
-        if (wv == 0) {
-            const int v = lane & 31;
-            const bool secondHalf = lane >= 32;
-            const bool doP = !secondHalf && (isW || r != c);
-            const bool doQ = secondHalf && needQ;
-            if (doP || doQ) {
-                double x[kNB];
-                if (doQ) {
-#pragma unroll
-                    for (int j = 0; j < kNB; ++j) x[j] = sQ[v][j];
-                } else if (isW) {
-#pragma unroll
-                    for (int j = 0; j < kNB; ++j) x[j] = sP[j][v];  // column v of R_k
-                } else {
-#pragma unroll
-                    for (int j = 0; j < kNB; ++j) x[j] = sP[v][j];  // row v of A_rk
-                }
-                fwdsub32(sLT, sRd, x);
-                if (doQ) {
-#pragma unroll
-                    for (int j = 0; j < kNB; ++j) sQ[v][j] = x[j];
-                } else if (isW) {
-#pragma unroll
-                    for (int j = 0; j < kNB; ++j) sP[j][v] = x[j];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < kNB; ++j) sP[v][j] = x[j];
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    if (isW && c == k) {
-        for (int e = tid; e < kNB * kNB; e += 256) {
-            const int rr = e / kNB, cc = e % kNB;
-            WO[(long long)(k * kNB + rr) * ldW + r * kNB + cc] = sP[rr][cc];
-        }
-    } else {
-        // ---- trailing update of this tile
-        if (isW) acc = mm32<false>(acc, sQ, sP, tm, tn, lane, -1.0);          // R_c -= L_ck Y_k
-        else acc = mm32<true>(acc, (r == c) ? sQ : sP, sQ, tm, tn, lane, -1.0);  // A_rc -= L_rk L_ck^T
-        if (!diagNext) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Ct[(long long)(16 * tm + (lane >> 4) + 4 * q) * ldc + 16 * tn + (lane & 15)] = acc[q];
-        } else {
-            // ---- look-ahead: factor (and, INVERSE, invert) the freshly updated diagonal block for launch k + 1
-            __syncthreads();
-            accToLds(acc, sP, tm, tn, lane);
-            __syncthreads();
-            if (wv == 0) {
-                potrf32(sP, sLT, sRd, lane, &bad);
-                double* Dn = D + ((long long)(k + 1) * 2) * kNB * kNB;
-                if (INVERSE) {
-                    double x[kNB];
-#pragma unroll
-                    for (int j = 0; j < kNB; ++j) x[j] = ((lane & 31) == j) ? 1.0 : 0.0;
-                    fwdsub32(sLT, sRd, x);
-                    if (lane < kNB) {
-#pragma unroll
-                        for (int j = 0; j < kNB; ++j) Dn[kNB * kNB + j * kNB + lane] = x[j];  // W_{k+1}[j][lane]
-                    }
-                } else if (lane < kNB) {
-#pragma unroll
-                    for (int j = 0; j < kNB; ++j) Dn[j * kNB + lane] = (lane >= j) ? sLT[j][lane] : 0.0;  // L_{k+1}^T image
-                    Dn[kNB * kNB + lane] = sRd[lane];
-                }
-            }
-        }
-    }
-    if (bad && errflag && tid == 0) atomicOr(errflag, 4);
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_update_reduce: the length-m / length-n_e dot products of the update, spread over many workgroups:
-//   gamma[col] = sum_r Y[r][col] z[r]  (z = Y[:, 11]),  hV = (L^-1 V)^T z,  G11 = [Zt | Et]^T [Zt | Et].
-// grid.x = colBlocks (64 columns of Y each) + 1 (the E-chain block), grid.y = B, block = 256.
-// ------------------------------------------------------------------------------------------------
-inline __global__ __launch_bounds__(1024) void k_update_reduce(UpdArgs a, int colBlocks) {
-    const int b = blockIdx.y;
-    const Glob& g = a.g[b];
-    if (!g.updateOk || g.N == 0) return;
-    const int N = g.N, cap = a.cap;
-    const int tid = threadIdx.x;
-    __shared__ double sRed[1024];
-    if ((int)blockIdx.x < colBlocks) {
-        // 64 columns x 16 row slices per workgroup: many independent loads in flight (the data was written by other
-        // XCDs in the previous launch, every access is a ~2 us miss)
-        const int mp = roundUp(sDim(N), a.pad), nv = kLm0 + 3 * N;
-        const double* Y = a.YO + (long long)b * a.strideY;
-        const int col = blockIdx.x * 64 + (tid & 63), part = tid >> 6;
-        double acc0 = 0, acc1 = 0;
-        if (col < nv + 6) {
-            int r = part;
-#pragma unroll 4
-            for (; r + 16 < mp; r += 32) {
-                acc0 += Y[(long long)r * a.ldY + col] * Y[(long long)r * a.ldY + 11];
-                acc1 += Y[(long long)(r + 16) * a.ldY + col] * Y[(long long)(r + 16) * a.ldY + 11];
-            }
-            if (r < mp) acc0 += Y[(long long)r * a.ldY + col] * Y[(long long)r * a.ldY + 11];
-        }
-        sRed[tid] = acc0 + acc1;
-        __syncthreads();
-        if (tid < 64 && col < nv + 6) {
-            double v = 0;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) v += sRed[64 * q + tid];
-            if (col < nv) a.dbgGamma[(long long)b * (kLm0 + 3 * cap) + col] = (col == 11) ? 0.0 : v;
-            else a.red[(long long)b * 256 + col - nv] = v;
-        }
-    } else {
-        const int nep = roundUp(eDim(N), a.pad);
-        const double* Z = a.ZO + (long long)b * a.strideZ;
-        const int pr = tid % 121, part = tid / 121;  // 121 column pairs x 8 row slices (threads 968..1023 idle)
-        double acc = 0;
-        if (part < 8) {
-            const int c0 = pr / 11, c1 = pr % 11;
-#pragma unroll 4
-            for (int r = part; r < nep; r += 8) acc += Z[(long long)r * a.ldZ + c0] * Z[(long long)r * a.ldZ + c1];
-        }
-        sRed[tid] = acc;
-        __syncthreads();
-        if (tid < 121) {
-            double v = 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v += sRed[121 * q + tid];
-            a.red[(long long)b * 256 + 8 + tid] = v;
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (through gpurun): collects the round's measurement evidence into gpurun_out/evidence/.
 # Usage: scripts/collect_evidence.sh <round tag, e.g. r01>
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/evidence
 mkdir -p "$OUT"
@@ -12,7 +12,7 @@ PY=python
 stats() {  # stats <name> <bench args...>: rocprofv3 kernel-trace summary of one bench invocation
   local name=$1; shift
   rm -rf /tmp/prof_$name
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o b -- $PY $ROOT/bench.py "$@" --no-cpu-baseline --no-traffic --no-roofline --no-batch64 --no-parity > /dev/null 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o b -- $PY $ROOT/bench.py "$@" --no-cpu-baseline --no-traffic --no-roofline --no-batch64 --no-parity --no-steady-state --no-tiled > /dev/null 2>&1
   f=$(find /tmp/prof_$name -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/${TAG}_${name}_kernel_stats.csv"
 }
@@ -44,26 +44,40 @@ pmc bench_N200 WRITE_SIZE --steps 220 --warmup 110
 pmc bench_N200 SQ_VALU_MFMA_BUSY_CYCLES --steps 220 --warmup 110
 pmc bench_N200 GRBM_GUI_ACTIVE --steps 220 --warmup 110
 # 1b. the same workload with the per-column launches instead of the resident update kernel, and with one launch per IMU call
-EQF_CHOL_RESIDENT=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-batch64 --no-parity > "$OUT/${TAG}_bench_N200_launches.json" 2>/dev/null
+EQF_CHOL_RESIDENT=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-batch64 --no-parity --no-tiled --no-steady-state > "$OUT/${TAG}_bench_N200_launches.json" 2>/dev/null
+EQF_RES_STAGED=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-batch64 --no-parity --no-traffic --no-tiled --no-steady-state > "$OUT/${TAG}_bench_N200_unstaged.json" 2>/dev/null
 EQF_CHOL_RESIDENT=0 stats bench_N200_launches
-EQF_IMU_BURST=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-traffic --no-batch64 --no-parity > "$OUT/${TAG}_bench_N200_noburst.json" 2>/dev/null
+EQF_IMU_BURST=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-steady-state > "$OUT/${TAG}_bench_N200_noburst.json" 2>/dev/null
 # 2. a batch of 64 filters on one GPU (cfg 4's filters, all on one device)
-timeout 900 $PY $ROOT/bench.py --filters-per-gpu 64 --steps 440 --warmup 110 --no-cpu-baseline --no-traffic --no-batch64 --no-parity > "$OUT/${TAG}_bench_batch64.json" 2>/dev/null
+timeout 900 $PY $ROOT/bench.py --filters-per-gpu 64 --steps 440 --warmup 110 --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-steady-state > "$OUT/${TAG}_bench_batch64.json" 2>/dev/null
 stats bench_N200_batch64 --filters-per-gpu 64 --steps 220 --warmup 110
-timeout 900 $PY $ROOT/bench.py --filters-per-gpu 8 --steps 880 --warmup 110 --no-cpu-baseline --no-traffic --no-batch64 --no-parity > "$OUT/${TAG}_bench_batch8.json" 2>/dev/null
+timeout 900 $PY $ROOT/bench.py --filters-per-gpu 8 --steps 880 --warmup 110 --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-steady-state > "$OUT/${TAG}_bench_batch8.json" 2>/dev/null
 # 3. N = 1000: structured kernel and the dense MFMA Riccati backend (cfg 3)
-timeout 900 $PY $ROOT/bench.py --landmarks 1000 --steps 220 --warmup 55 --no-cpu-baseline --no-traffic --no-batch64 --no-parity > "$OUT/${TAG}_bench_N1000.json" 2>/dev/null
-timeout 900 $PY $ROOT/bench.py --landmarks 1000 --steps 110 --warmup 22 --dense-propagate --no-cpu-baseline --no-traffic --no-batch64 --no-parity > "$OUT/${TAG}_bench_N1000_dense.json" 2>/dev/null
+timeout 900 $PY $ROOT/bench.py --landmarks 1000 --steps 220 --warmup 55 --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-steady-state > "$OUT/${TAG}_bench_N1000.json" 2>/dev/null
+timeout 900 $PY $ROOT/bench.py --landmarks 1000 --steps 110 --warmup 22 --dense-propagate --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-steady-state > "$OUT/${TAG}_bench_N1000_dense.json" 2>/dev/null
 # 3b. MFMA busy cycles next to the GPU-active cycles for the N = 1000 runs (structured path and dense Riccati), separate passes
 pmc bench_N1000 SQ_VALU_MFMA_BUSY_CYCLES --landmarks 1000 --steps 44 --warmup 11
 pmc bench_N1000 GRBM_GUI_ACTIVE --landmarks 1000 --steps 44 --warmup 11
 pmc bench_N1000_dense SQ_VALU_MFMA_BUSY_CYCLES --landmarks 1000 --steps 22 --warmup 11 --dense-propagate
 pmc bench_N1000_dense GRBM_GUI_ACTIVE --landmarks 1000 --steps 22 --warmup 11 --dense-propagate
 # 4. N = 4000 (Sigma = 1.15 GB)
-timeout 900 $PY $ROOT/bench.py --landmarks 4000 --steps 22 --warmup 11 --no-cpu-baseline --no-traffic --no-batch64 --no-parity > "$OUT/${TAG}_bench_N4000.json" 2>/dev/null
-# 4b. the same two sizes on the older 32-wide factorisation path, where the covariance downdate is a launch of its own
-EQF_CHOL_MODE=32inv timeout 900 $PY $ROOT/bench.py --landmarks 1000 --steps 220 --warmup 55 --no-cpu-baseline --no-traffic --no-batch64 --no-parity > "$OUT/${TAG}_bench_N1000_chol32.json" 2>/dev/null
-EQF_CHOL_MODE=32inv timeout 900 $PY $ROOT/bench.py --landmarks 4000 --steps 22 --warmup 11 --no-cpu-baseline --no-traffic --no-batch64 --no-parity > "$OUT/${TAG}_bench_N4000_chol32.json" 2>/dev/null
+timeout 900 $PY $ROOT/bench.py --landmarks 4000 --steps 22 --warmup 11 --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-steady-state > "$OUT/${TAG}_bench_N4000.json" 2>/dev/null
+# 4b. MFMA busy next to GPU-active cycles for the 64-filter batch and for N = 4000 (separate passes)
+pmc bench_batch64 SQ_VALU_MFMA_BUSY_CYCLES --filters-per-gpu 64 --steps 44 --warmup 22
+pmc bench_batch64 GRBM_GUI_ACTIVE --filters-per-gpu 64 --steps 44 --warmup 22
+pmc bench_N4000 SQ_VALU_MFMA_BUSY_CYCLES --landmarks 4000 --steps 22 --warmup 11
+pmc bench_N4000 GRBM_GUI_ACTIVE --landmarks 4000 --steps 22 --warmup 11
+# 4c. BASELINE configs[4] on one GPU: the 2-D partitioned filter (1 x 1 grid) at N = 4000 next to the monolithic path; kernel summary,
+# timeline of one update, the fp64 GEMM on its own
+timeout 900 $PY $ROOT/scripts/tiled_bench.py 4000 250 3 > "$OUT/${TAG}_bench_tiled_N4000.json" 2>/dev/null
+rm -rf /tmp/prof_tiled
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_tiled -o b -- $PY $ROOT/scripts/tiled_bench.py 4000 250 1 > /dev/null 2>&1
+f=$(find /tmp/prof_tiled -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$OUT/${TAG}_tiled_N4000_kernel_stats.csv"
+f=$(find /tmp/prof_tiled -name '*kernel_trace.csv' | head -1); [ -n "$f" ] && $PY $ROOT/scripts/tiled_timeline.py "$f" 400 > "$OUT/${TAG}_tiled_N4000_timeline.txt"
+timeout 300 $PY $ROOT/scripts/gemm_bench.py > "$OUT/${TAG}_gemm_tn.txt" 2>/dev/null
+# 4d. per-launch timeline of a frame at 8 and 64 filters per GPU
+timeout 900 bash $ROOT/scripts/launch_timeline.sh 8 > "$OUT/${TAG}_timeline_batch8.txt" 2>/dev/null
+timeout 900 bash $ROOT/scripts/launch_timeline.sh 64 > "$OUT/${TAG}_timeline_batch64.txt" 2>/dev/null
 # 5. long-run parity against the C++ oracle
 ( echo "# scripts/dev_compare.py 200 10.0 on MI355X: HIP path (fp64, per-call C ABI) vs oracle/eqf_oracle.cpp, same synthetic stream"
   echo "# (2000 IMU + 200 vision events, N = 200, template settings); relS = |Sigma_gpu - Sigma_ref|_F / |Sigma_ref|_F after the event"

@@ -512,15 +512,13 @@ def test_split_path_in_fp32_mode_and_under_the_dense_backend(hip, monkeypatch):
     assert all(np.abs(c[1][k] - e[1][k]).max() < 1e-9 for k in c[1])
 
 
-@pytest.mark.parametrize("mode,embed,split,tail", [("32", "1", "0", "1"), ("32inv", "1", "0", "1"), ("64", "0", "0", "1"), ("64", "1", "1", "1"),
-                                                   ("64", "0", "1", "1"), ("64", "1", "1", "0"), ("64", "0", "1", "0")])
-def test_alternative_factorisation_kernels_agree(hip, monkeypatch, mode, embed, split, tail):
-    """The update has three interchangeable factorisation paths: k_chol_step64 (default; reductions, downdate and
-    innovation lift riding along in the chain launches), the same with downdate / lift as a launch of their own, the split
-    chain (panel + update launches, the throughput variant), and the older 32-wide kernels (forward substitution or
-    explicit block inverses).  The split chain itself comes as one launch per block column (update launches that also solve
-    the next column after an in-launch hand-off of the diagonal factor, EQF_CHOL_TAIL=1, default) or as panel + update
-    launches (EQF_CHOL_TAIL=0).  They must agree to rounding."""
+@pytest.mark.parametrize("embed,split,tail", [("0", "0", "1"), ("1", "1", "1"), ("0", "1", "1"), ("1", "1", "0"), ("0", "1", "0")])
+def test_alternative_factorisation_kernels_agree(hip, monkeypatch, embed, split, tail):
+    """The update's factorisation comes in interchangeable launch shapes of the same mathematics: the fused k_chol_step64 launches
+    (reductions, downdate and innovation lift riding along in the chain launches), the same with downdate / lift as a launch of their
+    own, and the split chain (the throughput variant) -- itself as one launch per block column (update launches that also solve the next
+    column after an in-launch hand-off of the diagonal factor, EQF_CHOL_TAIL=1, default) or as panel + update launches (EQF_CHOL_TAIL=0).
+    They must agree to rounding.  (The 32-wide kernel family of round 1 was removed in round 3.)"""
     from eqf_vio_amd import synth
 
     N = 70  # S-chain 3 and E-chain 4 block columns of 64; 5 and 7 of 32
@@ -528,8 +526,7 @@ def test_alternative_factorisation_kernels_agree(hip, monkeypatch, mode, embed, 
     st = synth.make_stream(N, duration=0.5)
     d = synth.template_settings_dict()
     out = []
-    for m, e, sp in (("64", "1", "0"), (mode, embed, split)):
-        monkeypatch.setenv("EQF_CHOL_MODE", m)
+    for e, sp in (("1", "0"), (embed, split)):
         monkeypatch.setenv("EQF_CHOL_EMBED", e)
         monkeypatch.setenv("EQF_CHOL_SPLIT", sp)
         f = hip.FilterBatch(d, capacity=N, batch=1)
@@ -544,17 +541,17 @@ def test_alternative_factorisation_kernels_agree(hip, monkeypatch, mode, embed, 
     assert np.abs(out[0][3]["gamma"] - out[1][3]["gamma"]).max() < 1e-9
 
 
-def test_large_filter_split_chain_agrees_with_the_32_wide_kernels(hip, monkeypatch):
-    """N = 600 (19 / 29 block columns of 64): the default picks the split chain (panel + update launches); cross-check
-    against the independent 32-wide kernels with explicit block inverses, and against the fused 64-wide launches."""
+def test_large_filter_split_chain_agrees_with_the_fused_launches(hip, monkeypatch):
+    """N = 600 (19 / 29 block columns of 64): the default picks the split chain (one launch per block column, in-launch hand-off);
+    cross-check against panel + update launches and against the fused launches (every tile solves its own panel blocks)."""
     from eqf_vio_amd import synth
 
     N = 600
     st = synth.make_stream(N, duration=0.12)
     d = synth.template_settings_dict()
     out = []
-    for m, sp in (("64", None), ("32inv", None), ("64", "0")):
-        monkeypatch.setenv("EQF_CHOL_MODE", m)
+    for sp, tail in ((None, "1"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("EQF_CHOL_TAIL", tail)
         if sp is None:
             monkeypatch.delenv("EQF_CHOL_SPLIT", raising=False)
         else:
@@ -813,11 +810,9 @@ def test_cpp_facade_auxiliary_start_matches_the_oracle():
     assert abs(fro - np.linalg.norm(fo.stateCovariance())) < 1e-5 * fro
 
 
-def _run_bursts(hip, st, N, burst, peek=False, per_call=False, precision=0, ring=None, monkeypatch=None):
+def _run_bursts(hip, st, N, burst, peek=False, per_call=False, precision=0):
     from eqf_vio_amd import synth
 
-    if ring is not None:
-        monkeypatch.setenv("EQF_BURST_RING", ring)
     f = hip.FilterBatch(synth.template_settings_dict(), capacity=N, batch=1, precision=precision)
     f.set_imu_burst(burst)
     if not per_call:
@@ -845,25 +840,17 @@ def test_imu_bursts_equal_single_step_launches(hip, N, monkeypatch):
     st = synth.make_stream(N, duration=0.5)
     ref = _run_bursts(hip, st, N, 0)           # every call at once, single-step kernels
     full = _run_bursts(hip, st, N, 15)         # a frame's IMU calls + the vision call's integrateUpToTime as one burst
-    for burst, peek, per_call, ring in ((1, False, False, None), (4, False, False, None), (15, True, False, None), (15, False, True, None),
-                                        (7, True, True, None), (15, False, False, "0")):
-        o = _run_bursts(hip, st, N, burst, peek=peek, per_call=per_call, ring=ring, monkeypatch=monkeypatch)
-        if ring is None:
-            assert np.array_equal(o[0], full[0]), (burst, peek, per_call)
-            assert all(np.array_equal(o[1][k], full[1][k]) for k in full[1])
-            assert np.array_equal(o[2], full[2])
-        else:  # the other block kernel: the same formulas in another order
-            assert rel_fro(o[0], full[0]) < 1e-9
-    # the block kernel with 2 and 4 row landmarks per wavefront (large problems; EQF_BURST_ROWS forces it here)
-    for rows, ring in (("2", None), ("4", None), ("4", "0")):
-        monkeypatch.setenv("EQF_BURST_ROWS", rows)
-        o = _run_bursts(hip, st, N, 15, ring=ring, monkeypatch=monkeypatch)
-        monkeypatch.delenv("EQF_BURST_RING", raising=False)
-        if rows == "4" and ring is None:
-            # the ring kernel with four rows per wavefront: the arithmetic of the one-row ring kernel, block by block
-            assert np.array_equal(o[0], full[0])
-        assert rel_fro(o[0], full[0]) < 1e-9, rows
-        assert all(np.abs(o[1][k] - full[1][k]).max() < 1e-9 for k in full[1])
+    for burst, peek, per_call in ((1, False, False), (4, False, False), (15, True, False), (15, False, True), (7, True, True)):
+        o = _run_bursts(hip, st, N, burst, peek=peek, per_call=per_call)
+        assert np.array_equal(o[0], full[0]), (burst, peek, per_call)
+        assert all(np.array_equal(o[1][k], full[1][k]) for k in full[1])
+        assert np.array_equal(o[2], full[2])
+    # the block kernel with four row landmarks per wavefront (large problems; EQF_BURST_ROWS forces it here): the arithmetic of the
+    # one-row kernel, block by block
+    monkeypatch.setenv("EQF_BURST_ROWS", "4")
+    o = _run_bursts(hip, st, N, 15)
+    assert np.array_equal(o[0], full[0])
+    assert all(np.abs(o[1][k] - full[1][k]).max() < 1e-9 for k in full[1])
     monkeypatch.delenv("EQF_BURST_ROWS")
     # the builder's two role tables (4 / 16 landmarks per workgroup; chosen by launch size): the same formulas
     outs = []
