@@ -588,7 +588,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     // Factorisation kernels: k_chol_step64 / k_chol_resident (64-wide block columns, register-chained MFMA panel solves).  (The 32-wide
     // family of round 1 -- k_chol_step<INVERSE>, k_update_reduce, a separate prep launch -- was dominated at every size measured and has
     // been removed in round 3; the cross-checks of a factorisation are now the other launch shapes of the same mathematics -- resident
-    // vs per-column launches bitwise, fused vs split chain to rounding -- and the oracle.)
+    // vs per-column launches bitwise, fused vs split chain to rounding -- and the fp64 oracle of the tests.)
     const int nb64S = roundUp(sDim(Nmax), kSB) / kSB, nb64E = roundUp(eDim(Nmax), kSB) / kSB;
     const int wt64 = roundUp(yCols(Nmax), kSB) / kSB;
     const int nblk64 = nb64S * nb64S + wt64 * nb64S + nb64E * nb64E + nb64E;
