@@ -1120,7 +1120,7 @@ extern "C" int eqf_debug_chol_wg(long long* t, int* info) {
 #endif
 #ifdef EQF_RES_STAMPS
 extern "C" int eqf_debug_res_stamps(long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_resStamps), sizeof(long long) * 2 * 16 * 12) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_resStamps), sizeof(long long) * 2 * 16 * 16) == hipSuccess ? 0 : -1;
 }
 #endif
 #ifdef EQF_PREP_STAMPS

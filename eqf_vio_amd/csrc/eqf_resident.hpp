@@ -218,8 +218,48 @@ EQF_DEV void hoWait3(const int* f0, const int* f1, const int* f2, int epoch, int
     __syncthreads();
 }
 
+// Panel solve X = A L_KK^-T of a 64 x 64 tile held in accumulators (wave wv: rows 16 wv .. +15) against a diagonal factor D[K] that ANOTHER
+// workgroup is factoring right now: its record arrives in four 16-column stages (factor64's stageFlag), and the substitution
+// X_j^T = W_jj (A_j^T - sum_{i<j} L_ji X_i^T) only needs stage j for its step j.  The first three steps run in the shadow of the producer's
+// pivot chain; what is left after its last pivot is one flag, 2 KB (W_33) and one 16 x 16 x 16 product -- not the whole 40 KB record and the
+// whole solve.  (A consumer usually gets here about a microsecond before the record is complete, so the first three stages are out: one
+// wait, one round trip for the three of them, then the last stage on its own.)  Same operations in the same order as solveStrip<true>:
+// bitwise the same block.  Result in s.P; all 256 threads; ends with a barrier.
+EQF_DEV void stagedPanelSolve(const f64x4 (&acc)[4], const Lds64& s, const double* Dk, const int* stageIn, const int* flagWhole, int epoch, int tid,
+    int* bad) {
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stTile(acc[i], &s.P[0][0], kSP, kQB * wv, kQB * i, lane);
+    __syncthreads();
+    f64x4 Z[4], X[4];
+    const int lc = lane & 15, lg = lane >> 4, x0 = kQB * wv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Z[j][q] = s.P[x0 + lc][kQB * j + lg + 4 * q];
+    const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+    hoWait3(stageIn + 2, nullptr, nullptr, epoch, tid, bad);
+    hoLoadStages012(Dk, s, tid);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        X[j] = mmRegB(zero, &s.Wd[j][0][0], kWP, 0, 0, Z[j], lane, 1.0);
+#pragma unroll
+        for (int j2 = j + 1; j2 < 4; ++j2) Z[j2] = mmRegB(Z[j2], &s.L[0][0], kSP, kQB * j2, kQB * j, X[j], lane, -1.0);
+    }
+    hoWait3(flagWhole, nullptr, nullptr, epoch, tid, bad);
+    hoLoadW3(Dk, s, tid);
+    __syncthreads();
+    X[3] = mmRegB(zero, &s.Wd[3][0][0], kWP, 0, 0, Z[3], lane, 1.0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s.P[x0 + lc][kQB * j + lg + 4 * q] = X[j][q];
+    __syncthreads();
+}
+
 #ifdef EQF_RES_STAMPS
-__device__ long long g_resStamps[2][16][12];  // [chain][R][phase] wall-clock (100 MHz) stamps of the row heads, filter 0
+__device__ long long g_resStamps[2][16][16];  // [chain][R][phase] wall-clock (100 MHz) stamps of the row heads, filter 0
 #define EQF_HSTAMP(i) do { if (tid == 0 && b == 0 && R < 16) g_resStamps[role.kind][R][i] = wall_clock64(); } while (0)
 #define EQF_WSTAMP(i) do { if (tid == 0 && b == 0 && !isS && C == nb - 1) g_resStamps[1][15][i] = wall_clock64(); } while (0)
 #else
@@ -314,6 +354,7 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
                 EQF_HSTAMP(10);
                 hoLoadBlock(A + (long long)((R - 1) * kSB) * ldA + K * kSB, ldA, s.Q, tid);
                 __syncthreads();
+                EQF_HSTAMP(13);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a1[i] = mmTile<true, kSB>(a1[i], &s.P[0][0], kSP, kQB * wv, &s.Q[0][0], kSP, kQB * i, lane, -1.0);
                 __syncthreads();
@@ -334,45 +375,9 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
             solveStrip<true>(&s.P[0][0], kSP, s, kQB * wv, lane);
             __syncthreads();
         } else {
-            // D[R-1] is being factored by the previous row head RIGHT NOW: its record arrives in four 16-column stages (factor64's
-            // stageFlag), and the panel solve X_j^T = W_jj (A_j^T - sum_{i<j} L_ji X_i^T) only needs stage j for its step j.  So the
-            // first three steps run in the shadow of the previous head's pivot chain; what is left on the critical path after its
-            // last pivot is one flag, 2 KB (W_33) and one 16 x 16 x 16 product -- not the whole 40 KB record and the whole solve.
-            // (Same operations in the same order as solveStrip<true>: bitwise the same L_{R,R-1}.)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) stTile(a1[i], &s.P[0][0], kSP, kQB * wv, kQB * i, lane);
-            __syncthreads();
-            f64x4 Z[4], X[4];
-            const int lc = lane & 15, lg = lane >> 4, x0 = kQB * wv;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) Z[j][q] = s.P[x0 + lc][kQB * j + lg + 4 * q];
-            const int* stageIn = ra.stageFlags + (((long long)b * 2 + role.kind) * nbCap + (R - 1)) * 4;
-            // (A row head reaches this point about a microsecond before the previous one publishes D[R-1] -- its own last panel is the
-            // other critical path, see above -- so the first three stages are usually all out: one wait, one round trip for the three
-            // of them, then the last stage on its own.)
-            const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
-            hoWait3(stageIn + 2, nullptr, nullptr, epoch, tid, &bad);
-            hoLoadStages012(D + (long long)(R - 1) * kDRec, s, tid);
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                X[j] = mmRegB(zero, &s.Wd[j][0][0], kWP, 0, 0, Z[j], lane, 1.0);
-#pragma unroll
-                for (int j2 = j + 1; j2 < 4; ++j2) Z[j2] = mmRegB(Z[j2], &s.L[0][0], kSP, kQB * j2, kQB * j, X[j], lane, -1.0);
-            }
-            hoWait3(flagD + (R - 1), nullptr, nullptr, epoch, tid, &bad);
-            EQF_HSTAMP(2);
-            hoLoadW3(D + (long long)(R - 1) * kDRec, s, tid);
-            __syncthreads();
-            EQF_HSTAMP(3);
-            X[3] = mmRegB(zero, &s.Wd[3][0][0], kWP, 0, 0, Z[3], lane, 1.0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) s.P[x0 + lc][kQB * j + lg + 4 * q] = X[j][q];
-            __syncthreads();
+            // D[R-1] is being factored by the previous row head RIGHT NOW: stage by stage (stagedPanelSolve, above)
+            stagedPanelSolve(a1, s, D + (long long)(R - 1) * kDRec, ra.stageFlags + (((long long)b * 2 + role.kind) * nbCap + (R - 1)) * 4,
+                flagD + (R - 1), epoch, tid, &bad);
         }
         EQF_HSTAMP(4);
         // first column of the diagonal tile, then the factorisation with the other tiles deferred to waves 2, 3; the solved
@@ -400,6 +405,7 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
             hoDrain();
             __syncthreads();
             if (tid == 0) hoPublish(readyA + R * nbCap + (R - 1), epoch);
+            EQF_HSTAMP(12);
         };
         factor64<true>(s, tid, &bad, pre, D + (long long)R * kDRec, nullptr, realStages(ch.kind == 0 ? sDim(g.N) : eDim(g.N), kSB * R), mid,
             stageOut, epoch);
@@ -427,6 +433,10 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
             for (int i = 0; i < 4; ++i) acc[i] = mmTile<true, kSB>(acc[i], &s.P[0][0], kSP, kQB * wv, &s.Q[0][0], kSP, kQB * i, lane, -1.0);
             __syncthreads();
         }
+        // (Round 3 also tried the staged consumption of stagedPanelSolve for the tile T(C+2, C), whose block is the other thing the row
+        // head H(C+2) waits for: no change, 137.8 against 138.3 us per update -- once the heads consume D stage by stage the pivot chain
+        // and its hand-off are the critical path again, 13.6 us per block column: factor64 10.3, store issue + first column 1.1, flag +
+        // W_33 0.9, last solve step 0.3, publish 0.45.)
         hoWait3(C > 0 ? flagD + C : nullptr, nullptr, nullptr, epoch, tid, &bad);
         hoLoadRecord(D + (long long)C * kDRec, s, tid);
 #pragma unroll

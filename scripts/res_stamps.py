@@ -16,9 +16,9 @@ fb.stream_upload(st.imu, st.vision_stamps, st.ids, st.bearings)
 for kind, k in st.events():
     (fb.stream_imu if kind == "imu" else fb.stream_vision)(k)
 fb.synchronize()
-out = (C.c_longlong * (2 * 16 * 12))()
+out = (C.c_longlong * (2 * 16 * 16))()
 assert binding.lib().eqf_debug_res_stamps(out) == 0
-t = np.array(out, dtype=np.int64).reshape(2, 16, 12)
+t = np.array(out, dtype=np.int64).reshape(2, 16, 16)
 names = ["tiles loaded", "panels applied", "D flag seen", "D loaded + tile in LDS", "solved", "L published", "first column in LDS", "factored", "D published"]
 for ch, nm in ((1, "E-chain"), (0, "S-chain")):
     rows = [R for R in range(1, 16) if t[ch, R, 8] > 0]
@@ -29,7 +29,8 @@ for ch, nm in ((1, "E-chain"), (0, "S-chain")):
     for R in rows:
         print(f"  H({R:2d})", " ".join(f"{(t[ch, R, i] - t0) / 100.0:7.2f}" for i in range(9)), "  | last panel wait: from",
               " ".join(f"{(t[ch, R, i] - t0) / 100.0:7.2f}" if t[ch, R, i] > 0 else "      -" for i in (9, 10)), " T(R,R-2) published",
-              f"{(t[ch, R, 11] - t0) / 100.0:7.2f}" if t[ch, R, 11] > 0 else "-")
+              f"{(t[ch, R, 11] - t0) / 100.0:7.2f}" if t[ch, R, 11] > 0 else "-", " | L_{R,R-1} published, late block loaded, stage-2 flag seen, stages 0-2 loaded:",
+              " ".join(f"{(t[ch, R, i] - t0) / 100.0:7.2f}" if t[ch, R, i] > 0 else "      -" for i in (12, 13, 14, 15)))
 
 w = t[1, 15]
 if w[5] > 0:
