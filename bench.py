@@ -565,7 +565,10 @@ def main():
 
     # ---- BASELINE configs[4]: one N = 4000 filter partitioned over the ranks of the job
     if not args.no_tiled and world in GRIDS and not args.dense_propagate and not args.pmc_child:
-        line["tiled_cfg5"] = tiled_leg(args, dist, rank, world, device)
+        try:
+            line["tiled_cfg5"] = tiled_leg(args, dist, rank, world, device)
+        except Exception as e:  # (a failure of this leg must not take the headline line with it)
+            line["tiled_cfg5"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0 and world == 1:
         rl = line.get("roofline")

@@ -105,17 +105,25 @@ class ProcessGrid:
         return t
 
     def allgather_row(self, t):
+        """every rank of my process row contributes t (same shape); returns the Pc pieces.  Done as Pc broadcasts: small, once per update,
+        and it works for device tensors on every backend (gloo has no device all_gather)."""
         if self.Pc == 1:
             return [t]
-        out = [torch.empty_like(t) for _ in range(self.Pc)]
-        self.dist.all_gather(out, t, group=self.row_group)
+        out = []
+        for c in range(self.Pc):
+            piece = t if c == self.pc else torch.empty_like(t)
+            self.dist.broadcast(piece, src=self.pr * self.Pc + c, group=self.row_group)
+            out.append(piece)
         return out
 
     def allgather_all(self, t):
         if self.world == 1:
             return [t]
-        out = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(out, t)
+        out = []
+        for r in range(self.world):
+            piece = t if r == self.rank else torch.empty_like(t)
+            self.dist.broadcast(piece, src=r)
+            out.append(piece)
         return out
 
 

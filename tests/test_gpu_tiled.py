@@ -297,3 +297,67 @@ def test_tiled_filter_N4000_against_the_single_gpu_product_path():
     assert n_upd >= 2 and be.device_error() == 0 and fg.device_error() == 0
     et, eg = tf.stateEstimate(), fg.state_estimate()
     assert np.abs(et["x"] - eg["x"]).max() <= 1e-9 and np.abs(et["q"] - eg["q"]).max() <= 1e-9 and np.abs(et["p"] - eg["p"]).max() <= 1e-8
+
+
+def _multi_rank_worker(rank, world, port, Pr, Pc, N, bl, out_dir):
+    """One of `world` processes that SHARE the one GPU: HipBackend on cuda:0, the grid's broadcasts over gloo (device tensors)."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch
+    import torch.distributed as dist
+
+    from eqf_vio_amd import synth, tiled
+    from oracle import binding as ob
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = synth.template_settings_dict()
+    be = tiled.HipBackend(d, capacity=N, device_index=0, reserve_cus=0)  # (no CU reservation: eight processes share the chip)
+    tf = tiled.TiledFilter(tiled.ProcessGrid(dist, Pr, Pc, device=be.device), be, bl)
+    fo = ob.OracleFilter(d)
+    st = synth.make_stream(N, duration=0.21)
+    rel = lambda A, B: float(np.linalg.norm(A - B) / np.linalg.norm(B))
+    worst, n_upd = dict(S=0.0, pose=0.0, gamma=0.0), 0
+    for kind, k in st.events():
+        if kind == "imu":
+            r = st.imu[k]
+            fo.processIMUData(r[0], r[1:4], r[4:7])
+            tf.processIMUData(r[0], r[1:4], r[4:7])
+        else:
+            fo.processVisionData(st.vision_stamps[k], st.ids, st.bearings[k])
+            assert tf.processVisionData(st.vision_stamps[k], st.ids, st.bearings[k]) == 0
+            n_upd += 1
+            worst["S"] = max(worst["S"], rel(tf.stateCovariance(), fo.stateCovariance()))
+            eo, et = fo.stateEstimate(), tf.stateEstimate()
+            worst["pose"] = max(worst["pose"], float(np.abs(eo["x"] - et["x"]).max()), float(np.abs(eo["q"] - et["q"]).max()),
+                                float(np.abs(eo["p"] - et["p"]).max()), float(np.abs(fo.bias() - be.bias()).max()))
+            lo, lt = fo.last_update(), be.last_update()
+            worst["gamma"] = max(worst["gamma"], float(np.abs(lo["gamma"] - lt["gamma"]).max() / max(1.0, np.abs(lo["gamma"]).max())))
+    np.save(os.path.join(out_dir, f"w_{rank}.npy"), np.array([worst["S"], worst["pose"], worst["gamma"], n_upd, be.device_error()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("Pr,Pc,N,bl", [(1, 2, 50, 8), (2, 2, 70, 8), (2, 4, 100, 8)])
+def test_tiled_filter_multi_rank_grids_with_the_hip_kernels(tmp_path, Pr, Pc, N, bl):
+    """The multi-rank schedule WITH the HIP backend (block-cyclic local matrices with Pr, Pc > 1, the block-upper mask of the trailing
+    products, the interleaved row operand of non-square grids): Pr x Pc processes share the one MI355X, the grid's broadcasts go over
+    gloo on device tensors.  Closed loop against the dense oracle on every rank.  (What this cannot show is RCCL over xGMI itself.)"""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = Pr * Pc
+    mp.spawn(_multi_rank_worker, args=(world, port, Pr, Pc, N, bl, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        S, pose, gamma, n_upd, err = np.load(tmp_path / f"w_{r}.npy")
+        assert n_upd >= 4 and err == 0
+        assert S < 1e-9 and pose < 1e-8 and gamma < 1e-8, (r, S, pose, gamma)
