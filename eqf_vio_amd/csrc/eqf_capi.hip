@@ -143,6 +143,7 @@ struct eqf_filter {
     int updateEpoch = 0;           // one per launchUpdate
     // k_chol_resident (one launch per update while the grid fits the chip): EQF_CHOL_RESIDENT = 0 switches it off
     int cholResident = 1;
+    int resOversub = 7;            // EQF_RES_OVERSUB: roles per CU up to which a batch uses the resident kernel (interleaved grid, no-wait downdate)
     int resStaged = 1;             // row heads consume D[R-1] stage by stage (EQF_RES_STAGED = 0: whole record after its last pivot)
     int residentPerCU = -1;        // hipOccupancyMaxActiveBlocksPerMultiprocessor of k_chol_resident on this device (lazily queried)
     int eFromSigma = 1;            // split chain: block column 0 of the E-chain read straight from Sigma (EQF_E_FROM_SIGMA=0: copied by prep)
@@ -657,7 +658,13 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             f->residentPerCU = std::max(nblk, 0);
         }
         residentFits = (long long)f->rolesCount * B <= (long long)f->residentPerCU * f->numCUs;
-        resident = f->cholResident >= 2 || residentFits;
+        // Beyond co-residency the grid is interleaved (filter index fastest: all filters advance together, group by group) and nothing
+        // waits for later workgroups.  Its workgroups mostly wait for hand-offs, so the chip carries several per CU without slowing the
+        // chains down; the downdate tiles are workgroups of their own at the end of the grid.  Measured (round 3, N = 200, steps/s,
+        // per-column launches -> this): 2 filters 85.5 k -> 102.7 k, 4: 124.9 k -> 182.9 k, 6: 146.5 k -> 196.5 k, 8: 217.6 k -> 247.4 k,
+        // 12: 241.8 k -> 259.6 k; from 16 filters on the per-column launches win (300.0 k against 283.2 k).  EQF_RES_OVERSUB = the
+        // number of roles per CU up to which the resident kernel is used (default 7: up to 12 filters of N = 200; 0 = only when co-resident).
+        resident = f->cholResident >= 2 || residentFits || (long long)f->rolesCount * B <= (long long)f->resOversub * f->numCUs;
     }
     a.eFromSigma = (!resident && splitChain && f->cholTail && f->eFromSigma && f->precision != EQF_PRECISION_F32) ? 1 : 0;
     rc = profiled(f, EQF_PROF_UPDATE_PREP, [&] {
@@ -697,20 +704,16 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             ra.stageFlags = f->resStaged ? f->dStageFlags : nullptr;
             // 64 x 64 downdate tiles: a tile costs the same 14 dependent chunk fetches whatever its size, and there are enough
             // finished workgroups to take one each
-            // (a grid forced beyond what is co-resident -- EQF_CHOL_RESIDENT=2 -- must not wait for later workgroups while holding
-            // CUs: its downdate is the follow-up launch below)
-            ra.ddNt = residentFits ? nt64 : 0; ra.ddSmall = 0;
+            // (a grid larger than what is co-resident must not wait for later workgroups while holding CUs: no-wait mode, see the kernel)
+            ra.ddNt = nt64; ra.ddSmall = 0;
+            ra.ddWait = residentFits ? 1 : 2;
+            ra.nRoles = f->rolesCount;
             ra.errflag = f->errflag;
+            const int ddGrid = residentFits ? 0 : nt64 * (nt64 + 1) / 2;  // downdate tiles as workgroups of their own behind the roles
             rc = profiled(f, EQF_PROF_CHOL_RESIDENT, [&] {
-                hipLaunchKernelGGL(k_chol_resident<T>, dim3(f->rolesCount, B), dim3(256), sizeof(Step64Lds), f->stream, ra);
+                hipLaunchKernelGGL(k_chol_resident<T>, dim3(B, f->rolesCount + ddGrid), dim3(256), sizeof(Step64Lds), f->stream, ra);
             });
             if (rc) return rc;
-            if (!residentFits) {
-                rc = profiled(f, EQF_PROF_DOWNDATE, [&] {
-                    hipLaunchKernelGGL((k_downdate<T, 64>), dim3(nt64 * (nt64 + 1) / 2, B), dim3(256), (downdateLdsBytes<T, 64>()), f->stream, a, nt64, 0);
-                });
-                if (rc) return rc;
-            }
         } else if (splitChain && f->cholTail) {
             // one launch per block column: the panel launch of column 0, then update launches that also solve column k+1
             // (k_chol_step64<T, 3>); the S-chain's right-hand sides are complete after launch nb64S - 2, the downdate joins
@@ -1255,6 +1258,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (const char* e = std::getenv("EQF_CHOL_TAIL")) f->cholTail = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_RESIDENT")) f->cholResident = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_STAGED")) f->resStaged = std::atoi(e);
+    if (const char* e = std::getenv("EQF_RES_OVERSUB")) f->resOversub = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("EQF_E_FROM_SIGMA")) f->eFromSigma = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_ORDER")) f->cholOrder = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_STREAMS")) f->cholStreams = std::max(0, std::atoi(e));
@@ -1264,9 +1268,11 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
         if (!rc) f->numCUs = prop.multiProcessorCount;
         f->nbCap = std::max(mpC, nepC) / kSB;
         f->wtCap = ycC / kSB;
-        // the resident kernel only ever runs on grids that fit the chip: its buffers are only allocated for such handles
+        // the resident kernel is for small filters (its role table holds one workgroup per 64 x 64 tile): its buffers are only allocated
+        // while a filter has at most a few hundred roles (N <= ~330); the batch may be larger than the chip (interleaved grid, see
+        // launchUpdateT)
         const long long maxRoles = (long long)(f->nbCap + 1) * f->nbCap + (long long)f->wtCap * f->nbCap;
-        if (!rc && maxRoles * B <= 4LL * std::max(f->numCUs, 1)) {
+        if (!rc && maxRoles <= 4LL * std::max(f->numCUs, 1) && maxRoles * B <= 64LL * std::max(f->numCUs, 1)) {
             chk(dmalloc(&f->dReadyA, (size_t)2 * f->nbCap * f->nbCap * B));
             chk(dmalloc(&f->dReadyY, (size_t)2 * f->nbCap * f->wtCap * B));
             chk(dmalloc(&f->dResCounters, (size_t)4 * B));

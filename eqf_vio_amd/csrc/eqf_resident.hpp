@@ -52,6 +52,9 @@ struct ResArgs {
     int nbCap, wtCap;
     int ddNt, ddSmall;
     int* errflag;
+    int ddWait;            // 1: workgroups that are done WAIT for the last Y tile, then share the downdate (whole grid co-resident);
+                           // 2: the downdate tiles are workgroups of their own, appended to the grid behind the nRoles role workgroups
+    int nRoles;
     int* stageFlags;       // [B][2][nbCap][4]  stage j of D[K] of chain c is in the record (epoch valued; factor64's stageFlag)
 };
 
@@ -269,8 +272,36 @@ __device__ long long g_resStamps[2][16][16];  // [chain][R][phase] wall-clock (1
 template <typename T>
 __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smemR[];
-    const ResRole role = ra.roles[blockIdx.x];
-    const int b = blockIdx.y;
+    // grid = (batch, roles): the filter index runs FASTEST in dispatch order, so that a grid larger than the chip advances all filters
+    // together, dependency group by dependency group (role-major order would run the filters one after the other), and with a batch
+    // that is a multiple of 8 every workgroup of filter b runs on XCD b mod 8
+    if ((int)blockIdx.y >= ra.nRoles) {
+        // ---- ddWait = 2: a downdate tile of filter blockIdx.x.  These workgroups have the HIGHEST block indices: they are dispatched when
+        // the role workgroups in front of them have been, i.e. during the last block columns of the E-chain, and they wait -- for LOWER
+        // block indices only -- until the S-chain's last Y tile is out (it usually is).  The downdate overlaps the tail of the longer chain.
+        const int bb = blockIdx.x, tile = (int)blockIdx.y - ra.nRoles, t = threadIdx.x;
+        const Glob& gg = ra.a.g[bb];
+        int late = 0;
+        if (t == 0 && gg.updateOk && gg.N != 0) {
+            int nS, wS;
+            chainDims64(ra.c0, gg.N, &nS, &wS);
+            const int* cnt = ra.counters + (long long)bb * 4;
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nS * wS) {
+                __builtin_amdgcn_s_sleep(32);
+                if (wall_clock64() - t0 > 5000000LL) {
+                    if (ra.errflag) atomicOr(ra.errflag, 8);
+                    late = 1;
+                    break;
+                }
+            }
+        }
+        if (__syncthreads_or(late)) return;  // (Sigma_out is left untouched: the sticky flag makes the host fail the update)
+        downdateTile<T, 64>(ra.a, ra.ddNt, bb, tile, reinterpret_cast<T*>(smemR));
+        return;
+    }
+    const ResRole role = ra.roles[blockIdx.y];
+    const int b = blockIdx.x;
     const ChainArgs& ch = role.kind ? ra.c1 : ra.c0;
     const UpdArgs& a = ra.a;
     const Glob& g = ch.g[b];
@@ -562,14 +593,16 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
     // downdate tiles, so Sigma_out is not overwritten with a plausible-looking wrong matrix.
     if (__syncthreads_or(bad == 8)) return;
 
-    // ---- covariance downdate Sigma - Y^T Y: every workgroup that is done with its role takes tiles from a counter once every Y
-    // tile of this filter is out (a tile is latency-bound -- 14 dependent chunk fetches -- so it wants many workgroups, one
-    // tile each; workgroups that finish later find the counter exhausted and leave).
-    // This is the ONE wait of the kernel for workgroups with a HIGHER block index, made while holding a CU: it is only compiled into
-    // launches whose whole grid is co-resident by the occupancy calculation (ra.ddNt > 0 <=> the host checked; otherwise the downdate
-    // is a follow-up launch).  If the chip is shared with other work the late workgroups arrive as soon as that work retires; a wait
-    // that still times out skips the downdate (Sigma_out is left untouched) and raises the sticky flag.
-    if (ra.ddNt > 0 && (active || role.kind == 0)) {
+    // ---- covariance downdate Sigma - Y^T Y.
+    // ddWait = 1 (the whole grid is co-resident by the occupancy calculation -- one small filter): every workgroup that is done with its
+    //   role WAITS until all Y tiles of its filter are out, then they share the tiles from a counter -- a tile is latency-bound (14
+    //   dependent chunk fetches), so it wants many workgroups, one tile each.  This is the one wait of the kernel for workgroups with a
+    //   HIGHER block index, made while holding a CU: only safe with full co-residency.
+    // ddWait = 2 (a batch larger than the chip): the tiles are workgroups of their own at the END of the grid (above).  (Tried: finished
+    //   role workgroups take tiles only if the last Y tile is already out and leave otherwise -- no waiting at all: 2 filters 294 us
+    //   against 135 + 41 us with a follow-up launch; too few workgroups finish after the S-chain.)
+    // A wait that times out raises the sticky flag and skips the downdate (Sigma_out is left untouched).
+    if (ra.ddWait == 1 && ra.ddNt > 0 && (active || role.kind == 0)) {
         __shared__ int sTile;
         int late = 0;
         if (tid == 0 && active) {

@@ -373,6 +373,7 @@ class TiledFilter:
         self.geo = None
         self.Sll = self.M = self.E = None
         self.ids = None
+        self.lookahead = True  # factor the next diagonal block on a second stream in the shadow of the trailing update (_chain)
         self.phase_ms = None  # set to a dict to collect GPU time per phase (bench.py): {"propagate": ms, "prep": ms, "chain_S": ...}
         self._pending = []
 
@@ -612,7 +613,7 @@ class TiledFilter:
             il0 = BlockCyclic.blocks_upto(k, g.pr, g.Pr)
             if il0 * bsF < X.shape[0]:
                 Ua = self._rows_operand(contributions, unit, lambda c, wc: (0, 1), bk, self._aopA, all_blocks=False, k=k)
-                if k + 1 < geo.nb and g.pr == (k + 1) % g.Pr and g.pc == (k + 1) % g.Pc:
+                if self.lookahead and k + 1 < geo.nb and g.pr == (k + 1) % g.Pr and g.pc == (k + 1) % g.Pc:
                     # look-ahead: block (k+1, k+1) is the first trailing block of my rows and of my columns
                     b1 = unit * geo.block_size(k + 1)
                     nrec1 = ((b1 + 63) // 64) * HipBackend.DREC
