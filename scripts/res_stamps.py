@@ -10,8 +10,9 @@ import numpy as np
 from eqf_vio_amd import binding, synth
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # filters in the handle (stamps are those of filter 0)
 st = synth.make_stream(N, duration=0.3)
-fb = binding.FilterBatch(synth.template_settings_dict(), capacity=N, batch=1)
+fb = binding.FilterBatch(synth.template_settings_dict(), capacity=N, batch=B)
 fb.stream_upload(st.imu, st.vision_stamps, st.ids, st.bearings)
 for kind, k in st.events():
     (fb.stream_imu if kind == "imu" else fb.stream_vision)(k)
