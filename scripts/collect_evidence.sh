@@ -52,6 +52,14 @@ EQF_IMU_BURST=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-traffic --
 timeout 900 $PY $ROOT/bench.py --filters-per-gpu 64 --steps 440 --warmup 110 --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-steady-state > "$OUT/${TAG}_bench_batch64.json" 2>/dev/null
 stats bench_N200_batch64 --filters-per-gpu 64 --steps 220 --warmup 110
 timeout 900 $PY $ROOT/bench.py --filters-per-gpu 8 --steps 880 --warmup 110 --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-steady-state > "$OUT/${TAG}_bench_batch8.json" 2>/dev/null
+# 2b. small batches: the resident update kernel on an interleaved grid larger than the chip (default) against the per-column launches
+( echo "# bench.py --filters-per-gpu B --steps 440 --warmup 110 (N = 200): steps/s, update kernels (avg us per launch)"
+  for B in 2 4 6 8 12 16; do for O in default 0; do
+    if [ $O = default ]; then envs=""; else envs="EQF_RES_OVERSUB=0"; fi
+    env $envs timeout 600 $PY $ROOT/bench.py --filters-per-gpu $B --steps 440 --warmup 110 --no-batch64 --no-cpu-baseline --no-traffic --no-parity --no-tiled --no-steady-state 2>/dev/null | $PY -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('B=$B EQF_RES_OVERSUB=$O', round(d['value']), 'steps/s  err', d['device_error_flag'], [(k['kernel'], k['avg_us']) for k in d['kernels'][:4]])"
+  done; done ) > "$OUT/${TAG}_batch_sweep.txt" 2>&1
 # 3. N = 1000: structured kernel and the dense MFMA Riccati backend (cfg 3)
 timeout 900 $PY $ROOT/bench.py --landmarks 1000 --steps 220 --warmup 55 --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-steady-state > "$OUT/${TAG}_bench_N1000.json" 2>/dev/null
 timeout 900 $PY $ROOT/bench.py --landmarks 1000 --steps 110 --warmup 22 --dense-propagate --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-steady-state > "$OUT/${TAG}_bench_N1000_dense.json" 2>/dev/null
