@@ -143,7 +143,7 @@ struct eqf_filter {
     int updateEpoch = 0;           // one per launchUpdate
     // k_chol_resident (one launch per update while the grid fits the chip): EQF_CHOL_RESIDENT = 0 switches it off
     int cholResident = 1;
-    int resOversub = 7;            // EQF_RES_OVERSUB: roles per CU up to which a batch uses the resident kernel (interleaved grid, no-wait downdate)
+    int resOversub = 10;           // EQF_RES_OVERSUB: roles per CU up to which a batch uses the resident kernel (interleaved grid, downdate tiles as workgroups of their own)
     int resStaged = 1;             // row heads consume D[R-1] stage by stage (EQF_RES_STAGED = 0: whole record after its last pivot)
     int residentPerCU = -1;        // hipOccupancyMaxActiveBlocksPerMultiprocessor of k_chol_resident on this device (lazily queried)
     int eFromSigma = 1;            // split chain: block column 0 of the E-chain read straight from Sigma (EQF_E_FROM_SIGMA=0: copied by prep)
@@ -661,9 +661,10 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         // Beyond co-residency the grid is interleaved (filter index fastest: all filters advance together, group by group) and nothing
         // waits for later workgroups.  Its workgroups mostly wait for hand-offs, so the chip carries several per CU without slowing the
         // chains down; the downdate tiles are workgroups of their own at the end of the grid.  Measured (round 3, N = 200, steps/s,
-        // per-column launches -> this): 2 filters 85.5 k -> 102.7 k, 4: 124.9 k -> 182.9 k, 6: 146.5 k -> 196.5 k, 8: 217.6 k -> 247.4 k,
-        // 12: 241.8 k -> 259.6 k; from 16 filters on the per-column launches win (300.0 k against 283.2 k).  EQF_RES_OVERSUB = the
-        // number of roles per CU up to which the resident kernel is used (default 7: up to 12 filters of N = 200; 0 = only when co-resident).
+        // per-column launches -> this, with the pipelined panel loops of the interior / right-hand-side tiles): 2 filters 85.5 k -> 102.7 k,
+        // 4: 124.9 k -> 184 k, 8: 217.6 k -> 259.3 k, 12: 241.8 k -> 281.7 k, 16: 299.7 k -> 305.0 k; from 24 filters on the per-column
+        // launches win (331.3 k against 311.5 k).  EQF_RES_OVERSUB = the
+        // number of roles per CU up to which the resident kernel is used (default 10: up to 16 filters of N = 200; 0 = only when co-resident).
         resident = f->cholResident >= 2 || residentFits || (long long)f->rolesCount * B <= (long long)f->resOversub * f->numCUs;
     }
     a.eFromSigma = (!resident && splitChain && f->cholTail && f->eFromSigma && f->precision != EQF_PRECISION_F32) ? 1 : 0;

@@ -261,6 +261,44 @@ EQF_DEV void stagedPanelSolve(const f64x4 (&acc)[4], const Lds64& s, const doubl
     __syncthreads();
 }
 
+// ---- software-pipelined panel loop (round 3): the two 64 x 64 operand blocks of panel K+1 travel global -> REGISTERS while the matrix
+// cores work on panel K from LDS.  The loads are 8-byte agent-scope atomic loads (hoLoad8), not the 16-byte asm loads of hoLoadBlocks2:
+// the compiler tracks them, so they may stay in flight across the products (an asm load must carry its s_waitcnt inside the statement).
+// Thread t holds elements t + 256 u, u = 0..15, of each block (a wavefront reads 512 contiguous bytes per instruction).
+// Why: a workgroup that is dispatched late (a batch on a grid larger than the chip) finds ALL its panels waiting and used to apply them
+// one after the other at 5 us each (flag poll + 64 KB round trip + 1.7 us of MFMAs + two barriers); pipelined a panel costs what the
+// longer of the two takes.
+struct PanelRegs {
+    double p[16], q[16];
+};
+EQF_DEV void panelIssue(PanelRegs& r, const double* srcP, int ldP, const double* srcQ, int ldQ, int tid) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int e = tid + 256 * u, row = e >> 6, col = e & 63;
+        r.p[u] = hoLoad8(srcP + (long long)row * ldP + col);
+        r.q[u] = hoLoad8(srcQ + (long long)row * ldQ + col);
+    }
+}
+EQF_DEV void panelToLds(const PanelRegs& r, double (*dstP)[kSP], double (*dstQ)[kSP], int tid) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int e = tid + 256 * u, row = e >> 6, col = e & 63;
+        dstP[row][col] = r.p[u];
+        dstQ[row][col] = r.q[u];
+    }
+}
+EQF_DEV bool hoProbe3(const int* f0, const int* f1, const int* f2, int epoch) {
+    bool ok = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch &&
+              __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+    if (f2) ok = ok && __hip_atomic_load(f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+    return ok;
+}
+// non-blocking look at two flags (one lane): both published?
+EQF_DEV bool hoProbe2(const int* f0, const int* f1, int epoch) {
+    return __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch &&
+           __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+}
+
 #ifdef EQF_RES_STAMPS
 __device__ long long g_resStamps[2][16][16];  // [chain][R][phase] wall-clock (100 MHz) stamps of the row heads, filter 0
 #define EQF_HSTAMP(i) do { if (tid == 0 && b == 0 && R < 16) g_resStamps[role.kind][R][i] = wall_clock64(); } while (0)
@@ -456,13 +494,35 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[i][q] = Tg[(long long)(kQB * wv + (lane >> 4) + 4 * q) * ldA + kQB * i + (lane & 15)];
-        for (int K = 0; K < C; ++K) {
-            hoWait3(readyA + R * nbCap + K, readyA + C * nbCap + K, nullptr, epoch, tid, &bad);
-            hoLoadBlocks2(A + (long long)(R * kSB) * ldA + K * kSB, ldA, s.P, A + (long long)(C * kSB) * ldA + K * kSB, ldA, s.Q, tid);
-            __syncthreads();
+        if (C > 0) {
+            // pipelined panel loop (panelIssue above): panel K+1 is fetched during the products of panel K whenever its two blocks are
+            // already out (a look at the flags one iteration ahead, never a wait); at the frontier -- the newest panel not published
+            // yet -- it degenerates to wait, load, multiply as before
+            __shared__ int sAhead;
+            PanelRegs pr;
+            const double* rowP = A + (long long)(R * kSB) * ldA;
+            const double* rowQ = A + (long long)(C * kSB) * ldA;
+            hoWait3(readyA + R * nbCap, readyA + C * nbCap, nullptr, epoch, tid, &bad);
+            panelIssue(pr, rowP, ldA, rowQ, ldA, tid);
+            bool probe = (tid == 0 && C > 1) ? hoProbe2(readyA + R * nbCap + 1, readyA + C * nbCap + 1, epoch) : false;
+            for (int K = 0; K < C; ++K) {
+                panelToLds(pr, s.P, s.Q, tid);
+                if (tid == 0) sAhead = probe ? 1 : 0;
+                __syncthreads();
+                const bool ahead = K + 1 < C && sAhead;
+                if (ahead) {
+                    panelIssue(pr, rowP + (K + 1) * kSB, ldA, rowQ + (K + 1) * kSB, ldA, tid);
+                    probe = (tid == 0 && K + 2 < C) ? hoProbe2(readyA + R * nbCap + K + 2, readyA + C * nbCap + K + 2, epoch) : false;
+                }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = mmTile<true, kSB>(acc[i], &s.P[0][0], kSP, kQB * wv, &s.Q[0][0], kSP, kQB * i, lane, -1.0);
-            __syncthreads();
+                for (int i = 0; i < 4; ++i) acc[i] = mmTile<true, kSB>(acc[i], &s.P[0][0], kSP, kQB * wv, &s.Q[0][0], kSP, kQB * i, lane, -1.0);
+                __syncthreads();
+                if (K + 1 < C && !ahead) {
+                    hoWait3(readyA + R * nbCap + K + 1, readyA + C * nbCap + K + 1, nullptr, epoch, tid, &bad);
+                    panelIssue(pr, rowP + (K + 1) * kSB, ldA, rowQ + (K + 1) * kSB, ldA, tid);
+                    probe = (tid == 0 && K + 2 < C) ? hoProbe2(readyA + R * nbCap + K + 2, readyA + C * nbCap + K + 2, epoch) : false;
+                }
+            }
         }
         // (Round 3 also tried the staged consumption of stagedPanelSolve for the tile T(C+2, C), whose block is the other thing the row
         // head H(C+2) waits for: no change, 137.8 against 138.3 us per update -- once the heads consume D stage by stage the pivot chain
@@ -494,20 +554,48 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
         const bool isS = ch.kind == 0;
         double* zv = s.redL;  // [0, 64) the innovation column delta of this block row, [64, 128) z of block row K
         if (isS && tid < kSB) zv[tid] = W[(long long)(C * kSB + tid) * ldW + 11];
-        for (int K = 0; K < C; ++K) {
-            hoWait3(readyA + C * nbCap + K, readyY + K * wtCap + t, isS ? readyY + K * wtCap : nullptr, epoch, tid, &bad);
-            hoLoadBlocks2(A + (long long)(C * kSB) * ldA + K * kSB, ldA, s.Q, WO + (long long)(K * kSB) * ldW + t * kSB, ldW, s.P, tid);
-            if (isS && tid < kSB) zv[kSB + tid] = hoLoad8(WO + (long long)(K * kSB + tid) * ldW + 11);
-            __syncthreads();
-            if (isS && wv == 1) {  // delta -= L_CK z_K
-                double d = zv[lane];
+        if (C > 0) {
+            // pipelined panel loop (see panelIssue): Q <- L_{C,K}, P <- Y_{K,t}; the S-chain also carries z_K along
+            __shared__ int sAheadW;
+            PanelRegs pr;
+            double zNext = 0.0;
+            const double* rowQ = A + (long long)(C * kSB) * ldA;
+            const double* colP = WO + t * kSB;
+            auto issue = [&](int K) {
+                panelIssue(pr, colP + (long long)(K * kSB) * ldW, ldW, rowQ + K * kSB, ldA, tid);
+                if (isS && tid < kSB) zNext = hoLoad8(WO + (long long)(K * kSB + tid) * ldW + 11);
+            };
+            auto look = [&](int K) {
+                return (tid == 0 && K < C) ? hoProbe3(readyA + C * nbCap + K, readyY + K * wtCap + t, isS ? readyY + K * wtCap : nullptr, epoch) : false;
+            };
+            hoWait3(readyA + C * nbCap, readyY + t, isS ? readyY : nullptr, epoch, tid, &bad);
+            issue(0);
+            bool probe = look(1);
+            for (int K = 0; K < C; ++K) {
+                panelToLds(pr, s.P, s.Q, tid);
+                if (isS && tid < kSB) zv[kSB + tid] = zNext;
+                if (tid == 0) sAheadW = probe ? 1 : 0;
+                __syncthreads();
+                const bool ahead = K + 1 < C && sAheadW;
+                if (ahead) {
+                    issue(K + 1);
+                    probe = look(K + 2);
+                }
+                if (isS && wv == 1) {  // delta -= L_CK z_K
+                    double d = zv[lane];
 #pragma unroll 8
-                for (int k = 0; k < kSB; ++k) d = fma(-s.Q[lane][k], zv[kSB + k], d);
-                zv[lane] = d;
-            }
+                    for (int k = 0; k < kSB; ++k) d = fma(-s.Q[lane][k], zv[kSB + k], d);
+                    zv[lane] = d;
+                }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = mmTile<false, kSB>(acc[i], &s.Q[0][0], kSP, kQB * wv, &s.P[0][0], kSP, kQB * i, lane, -1.0);
-            __syncthreads();
+                for (int i = 0; i < 4; ++i) acc[i] = mmTile<false, kSB>(acc[i], &s.Q[0][0], kSP, kQB * wv, &s.P[0][0], kSP, kQB * i, lane, -1.0);
+                __syncthreads();
+                if (K + 1 < C && !ahead) {
+                    hoWait3(readyA + C * nbCap + K + 1, readyY + (K + 1) * wtCap + t, isS ? readyY + (K + 1) * wtCap : nullptr, epoch, tid, &bad);
+                    issue(K + 1);
+                    probe = look(K + 2);
+                }
+            }
         }
         EQF_WSTAMP(0);
         hoWait3(C > 0 ? flagD + C : nullptr, nullptr, nullptr, epoch, tid, &bad);
