@@ -59,7 +59,7 @@ EXPORTED_SYMBOLS = [
     "eqf_stream_upload", "eqf_stream_imu", "eqf_stream_vision", "eqf_synchronize", "eqf_get_time", "eqf_num_landmarks",
     "eqf_get_ids", "eqf_get_state_estimate", "eqf_get_origin", "eqf_get_group", "eqf_get_bias", "eqf_get_sigma",
     "eqf_set_sigma", "eqf_set_state", "eqf_set_camera_offset", "eqf_get_integrator", "eqf_get_last_update", "eqf_debug_get_blocks", "eqf_device_error", "eqf_set_dense_propagate", "eqf_set_imu_burst", "eqf_profile_enable",
-    "eqf_profile_get", "eqf_profile_class_name", "eqf_version", "eqf_tile_propagate", "eqf_tile_downdate", "eqf_tile_potrf", "eqf_tile_trsm", "eqf_tile_gemm_tn", "eqf_stream_create_masked", "eqf_stream_destroy",
+    "eqf_profile_get", "eqf_profile_class_name", "eqf_version", "eqf_tile_propagate", "eqf_tile_downdate", "eqf_tile_potrf", "eqf_tile_trsm", "eqf_tile_gemm_tn", "eqf_tile_mirror", "eqf_stream_create_masked", "eqf_stream_destroy",
     "eqf_tiled_create", "eqf_tiled_destroy", "eqf_tiled_set_stream", "eqf_tiled_set_geometry", "eqf_tiled_propagate", "eqf_tiled_add_landmarks",
     "eqf_tiled_update_prep", "eqf_tiled_update_finish", "eqf_tiled_synchronize", "eqf_tiled_num_landmarks", "eqf_tiled_get_time",
     "eqf_tiled_device_error", "eqf_tiled_get_state_estimate", "eqf_tiled_get_origin", "eqf_tiled_get_group", "eqf_tiled_get_bias",
@@ -117,6 +117,7 @@ def lib():
         L.eqf_tile_potrf.argtypes = [C.c_int, vpp, vpp, C.c_int, C.c_int, vpp, vpp]
         L.eqf_tile_trsm.argtypes = [C.c_int, vpp, vpp, C.c_int, C.c_int, vpp, vpp, C.c_int, C.c_int, C.c_int]
         L.eqf_tile_gemm_tn.argtypes = [C.c_int, vpp, vpp, C.c_int, C.c_int, C.c_int, vpp, C.c_int, vpp, C.c_int, C.c_int, C.c_double] + [C.c_int] * 8
+        L.eqf_tile_mirror.argtypes = [C.c_int, vpp, vpp, C.c_int, C.c_int, C.c_int]
         L.eqf_stream_create_masked.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vpp)]
         L.eqf_stream_destroy.argtypes = [C.c_int, vpp]
         # the 2-D block-partitioned filter (BASELINE configs[4]); device buffers are plain pointers (torch tensors' data_ptr)

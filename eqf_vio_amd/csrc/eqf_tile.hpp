@@ -240,6 +240,26 @@ __global__ __launch_bounds__(256, 2) void k_tile_gemm_tn(double* C, int ldc, int
 }
 
 
+// ---- C (n x n, symmetric in exact arithmetic, blocks of rb): every element below the BLOCK diagonal <- its mirror image,
+// C[r][c] = C[c][r] for r / rb > c / rb.  Completes a masked k_tile_gemm_tn on a rank whose local matrix is symmetric (square process
+// grid, diagonal rank: the partitioned downdate then costs half the flops).  grid = (ceil(n / 64), ceil(n / 64)), block = 256; the
+// transpose goes through LDS so that both the reads and the writes are row-contiguous.
+__global__ __launch_bounds__(256) void k_tile_mirror(double* C, int ld, int n, int rb) {
+    const int R0 = blockIdx.y * 64, C0 = blockIdx.x * 64;
+    if ((R0 + 63 < n ? R0 + 63 : n - 1) / rb <= C0 / rb) return;  // no element of this tile is below the block diagonal
+    __shared__ double sT[64][65];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int i = e >> 6, j = e & 63;  // source element (C0 + i, R0 + j)
+        sT[i][j] = (C0 + i < n && R0 + j < n) ? C[(long long)(C0 + i) * ld + R0 + j] : 0.0;
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int i = e >> 6, j = e & 63, r = R0 + i, c = C0 + j;
+        if (r < n && c < n && r / rb > c / rb) C[(long long)r * ld + c] = sT[j][i];
+    }
+}
+
 // ---- n x n block, lower triangle, row-major with leading dimension ld: A <- L (A = L L^T); drec[ceil(n / 64)][kDRec].
 // One workgroup of 256 threads, LDS = Step64Lds.  info: or-ed with 1 if a pivot is not positive.
 __global__ __launch_bounds__(256) void k_tile_potrf(double* A, int ld, int n, double* drec, int* info) {

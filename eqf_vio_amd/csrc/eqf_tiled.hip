@@ -626,6 +626,15 @@ int eqf_tile_gemm_tn(int device, void* stream, double* C, int ldc, int m, int n,
     return EQF_OK;
 }
 
+int eqf_tile_mirror(int device, void* stream, double* C, int ldc, int n, int rb) {
+    if (!C || n < 1 || ldc < n || rb < 1) return EQF_ERR_INVALID;
+    DeviceScope ds(device);
+    if (!ds.ok) return EQF_ERR_HIP;
+    hipLaunchKernelGGL(k_tile_mirror, dim3((n + 63) / 64, (n + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), C, ldc, n, rb);
+    HIPC(hipGetLastError());
+    return EQF_OK;
+}
+
 int eqf_tile_downdate(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k) {
     return eqf_tile_gemm_tn(device, stream, C, ldc, m, n, A, lda, B, ldb, k, -1.0, 0, 0, 0, 1, 0, 0, 1, 0);
 }

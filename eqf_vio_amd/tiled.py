@@ -155,14 +155,14 @@ class HipBackend:
 
         self.reserve = int(os.environ.get("EQF_TILED_RESERVE_CUS", "8")) if reserve_cus is None else int(reserve_cus)
         self._raw = []
-        self._main = self._side = None
+        self._main = self._side = self._aux = self._aux_side = None
         if self.reserve > 0:
-            pm, ps = ctypes.c_void_p(), ctypes.c_void_p()
-            binding._check(self.lib.eqf_stream_create_masked(self.dev, 0, self.reserve, 1, ctypes.byref(pm)), "eqf_stream_create_masked")
-            binding._check(self.lib.eqf_stream_create_masked(self.dev, 0, self.reserve, 0, ctypes.byref(ps)), "eqf_stream_create_masked")
-            self._raw = [pm, ps]
-            self._main = torch.cuda.ExternalStream(pm.value, device=self.device)
-            self._side = torch.cuda.ExternalStream(ps.value, device=self.device)
+            ptrs = [ctypes.c_void_p() for _ in range(4)]
+            for i, p in enumerate(ptrs):  # main, side, and a second pair for the E-chain, which runs next to the S-chain (TiledFilter._update)
+                binding._check(self.lib.eqf_stream_create_masked(self.dev, 0, self.reserve, 1 if i % 2 == 0 else 0, ctypes.byref(p)),
+                               "eqf_stream_create_masked")
+            self._raw = ptrs
+            self._main, self._side, self._aux, self._aux_side = [torch.cuda.ExternalStream(p.value, device=self.device) for p in ptrs]
         self._sync_stream()
 
     def close(self):
@@ -203,6 +203,17 @@ class HipBackend:
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
         return torch.cuda.stream(self._side)
+
+    def aux(self):
+        """context: a second 'main' stream (same CU set), for the factorisation that runs next to the other one"""
+        if self._aux is None:
+            self._aux = torch.cuda.Stream(device=self.device)
+        return torch.cuda.stream(self._aux)
+
+    def aux_side(self):
+        if self._aux_side is None:
+            self._aux_side = torch.cuda.Stream(device=self.device)
+        return torch.cuda.stream(self._aux_side)
 
     def record(self):
         ev = torch.cuda.Event()
@@ -284,6 +295,10 @@ class HipBackend:
         mk = mask if mask is not None else (0, 0, 0, 1, 0, 0, 1, 0)
         self.b._check(self.lib.eqf_tile_gemm_tn(self.dev, self._cur(), self._p(Cm), Cm.stride(0), m, n, self._p(A), A.stride(0), self._p(B),
                                                 B.stride(0), k, float(alpha), *[int(x) for x in mk]), "eqf_tile_gemm_tn")
+
+    def mirror_lower(self, Cm, rb):
+        """Cm (n x n view): every element below the block diagonal (blocks of rb) <- its mirror image."""
+        self.b._check(self.lib.eqf_tile_mirror(self.dev, self._cur(), self._p(Cm), Cm.stride(0), Cm.shape[0], int(rb)), "eqf_tile_mirror")
 
     def factor_info(self):
         """non-zero if a pivot of any diagonal block since the last call was not positive (synchronises)"""
@@ -370,6 +385,10 @@ class TiledFilter:
 
     def __init__(self, grid, backend, block_landmarks):
         self.g, self.be, self.bl = grid, backend, int(block_landmarks)
+        # the two factorisations of an update are independent: they run side by side on two streams, each with its own exchange buffers
+        # and -- on more than one rank -- its own process groups (two communicators: collectives of different streams must not share one)
+        self.overlap_chains = True
+        self.gE = ProcessGrid(grid.dist, grid.Pr, grid.Pc, grid.device) if grid.world > 1 else grid
         self.geo = None
         self.Sll = self.M = self.E = None
         self.ids = None
@@ -417,10 +436,20 @@ class TiledFilter:
         bsmax = 3 * min(self.bl, N)
         self._wmax = {c: 5 * geo.ncols_of(c) + NARROW_S for c in range(g.Pc)}
         self._wmax_e = {c: 3 * geo.ncols_of(c) + NARROW_E for c in range(g.Pc)}
-        self._buf = {c: be.empty(bsmax * max(self._wmax[c], self._wmax_e[c])) for c in range(g.Pc) if c == g.pc or c % g.Pr == g.pr}
-        self._pack = [be.empty(bsmax * bsmax + ((bsmax + 63) // 64) * HipBackend.DREC) for _ in range(2)]
-        self._aopA = be.empty(bsmax, max(3 * geo.nlr, 1))
+        mine = [c for c in range(g.Pc) if c == g.pc or c % g.Pr == g.pr]
+        self._bufs = {  # per chain: solved block row pieces, the diagonal factor + records (double-buffered), the interleaved row operand
+            "S": dict(buf={c: be.empty(bsmax * self._wmax[c]) for c in mine},
+                      pack=[be.empty(bsmax * bsmax + ((bsmax + 63) // 64) * HipBackend.DREC) for _ in range(2)], aopA=be.empty(bsmax, max(3 * geo.nlr, 1))),
+            "E": dict(buf={c: be.empty(bsmax * self._wmax_e[c]) for c in mine},
+                      pack=[be.empty(bsmax * bsmax + ((bsmax + 63) // 64) * HipBackend.DREC) for _ in range(2)], aopA=be.empty(bsmax, max(3 * geo.nlr, 1))),
+        }
         self._aopW = be.empty(bsmax, max(3 * geo.nlr, 1))
+        # the downdate Sigma_IJ -= sum_k Y_kI^T Y_kJ is ONE product per update (K = m = 2 N: Sll is read and written once instead of once
+        # per block row, and the product's prologue / epilogue are amortised): the solved block rows are kept -- the columns of my
+        # process column (B operand) and of my row blocks (A operand; the same matrix on a symmetric rank)
+        self.symmetric = g.Pr == g.Pc and g.pr == g.pc  # my row blocks ARE my column blocks: the local matrix is symmetric
+        self._Yc = be.empty(2 * N, max(3 * geo.nlc, 1))
+        self._Yr = self._Yc if self.symmetric else be.empty(2 * N, max(3 * geo.nlr, 1))
         self._accS = be.zeros(NARROW_S, 3 * geo.nlc + NARROW_S)
         self._accE = be.zeros(NARROW_E, NARROW_E)
 
@@ -484,18 +513,44 @@ class TiledFilter:
             # Bop[:, off:] = [Y_k (3 nlc) | Yn_k (18)] of my process column; the rank's share of the downdate and of the reductions
             Yw = Bop[:, off: off + 3 * geo.nlc]
             Yn = Bop[:, off + 3 * geo.nlc: off + 3 * geo.nlc + NARROW_S]
-            YI = self._rows_operand(contributions, 3, lambda c, wc: (wc - 3 * geo.ncols_of(c) - NARROW_S, 0), bk, self._aopW, all_blocks=True)
-            be.gemm_tn(self.Sll, YI, Yw, -1.0)                           # Sigma_IJ -= Y_kI^T Y_kJ    (VIOFilter.cpp:297)
+            r0 = 2 * k * geo.bl
+            self._Yc[r0: r0 + bk].copy_(Yw)
+            if not self.symmetric:
+                YI = self._rows_operand(contributions, 3, lambda c, wc: (wc - 3 * geo.ncols_of(c) - NARROW_S, 0), bk, self._aopW, all_blocks=True)
+                self._Yr[r0: r0 + bk].copy_(YI)
             be.gemm_tn(self._accS, Yn, Bop[:, off:], 1.0)               # [Sigma_b's downdate ; gamma_L ; .. | Gnn] += Yn_k^T [Y_k | Yn_k]
 
         def hook_e(k, bk, Bop, off, contributions):
             En = Bop[:, off: off + NARROW_E]
             be.gemm_tn(self._accE, En, En, 1.0)
 
+        # the E-chain (bundleLift's weights) needs nothing of the S-chain: it runs on its own stream next to it.  It is bound by its serial
+        # diagonal blocks, the S-chain and the downdate by the matrix cores -- side by side they take little more than the longer one
+        prepared = be.record()
+        e_done = None
+        if self.overlap_chains:
+            with be.aux():
+                be.wait(prepared)
+                with self._Phase(self, "chain_E"):
+                    self._chain(self.E, 3, 3 * geo.nlc, hook_e, self._wmax_e, self.gE, self._bufs["E"], be.aux_side)
+                e_done = be.record()
         with self._Phase(self, "chain_S"):
-            self._chain(self.M, 2, nA, hook_s, self._wmax)
-        with self._Phase(self, "chain_E"):
-            self._chain(self.E, 3, 3 * geo.nlc, hook_e, self._wmax_e)
+            self._chain(self.M, 2, nA, hook_s, self._wmax, self.g, self._bufs["S"], be.side)
+        with self._Phase(self, "downdate"):
+            # Sigma_IJ -= Y_I^T Y_J (VIOFilter.cpp:297), one product; on a symmetric rank only the blocks on and above the block
+            # diagonal are computed and the rest is mirrored
+            if geo.nlr and geo.nlc:
+                w3 = 3 * geo.bl
+                if self.symmetric:
+                    be.gemm_tn(self.Sll, self._Yr, self._Yc, -1.0, mask=(w3, w3, 0, 1, 0, 0, 1, 0))
+                    be.mirror_lower(self.Sll, w3)
+                else:
+                    be.gemm_tn(self.Sll, self._Yr, self._Yc, -1.0)
+        if self.overlap_chains:
+            be.wait(e_done)
+        else:
+            with self._Phase(self, "chain_E"):
+                self._chain(self.E, 3, 3 * geo.nlc, hook_e, self._wmax_e, self.g, self._bufs["E"], be.side)
         with self._Phase(self, "finish"):
             # gamma_L and the base panel's downdate live with the process COLUMNS: gather them along the process row, global landmark order
             acc = self._gather_columns(self._accS[:, : 3 * geo.nlc])
@@ -563,17 +618,17 @@ class TiledFilter:
                 out[:, ilb * bsF: ilb * bsF + w] = piece[:, src: src + w]
         return out[:, il0 * bsF:]
 
-    def _chain(self, X, unit, nA, hook, wmax):
+    def _chain(self, X, unit, nA, hook, wmax, g, bufs, side):
         """Blocked right-looking Cholesky by block ROWS of the SPD matrix in X[:, :nA] (upper blocks, block size unit * bl, block-cyclic
         over the grid) with the right-hand sides X[:, nA:]; X is consumed.  hook(k, bk, Bop, off, contributions) runs on every rank once
         block row k is solved: Bop[:, off:] holds the right-hand-side part of my process column.
         Look-ahead: the diagonal block is the serial part (one workgroup, eqf_tile_potrf).  As soon as block row k is solved, the owner of
         block (k+1, k+1) applies row k to a COPY of that block and factors the copy on a second stream, in the shadow of the trailing
         update of step k; step k+1 then starts from the finished factor."""
-        g, geo, be = self.g, self.geo, self.be
+        geo, be = self.geo, self.be
         bsF = unit * geo.bl
         W = X.shape[1]
-        ahead = None  # event: the look-ahead factor of the current block is in self._pack[k & 1]
+        ahead = None  # event: the look-ahead factor of the current block is in bufs["pack"][k & 1]
         for k in range(geo.nb):
             prk, pck = k % g.Pr, k % g.Pc
             bk = unit * geo.block_size(k)
@@ -581,11 +636,11 @@ class TiledFilter:
             jl0 = BlockCyclic.blocks_upto(k, g.pc, g.Pc)
             c0 = min(jl0 * bsF, nA)
             width = W - c0
-            Bop = self._buf[g.pc][: bk * width].view(bk, width)
+            Bop = bufs["buf"][g.pc][: bk * width].view(bk, width)
             if g.pr == prk:
                 # 1. the diagonal block, L_kk and its records along the process row
                 nrec = ((bk + 63) // 64) * HipBackend.DREC
-                pack = self._pack[k & 1][: bk * bk + nrec]
+                pack = bufs["pack"][k & 1][: bk * bk + nrec]
                 Lkk, drec = pack[: bk * bk].view(bk, bk), pack[bk * bk:]
                 if g.pc == pck:
                     if ahead is not None:
@@ -606,22 +661,22 @@ class TiledFilter:
             for c in range(g.pr, g.Pc, g.Pr):
                 jl0c = BlockCyclic.blocks_upto(k, c, g.Pc)
                 wc = wmax[c] - min(jl0c * bsF, unit * geo.ncols_of(c))
-                piece = Bop if c == g.pc else self._buf[c][: bk * wc].view(bk, wc)
+                piece = Bop if c == g.pc else bufs["buf"][c][: bk * wc].view(bk, wc)
                 g.bcast_row(piece, c)
                 contributions[c] = (piece, jl0c)
             # 5. trailing updates of what this rank owns: rows of blocks i > k, columns from block jl0 on
             il0 = BlockCyclic.blocks_upto(k, g.pr, g.Pr)
             if il0 * bsF < X.shape[0]:
-                Ua = self._rows_operand(contributions, unit, lambda c, wc: (0, 1), bk, self._aopA, all_blocks=False, k=k)
+                Ua = self._rows_operand(contributions, unit, lambda c, wc: (0, 1), bk, bufs["aopA"], all_blocks=False, k=k)
                 if self.lookahead and k + 1 < geo.nb and g.pr == (k + 1) % g.Pr and g.pc == (k + 1) % g.Pc:
                     # look-ahead: block (k+1, k+1) is the first trailing block of my rows and of my columns
                     b1 = unit * geo.block_size(k + 1)
                     nrec1 = ((b1 + 63) // 64) * HipBackend.DREC
-                    pack1 = self._pack[(k + 1) & 1][: b1 * b1 + nrec1]
+                    pack1 = bufs["pack"][(k + 1) & 1][: b1 * b1 + nrec1]
                     L1, drec1 = pack1[: b1 * b1].view(b1, b1), pack1[b1 * b1:]
                     L1.copy_(X[il0 * bsF: il0 * bsF + b1, c0: c0 + b1])
                     ready = be.record()
-                    with be.side():
+                    with side():
                         be.wait(ready)
                         be.gemm_tn(L1, Ua[:, :b1], Bop[:, :b1], -1.0)
                         be.potrf(L1, drec1)

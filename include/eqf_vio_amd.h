@@ -274,6 +274,10 @@ int eqf_stream_create_masked(int device, int first_cu, int num_cus, int compleme
 int eqf_stream_destroy(int device, void* stream);
 int eqf_tile_gemm_tn(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k,
     double alpha, int mask_rb, int mask_cb, int rblk0, int Pr, int pr, int cblk0, int Pc, int pc);
+/* C (n x n, ldc; symmetric up to rounding, blocks of rb): C[r][c] <- C[c][r] wherever r / rb > c / rb.  Completes a block-upper-masked
+ * eqf_tile_gemm_tn on a rank whose local matrix is symmetric (square process grid, diagonal rank): Sigma - K C Sigma = Sigma - Y^T Y
+ * (VIOFilter.cpp:297) at half the flops there. */
+int eqf_tile_mirror(int device, void* stream, double* C, int ldc, int n, int rb);
 int eqf_tile_propagate(int device, void* stream, double* out, const double* in, int ld, int nI, int nJ, const double* D_I,
     const double* L_I, const double* D_J, const double* L_J, const double* Sbb, const double* SbI, int ldbI, const double* SbJ,
     int ldbJ, const double* BnI, const double* BnJ, const double* R6, double T, double diag_noise, int is_diag);

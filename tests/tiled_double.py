@@ -227,7 +227,7 @@ class NumpyBackend:
 
         return contextlib.nullcontext()
 
-    main = side
+    main = aux = aux_side = side
 
     def record(self):
         return True
@@ -258,6 +258,12 @@ class NumpyBackend:
             J = (cblk0 + torch.arange(Cm.shape[1]) // cb) * Pc + pc
             P = torch.where(I[:, None] <= J[None, :], P, torch.zeros_like(P))  # blocks below the diagonal: untouched
         Cm.add_(P, alpha=alpha)
+
+    def mirror_lower(self, Cm, rb):
+        n = Cm.shape[0]
+        I = torch.arange(n) // rb
+        low = I[:, None] > I[None, :]
+        Cm.copy_(torch.where(low, Cm.T, Cm))
 
     def factor_info(self):
         v, self._info = self._info, 0
