@@ -46,6 +46,7 @@ struct BurstArgs {
     const ImuRec* visRec;  // [B] record of the closing vision step (only its stamp is used); nullptr -> inl[K - 1]
     ImuRec inl[kBurstMax];
     int K;           // steps, the closing vision step included
+    int ringBy;      // k_burst_riccati_ring: row tiles (of 4 R landmarks) of the launch, see ringTiles()
     int visionLast;  // step K-1 is processVisionData's integrateUpToTime(stamp, true)   (VIOFilter.cpp:233)
     int* errflag;
     long long sigmaStride;
@@ -776,25 +777,44 @@ __global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
 // constants is a ~2 us miss: a one-step register prefetch cannot cover it.  Here the four wavefronts of a workgroup share
 // their 64 column landmarks (one row landmark each): each wave fetches a QUARTER of a step's 45 x 64 column constants, TWO
 // steps ahead (two register sets of 13 values), and passes them on through a two-slot LDS ring one step before they are
-// used -- loads have two full steps to arrive.  grid = (ceil(N / 64), ceil(N / 4), B), block = 256.
+// used -- loads have two full steps to arrive.  grid = (ringTiles(N, 1), B), block = 256.
 // ------------------------------------------------------------------------------------------------
 #ifdef EQF_BURST_STAMPS
 __device__ long long g_ringStamps[4][64];
-#define EQF_RSTAMP(i) do { if (blockIdx.x == 1 && blockIdx.y == 7 && blockIdx.z == 0 && lane == 0 && (i) < 64) g_ringStamps[wv][i] = __builtin_readcyclecounter(); } while (0)
+#define EQF_RSTAMP(i) do { if (blockIdx.x == 9 && blockIdx.y == 0 && lane == 0 && (i) < 64) g_ringStamps[wv][i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define EQF_RSTAMP(i) do { } while (0)
 #endif
+// tiles of the launch for nmx landmarks: sum over the column tiles bx of the row tiles by >= 16 bx / R
+inline int ringTiles(int nmx, int R, int* rowTiles) {
+    const int nBy = (nmx + 4 * R - 1) / (4 * R), nBx = (nmx + 63) / 64;
+    int t = 0;
+    for (int bx = 0; bx < nBx; ++bx) t += std::max(nBy - bx * (16 / R), 0);
+    *rowTiles = nBy;
+    return t;
+}
 constexpr int kRingTrips = 12;  // column-constant rows per wave and step: 45 rows over 4 waves
 // R = row landmarks per wavefront: 1 for the small launches described above; 4 for launches that fill the chip -- there the point
 // of the ring is that the 45 x 64 column constants of a step are fetched ONCE per workgroup (16 row landmarks) instead of once per
 // wavefront, and that a lane holds 13 + 3 prefetched values per register set instead of 46: 2 wavefronts per SIMD instead of 1.
-// grid = (ceil(N / 64), ceil(N / (4 R)), B).
+// grid = (ringTiles(N, R), B).
 template <typename T, int R = 1>
 __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(BurstArgs a) {
-    const int b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int N = a.gin[b].N, K = a.K, cap = a.cap, ld = a.ld;
-    const int J = blockIdx.x * 64 + lane;
-    const int I0raw = (blockIdx.y * 4 + wv) * R;
+    // Only the blocks on and below the diagonal (row landmark >= column landmark) are propagated; the others are their transposes and
+    // are written as such at the end (below).  The launch enumerates the tiles that hold such blocks and nothing else (column tile bx
+    // keeps the row tiles from by0 = 16 bx / R on: at N = 200 that is 28 of 52 tiles, and of the ragged last column tile -- 8 of 64
+    // lanes -- only one), so that consecutive workgroups, which go to consecutive XCDs, all carry the same work.
+    int bx = 0, by = blockIdx.x;
+    for (;; ++bx) {
+        const int cnt = a.ringBy - bx * (16 / R);
+        if (by < cnt) break;
+        by -= cnt;
+    }
+    by += bx * (16 / R);
+    const int J = bx * 64 + lane;
+    const int I0raw = (by * 4 + wv) * R;
     const bool validJ = J < N;
     const int I0 = min(I0raw, max(N - 1, 0)), Jc = validJ ? J : 0;  // (rows past N: the wave works on a copy of the last row, stores nothing)
     const int nI = max(min(R, N - I0), 1);
@@ -852,6 +872,18 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
             if (e < kRowVals) sRow[wv][sl][e] = x[kRingTrips + u];
         }
     };
+    // R > 1: the row constants are wave-uniform, so they come through the SCALAR cache (constant address space: s_load into SGPRs,
+    // one scalar operand per FMA) instead of 180 LDS broadcast reads per step and wave -- with 8 waves on a CU those reads alone kept
+    // the LDS pipe busy longer than the FMAs keep a SIMD (7.6 k against 5.2 k cycles per step).  The vector fetch of the same records
+    // one step ahead (fetch / pass above) stays as the L2 warm-up: the records were written by k_burst_build on other XCDs.
+    typedef const T __attribute__((address_space(4))) CT;
+    const int I0u = __builtin_amdgcn_readfirstlane(I0);
+    const int nIu = __builtin_amdgcn_readfirstlane(nI);
+    CT* const rowC = (CT*)(unsigned long long)(static_cast<const T*>(a.rowRec) + (long long)b * kBurstMax * cap * kBlkRec + (long long)I0u * kBlkRec);
+    auto rowConst = [&](int st, int i) __attribute__((always_inline)) {
+        if constexpr (R > 1) return rowC + ((long long)st * cap + min(i, nIu - 1)) * kBlkRec;
+        else return (const T*)(sRow[wv][st & 1] + i * kBlkRec);  // wave-uniform: LDS broadcast reads
+    };
     auto math = [&](int st) __attribute__((always_inline)) {
         const int sl = st & 1;
         // two passes over the wave's rows so that only one group of column constants is live at a time (Sw / Sv, then D^T / Lw /
@@ -865,7 +897,7 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
             }
 #pragma unroll
             for (int i = 0; i < R; ++i) {
-                const T* rc = sRow[wv][sl] + i * kBlkRec;  // wave-uniform: LDS broadcast reads
+                const auto* rc = rowConst(st, i);
                 T H[9];
 #pragma unroll
                 for (int rr = 0; rr < 3; ++rr)
@@ -915,7 +947,7 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
             for (int k = 0; k < 9; ++k) c[k] = sCol[sl][9 * grp + k][lane];
 #pragma unroll
             for (int i = 0; i < R; ++i) {
-                const T* rc = sRow[wv][sl] + i * kBlkRec + 18 + 9 * grp;
+                const auto* rc = rowConst(st, i) + 18 + 9 * grp;
 #pragma unroll
                 for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
@@ -928,6 +960,109 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
             }
         }
     };
+    // R > 1: the same arithmetic, element by element in the same order, with the row constants as SCALAR operands.  A step's 4 x 45
+    // constants are consumed as 20 chunks of nine (D_i, Lw_i, Lv_i for the four rows, then Gn_i, then Gv_i), two chunks to a group;
+    // group g + 1 is requested once group g has arrived and before its 54 FMAs per lane are issued (scalar loads return out of order,
+    // so the only wait there is is "all of them": a request must never be outstanding when the previous group is waited for).
+    auto mathS = [&](int st) __attribute__((always_inline)) {
+      if constexpr (R == 4) {
+        const int sl = st & 1;
+        CT* const base = rowC + (long long)st * cap * kBlkRec;
+        auto chunkPtr = [&](int c) __attribute__((always_inline)) {
+            const int i = c < 12 ? c / 3 : (c - 12) & 3;
+            const int off = c < 12 ? 9 * (c % 3) : (c < 16 ? 27 : 36);
+            return base + min(i, nIu - 1) * kBlkRec + off;
+        };
+        T buf[2][18];
+        auto request = [&](int g) __attribute__((always_inline)) {
+            CT* p0 = chunkPtr(2 * g);
+            CT* p1 = chunkPtr(2 * g + 1);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                buf[g & 1][k] = p0[k];
+                buf[g & 1][9 + k] = p1[k];
+            }
+        };
+        auto arrived = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < 18; ++k) asm volatile("" ::"s"(buf[g & 1][k]));
+        };
+        T H[9], cst[18];
+        const T TtP = sTtP[st];
+        auto chunk = [&](int c, const T* k9) __attribute__((always_inline)) {
+            if (c < 12) {
+                const int i = c / 3, part = c % 3;
+                const T* src = part == 0 ? S[i] : cst + 9 * (part - 1);  // S_i, Sw, Sv
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        T acc = part == 0 ? k9[3 * rr] * src[cc] : fma(k9[3 * rr], src[cc], H[3 * rr + cc]);
+#pragma unroll
+                        for (int k = 1; k < 3; ++k) acc = fma(k9[3 * rr + k], src[3 * k + cc], acc);
+                        H[3 * rr + cc] = acc;
+                    }
+                if (part == 2) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) S[i][k] = H[k];
+                }
+            } else {
+                const int i = (c - 12) & 3;
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        T acc = S[i][3 * rr + cc];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) acc = fma(k9[3 * rr + k], cst[3 * cc + k], acc);
+                        S[i][3 * rr + cc] = acc;
+                    }
+            }
+        };
+        request(0);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            cst[k] = sCol[sl][27 + k][lane];
+            cst[9 + k] = sCol[sl][36 + k][lane];
+        }
+#pragma unroll
+        for (int g = 0; g < 10; ++g) {
+            arrived(g);
+            if (g + 1 < 10) request(g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g == 6) {
+                // all of H_i = D_i S_i + Lw_i Sw + Lv_i Sv are in place: S_i' = H_i D_J^T (+ the landmark process noise on the diagonal)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) cst[k] = sCol[sl][k][lane];
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const bool diag = (I0raw + i) == J;
+                    T O[9];
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc) {
+                            T acc = (diag && rr == cc) ? TtP : (T)0;
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) acc = fma(S[i][3 * rr + k], cst[3 * cc + k], acc);
+                            O[3 * rr + cc] = acc;
+                        }
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) S[i][k] = O[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) cst[k] = sCol[sl][9 + k][lane];  // Lw_J, for + Gn_i Lw_J^T
+            }
+            if (g == 8) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) cst[k] = sCol[sl][18 + k][lane];  // Lv_J, for + Gv_i Lv_J^T
+            }
+            chunk(2 * g, buf[g & 1]);
+            chunk(2 * g + 1, buf[g & 1] + 9);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
     if (R > 1) {
         // throughput variant: one register set, constants fetched one step ahead (the other wavefront of the SIMD covers the wait)
         fetch(0, xA);
@@ -937,7 +1072,7 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
         __builtin_amdgcn_sched_barrier(0);
         ldsBarrier();
         for (int st = 0; st < K; ++st) {
-            if (sRicc[st]) math(st);
+            if (sRicc[st]) mathS(st);
             pass(st + 1, xA);
             fetch(st + 2, xA);
             __builtin_amdgcn_sched_barrier(0);
@@ -978,13 +1113,39 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
     if (validJ) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            if (I0raw + i < N) {
-                T* dst = Sout + (long long)(kLm0 + 3 * (I0raw + i)) * ld + kLm0 + 3 * J;
+            const int I = I0raw + i;
+            if (I < N && I >= J) {
+                T* dst = Sout + (long long)(kLm0 + 3 * I) * ld + kLm0 + 3 * J;
 #pragma unroll
                 for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
                     for (int cc = 0; cc < 3; ++cc) dst[(long long)rr * ld + cc] = S[i][3 * rr + cc];
             }
+        }
+    }
+    // Sigma_JI = Sigma_IJ^T for the blocks strictly below the diagonal.  Written from the registers, a lane's three rows would be 8-byte
+    // stores 3 ld apart (64 cache lines per instruction: the kernel took LONGER than with every block computed twice); instead the
+    // workgroup transposes its tile through the LDS ring (free now), kLanesPass column landmarks at a time, and writes rows of the
+    // mirror image -- the 4 R row landmarks of the workgroup side by side, 12 R consecutive values.
+    constexpr int kLanesPass = R == 4 ? 32 : 64, kWd = 12 * R, kPitch = kWd + 1, kRowsPass = 3 * kLanesPass;
+    static_assert(kRowsPass * kPitch <= 2 * kBlkRec * 64, "the staging tile lives in sCol");
+    T* const stage = &sCol[0][0][0];
+    for (int p = 0; p < 64 / kLanesPass; ++p) {
+        __syncthreads();
+        if (lane / kLanesPass == p) {
+            T* dst = stage + 3 * (lane % kLanesPass) * kPitch + 3 * wv * R;
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) dst[cc * kPitch + 3 * i + rr] = S[i][3 * rr + cc];
+        }
+        __syncthreads();
+        for (int e = tid; e < kRowsPass * kWd; e += 256) {
+            const int r = e / kWd, c = e % kWd;
+            const int Jm = bx * 64 + p * kLanesPass + r / 3, Im = by * 4 * R + c / 3;
+            if (Im < N && Im > Jm) Sout[(long long)(kLm0 + 3 * Jm + r % 3) * ld + kLm0 + 3 * Im + c % 3] = stage[r * kPitch + c];
         }
     }
 }

@@ -467,7 +467,7 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     const long long waves1 = (long long)((nmx + 63) / 64) * nmx * f->B;
     // (cross-over measured on the 256-CU part at 2800 wave-blocks = 11 per CU: four filters of N = 200, N >= 400)
     const int R = f->burstRows ? f->burstRows : (waves1 <= 11LL * cus ? 1 : 4);
-    const dim3 rgrid((nmx + 63) / 64, (nmx + 4 * R - 1) / (4 * R), f->B);
+    const dim3 rgrid(ringTiles(nmx, R, &a.ringBy), f->B);  // (the tiles on and below the diagonal)
     // every filter past its lazy initialisation (VIOFilter.cpp:122-124): the schedule with the precomputed step halves
     const bool fast = allDevInit(f);
     const int rc = profiled(f, EQF_PROF_BURST, [&] {
