@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--tiled", action="store_true", help="(the cfg 5 leg is on by default; kept for explicitness)")
     ap.add_argument("--tiled-landmarks", type=int, default=4000)
     ap.add_argument("--tiled-block", type=int, default=250, help="landmarks per block of the 2-D partition")
+    ap.add_argument("--tiled-timeout", type=int, default=240, help="several GPUs: seconds after which the cfg 5 leg is given up")
     ap.add_argument("--tiled-frames", type=int, default=3, help="timed frames (a frame = 10 IMU calls + 1 vision call) after one warm-up frame")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle-checked prefix (parity block of the JSON line)")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed throw-away run that precedes the measured job")
@@ -565,10 +566,31 @@ def main():
 
     # ---- BASELINE configs[4]: one N = 4000 filter partitioned over the ranks of the job
     if not args.no_tiled and world in GRIDS and not args.dense_propagate and not args.pmc_child:
+        # (a failure of this leg must not take the headline line with it: exceptions are reported in its place, and on several GPUs --
+        # where a lost peer shows as a collective that never returns -- a watchdog prints the line without the leg and ends the rank)
+        watchdog = None
+        if world > 1:
+            import threading
+
+            def give_up():
+                if rank == 0:
+                    line["tiled_cfg5"] = {"error": "no result after %d s (watchdog)" % args.tiled_timeout}
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+
+            watchdog = threading.Timer(args.tiled_timeout, give_up)
+            watchdog.daemon = True
+            watchdog.start()
         try:
             line["tiled_cfg5"] = tiled_leg(args, dist, rank, world, device)
-        except Exception as e:  # (a failure of this leg must not take the headline line with it)
+        except Exception as e:
             line["tiled_cfg5"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if watchdog is not None:
+            watchdog.cancel()
+            if "error" in line["tiled_cfg5"]:  # the other ranks may be stuck in a collective of the leg: no barrier with them
+                if rank == 0:
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
 
     if rank == 0 and world == 1:
         rl = line.get("roofline")

@@ -154,6 +154,7 @@ struct eqf_filter {
     int *dReadyA = nullptr, *dReadyY = nullptr, *dResCounters = nullptr, *dStageFlags = nullptr;
     double *dGammaPart = nullptr, *dG11Part = nullptr;
     ResRole* dRoles = nullptr;
+    int resPipeHeads = -1;         // EQF_RES_PIPEH: row heads with the pipelined panel loop (1), without (0), by grid size (-1)
     int rolesN = -1, rolesCount = 0;  // chain shape (nbS, nbE, wtS) the role table was built for
     // profiling
     bool prof = false;
@@ -615,6 +616,8 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsUpdateBytes));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<float>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<float, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTailBytes));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTailBytes));
         attrSet = true;
@@ -712,7 +715,10 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             ra.errflag = f->errflag;
             const int ddGrid = residentFits ? 0 : nt64 * (nt64 + 1) / 2;  // downdate tiles as workgroups of their own behind the roles
             rc = profiled(f, EQF_PROF_CHOL_RESIDENT, [&] {
-                hipLaunchKernelGGL(k_chol_resident<T>, dim3(B, f->rolesCount + ddGrid), dim3(256), sizeof(Step64Lds), f->stream, ra);
+                // (row heads with the pipelined panel loop only on a grid larger than the chip: see the kernel's PIPEH)
+                const bool pipeHeads = f->resPipeHeads >= 0 ? f->resPipeHeads != 0 : !residentFits;
+                if (pipeHeads) hipLaunchKernelGGL((k_chol_resident<T, true>), dim3(B, f->rolesCount + ddGrid), dim3(256), sizeof(Step64Lds), f->stream, ra);
+                else hipLaunchKernelGGL((k_chol_resident<T, false>), dim3(B, f->rolesCount + ddGrid), dim3(256), sizeof(Step64Lds), f->stream, ra);
             });
             if (rc) return rc;
         } else if (splitChain && f->cholTail) {
@@ -1261,6 +1267,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (const char* e = std::getenv("EQF_RES_STAGED")) f->resStaged = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_OVERSUB")) f->resOversub = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("EQF_E_FROM_SIGMA")) f->eFromSigma = std::atoi(e);
+    if (const char* e = std::getenv("EQF_RES_PIPEH")) f->resPipeHeads = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_ORDER")) f->cholOrder = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_STREAMS")) f->cholStreams = std::max(0, std::atoi(e));
     {

@@ -307,7 +307,12 @@ __device__ long long g_resStamps[2][16][16];  // [chain][R][phase] wall-clock (1
 #define EQF_HSTAMP(i) do { } while (0)
 #define EQF_WSTAMP(i) do { } while (0)
 #endif
-template <typename T>
+// PIPEH: the row heads apply their old panels with the pipelined loop of the interior tiles as well.  Off for a grid that is co-resident
+// (one or two small filters: every head is there from the start and applies each panel the moment it appears; the 64 prefetch registers
+// cost the pivot chain 4 us per update through the register allocation), on for a batch on a grid larger than the chip: there a head is
+// dispatched when R - 1 panels are already waiting, and at 6.5 us per panel (flag, 64 KB round trip, 3.4 us of MFMAs, two barriers) the heads of
+// the later block columns were still catching up when their diagonal factor was due (wall-clock stamps, 8 filters: H(8) 9 us late).
+template <typename T, bool PIPEH = false>
 __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smemR[];
     // grid = (batch, roles): the filter index runs FASTEST in dispatch order, so that a grid larger than the chip advances all filters
@@ -396,7 +401,40 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
         EQF_HSTAMP(0);
         // (A dry run of the serial part during the idle time before the panels arrive -- to take the instruction-cache misses of
         // code a workgroup executes exactly once off the critical path -- was tried and measured: no gain.)
-        for (int K = 0; K + 1 < R; ++K) {
+        if constexpr (PIPEH) {
+            if (R > 2) {
+                __shared__ int sAheadH;
+                PanelRegs pr;
+                const double* rowP = A + (long long)(R * kSB) * ldA;
+                const double* rowQ = A + (long long)((R - 1) * kSB) * ldA;
+                const int nK = R - 2;  // panels 0 .. R-3; the last one, K = R-2, below as always
+                hoWait3(readyA + R * nbCap, readyA + (R - 1) * nbCap, nullptr, epoch, tid, &bad);
+                panelIssue(pr, rowP, ldA, rowQ, ldA, tid);
+                bool probe = (tid == 0 && nK > 1) ? hoProbe2(readyA + R * nbCap + 1, readyA + (R - 1) * nbCap + 1, epoch) : false;
+                for (int K = 0; K < nK; ++K) {
+                    panelToLds(pr, s.P, s.Q, tid);
+                    if (tid == 0) sAheadH = probe ? 1 : 0;
+                    __syncthreads();
+                    const bool ahead = K + 1 < nK && sAheadH;
+                    if (ahead) {
+                        panelIssue(pr, rowP + (K + 1) * kSB, ldA, rowQ + (K + 1) * kSB, ldA, tid);
+                        probe = (tid == 0 && K + 2 < nK) ? hoProbe2(readyA + R * nbCap + K + 2, readyA + (R - 1) * nbCap + K + 2, epoch) : false;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a1[i] = mmTile<true, kSB>(a1[i], &s.P[0][0], kSP, kQB * wv, &s.Q[0][0], kSP, kQB * i, lane, -1.0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (i < nt) a2[i] = mmTile<true, kSB>(a2[i], &s.P[0][0], kSP, kQB * tr[i], &s.P[0][0], kSP, kQB * tc[i], lane, -1.0);
+                    __syncthreads();
+                    if (K + 1 < nK && !ahead) {
+                        hoWait3(readyA + R * nbCap + K + 1, readyA + (R - 1) * nbCap + K + 1, nullptr, epoch, tid, &bad);
+                        panelIssue(pr, rowP + (K + 1) * kSB, ldA, rowQ + (K + 1) * kSB, ldA, tid);
+                        probe = (tid == 0 && K + 2 < nK) ? hoProbe2(readyA + R * nbCap + K + 2, readyA + (R - 1) * nbCap + K + 2, epoch) : false;
+                    }
+                }
+            }
+        }
+        for (int K = PIPEH ? max(R - 2, 0) : 0; K + 1 < R; ++K) {
             if (K + 2 < R) {
                 hoWait3(readyA + R * nbCap + K, readyA + (R - 1) * nbCap + K, nullptr, epoch, tid, &bad);
                 hoLoadBlocks2(A + (long long)(R * kSB) * ldA + K * kSB, ldA, s.P, A + (long long)((R - 1) * kSB) * ldA + K * kSB, ldA, s.Q, tid);
