@@ -300,9 +300,12 @@ EQF_DEV bool hoProbe2(const int* f0, const int* f1, int epoch) {
 }
 
 #ifdef EQF_RES_STAMPS
+#ifndef EQF_STAMP_B
+#define EQF_STAMP_B 0  // the filter whose workgroups leave stamps (-DEQF_STAMP_B=(gridDim.x-1): the last one of a batch)
+#endif
 __device__ long long g_resStamps[2][16][16];  // [chain][R][phase] wall-clock (100 MHz) stamps of the row heads, filter 0
-#define EQF_HSTAMP(i) do { if (tid == 0 && b == 0 && R < 16) g_resStamps[role.kind][R][i] = wall_clock64(); } while (0)
-#define EQF_WSTAMP(i) do { if (tid == 0 && b == 0 && !isS && C == nb - 1) g_resStamps[1][15][i] = wall_clock64(); } while (0)
+#define EQF_HSTAMP(i) do { if (tid == 0 && b == EQF_STAMP_B && R < 16) g_resStamps[role.kind][R][i] = wall_clock64(); } while (0)
+#define EQF_WSTAMP(i) do { if (tid == 0 && b == EQF_STAMP_B && !isS && C == nb - 1) g_resStamps[1][15][i] = wall_clock64(); } while (0)
 #else
 #define EQF_HSTAMP(i) do { } while (0)
 #define EQF_WSTAMP(i) do { } while (0)
@@ -325,6 +328,10 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
         const int bb = blockIdx.x, tile = (int)blockIdx.y - ra.nRoles, t = threadIdx.x;
         const Glob& gg = ra.a.g[bb];
         int late = 0;
+#ifdef EQF_RES_STAMPS
+        const int slot = tile == 0 ? 0 : (tile == 27 ? 1 : (tile == 54 ? 2 : -1));
+        if (t == 0 && bb == EQF_STAMP_B && slot >= 0) g_resStamps[0][15][3 * slot] = wall_clock64();
+#endif
         if (t == 0 && gg.updateOk && gg.N != 0) {
             int nS, wS;
             chainDims64(ra.c0, gg.N, &nS, &wS);
@@ -340,7 +347,14 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
             }
         }
         if (__syncthreads_or(late)) return;  // (Sigma_out is left untouched: the sticky flag makes the host fail the update)
-        downdateTile<T, 64>(ra.a, ra.ddNt, bb, tile, reinterpret_cast<T*>(smemR));
+#ifdef EQF_RES_STAMPS
+        if (t == 0 && bb == EQF_STAMP_B && slot >= 0) g_resStamps[0][15][3 * slot + 1] = wall_clock64();
+#endif
+        downdateTile<T, 64, 4>(ra.a, ra.ddNt, bb, tile, reinterpret_cast<T*>(smemR));
+#ifdef EQF_RES_STAMPS
+        __syncthreads();
+        if (t == 0 && bb == EQF_STAMP_B && slot >= 0) g_resStamps[0][15][3 * slot + 2] = wall_clock64();
+#endif
         return;
     }
     const ResRole role = ra.roles[blockIdx.y];
@@ -751,7 +765,7 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
             __syncthreads();
             if (tile >= ddTiles) break;
             if (ra.ddSmall) downdateTile<T, 32>(a, ra.ddNt, b, tile, reinterpret_cast<T*>(smemR));
-            else downdateTile<T, 64>(a, ra.ddNt, b, tile, reinterpret_cast<T*>(smemR));
+            else downdateTile<T, 64, 4>(a, ra.ddNt, b, tile, reinterpret_cast<T*>(smemR));
             __syncthreads();
         }
     }

@@ -615,7 +615,10 @@ struct MfmaT<float> {
 // TS = output tile edge: 64 (each wave a 32x32 quadrant as 2x2 MFMA tiles; best operand reuse, used when there are
 // enough tiles to fill the chip) or 32 (each wave one 16x16 MFMA tile; 4x more workgroups for a single small filter).
 // One symmetric tile pair of the downdate; lds: 2 * 32 * (TS + 1) elements of T.  All 256 threads.
-template <typename T, int TS>
+// DEPTH = chunks in flight ahead of the one the matrix cores work on.  1 where the launch is bound by throughput (the per-column launches of
+// a large batch: the other workgroups of the CU cover the wait); 4 inside k_chol_resident, whose downdate tiles are few and LATE -- a tile is
+// 13 dependent 2 us fetches of Y written on other XCDs a moment ago, against 0.3 us of MFMAs per chunk.
+template <typename T, int TS, int DEPTH = 1>
 EQF_DI void downdateTile(const UpdArgs& a, int nt, int b, int tileIdx, T* lds) {
     constexpr int WM = TS / 32;  // MFMA tiles per wave and dimension
     const Glob& g = a.g[b];
@@ -663,39 +666,130 @@ EQF_DI void downdateTile(const UpdArgs& a, int nt, int b, int tileIdx, T* lds) {
     // staging assignment: thread -> row tid / 8 (0..31), PT consecutive columns starting at PT * (tid % 8)
     constexpr int PT = TS / 8;
     const int sr = tid >> 3, sc = (tid & 7) * PT;
-    double pi[PT], pj[PT];
-    auto fetch = [&](int k0) {
-        const double* yr = Y + (long long)(k0 + sr) * ldY;
+    if constexpr (TS == 64) {
+        // ---- 64 x 64 tiles (round 3): chunks of 16 rows of Y, two LDS buffers (one barrier per chunk), four chunks in flight in
+        // registers.  Layout chosen for the LDS, whose pipe a 2 x 2 wave tile keeps busy a quarter of the time at the full MFMA rate:
+        // row pitch 80 doubles (= 16 modulo the 32-double bank window), so the two k rows a half-wavefront reads for an MFMA operand fall
+        // on disjoint banks (pitch 65 made every operand read a 2-way conflict: SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE), and a
+        // half-wavefront stages one whole 64-value row (lane l: columns 2 l, 2 l + 1 -- one 512-byte global read, one conflict-free write).
+        constexpr int KC2 = 16, PITCH = 80, D = 4;
+        static_assert(2 * 2 * KC2 * PITCH >= TS * (TS + 1), "the epilogue's transposed tile lives in the same LDS");
+        const int h = lane >> 5, c2 = 2 * (lane & 31);
+        const bool fastI = I0 > 11 && I0 + TS <= nv, fastJ = J0 > 11 && J0 + TS <= nv;
+        typedef double f64x2u __attribute__((ext_vector_type(2), aligned(8)));
+        double pa[D][4], pb[D][4];
+        auto fetch2 = [&](int d, int chunk) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < PT; ++q) {
-            const int ci = I0 + sc + q, cj = J0 + sc + q;
-            // column 11 of Y holds z, not C*Sigma: rows/cols 11 of Sigma are structurally zero
-            pi[q] = (ci < nv && ci != 11) ? yr[ci] : 0.0;
-            pj[q] = (cj < nv && cj != 11) ? yr[cj] : 0.0;
-        }
-    };
-    fetch(0);
-    for (int k0 = 0; k0 < mp; k0 += KC) {
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < PT; ++q) {
-            sI[sr][sc + q] = (T)pi[q];
-            sJ[sr][sc + q] = (T)pj[q];
-        }
-        __syncthreads();
-        if (k0 + KC < mp) fetch(k0 + KC);
-#pragma unroll
-        for (int s = 0; s < KC / 4; ++s) {
-            T av[WM], bv[WM];
-#pragma unroll
-            for (int u = 0; u < WM; ++u) {
-                av[u] = sI[4 * s + lk][16 * WM * qi + 16 * u + lr];
-                bv[u] = sJ[4 * s + lk][16 * WM * qj + 16 * u + lr];
+            for (int j = 0; j < 2; ++j) {
+                const double* yr = Y + (long long)(chunk * KC2 + 4 * wv + 2 * j + h) * ldY;
+                if (fastI) {
+                    const f64x2u v = *reinterpret_cast<const f64x2u*>(yr + I0 + c2);
+                    pa[d][2 * j] = v.x; pa[d][2 * j + 1] = v.y;
+                } else {
+                    // column 11 of Y holds z, not C*Sigma: rows/cols 11 of Sigma are structurally zero
+                    const int ci = I0 + c2;
+                    pa[d][2 * j] = (ci < nv && ci != 11) ? yr[ci] : 0.0;
+                    pa[d][2 * j + 1] = (ci + 1 < nv && ci + 1 != 11) ? yr[ci + 1] : 0.0;
+                }
+                if (fastJ) {
+                    const f64x2u v = *reinterpret_cast<const f64x2u*>(yr + J0 + c2);
+                    pb[d][2 * j] = v.x; pb[d][2 * j + 1] = v.y;
+                } else {
+                    const int cj = J0 + c2;
+                    pb[d][2 * j] = (cj < nv && cj != 11) ? yr[cj] : 0.0;
+                    pb[d][2 * j + 1] = (cj + 1 < nv && cj + 1 != 11) ? yr[cj + 1] : 0.0;
+                }
             }
+        };
+        auto stage2 = [&](int d, int buf) __attribute__((always_inline)) {
 #pragma unroll
-            for (int u = 0; u < WM; ++u)
+            for (int j = 0; j < 2; ++j) {
+                const int r = 4 * wv + 2 * j + h;
+                T* da = lds + ((buf * 2 + 0) * KC2 + r) * PITCH + c2;
+                T* db = lds + ((buf * 2 + 1) * KC2 + r) * PITCH + c2;
+                da[0] = (T)pa[d][2 * j]; da[1] = (T)pa[d][2 * j + 1];
+                db[0] = (T)pb[d][2 * j]; db[1] = (T)pb[d][2 * j + 1];
+            }
+        };
+        const int nc = mp / KC2;  // (mp is a multiple of 64)
 #pragma unroll
-                for (int v = 0; v < WM; ++v) acc[u][v] = MF::mfma(av[u], bv[v], acc[u][v]);
+        for (int d = 0; d < D; ++d)
+            if (d < nc) fetch2(d, d);
+        stage2(0, 0);
+        if (D < nc) fetch2(0, D);
+        __syncthreads();
+        for (int c0 = 0; c0 < nc; c0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int c = c0 + d;
+                if (c < nc) {  // (uniform)
+                    const int nd = (d + 1) % D;
+                    if (c + 1 < nc) {
+                        stage2(nd, (c + 1) & 1);
+                        if (c + 1 + D < nc) fetch2(nd, c + 1 + D);
+                    }
+                    const T* sa = lds + ((c & 1) * 2 + 0) * KC2 * PITCH + 16 * WM * qi + lr;
+                    const T* sb = lds + ((c & 1) * 2 + 1) * KC2 * PITCH + 16 * WM * qj + lr;
+#pragma unroll
+                    for (int s = 0; s < KC2 / 4; ++s) {
+                        T av[WM], bv[WM];
+#pragma unroll
+                        for (int u = 0; u < WM; ++u) {
+                            av[u] = sa[(4 * s + lk) * PITCH + 16 * u];
+                            bv[u] = sb[(4 * s + lk) * PITCH + 16 * u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < WM; ++u)
+#pragma unroll
+                            for (int v = 0; v < WM; ++v) acc[u][v] = MF::mfma(av[u], bv[v], acc[u][v]);
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+    } else {
+        double pi[DEPTH][PT], pj[DEPTH][PT];
+        auto fetch = [&](int d, int k0) __attribute__((always_inline)) {
+            const double* yr = Y + (long long)(k0 + sr) * ldY;
+    #pragma unroll
+            for (int q = 0; q < PT; ++q) {
+                const int ci = I0 + sc + q, cj = J0 + sc + q;
+                // column 11 of Y holds z, not C*Sigma: rows/cols 11 of Sigma are structurally zero
+                pi[d][q] = (ci < nv && ci != 11) ? yr[ci] : 0.0;
+                pj[d][q] = (cj < nv && cj != 11) ? yr[cj] : 0.0;
+            }
+        };
+    #pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (d * KC < mp) fetch(d, d * KC);
+        for (int k0 = 0; k0 < mp; k0 += KC * DEPTH) {
+    #pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const int kk = k0 + d * KC;
+                if (kk < mp) {  // (uniform)
+                    __syncthreads();
+    #pragma unroll
+                    for (int q = 0; q < PT; ++q) {
+                        sI[sr][sc + q] = (T)pi[d][q];
+                        sJ[sr][sc + q] = (T)pj[d][q];
+                    }
+                    __syncthreads();
+                    if (kk + KC * DEPTH < mp) fetch(d, kk + KC * DEPTH);
+    #pragma unroll
+                    for (int s = 0; s < KC / 4; ++s) {
+                        T av[WM], bv[WM];
+    #pragma unroll
+                        for (int u = 0; u < WM; ++u) {
+                            av[u] = sI[4 * s + lk][16 * WM * qi + 16 * u + lr];
+                            bv[u] = sJ[4 * s + lk][16 * WM * qj + 16 * u + lr];
+                        }
+    #pragma unroll
+                        for (int u = 0; u < WM; ++u)
+    #pragma unroll
+                            for (int v = 0; v < WM; ++v) acc[u][v] = MF::mfma(av[u], bv[v], acc[u][v]);
+                    }
+                }
+            }
         }
     }
     // ---- epilogue.  Every read of Sigma_in is issued before the first write of Sigma_out (a load the compiler cannot prove
@@ -765,6 +859,6 @@ __global__ __launch_bounds__(256) void k_downdate(UpdArgs a, int nt, int withFin
     downdateTile<T, TS>(a, nt, b, (int)blockIdx.x, reinterpret_cast<T*>(sBufDd));
 }
 template <typename T, int TS>
-constexpr int downdateLdsBytes() { return int(sizeof(T)) * 2 * 32 * (TS + 1); }
+constexpr int downdateLdsBytes() { return int(sizeof(T)) * (TS == 64 ? 2 * 2 * 16 * 80 : 2 * 32 * (TS + 1)); }
 
 }  // namespace eqf

@@ -38,3 +38,10 @@ if w[5] > 0:
     t0 = t[1, [R for R in range(1, 15) if t[1, R, 8] > 0][0], 0]
     print("last right-hand-side workgroup of the E-chain (lift): ready, D flag seen, solved, published, sums collected, lift done")
     print("   ", " ".join(f"{(w[i] - t0) / 100.0:7.2f}" for i in range(6)))
+
+x = t[0, 15]
+if x[0] > 0:
+    t0 = t[1, [R for R in range(1, 15) if t[1, R, 8] > 0][0], 0]
+    print("downdate tiles 0 / 27 / 54 as workgroups of their own (grid larger than the chip): dispatched, last Y tile seen, done")
+    for k in range(3):
+        print("   ", " ".join(f"{(x[3 * k + i] - t0) / 100.0:7.2f}" for i in range(3)))
