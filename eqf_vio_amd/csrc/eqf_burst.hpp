@@ -960,17 +960,18 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
             }
         }
     };
-    // R > 1: the same arithmetic, element by element in the same order, with the row constants as SCALAR operands.  A step's 4 x 45
-    // constants are consumed as 20 chunks of nine (D_i, Lw_i, Lv_i for the four rows, then Gn_i, then Gv_i), two chunks to a group;
+    // R > 1: the same arithmetic, element by element in the same order, with the row constants as SCALAR operands.  A step's R x 45
+    // constants are consumed as 5 R chunks of nine (D_i, Lw_i, Lv_i for the R rows, then Gn_i, then Gv_i), two chunks to a group;
     // group g + 1 is requested once group g has arrived and before its 54 FMAs per lane are issued (scalar loads return out of order,
     // so the only wait there is is "all of them": a request must never be outstanding when the previous group is waited for).
     auto mathS = [&](int st) __attribute__((always_inline)) {
-      if constexpr (R == 4) {
+      if constexpr (R > 1) {
+        static_assert(R == 1 || R % 2 == 0, "5 R chunks in groups of two");
         const int sl = st & 1;
         CT* const base = rowC + (long long)st * cap * kBlkRec;
         auto chunkPtr = [&](int c) __attribute__((always_inline)) {
-            const int i = c < 12 ? c / 3 : (c - 12) & 3;
-            const int off = c < 12 ? 9 * (c % 3) : (c < 16 ? 27 : 36);
+            const int i = c < 3 * R ? c / 3 : (c - 3 * R) % R;
+            const int off = c < 3 * R ? 9 * (c % 3) : (c < 4 * R ? 27 : 36);
             return base + min(i, nIu - 1) * kBlkRec + off;
         };
         T buf[2][18];
@@ -990,7 +991,7 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
         T H[9], cst[18];
         const T TtP = sTtP[st];
         auto chunk = [&](int c, const T* k9) __attribute__((always_inline)) {
-            if (c < 12) {
+            if (c < 3 * R) {
                 const int i = c / 3, part = c % 3;
                 const T* src = part == 0 ? S[i] : cst + 9 * (part - 1);  // S_i, Sw, Sv
 #pragma unroll
@@ -1007,7 +1008,7 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
                     for (int k = 0; k < 9; ++k) S[i][k] = H[k];
                 }
             } else {
-                const int i = (c - 12) & 3;
+                const int i = (c - 3 * R) % R;
 #pragma unroll
                 for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
@@ -1026,11 +1027,11 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
             cst[9 + k] = sCol[sl][36 + k][lane];
         }
 #pragma unroll
-        for (int g = 0; g < 10; ++g) {
+        for (int g = 0; g < 5 * R / 2; ++g) {
             arrived(g);
-            if (g + 1 < 10) request(g + 1);
+            if (g + 1 < 5 * R / 2) request(g + 1);
             __builtin_amdgcn_sched_barrier(0);
-            if (g == 6) {
+            if (g == 3 * R / 2) {
                 // all of H_i = D_i S_i + Lw_i Sw + Lv_i Sv are in place: S_i' = H_i D_J^T (+ the landmark process noise on the diagonal)
 #pragma unroll
                 for (int k = 0; k < 9; ++k) cst[k] = sCol[sl][k][lane];
@@ -1053,7 +1054,7 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
 #pragma unroll
                 for (int k = 0; k < 9; ++k) cst[k] = sCol[sl][9 + k][lane];  // Lw_J, for + Gn_i Lw_J^T
             }
-            if (g == 8) {
+            if (g == 2 * R) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) cst[k] = sCol[sl][18 + k][lane];  // Lv_J, for + Gv_i Lv_J^T
             }

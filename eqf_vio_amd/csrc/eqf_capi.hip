@@ -127,7 +127,7 @@ struct eqf_filter {
     // full, when the vision call that follows them arrives (whose integrateUpToTime joins the burst), or when the host
     // touches the handle in any other way.  burstMax = 0: every call launches at once through k_propagate.
     int burstMax = kBurstMax;      // EQF_IMU_BURST / eqf_set_imu_burst
-    int burstRows = 0;             // block kernel: row landmarks per wavefront, 0 = by launch size (EQF_BURST_ROWS = 1 | 4)
+    int burstRows = 0;             // block kernel: row landmarks per wavefront, 0 = by launch size (EQF_BURST_ROWS = 1 | 2 | 4)
     int burstLm = 0;               // builder: landmarks per workgroup, 0 = by launch size (EQF_BURST_LM = 4 | 16)
     struct {
         int kind = 0;              // 0 nothing pending, 1 records k0 .. k0+cnt-1 of the uploaded stream, 2 inline records (one filter)
@@ -467,7 +467,11 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     // like four rows but half their reuse -- measured slower than both at every size, N = 200 x 2..64 filters, N = 400..4000.)
     const long long waves1 = (long long)((nmx + 63) / 64) * nmx * f->B;
     // (cross-over measured on the 256-CU part at 2800 wave-blocks = 11 per CU: four filters of N = 200, N >= 400)
-    const int R = f->burstRows ? f->burstRows : (waves1 <= 11LL * cus ? 1 : 4);
+    // (in between -- the four-row tiles of the launch would not even give every CU two workgroups: 4 .. 12 filters of N = 200 -- two rows per
+    // wavefront, twice the workgroups: 4 filters 62.8 -> 51.4 us per burst, 8: 75.7 -> 71.1, 12: 94.0 -> 89.6; 16: 101 -> 106)
+    int rowTiles4 = 0;
+    const int R = f->burstRows ? f->burstRows
+                               : (waves1 <= 11LL * cus ? 1 : ((long long)ringTiles(nmx, 4, &rowTiles4) * f->B <= 3LL * cus / 2 ? 2 : 4));
     const dim3 rgrid(ringTiles(nmx, R, &a.ringBy), f->B);  // (the tiles on and below the diagonal)
     // every filter past its lazy initialisation (VIOFilter.cpp:122-124): the schedule with the precomputed step halves
     const bool fast = allDevInit(f);
@@ -481,6 +485,7 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
             if (nmx > 0) {
                 // (the four wavefronts of a workgroup share a step's column constants through an LDS ring)
                 if (R == 1) hipLaunchKernelGGL((k_burst_riccati_ring<TT, 1>), rgrid, dim3(256), 0, f->stream, a);
+                else if (R == 2) hipLaunchKernelGGL((k_burst_riccati_ring<TT, 2>), rgrid, dim3(256), 0, f->stream, a);
                 else hipLaunchKernelGGL((k_burst_riccati_ring<TT, 4>), rgrid, dim3(256), 0, f->stream, a);
             }
         };
@@ -1255,7 +1260,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (!rc && hipMalloc(&f->dColRec, f->esz * (size_t)kBurstMax * kColRec * cap * B) != hipSuccess) rc = EQF_ERR_HIP;
     if (!rc && hipMalloc(&f->dRowRec, f->esz * (size_t)kBurstMax * kBlkRec * cap * B) != hipSuccess) rc = EQF_ERR_HIP;
     chk(dmalloc(&f->dSteps, (size_t)kBurstMax * B));
-    if (const char* e = std::getenv("EQF_BURST_ROWS")) f->burstRows = (std::atoi(e) == 1 || std::atoi(e) == 4) ? std::atoi(e) : 0;
+    if (const char* e = std::getenv("EQF_BURST_ROWS")) f->burstRows = (std::atoi(e) == 1 || std::atoi(e) == 2 || std::atoi(e) == 4) ? std::atoi(e) : 0;
     if (const char* e = std::getenv("EQF_BURST_LM")) f->burstLm = std::atoi(e) == 16 ? 16 : (std::atoi(e) == 4 ? 4 : 0);
     if (const char* e = std::getenv("EQF_IMU_BURST")) f->burstMax = std::max(0, std::min(kBurstMax, std::atoi(e)));
     if (const char* e = std::getenv("EQF_SPLIT_PROPAGATE")) f->splitPropagate = std::atoi(e);

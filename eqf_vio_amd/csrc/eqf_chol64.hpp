@@ -31,7 +31,7 @@
 namespace eqf {
 
 constexpr int kSB = 64;        // block-column width
-constexpr int kSP = kSB + 1;   // LDS pitch of a 64x64 tile
+constexpr int kSP = kSB + 1;   // LDS pitch of a 64x64 tile  (kSB + 2 would make the MFMA operand reads conflict-free: measured, one filter +3 us -- the column accesses of the pivot chain want the odd pitch -- batches within noise)
 constexpr int kQB = 16;        // sub-block (one MFMA tile)
 constexpr int kWP = kQB + 1;   // LDS pitch of a 16x16 inverse block
 constexpr int kDRec = kSB * kSB + 4 * kQB * kQB;  // doubles per diagonal-factor record in ChainArgs::D:
