@@ -847,10 +847,13 @@ def test_imu_bursts_equal_single_step_launches(hip, N, monkeypatch):
         assert np.array_equal(o[2], full[2])
     # the block kernel with four row landmarks per wavefront (large problems; EQF_BURST_ROWS forces it here): the arithmetic of the
     # one-row kernel, block by block
-    monkeypatch.setenv("EQF_BURST_ROWS", "4")
-    o = _run_bursts(hip, st, N, 15)
-    assert np.array_equal(o[0], full[0])
-    assert all(np.abs(o[1][k] - full[1][k]).max() < 1e-9 for k in full[1])
+    # (and with two: the variant for launches in between, round 3).  All three propagate the blocks on and below the diagonal only and
+    # write the others as their transposes.
+    for rows in ("4", "2"):
+        monkeypatch.setenv("EQF_BURST_ROWS", rows)
+        o = _run_bursts(hip, st, N, 15)
+        assert np.array_equal(o[0], full[0]), rows
+        assert all(np.abs(o[1][k] - full[1][k]).max() < 1e-9 for k in full[1])
     monkeypatch.delenv("EQF_BURST_ROWS")
     # the builder's two role tables (4 / 16 landmarks per workgroup; chosen by launch size): the same formulas
     outs = []
@@ -864,6 +867,38 @@ def test_imu_bursts_equal_single_step_launches(hip, N, monkeypatch):
     assert rel_fro(full[0], ref[0]) < 1e-9
     assert all(np.abs(full[1][k] - ref[1][k]).max() < 1e-9 for k in ref[1])
     assert np.abs(full[2] - ref[2]).max() < 1e-9
+
+
+@pytest.mark.parametrize("N,rows", [(70, "1"), (70, "2"), (130, "4")])
+def test_burst_leaves_the_landmark_block_exactly_symmetric(hip, N, rows, monkeypatch):
+    """The burst block kernel propagates the 3x3 blocks on and below the diagonal and writes the others as their transposes
+    (csrc/eqf_burst.hpp, round 3): after IMU steps that follow an update -- whose downdate leaves Sigma symmetric to rounding only --
+    the off-diagonal 3x3 blocks of Sigma[11:, 11:] are transposes of each other bit for bit, for every tile shape, and still agrees with the single-step kernels to rounding."""
+    from eqf_vio_amd import synth
+
+    st = synth.make_stream(N, duration=0.3)
+    ev = list(st.events())
+    vis = [i for i, (kind, _) in enumerate(ev) if kind == "vision"]
+    ev = ev[: vis[-2] + 6]  # five IMU calls after an update
+    assert ev[-1][0] == "imu"
+    outs = {}
+    for burst in (15, 0):
+        monkeypatch.setenv("EQF_BURST_ROWS", rows)
+        f = hip.FilterBatch(synth.template_settings_dict(), capacity=N, batch=1)
+        f.set_imu_burst(burst)
+        f.stream_upload(st.imu, st.vision_stamps, st.ids, st.bearings)
+        for kind, k in ev:
+            (f.stream_imu if kind == "imu" else f.stream_vision)(k)
+        outs[burst] = f.sigma()
+        assert f.device_error() == 0
+    monkeypatch.delenv("EQF_BURST_ROWS")
+    S = outs[15]
+    L = S[11:, 11:].copy()
+    for i in range(N):  # (the 3x3 blocks ON the diagonal are propagated whole, like every other block: symmetric to rounding)
+        L[3 * i:3 * i + 3, 3 * i:3 * i + 3] = 0.0
+    assert np.array_equal(L, L.T)
+    assert np.abs(S - S.T).max() < 1e-12 * np.abs(S).max()
+    assert rel_fro(S, outs[0]) < 1e-9
 
 
 def test_imu_bursts_with_irregular_stamps_and_fp32(hip):
