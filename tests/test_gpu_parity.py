@@ -657,11 +657,13 @@ def test_update_launch_layouts_give_the_same_bits(hip, monkeypatch):
             assert np.array_equal(o[0][b], ref[0][b]), (Ns, "copy", b)
 
 
-@pytest.mark.parametrize("Ns", [(70,), (200,), (30, 70), (9, 64, 21)])
+@pytest.mark.parametrize("Ns", [(70,), (200,), (30, 70), (9, 64, 21), (200,) * 8, (200, 150, 64, 200, 120, 200)])
 def test_resident_update_kernel_equals_the_per_column_launches(oracle_lib, hip, monkeypatch, Ns):
     """k_chol_resident (the whole factorisation part of an update as ONE launch: tiles resident in registers, solved blocks and
     diagonal factors handed over inside the launch) against the per-column launches of k_chol_step64 (EQF_CHOL_RESIDENT=0) and
-    against the oracle, single filters and ragged batches (chains of different lengths inside one launch)."""
+    against the oracle, single filters and ragged batches (chains of different lengths inside one launch).  The batches of N = 200
+    put the kernel on a grid several times larger than the chip (round 3): interleaved dispatch, row heads with the pipelined panel
+    loop, the downdate tiles as workgroups of their own at the end of the grid."""
     from eqf_vio_amd import synth
 
     B = len(Ns)
