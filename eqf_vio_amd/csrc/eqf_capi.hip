@@ -155,6 +155,7 @@ struct eqf_filter {
     double *dGammaPart = nullptr, *dG11Part = nullptr;
     ResRole* dRoles = nullptr;
     int resPipeHeads = -1;         // EQF_RES_PIPEH: row heads with the pipelined panel loop (1), without (0), by grid size (-1)
+    int prepOcc2 = -1;             // EQF_PREP_OCC2: the prep launch built for two workgroups per CU (1), one (0), by launch size (-1)
     int rolesN = -1, rolesCount = 0;  // chain shape (nbS, nbE, wtS) the role table was built for
     // profiling
     bool prof = false;
@@ -639,8 +640,10 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     cS.flags = f->dFlags; cS.strideF = 2 * f->flagStride; cS.epoch = f->updateEpoch;
     cE.flags = f->dFlags + f->flagStride; cE.strideF = 2 * f->flagStride; cE.epoch = f->updateEpoch;
     if (!attrSet64) {
-        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<double, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attrSet64 = true;
     }
     // ---- which shape the factorisation launches will have (decided here: the prep launch needs to know whether anybody reads EA's
@@ -679,8 +682,13 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     rc = profiled(f, EQF_PROF_UPDATE_PREP, [&] {
         // the landmark waves + E-chain operand + two more workgroups per filter that factor the first diagonal block of each chain
         // straight from Sigma (one launch: measured never slower than a separate factor launch, 4..64 filters)
-        hipLaunchKernelGGL(k_update_prep64<T>, dim3(lmBlocks + eBlocks + 2, B), dim3(256), std::max(lds, sizeof(Step64Lds)), f->stream, a, cS, cE,
-            lmBlocks, eBlocks, wpb, nvPad);
+        const bool occ2 = f->prepOcc2 >= 0 ? f->prepOcc2 != 0 : (B >= 4 && (long long)(lmBlocks + eBlocks + 2) * B > f->numCUs);
+        if (occ2)
+            hipLaunchKernelGGL((k_update_prep64<T, true>), dim3(lmBlocks + eBlocks + 2, B), dim3(256), std::max(lds, (size_t)kLdsFactorBytes), f->stream, a,
+                cS, cE, lmBlocks, eBlocks, wpb, nvPad);
+        else
+            hipLaunchKernelGGL((k_update_prep64<T, false>), dim3(lmBlocks + eBlocks + 2, B), dim3(256), std::max(lds, (size_t)kLdsFactorBytes), f->stream, a,
+                cS, cE, lmBlocks, eBlocks, wpb, nvPad);
     });
     if (rc) return rc;
     // downdate tiling: 64x64 tiles when they fill the chip, 32x32 tiles (4x the workgroups) for a single small filter
@@ -1272,6 +1280,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (const char* e = std::getenv("EQF_RES_STAGED")) f->resStaged = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_OVERSUB")) f->resOversub = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("EQF_E_FROM_SIGMA")) f->eFromSigma = std::atoi(e);
+    if (const char* e = std::getenv("EQF_PREP_OCC2")) f->prepOcc2 = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_PIPEH")) f->resPipeHeads = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_ORDER")) f->cholOrder = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_STREAMS")) f->cholStreams = std::max(0, std::atoi(e));

@@ -66,6 +66,15 @@ EQF_DI Lds64 ldsFull(unsigned char* smem) {
     Step64Lds* f = reinterpret_cast<Step64Lds*>(smem);
     return Lds64{f->P, f->Q, f->L, f->Wd, f->D0, f->Zs, f->redL, nullptr};
 }
+// what factor64 alone needs (the first diagonal blocks, factored inside the prep launch): L | Wd | D0   (44 KB)
+constexpr int kLdsFactorBytes = int(sizeof(double)) * (kSB * kSP + 4 * kQB * kWP + kQB * kWP);
+EQF_DI Lds64 ldsFactor(unsigned char* smem) {
+    double* d = reinterpret_cast<double*>(smem);
+    double (*L)[kSP] = reinterpret_cast<double (*)[kSP]>(d);
+    double (*Wd)[kQB][kWP] = reinterpret_cast<double (*)[kQB][kWP]>(d + kSB * kSP);
+    double (*D0)[kWP] = reinterpret_cast<double (*)[kWP]>(d + kSB * kSP + 4 * kQB * kWP);
+    return Lds64{nullptr, nullptr, L, Wd, D0, nullptr, nullptr, nullptr};
+}
 EQF_DI Lds64 ldsUpdate(unsigned char* smem) {
     double* d = reinterpret_cast<double*>(smem);
     double (*Q)[kSP] = reinterpret_cast<double (*)[kSP]>(d);
@@ -443,8 +452,12 @@ __device__ long long g_prepStamps[512][2];  // per workgroup: first / last cycle
 #else
 #define EQF_PREPSTAMP(k) do { } while (0)
 #endif
-template <typename T>
-__global__ __launch_bounds__(256) void k_update_prep64(UpdArgs a, ChainArgs cS, ChainArgs cE, int lmBlocks, int eBlocks, int wpb, int nvPad) {
+// OCC2: compiled for two workgroups per CU (256 registers instead of 268: 60 bytes of scratch in the first-block workgroups) and launched
+// with the 44 KB LDS the landmark waves / factor64 need instead of the 119 KB image -- for batches whose prep launch is larger than the
+// chip (4 filters of N = 200 on: 16 filters 55 -> 47 us, 64 filters 166 -> 122 us).  One or two filters keep the one-per-CU build: there the
+// two first-block workgroups ARE the launch's critical path and the spill costs them 1.8 us (12.5 -> 14.3 us).
+template <typename T, bool OCC2 = false>
+__global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_update_prep64(UpdArgs a, ChainArgs cS, ChainArgs cE, int lmBlocks, int eBlocks, int wpb, int nvPad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
     const int role = (int)blockIdx.x - (lmBlocks + eBlocks);
     EQF_PREPSTAMP(0);
@@ -455,7 +468,7 @@ __global__ __launch_bounds__(256) void k_update_prep64(UpdArgs a, ChainArgs cS, 
         return;
     }
     int bad = 0;
-    factorFirstFromSigma<T>(a, role == 0 ? cS : cE, blockIdx.y, ldsFull(smem64), &bad);
+    factorFirstFromSigma<T>(a, role == 0 ? cS : cE, blockIdx.y, ldsFactor(smem64), &bad);
     if (bad && a.errflag && threadIdx.x == 0) atomicOr(a.errflag, 4);
     __syncthreads();
     EQF_PREPSTAMP(1);
