@@ -271,8 +271,10 @@ EQF_DI void burstCommonCam(StepCommon& c, const StepPre& pr, const Params& p) {
 // chain): wave 4 runs stepGlobal on the LDS copy of the scalar state, wave 5 stepCommon + F_bb of step t -- the functions of
 // eqf_propagate.hpp as they are (Sigma_bb after step t-1 by wave 4 / wave 2).  Both schedules do the same arithmetic per step.
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool FAST, int LM>
-__global__ __launch_bounds__(kBuildThreads) void k_burst_build(BurstArgs a) {
+// OCC2 (LM = 16 only): built for two workgroups per CU -- 128 instead of 169 registers -- for launches with more workgroups than CUs
+// (from 20 filters of N = 200 on): every workgroup is a chain of ticks bound by latency, a second one on the CU runs in its gaps.
+template <typename T, bool FAST, int LM, bool OCC2 = false>
+__global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(OCC2 ? 4 : 2, OCC2 ? 4 : 2))) void k_burst_build(BurstArgs a) {
     static_assert(LM == 4 || LM == 16, "role tables exist for 4 and 16 landmarks per workgroup");
     constexpr bool kSpread = LM == 4;  // one panel wave: the Lw blocks and Sigma_bb get wavefronts of their own
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;

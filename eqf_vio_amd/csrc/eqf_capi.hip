@@ -156,6 +156,7 @@ struct eqf_filter {
     ResRole* dRoles = nullptr;
     int resPipeHeads = -1;         // EQF_RES_PIPEH: row heads with the pipelined panel loop (1), without (0), by grid size (-1)
     int prepOcc2 = -1;             // EQF_PREP_OCC2: the prep launch built for two workgroups per CU (1), one (0), by launch size (-1)
+    int burstOcc2 = -1;            // EQF_BURST_OCC2: the 16-landmark builder built for two workgroups per CU (1), one (0), by launch size (-1)
     int rolesN = -1, rolesCount = 0;  // chain shape (nbS, nbE, wtS) the role table was built for
     // profiling
     bool prof = false;
@@ -463,6 +464,7 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     const int cus = std::max(f->numCUs, 1);
     const int lm = f->burstLm ? f->burstLm : ((long long)((nmx + 3) / 4) * f->B <= cus ? 4 : 16);
     const dim3 bgrid(std::max(1, (nmx + lm - 1) / lm), f->B);
+    const bool occ2 = f->burstOcc2 >= 0 ? f->burstOcc2 != 0 : (lm == 16 && (long long)bgrid.x * bgrid.y > cus);
     // rows per wavefront of the block kernel: one while the launch cannot fill the chip anyway (latency), four once the
     // column constants of a lane are worth sharing between several of its blocks.  (Two rows: 286 VGPRs, one wave per SIMD
     // like four rows but half their reuse -- measured slower than both at every size, N = 200 x 2..64 filters, N = 400..4000.)
@@ -480,6 +482,7 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
         auto go = [&](auto zero) {
             typedef decltype(zero) TT;
             if (fast && lm == 4) hipLaunchKernelGGL((k_burst_build<TT, true, 4>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
+            else if (fast && occ2) hipLaunchKernelGGL((k_burst_build<TT, true, 16, true>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
             else if (fast) hipLaunchKernelGGL((k_burst_build<TT, true, 16>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
             else if (lm == 4) hipLaunchKernelGGL((k_burst_build<TT, false, 4>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
             else hipLaunchKernelGGL((k_burst_build<TT, false, 16>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
@@ -1280,6 +1283,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (const char* e = std::getenv("EQF_RES_STAGED")) f->resStaged = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_OVERSUB")) f->resOversub = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("EQF_E_FROM_SIGMA")) f->eFromSigma = std::atoi(e);
+    if (const char* e = std::getenv("EQF_BURST_OCC2")) f->burstOcc2 = std::atoi(e);
     if (const char* e = std::getenv("EQF_PREP_OCC2")) f->prepOcc2 = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_PIPEH")) f->resPipeHeads = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_ORDER")) f->cholOrder = std::atoi(e);
