@@ -10,7 +10,8 @@
 //     Sigma'_IJ = (D_I Sigma_IJ + L_I Sigma_bJ) D_J^T + G_I L_J^T     needs its own block and the panels of I and J
 // so the 11-wide base panels evolve on their own (k_burst_build, one workgroup per 4 or 16 landmarks, which also runs the
 // scalar state chain and the landmark group steps and leaves, per step and landmark, a 63-value record), and each 3x3
-// landmark block then runs all K steps in registers from those records (k_burst_riccati / k_burst_riccati_ring).
+// landmark block then runs all K steps in registers from those records (k_burst_riccati_ring).  Only the blocks with I >= J are
+// propagated; the others are written as their transposes (round 3).
 //
 // The per-step arithmetic does not depend on how the calls are cut into bursts: a filter replayed with other burst
 // boundaries (e.g. after eqf_dump / restore) produces the same bits.
@@ -796,7 +797,8 @@ inline int ringTiles(int nmx, int R, int* rowTiles) {
     return t;
 }
 constexpr int kRingTrips = 12;  // column-constant rows per wave and step: 45 rows over 4 waves
-// R = row landmarks per wavefront: 1 for the small launches described above; 4 for launches that fill the chip -- there the point
+// R = row landmarks per wavefront: 1 for the small launches described above; 4 for launches that fill the chip (2 in between: twice the
+// workgroups of 4, for launches whose four-row tiles would leave CUs with one workgroup or none) -- there the point
 // of the ring is that the 45 x 64 column constants of a step are fetched ONCE per workgroup (16 row landmarks) instead of once per
 // wavefront, and that a lane holds 13 + 3 prefetched values per register set instead of 46: 2 wavefronts per SIMD instead of 1.
 // grid = (ringTiles(N, R), B).
