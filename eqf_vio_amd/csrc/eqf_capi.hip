@@ -143,7 +143,7 @@ struct eqf_filter {
     int updateEpoch = 0;           // one per launchUpdate
     // k_chol_resident (one launch per update while the grid fits the chip): EQF_CHOL_RESIDENT = 0 switches it off
     int cholResident = 1;
-    int resOversub = 10;           // EQF_RES_OVERSUB: roles per CU up to which a batch uses the resident kernel (interleaved grid, downdate tiles as workgroups of their own)
+    int resOversub = -1;           // EQF_RES_OVERSUB: roles per CU up to which the resident kernel is used on a grid larger than the chip; -1 = 10 + 16 / batch
     int resStaged = 1;             // row heads consume D[R-1] stage by stage (EQF_RES_STAGED = 0: whole record after its last pivot)
     int residentPerCU = -1;        // hipOccupancyMaxActiveBlocksPerMultiprocessor of k_chol_resident on this device (lazily queried)
     int eFromSigma = 1;            // split chain: block column 0 of the E-chain read straight from Sigma (EQF_E_FROM_SIGMA=0: copied by prep)
@@ -679,7 +679,13 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         // 4: 124.9 k -> 184 k, 8: 217.6 k -> 259.3 k, 12: 241.8 k -> 281.7 k, 16: 299.7 k -> 305.0 k; from 24 filters on the per-column
         // launches win (331.3 k against 311.5 k).  EQF_RES_OVERSUB = the
         // number of roles per CU up to which the resident kernel is used (default 10: up to 16 filters of N = 200; 0 = only when co-resident).
-        resident = f->cholResident >= 2 || residentFits || (long long)f->rolesCount * B <= (long long)f->resOversub * f->numCUs;
+        // ... and the same for ONE filter several times the size the kernel was written for: per-column launches of a single filter sit on
+        // the latency floor of the diagonal workgroup (23-35 us per block column), the resident kernel's period stays near the pivot
+        // chain's.  Measured break-even in roles per CU: one filter ~26 (N = 600: 11.7 k -> 20.1 k steps/s, N = 1000: 5.2 k -> 6.4 k,
+        // N = 1200: 3.64 k -> 4.08 k, N = 1500 even), 4 filters ~18 (N = 600 +9 %), 8 filters ~16 (N = 400 even), 24 filters < 13.7
+        // (N = 200: per-column launches win).  Default: 10 + 16 / batch.
+        const long long oversub = f->resOversub >= 0 ? f->resOversub : 10 + 16 / B;
+        resident = f->cholResident >= 2 || residentFits || (long long)f->rolesCount * B <= oversub * f->numCUs;
     }
     a.eFromSigma = (!resident && splitChain && f->cholTail && f->eFromSigma && f->precision != EQF_PRECISION_F32) ? 1 : 0;
     rc = profiled(f, EQF_PROF_UPDATE_PREP, [&] {
@@ -1294,11 +1300,11 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
         if (!rc) f->numCUs = prop.multiProcessorCount;
         f->nbCap = std::max(mpC, nepC) / kSB;
         f->wtCap = ycC / kSB;
-        // the resident kernel is for small filters (its role table holds one workgroup per 64 x 64 tile): its buffers are only allocated
-        // while a filter has at most a few hundred roles (N <= ~330); the batch may be larger than the chip (interleaved grid, see
-        // launchUpdateT)
+        // the resident kernel's role table holds one workgroup per 64 x 64 tile: its buffers are only allocated while a filter has at
+        // most 28 roles per CU (N <= ~1500 on 256 CUs: beyond that the per-column launches win, see launchUpdateT); the batch may be
+        // larger than the chip (interleaved grid)
         const long long maxRoles = (long long)(f->nbCap + 1) * f->nbCap + (long long)f->wtCap * f->nbCap;
-        if (!rc && maxRoles <= 4LL * std::max(f->numCUs, 1) && maxRoles * B <= 64LL * std::max(f->numCUs, 1)) {
+        if (!rc && maxRoles <= 28LL * std::max(f->numCUs, 1) && maxRoles * B <= 64LL * std::max(f->numCUs, 1)) {
             chk(dmalloc(&f->dReadyA, (size_t)2 * f->nbCap * f->nbCap * B));
             chk(dmalloc(&f->dReadyY, (size_t)2 * f->nbCap * f->wtCap * B));
             chk(dmalloc(&f->dResCounters, (size_t)4 * B));
