@@ -764,12 +764,12 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
                 const int dd = (embed && k == nb64S - 1) ? ddTiles : 0;
                 if (dd) ddDone = true;
                 // workgroups per filter: 2 diagonal + the tails of block column k+1 + nStream streams over the pure updates
-                // (about two per CU over the whole launch) + the downdate tiles; see step3Counts
+                // (about two per CU over the whole launch; four for ONE large filter: N = 4000 150 -> 154 steps/s) + the downdate tiles; see step3Counts
                 int tS, uS, tE, uE;
                 step3Counts(cS.nbMax, cS.wtMax, k, &tS, &uS);
                 step3Counts(cE.nbMax, cE.wtMax, k, &tE, &uE);
                 const int nStream = f->cholStreams > 0 ? std::min(f->cholStreams, std::max(uS + uE, 1))
-                                                       : std::min(uS + uE, std::max(1, (2 * f->numCUs + B - 1) / B));
+                                                       : std::min(uS + uE, std::max(1, ((B == 1 ? 4 : 2) * f->numCUs + B - 1) / B));
                 const int tailsLast = f->cholOrder >= 0 ? f->cholOrder : 1;
                 rc = profiled(f, dd ? EQF_PROF_CHOL_DD : EQF_PROF_CHOL_STEP, [&] {
                     hipLaunchKernelGGL((k_chol_step64<T, 3>), dim3(2 + tS + tE + nStream + dd, B), dim3(256), kLdsTailBytes, f->stream, cS, cE, a,
