@@ -731,15 +731,12 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             // 64 x 64 downdate tiles: a tile costs the same 14 dependent chunk fetches whatever its size, and there are enough
             // finished workgroups to take one each
             // (a grid larger than what is co-resident must not wait for later workgroups while holding CUs: no-wait mode, see the kernel)
-            ra.ddNt = nt64; ra.ddSmall = 0;
-            // (the downdate tiles as workgroups of their own behind the roles even when the whole grid is co-resident: one filter 136.7 -> 134.8 us,
-            // and nothing waits for a higher block index any more; EQF_RES_DD_TAIL=0: finished role workgroups wait and share the tiles)
-            const char* ddTailEnv = std::getenv("EQF_RES_DD_TAIL");
-            const bool ddInRoles = residentFits && ddTailEnv && std::atoi(ddTailEnv) == 0;
-            ra.ddWait = ddInRoles ? 1 : 2;
+            ra.ddNt = nt64;
+            // (the downdate tiles are workgroups of their own behind the roles, also when the whole grid is co-resident: nothing in the kernel
+            // waits for a higher block index)
             ra.nRoles = f->rolesCount;
             ra.errflag = f->errflag;
-            const int ddGrid = ddInRoles ? 0 : nt64 * (nt64 + 1) / 2;  // downdate tiles as workgroups of their own behind the roles
+            const int ddGrid = nt64 * (nt64 + 1) / 2;  // downdate tiles as workgroups of their own behind the roles
             rc = profiled(f, EQF_PROF_CHOL_RESIDENT, [&] {
                 // (row heads with the pipelined panel loop only on a grid larger than the chip: see the kernel's PIPEH)
                 const bool pipeHeads = f->resPipeHeads >= 0 ? f->resPipeHeads != 0 : !residentFits;

@@ -50,10 +50,8 @@ struct ResArgs {
     double* gammaPart;     // [B][nbCap][ldY]   share of block row C in gamma / hV
     double* g11Part;       // [B][nbCap][128]   share of block row C in G11
     int nbCap, wtCap;
-    int ddNt, ddSmall;
+    int ddNt;              // 64 x 64 downdate tiles per edge (the tile workgroups behind the roles)
     int* errflag;
-    int ddWait;            // 1: workgroups that are done WAIT for the last Y tile, then share the downdate (whole grid co-resident);
-                           // 2: the downdate tiles are workgroups of their own, appended to the grid behind the nRoles role workgroups
     int nRoles;
     int* stageFlags;       // [B][2][nbCap][4]  stage j of D[K] of chain c is in the record (epoch valued; factor64's stageFlag)
 };
@@ -322,7 +320,7 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
     // together, dependency group by dependency group (role-major order would run the filters one after the other), and with a batch
     // that is a multiple of 8 every workgroup of filter b runs on XCD b mod 8
     if ((int)blockIdx.y >= ra.nRoles) {
-        // ---- ddWait = 2: a downdate tile of filter blockIdx.x.  These workgroups have the HIGHEST block indices: they are dispatched when
+        // ---- a downdate tile of filter blockIdx.x.  These workgroups have the HIGHEST block indices: they are dispatched when
         // the role workgroups in front of them have been, i.e. during the last block columns of the E-chain, and they wait -- for LOWER
         // block indices only -- until the S-chain's last Y tile is out (it usually is).  The downdate overlaps the tail of the longer chain.
         const int bb = blockIdx.x, tile = (int)blockIdx.y - ra.nRoles, t = threadIdx.x;
@@ -365,7 +363,7 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
     // a filter whose update is switched off (speculative outlier gate) or that has no landmarks: no factorisation work, but its
     // Sigma still has to reach the other ping-pong buffer -- the downdate loop below copies it
     const bool active = g.updateOk && g.N != 0;
-    if (!active && !(ra.ddNt > 0 && role.kind == 0)) return;  // (inactive filter: the S-chain's workgroups copy Sigma below)
+    if (!active) return;  // (its Sigma reaches the other ping-pong buffer through the downdate tile workgroups, which copy it)
     int nb, wt;
     chainDims64(ch, g.N, &nb, &wt);
     int nbS, wtS, nbE, wtE;
@@ -385,15 +383,11 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
     const int* flagD = ch.flags + (long long)b * ch.strideF;
     int* counters = ra.counters + (long long)b * 4;
     int bad = 0;
-    int finishStep = 0;  // the block column at which this workgroup's own work ends
 
-    if (!active) {
-        finishStep = 1 << 20;
-    } else if (role.role == 0) {
+    if (role.role == 0) {
         // =========================================================================================== H(R)
         const int R = role.R;
         if (R >= nb) return;
-        finishStep = R - 1;
         // tile (R, R-1): wave wv owns the 16-row strip (tiles (wv, 0..3)); tile (R, R): the lower triangle in the
         // diagonal-workgroup layout of k_chol_step64 (slot 0 = (wv, 0), the deferred tiles on waves 2, 3)
         int tr[4], tc[4], nt;
@@ -539,7 +533,6 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
         // =========================================================================================== T(R, C)
         const int R = role.R, C = role.C;
         if (R >= nb) return;
-        finishStep = C;
         const double* Tg = A + (long long)(R * kSB) * ldA + C * kSB;
         f64x4 acc[4];
 #pragma unroll
@@ -596,7 +589,6 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
         // =========================================================================================== W(t, C)
         const int t = role.R, C = role.C;
         if (t >= wt || C >= nb) return;
-        finishStep = C;
         const double* Tg = W + (long long)(C * kSB) * ldW + t * kSB;
         f64x4 acc[4];
 #pragma unroll
@@ -733,42 +725,12 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
     // downdate tiles, so Sigma_out is not overwritten with a plausible-looking wrong matrix.
     if (__syncthreads_or(bad == 8)) return;
 
-    // ---- covariance downdate Sigma - Y^T Y.
-    // ddWait = 1 (the whole grid is co-resident by the occupancy calculation -- one small filter): every workgroup that is done with its
-    //   role WAITS until all Y tiles of its filter are out, then they share the tiles from a counter -- a tile is latency-bound (14
-    //   dependent chunk fetches), so it wants many workgroups, one tile each.  This is the one wait of the kernel for workgroups with a
-    //   HIGHER block index, made while holding a CU: only safe with full co-residency.
-    // ddWait = 2 (a batch larger than the chip): the tiles are workgroups of their own at the END of the grid (above).  (Tried: finished
-    //   role workgroups take tiles only if the last Y tile is already out and leave otherwise -- no waiting at all: 2 filters 294 us
-    //   against 135 + 41 us with a follow-up launch; too few workgroups finish after the S-chain.)
-    // A wait that times out raises the sticky flag and skips the downdate (Sigma_out is left untouched).
-    if (ra.ddWait == 1 && ra.ddNt > 0 && (active || role.kind == 0)) {
-        __shared__ int sTile;
-        int late = 0;
-        if (tid == 0 && active) {
-            const long long t0 = wall_clock64();
-            while (__hip_atomic_load(counters + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nbS * wtS) {
-                __builtin_amdgcn_s_sleep(32);
-                if (wall_clock64() - t0 > 5000000LL) {
-                    if (ra.errflag) atomicOr(ra.errflag, 8);
-                    late = 1;
-                    break;
-                }
-            }
-        }
-        if (__syncthreads_or(late)) return;
-        const int ddTiles = ra.ddNt * (ra.ddNt + 1) / 2;
-        for (;;) {
-            if (tid == 0) sTile = __hip_atomic_fetch_add(counters + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            const int tile = sTile;
-            __syncthreads();
-            if (tile >= ddTiles) break;
-            if (ra.ddSmall) downdateTile<T, 32>(a, ra.ddNt, b, tile, reinterpret_cast<T*>(smemR));
-            else downdateTile<T, 64, 4>(a, ra.ddNt, b, tile, reinterpret_cast<T*>(smemR));
-            __syncthreads();
-        }
-    }
+    // ---- covariance downdate Sigma - Y^T Y: the tile workgroups behind the roles (top of the kernel).  Until late in round 3 a co-resident
+    // grid did it here instead -- every workgroup that was done with its role waited, holding its CU, until all Y tiles were out and then
+    // shared the tiles from a counter: the one wait of the kernel for HIGHER block indices (safe only with full co-residency; the advisor's
+    // round-2 finding) and 2 us slower than the tile workgroups (136.7 -> 134.8 us per update).  Removed.  (Also tried, for grids larger
+    // than the chip: finished role workgroups take tiles only if the last Y tile is already out and leave otherwise -- 2 filters 294 us
+    // against 135 + 41 us with a follow-up launch; too few workgroups finish after the S-chain.)
 }
 
 }  // namespace eqf
