@@ -18,17 +18,16 @@
 //                       Y_Ct; S-chain tiles also carry the innovation column z along and leave their share of
 //                       gamma = Y^T z; the E-chain's leave their share of G11 = [Zt|Et]^T [Zt|Et].
 //   The last right-hand-side workgroup of the E-chain waits for every share, sums them IN BLOCK-ROW ORDER (deterministic)
-//   and runs the innovation lift.  S-chain workgroups that finish late take the downdate tiles Sigma - Y^T Y from a
-//   counter once every Y tile is out.
-// Deadlock freedom: in the ROLES, block indices follow the dependency order (a workgroup only ever waits for workgroups with a
-// lower block index), so whatever part of the grid is resident contains a workgroup that can run.  The one exception is the
-// in-kernel downdate: workgroups that are done wait -- holding their CU -- until ALL Y tiles are out, i.e. also for higher block
-// indices.  That is only safe when the whole grid is co-resident, so the host compiles the downdate into this launch
-// (ResArgs::ddNt > 0) only when hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs covers the grid; a grid forced onto a larger
-// size (EQF_CHOL_RESIDENT=2) gets the downdate as a follow-up launch.  Every wait is bounded (eqf_handoff.hpp, 50 ms): a
-// timeout raises the sticky device error flag (bit 8 -> EQF_ERR_NUMERIC from eqf_device_error) and the workgroup that saw it
-// takes no downdate tiles -- Sigma_out is never overwritten from stale operands.  The host uses this kernel when the grid fits
-// the chip (one small filter -- the latency case); larger problems keep the per-column launches, which are bandwidth-bound.
+//   and runs the innovation lift.  The downdate tiles Sigma - Y^T Y are workgroups of their own BEHIND the roles in the grid: they
+//   wait for the S-chain's last Y tile and overlap the tail of the (longer) E-chain.
+// Deadlock freedom: block indices follow the dependency order -- a workgroup only ever waits for workgroups with a LOWER block index
+// (roles: the groups before theirs; downdate tiles: the S-chain's roles) -- so whatever part of the grid is resident contains a
+// workgroup that can run, co-resident grid or not.  (Until late in round 3 a co-resident grid ran the downdate in the finished role
+// workgroups, which waited for higher block indices while holding their CUs: removed.)  Every wait is bounded (eqf_handoff.hpp,
+// 50 ms): a timeout raises the sticky device error flag (bit 8 -> EQF_ERR_NUMERIC from eqf_device_error) and the workgroup that saw it
+// publishes nothing more; Sigma_out is never overwritten from stale operands.  The host uses this kernel for one filter up to
+// N ~ 1400 and for small batches (10 + 16 / batch roles per CU, eqf_capi.hip); larger problems keep the per-column launches, which are
+// bandwidth-bound.
 #pragma once
 #include "eqf_chol64.hpp"
 
