@@ -25,7 +25,7 @@
 // workgroup that can run, co-resident grid or not.  (Until late in round 3 a co-resident grid ran the downdate in the finished role
 // workgroups, which waited for higher block indices while holding their CUs: removed.)  Every wait is bounded (eqf_handoff.hpp,
 // 50 ms): a timeout raises the sticky device error flag (bit 8 -> EQF_ERR_NUMERIC from eqf_device_error) and the workgroup that saw it
-// publishes nothing more; Sigma_out is never overwritten from stale operands.  The host uses this kernel for one filter up to
+// publishes nothing more, so the downdate tiles never see the S-chain complete: Sigma_out is not overwritten from stale operands.  The host uses this kernel for one filter up to
 // N ~ 1400 and for small batches (10 + 16 / batch roles per CU, eqf_capi.hip); larger problems keep the per-column launches, which are
 // bandwidth-bound.
 #pragma once
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
         auto mid = [&] {
             hoDrain();
             __syncthreads();
-            if (tid == 0) hoPublish(readyA + R * nbCap + (R - 1), epoch);
+            if (tid == 0 && bad != 8) hoPublish(readyA + R * nbCap + (R - 1), epoch);
             EQF_HSTAMP(12);
         };
         factor64<true>(s, tid, &bad, pre, D + (long long)R * kDRec, nullptr, realStages(ch.kind == 0 ? sDim(g.N) : eDim(g.N), kSB * R), mid,
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
         EQF_HSTAMP(7);
         hoDrain();
         __syncthreads();
-        if (tid == 0) hoPublish(ch.flags + (long long)b * ch.strideF + R, epoch);
+        if (tid == 0 && bad != 8) hoPublish(ch.flags + (long long)b * ch.strideF + R, epoch);
         EQF_HSTAMP(8);
     } else if (role.role == 1) {
         // =========================================================================================== T(R, C)
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
         hoStoreBlock(A + (long long)(R * kSB) * ldA + C * kSB, ldA, s.P, tid);
         hoDrain();
         __syncthreads();
-        if (tid == 0) hoPublish(readyA + R * nbCap + C, epoch);
+        if (tid == 0 && bad != 8) hoPublish(readyA + R * nbCap + C, epoch);
         if (C + 2 == R) EQF_HSTAMP(11);
     } else {
         // =========================================================================================== W(t, C)
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
         }
         hoDrain();
         __syncthreads();
-        if (tid == 0) {
+        if (tid == 0 && bad != 8) {
             hoPublish(readyY + C * wtCap + t, epoch);
             if (isS) __hip_atomic_fetch_add(counters + 0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -719,10 +719,10 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
         }
     }
     if (bad && ra.errflag && tid == 0) atomicOr(ra.errflag, bad == 8 ? 8 : 4);
-    // A hand-off that timed out left this workgroup with stale operands: everything it published is wrong, and so would be a
-    // downdate from it.  The sticky flag (bit 8, include/eqf_vio_amd.h) makes the host report EQF_ERR_NUMERIC; this workgroup takes no
-    // downdate tiles, so Sigma_out is not overwritten with a plausible-looking wrong matrix.
-    if (__syncthreads_or(bad == 8)) return;
+    // A hand-off that timed out left this workgroup with stale operands.  The sticky flag (bit 8, include/eqf_vio_amd.h) makes the host
+    // report EQF_ERR_NUMERIC, and the workgroup has published NOTHING since (`bad != 8` at every publish above): the workgroups that depend
+    // on it time out in turn, the count of finished Y tiles stays short, the downdate tiles give up -- Sigma_out is not overwritten with
+    // a plausible-looking wrong matrix.
 
     // ---- covariance downdate Sigma - Y^T Y: the tile workgroups behind the roles (top of the kernel).  Until late in round 3 a co-resident
     // grid did it here instead -- every workgroup that was done with its role waited, holding its CU, until all Y tiles were out and then
