@@ -143,7 +143,7 @@ struct eqf_filter {
     int updateEpoch = 0;           // one per launchUpdate
     // k_chol_resident (one launch per update while the grid fits the chip): EQF_CHOL_RESIDENT = 0 switches it off
     int cholResident = 1;
-    int resOversub = -1;           // EQF_RES_OVERSUB: roles per CU up to which the resident kernel is used on a grid larger than the chip; -1 = 10 + 16 / batch
+    int resOversub = -1;           // EQF_RES_OVERSUB: roles per CU up to which the resident kernel is used on a grid larger than the chip; -1 = 12 + 16 / batch
     int resStaged = 1;             // row heads consume D[R-1] stage by stage (EQF_RES_STAGED = 0: whole record after its last pivot)
     int residentPerCU = -1;        // hipOccupancyMaxActiveBlocksPerMultiprocessor of k_chol_resident on this device (lazily queried)
     int eFromSigma = 1;            // split chain: block column 0 of the E-chain read straight from Sigma (EQF_E_FROM_SIGMA=0: copied by prep)
@@ -683,8 +683,8 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         // the latency floor of the diagonal workgroup (23-35 us per block column), the resident kernel's period stays near the pivot
         // chain's.  Measured break-even in roles per CU: one filter ~26 (N = 600: 11.7 k -> 20.1 k steps/s, N = 1000: 5.2 k -> 6.4 k,
         // N = 1200: 3.64 k -> 4.08 k, N = 1500 even), 4 filters ~18 (N = 600 +9 %), 8 filters ~16 (N = 400 even), 24 filters < 13.7
-        // (N = 200: per-column launches win).  Default: 10 + 16 / batch.
-        const long long oversub = f->resOversub >= 0 ? f->resOversub : 10 + 16 / B;
+        // (N = 200: per-column launches win; 20 filters, 11.4: 339 k -> 356 k).  Default: 12 + 16 / batch.
+        const long long oversub = f->resOversub >= 0 ? f->resOversub : 12 + 16 / B;
         resident = f->cholResident >= 2 || residentFits || (long long)f->rolesCount * B <= oversub * f->numCUs;
     }
     a.eFromSigma = (!resident && splitChain && f->cholTail && f->eFromSigma && f->precision != EQF_PRECISION_F32) ? 1 : 0;

@@ -26,7 +26,7 @@
 // workgroups, which waited for higher block indices while holding their CUs: removed.)  Every wait is bounded (eqf_handoff.hpp,
 // 50 ms): a timeout raises the sticky device error flag (bit 8 -> EQF_ERR_NUMERIC from eqf_device_error) and the workgroup that saw it
 // publishes nothing more, so the downdate tiles never see the S-chain complete: Sigma_out is not overwritten from stale operands.  The host uses this kernel for one filter up to
-// N ~ 1400 and for small batches (10 + 16 / batch roles per CU, eqf_capi.hip); larger problems keep the per-column launches, which are
+// N ~ 1400 and for small batches (12 + 16 / batch roles per CU, eqf_capi.hip); larger problems keep the per-column launches, which are
 // bandwidth-bound.
 #pragma once
 #include "eqf_chol64.hpp"
