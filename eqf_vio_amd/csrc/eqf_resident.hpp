@@ -596,6 +596,40 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
             for (int q = 0; q < 4; ++q) acc[i][q] = Tg[(long long)(kQB * wv + (lane >> 4) + 4 * q) * ldW + kQB * i + (lane & 15)];
         const bool isS = ch.kind == 0;
         double* zv = s.redL;  // [0, 64) the innovation column delta of this block row, [64, 128) z of block row K
+        const int nvv = kLm0 + 3 * g.N;
+        // The last right-hand-side workgroup of the E-chain is the END of the update's critical path (D[nb-1] -> its solve -> G11 -> innovation
+        // lift): what its epilogue needs of the S-chain -- the complete sums, which the S-chain's last block row carries; it finished several
+        // block columns ago -- is collected while this workgroup waits for its LAST panel (1.4 us off the path), and its own Y tile, share
+        // of G11 and flag, which nobody reads, are not stored, drained and published any more (1.6 us).
+        const bool last = ch.kind == 1 && C == nb - 1;
+        // (the co-resident kernel only: in the variant for grids larger than the chip the same changes cost 3.5 % -- 8 filters 181 -> 187 us)
+        const bool lastFast = last && !PIPEH;
+        bool collected = false;
+        auto collect = [&]() {
+            collected = true;
+            const int* ryS = ra.readyY + ((long long)b * 2 + 0) * nbCap * wtCap;
+            if (tid < wtS && !hoWait(ryS + (nbS - 1) * wtCap + tid, epoch)) bad = 8;
+            bad = __syncthreads_or(bad) ? 8 : 0;  // (a timeout seen by ANY of the polling threads is reported below by thread 0)
+            double* gam = a.dbgGamma + (long long)b * (kLm0 + 3 * a.cap);
+            const int ldY = ra.c0.ldW;
+            double gv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int col = tid + 256 * u;
+                gv[u] = col < nvv + 6 ? hoLoad8(ra.gammaPart + ((long long)b * nbCap + nbS - 1) * ldY + col) : 0.0;
+            }
+            for (int col = tid + 1024; col < nvv + 6; col += 256) {  // (more than 1024 columns: N > 335)
+                const double v = hoLoad8(ra.gammaPart + ((long long)b * nbCap + nbS - 1) * ldY + col);
+                if (col < nvv) gam[col] = v;
+                else s.redL[col - nvv] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int col = tid + 256 * u;
+                if (col < nvv) gam[col] = col == 11 ? 0.0 : gv[u];
+                else if (col < nvv + 6) s.redL[col - nvv] = gv[u];
+            }
+        };
         if (isS && tid < kSB) zv[tid] = W[(long long)(C * kSB + tid) * ldW + 11];
         if (C > 0) {
             // pipelined panel loop (see panelIssue): Q <- L_{C,K}, P <- Y_{K,t}; the S-chain also carries z_K along
@@ -634,19 +668,20 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
                 for (int i = 0; i < 4; ++i) acc[i] = mmTile<false, kSB>(acc[i], &s.Q[0][0], kSP, kQB * wv, &s.P[0][0], kSP, kQB * i, lane, -1.0);
                 __syncthreads();
                 if (K + 1 < C && !ahead) {
+                    if (lastFast && K + 2 == C) collect();  // (the last panel is not out yet: this wait is idle time on the critical path's side)
                     hoWait3(readyA + C * nbCap + K + 1, readyY + (K + 1) * wtCap + t, isS ? readyY + (K + 1) * wtCap : nullptr, epoch, tid, &bad);
                     issue(K + 1);
                     probe = look(K + 2);
                 }
             }
         }
+        if (last && !collected) collect();
         EQF_WSTAMP(0);
         hoWait3(C > 0 ? flagD + C : nullptr, nullptr, nullptr, epoch, tid, &bad);
         EQF_WSTAMP(1);
         hoLoadRecord(D + (long long)C * kDRec, s, tid);
         // running sums of the reductions: block row C adds its share to what block row C-1 of the same column tile left
         // (published together with that tile, which this workgroup has already waited for): a fixed summation order
-        const int nvv = kLm0 + 3 * g.N;
         double prevSum = 0.0;
         if (C > 0) {
             if (isS && tid < kSB && t * kSB + tid < nvv + 6) prevSum = hoLoad8(ra.gammaPart + ((long long)b * nbCap + C - 1) * ldW + t * kSB + tid);
@@ -659,7 +694,7 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
         if (isS && wv == 3) solveVec64(zv, s, lane);
         __syncthreads();
         EQF_WSTAMP(2);
-        hoStoreBlock(WO + (long long)(C * kSB) * ldW + t * kSB, ldW, s.P, tid);
+        if (!lastFast) hoStoreBlock(WO + (long long)(C * kSB) * ldW + t * kSB, ldW, s.P, tid);
         double g11Tot = 0.0;
         if (isS) {
             // gamma[col] = sum_C Y_C[:, col] . z_C (columns nvv .. nvv+5: hV), through block row C
@@ -676,40 +711,19 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
 #pragma unroll 8
             for (int r = 0; r < kSB; ++r) v = fma(s.P[r][q0], s.P[r][q1], v);
             g11Tot = prevSum + v;
-            hoStore8(ra.g11Part + ((long long)b * nbCap + C) * 128 + tid, g11Tot);
+            if (!lastFast) hoStore8(ra.g11Part + ((long long)b * nbCap + C) * 128 + tid, g11Tot);
         }
-        hoDrain();
-        __syncthreads();
-        if (tid == 0 && bad != 8) {
-            hoPublish(readyY + C * wtCap + t, epoch);
-            if (isS) __hip_atomic_fetch_add(counters + 0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!lastFast) {
+            hoDrain();
+            __syncthreads();
+            if (tid == 0 && bad != 8) {
+                hoPublish(readyY + C * wtCap + t, epoch);
+                if (isS) __hip_atomic_fetch_add(counters + 0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         EQF_WSTAMP(3);
-        if (!isS && C == nb - 1) {
-            // ---- the last right-hand-side workgroup of the E-chain: collect every share (block-row order), innovation lift
-            // the S-chain's last block row carries the complete sums: wait for its tiles only
-            const int* ryS = ra.readyY + ((long long)b * 2 + 0) * nbCap * wtCap;
-            if (tid < wtS && !hoWait(ryS + (nbS - 1) * wtCap + tid, epoch)) bad = 8;
-            bad = __syncthreads_or(bad) ? 8 : 0;  // (a timeout seen by ANY of the polling threads is reported below by thread 0)
-            double* gam = a.dbgGamma + (long long)b * (kLm0 + 3 * a.cap);
-            const int ldY = ra.c0.ldW;
-            double gv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int col = tid + 256 * u;
-                gv[u] = col < nvv + 6 ? hoLoad8(ra.gammaPart + ((long long)b * nbCap + nbS - 1) * ldY + col) : 0.0;
-            }
-            for (int col = tid + 1024; col < nvv + 6; col += 256) {  // (more than 1024 columns: N > 335, not a resident size)
-                const double v = hoLoad8(ra.gammaPart + ((long long)b * nbCap + nbS - 1) * ldY + col);
-                if (col < nvv) gam[col] = v;
-                else s.redL[col - nvv] = v;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int col = tid + 256 * u;
-                if (col < nvv) gam[col] = col == 11 ? 0.0 : gv[u];
-                else if (col < nvv + 6) s.redL[col - nvv] = gv[u];
-            }
+        if (last) {
+            // ---- the innovation lift (the sums of the S-chain were collected above)
             if (tid < 121) s.redL[8 + tid] = g11Tot;
             __syncthreads();
             EQF_WSTAMP(4);
