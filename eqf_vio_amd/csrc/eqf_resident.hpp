@@ -629,6 +629,10 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
                 if (col < nvv) gam[col] = col == 11 ? 0.0 : gv[u];
                 else if (col < nvv + 6) s.redL[col - nvv] = gv[u];
             }
+            if (lastFast) {  // (the part of the innovation lift that only needs gamma, now: updateFinishBody)
+                __syncthreads();
+                updateFinishBody(a, b, s.redL, 1);
+            }
         };
         if (isS && tid < kSB) zv[tid] = W[(long long)(C * kSB + tid) * ldW + 11];
         if (C > 0) {
@@ -727,7 +731,7 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
             if (tid < 121) s.redL[8 + tid] = g11Tot;
             __syncthreads();
             EQF_WSTAMP(4);
-            updateFinishBody(a, b, s.redL);
+            updateFinishBody(a, b, s.redL, lastFast ? 2 : 0);
             __syncthreads();
             EQF_WSTAMP(5);
         }
