@@ -95,6 +95,38 @@ def test_cfg3_N1000_structured_and_dense_mfma_riccati(oracle_lib, hip):
     print("cfg3 N=1000 worst relS:", worst)
 
 
+@pytest.mark.parametrize("N", [450, 600])
+def test_mid_size_filters_on_the_one_launch_update_kernel(oracle_lib, hip, N, monkeypatch):
+    """One filter between the sizes k_chol_resident was written for (N = 200) and BASELINE's N = 1000: since late in round 3 the host
+    keeps such a filter on the one-launch update kernel (a grid several times larger than the chip: 12 + 16 / batch roles per CU,
+    csrc/eqf_capi.hip) instead of one launch per block column.  Three vision updates against the structured oracle after every
+    frame, and the per-column launches (EQF_RES_OVERSUB=0) on the same stream to rounding."""
+    from eqf_vio_amd import synth
+
+    st = synth.make_stream(N, duration=0.16)
+    d = synth.template_settings_dict()
+    ref = _oracle_frames(oracle_lib, d, st)
+    out = {}
+    for oversub in (None, "0"):
+        if oversub is not None:
+            monkeypatch.setenv("EQF_RES_OVERSUB", oversub)
+        fg = hip.FilterBatch(d, capacity=N, batch=1)
+        fg.stream_upload(st.imu, st.vision_stamps, st.ids, st.bearings)
+        fr = 0
+        for kind, k in st.events():
+            if kind == "imu":
+                fg.stream_imu(k)
+            else:
+                fg.stream_vision(k)
+                _check_frame(fg, 0, ref[fr], (N, oversub, fr))
+                fr += 1
+        assert fr == 3 and fg.device_error() == 0
+        out[oversub] = fg.sigma(0)
+        fg.close()
+    monkeypatch.delenv("EQF_RES_OVERSUB")
+    assert rel_fro(out[None], out["0"]) < 1e-9
+
+
 def test_cfg4_batch_of_64_filters_N200(oracle_lib, hip):
     """BASELINE configs[3] on one GPU: 64 independent filters of N = 200 in one handle, each on its own stream (seed 1234 + b),
     three vision updates.  Every filter's pose / velocity / bias / landmarks and |Sigma|_F against its own structured oracle;
