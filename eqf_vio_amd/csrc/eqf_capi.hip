@@ -143,7 +143,7 @@ struct eqf_filter {
     int updateEpoch = 0;           // one per launchUpdate
     // k_chol_resident (one launch per update while the grid fits the chip): EQF_CHOL_RESIDENT = 0 switches it off
     int cholResident = 1;
-    int resOversub = -1;           // EQF_RES_OVERSUB: roles per CU up to which the resident kernel is used on a grid larger than the chip; -1 = 12 + 16 / batch
+    int resOversub = -1;           // EQF_RES_OVERSUB: roles per CU up to which the resident kernel is used on a grid larger than the chip; -1 = no limit
     int resStaged = 1;             // row heads consume D[R-1] stage by stage (EQF_RES_STAGED = 0: whole record after its last pivot)
     int residentPerCU = -1;        // hipOccupancyMaxActiveBlocksPerMultiprocessor of k_chol_resident on this device (lazily queried)
     int eFromSigma = 1;            // split chain: block column 0 of the E-chain read straight from Sigma (EQF_E_FROM_SIGMA=0: copied by prep)
@@ -157,6 +157,7 @@ struct eqf_filter {
     int resPipeHeads = -1;         // EQF_RES_PIPEH: row heads with the pipelined panel loop (1), without (0), by grid size (-1)
     int prepOcc2 = -1;             // EQF_PREP_OCC2: the prep launch built for two workgroups per CU (1), one (0), by launch size (-1)
     int burstOcc2 = -1;            // EQF_BURST_OCC2: the 16-landmark builder built for two workgroups per CU (1), one (0), by launch size (-1)
+    int resOcc2 = -1;              // EQF_RES_OCC2: k_chol_resident built for two workgroups per CU (1), one (0), by grid size (-1)
     int rolesN = -1, rolesCount = 0;  // chain shape (nbS, nbE, wtS) the role table was built for
     // profiling
     bool prof = false;
@@ -627,6 +628,8 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<float, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRes2Bytes));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRes2Bytes));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<float, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTailBytes));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTailBytes));
         attrSet = true;
@@ -684,7 +687,11 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         // chain's.  Measured break-even in roles per CU: one filter ~26 (N = 600: 11.7 k -> 20.1 k steps/s, N = 1000: 5.2 k -> 6.4 k,
         // N = 1200: 3.64 k -> 4.08 k, N = 1500 even), 4 filters ~18 (N = 600 +9 %), 8 filters ~16 (N = 400 even), 24 filters < 13.7
         // (N = 200: per-column launches win; 20 filters, 11.4: 339 k -> 356 k).  Default: 12 + 16 / batch.
-        const long long oversub = f->resOversub >= 0 ? f->resOversub : 12 + 16 / B;
+        // Since the build for two workgroups per CU (k_chol_resident's OCC2, late in round 3) the resident kernel wins at EVERY size measured
+        // -- 24 / 32 / 64 / 96 filters of N = 200: 386 -> 447 k, 410 -> 479 k, 453 -> 509 k, 478 -> 507 k steps/s; one filter of N = 1500 / 2000 /
+        // 3000 / 4000: 2.23 -> 2.85 k, 1053 -> 1335, 344 -> 406, 151 -> 174 -- so the default is "whenever its buffers exist"; the per-column
+        // launches remain for EQF_CHOL_RESIDENT=0 / EQF_RES_OVERSUB and for filters whose chains are equally long (a handful of landmarks).
+        const long long oversub = f->resOversub >= 0 ? f->resOversub : 1000000;
         resident = f->cholResident >= 2 || residentFits || (long long)f->rolesCount * B <= oversub * f->numCUs;
     }
     a.eFromSigma = (!resident && splitChain && f->cholTail && f->eFromSigma && f->precision != EQF_PRECISION_F32) ? 1 : 0;
@@ -740,8 +747,15 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             rc = profiled(f, EQF_PROF_CHOL_RESIDENT, [&] {
                 // (row heads with the pipelined panel loop only on a grid larger than the chip: see the kernel's PIPEH)
                 const bool pipeHeads = f->resPipeHeads >= 0 ? f->resPipeHeads != 0 : !residentFits;
-                if (pipeHeads) hipLaunchKernelGGL((k_chol_resident<T, true>), dim3(B, f->rolesCount + ddGrid), dim3(256), sizeof(Step64Lds), f->stream, ra);
-                else hipLaunchKernelGGL((k_chol_resident<T, false>), dim3(B, f->rolesCount + ddGrid), dim3(256), sizeof(Step64Lds), f->stream, ra);
+                // (two workgroups per CU when the grid is many times the chip: see the kernel's OCC2)
+                const double perCU = double(f->rolesCount) * B / std::max(f->numCUs, 1);
+                const bool occ2 = f->resOcc2 >= 0 ? f->resOcc2 != 0 : (pipeHeads && (perCU > 6.0 || (B >= 8 && perCU > 4.5)));
+                ra.nDdTiles = ddGrid;
+                ra.rolesPerRow = std::min(f->rolesCount + ddGrid, 32768);
+                const dim3 rg(B * ra.rolesPerRow, (f->rolesCount + ddGrid + ra.rolesPerRow - 1) / ra.rolesPerRow);
+                if (pipeHeads && occ2) hipLaunchKernelGGL((k_chol_resident<T, true, true>), rg, dim3(256), kLdsRes2Bytes, f->stream, ra);
+                else if (pipeHeads) hipLaunchKernelGGL((k_chol_resident<T, true>), rg, dim3(256), sizeof(Step64Lds), f->stream, ra);
+                else hipLaunchKernelGGL((k_chol_resident<T, false>), rg, dim3(256), sizeof(Step64Lds), f->stream, ra);
             });
             if (rc) return rc;
         } else if (splitChain && f->cholTail) {
@@ -1290,6 +1304,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (const char* e = std::getenv("EQF_RES_STAGED")) f->resStaged = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_OVERSUB")) f->resOversub = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("EQF_E_FROM_SIGMA")) f->eFromSigma = std::atoi(e);
+    if (const char* e = std::getenv("EQF_RES_OCC2")) f->resOcc2 = std::atoi(e);
     if (const char* e = std::getenv("EQF_BURST_OCC2")) f->burstOcc2 = std::atoi(e);
     if (const char* e = std::getenv("EQF_PREP_OCC2")) f->prepOcc2 = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_PIPEH")) f->resPipeHeads = std::atoi(e);
@@ -1305,7 +1320,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
         // most 28 roles per CU (N <= ~1500 on 256 CUs: beyond that the per-column launches win, see launchUpdateT); the batch may be
         // larger than the chip (interleaved grid)
         const long long maxRoles = (long long)(f->nbCap + 1) * f->nbCap + (long long)f->wtCap * f->nbCap;
-        if (!rc && maxRoles <= 28LL * std::max(f->numCUs, 1) && maxRoles * B <= 64LL * std::max(f->numCUs, 1)) {
+        if (!rc && maxRoles * B <= 200000) {  // (N = 4000: 71 k roles)
             chk(dmalloc(&f->dReadyA, (size_t)2 * f->nbCap * f->nbCap * B));
             chk(dmalloc(&f->dReadyY, (size_t)2 * f->nbCap * f->wtCap * B));
             chk(dmalloc(&f->dResCounters, (size_t)4 * B));

@@ -93,6 +93,19 @@ EQF_DI Lds64 ldsTail(unsigned char* smem) {
     return s;
 }
 
+// k_chol_resident on a grid larger than the chip: Q | P | Wd | D0 | redL with L ALIASING Q (78 KB: two workgroups per CU).  Valid there
+// because every role is done with its panel operand Q before it touches L: the record of D[K] (hoLoadRecord / the staged loads) arrives
+// after the panel loop, and a row head factors its diagonal tile in L while `pre` still reads P.
+constexpr int kLdsRes2Bytes = int(sizeof(double)) * (2 * kSB * kSP + 4 * kQB * kWP + kQB * kWP + 256);
+EQF_DI Lds64 ldsRes2(unsigned char* smem) {
+    double* d = reinterpret_cast<double*>(smem);
+    double (*Q)[kSP] = reinterpret_cast<double (*)[kSP]>(d);
+    double (*P)[kSP] = reinterpret_cast<double (*)[kSP]>(d + kSB * kSP);
+    double (*Wd)[kQB][kWP] = reinterpret_cast<double (*)[kQB][kWP]>(d + 2 * kSB * kSP);
+    double (*D0)[kWP] = reinterpret_cast<double (*)[kWP]>(d + 2 * kSB * kSP + 4 * kQB * kWP);
+    return Lds64{P, Q, Q, Wd, D0, nullptr, d + 2 * kSB * kSP + 4 * kQB * kWP + kQB * kWP, nullptr};
+}
+
 EQF_DI void chainDims64(const ChainArgs& ch, int N, int* nb, int* wt) {
     if (ch.kind == 0) {
         *nb = roundUp(sDim(N), kSB) / kSB;

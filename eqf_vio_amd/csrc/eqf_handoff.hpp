@@ -37,7 +37,7 @@ EQF_DEV bool hoWait(const int* flag, int epoch) {
     const long long t0 = wall_clock64();  // 100 MHz
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
         __builtin_amdgcn_s_sleep(1);
-        if (wall_clock64() - t0 > 5000000LL) return false;  // 50 ms
+        if (wall_clock64() - t0 > 50000000LL) return false;  // 0.5 s (a launch for N = 4000 runs 60 ms)
     }
     return true;
 }

@@ -51,7 +51,8 @@ struct ResArgs {
     int nbCap, wtCap;
     int ddNt;              // 64 x 64 downdate tiles per edge (the tile workgroups behind the roles)
     int* errflag;
-    int nRoles;
+    int nRoles, nDdTiles;  // role workgroups, downdate-tile workgroups behind them (per filter)
+    int rolesPerRow;       // grid.x = batch * rolesPerRow
     int* stageFlags;       // [B][2][nbCap][4]  stage j of D[K] of chain c is in the record (epoch valued; factor64's stageFlag)
 };
 
@@ -312,17 +313,26 @@ __device__ long long g_resStamps[2][16][16];  // [chain][R][phase] wall-clock (1
 // cost the pivot chain 4 us per update through the register allocation), on for a batch on a grid larger than the chip: there a head is
 // dispatched when R - 1 panels are already waiting, and at 6.5 us per panel (flag, 64 KB round trip, 3.4 us of MFMAs, two barriers) the heads of
 // the later block columns were still catching up when their diagonal factor was due (wall-clock stamps, 8 filters: H(8) 9 us late).
-template <typename T, bool PIPEH = false>
-__global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
+// OCC2: the build for grids MANY times the chip (from ~4.5 roles per CU with a batch of 8 or more, ~6 otherwise): two workgroups per CU --
+// 237 registers, and the 78 KB LDS view in which L aliases Q (ldsRes2).  Twice the workgroups in flight reach twice as many block columns
+// ahead of the pivot chains: 8 filters 181 -> 170 us per update, 12: 254 -> 220, 16: 312 -> 255, 20: 401 -> 315, N = 1000 1.54 -> 1.28 ms.
+// On lightly oversubscribed grids two workgroups on a CU only get in each other's way (4 filters 134 -> 153 us, N = 600 455 -> 475).
+template <typename T, bool PIPEH = false, bool OCC2 = false>
+__global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smemR[];
     // grid = (batch, roles): the filter index runs FASTEST in dispatch order, so that a grid larger than the chip advances all filters
     // together, dependency group by dependency group (role-major order would run the filters one after the other), and with a batch
     // that is a multiple of 8 every workgroup of filter b runs on XCD b mod 8
-    if ((int)blockIdx.y >= ra.nRoles) {
+    // (role index and filter from the linear workgroup index: grid = (B * rolesPerRow, rows), filter fastest; one row unless the roles and
+    // downdate tiles of a filter are more than 32768 -- N > ~2700)
+    const int nB = (int)gridDim.x / ra.rolesPerRow;
+    const int roleIdx = (int)blockIdx.x / nB + ra.rolesPerRow * (int)blockIdx.y, bIdx = (int)blockIdx.x % nB;
+    if (roleIdx >= ra.nRoles + ra.nDdTiles) return;
+    if (roleIdx >= ra.nRoles) {
         // ---- a downdate tile of filter blockIdx.x.  These workgroups have the HIGHEST block indices: they are dispatched when
         // the role workgroups in front of them have been, i.e. during the last block columns of the E-chain, and they wait -- for LOWER
         // block indices only -- until the S-chain's last Y tile is out (it usually is).  The downdate overlaps the tail of the longer chain.
-        const int bb = blockIdx.x, tile = (int)blockIdx.y - ra.nRoles, t = threadIdx.x;
+        const int bb = bIdx, tile = roleIdx - ra.nRoles, t = threadIdx.x;
         const Glob& gg = ra.a.g[bb];
         int late = 0;
 #ifdef EQF_RES_STAMPS
@@ -354,8 +364,8 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
 #endif
         return;
     }
-    const ResRole role = ra.roles[blockIdx.y];
-    const int b = blockIdx.x;
+    const ResRole role = ra.roles[roleIdx];
+    const int b = bIdx;
     const ChainArgs& ch = role.kind ? ra.c1 : ra.c0;
     const UpdArgs& a = ra.a;
     const Glob& g = ch.g[b];
@@ -370,7 +380,7 @@ __global__ __launch_bounds__(256) void k_chol_resident(ResArgs ra) {
     chainDims64(ra.c1, g.N, &nbE, &wtE);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int epoch = ch.epoch;
-    const Lds64 s = ldsFull(smemR);
+    const Lds64 s = OCC2 ? ldsRes2(smemR) : ldsFull(smemR);
     double* A = ch.A + (long long)b * ch.strideA;
     double* D = ch.D + (long long)b * ch.strideD;
     double* W = ch.W + (long long)b * ch.strideW;
