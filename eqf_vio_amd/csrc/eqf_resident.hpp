@@ -24,10 +24,10 @@
 // (roles: the groups before theirs; downdate tiles: the S-chain's roles) -- so whatever part of the grid is resident contains a
 // workgroup that can run, co-resident grid or not.  (Until late in round 3 a co-resident grid ran the downdate in the finished role
 // workgroups, which waited for higher block indices while holding their CUs: removed.)  Every wait is bounded (eqf_handoff.hpp,
-// 50 ms): a timeout raises the sticky device error flag (bit 8 -> EQF_ERR_NUMERIC from eqf_device_error) and the workgroup that saw it
-// publishes nothing more, so the downdate tiles never see the S-chain complete: Sigma_out is not overwritten from stale operands.  The host uses this kernel for one filter up to
-// N ~ 1400 and for small batches (12 + 16 / batch roles per CU, eqf_capi.hip); larger problems keep the per-column launches, which are
-// bandwidth-bound.
+// 0.5 s): a timeout raises the sticky device error flag (bit 8 -> EQF_ERR_NUMERIC from eqf_device_error) and the workgroup that saw it
+// publishes nothing more, so the downdate tiles never see the S-chain complete: Sigma_out is not overwritten from stale operands.
+// The host uses this kernel at every size whose chains are of unequal length (eqf_capi.hip: since the build for two workgroups per CU,
+// OCC2 below, it beats the per-column launches from one filter of N = 200 to 96 of them and to one filter of N = 4000).
 #pragma once
 #include "eqf_chol64.hpp"
 
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
             const long long t0 = wall_clock64();
             while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nS * wS) {
                 __builtin_amdgcn_s_sleep(32);
-                if (wall_clock64() - t0 > 5000000LL) {
+                if (wall_clock64() - t0 > 50000000LL) {  // 0.5 s
                     if (ra.errflag) atomicOr(ra.errflag, 8);
                     late = 1;
                     break;

@@ -150,7 +150,7 @@ int eqf_debug_get_blocks(eqf_filter* f, int b, double* common, double* rec, doub
 /* Sticky device-side error flag, 0 if none; a bit mask (any bit -> the C++ facade throws std::domain_error, like the reference's
  * SO3FromVectors, SO3.cpp:160): 1 antipodal vectors / singular gravity chart in a propagate step; 2 the same while building the residual
  * or C0i; 4 a pivot of S or Sigma_e not positive; 8 antipodal vectors in the innovation lift, OR an in-launch hand-off of k_chol_resident
- * timed out (50 ms: the chip was shared beyond what the kernel's co-residency allows) -- that update's Sigma was NOT written and the
+ * timed out (0.5 s: the GPU was taken away from the launch for that long) -- that update's Sigma was NOT written and the
  * filter must be reset or restored; 16 / 32 a new / restored landmark on the chart pole. */
 int eqf_device_error(eqf_filter* f);
 
