@@ -662,7 +662,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     if (!f->cholEmbed) embed = false;
     // (measured on the 256-CU part: 1500 workgroups = six per CU -- N = 200 from 8 filters on, N >= ~600)
     const bool splitChain = f->cholSplit >= 0 ? f->cholSplit != 0 : (long long)nblk64 * B >= 6LL * std::max(f->numCUs, 1);
-    bool resident = false, residentFits = false;
+    bool resident = false, residentFits = false, resPipeHeads = false, resOcc2 = false;
     int rc = EQF_OK;
     if (embed && f->cholResident && f->cholSplit <= 0 && f->dReadyA) {
         rc = buildRoles(f, Nmax);
@@ -693,8 +693,15 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         // launches remain for EQF_CHOL_RESIDENT=0 / EQF_RES_OVERSUB and for filters whose chains are equally long (a handful of landmarks).
         const long long oversub = f->resOversub >= 0 ? f->resOversub : 1000000;
         resident = f->cholResident >= 2 || residentFits || (long long)f->rolesCount * B <= oversub * f->numCUs;
+        // the builds of the kernel: row heads with the pipelined panel loop on grids larger than the chip (PIPEH), two workgroups per CU when
+        // the grid is many times the chip (OCC2)
+        resPipeHeads = f->resPipeHeads >= 0 ? f->resPipeHeads != 0 : !residentFits;
+        const double perCU = double(f->rolesCount) * B / std::max(f->numCUs, 1);
+        resOcc2 = resident && (f->resOcc2 >= 0 ? f->resOcc2 != 0 : (resPipeHeads && (perCU > 6.0 || (B >= 8 && perCU > 4.5))));
     }
     a.eFromSigma = (!resident && splitChain && f->cholTail && f->eFromSigma && f->precision != EQF_PRECISION_F32) ? 1 : 0;
+    // (the OCC2 build reads the E-chain's tiles straight from Sigma: no copy in the prep launch; EQF_E_FROM_SIGMA=0: copied)
+    if (resOcc2 && resPipeHeads && f->eFromSigma && f->precision != EQF_PRECISION_F32) a.eFromSigma = 2;
     rc = profiled(f, EQF_PROF_UPDATE_PREP, [&] {
         // the landmark waves + E-chain operand + two more workgroups per filter that factor the first diagonal block of each chain
         // straight from Sigma (one launch: measured never slower than a separate factor launch, 4..64 filters)
@@ -735,6 +742,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             ra.gammaPart = f->dGammaPart; ra.g11Part = f->dG11Part;
             ra.nbCap = f->nbCap; ra.wtCap = f->wtCap;
             ra.stageFlags = f->resStaged ? f->dStageFlags : nullptr;
+            ra.eFromSigma = a.eFromSigma == 2 ? 1 : 0;
             // 64 x 64 downdate tiles: a tile costs the same 14 dependent chunk fetches whatever its size, and there are enough
             // finished workgroups to take one each
             // (a grid larger than what is co-resident must not wait for later workgroups while holding CUs: no-wait mode, see the kernel)
@@ -746,10 +754,9 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             const int ddGrid = nt64 * (nt64 + 1) / 2;  // downdate tiles as workgroups of their own behind the roles
             rc = profiled(f, EQF_PROF_CHOL_RESIDENT, [&] {
                 // (row heads with the pipelined panel loop only on a grid larger than the chip: see the kernel's PIPEH)
-                const bool pipeHeads = f->resPipeHeads >= 0 ? f->resPipeHeads != 0 : !residentFits;
+                const bool pipeHeads = resPipeHeads;
                 // (two workgroups per CU when the grid is many times the chip: see the kernel's OCC2)
-                const double perCU = double(f->rolesCount) * B / std::max(f->numCUs, 1);
-                const bool occ2 = f->resOcc2 >= 0 ? f->resOcc2 != 0 : (pipeHeads && (perCU > 6.0 || (B >= 8 && perCU > 4.5)));
+                const bool occ2 = resOcc2;
                 ra.nDdTiles = ddGrid;
                 ra.rolesPerRow = std::min(f->rolesCount + ddGrid, 32768);
                 const dim3 rg(B * ra.rolesPerRow, (f->rolesCount + ddGrid + ra.rolesPerRow - 1) / ra.rolesPerRow);

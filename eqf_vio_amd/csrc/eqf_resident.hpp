@@ -53,6 +53,8 @@ struct ResArgs {
     int* errflag;
     int nRoles, nDdTiles;  // role workgroups, downdate-tile workgroups behind them (per filter)
     int rolesPerRow;       // grid.x = batch * rolesPerRow
+    int eFromSigma;        // OCC2 build: the E-chain's tiles are first read straight from Sigma (EA = Sigma[6:, 6:] with the pad row / column 5 and
+                           // the rows past n_e as the identity): the prep launch does not copy them
     int* stageFlags;       // [B][2][nbCap][4]  stage j of D[K] of chain c is in the record (epoch valued; factor64's stageFlag)
 };
 
@@ -392,6 +394,17 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
     const int* flagD = ch.flags + (long long)b * ch.strideF;
     int* counters = ra.counters + (long long)b * 4;
     int bad = 0;
+    // element (i, j) of tile (R, C) of the chain matrix BEFORE any of this update's operations
+    const bool srcSigma = OCC2 && ra.eFromSigma && role.kind == 1;
+    const T* Sg = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
+    const int neE = eDim(g.N), ldS = a.ld;
+    auto tile0 = [&](int R, int C, int i, int j) __attribute__((always_inline)) {
+        if (!srcSigma) return A[(long long)(R * kSB + i) * ldA + C * kSB + j];
+        const int r = R * kSB + i, c = C * kSB + j;
+        const bool in = r < neE && c < neE && r != 5 && c != 5;
+        const double v = (double)Sg[in ? (long long)(6 + r) * ldS + 6 + c : 0];
+        return in ? v : (r == c ? 1.0 : 0.0);
+    };
 
     if (role.role == 0) {
         // =========================================================================================== H(R)
@@ -405,15 +418,13 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         tr[1] = wv == 2 ? 1 : 2; tc[1] = 1;
         tr[2] = wv == 2 ? 3 : 2; tc[2] = wv == 2 ? 1 : 2;
         tr[3] = 3;               tc[3] = wv == 2 ? 2 : 3;
-        const double* T1 = A + (long long)(R * kSB) * ldA + (R - 1) * kSB;
-        const double* T2 = A + (long long)(R * kSB) * ldA + R * kSB;
         f64x4 a1[4], a2[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                a1[i][q] = T1[(long long)(kQB * wv + (lane >> 4) + 4 * q) * ldA + kQB * i + (lane & 15)];
-                a2[i][q] = i < nt ? T2[(long long)(kQB * tr[i] + (lane >> 4) + 4 * q) * ldA + kQB * tc[i] + (lane & 15)] : 0.0;
+                a1[i][q] = tile0(R, R - 1, kQB * wv + (lane >> 4) + 4 * q, kQB * i + (lane & 15));
+                a2[i][q] = i < nt ? tile0(R, R, kQB * tr[i] + (lane >> 4) + 4 * q, kQB * tc[i] + (lane & 15)) : 0.0;
             }
         EQF_HSTAMP(0);
         // (A dry run of the serial part during the idle time before the panels arrive -- to take the instruction-cache misses of
@@ -542,12 +553,11 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         // =========================================================================================== T(R, C)
         const int R = role.R, C = role.C;
         if (R >= nb) return;
-        const double* Tg = A + (long long)(R * kSB) * ldA + C * kSB;
         f64x4 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[i][q] = Tg[(long long)(kQB * wv + (lane >> 4) + 4 * q) * ldA + kQB * i + (lane & 15)];
+            for (int q = 0; q < 4; ++q) acc[i][q] = tile0(R, C, kQB * wv + (lane >> 4) + 4 * q, kQB * i + (lane & 15));
         if (C > 0) {
             // pipelined panel loop (panelIssue above): panel K+1 is fetched during the products of panel K whenever its two blocks are
             // already out (a look at the flags one iteration ahead, never a wait); at the frontier -- the newest panel not published

@@ -167,7 +167,7 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, d
         const int nw = (int)blockDim.x >> 6;
         constexpr int kRowsTrip = 4, kColGroups = 10;
         // (a.eFromSigma: only the last 64-row block row is copied, 6 MB less traffic per filter and update at N = 200)
-        const bool copyRows = !a.eFromSigma || r0 + kNB > nep - 64;
+        const bool copyRows = a.eFromSigma != 2 && (!a.eFromSigma || r0 + kNB > nep - 64);  // (2: k_chol_resident, OCC2 build, reads every tile from Sigma)
         for (int rb = wv; rb < (copyRows ? kNB : 0); rb += nw * kRowsTrip) {
             for (int c0 = lane; c0 < nep; c0 += 64 * kColGroups) {
                 // raw loads first, conversion afterwards: with T = float a convert right behind each load makes hipcc wait
