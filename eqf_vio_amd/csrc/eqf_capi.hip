@@ -662,7 +662,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     if (!f->cholEmbed) embed = false;
     // (measured on the 256-CU part: 1500 workgroups = six per CU -- N = 200 from 8 filters on, N >= ~600)
     const bool splitChain = f->cholSplit >= 0 ? f->cholSplit != 0 : (long long)nblk64 * B >= 6LL * std::max(f->numCUs, 1);
-    bool resident = false, residentFits = false, resPipeHeads = false, resOcc2 = false;
+    bool resident = false, residentFits = false, resPipeHeads = false, resOcc2 = false, resESigma = false;
     int rc = EQF_OK;
     if (embed && f->cholResident && f->cholSplit <= 0 && f->dReadyA) {
         rc = buildRoles(f, Nmax);
@@ -698,10 +698,11 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         resPipeHeads = f->resPipeHeads >= 0 ? f->resPipeHeads != 0 : !residentFits;
         const double perCU = double(f->rolesCount) * B / std::max(f->numCUs, 1);
         resOcc2 = resident && (f->resOcc2 >= 0 ? f->resOcc2 != 0 : (resPipeHeads && (perCU > 6.0 || (B >= 8 && perCU > 4.5))));
+        resESigma = resOcc2 && resPipeHeads && perCU > 8.0;  // (8 filters of N = 200, 6.3 roles per CU: the kernel loses what the prep launch gains)
     }
     a.eFromSigma = (!resident && splitChain && f->cholTail && f->eFromSigma && f->precision != EQF_PRECISION_F32) ? 1 : 0;
     // (the OCC2 build reads the E-chain's tiles straight from Sigma: no copy in the prep launch; EQF_E_FROM_SIGMA=0: copied)
-    if (resOcc2 && resPipeHeads && f->eFromSigma && f->precision != EQF_PRECISION_F32) a.eFromSigma = 2;
+    if (resESigma && f->eFromSigma && f->precision != EQF_PRECISION_F32) a.eFromSigma = 2;
     rc = profiled(f, EQF_PROF_UPDATE_PREP, [&] {
         // the landmark waves + E-chain operand + two more workgroups per filter that factor the first diagonal block of each chain
         // straight from Sigma (one launch: measured never slower than a separate factor launch, 4..64 filters)
