@@ -677,16 +677,10 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         residentFits = (long long)f->rolesCount * B <= (long long)f->residentPerCU * f->numCUs;
         // Beyond co-residency the grid is interleaved (filter index fastest: all filters advance together, group by group) and nothing
         // waits for later workgroups.  Its workgroups mostly wait for hand-offs, so the chip carries several per CU without slowing the
-        // chains down; the downdate tiles are workgroups of their own at the end of the grid.  Measured (round 3, N = 200, steps/s,
-        // per-column launches -> this, with the pipelined panel loops of the interior / right-hand-side tiles): 2 filters 85.5 k -> 102.7 k,
-        // 4: 124.9 k -> 184 k, 8: 217.6 k -> 259.3 k, 12: 241.8 k -> 281.7 k, 16: 299.7 k -> 305.0 k; from 24 filters on the per-column
-        // launches win (331.3 k against 311.5 k).  EQF_RES_OVERSUB = the
-        // number of roles per CU up to which the resident kernel is used (default 10: up to 16 filters of N = 200; 0 = only when co-resident).
-        // ... and the same for ONE filter several times the size the kernel was written for: per-column launches of a single filter sit on
-        // the latency floor of the diagonal workgroup (23-35 us per block column), the resident kernel's period stays near the pivot
-        // chain's.  Measured break-even in roles per CU: one filter ~26 (N = 600: 11.7 k -> 20.1 k steps/s, N = 1000: 5.2 k -> 6.4 k,
-        // N = 1200: 3.64 k -> 4.08 k, N = 1500 even), 4 filters ~18 (N = 600 +9 %), 8 filters ~16 (N = 400 even), 24 filters < 13.7
-        // (N = 200: per-column launches win; 20 filters, 11.4: 339 k -> 356 k).  Default: 12 + 16 / batch.
+        // chains down; the downdate tiles are workgroups of their own at the end of the grid.  History of the switch-over (round 3, steps/s,
+        // per-column launches -> this): first up to 10 roles per CU (2 .. 16 filters of N = 200: 89 -> 107 k, 132 -> 202 k, 226 -> 298 k,
+        // 340 -> 373 k), then ONE filter up to ~26 roles per CU, whose per-column launches sit on the latency floor of the diagonal workgroup
+        // (N = 600: 11.7 k -> 19.7 k, N = 1000: 5.2 k -> 6.3 k), and finally:
         // Since the build for two workgroups per CU (k_chol_resident's OCC2, late in round 3) the resident kernel wins at EVERY size measured
         // -- 24 / 32 / 64 / 96 filters of N = 200: 386 -> 447 k, 410 -> 479 k, 453 -> 509 k, 478 -> 507 k steps/s; one filter of N = 1500 / 2000 /
         // 3000 / 4000: 2.23 -> 2.85 k, 1053 -> 1335, 344 -> 406, 151 -> 174 -- so the default is "whenever its buffers exist"; the per-column
@@ -1324,9 +1318,8 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
         if (!rc) f->numCUs = prop.multiProcessorCount;
         f->nbCap = std::max(mpC, nepC) / kSB;
         f->wtCap = ycC / kSB;
-        // the resident kernel's role table holds one workgroup per 64 x 64 tile: its buffers are only allocated while a filter has at
-        // most 28 roles per CU (N <= ~1500 on 256 CUs: beyond that the per-column launches win, see launchUpdateT); the batch may be
-        // larger than the chip (interleaved grid)
+        // the resident kernel's role table holds one workgroup per 64 x 64 tile; its flag / partial-sum buffers are allocated up to 200 k
+        // roles in the batch (one filter of N = 4000: 71 k), beyond that the per-column launches run
         const long long maxRoles = (long long)(f->nbCap + 1) * f->nbCap + (long long)f->wtCap * f->nbCap;
         if (!rc && maxRoles * B <= 200000) {  // (N = 4000: 71 k roles)
             chk(dmalloc(&f->dReadyA, (size_t)2 * f->nbCap * f->nbCap * B));
