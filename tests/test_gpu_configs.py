@@ -157,6 +157,32 @@ def test_cfg4_batch_of_64_filters_N200(oracle_lib, hip):
     assert rel_fro(fg.sigma(0), fg.sigma(1)) > 1e-3  # the filters really are different
 
 
+def test_batch_of_16_filters_N200_one_second_every_frame(oracle_lib, hip):
+    """16 filters of N = 200 in one handle over one second (20 vision updates): the one-launch update kernel in its build for two
+    workgroups per CU on a grid ten times the chip (round 3), every filter against its own structured oracle after EVERY frame --
+    epoch flags, ping-pong buffers and the hand-off buffers are reused twenty times."""
+    from eqf_vio_amd import synth
+
+    N, B = 200, 16
+    sts = [synth.make_stream(N, seed=4321 + b, duration=1.0) for b in range(B)]
+    d = synth.template_settings_dict()
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        refs = list(ex.map(lambda b: _oracle_frames(oracle_lib, d, sts[b], keep_sigma=b in (0, 7, 15)), range(B)))
+    fg = hip.FilterBatch(d, capacity=N, batch=B)
+    fg.stream_upload(np.stack([s.imu for s in sts], axis=1), np.stack([s.vision_stamps for s in sts], axis=1), sts[0].ids,
+                     np.stack([s.bearings for s in sts], axis=1))
+    fr = 0
+    for kind, k in sts[0].events():
+        if kind == "imu":
+            fg.stream_imu(k)
+        else:
+            fg.stream_vision(k)
+            for b in range(B):
+                _check_frame(fg, b, refs[b][fr], (b, fr))
+            fr += 1
+    assert fr == len(refs[0]) and fr >= 19 and fg.device_error() == 0
+
+
 def test_cfg2_N200_two_seconds_worst_frame(oracle_lib, hip):
     """BASELINE configs[1] over 2 s (400 IMU + 40 vision calls, per-call API, IMU bursts): Sigma and pose after EVERY vision
     update against the structured oracle, worst frame reported; the first second also against the dense oracle."""
