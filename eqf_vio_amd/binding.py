@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libeqf_vio_amd.so")
+# (EQF_VIO_AMD_LIB: an instrumented build of the same library for the stamp scripts, scripts/README.md -- never a fallback)
+LIB_PATH = os.environ.get("EQF_VIO_AMD_LIB") or os.path.join(_HERE, "libeqf_vio_amd.so")
 
 EQF_OK = 0
 SKIPPED_BEFORE_FIRST_IMU = 1

@@ -646,10 +646,15 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     cS.flags = f->dFlags; cS.strideF = 2 * f->flagStride; cS.epoch = f->updateEpoch;
     cE.flags = f->dFlags + f->flagStride; cE.strideF = 2 * f->flagStride; cE.epoch = f->updateEpoch;
     if (!attrSet64) {
-        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<double, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#ifdef EQF_F64_STAMPS
+        const int prepLdsMax = 158 * 1024;  // (the instrumented build keeps factor64's stamps in 1 KB of static LDS)
+#else
+        const int prepLdsMax = 160 * 1024;
+#endif
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, prepLdsMax));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<double, false>), hipFuncAttributeMaxDynamicSharedMemorySize, prepLdsMax));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, prepLdsMax));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_prep64<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, prepLdsMax));
         attrSet64 = true;
     }
     // ---- which shape the factorisation launches will have (decided here: the prep launch needs to know whether anybody reads EA's
@@ -1170,6 +1175,11 @@ extern "C" int eqf_debug_chol_wg(long long* t, int* info) {
 #ifdef EQF_RES_STAMPS
 extern "C" int eqf_debug_res_stamps(long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_resStamps), sizeof(long long) * 2 * 16 * 16) == hipSuccess ? 0 : -1;
+}
+#endif
+#if defined(EQF_RES_STAMPS) && defined(EQF_F64_STAMPS)
+extern "C" int eqf_debug_res_f64_stamps(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_resF64), sizeof(long long) * 2 * 16 * 128) == hipSuccess ? 0 : -1;
 }
 #endif
 #ifdef EQF_PREP_STAMPS

@@ -176,6 +176,15 @@ __device__ long long g_stamps[64][16];
 #define EQF_STAMP(i) do { } while (0)
 #define EQF_FSTAMP(i) do { } while (0)
 #endif
+// -DEQF_F64_STAMPS: shader-clock stamps of every wave inside factor64 (scripts/micro/factor64_bench.hip, scripts/res_stamps.py):
+// [wave][stage][0 stage start, 1 phase P done, 2 barrier A passed, 3 phase U done, 4 barrier B passed].  Kept in LDS (a global store per
+// stamp would sit in front of every __syncthreads' vmcnt(0)) and copied out at the end of the factorisation.
+#ifdef EQF_F64_STAMPS
+__shared__ long long sF64Stamps[4][4][8];
+#define EQF_F64STAMP(j, k) do { if ((threadIdx.x & 63) == 0) sF64Stamps[threadIdx.x >> 6][j][k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define EQF_F64STAMP(j, k) do { } while (0)
+#endif
 
 // Right-looking Cholesky of 16 columns of a 64-row panel by one wave, one row per lane.  The rows are ROTATED so that
 // every lane index in the loop is a compile-time constant (a run-time lane select costs an SALU add + hazard nops per
@@ -188,7 +197,7 @@ __device__ long long g_stamps[64][16];
 // iteration later, filling the latency of the next pivot's rsqrt chain) all use v_readlane broadcasts.
 // Measured in isolation (scripts/micro/potrf16_bench.hip): 4.1 k cycles warm, of which the pivot chain alone is 2.6 k.
 EQF_DI void potrf16(double (*T)[kSP], const double* src, int srcLd, double (*Wj)[kWP], int colBase, int rot, int nReal, bool hasId,
-    bool writeBack, int lane, int* bad) {
+    bool writeBack, int lane, int* bad, int stampStage = -1) {
     double row[kQB];
     const bool isId = hasId && lane >= 48;
     const bool isReal = lane < nReal;
@@ -196,6 +205,7 @@ EQF_DI void potrf16(double (*T)[kSP], const double* src, int srcLd, double (*Wj)
 #pragma unroll
     for (int c = 0; c < kQB; ++c) row[c] = isId ? ((lane - 48 == c) ? 1.0 : 0.0) : (isReal ? src[r * srcLd + colBase + c] : 0.0);
     double ljPrev = 0.0;
+    if (stampStage >= 0) EQF_F64STAMP(stampStage, 5);
 #pragma unroll
     for (int c = 0; c < kQB; ++c) {
         const double d = readlane64(row[c], c);
@@ -223,6 +233,7 @@ EQF_DI void potrf16(double (*T)[kSP], const double* src, int srcLd, double (*Wj)
         for (int c2 = c + 1; c2 < kQB; ++c2) __asm__ volatile("" : "+v"(row[c2]));
 #endif
     }
+    if (stampStage >= 0) EQF_F64STAMP(stampStage, 6);
     if (writeBack && isReal) {
 #pragma unroll
         for (int c = 0; c < kQB; ++c) T[r][colBase + c] = (lane >= c) ? row[c] : 0.0;
@@ -251,6 +262,288 @@ EQF_DI void storeDiagColumns(const Lds64& s, double* Dn, int j, int t, int nthr)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// factor64, round 4.  Shader-clock stamps of every wave (scripts/micro/factor64_bench.hip) showed that of the 5.8 k cycles a 16-column
+// stage of the round-3 version (factor64v1, kept below for the microbenchmark) cost, the sixteen pivots were 2.7 k: the rest was the
+// INSTRUCTION COUNT of the lone pivot wave around them -- a wave on its own issues one instruction per ~5 cycles -- namely 0.95 k cycles
+// to load its sixteen columns (exec-masked 8-byte loads, selects for the identity / idle lanes, SGPR spills), 0.9-1.1 k to write them back
+// (a select pair + store per value, the transposed scatter of the inverse block), and 1.0 k for two barriers with a tile update of its own
+// in between.  Now the pivot wave does nothing but: 8 ds_read2_b64 from a per-lane row address (real rows in s.L, the identity rows in
+// s.Wd[j], which is preset to I and receives L_jj^-T in the same eight ds_write2_b64 as the real rows), sixteen pivots, 8 ds_write2_b64,
+// two barriers.  Everything else moved to the other waves:
+//   waves 2, 3  own the six 16 x 16 tiles (r, c), 1 <= c <= r, IN REGISTERS from `pre` to their last update (v1: LDS round trip per update):
+//               after barrier A of stage j the tiles of column j+1 get update j and go to LDS (the only thing between two pivot chains),
+//               the others get it during the next stage's pivots;
+//   wave 1      carries the identity rows of stage 0 (as before) and from then on does the chores one stage behind the pivots: W_jj back to
+//               row-major, zeros above the diagonal of L_jj, columns j of the record to global memory (16-byte stores), drain, stage flag.
+// Same operations on every element in the same order as factor64v1: bitwise the same L and W.
+// Pre-condition (factorPrologue): s.D0 = leading 16 x 16 block of s.L, s.Wd[0] = I; post-condition: s.L lower block triangle, s.Wd row-major,
+// all LDS writes visible (ends with a barrier).
+EQF_DI void factorPrologue(const Lds64& s, int tid) {
+    if (tid < kQB * kQB) {
+        s.D0[tid >> 4][tid & 15] = s.L[tid >> 4][tid & 15];
+        s.Wd[0][tid >> 4][tid & 15] = ((tid >> 4) == (tid & 15)) ? 1.0 : 0.0;
+    }
+}
+// (the same for callers whose wave 0 writes s.D0 from registers: s.Wd[0] = I by the 64 lanes of another wave)
+EQF_DI void factorPrologueW(const Lds64& s, int lane) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s.Wd[0][(lane >> 4) + 4 * k][lane & 15] = ((lane >> 4) + 4 * k == (lane & 15)) ? 1.0 : 0.0;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EQF_LDS_BARRIER() __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define EQF_LDS_BARRIER() do { } while (0)
+#endif
+// The pivot wave's stage: sixteen values from rowPtr (8-byte aligned LDS address of this lane's row: a real row, an identity row, or any
+// harmless row for an idle lane), the right-looking 16-column factorisation with the pivots in lanes 0..15 (see potrf16), sixteen values
+// back to the same address (lanes with `store`).  scatterW: lanes 48.. instead scatter their row as a COLUMN of Wj (row-major inverse).
+EQF_DI void potrf16v2(double* rowPtr, bool store, bool scatterW, double (*Wj)[kWP], int lane, int* bad, int stampStage = -1) {
+    double row[kQB];
+#pragma unroll
+    for (int c = 0; c < kQB; ++c) row[c] = rowPtr[c];
+    double ljPrev = 0.0;
+    if (stampStage >= 0) EQF_F64STAMP(stampStage, 5);
+#pragma unroll
+    for (int c = 0; c < kQB; ++c) {
+        const double d = readlane64(row[c], c);
+        const double rd = rsqrtPivot(d);
+        if (c >= 1) {
+            double bc[kQB];
+#pragma unroll
+            for (int c2 = c + 1; c2 < kQB; ++c2) bc[c2] = readlane64(ljPrev, c2);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int c2 = c + 1; c2 < kQB; ++c2) __asm__ volatile("" : "+s"(bc[c2]));
+#endif
+#pragma unroll
+            for (int c2 = c + 1; c2 < kQB; ++c2) row[c2] = fma(-ljPrev, bc[c2], row[c2]);
+        }
+        const double lj = row[c] * rd;
+        if (c + 1 < kQB) row[c + 1] = fma(-lj, readlane64(lj, c + 1), row[c + 1]);
+        row[c] = lj;
+        ljPrev = lj;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int c2 = c + 1; c2 < kQB; ++c2) __asm__ volatile("" : "+v"(row[c2]));
+#endif
+    }
+    // a pivot that is not positive (or not a number) leaves NaNs in every later diagonal entry -- rsq of a negative number is NaN, of
+    // zero infinite, and 0 * inf, x - inf * inf end as NaN / -inf under the next square root -- so ONE test of the last diagonal entry
+    // replaces sixteen (which cost the lone pivot wave 32 instructions per stage)
+    if (!(readlane64(row[kQB - 1], kQB - 1) > 0.0)) *bad = 1;
+    if (stampStage >= 0) EQF_F64STAMP(stampStage, 6);
+    if (scatterW) {
+        if (store && lane < 48) {
+#pragma unroll
+            for (int c = 0; c < kQB; ++c) rowPtr[c] = row[c];
+        }
+        if (lane >= 48) {
+#pragma unroll
+            for (int c = 0; c < kQB; ++c) Wj[c][lane - 48] = row[c];
+        }
+    } else if (store) {
+#pragma unroll
+        for (int c = 0; c < kQB; ++c) rowPtr[c] = row[c];
+    }
+}
+// 16 x 16 block of LDS transposed in place by ONE wave (all reads before the first write)
+EQF_DI void transpose16(double (*Wj)[kWP], int lane) {
+    double v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = Wj[(lane + 64 * k) >> 4][lane & 15];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Wj[lane & 15][(lane + 64 * k) >> 4] = v[k];
+}
+// zeros above the diagonal of the 16 x 16 block at (base, base) of s.L, one wave, two unmasked stores per lane: the 120 entries in eight
+// groups of sixteen -- row g (15 - g entries) together with row 14 - g (g + 1 entries); row 7 pairs with itself (eight entries written twice)
+EQF_DI void zeroUpper16(const Lds64& s, int base, int lane) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int g = (lane >> 4) + 4 * k, idx = lane & 15;
+        const bool first = idx < 15 - g;
+        const int r = first ? g : 14 - g, c = first ? g + 1 + idx : 15 - (idx - (15 - g));
+        s.L[base + r][base + c] = 0.0;
+    }
+}
+// Columns [16 j, 16 j + 16) of s.L and W_jj (row-major in s.Wd[j]) -> record Dn, by ONE wave: ten 16-byte stores per lane, every LDS read
+// issued before the first store.  (The entries above the diagonal of L_jj are whatever LDS holds: zeroUpper16 comes first.)
+template <bool WT>
+EQF_DI void storeStageWave(const Lds64& s, double* Dn, int j, int lane) {
+    double v[10][2];
+    const int r0 = lane >> 3, c0 = kQB * j + 2 * (lane & 7);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        v[u][0] = s.L[r0 + 8 * u][c0];
+        v[u][1] = s.L[r0 + 8 * u][c0 + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = 2 * (lane + 64 * u);
+        v[8 + u][0] = s.Wd[j][e >> 4][e & 15];
+        v[8 + u][1] = s.Wd[j][e >> 4][(e & 15) + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        double* p = Dn + (r0 + 8 * u) * kSB + c0;
+        if (WT) hoStore16(p, v[u][0], v[u][1]);
+        else { p[0] = v[u][0]; p[1] = v[u][1]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        double* p = Dn + kSB * kSB + kQB * kQB * j + 2 * (lane + 64 * u);
+        if (WT) hoStore16(p, v[8 + u][0], v[8 + u][1]);
+        else { p[0] = v[8 + u][0]; p[1] = v[8 + u][1]; }
+    }
+}
+// The same by all 256 threads (the last stage and the identity padding behind it), with the zeros above the diagonal of L_jj supplied
+// here -- wave 1 may be zeroing them in LDS at the same time
+template <bool WT>
+EQF_DI void storeDiagColumns16(const Lds64& s, double* Dn, int j, int t, int nthr) {
+    for (int ch = t; ch < kSB * 8; ch += nthr) {
+        const int r = ch >> 3, c = kQB * j + 2 * (ch & 7);
+        const bool dg = (r >> 4) == j;
+        const double v0 = (dg && c > r) ? 0.0 : s.L[r][c], v1 = (dg && c + 1 > r) ? 0.0 : s.L[r][c + 1];
+        double* p = Dn + r * kSB + c;
+        if (WT) hoStore16(p, v0, v1);
+        else { p[0] = v0; p[1] = v1; }
+    }
+    for (int ch = t; ch < kQB * 8; ch += nthr) {
+        const int e = 2 * ch;
+        double* p = Dn + kSB * kSB + kQB * kQB * j + e;
+        if (WT) hoStore16(p, s.Wd[j][e >> 4][e & 15], s.Wd[j][e >> 4][(e & 15) + 1]);
+        else { p[0] = s.Wd[j][e >> 4][e & 15]; p[1] = s.Wd[j][e >> 4][(e & 15) + 1]; }
+    }
+}
+// The tile work of wave W = 2, 3 (compile-time tile tables, stages unrolled: every LDS address is a constant plus the lane's offset).
+//   slot: tile   wave 2: (1,1) (3,1) (3,2)   wave 3: (2,1) (2,2) (3,3)
+template <int W, bool WT, typename Pre>
+EQF_DI void factorTiles(const Lds64& s, int lane, Pre pre, int nStages) {
+    constexpr int TR[3] = {W == 2 ? 1 : 2, W == 2 ? 3 : 2, 3}, TC[3] = {1, W == 2 ? 1 : 2, W == 2 ? 2 : 3};
+    double* const L0 = &s.L[0][0];
+    // Wd[1..3] = I: the identity rows the pivot wave picks up in stage j >= 1 (and W_jj of the chain's identity padding, j >= nStages)
+    for (int e = lane + 64 * (W - 2); e < 3 * kQB * kQB; e += 128) s.Wd[1 + (e >> 8)][(e >> 4) & 15][e & 15] = (((e >> 4) & 15) == (e & 15)) ? 1.0 : 0.0;
+    pre(W);
+    f64x4 acc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc[k] = ldTile(L0, kSP, kQB * TR[k], kQB * TC[k], lane);
+    if (WT) hoDrain();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j < nStages) {
+            if (j > 0) {
+                // update j-1 of the tiles that are not due yet, in the shadow of the pivots of stage j
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if (TC[k] > j && TC[k] < nStages)
+                        acc[k] = mmTile<true, kQB>(acc[k], L0 + kQB * (j - 1), kSP, kQB * TR[k], L0 + kQB * (j - 1), kSP, kQB * TC[k], lane, -1.0);
+            }
+            EQF_F64STAMP(j, 1);
+            EQF_LDS_BARRIER();  // ---- A: columns j of L are in LDS
+            EQF_F64STAMP(j, 2);
+            if (j + 1 < nStages) {
+                // update j of the tiles of column j+1, which the next sixteen pivots start from: the only thing between two pivot chains
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if (TC[k] == j + 1) {
+                        acc[k] = mmTile<true, kQB>(acc[k], L0 + kQB * j, kSP, kQB * TR[k], L0 + kQB * j, kSP, kQB * (j + 1), lane, -1.0);
+                        stTile(acc[k], L0, kSP, kQB * TR[k], kQB * (j + 1), lane);
+                    }
+                EQF_F64STAMP(j, 3);
+                EQF_LDS_BARRIER();  // ---- B
+                EQF_F64STAMP(j, 4);
+            }
+        }
+    }
+}
+// `pre(wave)`: extra work of waves 2 and 3 in the shadow of the first sixteen pivots -- it leaves the tiles (r, c), c >= 1, of the block in
+// s.L (the diagonal workgroup's remaining trailing-update tiles).  `mid()`: thread 0, once, after the first stage's barrier A, by which
+// every thread has drained its write-through stores (WT): k_chol_resident publishes the solved block L_{R,R-1} there.
+// `stageFlag` (WT only; nullptr = none): stageFlag[j] <- epoch as soon as columns [16 j, 16 j + 16) of L and W_jj are in the record Dn,
+// j = 0..nStages-2 -- one stage behind the pivot chain.
+// One loop per wave role (the wave index is branched on OUTSIDE the stage loops: inside a common loop every wave pays for the address
+// induction variables and the branches of all roles -- a quarter of what was left between two pivot chains).  Every role passes the same
+// barriers: A_0 B_0 A_1 B_1 .. A_{n-1}, then the tail's.
+template <bool WT = false, typename Pre, typename Mid>
+EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn, long long* st, int nStages, Mid mid, int* stageFlag = nullptr,
+    int epoch = 0) {
+    const int lane = tid & 63, wv = tid >> 6;
+    double* const L0 = &s.L[0][0];
+    const int jl = nStages - 1;
+    if (wv == 0) {
+        // ---- the pivot wave
+        double* rp = L0 + lane * kSP;  // stage 0: row `lane`, columns 0..15
+#pragma unroll 1
+        for (int j = 0; j < nStages; ++j) {
+            EQF_F64STAMP(j, 0);
+            if (j > 0) {
+                const int base = kQB * j;
+                rp = lane < kSB - base ? L0 + (lane + base) * kSP + base : &s.Wd[j][lane >= 48 ? lane - 48 : 0][0];
+            }
+            potrf16v2(rp, j == 0 || lane < kSB - kQB * j || lane >= 48, j == jl && j > 0, s.Wd[j], lane, bad, j);
+            if (WT && j == 0) hoDrain();
+            EQF_F64STAMP(j, 1);
+            EQF_LDS_BARRIER();  // A
+            EQF_F64STAMP(j, 2);
+            if (j == 0 && lane == 0) mid();
+            if (j == jl) break;
+            EQF_LDS_BARRIER();  // B
+            EQF_F64STAMP(j, 4);
+        }
+    } else if (wv == 1) {
+        // ---- stage 0: the identity rows next to a copy of the leading block (the pivot wave has no idle lanes there); then the chores,
+        // one stage behind the pivots: W_jj^T -> W_jj, zeros above the diagonal of L_jj, columns j of the record, drain, stage flag
+        EQF_F64STAMP(0, 0);
+        potrf16v2(lane < kQB ? &s.D0[lane][0] : &s.Wd[0][lane >= 48 ? lane - 48 : 0][0], lane >= 48, false, s.Wd[0], lane, bad);
+        if (WT) hoDrain();
+        EQF_F64STAMP(0, 1);
+        EQF_LDS_BARRIER();  // A_0
+#pragma unroll 1
+        for (int j = 1; j < nStages; ++j) {
+            EQF_LDS_BARRIER();  // B_{j-1}
+            EQF_F64STAMP(j, 0);
+            transpose16(s.Wd[j - 1], lane);
+            zeroUpper16(s, kQB * (j - 1), lane);
+            EQF_F64STAMP(j, 5);
+            if (Dn) {
+                storeStageWave<WT>(s, Dn, j - 1, lane);
+                EQF_F64STAMP(j, 6);
+                if (WT && stageFlag) {
+                    hoDrain();
+                    if (lane == 0) hoPublish(stageFlag + (j - 1), epoch);
+                }
+            }
+            EQF_F64STAMP(j, 1);
+            EQF_LDS_BARRIER();  // A_j
+        }
+    } else if (wv == 2) {
+        factorTiles<2, WT>(s, lane, pre, nStages);
+    } else {
+        factorTiles<3, WT>(s, lane, pre, nStages);
+    }
+    // ---- tail.  The last real stage jl: its inverse block is already row-major (the pivot wave scattered it) unless jl == 0 (wave 1 held
+    // the identity rows: transposed)
+    if (jl == 0) {
+        if (wv == 1) transpose16(s.Wd[0], lane);
+        EQF_LDS_BARRIER();
+    }
+    if (wv == 1) zeroUpper16(s, kQB * jl, lane);
+#ifdef EQF_F64_STAMPS
+    if (st) {
+        EQF_LDS_BARRIER();
+        if (tid < 128) st[tid] = (&sF64Stamps[0][0][0])[tid];
+    }
+#endif
+    if (Dn)
+        for (int j = jl; j < 4; ++j) storeDiagColumns16<WT>(s, Dn, j, tid, 256);
+    EQF_LDS_BARRIER();
+}
+template <typename Pre>
+EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn = nullptr, long long* st = nullptr, int nStages = 4) {
+    factor64<false>(s, tid, bad, pre, Dn, st, nStages, [] {});
+}
+
+// ---- the round-3 version, kept for scripts/micro/factor64_bench.hip (variant 1)
 // Factor the 64x64 symmetric block in s.L in place (lower block triangle; the upper triangles of the diagonal blocks are
 // zeroed) and form s.Wd.  All 256 threads.  `pre` is extra work for waves 2 and 3 during the first stage (the diagonal
 // workgroup's remaining trailing-update tiles): pre(wave).
@@ -260,7 +553,7 @@ EQF_DI void storeDiagColumns(const Lds64& s, double* Dn, int j, int t, int nthr)
 // j = 0..nStages-2 -- one stage behind the pivot chain, stored and drained by waves 2, 3 in its shadow.  A consumer that only needs the
 // record stage by stage (the row head of k_chol_resident's next block column) overlaps its own work with the rest of this factorisation.
 template <bool WT = false, typename Pre, typename Mid>
-EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn, long long* st, int nStages, Mid mid, int* stageFlag = nullptr,
+EQF_DI void factor64v1(const Lds64& s, int tid, int* bad, Pre pre, double* Dn, long long* st, int nStages, Mid mid, int* stageFlag = nullptr,
     int epoch = 0) {
     const int lane = tid & 63, wv = tid >> 6;
     int* const stageCnt = reinterpret_cast<int*>(&s.D0[kQB - 1][kQB]);  // (pad column of D0: nobody reads it)
@@ -272,9 +565,10 @@ EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn, lon
 #pragma unroll 1
     for (int j = 0; j < nStages; ++j) {
         const int base = kQB * j;
+        EQF_F64STAMP(j, 0);
         // ---- phase P: the next 16 columns (wave 0; wave 1 carries the identity rows at stage 0, where wave 0 has no idle
         // lanes) while waves 2, 3 apply the deferred updates of stage j-1 to the columns >= j+1
-        if (wv == 0) potrf16(s.L, &s.L[0][0], kSP, s.Wd[j], base, base, kSB - base, j > 0, true, lane, bad);
+        if (wv == 0) potrf16(s.L, &s.L[0][0], kSP, s.Wd[j], base, base, kSB - base, j > 0, true, lane, bad, j);
         else if (wv == 1 && j == 0) potrf16(s.L, &s.D0[0][0], kWP, s.Wd[0], 0, 0, kQB, true, false, lane, bad);
         else if (wv >= 2) {
             if (j == 0) pre(wv);
@@ -306,7 +600,9 @@ EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn, lon
 #ifdef EQF_STEP64_STAMPS
         if (st && tid == 0) st[2 * j] = __builtin_readcyclecounter();
 #endif
+        EQF_F64STAMP(j, 1);
         __syncthreads();
+        EQF_F64STAMP(j, 2);
         // ---- phase U: the tiles of column j+1 (needed by the next stage), one per wave:  T_r,j+1 -= L_rj L_j+1,j^T
         if (j + 1 < nStages && wv < 3 - j) {
             const int r = j + 1 + wv;
@@ -317,15 +613,23 @@ EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn, lon
 #ifdef EQF_STEP64_STAMPS
         if (st && tid == 0) st[2 * j + 1] = __builtin_readcyclecounter();
 #endif
+        EQF_F64STAMP(j, 3);
         __syncthreads();
+        EQF_F64STAMP(j, 4);
         if (j == 0) mid();
     }
+#ifdef EQF_F64_STAMPS
+    if (st) {
+        __syncthreads();
+        if (tid < 128) st[tid] = (&sF64Stamps[0][0][0])[tid];
+    }
+#endif
     if (Dn)
         for (int j = nStages - 1; j < 4; ++j) storeDiagColumns<WT>(s, Dn, j, tid, 256);
 }
 template <typename Pre>
-EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn = nullptr, long long* st = nullptr, int nStages = 4) {
-    factor64<false>(s, tid, bad, pre, Dn, st, nStages, [] {});
+EQF_DI void factor64v1(const Lds64& s, int tid, int* bad, Pre pre, double* Dn = nullptr, long long* st = nullptr, int nStages = 4) {
+    factor64v1<false>(s, tid, bad, pre, Dn, st, nStages, [] {});
 }
 // stages of the 64-wide block starting at column c0 of a chain of real order n that hold a real column
 EQF_DI int realStages(int n, int c0) { return max(1, min(4, (min(kSB, n - c0) + kQB - 1) / kQB)); }
@@ -454,7 +758,7 @@ EQF_DI void factorFirstFromSigma(const UpdArgs& a, const ChainArgs& ch, int b, c
         }
     }
     __syncthreads();
-    if (tid < kQB * kQB) s.D0[tid >> 4][tid & 15] = s.L[tid >> 4][tid & 15];
+    factorPrologue(s, tid);
     __syncthreads();
     factor64(s, tid, bad, [](int) {}, ch.D + (long long)b * ch.strideD, nullptr, realStages(ch.kind == 0 ? sDim(N) : eDim(N), 0));
 }
@@ -498,7 +802,7 @@ inline __global__ __launch_bounds__(256) void k_factor_first64(ChainArgs c0, Cha
     const double* A = ch.A + (long long)b * ch.strideA;
     for (int e = tid; e < kSB * kSB; e += 256) s.L[e >> 6][e & 63] = A[(long long)(e >> 6) * ch.ldA + (e & 63)];
     __syncthreads();
-    if (tid < kQB * kQB) s.D0[tid >> 4][tid & 15] = s.L[tid >> 4][tid & 15];
+    factorPrologue(s, tid);
     __syncthreads();
     int bad = 0;
     factor64(s, tid, &bad, [](int) {}, ch.D + (long long)b * ch.strideD);
@@ -1094,6 +1398,7 @@ __global__ __launch_bounds__(256, (PHASE == 2 || PHASE == 3) ? 2 : 1) void k_cho
             upd(0);
             stTile(acc[0], &s.L[0][0], kSP, kQB * tr[0], kQB * tc[0], lane);
             if (wv == 0) stTile(acc[0], &s.D0[0][0], kWP, 0, 0, lane);
+            if (wv == 1) factorPrologueW(s, lane);
             __syncthreads();
             EQF_STAMP(3);
             auto pre = [&](int) {

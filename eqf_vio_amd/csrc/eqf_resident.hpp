@@ -310,6 +310,12 @@ __device__ long long g_resStamps[2][16][16];  // [chain][R][phase] wall-clock (1
 #define EQF_HSTAMP(i) do { } while (0)
 #define EQF_WSTAMP(i) do { } while (0)
 #endif
+#if defined(EQF_RES_STAMPS) && defined(EQF_F64_STAMPS)
+__device__ long long g_resF64[2][16][128];  // [chain][R]: factor64's per-wave stamps (sF64Stamps) of the row heads, filter EQF_STAMP_B
+#define EQF_F64_ST() ((b == EQF_STAMP_B && R < 16) ? &g_resF64[role.kind][R][0] : nullptr)
+#else
+#define EQF_F64_ST() nullptr
+#endif
 // PIPEH: the row heads apply their old panels with the pipelined loop of the interior tiles as well.  Off for a grid that is co-resident
 // (one or two small filters: every head is there from the start and applies each panel the moment it appears; the 64 prefetch registers
 // cost the pivot chain 4 us per update through the register allocation), on for a batch on a grid larger than the chip: there a head is
@@ -523,6 +529,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         EQF_HSTAMP(5);
         stTile(a2[0], &s.L[0][0], kSP, kQB * tr[0], kQB * tc[0], lane);
         if (wv == 0) stTile(a2[0], &s.D0[0][0], kWP, 0, 0, lane);
+        if (wv == 1) factorPrologueW(s, lane);
         __syncthreads();
         auto pre = [&](int) {
 #pragma unroll
@@ -536,13 +543,12 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         // waves 2, 3 alone store the block and the second of them to have drained publishes it right after its deferred tiles, 1.5 us
         // earlier for the next row head -- 138 -> 142 us per update: sixteen write-through stores per thread and a drain in front of the
         // first stage's barrier cost the pivot chain more than the next head gains.)
+        // (factor64 calls this from thread 0 alone, after the first stage's barrier, by which every thread has drained its stores)
         auto mid = [&] {
-            hoDrain();
-            __syncthreads();
-            if (tid == 0 && bad != 8) hoPublish(readyA + R * nbCap + (R - 1), epoch);
+            if (bad != 8) hoPublish(readyA + R * nbCap + (R - 1), epoch);
             EQF_HSTAMP(12);
         };
-        factor64<true>(s, tid, &bad, pre, D + (long long)R * kDRec, nullptr, realStages(ch.kind == 0 ? sDim(g.N) : eDim(g.N), kSB * R), mid,
+        factor64<true>(s, tid, &bad, pre, D + (long long)R * kDRec, EQF_F64_ST(), realStages(ch.kind == 0 ? sDim(g.N) : eDim(g.N), kSB * R), mid,
             stageOut, epoch);
         EQF_HSTAMP(7);
         hoDrain();

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void k_tile_potrf(double* A, int ld, int n, do
     for (int kb = 0; kb < nb; ++kb) {
         loadBlock(s.L, kb, kb, true);
         __syncthreads();
-        if (tid < kQB * kQB) s.D0[tid >> 4][tid & 15] = s.L[tid >> 4][tid & 15];
+        factorPrologue(s, tid);
         __syncthreads();
         factor64(s, tid, &bad, [](int) {}, drec + (long long)kb * kDRec, nullptr, realStages(n, kSB * kb));
         __syncthreads();

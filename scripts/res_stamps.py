@@ -45,3 +45,18 @@ if x[0] > 0:
     print("downdate tiles 0 / 27 / 54 as workgroups of their own (grid larger than the chip): dispatched, last Y tile seen, done")
     for k in range(3):
         print("   ", " ".join(f"{(x[3 * k + i] - t0) / 100.0:7.2f}" for i in range(3)))
+
+# factor64's own stamps of every wave (library built with -DEQF_RES_STAMPS -DEQF_F64_STAMPS): shader cycles since wave 0 entered stage 0
+if hasattr(binding.lib(), "eqf_debug_res_f64_stamps"):
+    o2 = (C.c_longlong * (2 * 16 * 128))()
+    assert binding.lib().eqf_debug_res_f64_stamps(o2) == 0
+    f = np.array(o2, dtype=np.int64).reshape(2, 16, 4, 4, 8)
+    for ch, nm in ((1, "E-chain"), (0, "S-chain")):
+        for R in (2, 5):
+            if f[ch, R, 0, 0, 0] == 0:
+                continue
+            t0 = f[ch, R, 0, 0, 0]
+            print(f"factor64 inside {nm} H({R}): per wave and stage: start | P done | A passed | U done | B passed | rows loaded | pivots done  (cycles)")
+            for w in range(4):
+                for j in range(4):
+                    print(f"   wave {w} stage {j}:", " ".join(f"{(f[ch, R, w, j, k] - t0) if f[ch, R, w, j, k] else -1:7d}" for k in range(7)))
