@@ -298,6 +298,12 @@ EQF_DI void factorPrologueW(const Lds64& s, int lane) {
 // The pivot wave's stage: sixteen values from rowPtr (8-byte aligned LDS address of this lane's row: a real row, an identity row, or any
 // harmless row for an idle lane), the right-looking 16-column factorisation with the pivots in lanes 0..15 (see potrf16), sixteen values
 // back to the same address (lanes with `store`).  scatterW: lanes 48.. instead scatter their row as a COLUMN of Wj (row-major inverse).
+// (Round 4, measured with scripts/micro/factor64_bench.hip and not kept: the next pivot formed as a wave-uniform d' = a - l^2 from two
+// broadcasts, one of them off the dependent chain -- one v_readlane round trip less per pivot, bitwise the same value: 15.67 k -> 16.03 k
+// cycles per block, three more instructions per pivot cost more than the shorter chain gains; the multipliers of the rank-1 updates from
+// LDS (one 8-byte store per pivot, one ds_read2_b64 per two multipliers instead of four v_readlane_b32): 160 instructions fewer per stage and
+// 16.9 k cycles -- the waits for LDS sit in front of the chain's instructions, a lone wave issues in order.  v_rsq_f64 is good to 2^-24.2,
+// one Newton step leaves 4.2e-15 = 38 ulp, two 2.4e-16 (scripts/micro/rsq_acc.hip): both steps stay.)
 EQF_DI void potrf16v2(double* rowPtr, bool store, bool scatterW, double (*Wj)[kWP], int lane, int* bad, int stampStage = -1) {
     double row[kQB];
 #pragma unroll
@@ -309,6 +315,7 @@ EQF_DI void potrf16v2(double* rowPtr, bool store, bool scatterW, double (*Wj)[kW
         const double d = readlane64(row[c], c);
         const double rd = rsqrtPivot(d);
         if (c >= 1) {
+            // all broadcasts of the column first (distinct SGPR pairs, pinned), then the FMAs: one v_readlane -> VALU hazard per column
             double bc[kQB];
 #pragma unroll
             for (int c2 = c + 1; c2 < kQB; ++c2) bc[c2] = readlane64(ljPrev, c2);

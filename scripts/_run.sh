@@ -1,6 +1,8 @@
-mkdir -p gpurun_out/r4e
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r4e/pytest.txt 2>&1
-EQF_VIO_AMD_LIB=$PWD/build_variants/libeqf_stamps.so python scripts/res_stamps.py 200 1 > gpurun_out/r4e/res_stamps.txt 2>&1
-python bench.py --no-cpu-baseline --no-batch64 --no-parity --no-tiled --no-traffic > gpurun_out/r4e/bench_N200.json 2> gpurun_out/r4e/bench_N200.err
-python bench.py --filters-per-gpu 8 --steps 880 --warmup 110 --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-steady-state > gpurun_out/r4e/bench_b8.json 2>/dev/null
-python bench.py --filters-per-gpu 64 --steps 440 --warmup 110 --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-steady-state > gpurun_out/r4e/bench_b64.json 2>/dev/null
+mkdir -p gpurun_out/r4f
+./scripts/micro/rsq_acc > gpurun_out/r4f/rsq.txt 2>&1
+for m in 0 1 2; do for wt in 0 1; do
+  echo "=== mode $m wt $wt" >> gpurun_out/r4f/f64.txt
+  timeout 60 ./scripts/micro/factor64_bench_m$m 0 $wt 4 | head -3 >> gpurun_out/r4f/f64.txt 2>&1
+done; done
+timeout 60 ./scripts/micro/factor64_bench_m2s 0 0 4 > gpurun_out/r4f/f64_m2_stamps.txt 2>&1
+EQF_VIO_AMD_LIB=$PWD/build_variants/libeqf_stamps.so python scripts/res_stamps.py 200 1 > gpurun_out/r4f/res_stamps.txt 2>&1
