@@ -1369,7 +1369,7 @@ __global__ __launch_bounds__(256, (PHASE == 2 || PHASE == 3) ? 2 : 1) void k_cho
 #pragma unroll
             for (int i = 0; i < 4; ++i) stTile(acc[i], &s.P[0][0], kSP, kQB * tr[i], kQB * tc[i], lane);
             const double* Dn = D + (long long)(K + 1) * kDRec;
-            if (tid == 0 && !hoWait(ch.flags + (long long)b * ch.strideF + K + 1, ch.epoch)) bad = 8;  // (timed out: flagged, no hang)
+            if (tid == 0 && !hoWait(ch.flags + (long long)b * ch.strideF + K + 1, ch.epoch, errflag)) bad = 8;  // (timed out: flagged, no hang)
             __syncthreads();
             Lds64 sT = s;
             sT.L = s.Q;  // the factor of the diagonal block goes where L_CK was

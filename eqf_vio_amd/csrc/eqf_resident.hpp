@@ -212,11 +212,12 @@ EQF_DEV void hoStoreRecord(double* Dk, const Lds64& s, int tid) {
 }
 
 // Thread 0 waits for up to three flags (nullptr = none).  Returns through `bad` (8 = timed out).
-EQF_DEV void hoWait3(const int* f0, const int* f1, const int* f2, int epoch, int tid, int* bad) {
-    if (tid == 0) {
-        if (f0 && !hoWait(f0, epoch)) *bad = 8;
-        if (f1 && !hoWait(f1, epoch)) *bad = 8;
-        if (f2 && !hoWait(f2, epoch)) *bad = 8;
+// (once a wait has failed -- *bad == 8 -- the later ones of this workgroup are skipped: it publishes nothing more anyway)
+EQF_DEV void hoWait3(const int* f0, const int* f1, const int* f2, int epoch, int tid, int* bad, int* err) {
+    if (tid == 0 && *bad != 8) {
+        if (f0 && !hoWait(f0, epoch, err)) *bad = 8;
+        if (*bad != 8 && f1 && !hoWait(f1, epoch, err)) *bad = 8;
+        if (*bad != 8 && f2 && !hoWait(f2, epoch, err)) *bad = 8;
     }
     __syncthreads();
 }
@@ -229,7 +230,7 @@ EQF_DEV void hoWait3(const int* f0, const int* f1, const int* f2, int epoch, int
 // wait, one round trip for the three of them, then the last stage on its own.)  Same operations in the same order as solveStrip<true>:
 // bitwise the same block.  Result in s.P; all 256 threads; ends with a barrier.
 EQF_DEV void stagedPanelSolve(const f64x4 (&acc)[4], const Lds64& s, const double* Dk, const int* stageIn, const int* flagWhole, int epoch, int tid,
-    int* bad) {
+    int* bad, int* err) {
     const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
     for (int i = 0; i < 4; ++i) stTile(acc[i], &s.P[0][0], kSP, kQB * wv, kQB * i, lane);
@@ -241,7 +242,7 @@ EQF_DEV void stagedPanelSolve(const f64x4 (&acc)[4], const Lds64& s, const doubl
 #pragma unroll
         for (int q = 0; q < 4; ++q) Z[j][q] = s.P[x0 + lc][kQB * j + lg + 4 * q];
     const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
-    hoWait3(stageIn + 2, nullptr, nullptr, epoch, tid, bad);
+    hoWait3(stageIn + 2, nullptr, nullptr, epoch, tid, bad, err);
     hoLoadStages012(Dk, s, tid);
     __syncthreads();
 #pragma unroll
@@ -250,7 +251,7 @@ EQF_DEV void stagedPanelSolve(const f64x4 (&acc)[4], const Lds64& s, const doubl
 #pragma unroll
         for (int j2 = j + 1; j2 < 4; ++j2) Z[j2] = mmRegB(Z[j2], &s.L[0][0], kSP, kQB * j2, kQB * j, X[j], lane, -1.0);
     }
-    hoWait3(flagWhole, nullptr, nullptr, epoch, tid, bad);
+    hoWait3(flagWhole, nullptr, nullptr, epoch, tid, bad, err);
     hoLoadW3(Dk, s, tid);
     __syncthreads();
     X[3] = mmRegB(zero, &s.Wd[3][0][0], kWP, 0, 0, Z[3], lane, 1.0);
@@ -354,8 +355,12 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
             const long long t0 = wall_clock64();
             while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nS * wS) {
                 __builtin_amdgcn_s_sleep(32);
+                if (hoAborted(ra.errflag)) {  // (some hand-off of this launch timed out: nobody will finish the S-chain)
+                    late = 1;
+                    break;
+                }
                 if (wall_clock64() - t0 > 50000000LL) {  // 0.5 s
-                    if (ra.errflag) atomicOr(ra.errflag, 8);
+                    if (ra.errflag) atomicOr(ra.errflag, kHoErrTimeout);
                     late = 1;
                     break;
                 }
@@ -372,6 +377,9 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
 #endif
         return;
     }
+    // (bit 8 of the sticky device error word: a hand-off of this launch -- or of an earlier one: the handle must be reset -- timed out.
+    // Role workgroups that start after that leave at once; nothing they would publish could be complete.)
+    if (hoAborted(ra.errflag)) return;
     const ResRole role = ra.roles[roleIdx];
     const int b = bIdx;
     const ChainArgs& ch = role.kind ? ra.c1 : ra.c0;
@@ -442,7 +450,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
                 const double* rowP = A + (long long)(R * kSB) * ldA;
                 const double* rowQ = A + (long long)((R - 1) * kSB) * ldA;
                 const int nK = R - 2;  // panels 0 .. R-3; the last one, K = R-2, below as always
-                hoWait3(readyA + R * nbCap, readyA + (R - 1) * nbCap, nullptr, epoch, tid, &bad);
+                hoWait3(readyA + R * nbCap, readyA + (R - 1) * nbCap, nullptr, epoch, tid, &bad, ra.errflag);
                 panelIssue(pr, rowP, ldA, rowQ, ldA, tid);
                 bool probe = (tid == 0 && nK > 1) ? hoProbe2(readyA + R * nbCap + 1, readyA + (R - 1) * nbCap + 1, epoch) : false;
                 for (int K = 0; K < nK; ++K) {
@@ -461,7 +469,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
                         if (i < nt) a2[i] = mmTile<true, kSB>(a2[i], &s.P[0][0], kSP, kQB * tr[i], &s.P[0][0], kSP, kQB * tc[i], lane, -1.0);
                     __syncthreads();
                     if (K + 1 < nK && !ahead) {
-                        hoWait3(readyA + R * nbCap + K + 1, readyA + (R - 1) * nbCap + K + 1, nullptr, epoch, tid, &bad);
+                        hoWait3(readyA + R * nbCap + K + 1, readyA + (R - 1) * nbCap + K + 1, nullptr, epoch, tid, &bad, ra.errflag);
                         panelIssue(pr, rowP + (K + 1) * kSB, ldA, rowQ + (K + 1) * kSB, ldA, tid);
                         probe = (tid == 0 && K + 2 < nK) ? hoProbe2(readyA + R * nbCap + K + 2, readyA + (R - 1) * nbCap + K + 2, epoch) : false;
                     }
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         }
         for (int K = PIPEH ? max(R - 2, 0) : 0; K + 1 < R; ++K) {
             if (K + 2 < R) {
-                hoWait3(readyA + R * nbCap + K, readyA + (R - 1) * nbCap + K, nullptr, epoch, tid, &bad);
+                hoWait3(readyA + R * nbCap + K, readyA + (R - 1) * nbCap + K, nullptr, epoch, tid, &bad, ra.errflag);
                 hoLoadBlocks2(A + (long long)(R * kSB) * ldA + K * kSB, ldA, s.P, A + (long long)((R - 1) * kSB) * ldA + K * kSB, ldA, s.Q, tid);
                 __syncthreads();
 #pragma unroll
@@ -485,13 +493,13 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
                 // applied to the diagonal tile first, and what is left behind the late block is one 64 x 64 x 64 product instead of two
                 // (measured: 7 us from that flag to "panels applied" before -- a second critical path as long as the pivot chain's).
                 EQF_HSTAMP(9);
-                hoWait3(readyA + R * nbCap + K, nullptr, nullptr, epoch, tid, &bad);
+                hoWait3(readyA + R * nbCap + K, nullptr, nullptr, epoch, tid, &bad, ra.errflag);
                 hoLoadBlock(A + (long long)(R * kSB) * ldA + K * kSB, ldA, s.P, tid);
                 __syncthreads();
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (i < nt) a2[i] = mmTile<true, kSB>(a2[i], &s.P[0][0], kSP, kQB * tr[i], &s.P[0][0], kSP, kQB * tc[i], lane, -1.0);
-                hoWait3(readyA + (R - 1) * nbCap + K, nullptr, nullptr, epoch, tid, &bad);
+                hoWait3(readyA + (R - 1) * nbCap + K, nullptr, nullptr, epoch, tid, &bad, ra.errflag);
                 EQF_HSTAMP(10);
                 hoLoadBlock(A + (long long)((R - 1) * kSB) * ldA + K * kSB, ldA, s.Q, tid);
                 __syncthreads();
@@ -506,7 +514,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         int* const stageOut = ra.stageFlags ? ra.stageFlags + (((long long)b * 2 + role.kind) * nbCap + R) * 4 : nullptr;
         if (R - 1 == 0 || !ra.stageFlags) {
             // D[0] comes complete from the prep launch
-            hoWait3(R - 1 > 0 ? flagD + (R - 1) : nullptr, nullptr, nullptr, epoch, tid, &bad);
+            hoWait3(R - 1 > 0 ? flagD + (R - 1) : nullptr, nullptr, nullptr, epoch, tid, &bad, ra.errflag);
             EQF_HSTAMP(2);
             hoLoadRecord(D + (long long)(R - 1) * kDRec, s, tid);
 #pragma unroll
@@ -518,7 +526,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         } else {
             // D[R-1] is being factored by the previous row head RIGHT NOW: stage by stage (stagedPanelSolve, above)
             stagedPanelSolve(a1, s, D + (long long)(R - 1) * kDRec, ra.stageFlags + (((long long)b * 2 + role.kind) * nbCap + (R - 1)) * 4,
-                flagD + (R - 1), epoch, tid, &bad);
+                flagD + (R - 1), epoch, tid, &bad, ra.errflag);
         }
         EQF_HSTAMP(4);
         // first column of the diagonal tile, then the factorisation with the other tiles deferred to waves 2, 3; the solved
@@ -572,7 +580,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
             PanelRegs pr;
             const double* rowP = A + (long long)(R * kSB) * ldA;
             const double* rowQ = A + (long long)(C * kSB) * ldA;
-            hoWait3(readyA + R * nbCap, readyA + C * nbCap, nullptr, epoch, tid, &bad);
+            hoWait3(readyA + R * nbCap, readyA + C * nbCap, nullptr, epoch, tid, &bad, ra.errflag);
             panelIssue(pr, rowP, ldA, rowQ, ldA, tid);
             bool probe = (tid == 0 && C > 1) ? hoProbe2(readyA + R * nbCap + 1, readyA + C * nbCap + 1, epoch) : false;
             for (int K = 0; K < C; ++K) {
@@ -588,7 +596,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
                 for (int i = 0; i < 4; ++i) acc[i] = mmTile<true, kSB>(acc[i], &s.P[0][0], kSP, kQB * wv, &s.Q[0][0], kSP, kQB * i, lane, -1.0);
                 __syncthreads();
                 if (K + 1 < C && !ahead) {
-                    hoWait3(readyA + R * nbCap + K + 1, readyA + C * nbCap + K + 1, nullptr, epoch, tid, &bad);
+                    hoWait3(readyA + R * nbCap + K + 1, readyA + C * nbCap + K + 1, nullptr, epoch, tid, &bad, ra.errflag);
                     panelIssue(pr, rowP + (K + 1) * kSB, ldA, rowQ + (K + 1) * kSB, ldA, tid);
                     probe = (tid == 0 && K + 2 < C) ? hoProbe2(readyA + R * nbCap + K + 2, readyA + C * nbCap + K + 2, epoch) : false;
                 }
@@ -598,7 +606,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         // head H(C+2) waits for: no change, 137.8 against 138.3 us per update -- once the heads consume D stage by stage the pivot chain
         // and its hand-off are the critical path again, 13.6 us per block column: factor64 10.3, store issue + first column 1.1, flag +
         // W_33 0.9, last solve step 0.3, publish 0.45.)
-        hoWait3(C > 0 ? flagD + C : nullptr, nullptr, nullptr, epoch, tid, &bad);
+        hoWait3(C > 0 ? flagD + C : nullptr, nullptr, nullptr, epoch, tid, &bad, ra.errflag);
         hoLoadRecord(D + (long long)C * kDRec, s, tid);
 #pragma unroll
         for (int i = 0; i < 4; ++i) stTile(acc[i], &s.P[0][0], kSP, kQB * wv, kQB * i, lane);
@@ -634,7 +642,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         auto collect = [&]() {
             collected = true;
             const int* ryS = ra.readyY + ((long long)b * 2 + 0) * nbCap * wtCap;
-            if (tid < wtS && !hoWait(ryS + (nbS - 1) * wtCap + tid, epoch)) bad = 8;
+            if (tid < wtS && !hoWait(ryS + (nbS - 1) * wtCap + tid, epoch, ra.errflag)) bad = 8;
             bad = __syncthreads_or(bad) ? 8 : 0;  // (a timeout seen by ANY of the polling threads is reported below by thread 0)
             double* gam = a.dbgGamma + (long long)b * (kLm0 + 3 * a.cap);
             const int ldY = ra.c0.ldW;
@@ -675,7 +683,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
             auto look = [&](int K) {
                 return (tid == 0 && K < C) ? hoProbe3(readyA + C * nbCap + K, readyY + K * wtCap + t, isS ? readyY + K * wtCap : nullptr, epoch) : false;
             };
-            hoWait3(readyA + C * nbCap, readyY + t, isS ? readyY : nullptr, epoch, tid, &bad);
+            hoWait3(readyA + C * nbCap, readyY + t, isS ? readyY : nullptr, epoch, tid, &bad, ra.errflag);
             issue(0);
             bool probe = look(1);
             for (int K = 0; K < C; ++K) {
@@ -699,7 +707,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
                 __syncthreads();
                 if (K + 1 < C && !ahead) {
                     if (lastFast && K + 2 == C) collect();  // (the last panel is not out yet: this wait is idle time on the critical path's side)
-                    hoWait3(readyA + C * nbCap + K + 1, readyY + (K + 1) * wtCap + t, isS ? readyY + (K + 1) * wtCap : nullptr, epoch, tid, &bad);
+                    hoWait3(readyA + C * nbCap + K + 1, readyY + (K + 1) * wtCap + t, isS ? readyY + (K + 1) * wtCap : nullptr, epoch, tid, &bad, ra.errflag);
                     issue(K + 1);
                     probe = look(K + 2);
                 }
@@ -707,7 +715,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         }
         if (last && !collected) collect();
         EQF_WSTAMP(0);
-        hoWait3(C > 0 ? flagD + C : nullptr, nullptr, nullptr, epoch, tid, &bad);
+        hoWait3(C > 0 ? flagD + C : nullptr, nullptr, nullptr, epoch, tid, &bad, ra.errflag);
         EQF_WSTAMP(1);
         hoLoadRecord(D + (long long)C * kDRec, s, tid);
         // running sums of the reductions: block row C adds its share to what block row C-1 of the same column tile left

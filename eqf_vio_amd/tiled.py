@@ -318,6 +318,9 @@ class HipBackend:
     def device_error(self):
         return self.lib.eqf_tiled_device_error(self._h)
 
+    def outlier_threshold(self):
+        return float(self.settings.outlierThreshold)
+
     def state_estimate(self):
         N = self.num_landmarks()
         q, x, v, p = np.zeros(4), np.zeros(3), np.zeros(3), np.zeros((max(N, 1), 3))
@@ -377,6 +380,10 @@ class HipBackend:
         cv, av = f(st["currentVelocity"]), f(st["accumulatedVelocity"])
         self.b._check(self.lib.eqf_tiled_set_state(self._h, N, *[self._dp(a) for a in arrs], sb.shape[1], float(st["time"]), self._dp(cv),
                                                    self._dp(av), float(st["accumulatedTime"]), int(st["initialised"])), "eqf_tiled_set_state")
+
+
+class TiledOutlierError(RuntimeError):
+    """A vision frame tripped the outlier gate of the fixed-landmark-set filter (TiledFilter._outlier_gate)."""
 
 
 class TiledFilter:
@@ -481,8 +488,30 @@ class TiledFilter:
             self._alloc(len(ids))  # addNewLandmarks on the empty state, :345-391
             self.be.add_landmarks(y, self.Sll)
             self.ids = ids.copy()
+        else:
+            self._outlier_gate(y)
         self._update(y)
         return 0
+
+    def _outlier_gate(self, y):
+        """removeOutliers (VIOFilter.cpp:429-443) for a landmark set that cannot change: the reference drops every landmark whose measured
+        bearing is further than settings.outlierThreshold (chord of unit vectors) from the estimated one BEFORE the update.  Dropping needs
+        landmark churn, which lives in the single-GPU path; fusing the outlier silently would leave the reference's trajectory.  So the gate
+        is evaluated -- O(N) on the replicated state, identical on every rank -- and a frame that trips it is REFUSED (TiledOutlierError,
+        raised on every rank before anything of the update has run).  A threshold >= 2 (no chord of unit vectors is longer) skips the test
+        and its readback."""
+        thr = self.be.outlier_threshold()
+        if not thr < 2.0:
+            return
+        p = np.asarray(self.be.state_estimate()["p"], dtype=np.float64).reshape(-1, 3)
+        yhat = p / np.linalg.norm(p, axis=1, keepdims=True)
+        chord = np.linalg.norm(y - yhat, axis=1)
+        bad = np.nonzero(chord > thr)[0]
+        if len(bad):
+            raise TiledOutlierError(
+                f"{len(bad)} bearing(s) beyond outlierThreshold={thr} (largest chord {chord.max():.3g}, first id {int(self.ids[bad[0]])}): "
+                "the reference removes these landmarks (VIOFilter.cpp:429-443); the 2-D partitioned filter keeps a fixed landmark set and "
+                "refuses the frame instead of fusing an outlier")
 
     def initialise_from(self, st):
         """Restart from a single-GPU snapshot (FilterBatch.dump_state(); every rank holds the dense Sigma once, here)."""

@@ -151,7 +151,16 @@ int eqf_debug_get_blocks(eqf_filter* f, int b, double* common, double* rec, doub
  * SO3FromVectors, SO3.cpp:160): 1 antipodal vectors / singular gravity chart in a propagate step; 2 the same while building the residual
  * or C0i; 4 a pivot of S or Sigma_e not positive; 8 antipodal vectors in the innovation lift, OR an in-launch hand-off of k_chol_resident
  * timed out (0.5 s: the GPU was taken away from the launch for that long) -- that update's Sigma was NOT written and the
- * filter must be reset or restored; 16 / 32 a new / restored landmark on the chart pole. */
+ * filter must be reset or restored; 16 / 32 a new / restored landmark on the chart pole.
+ * About the hand-offs behind bit 8: k_chol_resident (one launch per vision update, csrc/eqf_resident.hpp) lets workgroups of ONE launch
+ * wait for each other.  It is free of deadlock on any grid -- also many times larger than the chip -- under ONE assumption about the
+ * hardware that HIP does not document: workgroups are started in the order of their linear index (a workgroup only ever waits for
+ * lower indices, so whatever is resident contains a runnable one).  If a device or driver ever broke that order, or took the GPU away
+ * for more than 0.5 s (preemption, a debugger), nothing hangs and nothing wrong is written: the first wait that times out sets bit 8 at
+ * once, every other wait of the launch sees the bit within microseconds and gives up, no workgroup publishes anything after a failed
+ * wait, the covariance downdate does not run (Sigma keeps its pre-update value), and the call that next touches the handle returns
+ * EQF_ERR_NUMERIC.  The flag is sticky: later updates of the handle leave at once until eqf_reset.
+ * EQF_CHOL_RESIDENT=0 selects one launch per 64-wide block column instead (no in-launch dependency at all). */
 int eqf_device_error(eqf_filter* f);
 
 /* IMU bursts.  processIMUData calls (VIOFilter.cpp:120-131) only depend on each other and on the state, so the library

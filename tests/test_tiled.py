@@ -104,3 +104,41 @@ def test_block_cyclic_geometry():
             assert all(g.block_size(b) == bl for b in g.row_blocks[:-1]) and all(g.block_size(b) == bl for b in g.col_blocks[:-1])
     assert (seen == 1).all()
     assert [BlockCyclic.blocks_upto(k, 1, 4) for k in range(10)] == [0, 1, 1, 1, 1, 2, 2, 2, 2, 3]
+
+
+def test_tiled_filter_evaluates_the_outlier_gate_and_refuses_a_frame_that_trips_it():
+    """removeOutliers (VIOFilter.cpp:429-443) at the reference's default threshold 0.01: on a clean stream the gate is evaluated every
+    frame and changes nothing (the oracle removes nothing either); a corrupted bearing is refused loudly -- the fixed-landmark-set filter
+    must not fuse what the reference would have dropped."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from eqf_vio_amd import synth, tiled
+    from oracle import binding as ob
+    from tiled_double import NumpyBackend
+
+    N = 14
+    st = synth.make_stream(N, duration=0.26)
+    d = synth.template_settings_dict()
+    d["outlierThreshold"] = 0.01  # include/eqf_vio/VIOFilterSettings.h default
+    tf = tiled.TiledFilter(tiled.ProcessGrid(None, 1, 1), NumpyBackend(d, N), 4)
+    fo = ob.OracleFilter(d)
+    frames = 0
+    for kind, k in st.events():
+        if kind == "imu":
+            r = st.imu[k]
+            fo.processIMUData(r[0], r[1:4], r[4:7])
+            tf.processIMUData(r[0], r[1:4], r[4:7])
+        else:
+            y = st.bearings[k].copy()
+            if frames == 3:
+                bad = y.copy()
+                bad[5] = np.array([np.sin(0.3), 0.0, np.cos(0.3)])  # 0.3 rad off: far beyond the gate
+                with pytest.raises(tiled.TiledOutlierError):
+                    tf.processVisionData(st.vision_stamps[k], st.ids, bad)
+                break
+            fo.processVisionData(st.vision_stamps[k], st.ids, y)
+            assert tf.processVisionData(st.vision_stamps[k], st.ids, y) == 0
+            assert fo.N == N  # the oracle's gate removed nothing
+            assert np.linalg.norm(tf.stateCovariance() - fo.stateCovariance()) / np.linalg.norm(fo.stateCovariance()) < 1e-9
+            frames += 1
+    assert frames == 3

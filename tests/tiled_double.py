@@ -279,6 +279,9 @@ class NumpyBackend:
     def device_error(self):
         return 0
 
+    def outlier_threshold(self):
+        return float(self.f.settings.outlierThreshold)
+
     def state_estimate(self):
         e = self.f.stateEstimate()
         return {"q": e.pose.q, "x": e.pose.x, "v": e.velocity, "p": e.p}
