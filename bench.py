@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--tiled-timeout", type=int, default=240, help="several GPUs: seconds after which the cfg 5 leg is given up")
     ap.add_argument("--tiled-frames", type=int, default=3, help="timed frames (a frame = 10 IMU calls + 1 vision call) after one warm-up frame")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle-checked prefix (parity block of the JSON line)")
+    ap.add_argument("--no-churn", action="store_true", help="skip the landmark-churn + outlier-gate leg (per-call API, N ~ 200)")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed throw-away run that precedes the measured job")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE)")
@@ -359,6 +360,61 @@ def timed_job(args, dist, rank, world, device, N, B, steps, warmup, dense=False)
     return fb, timed, dt, res
 
 
+def churn_leg(device, seconds=3.0, pool=260, fixed=200):
+    """SURVEY.md 8(d) "a separate churn run exercises a18": the landmark bookkeeping of VIOFilter.cpp:211-230, 345-443 at N ~ 200 with the
+    outlier gate at the REFERENCE DEFAULT (include/eqf_vio/VIOFilterSettings.h: outlierThreshold = 0.01), through the per-call API (host
+    buffers: the caller owns the ids).  A pool of `pool` landmarks, each visible on a window of frames, ~`fixed` in view, a few entering
+    and leaving every frame.  Four modes on the same stream, best of three runs each: a fixed set / churn, gate off / on."""
+    from eqf_vio_amd import binding, synth
+
+    st = synth.make_stream(pool, seed=1234, duration=seconds)
+    F = st.bearings.shape[0]
+    rng = np.random.default_rng(3)
+    start = rng.integers(-F, F, size=pool)
+    length = rng.integers(F // 2, F, size=pool)
+    start[:120], length[:120] = -1, 10 * F
+    ev = list(st.events())
+    d0 = synth.template_settings_dict()
+
+    def run(churn, gate):
+        d = dict(d0)
+        if gate:
+            d["outlierThreshold"] = 0.01
+        fb = binding.FilterBatch(d, capacity=pool, batch=1, device=device)
+        prev, nch, nvis = None, 0, 0
+        fb.synchronize()
+        t0 = time.perf_counter()
+        for kind, k in ev:
+            if kind == "imu":
+                r = st.imu[k]
+                fb.process_imu([r[0]], r[1:4], r[4:7])
+            else:
+                vis = np.where((start <= k) & (k < start + length))[0] if churn else np.arange(fixed)
+                if prev is not None:
+                    nch += len(set(vis) ^ set(prev))
+                prev = vis
+                fb.process_vision([st.vision_stamps[k]], st.ids[vis].astype(np.int32), st.bearings[k, vis].copy())
+                nvis += 1
+        fb.synchronize()
+        dt = time.perf_counter() - t0
+        out = (dt, fb.num_landmarks(), nch / max(nvis - 1, 1), fb.device_error())
+        del fb
+        return out
+
+    run(False, False)  # (first launches of the churn kernels)
+    res = {}
+    for name, churn, gate in (("fixed_set", False, False), ("fixed_set_gate", False, True), ("churn", True, False), ("churn_gate", True, True)):
+        dt, nEnd, chg, err = min(run(churn, gate) for _ in range(3))
+        res[name] = {"value": round(len(ev) / dt, 1), "landmarks_at_end": nEnd, "landmark_changes_per_frame": round(chg, 2), "device_error_flag": err}
+    return {
+        "metric": "EqF propagate+update steps/sec, per-call API, pool of %d landmarks, ~%d in view, outlier gate at the reference default 0.01" % (pool, fixed),
+        "unit": "steps/s", "steps": len(ev), "modes": res,
+        "churn_gate_over_fixed_set": round(res["churn_gate"]["value"] / res["fixed_set"]["value"], 3),
+        "note": "per-call API with host buffers (PCIe and the host-side id matching included), best of 3; `value` of the main line replays a "
+                "resident stream with a fixed set and the gate off",
+    }
+
+
 GRIDS = {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (2, 4)}
 
 
@@ -481,6 +537,9 @@ def main():
     line = {
         # BASELINE.json's metric string, verbatim for the configuration it is quoted on (N = 200); other N only change the number
         "metric": "EqF propagate+update steps/sec at N=%d landmarks (fp32); 1-GPU + 8-GPU batch" % N,
+        "baseline_metric": "EqF propagate+update steps/sec at N=200 landmarks (fp32); 1-GPU + 8-GPU batch",
+        "metric_as_run": "EqF propagate+update steps/sec at N=%d landmarks, %s arithmetic, %d GPU(s) x %d filter(s)" % (
+            N, "fp64" if args.precision == "f64" else "fp32", world, B),
         "metric_note": "arithmetic is %s, not the fp32 the metric string names: fp64 is the reference's own type and the only one that "
                        "meets the 1e-4 Sigma tolerance on the reference's settings (measured on the device: DESIGN.md section 2, "
                        "profiles/r02_fp32_study.txt); `dtype` says what was computed" % ("fp64" if args.precision == "f64" else "fp32 (EQF_PRECISION_F32, not parity grade)"),
@@ -591,6 +650,12 @@ def main():
                 if rank == 0:
                     print(json.dumps(line), flush=True)
                 os._exit(0)
+
+    if rank == 0 and not args.no_churn and N == 200 and B == 1 and not args.dense_propagate and args.precision == "f64":
+        try:
+            line["churn"] = churn_leg(device)
+        except Exception as e:
+            line["churn"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0 and world == 1:
         rl = line.get("roofline")

@@ -5,7 +5,7 @@ counters=$1; pat=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
 for c in $counters; do
   rm -rf /tmp/pmck
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmck -o b -- $PY $ROOT/bench.py "$@" --steps 44 --warmup 22 --no-batch64 --no-cpu-baseline --no-traffic --no-parity --no-tiled --no-steady-state --pmc-child > /dev/null 2>&1
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmck -o b -- $PY $ROOT/bench.py "$@" --steps 44 --warmup 22 --no-batch64 --no-cpu-baseline --no-traffic --no-parity --no-tiled --no-churn --no-steady-state --pmc-child > /dev/null 2>&1
   f=$(find /tmp/pmck -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && $PY - "$f" "$pat" "$c" <<'P'
 import csv,sys,statistics
