@@ -186,85 +186,9 @@ __shared__ long long sF64Stamps[4][4][8];
 #define EQF_F64STAMP(j, k) do { } while (0)
 #endif
 
-// Right-looking Cholesky of 16 columns of a 64-row panel by one wave, one row per lane.  The rows are ROTATED so that
-// every lane index in the loop is a compile-time constant (a run-time lane select costs an SALU add + hazard nops per
-// v_readlane): lane l holds row (l + rot) & 63 of src, the pivots sit in lanes 0..15.
-//   lanes [0, nReal)   real rows (columns colBase..colBase+15 of src).  Rows below the diagonal block take part in every
-//                      scaling / rank-1 update, so they leave as L_rj = A_rj L_jj^-T.
-//   lanes [48, 64)     if hasId: the rows of the identity, which leave as the rows of L_jj^-T:
-//                      Wj[c][i] = (L_jj^-1)[c][i] comes from lane 48 + i, register c.   (needs nReal <= 48)
-// No LDS inside the loop: the pivot chain, the next column (immediately) and the rest of each rank-1 update (one
-// iteration later, filling the latency of the next pivot's rsqrt chain) all use v_readlane broadcasts.
-// Measured in isolation (scripts/micro/potrf16_bench.hip): 4.1 k cycles warm, of which the pivot chain alone is 2.6 k.
-EQF_DI void potrf16(double (*T)[kSP], const double* src, int srcLd, double (*Wj)[kWP], int colBase, int rot, int nReal, bool hasId,
-    bool writeBack, int lane, int* bad, int stampStage = -1) {
-    double row[kQB];
-    const bool isId = hasId && lane >= 48;
-    const bool isReal = lane < nReal;
-    const int r = (lane + rot) & (kSB - 1);
-#pragma unroll
-    for (int c = 0; c < kQB; ++c) row[c] = isId ? ((lane - 48 == c) ? 1.0 : 0.0) : (isReal ? src[r * srcLd + colBase + c] : 0.0);
-    double ljPrev = 0.0;
-    if (stampStage >= 0) EQF_F64STAMP(stampStage, 5);
-#pragma unroll
-    for (int c = 0; c < kQB; ++c) {
-        const double d = readlane64(row[c], c);
-        if (!(d > 0.0)) *bad = 1;
-        const double rd = rsqrtPivot(d);
-        if (c >= 1) {
-            // all broadcasts of the column first (distinct SGPR pairs, pinned), then the FMAs: one v_readlane -> VALU
-            // hazard per column instead of one per element (4.1 k -> 3.75 k cycles)
-            double bc[kQB];
-#pragma unroll
-            for (int c2 = c + 1; c2 < kQB; ++c2) bc[c2] = readlane64(ljPrev, c2);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-            for (int c2 = c + 1; c2 < kQB; ++c2) __asm__ volatile("" : "+s"(bc[c2]));
-#endif
-#pragma unroll
-            for (int c2 = c + 1; c2 < kQB; ++c2) row[c2] = fma(-ljPrev, bc[c2], row[c2]);
-        }
-        const double lj = row[c] * rd;
-        if (c + 1 < kQB) row[c + 1] = fma(-lj, readlane64(lj, c + 1), row[c + 1]);
-        row[c] = lj;
-        ljPrev = lj;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-        for (int c2 = c + 1; c2 < kQB; ++c2) __asm__ volatile("" : "+v"(row[c2]));
-#endif
-    }
-    if (stampStage >= 0) EQF_F64STAMP(stampStage, 6);
-    if (writeBack && isReal) {
-#pragma unroll
-        for (int c = 0; c < kQB; ++c) T[r][colBase + c] = (lane >= c) ? row[c] : 0.0;
-    }
-    if (isId) {
-#pragma unroll
-        for (int c = 0; c < kQB; ++c) Wj[c][lane - 48] = row[c];
-    }
-}
-
-// Columns [16 j, 16 j + 16) of s.L and the inverse block Wd[j] -> diagonal-factor record Dn, by threads t = 0..nthr-1
-// (WT: write-through 8-byte stores for a record that is handed over inside the launch, eqf_handoff.hpp)
-template <bool WT = false>
-EQF_DI void storeDiagColumns(const Lds64& s, double* Dn, int j, int t, int nthr) {
-    for (int e = t; e < kSB * kQB; e += nthr) {
-        double* p = Dn + (e >> 4) * kSB + kQB * j + (e & 15);
-        const double v = s.L[e >> 4][kQB * j + (e & 15)];
-        if (WT) hoStore8(p, v);
-        else *p = v;
-    }
-    for (int e = t; e < kQB * kQB; e += nthr) {
-        double* p = Dn + kSB * kSB + kQB * kQB * j + e;
-        const double v = s.Wd[j][e >> 4][e & 15];
-        if (WT) hoStore8(p, v);
-        else *p = v;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------------
 // factor64, round 4.  Shader-clock stamps of every wave (scripts/micro/factor64_bench.hip) showed that of the 5.8 k cycles a 16-column
-// stage of the round-3 version (factor64v1, kept below for the microbenchmark) cost, the sixteen pivots were 2.7 k: the rest was the
+// stage of the round-3 version cost (8.66 us per block, removed late in round 4), the sixteen pivots were 2.7 k: the rest was the
 // INSTRUCTION COUNT of the lone pivot wave around them -- a wave on its own issues one instruction per ~5 cycles -- namely 0.95 k cycles
 // to load its sixteen columns (exec-masked 8-byte loads, selects for the identity / idle lanes, SGPR spills), 0.9-1.1 k to write them back
 // (a select pair + store per value, the transposed scatter of the inverse block), and 1.0 k for two barriers with a tile update of its own
@@ -276,7 +200,7 @@ EQF_DI void storeDiagColumns(const Lds64& s, double* Dn, int j, int t, int nthr)
 //               the others get it during the next stage's pivots;
 //   wave 1      carries the identity rows of stage 0 (as before) and from then on does the chores one stage behind the pivots: W_jj back to
 //               row-major, zeros above the diagonal of L_jj, columns j of the record to global memory (16-byte stores), drain, stage flag.
-// Same operations on every element in the same order as factor64v1: bitwise the same L and W.
+// Same operations on every element in the same order as the round-3 version: bitwise the same L and W (checked hash against hash).
 // Pre-condition (factorPrologue): s.D0 = leading 16 x 16 block of s.L, s.Wd[0] = I; post-condition: s.L lower block triangle, s.Wd row-major,
 // all LDS writes visible (ends with a barrier).
 EQF_DI void factorPrologue(const Lds64& s, int tid) {
@@ -430,14 +354,18 @@ EQF_DI void factorTiles(const Lds64& s, int lane, Pre pre, int nStages) {
     double* const L0 = &s.L[0][0];
     // Wd[1..3] = I: the identity rows the pivot wave picks up in stage j >= 1 (and W_jj of the chain's identity padding, j >= nStages)
     for (int e = lane + 64 * (W - 2); e < 3 * kQB * kQB; e += 128) s.Wd[1 + (e >> 8)][(e >> 4) & 15][e & 15] = (((e >> 4) & 15) == (e & 15)) ? 1.0 : 0.0;
-    pre(W);
+    // `pre(wave, r, c, acc)` delivers tile (r, c): two tiles per wave now -- all of column 1, which the first barrier is followed by, and
+    // (2,2) -- the third in the shadow of the SECOND sixteen pivots (all six at once took waves 2, 3 longer than the first sixteen pivots:
+    // 5.0 k against 3.5 k cycles; the column-1 tiles alone left wave 3 with 5.1 k cycles in the second stage)
     f64x4 acc[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) acc[k] = ldTile(L0, kSP, kQB * TR[k], kQB * TC[k], lane);
+    for (int k = 0; k < 2; ++k)
+        if (TC[k] < nStages) pre(W, TR[k], TC[k], acc[k]);
     if (WT) hoDrain();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (j < nStages) {
+            if (j == 1 && TC[2] < nStages) pre(W, TR[2], TC[2], acc[2]);
             if (j > 0) {
                 // update j-1 of the tiles that are not due yet, in the shadow of the pivots of stage j
 #pragma unroll
@@ -463,8 +391,8 @@ EQF_DI void factorTiles(const Lds64& s, int lane, Pre pre, int nStages) {
         }
     }
 }
-// `pre(wave)`: extra work of waves 2 and 3 in the shadow of the first sixteen pivots -- it leaves the tiles (r, c), c >= 1, of the block in
-// s.L (the diagonal workgroup's remaining trailing-update tiles).  `mid()`: thread 0, once, after the first stage's barrier A, by which
+// `pre(wave, r, c, acc)`: waves 2 and 3 ask for the 16 x 16 tile (r, c), c >= 1, of the block in the accumulator layout, each once, in the
+// shadow of the pivots (the diagonal workgroup's remaining trailing-update tiles; preFromLds: they already are in s.L).  `mid()`: thread 0, once, after the first stage's barrier A, by which
 // every thread has drained its write-through stores (WT): k_chol_resident publishes the solved block L_{R,R-1} there.
 // `stageFlag` (WT only; nullptr = none): stageFlag[j] <- epoch as soon as columns [16 j, 16 j + 16) of L and W_jj are in the record Dn,
 // j = 0..nStages-2 -- one stage behind the pivot chain.
@@ -545,99 +473,13 @@ EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn, lon
         for (int j = jl; j < 4; ++j) storeDiagColumns16<WT>(s, Dn, j, tid, 256);
     EQF_LDS_BARRIER();
 }
-template <typename Pre>
-EQF_DI void factor64(const Lds64& s, int tid, int* bad, Pre pre, double* Dn = nullptr, long long* st = nullptr, int nStages = 4) {
-    factor64<false>(s, tid, bad, pre, Dn, st, nStages, [] {});
+// (the block is complete in s.L: the tiles come from there)
+EQF_DI void factor64(const Lds64& s, int tid, int* bad, double* Dn = nullptr, long long* st = nullptr, int nStages = 4) {
+    const int lane = tid & 63;
+    double* const L0 = &s.L[0][0];
+    factor64<false>(s, tid, bad, [&](int, int r, int c, f64x4& acc) { acc = ldTile(L0, kSP, kQB * r, kQB * c, lane); }, Dn, st, nStages, [] {});
 }
 
-// ---- the round-3 version, kept for scripts/micro/factor64_bench.hip (variant 1)
-// Factor the 64x64 symmetric block in s.L in place (lower block triangle; the upper triangles of the diagonal blocks are
-// zeroed) and form s.Wd.  All 256 threads.  `pre` is extra work for waves 2 and 3 during the first stage (the diagonal
-// workgroup's remaining trailing-update tiles): pre(wave).
-// `mid` (all threads) runs once, right after the first stage's two barriers: a place to finish something asynchronous that
-// was started before the call (k_chol_resident drains and publishes the write-through stores of the solved block there).
-// `stageFlag` (WT only; nullptr = none): stageFlag[j] <- epoch as soon as columns [16 j, 16 j + 16) of L and W_jj are in the record Dn,
-// j = 0..nStages-2 -- one stage behind the pivot chain, stored and drained by waves 2, 3 in its shadow.  A consumer that only needs the
-// record stage by stage (the row head of k_chol_resident's next block column) overlaps its own work with the rest of this factorisation.
-template <bool WT = false, typename Pre, typename Mid>
-EQF_DI void factor64v1(const Lds64& s, int tid, int* bad, Pre pre, double* Dn, long long* st, int nStages, Mid mid, int* stageFlag = nullptr,
-    int epoch = 0) {
-    const int lane = tid & 63, wv = tid >> 6;
-    int* const stageCnt = reinterpret_cast<int*>(&s.D0[kQB - 1][kQB]);  // (pad column of D0: nobody reads it)
-    if (WT && stageFlag && tid == 0) *stageCnt = 0;
-    // nStages: 16-column stages that hold a real column.  The rest of the block is the identity padding of the chain's
-    // last block (off-diagonal zero): its L_jj = I stands as it is, W_jj = I is set here, and the pivot chain stops early.
-    for (int j = nStages; j < 4; ++j)
-        if (tid < kQB * kQB) s.Wd[j][tid >> 4][tid & 15] = ((tid >> 4) == (tid & 15)) ? 1.0 : 0.0;
-#pragma unroll 1
-    for (int j = 0; j < nStages; ++j) {
-        const int base = kQB * j;
-        EQF_F64STAMP(j, 0);
-        // ---- phase P: the next 16 columns (wave 0; wave 1 carries the identity rows at stage 0, where wave 0 has no idle
-        // lanes) while waves 2, 3 apply the deferred updates of stage j-1 to the columns >= j+1
-        if (wv == 0) potrf16(s.L, &s.L[0][0], kSP, s.Wd[j], base, base, kSB - base, j > 0, true, lane, bad, j);
-        else if (wv == 1 && j == 0) potrf16(s.L, &s.D0[0][0], kWP, s.Wd[0], 0, 0, kQB, true, false, lane, bad);
-        else if (wv >= 2) {
-            if (j == 0) pre(wv);
-            else {
-                // the 16 columns finished in the previous stage (and their inverse block) go to the record in global memory
-                // now, in the shadow of wave 0's pivot chain, instead of all at the end of the launch
-                if (Dn) storeDiagColumns<WT>(s, Dn, j - 1, tid - 128, 128);
-                int t = 0;
-#pragma unroll 1
-                for (int c = j + 1; c < nStages; ++c)
-#pragma unroll 1
-                    for (int r = c; r < 4; ++r, ++t) {
-                        if ((t & 1) != (wv & 1)) continue;
-                        f64x4 acc = ldTile(&s.L[0][0], kSP, kQB * r, kQB * c, lane);
-                        acc = mmTile<true, kQB>(acc, &s.L[0][base - kQB], kSP, kQB * r, &s.L[0][base - kQB], kSP, kQB * c, lane, -1.0);
-                        stTile(acc, &s.L[0][0], kSP, kQB * r, kQB * c, lane);
-                    }
-                if (WT && stageFlag) {
-                    // stage j-1 of the record is out as soon as BOTH storing waves have drained: the second one to arrive publishes it
-                    // (an LDS counter in the pad column of D0) -- half a stage earlier than the barrier below would allow
-                    hoDrain();
-                    if (lane == 0) {
-                        const int old = __hip_atomic_fetch_add(stageCnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (old & 1) hoPublish(stageFlag + (j - 1), epoch);
-                    }
-                }
-            }
-        }
-#ifdef EQF_STEP64_STAMPS
-        if (st && tid == 0) st[2 * j] = __builtin_readcyclecounter();
-#endif
-        EQF_F64STAMP(j, 1);
-        __syncthreads();
-        EQF_F64STAMP(j, 2);
-        // ---- phase U: the tiles of column j+1 (needed by the next stage), one per wave:  T_r,j+1 -= L_rj L_j+1,j^T
-        if (j + 1 < nStages && wv < 3 - j) {
-            const int r = j + 1 + wv;
-            f64x4 acc = ldTile(&s.L[0][0], kSP, kQB * r, base + kQB, lane);
-            acc = mmTile<true, kQB>(acc, &s.L[0][base], kSP, kQB * r, &s.L[0][base], kSP, base + kQB, lane, -1.0);
-            stTile(acc, &s.L[0][0], kSP, kQB * r, base + kQB, lane);
-        }
-#ifdef EQF_STEP64_STAMPS
-        if (st && tid == 0) st[2 * j + 1] = __builtin_readcyclecounter();
-#endif
-        EQF_F64STAMP(j, 3);
-        __syncthreads();
-        EQF_F64STAMP(j, 4);
-        if (j == 0) mid();
-    }
-#ifdef EQF_F64_STAMPS
-    if (st) {
-        __syncthreads();
-        if (tid < 128) st[tid] = (&sF64Stamps[0][0][0])[tid];
-    }
-#endif
-    if (Dn)
-        for (int j = nStages - 1; j < 4; ++j) storeDiagColumns<WT>(s, Dn, j, tid, 256);
-}
-template <typename Pre>
-EQF_DI void factor64v1(const Lds64& s, int tid, int* bad, Pre pre, double* Dn = nullptr, long long* st = nullptr, int nStages = 4) {
-    factor64v1<false>(s, tid, bad, pre, Dn, st, nStages, [] {});
-}
 // stages of the 64-wide block starting at column c0 of a chain of real order n that hold a real column
 EQF_DI int realStages(int n, int c0) { return max(1, min(4, (min(kSB, n - c0) + kQB - 1) / kQB)); }
 
@@ -767,7 +609,7 @@ EQF_DI void factorFirstFromSigma(const UpdArgs& a, const ChainArgs& ch, int b, c
     __syncthreads();
     factorPrologue(s, tid);
     __syncthreads();
-    factor64(s, tid, bad, [](int) {}, ch.D + (long long)b * ch.strideD, nullptr, realStages(ch.kind == 0 ? sDim(N) : eDim(N), 0));
+    factor64(s, tid, bad, ch.D + (long long)b * ch.strideD, nullptr, realStages(ch.kind == 0 ? sDim(N) : eDim(N), 0));
 }
 // k_update_prep + the two first-block workgroups (grid.x = lmBlocks + eBlocks + 2)
 #ifdef EQF_PREP_STAMPS
@@ -812,7 +654,7 @@ inline __global__ __launch_bounds__(256) void k_factor_first64(ChainArgs c0, Cha
     factorPrologue(s, tid);
     __syncthreads();
     int bad = 0;
-    factor64(s, tid, &bad, [](int) {}, ch.D + (long long)b * ch.strideD);
+    factor64(s, tid, &bad, ch.D + (long long)b * ch.strideD);
     if (bad && errflag && tid == 0) atomicOr(errflag, 4);
 }
 
@@ -1408,19 +1250,21 @@ __global__ __launch_bounds__(256, (PHASE == 2 || PHASE == 3) ? 2 : 1) void k_cho
             if (wv == 1) factorPrologueW(s, lane);
             __syncthreads();
             EQF_STAMP(3);
-            auto pre = [&](int) {
+            // (slot i of this wave is tile (tr[i], tc[i]): the table of factorTiles)
+            auto pre = [&](int, int r, int c, f64x4& t) {
 #pragma unroll
-                for (int i = 1; i < 4; ++i) {
-                    upd(i);
-                    stTile(acc[i], &s.L[0][0], kSP, kQB * tr[i], kQB * tc[i], lane);
-                }
+                for (int i = 1; i < 4; ++i)
+                    if (tr[i] == r && tc[i] == c) {
+                        upd(i);
+                        t = acc[i];
+                    }
             };
             // (PHASE 3 publishes the whole record at the end, write-through, instead of plain stores along the way)
             double* Dnext = D + (long long)(K + 1) * kDRec;
 #ifdef EQF_STEP64_STAMPS
-            factor64(s, tid, &bad, pre, PHASE == 3 ? nullptr : Dnext, !second ? &g_stamps[K][8] : nullptr, realStages(ch.kind == 0 ? sDim(g.N) : eDim(g.N), kSB * (K + 1)));
+            factor64<false>(s, tid, &bad, pre, PHASE == 3 ? nullptr : Dnext, !second ? &g_stamps[K][8] : nullptr, realStages(ch.kind == 0 ? sDim(g.N) : eDim(g.N), kSB * (K + 1)), [] {});
 #else
-            factor64(s, tid, &bad, pre, PHASE == 3 ? nullptr : Dnext, nullptr, realStages(ch.kind == 0 ? sDim(g.N) : eDim(g.N), kSB * (K + 1)));
+            factor64<false>(s, tid, &bad, pre, PHASE == 3 ? nullptr : Dnext, nullptr, realStages(ch.kind == 0 ? sDim(g.N) : eDim(g.N), kSB * (K + 1)), [] {});
 #endif
             EQF_STAMP(4);
             if (PHASE == 3) {

@@ -539,12 +539,11 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         if (wv == 0) stTile(a2[0], &s.D0[0][0], kWP, 0, 0, lane);
         if (wv == 1) factorPrologueW(s, lane);
         __syncthreads();
-        auto pre = [&](int) {
+        // (slot i of this wave is tile (tr[i], tc[i]): the table of factorTiles)
+        auto pre = [&](int, int r, int c, f64x4& t) {
 #pragma unroll
-            for (int i = 1; i < 4; ++i) {
-                a2[i] = mmTile<true, kSB>(a2[i], &s.P[0][0], kSP, kQB * tr[i], &s.P[0][0], kSP, kQB * tc[i], lane, -1.0);
-                stTile(a2[i], &s.L[0][0], kSP, kQB * tr[i], kQB * tc[i], lane);
-            }
+            for (int i = 1; i < 4; ++i)
+                if (tr[i] == r && tc[i] == c) t = mmTile<true, kSB>(a2[i], &s.P[0][0], kSP, kQB * tr[i], &s.P[0][0], kSP, kQB * tc[i], lane, -1.0);
         };
         EQF_HSTAMP(6);
         // the solved block's stores drain in the shadow of the first 16 pivots; it is published right after them.  (Tried in round 3:

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void k_tile_potrf(double* A, int ld, int n, do
         __syncthreads();
         factorPrologue(s, tid);
         __syncthreads();
-        factor64(s, tid, &bad, [](int) {}, drec + (long long)kb * kDRec, nullptr, realStages(n, kSB * kb));
+        factor64(s, tid, &bad, drec + (long long)kb * kDRec, nullptr, realStages(n, kSB * kb));
         __syncthreads();
         storeBlock(s.L, kb, kb, true);
         // panel: A_rb,kb <- A_rb,kb L_kk^-T

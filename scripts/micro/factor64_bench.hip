@@ -25,8 +25,9 @@ __global__ __launch_bounds__(256) void k_f64(const double* A, double* outL, doub
         factorPrologue(s, tid);
         __syncthreads();
         const long long t0 = __builtin_readcyclecounter();
-        if (VARIANT == 0) factor64<WT>(s, tid, &bad, [](int) {}, WT ? Dn : nullptr, stamps + 128 * rep, nst, [] {}, WT ? flags : nullptr, rep + 1);
-        if (VARIANT == 1) factor64v1<WT>(s, tid, &bad, [](int) {}, WT ? Dn : nullptr, stamps + 128 * rep, nst, [] {}, WT ? flags : nullptr, rep + 1);
+        const int ln = tid & 63;
+        factor64<WT>(s, tid, &bad, [&](int, int r, int c, f64x4& acc) { acc = ldTile(&s.L[0][0], kSP, kQB * r, kQB * c, ln); }, WT ? Dn : nullptr,
+            stamps + 128 * rep, nst, [] {}, WT ? flags : nullptr, rep + 1);
         __syncthreads();
         const long long t1 = __builtin_readcyclecounter();
         if (tid == 0) total[rep] = t1 - t0;
@@ -75,8 +76,6 @@ int main(int argc, char** argv) {
     };
     if (variant == 0 && !wt) launch(k_f64<0, false>);
     else if (variant == 0) launch(k_f64<0, true>);
-    else if (variant == 1 && !wt) launch(k_f64<1, false>);
-    else if (variant == 1) launch(k_f64<1, true>);
     else { printf("unknown variant\n"); return 1; }
     if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 1; }
     std::vector<double> gL(n * n), gW(1024);
