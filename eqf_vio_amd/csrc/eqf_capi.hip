@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/eqf_vio_amd.h"
@@ -145,6 +146,10 @@ struct eqf_filter {
     int cholResident = 1;
     int resOversub = -1;           // EQF_RES_OVERSUB: roles per CU up to which the resident kernel is used on a grid larger than the chip; -1 = no limit
     int resStaged = 1;             // row heads consume D[R-1] stage by stage (EQF_RES_STAGED = 0: whole record after its last pivot)
+    int resFoldPrep = 1;           // co-resident grid: the prep work as roles of the SAME launch (EQF_RES_FOLD_PREP = 0: k_update_prep64 launched first)
+    int* dPrepFlags = nullptr;     // [B][nPrepCap]
+    int nPrepCap = 0;
+    bool rolesFold = false;
     int residentPerCU = -1;        // hipOccupancyMaxActiveBlocksPerMultiprocessor of k_chol_resident on this device (lazily queried)
     int eFromSigma = 1;            // split chain: block column 0 of the E-chain read straight from Sigma (EQF_E_FROM_SIGMA=0: copied by prep)
     int cholOrder = -1;            // order of the workgroup classes in an update launch, -1 = by launch size (EQF_CHOL_ORDER = 0 | 1 | 2)
@@ -569,11 +574,16 @@ UpdArgs makeUpdArgs(eqf_filter* f, const double* bearings, long long bearStride,
 
 // Role table of k_chol_resident for chains of nbS / nbE block columns (wtS right-hand-side column tiles in the S-chain):
 // block index = dependency order -- group s holds the workgroups whose last step consumes D[s]; they only wait for groups < s.
-int buildRoles(eqf_filter* f, int Nmax) {
+// fold: the prep work runs as roles of the same launch (ResArgs::nPrep), so the chains' first diagonal blocks are roles too (F0, in front).
+int buildRoles(eqf_filter* f, int Nmax, bool fold) {
     const int nbS = roundUp(sDim(Nmax), kSB) / kSB, nbE = roundUp(eDim(Nmax), kSB) / kSB, wtS = roundUp(yCols(Nmax), kSB) / kSB;
-    const int key = (nbS << 20) | (nbE << 10) | wtS;  // the table only changes when a chain crosses a 64-block boundary
+    const int key = (fold ? 1 << 30 : 0) | (nbS << 20) | (nbE << 10) | wtS;  // the table only changes when a chain crosses a 64-block boundary
     if (f->rolesN == key) return EQF_OK;
     std::vector<ResRole> r;
+    if (fold) {
+        r.push_back({1, 6, 0, 0});
+        r.push_back({0, 6, 0, 0});
+    }
     for (int s = 0; s < std::max(nbS, nbE); ++s)
         for (int kind = 1; kind >= 0; --kind) {  // the E-chain (the longer one) first
             const int nb = kind ? nbE : nbS, wt = kind ? 1 : wtS;
@@ -591,6 +601,12 @@ int buildRoles(eqf_filter* f, int Nmax) {
     f->rolesN = key;
     f->rolesCount = int(r.size());
     return EQF_OK;
+}
+
+// (the FOLD build only exists for fp64: the fp32 mode keeps the prep launch)
+template <typename T>
+void launchFold(dim3 rg, hipStream_t st, const ResArgs& ra) {
+    if constexpr (std::is_same<T, double>::value) hipLaunchKernelGGL((k_chol_resident<double, false, false, true>), rg, dim3(256), sizeof(Step64Lds), st, ra);
 }
 
 template <typename T>
@@ -626,6 +642,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsUpdateBytes));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<float>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<float, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRes2Bytes));
@@ -669,9 +686,8 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     const bool splitChain = f->cholSplit >= 0 ? f->cholSplit != 0 : (long long)nblk64 * B >= 6LL * std::max(f->numCUs, 1);
     bool resident = false, residentFits = false, resPipeHeads = false, resOcc2 = false, resESigma = false;
     int rc = EQF_OK;
+    bool fold = false;
     if (embed && f->cholResident && f->cholSplit <= 0 && f->dReadyA) {
-        rc = buildRoles(f, Nmax);
-        if (rc) return rc;
         // co-residency of the whole grid by the occupancy calculation (one workgroup per CU with the 119 KB LDS image), not by
         // the CU count alone: the in-kernel downdate waits for workgroups with HIGHER block indices while holding its CU
         if (f->residentPerCU < 0) {
@@ -679,7 +695,17 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(&k_chol_resident<T>), 256, sizeof(Step64Lds)));
             f->residentPerCU = std::max(nblk, 0);
         }
-        residentFits = (long long)f->rolesCount * B <= (long long)f->residentPerCU * f->numCUs;
+        auto chainRoles = [](int nb, int wt) { return (nb - 1) + (nb - 1) * (nb - 2) / 2 + wt * nb; };
+        const int rolesAll = chainRoles(nb64S, wt64) + chainRoles(nb64E, 1);
+        residentFits = (long long)rolesAll * B <= (long long)f->residentPerCU * f->numCUs;
+        // A co-resident grid (one small filter: the latency case): the prep work -- residuals, C Sigma, S, the lift rows, the chains' first
+        // diagonal blocks -- runs as roles of the SAME launch (ResArgs::nPrep, role F0).  The E-chain's diagonal-factor chain, the critical
+        // path of the update, needs nothing of it (Sigma_e is Sigma[6:, 6:]: its tiles are read straight from Sigma) and starts at t = 0
+        // instead of behind a 12 us launch and a dispatch gap; the S-chain and the right-hand sides wait for the prep roles' flags.
+        fold = f->resFoldPrep && residentFits && std::is_same<T, double>::value && f->cholResident < 2 && f->resPipeHeads <= 0 && f->resOcc2 <= 0 &&
+               nb64E > 1 && f->dPrepFlags && lmBlocks + eBlocks <= f->nPrepCap && lds <= sizeof(Step64Lds);
+        rc = buildRoles(f, Nmax, fold);
+        if (rc) return rc;
         // Beyond co-residency the grid is interleaved (filter index fastest: all filters advance together, group by group) and nothing
         // waits for later workgroups.  Its workgroups mostly wait for hand-offs, so the chip carries several per CU without slowing the
         // chains down; the downdate tiles are workgroups of their own at the end of the grid.  History of the switch-over (round 3, steps/s,
@@ -702,7 +728,9 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
     a.eFromSigma = (!resident && splitChain && f->cholTail && f->eFromSigma && f->precision != EQF_PRECISION_F32) ? 1 : 0;
     // (the OCC2 build reads the E-chain's tiles straight from Sigma: no copy in the prep launch; EQF_E_FROM_SIGMA=0: copied)
     if (resESigma && f->eFromSigma && f->precision != EQF_PRECISION_F32) a.eFromSigma = 2;
-    rc = profiled(f, EQF_PROF_UPDATE_PREP, [&] {
+    fold = fold && resident;
+    if (fold) a.eFromSigma = 2;
+    if (!fold) rc = profiled(f, EQF_PROF_UPDATE_PREP, [&] {
         // the landmark waves + E-chain operand + two more workgroups per filter that factor the first diagonal block of each chain
         // straight from Sigma (one launch: measured never slower than a separate factor launch, 4..64 filters)
         const bool occ2 = f->prepOcc2 >= 0 ? f->prepOcc2 != 0 : (B >= 4 && (long long)(lmBlocks + eBlocks + 2) * B > f->numCUs);
@@ -743,25 +771,36 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             ra.nbCap = f->nbCap; ra.wtCap = f->wtCap;
             ra.stageFlags = f->resStaged ? f->dStageFlags : nullptr;
             ra.eFromSigma = a.eFromSigma == 2 ? 1 : 0;
+            if (fold) {
+                ra.waitD0 = 3;
+                ra.nPrep = lmBlocks + eBlocks;
+                ra.lmBlocks = lmBlocks;
+                ra.prepWpb = wpb;
+                ra.prepNvPad = nvPad;
+                ra.prepFlags = f->dPrepFlags;
+                ra.nPrepCap = f->nPrepCap;
+            }
             // 64 x 64 downdate tiles: a tile costs the same 14 dependent chunk fetches whatever its size, and there are enough
             // finished workgroups to take one each
             // (a grid larger than what is co-resident must not wait for later workgroups while holding CUs: no-wait mode, see the kernel)
-            ra.ddNt = nt64;
+            ra.ddNt = fold ? nt32 : nt64;
             // (the downdate tiles are workgroups of their own behind the roles, also when the whole grid is co-resident: nothing in the kernel
             // waits for a higher block index)
             ra.nRoles = f->rolesCount;
             ra.errflag = f->errflag;
-            const int ddGrid = nt64 * (nt64 + 1) / 2;  // downdate tiles as workgroups of their own behind the roles
+            const int ddGrid = ra.ddNt * (ra.ddNt + 1) / 2;  // downdate tiles as workgroups of their own behind the roles
             rc = profiled(f, EQF_PROF_CHOL_RESIDENT, [&] {
                 // (row heads with the pipelined panel loop only on a grid larger than the chip: see the kernel's PIPEH)
                 const bool pipeHeads = resPipeHeads;
                 // (two workgroups per CU when the grid is many times the chip: see the kernel's OCC2)
                 const bool occ2 = resOcc2;
                 ra.nDdTiles = ddGrid;
-                ra.rolesPerRow = std::min(f->rolesCount + ddGrid, 32768);
-                const dim3 rg(B * ra.rolesPerRow, (f->rolesCount + ddGrid + ra.rolesPerRow - 1) / ra.rolesPerRow);
+                const int perFilter = ra.nPrep + f->rolesCount + ddGrid;
+                ra.rolesPerRow = std::min(perFilter, 32768);
+                const dim3 rg(B * ra.rolesPerRow, (perFilter + ra.rolesPerRow - 1) / ra.rolesPerRow);
                 if (pipeHeads && occ2) hipLaunchKernelGGL((k_chol_resident<T, true, true>), rg, dim3(256), kLdsRes2Bytes, f->stream, ra);
                 else if (pipeHeads) hipLaunchKernelGGL((k_chol_resident<T, true>), rg, dim3(256), sizeof(Step64Lds), f->stream, ra);
+                else if (fold) launchFold<T>(rg, f->stream, ra);
                 else hipLaunchKernelGGL((k_chol_resident<T, false>), rg, dim3(256), sizeof(Step64Lds), f->stream, ra);
             });
             if (rc) return rc;
@@ -1128,7 +1167,7 @@ void freeAll(eqf_filter* f) {
     for (void* p : {(void*)f->p0, (void*)f->lmc, (void*)f->SA, (void*)f->SL, (void*)f->YW, (void*)f->YO, (void*)f->EA, (void*)f->EL, (void*)f->ZW,
              (void*)f->ZO, (void*)f->dbgDelta, (void*)f->dbgGamma, (void*)f->dbgGammaTot, (void*)f->red, (void*)f->errflag, (void*)f->dMap,
              (void*)f->dNewN, (void*)f->dPerm, (void*)f->dSrc, (void*)f->dChord, (void*)f->dDepth2, (void*)f->dDepthSel, (void*)f->dScratch, (void*)f->dMeas,
-             (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn, f->dBlk, (void*)f->dBlkCommon, f->dColRec, f->dRowRec, (void*)f->dSteps, (void*)f->dFlags, (void*)f->dReadyA, (void*)f->dReadyY, (void*)f->dResCounters, (void*)f->dStageFlags, (void*)f->dGammaPart,
+             (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn, f->dBlk, (void*)f->dBlkCommon, f->dColRec, f->dRowRec, (void*)f->dSteps, (void*)f->dFlags, (void*)f->dReadyA, (void*)f->dReadyY, (void*)f->dResCounters, (void*)f->dStageFlags, (void*)f->dPrepFlags, (void*)f->dGammaPart,
              (void*)f->dG11Part, (void*)f->dRoles})
         hipFree(p);
     if (f->hGate) hipHostFree(f->hGate);
@@ -1314,6 +1353,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (const char* e = std::getenv("EQF_CHOL_TAIL")) f->cholTail = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_RESIDENT")) f->cholResident = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_STAGED")) f->resStaged = std::atoi(e);
+    if (const char* e = std::getenv("EQF_RES_FOLD_PREP")) f->resFoldPrep = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_OVERSUB")) f->resOversub = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("EQF_E_FROM_SIGMA")) f->eFromSigma = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_OCC2")) f->resOcc2 = std::atoi(e);
@@ -1337,6 +1377,9 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
             chk(dmalloc(&f->dResCounters, (size_t)4 * B));
             chk(dmalloc(&f->dStageFlags, (size_t)2 * f->nbCap * 4 * B));
             if (!rc && hipMemset(f->dStageFlags, 0, sizeof(int) * 2 * f->nbCap * 4 * B) != hipSuccess) rc = EQF_ERR_HIP;
+            f->nPrepCap = (mpC / 2 + 3) / 1 + nepC / kNB + 8;  // (landmark workgroups carry >= 1 wave each; Z-row workgroups of kNB rows)
+            chk(dmalloc(&f->dPrepFlags, (size_t)f->nPrepCap * B));
+            if (!rc && hipMemset(f->dPrepFlags, 0, sizeof(int) * f->nPrepCap * B) != hipSuccess) rc = EQF_ERR_HIP;
             chk(dmalloc(&f->dGammaPart, (size_t)f->nbCap * ycC * B));
             chk(dmalloc(&f->dG11Part, (size_t)f->nbCap * 128 * B));
             if (!rc && (hipMemset(f->dReadyA, 0, sizeof(int) * 2 * f->nbCap * f->nbCap * B) != hipSuccess ||

@@ -541,7 +541,8 @@ EQF_DI void solveVec64(double* z, const Lds64& s, int lane) {
 // workgroups per filter that finish in the shadow of the landmark waves), so that the first chain launch is an ordinary
 // one:   kind 0:  S_00 = C Sigma C^T + R for the first 32 landmarks   (same expression order as k_update_prep)
 //        kind 1:  Sigma_e[0:64, 0:64]                                 (identity at the pad index 5 and beyond n_e)
-template <typename T>
+// WT: the record is handed over INSIDE a launch (k_chol_resident's role F0: write-through stores; the caller drains and publishes D[0]'s flag)
+template <typename T, bool WT = false>
 EQF_DI void factorFirstFromSigma(const UpdArgs& a, const ChainArgs& ch, int b, const Lds64& s, int* bad) {
     const Glob& g = a.g[b];
     if (ch.kind == 0 && a.resCounters && threadIdx.x < 4) a.resCounters[4 * b + threadIdx.x] = 0;  // (k_chol_resident's work counters)
@@ -609,7 +610,15 @@ EQF_DI void factorFirstFromSigma(const UpdArgs& a, const ChainArgs& ch, int b, c
     __syncthreads();
     factorPrologue(s, tid);
     __syncthreads();
-    factor64(s, tid, bad, ch.D + (long long)b * ch.strideD, nullptr, realStages(ch.kind == 0 ? sDim(N) : eDim(N), 0));
+    const int nst = realStages(ch.kind == 0 ? sDim(N) : eDim(N), 0);
+    if (WT) {
+        const int ln = tid & 63;
+        double* const L0 = &s.L[0][0];
+        factor64<true>(s, tid, bad, [&](int, int r, int c, f64x4& acc) { acc = ldTile(L0, kSP, kQB * r, kQB * c, ln); }, ch.D + (long long)b * ch.strideD, nullptr, nst,
+            [] {});
+    } else {
+        factor64(s, tid, bad, ch.D + (long long)b * ch.strideD, nullptr, nst);
+    }
 }
 // k_update_prep + the two first-block workgroups (grid.x = lmBlocks + eBlocks + 2)
 #ifdef EQF_PREP_STAMPS
@@ -628,7 +637,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_update_prep64(UpdArgs a, 
     const int role = (int)blockIdx.x - (lmBlocks + eBlocks);
     EQF_PREPSTAMP(0);
     if (role < 0) {
-        updatePrepBody<T>(a, lmBlocks, wpb, nvPad, reinterpret_cast<double*>(smem64));
+        updatePrepBody<T>(a, (int)blockIdx.x, (int)blockIdx.y, lmBlocks, wpb, nvPad, reinterpret_cast<double*>(smem64));
         __syncthreads();
         EQF_PREPSTAMP(1);
         return;

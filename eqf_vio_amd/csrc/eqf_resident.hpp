@@ -35,7 +35,7 @@ namespace eqf {
 
 struct ResRole {
     int kind;  // 0 S-chain, 1 E-chain
-    int role;  // 0 H, 1 T, 2 W
+    int role;  // 0 H, 1 T, 2 W, 6 F0 (the chain's first diagonal block, from Sigma)
     int R, C;  // H: R ; T: (R, C) ; W: R = column tile t, C = block row
 };
 
@@ -53,7 +53,14 @@ struct ResArgs {
     int* errflag;
     int nRoles, nDdTiles;  // role workgroups, downdate-tile workgroups behind them (per filter)
     int rolesPerRow;       // grid.x = batch * rolesPerRow
-    int eFromSigma;        // OCC2 build: the E-chain's tiles are first read straight from Sigma (EA = Sigma[6:, 6:] with the pad row / column 5 and
+    int waitD0;            // bit `kind`: D[0] of that chain is produced inside this launch (role F0): its consumers wait for the flag like for any D[K]
+    // ---- the prep work INSIDE this launch (co-resident grids): nPrep = lmBlocks + eBlocks workgroups per filter in FRONT of the roles do
+    // what k_update_prep64's landmark waves and Z-row workgroups do (updatePrepBody, write-through), each raising prepFlags[b][i] = epoch;
+    // the roles that read S, the right-hand sides or Z_P wait for all of them and read through agent-scope loads.  0: a prep launch came first.
+    int nPrep, lmBlocks, prepWpb, prepNvPad;
+    int* prepFlags;        // [B][nPrepCap]
+    int nPrepCap;
+    int eFromSigma;        // the E-chain's tiles are first read straight from Sigma (EA = Sigma[6:, 6:] with the pad row / column 5 and
                            // the rows past n_e as the identity): the prep launch does not copy them
     int* stageFlags;       // [B][2][nbCap][4]  stage j of D[K] of chain c is in the record (epoch valued; factor64's stageFlag)
 };
@@ -326,7 +333,10 @@ __device__ long long g_resF64[2][16][128];  // [chain][R]: factor64's per-wave s
 // 237 registers, and the 78 KB LDS view in which L aliases Q (ldsRes2).  Twice the workgroups in flight reach twice as many block columns
 // ahead of the pivot chains: 8 filters 181 -> 170 us per update, 12: 254 -> 220, 16: 312 -> 255, 20: 401 -> 315, N = 1000 1.54 -> 1.28 ms.
 // On lightly oversubscribed grids two workgroups on a CU only get in each other's way (4 filters 134 -> 153 us, N = 600 455 -> 475).
-template <typename T, bool PIPEH = false, bool OCC2 = false>
+// FOLD: the build with the prep roles inside (ResArgs::nPrep; co-resident grids).  A build of its own because the mere presence of the prep
+// role and of the agent-scope loads of S / the right-hand sides cost the other builds 3 + 7 us per update (124 -> 134: this kernel is
+// bound by a chain of latencies and feels every change of its code layout).
+template <typename T, bool PIPEH = false, bool OCC2 = false, bool FOLD = false>
 __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smemR[];
     // grid = (batch, roles): the filter index runs FASTEST in dispatch order, so that a grid larger than the chip advances all filters
@@ -335,7 +345,19 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
     // (role index and filter from the linear workgroup index: grid = (B * rolesPerRow, rows), filter fastest; one row unless the roles and
     // downdate tiles of a filter are more than 32768 -- N > ~2700)
     const int nB = (int)gridDim.x / ra.rolesPerRow;
-    const int roleIdx = (int)blockIdx.x / nB + ra.rolesPerRow * (int)blockIdx.y, bIdx = (int)blockIdx.x % nB;
+    const int roleIdxAll = (int)blockIdx.x / nB + ra.rolesPerRow * (int)blockIdx.y, bIdx = (int)blockIdx.x % nB;
+    if (FOLD && roleIdxAll < ra.nPrep) {
+        // ---- a prep role (see ResArgs::nPrep): the lowest block indices of the grid -- nothing they need is produced in this launch
+        const Glob& gp = ra.a.g[bIdx];
+        if (gp.updateOk && gp.N != 0) {
+            updatePrepBody<T, true>(ra.a, roleIdxAll, bIdx, ra.lmBlocks, ra.prepWpb, ra.prepNvPad, reinterpret_cast<double*>(smemR));
+            hoDrain();
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) hoPublish(ra.prepFlags + (long long)bIdx * ra.nPrepCap + roleIdxAll, ra.c0.epoch);
+        return;
+    }
+    const int roleIdx = roleIdxAll - (FOLD ? ra.nPrep : 0);
     if (roleIdx >= ra.nRoles + ra.nDdTiles) return;
     if (roleIdx >= ra.nRoles) {
         // ---- a downdate tile of filter blockIdx.x.  These workgroups have the HIGHEST block indices: they are dispatched when
@@ -348,29 +370,40 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         const int slot = tile == 0 ? 0 : (tile == 27 ? 1 : (tile == 54 ? 2 : -1));
         if (t == 0 && bb == EQF_STAMP_B && slot >= 0) g_resStamps[0][15][3 * slot] = wall_clock64();
 #endif
-        if (t == 0 && gg.updateOk && gg.N != 0) {
+        if (gg.updateOk && gg.N != 0) {
+            // (the Y tiles of the S-chain's LAST block row carry the epoch when they are out, and a tile of block row C is only solved after
+            // the tiles above it: one flag per column tile says "all of Y".  A counter said the same until round 4; it had to be zeroed by
+            // an earlier launch, which the prep roles of this launch are not.)
             int nS, wS;
             chainDims64(ra.c0, gg.N, &nS, &wS);
-            const int* cnt = ra.counters + (long long)bb * 4;
-            const long long t0 = wall_clock64();
-            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nS * wS) {
-                __builtin_amdgcn_s_sleep(32);
-                if (hoAborted(ra.errflag)) {  // (some hand-off of this launch timed out: nobody will finish the S-chain)
-                    late = 1;
-                    break;
-                }
-                if (wall_clock64() - t0 > 50000000LL) {  // 0.5 s
-                    if (ra.errflag) atomicOr(ra.errflag, kHoErrTimeout);
-                    late = 1;
-                    break;
-                }
+            // (ONE lane, long sleeps: on a co-resident grid these 55 workgroups poll from the first microsecond on -- with every lane of
+            // ten polling at hoWait's rate the flags of the chains' own hand-offs got slower: 124 -> 133 us per update)
+            const int* ry = ra.readyY + ((long long)bb * 2 + 0) * ra.nbCap * ra.wtCap + (nS - 1) * ra.wtCap;
+            if (t == 0) {
+                const long long t0 = wall_clock64();
+                for (int i = 0; i < wS && !late; ++i)
+                    while (__hip_atomic_load(ry + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ra.c0.epoch) {
+                        __builtin_amdgcn_s_sleep(32);
+                        if (hoAborted(ra.errflag)) {  // (some hand-off of this launch timed out: nobody will finish the S-chain)
+                            late = 1;
+                            break;
+                        }
+                        if (wall_clock64() - t0 > 50000000LL) {  // 0.5 s
+                            if (ra.errflag) atomicOr(ra.errflag, kHoErrTimeout);
+                            late = 1;
+                            break;
+                        }
+                    }
             }
         }
         if (__syncthreads_or(late)) return;  // (Sigma_out is left untouched: the sticky flag makes the host fail the update)
 #ifdef EQF_RES_STAMPS
         if (t == 0 && bb == EQF_STAMP_B && slot >= 0) g_resStamps[0][15][3 * slot + 1] = wall_clock64();
 #endif
-        downdateTile<T, 64, 4>(ra.a, ra.ddNt, bb, tile, reinterpret_cast<T*>(smemR));
+        // (FOLD: 32 x 32 tiles -- with the S-chain starting behind the prep roles the downdate ends the launch, and a 64 x 64 tile is 28 us
+        // of dependent fetches for one workgroup; four times the workgroups, each a third of that)
+        if (FOLD) downdateTile<T, 32>(ra.a, ra.ddNt, bb, tile, reinterpret_cast<T*>(smemR));
+        else downdateTile<T, 64, 4>(ra.a, ra.ddNt, bb, tile, reinterpret_cast<T*>(smemR));
 #ifdef EQF_RES_STAMPS
         __syncthreads();
         if (t == 0 && bb == EQF_STAMP_B && slot >= 0) g_resStamps[0][15][3 * slot + 2] = wall_clock64();
@@ -382,6 +415,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
     if (hoAborted(ra.errflag)) return;
     const ResRole role = ra.roles[roleIdx];
     const int b = bIdx;
+    constexpr bool fold = FOLD;
     const ChainArgs& ch = role.kind ? ra.c1 : ra.c0;
     const UpdArgs& a = ra.a;
     const Glob& g = ch.g[b];
@@ -409,18 +443,37 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
     int* counters = ra.counters + (long long)b * 4;
     int bad = 0;
     // element (i, j) of tile (R, C) of the chain matrix BEFORE any of this update's operations
-    const bool srcSigma = OCC2 && ra.eFromSigma && role.kind == 1;
+    const bool srcSigma = ra.eFromSigma && role.kind == 1;
     const T* Sg = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
     const int neE = eDim(g.N), ldS = a.ld;
     auto tile0 = [&](int R, int C, int i, int j) __attribute__((always_inline)) {
-        if (!srcSigma) return A[(long long)(R * kSB + i) * ldA + C * kSB + j];
+        if (!srcSigma) return fold ? hoLoad8(A + (long long)(R * kSB + i) * ldA + C * kSB + j) : A[(long long)(R * kSB + i) * ldA + C * kSB + j];
         const int r = R * kSB + i, c = C * kSB + j;
         const bool in = r < neE && c < neE && r != 5 && c != 5;
         const double v = (double)Sg[in ? (long long)(6 + r) * ldS + 6 + c : 0];
         return in ? v : (r == c ? 1.0 : 0.0);
     };
 
-    if (role.role == 0) {
+    // (fold) everything the prep roles of this launch write -- S, both chains' right-hand sides -- is there once all of them have published
+    auto waitPrep = [&]() {
+        if (!fold) return;
+        for (int i = tid; i < ra.nPrep; i += 256)
+            if (!hoWait(ra.prepFlags + (long long)b * ra.nPrepCap + i, epoch, ra.errflag)) bad = 8;
+        bad = __syncthreads_or(bad) ? 8 : 0;
+    };
+    const bool waitD0 = (ra.waitD0 >> role.kind) & 1;
+
+    if (role.role == 6) {
+        // =========================================================================================== F0: the chain's first diagonal block
+        // (what two extra workgroups of the prep launch do otherwise; here for the E-chain when its diagonal-factor chain runs as a launch
+        // of its own NEXT to the prep launch -- it needs nothing of it: Sigma_e is Sigma[6:, 6:])
+        // (Tried: the first row head factors D[0] itself and keeps it in LDS -- no flag, no 40 KB round trip into the chain -- 134.8 -> 140-145 us
+        // per update: the inlined factorisation costs EVERY row head more than the first one saves.)
+        factorFirstFromSigma<T, true>(a, ch, b, s, &bad);
+        hoDrain();
+        __syncthreads();
+        if (tid == 0 && !bad) hoPublish(ch.flags + (long long)b * ch.strideF, epoch);
+    } else if (role.role == 0) {
         // =========================================================================================== H(R)
         const int R = role.R;
         if (R >= nb) return;
@@ -432,6 +485,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         tr[1] = wv == 2 ? 1 : 2; tc[1] = 1;
         tr[2] = wv == 2 ? 3 : 2; tc[2] = wv == 2 ? 1 : 2;
         tr[3] = 3;               tc[3] = wv == 2 ? 2 : 3;
+        if (!srcSigma) waitPrep();
         f64x4 a1[4], a2[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -514,7 +568,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         int* const stageOut = ra.stageFlags ? ra.stageFlags + (((long long)b * 2 + role.kind) * nbCap + R) * 4 : nullptr;
         if (R - 1 == 0 || !ra.stageFlags) {
             // D[0] comes complete from the prep launch
-            hoWait3(R - 1 > 0 ? flagD + (R - 1) : nullptr, nullptr, nullptr, epoch, tid, &bad, ra.errflag);
+            hoWait3((R - 1 > 0 || waitD0) ? flagD + (R - 1) : nullptr, nullptr, nullptr, epoch, tid, &bad, ra.errflag);
             EQF_HSTAMP(2);
             hoLoadRecord(D + (long long)(R - 1) * kDRec, s, tid);
 #pragma unroll
@@ -566,6 +620,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         // =========================================================================================== T(R, C)
         const int R = role.R, C = role.C;
         if (R >= nb) return;
+        if (!srcSigma) waitPrep();
         f64x4 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -605,7 +660,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         // head H(C+2) waits for: no change, 137.8 against 138.3 us per update -- once the heads consume D stage by stage the pivot chain
         // and its hand-off are the critical path again, 13.6 us per block column: factor64 10.3, store issue + first column 1.1, flag +
         // W_33 0.9, last solve step 0.3, publish 0.45.)
-        hoWait3(C > 0 ? flagD + C : nullptr, nullptr, nullptr, epoch, tid, &bad, ra.errflag);
+        hoWait3((C > 0 || waitD0) ? flagD + C : nullptr, nullptr, nullptr, epoch, tid, &bad, ra.errflag);
         hoLoadRecord(D + (long long)C * kDRec, s, tid);
 #pragma unroll
         for (int i = 0; i < 4; ++i) stTile(acc[i], &s.P[0][0], kSP, kQB * wv, kQB * i, lane);
@@ -622,11 +677,15 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         const int t = role.R, C = role.C;
         if (t >= wt || C >= nb) return;
         const double* Tg = W + (long long)(C * kSB) * ldW + t * kSB;
+        waitPrep();
         f64x4 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[i][q] = Tg[(long long)(kQB * wv + (lane >> 4) + 4 * q) * ldW + kQB * i + (lane & 15)];
+            for (int q = 0; q < 4; ++q) {
+                const double* p = Tg + (long long)(kQB * wv + (lane >> 4) + 4 * q) * ldW + kQB * i + (lane & 15);
+                acc[i][q] = fold ? hoLoad8(p) : *p;
+            }
         const bool isS = ch.kind == 0;
         double* zv = s.redL;  // [0, 64) the innovation column delta of this block row, [64, 128) z of block row K
         const int nvv = kLm0 + 3 * g.N;
@@ -667,7 +726,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
                 updateFinishBody(a, b, s.redL, 1);
             }
         };
-        if (isS && tid < kSB) zv[tid] = W[(long long)(C * kSB + tid) * ldW + 11];
+        if (isS && tid < kSB) zv[tid] = fold ? hoLoad8(W + (long long)(C * kSB + tid) * ldW + 11) : W[(long long)(C * kSB + tid) * ldW + 11];
         if (C > 0) {
             // pipelined panel loop (see panelIssue): Q <- L_{C,K}, P <- Y_{K,t}; the S-chain also carries z_K along
             __shared__ int sAheadW;
@@ -714,7 +773,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         }
         if (last && !collected) collect();
         EQF_WSTAMP(0);
-        hoWait3(C > 0 ? flagD + C : nullptr, nullptr, nullptr, epoch, tid, &bad, ra.errflag);
+        hoWait3((C > 0 || waitD0) ? flagD + C : nullptr, nullptr, nullptr, epoch, tid, &bad, ra.errflag);
         EQF_WSTAMP(1);
         hoLoadRecord(D + (long long)C * kDRec, s, tid);
         // running sums of the reductions: block row C adds its share to what block row C-1 of the same column tile left

@@ -140,9 +140,19 @@ EQF_DI void liftRows(const LiftCommon& L, quat Qq, double Qa, d3 p0, double* Z /
 // ------------------------------------------------------------------------------------------------
 // Dynamic LDS: wpb (waves per workgroup) x 2 rows x nvPad doubles for one column chunk of the C*Sigma rows.
 constexpr int kPrepLmChunk = 512;
-template <typename T>
-EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, double* sCSraw) {
-    const int b = blockIdx.y;
+// WT (k_chol_resident's prep roles: the results are consumed by other workgroups of the SAME launch): every global store is an 8-byte
+// agent-scope store (write-through, eqf_handoff.hpp); the caller drains and publishes.  bx / b: the workgroup's index in the prep grid.
+template <bool WT>
+EQF_DI void prepStore(double* p, double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+#else
+    *p = v;
+#endif
+}
+template <typename T, bool WT = false>
+EQF_DI void updatePrepBody(const UpdArgs& a, int bx, int b, int lmBlocks, int wpb, int nvPad, double* sCSraw) {
     const Glob& g = a.g[b];
     if (!g.updateOk) return;
     const int N = g.N;
@@ -154,10 +164,10 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, d
     const double* Q = a.Q + (long long)b * 5 * cap;
     int bad = 0;
 
-    if ((int)blockIdx.x >= lmBlocks) {
+    if (bx >= lmBlocks) {
         // ---- E-chain operand: EA = Sigma[6:,6:] (pad e=5 -> identity), ZW = [Z_P | E_top], 32 rows per workgroup
         const int ne = eDim(N), nep = roundUp(ne, a.pad);
-        const int r0 = ((int)blockIdx.x - lmBlocks) * kNB;
+        const int r0 = (bx - lmBlocks) * kNB;
         if (r0 >= nep) return;
         double* EA = a.EA + (long long)b * a.strideE;
         double* ZW = a.ZW + (long long)b * a.strideZ;
@@ -190,7 +200,7 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, d
                     for (int u = 0; u < kColGroups; ++u) {
                         const int c2 = c0 + 64 * u;
                         const bool in = rr < ne && c2 < ne && rr != 5 && c2 != 5;
-                        if (rb + q * nw < kNB && c2 < nep) EA[(long long)rr * a.ldE + c2] = in ? (double)v[q][u] : ((rr == c2) ? 1.0 : 0.0);
+                        if (rb + q * nw < kNB && c2 < nep) prepStore<WT>(&EA[(long long)rr * a.ldE + c2], in ? (double)v[q][u] : ((rr == c2) ? 1.0 : 0.0));
                     }
                 }
             }
@@ -210,7 +220,7 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, d
                 for (int c = 0; c < 6; ++c) row[c] = (comp == 0) ? Z[c] : (comp == 1 ? Z[6 + c] : Z[12 + c]);
             }
             if (rr < 5) row[6 + rr] = 1.0;  // E_top
-            for (int c = 0; c < a.ldZ; ++c) ZW[(long long)rr * a.ldZ + c] = (c < 16) ? row[c] : 0.0;
+            for (int c = 0; c < a.ldZ; ++c) prepStore<WT>(&ZW[(long long)rr * a.ldZ + c], (c < 16) ? row[c] : 0.0);
         }
         return;
     }
@@ -219,7 +229,7 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, d
     // kPrepLmChunk landmarks each (one chunk up to N = 512; larger N loops), so LDS use does not grow with N.
     double* sCS0 = sCSraw + (long long)(2 * wv) * nvPad;
     double* sCS1 = sCS0 + nvPad;
-    const int i = blockIdx.x * wpb + wv;
+    const int i = bx * wpb + wv;
     const int m = sDim(N), mp = roundUp(m, a.pad);
     const int yc = yCols(N), ycp = roundUp(yc, a.pad);
     double* SA = a.SA + (long long)b * a.strideS;
@@ -303,8 +313,8 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, d
         if (valid) {
             for (int col = colLo + lane; col < colHi; col += 64) {  // right-hand sides: C Sigma, delta in column 11
                 const bool isz = (col == 11);
-                YW[(long long)(2 * i) * a.ldY + col] = isz ? dl[0] : sCS0[col - colLo];
-                YW[(long long)(2 * i + 1) * a.ldY + col] = isz ? dl[1] : sCS1[col - colLo];
+                prepStore<WT>(&YW[(long long)(2 * i) * a.ldY + col], isz ? dl[0] : sCS0[col - colLo]);
+                prepStore<WT>(&YW[(long long)(2 * i + 1) * a.ldY + col], isz ? dl[1] : sCS1[col - colLo]);
             }
             // S[2i+r][2j+s] = sum_c CS[r][12+3j+c] C_j[s][c]  (+ measurementVariance on the diagonal)
             for (int j = q0 + lane; j < q1; j += 64) {
@@ -322,8 +332,8 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, d
                     s11 += a.prm.measurementVariance;
                 }
                 double* r0p = SA + (long long)(2 * i) * a.ldS + 2 * j;
-                r0p[0] = s00; r0p[1] = s01;
-                r0p[a.ldS] = s10; r0p[a.ldS + 1] = s11;
+                prepStore<WT>(r0p, s00); prepStore<WT>(r0p + 1, s01);
+                prepStore<WT>(r0p + a.ldS, s10); prepStore<WT>(r0p + a.ldS + 1, s11);
             }
         }
         __syncthreads();
@@ -331,12 +341,12 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, d
     const int nvv = kLm0 + 3 * N;
     if (valid) {
         for (int col = nvv + lane; col < ycp; col += 64) {  // V (6 columns) and zero padding
-            YW[(long long)(2 * i) * a.ldY + col] = (col < nvv + 6) ? V[col - nvv] : 0.0;
-            YW[(long long)(2 * i + 1) * a.ldY + col] = (col < nvv + 6) ? V[6 + col - nvv] : 0.0;
+            prepStore<WT>(&YW[(long long)(2 * i) * a.ldY + col], (col < nvv + 6) ? V[col - nvv] : 0.0);
+            prepStore<WT>(&YW[(long long)(2 * i + 1) * a.ldY + col], (col < nvv + 6) ? V[6 + col - nvv] : 0.0);
         }
         for (int j = N + lane; j < mp / 2; j += 64) {  // padding columns of S
             double* r0p = SA + (long long)(2 * i) * a.ldS + 2 * j;
-            r0p[0] = r0p[1] = r0p[a.ldS] = r0p[a.ldS + 1] = 0.0;
+            prepStore<WT>(r0p, 0.0); prepStore<WT>(r0p + 1, 0.0); prepStore<WT>(r0p + a.ldS, 0.0); prepStore<WT>(r0p + a.ldS + 1, 0.0);
         }
         if (lane == 0 && a.dbgDelta) {
             a.dbgDelta[(long long)b * 2 * cap + 2 * i] = dl[0];
@@ -345,12 +355,12 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int lmBlocks, int wpb, int nvPad, d
     } else if (2 * i < mp) {
         // padding rows of the S-chain: identity in S, zero right-hand sides
         for (int col = lane; col < ycp; col += 64) {
-            YW[(long long)(2 * i) * a.ldY + col] = 0.0;
-            YW[(long long)(2 * i + 1) * a.ldY + col] = 0.0;
+            prepStore<WT>(&YW[(long long)(2 * i) * a.ldY + col], 0.0);
+            prepStore<WT>(&YW[(long long)(2 * i + 1) * a.ldY + col], 0.0);
         }
         for (int col = lane; col < mp; col += 64) {
-            SA[(long long)(2 * i) * a.ldS + col] = (col == 2 * i) ? 1.0 : 0.0;
-            SA[(long long)(2 * i + 1) * a.ldS + col] = (col == 2 * i + 1) ? 1.0 : 0.0;
+            prepStore<WT>(&SA[(long long)(2 * i) * a.ldS + col], (col == 2 * i) ? 1.0 : 0.0);
+            prepStore<WT>(&SA[(long long)(2 * i + 1) * a.ldS + col], (col == 2 * i + 1) ? 1.0 : 0.0);
         }
     }
     if (bad && a.errflag) atomicOr(a.errflag, 2);
