@@ -487,7 +487,12 @@ def tiled_leg(args, dist, rank, world, device):
         "device_error_flag": be.device_error(),
         "sigma_fro_local": float(torch.linalg.norm(tf.Sll).item()),
         "phases_ms_per_frame": {k: round(v / n_vis_ph, 3) for k, v in tf.phase_ms.items()},
-        "update_algorithmic_tflops": round(update_flops * n_vis_ph / max(sum(v for k, v in tf.phase_ms.items() if k != "propagate"), 1e-9) / 1e9, 2)
+        # chain_E runs on its own stream pair NEXT TO chain_S + downdate: the phases are stream-busy times and do not add up to the frame
+        "phases_concurrent": [["chain_S", "downdate"], ["chain_E"]],
+        "phases_note": "GPU time per phase on the phase's own stream; chain_E overlaps chain_S + downdate (two stream pairs on disjoint CU "
+                       "sets), so ms_per_frame ~ propagate + prep + max(chain_S + downdate, chain_E) + finish, not the sum",
+        # the rate of an update: SURVEY 8(d)'s flops over the WALL time of an update (frame minus its Riccati steps), not over the sum of phases
+        "update_algorithmic_tflops": round(update_flops / max(dt * 1e3 / max(n_vis, 1) - tf.phase_ms.get("propagate", 0.0) / n_vis_ph, 1e-9) / 1e9, 2)
         if tf.phase_ms else None,
         "note": "closed loop through the C ABI (eqf_tiled_* / eqf_tile_*), torch.distributed only moves solved block rows; "
                 + ("one rank: no exchange" if world == 1 else "RCCL broadcasts along process rows / columns"),

@@ -133,7 +133,9 @@ class HipBackend:
 
     DREC = 64 * 64 + 4 * 16 * 16  # doubles per 64-wide block column of a diagonal-factor record
 
-    def __init__(self, settings, capacity, device_index=0, reserve_cus=None):
+    def __init__(self, settings, capacity, device_index=0, reserve_cus=None, cu_range=None):
+        """cu_range = (first_cu, num_cus): confine EVERY stream of this rank to that slice of the GPU (experiments with several ranks on one
+        device, scripts/tiled_cumask.py: main streams on [first + reserve, first + num), look-ahead streams on [first, first + reserve))."""
         from . import binding
 
         self.b = binding
@@ -159,8 +161,11 @@ class HipBackend:
         if self.reserve > 0:
             ptrs = [ctypes.c_void_p() for _ in range(4)]
             for i, p in enumerate(ptrs):  # main, side, and a second pair for the E-chain, which runs next to the S-chain (TiledFilter._update)
-                binding._check(self.lib.eqf_stream_create_masked(self.dev, 0, self.reserve, 1 if i % 2 == 0 else 0, ctypes.byref(p)),
-                               "eqf_stream_create_masked")
+                if cu_range is None:
+                    first, count, comp = 0, self.reserve, 1 if i % 2 == 0 else 0
+                else:
+                    first, count, comp = (cu_range[0] + self.reserve, cu_range[1] - self.reserve, 0) if i % 2 == 0 else (cu_range[0], self.reserve, 0)
+                binding._check(self.lib.eqf_stream_create_masked(self.dev, first, count, comp, ctypes.byref(p)), "eqf_stream_create_masked")
             self._raw = ptrs
             self._main, self._side, self._aux, self._aux_side = [torch.cuda.ExternalStream(p.value, device=self.device) for p in ptrs]
         self._sync_stream()

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (through gpurun): collects the round's measurement evidence into gpurun_out/evidence/.
 # Usage: scripts/collect_evidence.sh <round tag, e.g. r01>
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/evidence
 mkdir -p "$OUT"
@@ -46,6 +46,9 @@ pmc bench_N200 GRBM_GUI_ACTIVE --steps 220 --warmup 110
 # 1b. the same workload with the per-column launches instead of the resident update kernel, and with one launch per IMU call
 EQF_CHOL_RESIDENT=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-batch64 --no-parity --no-tiled --no-churn --no-steady-state > "$OUT/${TAG}_bench_N200_launches.json" 2>/dev/null
 EQF_RES_STAGED=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-batch64 --no-parity --no-traffic --no-tiled --no-churn --no-steady-state > "$OUT/${TAG}_bench_N200_unstaged.json" 2>/dev/null
+# 1c. the same with the prep launch in front of the update launch (round 3's shape) instead of the prep roles inside it
+EQF_RES_FOLD_PREP=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-batch64 --no-parity --no-traffic --no-tiled --no-churn --no-steady-state > "$OUT/${TAG}_bench_N200_preplaunch.json" 2>/dev/null
+EQF_RES_FOLD_PREP=0 stats bench_N200_preplaunch
 EQF_CHOL_RESIDENT=0 stats bench_N200_launches
 EQF_IMU_BURST=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-churn --no-steady-state > "$OUT/${TAG}_bench_N200_noburst.json" 2>/dev/null
 # 2. a batch of 64 filters on one GPU (cfg 4's filters, all on one device)
@@ -90,4 +93,23 @@ timeout 900 bash $ROOT/scripts/launch_timeline.sh 64 > "$OUT/${TAG}_timeline_bat
 ( echo "# scripts/dev_compare.py 200 10.0 on MI355X: HIP path (fp64, per-call C ABI) vs oracle/eqf_oracle.cpp, same synthetic stream"
   echo "# (2000 IMU + 200 vision events, N = 200, template settings); relS = |Sigma_gpu - Sigma_ref|_F / |Sigma_ref|_F after the event"
   cd $ROOT && timeout 1200 $PY scripts/dev_compare.py 200 10.0 | grep -E "vision|worst|eqf_vio" | awk 'NR%20==1 || /worst/' ) > "$OUT/${TAG}_parity_N200_10s.txt" 2>&1
+# 6. parity at the large sizes against the structured oracle, with the kernels that are the default at those sizes THIS round
+# (k_chol_resident in its two-per-CU build; the N = 4000 oracle needs minutes of one core per frame)
+( echo "# scripts/dev_compare.py N seconds 0 structured on MI355X: HIP path (fp64, per-call C ABI, IMU bursts, default kernels of this round:"
+  echo "# ONE update launch, k_chol_resident<double, PIPEH, OCC2>) vs oracle/eqf_oracle.cpp structured backend, same synthetic stream"
+  for spec in "1000 0.3" "2000 0.16" "4000 0.11"; do
+    set -- $spec
+    echo "# N = $1, $2 s"
+    cd $ROOT && timeout 1500 $PY scripts/dev_compare.py $1 $2 0 structured | grep -E "vision|worst"
+  done ) > "$OUT/${TAG}_parity_large_N.txt" 2>&1
+# 7. the chain of ONE filter of N = 200 from the inside: wall-clock stamps of every row head (instrumented build, if it was shipped)
+if [ -f $ROOT/build_variants/libeqf_stamps.so ]; then
+  EQF_VIO_AMD_LIB=$ROOT/build_variants/libeqf_stamps.so timeout 300 $PY $ROOT/scripts/res_stamps.py 200 1 > "$OUT/${TAG}_res_stamps_N200.txt" 2>&1
+fi
+# 8. factor64 alone (scripts/micro/factor64_bench.hip, if built): cycles per 64-column block, per-wave stamps
+for b in factor64_bench factor64_bench_ns; do
+  [ -x $ROOT/scripts/micro/$b ] && ( $ROOT/scripts/micro/$b 0 1 4; $ROOT/scripts/micro/$b 0 0 4 ) > "$OUT/${TAG}_${b}.txt" 2>&1
+done
+# 9. sub-batches on their own streams (verdict r3 item 3): 8 and 16 filters as 1 / 2 / 4 / 8 handles
+( timeout 600 $PY $ROOT/scripts/two_handles.py 8 880; timeout 600 $PY $ROOT/scripts/two_handles.py 16 880 ) > "$OUT/${TAG}_two_handles.txt" 2>&1
 ls -la "$OUT"

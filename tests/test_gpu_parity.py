@@ -933,3 +933,37 @@ def test_imu_bursts_with_irregular_stamps_and_fp32(hip):
     b = _run_bursts(hip, st, N, 15, precision=hip.PRECISION_F32)
     assert rel_fro(b[0], a[0]) < 5e-2  # the documented bound of the fp32 mode (see the split-path test above)
     assert np.abs(a[1]["x"] - b[1]["x"]).max() < 5e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [21, 70, 107, 200])
+def test_prep_roles_inside_the_update_launch_equal_the_prep_launch(hip, monkeypatch, N):
+    """Round 4: for a co-resident grid (one small filter) the prep work -- residuals, C Sigma, S, the lift rows, the chains' first diagonal
+    blocks -- runs as roles of k_chol_resident's launch (its FOLD build: write-through stores, flags, agent-scope loads, the E-chain's tiles
+    read straight from Sigma, 32 x 32 downdate tiles) instead of as the launch k_update_prep64 in front of it (EQF_RES_FOLD_PREP=0).
+    Same operations on the same values: the two must agree bit for bit after every vision update.  N = 21: the S-chain has ONE block column
+    (no row head: its first diagonal block is factored by the role F0)."""
+    from eqf_vio_amd import synth
+
+    st = synth.make_stream(N, seed=77, duration=0.36 if N >= 200 else 0.6)
+    d = synth.template_settings_dict()
+    outs = []
+    for fold in ("1", "0"):
+        monkeypatch.setenv("EQF_RES_FOLD_PREP", fold)
+        fg = hip.FilterBatch(d, capacity=N, batch=1)
+        seq = []
+        for kind, k in st.events():
+            if kind == "imu":
+                r = st.imu[k]
+                fg.process_imu([r[0]], r[1:4], r[4:7])
+            else:
+                fg.process_vision([st.vision_stamps[k]], st.ids, st.bearings[k])
+                e = fg.state_estimate()
+                seq.append((fg.sigma().copy(), e["x"].copy(), e["q"].copy(), e["p"].copy(), fg.bias().copy()))
+        assert fg.device_error() == 0
+        outs.append(seq)
+    monkeypatch.delenv("EQF_RES_FOLD_PREP")
+    assert len(outs[0]) == len(outs[1]) > 3
+    for f, (a, b) in enumerate(zip(*outs)):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v), (N, f)
