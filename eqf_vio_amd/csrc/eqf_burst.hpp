@@ -17,6 +17,7 @@
 // boundaries (e.g. after eqf_dump / restore) produces the same bits.
 #pragma once
 #include "eqf_propagate.hpp"
+#include "eqf_handoff.hpp"
 
 namespace eqf {
 
@@ -26,6 +27,11 @@ constexpr int kLwWave = 1, kSbbWave = 2;  // k_burst_build<.., 4>: waves 1..3 ca
 // per step and landmark (element type T): D, Lw, Lv, Gn, Gv (the row constants, kBlkRec = 45 as in k_build_blocks) and
 // Sw = Sigma[0:3, J], Sv = Sigma[8:11, J] (entering the step) for the column side
 constexpr int kColRec = 63;
+// Every builder publishes its step count kFlagReplicas times, a few KB apart (one store instruction, one lane per replica), and a block
+// workgroup polls replica (tile index mod kFlagReplicas): a hundred pollers on ONE line saturate its memory channel, and the builders'
+// write-through stores queue up behind them (measured: ticks of 3 us instead of 1.4).
+constexpr int kFlagReplicas = 8;
+inline long long burstRecStep(long long elems) { return (elems + 31) / 32 * 32; }
 constexpr int kBuildThreads = 512;  // 8 wavefronts, see k_burst_build (a ninth would cap every wave at 168 VGPRs: spills)
 
 struct BurstStep {
@@ -55,6 +61,13 @@ struct BurstArgs {
     void* colRec;      // [B][kBurstMax][kColRec][cap]  (T)
     void* rowRec;      // [B][kBurstMax][cap][kBlkRec]  (T)
     BurstStep* steps;  // [B][kBurstMax]
+    // k_burst_fused (builder and block workgroups in ONE launch): buildFlags[b * nBuildCap + w] = epoch * 32 + s once builder workgroup w
+    // has the records of steps 0 .. s-1 in memory (write-through stores, drained); nBuild = builder workgroups per filter
+    int* buildFlags;   // [B][kFlagReplicas][nBuildCap (the stride of a replica)]
+    int epoch, nBuild, nBuildCap;
+    // elements between two steps' records: kColRec * cap and cap * kBlkRec rounded up to whole 128-byte lines (burstRecStep), so that no
+    // cache line holds entries of two steps -- the fused launch reads a step's lines through the L2 while later steps are still being written
+    long long colStep, rowStep;
     Params prm;
 };
 
@@ -71,6 +84,10 @@ EQF_DI void waveSync() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS operations of one wave are performed in order
 #endif
 }
+// flags in LDS: relaxed workgroup-scope atomics.  (A `volatile` LDS access makes the compiler wait for EVERY outstanding memory
+// operation of the wave -- s_waitcnt vmcnt(0) lgkmcnt(0) -- i.e. for write-through stores and prefetches that are meant to stay in flight.)
+EQF_DI int ldsFlagLoad(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+EQF_DI void ldsFlagStore(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 EQF_DI void ldsBarrier() {
 #ifdef __HIP_DEVICE_COMPILE__
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -79,7 +96,7 @@ EQF_DI void ldsBarrier() {
 
 #ifdef EQF_BURST_STAMPS
 __device__ long long g_burstStamps[8][20][4];  // [wave][tick]: work begins / ends (workgroup 0)
-#define EQF_BSTAMP(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && t < 20) g_burstStamps[wv][t][k] = __builtin_readcyclecounter(); } while (0)
+#define EQF_BSTAMP(k) do { if (bxIdx == 0 && b == 0 && lane == 0 && t < 20) g_burstStamps[wv][t][k] = wall_clock64(); } while (0)  /* 100 MHz, the same clock on every CU */
 #else
 #define EQF_BSTAMP(k) do { } while (0)
 #endif
@@ -111,14 +128,15 @@ struct BurstLds {
     T Tt[4];
     T swT[4];           // sigma_w^2 / T
     double Q[2][kBurstLmMax][5];
-    T blk[2][kBurstLmMax][28];  // D, Lw, Lv
+    T blk[4][kBurstLmMax][28];  // D, Lw, Lv of step u in slot u & 3 (written in tick u + 1, read by the panels in tick u + 2 and -- fused launch -- by the store wave in tick u + 3)
+    T g2[4][4][36];     // fused launch, LM = 4: Gn, Gv, Sw, Sv of step u (record entries 27 .. 62), written by the panel wave in tick u + 2
     T Sbb[4][11][12];   // Sigma_bb ENTERING step u in slot u & 3
     T Tb[11][12];
     T Gs[4][4][3][12];  // [panel wave][landmark][row]: G_I = L_I Sigma_bb + D_I Sigma_Ib, exchanged between the column lanes
     ImuRec rec[kBurstMax];
     StepPre pre[kBurstMax];
     unsigned stepMask;
-    volatile int handStep;  // LM = 4: wave 4 has published R_A / vhat / etahat of this step (wave 3 polls it inside the tick)
+    int handStep;  // (ldsFlagLoad / ldsFlagStore) LM = 4: wave 4 has published R_A / vhat / etahat of this step (wave 3 polls it inside the tick)
 };
 
 // The two 11 x 11 pieces every step needs of its common values: F_bb = I + T [[0,0,0,0],[-B_g^w,0,0,0],[-B_v^w,-R_A,A_vg,0]]
@@ -274,23 +292,27 @@ EQF_DI void burstCommonCam(StepCommon& c, const StepPre& pr, const Params& p) {
 // ------------------------------------------------------------------------------------------------
 // OCC2 (LM = 16 only): built for two workgroups per CU -- 128 instead of 169 registers -- for launches with more workgroups than CUs
 // (from 20 filters of N = 200 on): every workgroup is a chain of ticks bound by latency, a second one on the CU runs in its gaps.
-template <typename T, bool FAST, int LM, bool OCC2 = false>
-__global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(OCC2 ? 4 : 2, OCC2 ? 4 : 2))) void k_burst_build(BurstArgs a) {
+// FUSE (FAST, LM = 4, T = double; k_burst_fused): the block workgroups run in the SAME launch and consume a step's records as soon as
+// they are in memory.  The record entries then leave through LDS (blk, g2) and ONE wave -- wave 3, idle once the camera-frame values
+// of the tick are done -- stores them with write-through stores, drains them a tick later (for free) and publishes the step count.
+template <typename T, bool FAST, int LM, bool OCC2, bool FUSE>
+EQF_DI void burstBuildBody(const BurstArgs& a, const int bxIdx, const int b) {
     static_assert(LM == 4 || LM == 16, "role tables exist for 4 and 16 landmarks per workgroup");
+    static_assert(!FUSE || (FAST && LM == 4 && sizeof(T) == 8), "the fused launch exists for the latency case only");
     constexpr bool kSpread = LM == 4;  // one panel wave: the Lw blocks and Sigma_bb get wavefronts of their own
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int L0 = blockIdx.x * LM;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int L0 = bxIdx * LM;
     __shared__ BurstLds<T> s;
     const Glob& G0 = a.gin[b];
     const int N = G0.N, K = a.K, cap = a.cap, ld = a.ld;
-    const bool first = blockIdx.x == 0;
+    const bool first = bxIdx == 0;
     const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
     T* Sout = static_cast<T*>(a.Sout) + (long long)b * a.sigmaStride;
     const double* p0 = a.p0 + (long long)b * 3 * cap;
     const double* Qin = a.Qin + (long long)b * 5 * cap;
     double* Qout = a.Qout + (long long)b * 5 * cap;
-    T* colRec = static_cast<T*>(a.colRec) + (long long)b * kBurstMax * kColRec * cap;
-    T* rowRec = static_cast<T*>(a.rowRec) + (long long)b * kBurstMax * cap * kBlkRec;
+    T* colRec = static_cast<T*>(a.colRec) + (long long)b * kBurstMax * a.colStep;
+    T* rowRec = static_cast<T*>(a.rowRec) + (long long)b * kBurstMax * a.rowStep;
     int bad = 0;
 
     // ---- prologue: everything this workgroup reads of the state, issued together
@@ -320,7 +342,7 @@ __global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(O
             rW = mk3(G0.w[0], G0.w[1], G0.w[2]);
             rV0 = mk3(G0.v0[0], G0.v0[1], G0.v0[2]);
             rEta0 = mk3(G0.eta0[0], G0.eta0[1], G0.eta0[2]);
-            if (lane == 0) s.handStep = -1;
+            if (lane == 0) ldsFlagStore(&s.handStep, -1);
             if (lane < 4) {  // constants of the camera offset in every slot of the ring
                 StepCommon& c = s.com[lane];
 #pragma unroll
@@ -381,7 +403,13 @@ __global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(O
                 bs.riccati = o.step;
                 bs.pad_ = 0;
                 bs.TtP = o.step ? o.T * a.prm.pointProcessVariance : 0.0;
-                a.steps[b * kBurstMax + lane] = bs;
+                if (FUSE) {  // (read by the block workgroups of this launch: write-through, drained by the __syncthreads() below)
+                    double* dst = reinterpret_cast<double*>(a.steps + b * kBurstMax + lane);
+                    hoStore8(dst, __hiloint2double(0, bs.riccati));
+                    hoStore8(dst + 1, bs.TtP);
+                } else {
+                    a.steps[b * kBurstMax + lane] = bs;
+                }
             }
             if (o.step) {
                 const double invT = 1.0 / o.T;
@@ -447,7 +475,7 @@ __global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(O
                     if (kSpread) {
                         // the camera-frame velocities of the step are wave 3's (it has no other work): hand R_A, vhat over now
                         waveSync();
-                        s.handStep = t;
+                        ldsFlagStore(&s.handStep, t);
                     }
                     if (pr.step) {
                         if (!kSpread) burstCommonCam(c, pr, a.prm);
@@ -571,17 +599,19 @@ __global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(O
                 const double Qa = s.Q[cur][lane][4];
                 m33 Dm, Lvm;
                 buildDLv(s.com[st & 3], Qq, Qa, q0, &Dm, &Lvm);
-                T* cr = colRec + (long long)st * kColRec * cap + li;
-                T* rr = rowRec + ((long long)st * cap + li) * kBlkRec;
+                T* cr = colRec + (long long)st * a.colStep + li;
+                T* rr = rowRec + (long long)st * a.rowStep + (long long)li * kBlkRec;
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const T d = (T)Dm.a[k], lv = (T)Lvm.a[k];
-                    s.blk[cur][lane][k] = d;
-                    s.blk[cur][lane][18 + k] = lv;
-                    cr[(long long)k * cap] = d;
-                    cr[(long long)(18 + k) * cap] = lv;
-                    rr[k] = d;
-                    rr[18 + k] = lv;
+                    s.blk[st & 3][lane][k] = d;
+                    s.blk[st & 3][lane][18 + k] = lv;
+                    if (!FUSE) {
+                        cr[(long long)k * cap] = d;
+                        cr[(long long)(18 + k) * cap] = lv;
+                        rr[k] = d;
+                        rr[18 + k] = lv;
+                    }
                 }
                 if (!kSpread) {  // (LM = 16: no wavefront to spare for Lw)
                     const StepCommon& c = s.com[st & 3];
@@ -589,7 +619,7 @@ __global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(O
 #pragma unroll
                     for (int k = 0; k < 9; ++k) {
                         const T lw = (T)Lwm.a[k];
-                        s.blk[cur][lane][9 + k] = lw;
+                        s.blk[st & 3][lane][9 + k] = lw;
                         cr[(long long)(9 + k) * cap] = lw;
                         rr[9 + k] = lw;
                     }
@@ -600,15 +630,83 @@ __global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(O
         }
     } else if (kSpread && FAST && wv == 3) {
         // ---- the camera-frame common values of step t, inside the tick, as soon as wave 4 has handed R_A / vhat over
+        // fused launch: this wave also carries the records out.  Step u's entries are complete in LDS when tick u + 2 ends and are stored at
+        // the start of tick u + 3 (while wave 4 is busy with the first part of the recurrence): seven write-through store instructions.
+        // Their acknowledgement takes longer than a tick (measured: a drain one tick later stalled 0.5 - 1 us), so a step is published
+        // TWO ticks after its stores -- vmcnt counts in order: "at most the previous tick's seven outstanding" means the older ones are
+        // in memory -- and the wait costs nothing.
+        int* const myFlag = FUSE ? a.buildFlags + ((long long)b * kFlagReplicas + min(lane, kFlagReplicas - 1)) * a.nBuildCap + bxIdx : nullptr;  // lane r: replica r
+        const int ebase = a.epoch * 32;
+        // (a lone wave is bound by instruction issue: where a lane's seven values come from and go to is worked out once, per step there is
+        // one LDS read and one store per value -- the first version did the index arithmetic per step: 0.7 us in front of the camera job)
+        const T* srcL[7];   // slot 0 of the LDS ring
+        int srcStride[7];   // elements per slot
+        double* dstG[7];    // step 0
+        long long dstStride[7];
+        bool on[7];
+#pragma unroll
+        for (int p = 0; p < 7; ++p) {
+            int l, k;
+            if (p < 4) {  // column side: [step][entry][landmark]   (every instruction has active lanes: L0 < N)
+                const int e = lane + 64 * p;
+                k = min(e >> 2, kColRec - 1);
+                l = e & 3;
+                on[p] = e < 4 * kColRec && L0 + l < N;
+                dstG[p] = reinterpret_cast<double*>(colRec) + (long long)k * cap + L0 + l;
+                dstStride[p] = a.colStep;
+            } else {  // row side: [step][landmark][entry]
+                const int e = lane + 64 * (p - 4);
+                l = min(e / kBlkRec, 3);
+                k = e - l * kBlkRec;
+                on[p] = e < 4 * kBlkRec && L0 + l < N;
+                k = min(k, kBlkRec - 1);
+                dstG[p] = reinterpret_cast<double*>(rowRec) + (long long)(L0 + l) * kBlkRec + k;
+                dstStride[p] = a.rowStep;
+            }
+            srcL[p] = k < 27 ? &s.blk[0][l][k] : &s.g2[0][l][k - 27];
+            srcStride[p] = k < 27 ? kBurstLmMax * 28 : 4 * 36;
+        }
+        auto storeRecords = [&](int u) __attribute__((always_inline)) {  // returns the store instructions issued: 7 or 0
+            if (!s.ricc[u & 3]) return 0;
+            const int sl = u & 3;
+#pragma unroll
+            for (int p = 0; p < 7; ++p)
+                if (on[p]) hoStore8(dstG[p] + u * dstStride[p], (double)srcL[p][sl * srcStride[p]]);
+            return 7;
+        };
+        int prevStores = 0;
+        auto olderStoresDone = [&]() __attribute__((always_inline)) {
+            if (prevStores == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else hoDrain();
+        };
         for (int t = 0; t < K + 2; ++t) {
             EQF_BSTAMP(0);
+            if (FUSE) {
+                const int u = t - 3;
+                if (u >= 2) {
+                    olderStoresDone();
+                    if (lane < kFlagReplicas) hoPublish(myFlag, ebase + u - 1);  // steps 0 .. u-2
+                }
+                EQF_BSTAMP(2);
+                if (u >= 0) prevStores = storeRecords(u);
+                EQF_BSTAMP(3);
+            }
             if (t < K) {
-                while (s.handStep < t) __builtin_amdgcn_s_sleep(2);
+                while (ldsFlagLoad(&s.handStep) < t) __builtin_amdgcn_s_sleep(2);
                 waveSync();
                 if (lane == 0 && s.pre[t].step) burstCommonCam(s.com[t & 3], s.pre[t], a.prm);
             }
             EQF_BSTAMP(1);
             ldsBarrier();
+        }
+        if (FUSE) {  // the last steps: K-2 went out in the last tick, K-1 is complete in LDS now
+            if (K >= 3) {
+                olderStoresDone();
+                if (lane < kFlagReplicas) hoPublish(myFlag, ebase + K - 2);
+            }
+            storeRecords(K - 1);
+            hoDrain();
+            if (lane < kFlagReplicas) hoPublish(myFlag, ebase + K);
         }
     } else if (kSpread && wv == kLwWave) {
         // ---- Lw = -T B_i of step t-1: needs nothing of the state but T and the landmark's group element
@@ -621,14 +719,16 @@ __global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(O
                 const double Qa = s.Q[cur][lane][4];
                 const StepCommon& c = s.com[st & 3];
                 const m33 Lwm = buildLw(c.T, c.RICt, c.xIC, Qq, Qa, q0);
-                T* cr = colRec + (long long)st * kColRec * cap + li;
-                T* rr = rowRec + ((long long)st * cap + li) * kBlkRec;
+                T* cr = colRec + (long long)st * a.colStep + li;
+                T* rr = rowRec + (long long)st * a.rowStep + (long long)li * kBlkRec;
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const T lw = (T)Lwm.a[k];
-                    s.blk[cur][lane][9 + k] = lw;
-                    cr[(long long)(9 + k) * cap] = lw;
-                    rr[9 + k] = lw;
+                    s.blk[st & 3][lane][9 + k] = lw;
+                    if (!FUSE) {
+                        cr[(long long)(9 + k) * cap] = lw;
+                        rr[9 + k] = lw;
+                    }
                 }
             }
             EQF_BSTAMP(1);
@@ -649,8 +749,8 @@ __global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(O
             // ---- panel waves: step t-2
             const int st = t - 2;
             if (st >= 0 && st < K && s.ricc[st & 3] && 4 * wv < LM && L0 + 4 * wv < N) {
-                const int sl = st & 3, cur = st & 1;
-                const T* bk = s.blk[cur][4 * wv + pi];  // D, Lw, Lv of the lane's landmark (the same address for its 16 lanes)
+                const int sl = st & 3;
+                const T* bk = s.blk[sl][4 * wv + pi];  // D, Lw, Lv of the lane's landmark (the same address for its 16 lanes)
                 const int cq = pc < 11 ? pc : 0;
                 T sb[6], g[3];
 #pragma unroll
@@ -673,16 +773,21 @@ __global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(O
                 // records: Gn / Gv for the row side, Sw / Sv (entering the step) for the column side
                 if (pOk && (pc < 3 || (pc >= 8 && pc < 11))) {
                     const int cc = pc < 3 ? pc : pc - 8;
-                    T* cr = colRec + (long long)st * kColRec * cap + plm;
-                    T* rw = rowRec + ((long long)st * cap + plm) * kBlkRec;
+                    T* cr = colRec + (long long)st * a.colStep + plm;
+                    T* rw = rowRec + (long long)st * a.rowStep + (long long)plm * kBlkRec;
                     const T swT = s.swT[sl];
 #pragma unroll
                     for (int rr = 0; rr < 3; ++rr) {
                         const T gv = pc < 3 ? fma(swT, bk[9 + 3 * rr + cc], g[rr]) : g[rr];
                         const int ko = (pc < 3 ? 27 : 36) + 3 * rr + cc;
-                        cr[(long long)ko * cap] = gv;
-                        rw[ko] = gv;
-                        cr[(long long)((pc < 3 ? 45 : 54) + 3 * cc + rr) * cap] = pP[rr];
+                        if (FUSE) {
+                            s.g2[sl][pi][ko - 27] = gv;
+                            s.g2[sl][pi][(pc < 3 ? 18 : 27) + 3 * cc + rr] = pP[rr];
+                        } else {
+                            cr[(long long)ko * cap] = gv;
+                            rw[ko] = gv;
+                            cr[(long long)((pc < 3 ? 45 : 54) + 3 * cc + rr) * cap] = pP[rr];
+                        }
                     }
                 }
                 waveSync();
@@ -773,6 +878,10 @@ __global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(O
     }
     if (bad && a.errflag) atomicOr(a.errflag, 1);
 }
+template <typename T, bool FAST, int LM, bool OCC2 = false>
+__global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(OCC2 ? 4 : 2, OCC2 ? 4 : 2))) void k_burst_build(BurstArgs a) {
+    burstBuildBody<T, FAST, LM, OCC2, false>(a, (int)blockIdx.x, (int)blockIdx.y);
+}
 
 // ------------------------------------------------------------------------------------------------
 // k_burst_riccati_ring: the landmark x landmark blocks of a SMALL problem (the launch cannot fill the chip, every wave is
@@ -784,7 +893,7 @@ __global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(O
 // ------------------------------------------------------------------------------------------------
 #ifdef EQF_BURST_STAMPS
 __device__ long long g_ringStamps[4][64];
-#define EQF_RSTAMP(i) do { if (blockIdx.x == 9 && blockIdx.y == 0 && lane == 0 && (i) < 64) g_ringStamps[wv][i] = __builtin_readcyclecounter(); } while (0)
+#define EQF_RSTAMP(i) do { if (tileIdx == 9 && b == 0 && lane == 0 && (i) < 64) g_ringStamps[wv][i] = wall_clock64(); } while (0)
 #else
 #define EQF_RSTAMP(i) do { } while (0)
 #endif
@@ -802,15 +911,19 @@ constexpr int kRingTrips = 12;  // column-constant rows per wave and step: 45 ro
 // of the ring is that the 45 x 64 column constants of a step are fetched ONCE per workgroup (16 row landmarks) instead of once per
 // wavefront, and that a lane holds 13 + 3 prefetched values per register set instead of 46: 2 wavefronts per SIMD instead of 1.
 // grid = (ringTiles(N, R), B).
-template <typename T, int R = 1>
-__global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(BurstArgs a) {
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// FUSE (R = 1, T = double; k_burst_fused): the records are being written by the builder workgroups of the same launch.  Before a
+// wave requests step s it waits for the 16 builders of its column landmarks and the builder of its row landmarks to have published
+// s + 1 steps (lanes 0 .. 16 poll one flag each), and it reads the records with agent-scope loads (never from a stale L2 line).
+template <typename T, int R, bool FUSE>
+EQF_DI void burstRingBody(const BurstArgs& a, const int tileIdx, const int b) {
+    static_assert(!FUSE || (R == 1 && sizeof(T) == 8), "the fused launch exists for the latency case only");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int N = a.gin[b].N, K = a.K, cap = a.cap, ld = a.ld;
     // Only the blocks on and below the diagonal (row landmark >= column landmark) are propagated; the others are their transposes and
     // are written as such at the end (below).  The launch enumerates the tiles that hold such blocks and nothing else (column tile bx
     // keeps the row tiles from by0 = 16 bx / R on: at N = 200 that is 28 of 52 tiles, and of the ragged last column tile -- 8 of 64
     // lanes -- only one), so that consecutive workgroups, which go to consecutive XCDs, all carry the same work.
-    int bx = 0, by = blockIdx.x;
+    int bx = 0, by = tileIdx;
     for (;; ++bx) {
         const int cnt = a.ringBy - bx * (16 / R);
         if (by < cnt) break;
@@ -824,8 +937,8 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
     const int nI = max(min(R, N - I0), 1);
     const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
     T* Sout = static_cast<T*>(a.Sout) + (long long)b * a.sigmaStride;
-    const T* colRec = static_cast<const T*>(a.colRec) + (long long)b * kBurstMax * kColRec * cap + Jc;
-    const T* rowRec = static_cast<const T*>(a.rowRec) + (long long)b * kBurstMax * cap * kBlkRec + (long long)I0 * kBlkRec;
+    const T* colRec = static_cast<const T*>(a.colRec) + (long long)b * kBurstMax * a.colStep + Jc;
+    const T* rowRec = static_cast<const T*>(a.rowRec) + (long long)b * kBurstMax * a.rowStep + (long long)I0 * kBlkRec;
     const BurstStep* steps = a.steps + b * kBurstMax;
     constexpr int kRowVals = R * kBlkRec, kRowTrips = (kRowVals + 63) / 64;
     __shared__ T sCol[2][kBlkRec][64];
@@ -844,24 +957,89 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc) S[i][3 * rr + cc] = src[(long long)rr * ld + cc];
     }
-    if (tid < K) {
-        sTtP[tid] = (T)steps[tid].TtP;
-        sRicc[tid] = steps[tid].riccati;
+    // fused launch: how many steps ALL builders of the filter are known to have in memory.  A FIFTH wavefront does the polling (one lane
+    // per builder flag; the flags of a filter are contiguous: a poll is a line or two) and tells the others through LDS: vector loads
+    // return in order, so a wave that polled with its own loads would wait for its prefetches -- two steps of latency -- at every poll.
+    // The poller passes the same barriers as the four arithmetic waves (s_barrier counts every live wave of the workgroup).
+    const int ebase = a.epoch * 32;
+    const int* const flags = FUSE ? a.buildFlags + ((long long)b * kFlagReplicas + tileIdx % kFlagReplicas) * a.nBuildCap : nullptr;
+    __shared__ int sHave;
+    if (FUSE) {
+        if (tid == 0) ldsFlagStore(&sHave, 0);
+        ldsBarrier();
     }
+    int have = 0;
+    auto pollAvail = [&](int st) __attribute__((always_inline)) {  // (the poller wave)
+        const int need = min(st, K - 1) + 1;
+        if (have >= need) return;
+        const long long t0 = wall_clock64();
+        int polls = 0;
+        for (;;) {
+            int v = 1 << 20;
+            for (int w = lane; w < a.nBuild; w += 64) v = min(v, __hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ebase);
+            if (__ballot(v < need) == 0) break;  // (a flag of an earlier burst reads negative)
+            __builtin_amdgcn_s_sleep(12);  // ~0.3 us: a tick of the builders takes 1.4
+            if ((++polls & 63) == 0 && wall_clock64() - t0 > 50000000LL) {  // 0.5 s: never hang the GPU
+                if (lane == 0 && a.errflag) atomicOr(a.errflag, kHoErrTimeout);
+                break;
+            }
+        }
+        if (lane == 0) ldsFlagStore(&sHave, need);
+        have = need;
+    };
+    if (FUSE && wv == 4) {
+        pollAvail(0);
+        pollAvail(1);
+        pollAvail(2);
+        ldsBarrier();  // (the arithmetic waves' prologue barrier)
+        for (int st = 0; st < K; ++st) {
+            pollAvail(st + 3);
+            ldsBarrier();
+        }
+        __syncthreads();  // (the two barriers of the mirror-image pass)
+        __syncthreads();
+        return;
+    }
+    auto waitAvail = [&](int st) __attribute__((always_inline)) {
+        if constexpr (FUSE) {
+            const int need = min(st, K - 1) + 1;
+            if (have >= need) return;
+            while (ldsFlagLoad(&sHave) < need) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            have = need;
+        }
+    };
+    auto readSteps = [&]() __attribute__((always_inline)) {
+        if (tid < K) {
+            if (FUSE) {  // (builder 0's: write-through stores, in memory before its first publication)
+                const double* sp = reinterpret_cast<const double*>(steps + tid);
+                sRicc[tid] = __double2loint(hoLoad8(sp));
+                sTtP[tid] = (T)hoLoad8(sp + 1);
+            } else {
+                sTtP[tid] = (T)steps[tid].TtP;
+                sRicc[tid] = steps[tid].riccati;
+            }
+        }
+    };
+    if (!FUSE) readSteps();
     // this wave's share of a step's column constants: ring rows q = wv + 4 j  (source row q, or q + 18 for Sw / Sv), and the
     // row constants of its own R landmarks
     T xA[kRingTrips + kRowTrips], xB[kRingTrips + kRowTrips];
     auto fetch = [&](int st, T* x) __attribute__((always_inline)) {
         const int sc = min(st, K - 1);  // (past the end: re-read the last step, nobody uses it)
-        const T* cp = colRec + (long long)sc * kColRec * cap;
+        const T* cp = colRec + (long long)sc * a.colStep;
+        // (fused launch: plain loads too -- through the L2, which fetches a line once per XCD; 104 workgroups reading the same 100 KB per
+        // step with agent-scope loads, every one of them served by the memory side, took 10 us per step.  No stale line can be hit: the
+        // launch starts with the L2s invalidated, and a line of step s is only touched once ALL builders have step s in memory.)
+        auto ld1 = [&](const T* q) __attribute__((always_inline)) { return *q; };
 #pragma unroll
         for (int j = 0; j < kRingTrips; ++j) {
             const int q = min(wv + 4 * j, kBlkRec - 1);
-            x[j] = cp[(long long)(q < 27 ? q : q + 18) * cap];
+            x[j] = ld1(cp + (long long)(q < 27 ? q : q + 18) * cap);
         }
-        const T* rp = rowRec + (long long)sc * cap * kBlkRec;
+        const T* rp = rowRec + (long long)sc * a.rowStep;
 #pragma unroll
-        for (int u = 0; u < kRowTrips; ++u) x[kRingTrips + u] = rp[min(lane + 64 * u, nI * kBlkRec - 1)];
+        for (int u = 0; u < kRowTrips; ++u) x[kRingTrips + u] = ld1(rp + min(lane + 64 * u, nI * kBlkRec - 1));
     };
     auto pass = [&](int st, const T* x) __attribute__((always_inline)) {
         const int sl = st & 1;
@@ -883,9 +1061,9 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
     typedef const T __attribute__((address_space(4))) CT;
     const int I0u = __builtin_amdgcn_readfirstlane(I0);
     const int nIu = __builtin_amdgcn_readfirstlane(nI);
-    CT* const rowC = (CT*)(unsigned long long)(static_cast<const T*>(a.rowRec) + (long long)b * kBurstMax * cap * kBlkRec + (long long)I0u * kBlkRec);
+    CT* const rowC = (CT*)(unsigned long long)(static_cast<const T*>(a.rowRec) + (long long)b * kBurstMax * a.rowStep + (long long)I0u * kBlkRec);
     auto rowConst = [&](int st, int i) __attribute__((always_inline)) {
-        if constexpr (R > 1) return rowC + ((long long)st * cap + min(i, nIu - 1)) * kBlkRec;
+        if constexpr (R > 1) return rowC + (long long)st * a.rowStep + (long long)min(i, nIu - 1) * kBlkRec;
         else return (const T*)(sRow[wv][st & 1] + i * kBlkRec);  // wave-uniform: LDS broadcast reads
     };
     auto math = [&](int st) __attribute__((always_inline)) {
@@ -972,7 +1150,7 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
       if constexpr (R > 1) {
         static_assert(R == 1 || R % 2 == 0, "5 R chunks in groups of two");
         const int sl = st & 1;
-        CT* const base = rowC + (long long)st * cap * kBlkRec;
+        CT* const base = rowC + (long long)st * a.rowStep;
         auto chunkPtr = [&](int c) __attribute__((always_inline)) {
             const int i = c < 3 * R ? c / 3 : (c - 3 * R) % R;
             const int off = c < 3 * R ? 9 * (c % 3) : (c < 4 * R ? 27 : 36);
@@ -1085,10 +1263,14 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
         }
     } else {
     // prologue: steps 0 and 1 in flight, step 0 handed to the ring, step 2 issued
+    waitAvail(0);
+    if (FUSE) readSteps();
     fetch(0, xA);
+    waitAvail(1);
     fetch(1, xB);
     __builtin_amdgcn_sched_barrier(0);
     pass(0, xA);
+    waitAvail(2);
     fetch(2, xA);
     __builtin_amdgcn_sched_barrier(0);
     EQF_RSTAMP(0);
@@ -1100,6 +1282,7 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
         EQF_RSTAMP(2 + 3 * st);
         pass(st + 1, xB);
         EQF_RSTAMP(3 + 3 * st);
+        waitAvail(st + 3);
         fetch(st + 3, xB);
         __builtin_amdgcn_sched_barrier(0);
         ldsBarrier();
@@ -1109,6 +1292,7 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
         EQF_RSTAMP(2 + 3 * (st + 1));
         pass(st + 2, xA);
         EQF_RSTAMP(3 + 3 * (st + 1));
+        waitAvail(st + 4);
         fetch(st + 4, xA);
         __builtin_amdgcn_sched_barrier(0);
         ldsBarrier();
@@ -1153,6 +1337,22 @@ __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(Burs
             if (Im < N && Im > Jm) Sout[(long long)(kLm0 + 3 * Jm + r % 3) * ld + kLm0 + 3 * Im + c % 3] = stage[r * kPitch + c];
         }
     }
+}
+template <typename T, int R = 1>
+__global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(BurstArgs a) {
+    burstRingBody<T, R, false>(a, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_burst_fused: builder and block workgroups of the latency case (4 landmarks per builder, one row landmark per wave) in ONE
+// launch.  grid = (nBuild + ringTiles(N, 1), B), block = 512; workgroups [0, nBuild) are builders -- dispatched first, and they
+// never wait for anybody, so the launch cannot deadlock whatever is resident -- the others propagate a tile of blocks with their
+// first four wavefronts (the other four leave at once) and trail the builders by about four ticks instead of a whole launch.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_burst_fused(BurstArgs a) {
+    if ((int)blockIdx.x < a.nBuild) burstBuildBody<T, true, 4, false, true>(a, (int)blockIdx.x, (int)blockIdx.y);
+    else if (threadIdx.x < 320) burstRingBody<T, 1, true>(a, (int)blockIdx.x - a.nBuild, (int)blockIdx.y);  // (4 arithmetic waves + the poller)
 }
 
 }  // namespace eqf

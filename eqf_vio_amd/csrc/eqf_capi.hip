@@ -149,6 +149,9 @@ struct eqf_filter {
     int resFoldPrep = 1;           // co-resident grid: the prep work as roles of the SAME launch (EQF_RES_FOLD_PREP = 0: k_update_prep64 launched first)
     int* dPrepFlags = nullptr;     // [B][nPrepCap]
     int nPrepCap = 0;
+    int burstFused = 1;            // latency case: builder and block workgroups of a burst in ONE launch (EQF_BURST_FUSED = 0: two launches)
+    int* dBuildFlags = nullptr;    // [B][nBuildCap]: steps each builder workgroup has published, + 32 * burstEpoch
+    int nBuildCap = 0, burstEpoch = 0;
     bool rolesFold = false;
     int residentPerCU = -1;        // hipOccupancyMaxActiveBlocksPerMultiprocessor of k_chol_resident on this device (lazily queried)
     int eFromSigma = 1;            // split chain: block column 0 of the E-chain read straight from Sigma (EQF_E_FROM_SIGMA=0: copied by prep)
@@ -463,6 +466,8 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     a.colRec = f->dColRec;
     a.rowRec = f->dRowRec;
     a.steps = f->dSteps;
+    a.colStep = burstRecStep((long long)kColRec * f->cap);
+    a.rowStep = burstRecStep((long long)kBlkRec * f->cap);
     a.prm = f->prm;
     const int nmx = maxN(f);
     // builder: 4 landmarks per workgroup (its eight stages on eight wavefronts, shortest tick) while that launch fits the chip,
@@ -484,7 +489,25 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     const dim3 rgrid(ringTiles(nmx, R, &a.ringBy), f->B);  // (the tiles on and below the diagonal)
     // every filter past its lazy initialisation (VIOFilter.cpp:122-124): the schedule with the precomputed step halves
     const bool fast = allDevInit(f);
+    // the latency case in ONE launch: the block workgroups consume a step's records as soon as the builders have them in memory
+    // (k_burst_fused).  Only while every workgroup of the launch has a CU of its own; fp64.
+    const bool fused = f->burstFused && fast && lm == 4 && R == 1 && nmx > 0 && f->precision != EQF_PRECISION_F32 && f->dBuildFlags &&
+                       (long long)(bgrid.x + rgrid.x) * f->B <= cus && (int)bgrid.x <= f->nBuildCap - 1088;
+    if (fused) {
+        if (f->burstEpoch >= (1 << 25)) {  // (flags are epoch * 32 + steps: start over long before the int wraps)
+            HIPC(hipMemsetAsync(f->dBuildFlags, 0, sizeof(int) * f->nBuildCap * kFlagReplicas * f->B, f->stream));
+            f->burstEpoch = 0;
+        }
+        a.buildFlags = f->dBuildFlags;
+        a.epoch = ++f->burstEpoch;
+        a.nBuild = (int)bgrid.x;
+        a.nBuildCap = f->nBuildCap;
+    }
     const int rc = profiled(f, EQF_PROF_BURST, [&] {
+        if (fused) {
+            hipLaunchKernelGGL((k_burst_fused<double>), dim3(bgrid.x + rgrid.x, f->B), dim3(kBuildThreads), 0, f->stream, a);
+            return;
+        }
         auto go = [&](auto zero) {
             typedef decltype(zero) TT;
             if (fast && lm == 4) hipLaunchKernelGGL((k_burst_build<TT, true, 4>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
@@ -1167,7 +1190,7 @@ void freeAll(eqf_filter* f) {
     for (void* p : {(void*)f->p0, (void*)f->lmc, (void*)f->SA, (void*)f->SL, (void*)f->YW, (void*)f->YO, (void*)f->EA, (void*)f->EL, (void*)f->ZW,
              (void*)f->ZO, (void*)f->dbgDelta, (void*)f->dbgGamma, (void*)f->dbgGammaTot, (void*)f->red, (void*)f->errflag, (void*)f->dMap,
              (void*)f->dNewN, (void*)f->dPerm, (void*)f->dSrc, (void*)f->dChord, (void*)f->dDepth2, (void*)f->dDepthSel, (void*)f->dScratch, (void*)f->dMeas,
-             (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn, f->dBlk, (void*)f->dBlkCommon, f->dColRec, f->dRowRec, (void*)f->dSteps, (void*)f->dFlags, (void*)f->dReadyA, (void*)f->dReadyY, (void*)f->dResCounters, (void*)f->dStageFlags, (void*)f->dPrepFlags, (void*)f->dGammaPart,
+             (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn, f->dBlk, (void*)f->dBlkCommon, f->dColRec, f->dRowRec, (void*)f->dSteps, (void*)f->dFlags, (void*)f->dReadyA, (void*)f->dReadyY, (void*)f->dResCounters, (void*)f->dStageFlags, (void*)f->dPrepFlags, (void*)f->dBuildFlags, (void*)f->dGammaPart,
              (void*)f->dG11Part, (void*)f->dRoles})
         hipFree(p);
     if (f->hGate) hipHostFree(f->hGate);
@@ -1340,9 +1363,12 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     chk(dmalloc(&f->dRing, (size_t)kRing * B));
     if (!rc && hipMalloc(&f->dBlk, f->esz * (size_t)kBlkRec * cap * B) != hipSuccess) rc = EQF_ERR_HIP;
     chk(dmalloc(&f->dBlkCommon, B));
-    if (!rc && hipMalloc(&f->dColRec, f->esz * (size_t)kBurstMax * kColRec * cap * B) != hipSuccess) rc = EQF_ERR_HIP;
-    if (!rc && hipMalloc(&f->dRowRec, f->esz * (size_t)kBurstMax * kBlkRec * cap * B) != hipSuccess) rc = EQF_ERR_HIP;
+    if (!rc && hipMalloc(&f->dColRec, f->esz * (size_t)kBurstMax * burstRecStep((long long)kColRec * cap) * B) != hipSuccess) rc = EQF_ERR_HIP;
+    if (!rc && hipMalloc(&f->dRowRec, f->esz * (size_t)kBurstMax * burstRecStep((long long)kBlkRec * cap) * B) != hipSuccess) rc = EQF_ERR_HIP;
     chk(dmalloc(&f->dSteps, (size_t)kBurstMax * B));
+    f->nBuildCap = ((cap + 3) / 4 + 63) / 64 * 64 + 1088;  // stride of a replica: > 4 KB, not a multiple of it
+    chk(dmalloc(&f->dBuildFlags, (size_t)f->nBuildCap * kFlagReplicas * B));
+    if (!rc && hipMemset(f->dBuildFlags, 0, sizeof(int) * f->nBuildCap * kFlagReplicas * B) != hipSuccess) rc = EQF_ERR_HIP;
     if (const char* e = std::getenv("EQF_BURST_ROWS")) f->burstRows = (std::atoi(e) == 1 || std::atoi(e) == 2 || std::atoi(e) == 4) ? std::atoi(e) : 0;
     if (const char* e = std::getenv("EQF_BURST_LM")) f->burstLm = std::atoi(e) == 16 ? 16 : (std::atoi(e) == 4 ? 4 : 0);
     if (const char* e = std::getenv("EQF_IMU_BURST")) f->burstMax = std::max(0, std::min(kBurstMax, std::atoi(e)));
@@ -1354,6 +1380,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (const char* e = std::getenv("EQF_CHOL_RESIDENT")) f->cholResident = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_STAGED")) f->resStaged = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_FOLD_PREP")) f->resFoldPrep = std::atoi(e);
+    if (const char* e = std::getenv("EQF_BURST_FUSED")) f->burstFused = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_OVERSUB")) f->resOversub = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("EQF_E_FROM_SIGMA")) f->eFromSigma = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_OCC2")) f->resOcc2 = std::atoi(e);

@@ -967,3 +967,41 @@ def test_prep_roles_inside_the_update_launch_equal_the_prep_launch(hip, monkeypa
     for f, (a, b) in enumerate(zip(*outs)):
         for u, v in zip(a, b):
             assert np.array_equal(u, v), (N, f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [3, 21, 70, 130, 200])
+def test_builder_and_block_workgroups_in_one_launch_equal_the_two_launches(hip, monkeypatch, N):
+    """Round 4: in the latency case (one small filter: 4 landmarks per builder workgroup, one row landmark per wave of the block kernel)
+    a burst of IMU steps is ONE launch, k_burst_fused: the block workgroups consume a step's records as soon as the builder workgroups of
+    the same launch have them in memory (write-through stores by one wave, per-builder step counters, agent-scope loads) instead of after
+    the builder LAUNCH (EQF_BURST_FUSED=0).  Same operations on the same values: bit for bit after every call, with bursts cut at
+    different lengths (the stream API flushes at 15 queued calls and at every vision call; getters in between cut shorter ones)."""
+    from eqf_vio_amd import synth
+
+    st = synth.make_stream(N, seed=123, duration=0.5 if N >= 130 else 0.8)
+    d = synth.template_settings_dict()
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("EQF_BURST_FUSED", fused)
+        fg = hip.FilterBatch(d, capacity=N, batch=1)
+        seq = []
+        n_imu = 0
+        for kind, k in st.events():
+            if kind == "imu":
+                r = st.imu[k]
+                fg.process_imu([r[0]], r[1:4], r[4:7])
+                n_imu += 1
+                if n_imu % 7 == 0:  # a getter cuts the queue: bursts of 1 .. 7 steps besides the 10-step ones
+                    seq.append((fg.sigma().copy(),))
+            else:
+                fg.process_vision([st.vision_stamps[k]], st.ids, st.bearings[k])
+                e = fg.state_estimate()
+                seq.append((fg.sigma().copy(), e["x"].copy(), e["q"].copy(), e["p"].copy(), fg.bias().copy()))
+        assert fg.device_error() == 0
+        outs.append(seq)
+    monkeypatch.delenv("EQF_BURST_FUSED")
+    assert len(outs[0]) == len(outs[1]) > 8
+    for f, (a, b) in enumerate(zip(*outs)):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v), (N, f)
