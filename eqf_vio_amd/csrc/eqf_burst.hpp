@@ -31,6 +31,9 @@ constexpr int kColRec = 63;
 // workgroup polls replica (tile index mod kFlagReplicas): a hundred pollers on ONE line saturate its memory channel, and the builders'
 // write-through stores queue up behind them (measured: ticks of 3 us instead of 1.4).
 constexpr int kFlagReplicas = 8;
+#ifndef EQF_BURST_PUBLISH_LAG
+#define EQF_BURST_PUBLISH_LAG 1  // ticks between a step's write-through stores and its publication (2: behind a counted wait, vmcnt(7); 1: a full drain that stalls 0.2 - 0.5 us of a 1.4 us tick -- and the block workgroups finish 1.4 us earlier: 35.4 -> 34.0 us per burst)
+#endif
 inline long long burstRecStep(long long elems) { return (elems + 31) / 32 * 32; }
 constexpr int kBuildThreads = 512;  // 8 wavefronts, see k_burst_build (a ninth would cap every wave at 168 VGPRs: spills)
 
@@ -683,9 +686,10 @@ EQF_DI void burstBuildBody(const BurstArgs& a, const int bxIdx, const int b) {
             EQF_BSTAMP(0);
             if (FUSE) {
                 const int u = t - 3;
-                if (u >= 2) {
-                    olderStoresDone();
-                    if (lane < kFlagReplicas) hoPublish(myFlag, ebase + u - 1);  // steps 0 .. u-2
+                if (EQF_BURST_PUBLISH_LAG == 2 ? u >= 2 : u >= 1) {
+                    if (EQF_BURST_PUBLISH_LAG == 2) olderStoresDone();
+                    else hoDrain();
+                    if (lane < kFlagReplicas) hoPublish(myFlag, ebase + u - (EQF_BURST_PUBLISH_LAG - 1));  // steps 0 .. u-2 (lag 2) / u-1 (lag 1)
                 }
                 EQF_BSTAMP(2);
                 if (u >= 0) prevStores = storeRecords(u);
@@ -700,9 +704,13 @@ EQF_DI void burstBuildBody(const BurstArgs& a, const int bxIdx, const int b) {
             ldsBarrier();
         }
         if (FUSE) {  // the last steps: K-2 went out in the last tick, K-1 is complete in LDS now
-            if (K >= 3) {
+            if (EQF_BURST_PUBLISH_LAG == 2 && K >= 3) {
                 olderStoresDone();
                 if (lane < kFlagReplicas) hoPublish(myFlag, ebase + K - 2);
+            }
+            if (EQF_BURST_PUBLISH_LAG == 1 && K >= 2) {
+                hoDrain();
+                if (lane < kFlagReplicas) hoPublish(myFlag, ebase + K - 1);
             }
             storeRecords(K - 1);
             hoDrain();
@@ -911,12 +919,8 @@ constexpr int kRingTrips = 12;  // column-constant rows per wave and step: 45 ro
 // of the ring is that the 45 x 64 column constants of a step are fetched ONCE per workgroup (16 row landmarks) instead of once per
 // wavefront, and that a lane holds 13 + 3 prefetched values per register set instead of 46: 2 wavefronts per SIMD instead of 1.
 // grid = (ringTiles(N, R), B).
-// FUSE (R = 1, T = double; k_burst_fused): the records are being written by the builder workgroups of the same launch.  Before a
-// wave requests step s it waits for the 16 builders of its column landmarks and the builder of its row landmarks to have published
-// s + 1 steps (lanes 0 .. 16 poll one flag each), and it reads the records with agent-scope loads (never from a stale L2 line).
-template <typename T, int R, bool FUSE>
+template <typename T, int R>
 EQF_DI void burstRingBody(const BurstArgs& a, const int tileIdx, const int b) {
-    static_assert(!FUSE || (R == 1 && sizeof(T) == 8), "the fused launch exists for the latency case only");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int N = a.gin[b].N, K = a.K, cap = a.cap, ld = a.ld;
     // Only the blocks on and below the diagonal (row landmark >= column landmark) are propagated; the others are their transposes and
@@ -957,89 +961,24 @@ EQF_DI void burstRingBody(const BurstArgs& a, const int tileIdx, const int b) {
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc) S[i][3 * rr + cc] = src[(long long)rr * ld + cc];
     }
-    // fused launch: how many steps ALL builders of the filter are known to have in memory.  A FIFTH wavefront does the polling (one lane
-    // per builder flag; the flags of a filter are contiguous: a poll is a line or two) and tells the others through LDS: vector loads
-    // return in order, so a wave that polled with its own loads would wait for its prefetches -- two steps of latency -- at every poll.
-    // The poller passes the same barriers as the four arithmetic waves (s_barrier counts every live wave of the workgroup).
-    const int ebase = a.epoch * 32;
-    const int* const flags = FUSE ? a.buildFlags + ((long long)b * kFlagReplicas + tileIdx % kFlagReplicas) * a.nBuildCap : nullptr;
-    __shared__ int sHave;
-    if (FUSE) {
-        if (tid == 0) ldsFlagStore(&sHave, 0);
-        ldsBarrier();
+    if (tid < K) {
+        sTtP[tid] = (T)steps[tid].TtP;
+        sRicc[tid] = steps[tid].riccati;
     }
-    int have = 0;
-    auto pollAvail = [&](int st) __attribute__((always_inline)) {  // (the poller wave)
-        const int need = min(st, K - 1) + 1;
-        if (have >= need) return;
-        const long long t0 = wall_clock64();
-        int polls = 0;
-        for (;;) {
-            int v = 1 << 20;
-            for (int w = lane; w < a.nBuild; w += 64) v = min(v, __hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ebase);
-            if (__ballot(v < need) == 0) break;  // (a flag of an earlier burst reads negative)
-            __builtin_amdgcn_s_sleep(12);  // ~0.3 us: a tick of the builders takes 1.4
-            if ((++polls & 63) == 0 && wall_clock64() - t0 > 50000000LL) {  // 0.5 s: never hang the GPU
-                if (lane == 0 && a.errflag) atomicOr(a.errflag, kHoErrTimeout);
-                break;
-            }
-        }
-        if (lane == 0) ldsFlagStore(&sHave, need);
-        have = need;
-    };
-    if (FUSE && wv == 4) {
-        pollAvail(0);
-        pollAvail(1);
-        pollAvail(2);
-        ldsBarrier();  // (the arithmetic waves' prologue barrier)
-        for (int st = 0; st < K; ++st) {
-            pollAvail(st + 3);
-            ldsBarrier();
-        }
-        __syncthreads();  // (the two barriers of the mirror-image pass)
-        __syncthreads();
-        return;
-    }
-    auto waitAvail = [&](int st) __attribute__((always_inline)) {
-        if constexpr (FUSE) {
-            const int need = min(st, K - 1) + 1;
-            if (have >= need) return;
-            while (ldsFlagLoad(&sHave) < need) __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
-            have = need;
-        }
-    };
-    auto readSteps = [&]() __attribute__((always_inline)) {
-        if (tid < K) {
-            if (FUSE) {  // (builder 0's: write-through stores, in memory before its first publication)
-                const double* sp = reinterpret_cast<const double*>(steps + tid);
-                sRicc[tid] = __double2loint(hoLoad8(sp));
-                sTtP[tid] = (T)hoLoad8(sp + 1);
-            } else {
-                sTtP[tid] = (T)steps[tid].TtP;
-                sRicc[tid] = steps[tid].riccati;
-            }
-        }
-    };
-    if (!FUSE) readSteps();
     // this wave's share of a step's column constants: ring rows q = wv + 4 j  (source row q, or q + 18 for Sw / Sv), and the
     // row constants of its own R landmarks
     T xA[kRingTrips + kRowTrips], xB[kRingTrips + kRowTrips];
     auto fetch = [&](int st, T* x) __attribute__((always_inline)) {
         const int sc = min(st, K - 1);  // (past the end: re-read the last step, nobody uses it)
         const T* cp = colRec + (long long)sc * a.colStep;
-        // (fused launch: plain loads too -- through the L2, which fetches a line once per XCD; 104 workgroups reading the same 100 KB per
-        // step with agent-scope loads, every one of them served by the memory side, took 10 us per step.  No stale line can be hit: the
-        // launch starts with the L2s invalidated, and a line of step s is only touched once ALL builders have step s in memory.)
-        auto ld1 = [&](const T* q) __attribute__((always_inline)) { return *q; };
 #pragma unroll
         for (int j = 0; j < kRingTrips; ++j) {
             const int q = min(wv + 4 * j, kBlkRec - 1);
-            x[j] = ld1(cp + (long long)(q < 27 ? q : q + 18) * cap);
+            x[j] = cp[(long long)(q < 27 ? q : q + 18) * cap];
         }
         const T* rp = rowRec + (long long)sc * a.rowStep;
 #pragma unroll
-        for (int u = 0; u < kRowTrips; ++u) x[kRingTrips + u] = ld1(rp + min(lane + 64 * u, nI * kBlkRec - 1));
+        for (int u = 0; u < kRowTrips; ++u) x[kRingTrips + u] = rp[min(lane + 64 * u, nI * kBlkRec - 1)];
     };
     auto pass = [&](int st, const T* x) __attribute__((always_inline)) {
         const int sl = st & 1;
@@ -1263,14 +1202,10 @@ EQF_DI void burstRingBody(const BurstArgs& a, const int tileIdx, const int b) {
         }
     } else {
     // prologue: steps 0 and 1 in flight, step 0 handed to the ring, step 2 issued
-    waitAvail(0);
-    if (FUSE) readSteps();
     fetch(0, xA);
-    waitAvail(1);
     fetch(1, xB);
     __builtin_amdgcn_sched_barrier(0);
     pass(0, xA);
-    waitAvail(2);
     fetch(2, xA);
     __builtin_amdgcn_sched_barrier(0);
     EQF_RSTAMP(0);
@@ -1282,7 +1217,6 @@ EQF_DI void burstRingBody(const BurstArgs& a, const int tileIdx, const int b) {
         EQF_RSTAMP(2 + 3 * st);
         pass(st + 1, xB);
         EQF_RSTAMP(3 + 3 * st);
-        waitAvail(st + 3);
         fetch(st + 3, xB);
         __builtin_amdgcn_sched_barrier(0);
         ldsBarrier();
@@ -1292,7 +1226,6 @@ EQF_DI void burstRingBody(const BurstArgs& a, const int tileIdx, const int b) {
         EQF_RSTAMP(2 + 3 * (st + 1));
         pass(st + 2, xA);
         EQF_RSTAMP(3 + 3 * (st + 1));
-        waitAvail(st + 4);
         fetch(st + 4, xA);
         __builtin_amdgcn_sched_barrier(0);
         ldsBarrier();
@@ -1340,19 +1273,252 @@ EQF_DI void burstRingBody(const BurstArgs& a, const int tileIdx, const int b) {
 }
 template <typename T, int R = 1>
 __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(BurstArgs a) {
-    burstRingBody<T, R, false>(a, (int)blockIdx.x, (int)blockIdx.y);
+    burstRingBody<T, R>(a, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_burst_fused: builder and block workgroups of the latency case (4 landmarks per builder, one row landmark per wave) in ONE
-// launch.  grid = (nBuild + ringTiles(N, 1), B), block = 512; workgroups [0, nBuild) are builders -- dispatched first, and they
-// never wait for anybody, so the launch cannot deadlock whatever is resident -- the others propagate a tile of blocks with their
-// first four wavefronts (the other four leave at once) and trail the builders by about four ticks instead of a whole launch.
+// k_burst_fused: builder and block workgroups of the latency case (4 landmarks per builder, one row landmark per arithmetic wave) in
+// ONE launch.  grid = (nBuild + ringTiles(N, 1), B), block = 512; workgroups [0, nBuild) are builders -- dispatched first, and they
+// never wait for anybody, so the launch cannot deadlock whatever is resident -- the others propagate a tile of 4 x 64 blocks and trail
+// the builders by the publication lag (five ticks) plus one fetch instead of by a whole launch.
+//
+// A block workgroup has seven live wavefronts and no workgroup barrier in its step loop:
+//   waves 0..3  arithmetic, one row landmark each (the step of k_burst_riccati_ring<T, 1>, operation for operation: same bits);
+//   wave 4      the poller: one lane per builder flag (the flags of a replica are contiguous: a poll is a line or two), publishes in LDS
+//               how many steps ALL builders of the filter have in memory.  A wave that polled with its own loads would wait for its
+//               prefetches at every poll (vector loads return in order);
+//   waves 5, 6  the fetchers (even / odd steps): the step's 45 x 64 column constants and 4 x 45 row constants into one of three LDS slots,
+//               as soon as the poller says the step is there -- independent of where the arithmetic is.  Plain loads, through the L2 (which
+//               fetches a line once per XCD: with agent-scope loads every workgroup's every load was served by the memory side, 10 us per
+//               step).  No stale line can be hit: the launch starts with the L2s invalidated, a line of step s is only touched once ALL
+//               builders have step s in memory, and no line holds entries of two steps (BurstArgs::colStep / rowStep).
+// Hand-over inside the workgroup is by LDS counters (ldsFlagLoad / ldsFlagStore): sHave (poller -> fetchers), sReady[f] (fetcher f ->
+// arithmetic: its steps delivered), sDone[w] (arithmetic wave w -> fetchers: a slot is rewritten three steps later).
 // ------------------------------------------------------------------------------------------------
+template <typename T>
+EQF_DI void burstRingFusedBody(const BurstArgs& a, const int tileIdx, const int b) {
+    static_assert(sizeof(T) == 8, "the fused launch exists for fp64");
+    constexpr int kSlots = 3;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int N = a.gin[b].N, K = a.K, cap = a.cap, ld = a.ld;
+    int bx = 0, by = tileIdx;  // (the tiles on and below the diagonal, as in burstRingBody with R = 1)
+    for (;; ++bx) {
+        const int cnt = a.ringBy - bx * 16;
+        if (by < cnt) break;
+        by -= cnt;
+    }
+    by += bx * 16;
+    const int J = bx * 64 + lane;
+    const bool validJ = J < N;
+    const int Jc = validJ ? J : 0;
+    __shared__ T sCol[kSlots][kBlkRec][64];
+    __shared__ T sRow[kSlots][4][kBlkRec + 3];
+    __shared__ T sTtP[kBurstMax];
+    __shared__ int sRicc[kBurstMax];
+    __shared__ int sHave, sReady[2], sDone[4];
+    if (tid < 7) ldsFlagStore(tid == 0 ? &sHave : (tid < 3 ? &sReady[tid - 1] : &sDone[tid - 3]), 0);
+    ldsBarrier();  // (the only barrier before the mirror-image pass: every live wave, i.e. 0 .. 6)
+    const T* const colRec = static_cast<const T*>(a.colRec) + (long long)b * kBurstMax * a.colStep + Jc;
+    const T* const rowRec = static_cast<const T*>(a.rowRec) + (long long)b * kBurstMax * a.rowStep;
+
+    if (wv == 4) {
+        // ---- poller
+        const int ebase = a.epoch * 32;
+        const int* const flags = a.buildFlags + ((long long)b * kFlagReplicas + tileIdx % kFlagReplicas) * a.nBuildCap;
+        const long long t0 = wall_clock64();
+        int have = 0, polls = 0;
+        while (have < K) {
+            int v = 1 << 20;
+            for (int w = lane; w < a.nBuild; w += 64) v = min(v, __hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ebase);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));  // (a flag of an earlier burst reads negative)
+            if (v > have) {
+                have = min(v, K);
+                if (lane == 0) ldsFlagStore(&sHave, have);
+                continue;
+            }
+            __builtin_amdgcn_s_sleep(12);  // ~0.3 us: a tick of the builders takes 1.4
+            if ((++polls & 63) == 0 && wall_clock64() - t0 > 50000000LL) {  // 0.5 s: never hang the GPU
+                if (lane == 0) {
+                    if (a.errflag) atomicOr(a.errflag, kHoErrTimeout);
+                    ldsFlagStore(&sHave, K);
+                }
+                break;
+            }
+        }
+        return;
+    }
+    if (wv == 5 || wv == 6) {
+        // ---- fetchers
+        const int f = wv - 5;
+        if (f == 0) {  // the step table is builder 0's (write-through stores, in memory before its first publication)
+            while (ldsFlagLoad(&sHave) < 1) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            if (lane < K) {
+                const double* sp = reinterpret_cast<const double*>(a.steps + b * kBurstMax + lane);
+                sRicc[lane] = __double2loint(hoLoad8(sp));
+                sTtP[lane] = (T)hoLoad8(sp + 1);
+            }
+        }
+        // where this lane's three row-constant values of a step come from: the tile's four row landmarks (clamped: rows past N are
+        // computed on a copy of the last row and never stored)
+        long long rowOff[3];
+        int rowDst[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int e = min(lane + 64 * u, 4 * kBlkRec - 1), r = e / kBlkRec, k = e - r * kBlkRec;
+            rowOff[u] = (long long)min(by * 4 + r, max(N - 1, 0)) * kBlkRec + k;
+            rowDst[u] = r * (kBlkRec + 3) + k;
+        }
+        for (int st = f; st < K; st += 2) {
+            while (ldsFlagLoad(&sHave) < st + 1) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            T x[kBlkRec + 3];
+            const T* cp = colRec + (long long)st * a.colStep;
+#pragma unroll
+            for (int q = 0; q < kBlkRec; ++q) x[q] = cp[(long long)(q < 27 ? q : q + 18) * cap];
+            const T* rp = rowRec + (long long)st * a.rowStep;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) x[kBlkRec + u] = rp[rowOff[u]];
+            if (st >= kSlots) {  // the slot was read by step st - 3: every arithmetic wave must be past it
+                const int need = st - kSlots + 1;
+                while (__ballot(lane < 4 && ldsFlagLoad(&sDone[lane & 3]) < need) != 0) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+            }
+            const int sl = st % kSlots;
+#pragma unroll
+            for (int q = 0; q < kBlkRec; ++q) sCol[sl][q][lane] = x[q];
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (lane + 64 * u < 4 * kBlkRec) (&sRow[sl][0][0])[rowDst[u]] = x[kBlkRec + u];
+            waveSync();
+            if (lane == 0) ldsFlagStore(&sReady[f], st + 1);
+        }
+        return;
+    }
+
+    // ---- arithmetic waves
+    const int I0raw = by * 4 + wv;
+    const int I0 = min(I0raw, max(N - 1, 0));
+    const T* Sin = static_cast<const T*>(a.Sin) + (long long)b * a.sigmaStride;
+    T* Sout = static_cast<T*>(a.Sout) + (long long)b * a.sigmaStride;
+    EQF_RSTAMP(63);
+    T S[9];
+    {
+        const T* src = Sin + (long long)(kLm0 + 3 * I0) * ld + kLm0 + 3 * Jc;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) S[3 * rr + cc] = src[(long long)rr * ld + cc];
+    }
+    const bool diag = I0raw == J;
+    for (int st = 0; st < K; ++st) {
+        while (ldsFlagLoad(&sReady[st & 1]) < st + 1) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        EQF_RSTAMP(2 + 3 * st);
+        if (sRicc[st]) {
+            // the step of k_burst_riccati_ring<T, 1>: H = D S + Lw Sw + Lv Sv in place of S, then S' = H D_J^T (+ the process noise on
+            // the diagonal) + Gn Lw_J^T + Gv Lv_J^T -- the same operations in the same order
+            const int sl = st % kSlots;
+            const T* rc = sRow[sl][wv];  // wave-uniform: LDS broadcast reads
+            {
+                T Sw[9], Sv[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    Sw[k] = sCol[sl][27 + k][lane];
+                    Sv[k] = sCol[sl][36 + k][lane];
+                }
+                T H[9];
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        T acc = rc[3 * rr] * S[cc];
+#pragma unroll
+                        for (int k = 1; k < 3; ++k) acc = fma(rc[3 * rr + k], S[3 * k + cc], acc);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) acc = fma(rc[9 + 3 * rr + k], Sw[3 * k + cc], acc);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) acc = fma(rc[18 + 3 * rr + k], Sv[3 * k + cc], acc);
+                        H[3 * rr + cc] = acc;
+                    }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) S[k] = H[k];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const T TtP = sTtP[st];
+            {
+                T c[9];  // D_J^T
+#pragma unroll
+                for (int k = 0; k < 9; ++k) c[k] = sCol[sl][k][lane];
+                T O[9];
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        T acc = (diag && rr == cc) ? TtP : (T)0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) acc = fma(S[3 * rr + k], c[3 * cc + k], acc);
+                        O[3 * rr + cc] = acc;
+                    }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) S[k] = O[k];
+            }
+#pragma unroll
+            for (int grp = 1; grp < 3; ++grp) {  // + Gn Lw_J^T, then + Gv Lv_J^T
+                __builtin_amdgcn_sched_barrier(0);
+                T c[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) c[k] = sCol[sl][9 * grp + k][lane];
+                const T* rg = rc + 18 + 9 * grp;
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        T acc = S[3 * rr + cc];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) acc = fma(rg[3 * rr + k], c[3 * cc + k], acc);
+                        S[3 * rr + cc] = acc;
+                    }
+            }
+        }
+        EQF_RSTAMP(3 + 3 * st);
+        waveSync();  // (every LDS read of the step has returned)
+        if (lane == 0) ldsFlagStore(&sDone[wv], st + 1);
+        EQF_RSTAMP(4 + 3 * st);
+    }
+    if (validJ && I0raw < N && I0raw >= J) {
+        T* dst = Sout + (long long)(kLm0 + 3 * I0raw) * ld + kLm0 + 3 * J;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) dst[(long long)rr * ld + cc] = S[3 * rr + cc];
+    }
+    // Sigma_JI = Sigma_IJ^T for the blocks strictly below the diagonal, transposed through LDS (burstRingBody).  The poller and the fetchers
+    // have left by now or leave without passing another barrier: s_barrier counts the live waves.
+    constexpr int kWd = 12, kPitch = kWd + 1, kRowsPass = 3 * 64;
+    static_assert(kRowsPass * kPitch <= kSlots * kBlkRec * 64, "the staging tile lives in sCol");
+    T* const stage = &sCol[0][0][0];
+    __syncthreads();
+    {
+        T* dst = stage + 3 * lane * kPitch + 3 * wv;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) dst[cc * kPitch + rr] = S[3 * rr + cc];
+    }
+    __syncthreads();
+    for (int e = tid; e < kRowsPass * kWd; e += 256) {
+        const int r = e / kWd, c = e % kWd;
+        const int Jm = bx * 64 + r / 3, Im = by * 4 + c / 3;
+        if (Im < N && Im > Jm) Sout[(long long)(kLm0 + 3 * Jm + r % 3) * ld + kLm0 + 3 * Im + c % 3] = stage[r * kPitch + c];
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBuildThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_burst_fused(BurstArgs a) {
     if ((int)blockIdx.x < a.nBuild) burstBuildBody<T, true, 4, false, true>(a, (int)blockIdx.x, (int)blockIdx.y);
-    else if (threadIdx.x < 320) burstRingBody<T, 1, true>(a, (int)blockIdx.x - a.nBuild, (int)blockIdx.y);  // (4 arithmetic waves + the poller)
+    else if (threadIdx.x < 448) burstRingFusedBody<T>(a, (int)blockIdx.x - a.nBuild, (int)blockIdx.y);  // (wave 7 has no role)
 }
 
 }  // namespace eqf

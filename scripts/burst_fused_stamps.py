@@ -27,5 +27,5 @@ r = (C.c_longlong * 256)()
 hip.lib().eqf_debug_ring_stamps(r)
 r = np.array(r[:]).reshape(4, 64).astype(np.float64) / 100.0
 for w in range(4):
-    print("block tile 9 wave %d: starts %.2f, prologue done %.2f, first barrier %.2f;  per step: math done | handed on | barrier passed" % (w, r[w, 63] - t0, r[w, 0] - t0, r[w, 1] - t0))
-    print("    " + "  ".join("%.2f|%.2f|%.2f" % (r[w, 2 + 3 * s] - t0, r[w, 3 + 3 * s] - t0, r[w, 4 + 3 * s] - t0) for s in range(12)))
+    print("block tile 9 wave %d: starts %.2f;  per step: data there | arithmetic done" % (w, r[w, 63] - t0))
+    print("    " + "  ".join("%.2f|%.2f" % (r[w, 2 + 3 * s] - t0, r[w, 3 + 3 * s] - t0) for s in range(12)))

@@ -1,4 +1,5 @@
-"""Per-wave, per-tick cycle stamps of k_burst_build (library built with -DEQF_BURST_STAMPS): where a tick's time goes."""
+"""Per-wave, per-tick stamps of k_burst_build (library built with -DEQF_BURST_STAMPS): where a tick's time goes.  Units: 10 ns (the 100 MHz
+wall clock, the same on every CU; scripts/burst_fused_stamps.py prints the fused launch in microseconds).  Run with EQF_BURST_FUSED=0 for the two launches."""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
