@@ -106,6 +106,14 @@ timeout 900 bash $ROOT/scripts/launch_timeline.sh 64 > "$OUT/${TAG}_timeline_bat
 if [ -f $ROOT/build_variants/libeqf_stamps.so ]; then
   EQF_VIO_AMD_LIB=$ROOT/build_variants/libeqf_stamps.so timeout 300 $PY $ROOT/scripts/res_stamps.py 200 1 > "$OUT/${TAG}_res_stamps_N200.txt" 2>&1
 fi
+# 7b. an IMU burst from the inside: builder workgroup 0 and block workgroup 9 of the fused launch on one clock (instrumented build, if shipped),
+#     and the bench line with the burst as two launches
+if [ -f $ROOT/build_variants/libeqf_bstamps.so ]; then
+  { echo "## k_burst_fused (one launch)"; EQF_VIO_AMD_LIB=$ROOT/build_variants/libeqf_bstamps.so timeout 300 $PY $ROOT/scripts/burst_fused_stamps.py;
+    echo; echo "## EQF_BURST_FUSED=0: k_burst_build, then k_burst_riccati_ring (block workgroup stamps: math done | handed on | barrier passed)";
+    EQF_BURST_FUSED=0 EQF_VIO_AMD_LIB=$ROOT/build_variants/libeqf_bstamps.so timeout 300 $PY $ROOT/scripts/burst_fused_stamps.py; } > "$OUT/${TAG}_burst_stamps_N200.txt" 2>&1
+fi
+EQF_BURST_FUSED=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-batch64 --no-parity --no-traffic --no-tiled --no-churn --no-steady-state > "$OUT/${TAG}_bench_N200_burst_two_launches.json" 2>/dev/null
 # 8. factor64 alone (scripts/micro/factor64_bench.hip, if built): cycles per 64-column block, per-wave stamps
 for b in factor64_bench factor64_bench_ns; do
   [ -x $ROOT/scripts/micro/$b ] && ( $ROOT/scripts/micro/$b 0 1 4; $ROOT/scripts/micro/$b 0 0 4 ) > "$OUT/${TAG}_${b}.txt" 2>&1
