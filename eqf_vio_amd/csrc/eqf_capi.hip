@@ -77,9 +77,10 @@ struct eqf_filter {
     double *dbgDelta = nullptr, *dbgGamma = nullptr, *dbgGammaTot = nullptr, *red = nullptr;
     int* errflag = nullptr;
     // churn scratch
-    int *dMap = nullptr, *dNewN = nullptr, *dPerm = nullptr, *dSrc = nullptr;
+    int *dMap = nullptr, *dNewN = nullptr, *dPerm = nullptr;  // (dNewN = dMap + B * cap)
+    std::vector<std::vector<int>> permOnDevice;  // what dPerm holds (uploadPerm): the same landmark set in the same order needs no new copy
     double *dChord = nullptr, *dDepth2 = nullptr, *dScratch = nullptr, *dMeas = nullptr, *dOut = nullptr;
-    IntStage stMap, stPerm, stSrc;  // pinned rings: [B*cap + B] (map + new counts), [B*cap], [cap]
+    IntStage stMap, stPerm;  // pinned rings: [B*cap + B] (map + new counts), [B*cap]
     double* dDepthSel = nullptr;    // [B] median scene depth selected on the device
     double *hChord = nullptr, *hMeas = nullptr, *hOut = nullptr;
     double* hChordDev = nullptr;  // device-side address of the pinned hChord
@@ -116,6 +117,7 @@ struct eqf_filter {
         std::vector<std::vector<int>> ids;  // measurement ids per filter
         std::vector<int> nb;
         std::vector<char> active;
+        std::vector<int> nOld;              // landmarks per filter before the frame's new ones were appended
         const double* bearings = nullptr;   // device
         long long bearStride = 0;
     } gate;
@@ -123,6 +125,8 @@ struct eqf_filter {
     int* hGateDev = nullptr;     // device-side address of hGate
     int* dMask = nullptr;        // [B]
     hipEvent_t evGate = nullptr;
+    hipEvent_t evMask = nullptr;   // k_set_update_ok has read hGate (resolveGate's redo): recorded before the host may clear it again
+    bool maskPending = false;
     int gateSpeculative = 1;     // EQF_GATE_SPECULATIVE = 0: always wait for the gate's answer before the update
     // IMU bursts (eqf_burst.hpp): processIMUData calls are queued on the host and launched together -- when the queue is
     // full, when the vision call that follows them arrives (whose integrateUpToTime joins the burst), or when the host
@@ -912,20 +916,19 @@ int compact(eqf_filter* f, const std::vector<std::vector<int>>& keep) {
         nmax = std::max(nmax, int(keep[b].size()));
         std::copy(keep[b].begin(), keep[b].end(), h + (size_t)b * cap);
     }
-    HIPC(hipMemcpyAsync(f->dMap, h, sizeof(int) * B * cap, hipMemcpyHostToDevice, f->stream));
-    HIPC(hipMemcpyAsync(f->dNewN, h + (size_t)B * cap, sizeof(int) * B, hipMemcpyHostToDevice, f->stream));
+    HIPC(hipMemcpyAsync(f->dMap, h, sizeof(int) * ((size_t)B * cap + B), hipMemcpyHostToDevice, f->stream));  // (map + new counts: one copy)
     HIPC(hipEventRecord(f->stMap.ev[slot], f->stream));
     const int nvn = kLm0 + 3 * nmax;
     int rc = profiled(f, EQF_PROF_CHURN, [&] {
         const dim3 grid((nvn + 255) / 256, nvn, B);
         if (f->precision == EQF_PRECISION_F32)
-            hipLaunchKernelGGL(k_compact_sigma<float>, grid, dim3(256), 0, f->stream, f->g[f->pG], f->dMap, f->dNewN, cap,
-                static_cast<const float*>(f->Sigma[f->pS]), static_cast<float*>(f->Sigma[f->pS ^ 1]), f->sigmaStride, f->ld);
+            hipLaunchKernelGGL(k_compact<float>, grid, dim3(256), 0, f->stream, f->g[f->pG], f->dMap, f->dNewN, cap,
+                static_cast<const float*>(f->Sigma[f->pS]), static_cast<float*>(f->Sigma[f->pS ^ 1]), f->sigmaStride, f->ld, f->p0, f->Q[f->pG], f->lmc,
+                f->dScratch);
         else
-            hipLaunchKernelGGL(k_compact_sigma<double>, grid, dim3(256), 0, f->stream, f->g[f->pG], f->dMap, f->dNewN, cap,
-                static_cast<const double*>(f->Sigma[f->pS]), static_cast<double*>(f->Sigma[f->pS ^ 1]), f->sigmaStride, f->ld);
-        hipLaunchKernelGGL(k_compact_lm_gather, dim3(B), dim3(256), 0, f->stream, f->dMap, f->dNewN, cap, f->p0, f->Q[f->pG], f->lmc, f->dScratch);
-        hipLaunchKernelGGL(k_compact_lm_scatter, dim3(B), dim3(256), 0, f->stream, f->g[f->pG], f->dNewN, cap, f->p0, f->Q[f->pG], f->lmc, f->dScratch);
+            hipLaunchKernelGGL(k_compact<double>, grid, dim3(256), 0, f->stream, f->g[f->pG], f->dMap, f->dNewN, cap,
+                static_cast<const double*>(f->Sigma[f->pS]), static_cast<double*>(f->Sigma[f->pS ^ 1]), f->sigmaStride, f->ld, f->p0, f->Q[f->pG], f->lmc,
+                f->dScratch);
     });
     if (rc) return rc;
     HIPC(hipGetLastError());
@@ -936,6 +939,10 @@ int compact(eqf_filter* f, const std::vector<std::vector<int>>& keep) {
 // perm[b][i] = index into the measurement of state landmark i (or -1)
 int uploadPerm(eqf_filter* f, const std::vector<std::vector<int>>& perm) {
     const int B = f->B, cap = f->cap;
+    // A landmark that was removed as an outlier and comes back is appended at the END of the state: from then on the state's order differs
+    // from the measurement's on every frame, with the SAME permutation as long as the set does not change.  Each copy is a blit launch on
+    // the stream (4 us + its boundaries; the gate and the update both ask for the permutation: 2.4 copies per frame in the churn leg).
+    if (perm == f->permOnDevice) return EQF_OK;
     int* h = nullptr;
     int slot = 0;
     int rc = stageAcquire(f->stPerm, &h, &slot);
@@ -944,8 +951,10 @@ int uploadPerm(eqf_filter* f, const std::vector<std::vector<int>>& perm) {
         std::fill(h + (size_t)b * cap, h + (size_t)(b + 1) * cap, -1);
         std::copy(perm[b].begin(), perm[b].end(), h + (size_t)b * cap);
     }
+    f->permOnDevice.clear();  // (not valid if the copy cannot be enqueued)
     HIPC(hipMemcpyAsync(f->dPerm, h, sizeof(int) * B * cap, hipMemcpyHostToDevice, f->stream));
     HIPC(hipEventRecord(f->stPerm.ev[slot], f->stream));
+    f->permOnDevice = perm;
     return EQF_OK;
 }
 
@@ -955,7 +964,7 @@ int probe(eqf_filter* f, const double* bearings, long long bearStride, bool with
     const int B = f->B, cap = f->cap;
     const int nmax = std::max(1, maxN(f));
     // with readback the kernel writes the chords straight into pinned host memory (no copy command behind it)
-    double* chordDst = readback ? f->hChordDev : f->dChord;
+    double* chordDst = (readback || speculative) ? f->hChordDev : f->dChord;  // (speculative: resolveGate reads them if the gate tripped)
     int rc = profiled(f, EQF_PROF_CHURN, [&] {
         hipLaunchKernelGGL(k_probe, dim3((nmax + 127) / 128, B), dim3(128), 0, f->stream, f->g[f->pG], f->p0, f->Q[f->pG], cap, bearings,
             bearStride, withPerm ? f->dPerm : nullptr, chordDst, f->dDepth2, f->set.outlierThreshold, speculative ? f->hGateDev : nullptr);
@@ -968,7 +977,9 @@ int probe(eqf_filter* f, const double* bearings, long long bearStride, bool with
 // processVisionData after integrateUpToTime: bookkeeping + update.  measIds[b] ascending ids of filter b,
 // device bearings at bearings + b*bearStride.  active[b] = integration succeeded && initialised.
 int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std::vector<int>& nb, const double* bearings,
-    long long bearStride, const std::vector<char>& active, int* status) {
+    long long bearStride, const std::vector<char>& active, int* status, const std::vector<std::vector<char>>* gated = nullptr) {
+    // gated (resolveGate's redo of a frame whose speculative gate tripped): the outliers are known and already removed, (*gated)[b][k] marks
+    // their measurement entries -- the gate is not evaluated again
     const int B = f->B, cap = f->cap;
     // ---- removeOldLandmarks (VIOFilter.cpp:393-419): state ids absent from the measurement
     bool anyLost = false;
@@ -1011,30 +1022,50 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
     // ---- removeOutliers (:429-443).  A chord between unit vectors never exceeds 2.
     std::vector<std::vector<char>> dropped(B);  // measurement indices erased together with their landmark
     for (int b = 0; b < B; ++b) dropped[b].assign(nb[b], 0);
-    const bool gateOn = f->set.outlierThreshold < 2.0 && maxN(f) > 0;
-    // Speculative gate on frames without NEW landmarks (the common case): the probe decides on the
-    // device, the update is enqueued without waiting for the answer, and a frame that did have an outlier is redone the
-    // slow way by resolveGate() the next time the host touches the handle.
+    if (gated) dropped = *gated;
+    const bool gateOn = !gated && f->set.outlierThreshold < 2.0 && maxN(f) > 0;
+    // Speculative gate: the probe decides on the device, the frame's new landmarks and the update are enqueued without waiting for the
+    // answer, and a frame that did have an outlier is redone the slow way by resolveGate() the next time the host touches the handle
+    // (which first takes the frame's new landmarks out again: the reference removes the outliers BEFORE it initialises new landmarks
+    // at the median depth, VIOFilter.cpp:429-443 then :345-391).
     bool speculate = gateOn && f->gateSpeculative && !f->gate.pending;  // (lost landmarks are already compacted away)
-    for (int b = 0; b < B && speculate; ++b)
-        if (active[b] && nb[b] != int(f->ids[b].size())) speculate = false;
+    bool depthFresh = false;  // dDepth2 holds the squared depths of the CURRENT landmark set
     if (speculate) {
+        // the permutation the update will use -- the frame's new landmarks appended in measurement order -- is uploaded once, now: the
+        // probe reads its first N entries
+        std::vector<std::vector<int>> permFull = perm;
+        for (int b = 0; b < B; ++b) {
+            if (!active[b]) continue;
+            std::vector<char> used(nb[b], 0);
+            for (int k : perm[b]) used[k] = 1;
+            for (int k = 0; k < nb[b]; ++k)
+                if (!used[k]) permFull[b].push_back(k);
+        }
         bool identityPerm = true;
         for (int b = 0; b < B && identityPerm; ++b)
-            for (size_t i = 0; i < perm[b].size(); ++i)
-                if (perm[b][i] != int(i)) {
+            for (size_t i = 0; i < permFull[b].size(); ++i)
+                if (permFull[b][i] != int(i)) {
                     identityPerm = false;
                     break;
                 }
-        int rc = identityPerm ? EQF_OK : uploadPerm(f, perm);
+        int rc = identityPerm ? EQF_OK : uploadPerm(f, permFull);
         if (rc) return rc;
+        if (f->maskPending) {  // (a redo's k_set_update_ok reads hGate)
+            HIPC(hipEventSynchronize(f->evMask));
+            f->maskPending = false;
+        }
         std::fill(f->hGate, f->hGate + B, 0);
         rc = probe(f, bearings, bearStride, !identityPerm, false, true);
         if (rc) return rc;
+        depthFresh = true;
         HIPC(hipEventRecord(f->evGate, f->stream));
         f->gate.pending = true;
         f->gate.ids.assign(B, {});
-        for (int b = 0; b < B; ++b) f->gate.ids[b].assign(measIds[b], measIds[b] + nb[b]);
+        f->gate.nOld.assign(B, 0);
+        for (int b = 0; b < B; ++b) {
+            f->gate.ids[b].assign(measIds[b], measIds[b] + nb[b]);
+            f->gate.nOld[b] = int(f->ids[b].size());
+        }
         f->gate.nb = nb;
         f->gate.active = active;
         f->gate.bearings = bearings;
@@ -1074,15 +1105,20 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
             }
             buildPerm();
         }
+        depthFresh = !anyOut;  // (the probe also left the squared depths -- of the set before any removal)
     }
     // ---- addNewLandmarks (:345-391)
     bool needDepth = false;
     std::vector<std::vector<int>> fresh(B);  // measurement indices of new landmarks, in measurement order
     for (int b = 0; b < B; ++b) {
         if (!active[b]) continue;
-        for (int k = 0; k < nb[b]; ++k) {
-            if (dropped[b][k]) continue;
-            if (std::find(f->ids[b].begin(), f->ids[b].end(), measIds[b][k]) == f->ids[b].end()) fresh[b].push_back(k);
+        {
+            // (every state id is in the measurement by now: perm marks the measurement entries that have a landmark)
+            std::vector<char> used(nb[b], 0);
+            for (int k : perm[b])
+                if (k >= 0 && k < nb[b]) used[k] = 1;
+            for (int k = 0; k < nb[b]; ++k)
+                if (!used[k] && !dropped[b][k]) fresh[b].push_back(k);
         }
         if (!fresh[b].empty()) {
             // (cannot happen: every entry point checks nb <= capacity and strictly ascending ids before any effect)
@@ -1090,43 +1126,13 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
             if (!f->ids[b].empty()) needDepth = true;
         }
     }
-    if (needDepth) {
-        // squared depths of the current estimate and their median, both on the device: adding landmarks needs no readback
-        int rc = probe(f, nullptr, 0, false, false);
-        if (rc) return rc;
-        const int nmx = std::max(1, maxN(f));
-        rc = profiled(f, EQF_PROF_CHURN, [&] {
-            hipLaunchKernelGGL(k_median_depth, dim3((nmx + 255) / 256, B), dim3(256), 0, f->stream, f->g[f->pG], f->dDepth2, cap, f->dDepthSel);
-        });
-        if (rc) return rc;
-    }
+    // the host's ids first, then the permutation the update will use (new landmarks at the end, in measurement order): uploaded once, and
+    // k_append finds the bearing of the j-th new landmark in it
+    std::vector<int> nOldV(B, 0);
     for (int b = 0; b < B; ++b) {
-        if (fresh[b].empty()) continue;
-        const int nOld = int(f->ids[b].size()), nNew = int(fresh[b].size());
-        int* h = nullptr;
-        int slot = 0;
-        int rc = stageAcquire(f->stSrc, &h, &slot);
-        if (rc) return rc;
-        std::copy(fresh[b].begin(), fresh[b].end(), h);
-        HIPC(hipMemcpyAsync(f->dSrc, h, sizeof(int) * nNew, hipMemcpyHostToDevice, f->stream));
-        HIPC(hipEventRecord(f->stSrc.ev[slot], f->stream));
-        const long long work = (long long)3 * nNew * (kLm0 + 3 * (nOld + nNew)) * 2;
-        const int blocks = int(std::min<long long>(1024, (work + 255) / 256));
-        rc = profiled(f, EQF_PROF_CHURN, [&] {
-            if (f->precision == EQF_PRECISION_F32)
-                hipLaunchKernelGGL(k_append<float>, dim3(std::max(1, blocks)), dim3(256), 0, f->stream, f->g[f->pG], b, nOld, nNew, f->dDepthSel,
-                    f->set.initialSceneDepth, f->set.initialPointVariance, cap, bearings + (long long)b * bearStride, f->dSrc, f->p0,
-                    f->Q[f->pG], f->lmc, f->errflag, static_cast<float*>(f->Sigma[f->pS]), f->sigmaStride, f->ld);
-            else
-                hipLaunchKernelGGL(k_append<double>, dim3(std::max(1, blocks)), dim3(256), 0, f->stream, f->g[f->pG], b, nOld, nNew, f->dDepthSel,
-                    f->set.initialSceneDepth, f->set.initialPointVariance, cap, bearings + (long long)b * bearStride, f->dSrc, f->p0,
-                    f->Q[f->pG], f->lmc, f->errflag, static_cast<double*>(f->Sigma[f->pS]), f->sigmaStride, f->ld);
-        });
-        if (rc) return rc;
-        HIPC(hipGetLastError());
+        nOldV[b] = int(f->ids[b].size());
         for (int k : fresh[b]) f->ids[b].push_back(measIds[b][k]);
     }
-    // ---- the update proper (:258-297)
     buildPerm();
     bool identity = true, anyWork = false;
     int Nmax = 0;
@@ -1141,11 +1147,50 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
         for (size_t i = 0; i < perm[b].size(); ++i)
             if (perm[b][i] != int(i)) identity = false;
     }
-    if (!anyWork) return EQF_OK;
-    if (!identity) {
+    if (anyWork && !identity) {
         int rc = uploadPerm(f, perm);
         if (rc) return rc;
     }
+    bool medianLaunch = false;
+    if (needDepth) {
+        // squared depths of the current estimate on the device (adding landmarks needs no readback); their median is selected by k_append
+        // itself, or by a launch of its own for sets too large for that
+        int rc = depthFresh ? EQF_OK : probe(f, nullptr, 0, false, false);  // (the gate's probe left them already)
+        if (rc) return rc;
+        for (int b = 0; b < B; ++b)
+            if (!fresh[b].empty() && nOldV[b] > kMedianInAppend) medianLaunch = true;
+        if (medianLaunch) {
+            int nmx = 1;
+            for (int b = 0; b < B; ++b) nmx = std::max(nmx, nOldV[b]);
+            // (k_median_depth reads N from the device state, which still holds the old counts)
+            rc = profiled(f, EQF_PROF_CHURN, [&] {
+                hipLaunchKernelGGL(k_median_depth, dim3((nmx + 255) / 256, B), dim3(256), 0, f->stream, f->g[f->pG], f->dDepth2, cap, f->dDepthSel);
+            });
+            if (rc) return rc;
+        }
+    }
+    for (int b = 0; b < B; ++b) {
+        if (fresh[b].empty()) continue;
+        const int nOld = nOldV[b], nNew = int(fresh[b].size());
+        const long long work = (long long)3 * nNew * (kLm0 + 3 * (nOld + nNew)) * 2;
+        const int blocks = int(std::min<long long>(1024, (work + 255) / 256));
+        const double* depthSel = medianLaunch ? f->dDepthSel : nullptr;
+        const int* permDev = identity ? nullptr : f->dPerm;
+        int rc = profiled(f, EQF_PROF_CHURN, [&] {
+            if (f->precision == EQF_PRECISION_F32)
+                hipLaunchKernelGGL(k_append<float>, dim3(std::max(1, blocks)), dim3(256), 0, f->stream, f->g[f->pG], b, nOld, nNew, depthSel, f->dDepth2,
+                    f->set.initialSceneDepth, f->set.initialPointVariance, cap, bearings + (long long)b * bearStride, permDev, f->p0,
+                    f->Q[f->pG], f->lmc, f->errflag, static_cast<float*>(f->Sigma[f->pS]), f->sigmaStride, f->ld);
+            else
+                hipLaunchKernelGGL(k_append<double>, dim3(std::max(1, blocks)), dim3(256), 0, f->stream, f->g[f->pG], b, nOld, nNew, depthSel, f->dDepth2,
+                    f->set.initialSceneDepth, f->set.initialPointVariance, cap, bearings + (long long)b * bearStride, permDev, f->p0,
+                    f->Q[f->pG], f->lmc, f->errflag, static_cast<double*>(f->Sigma[f->pS]), f->sigmaStride, f->ld);
+        });
+        if (rc) return rc;
+        HIPC(hipGetLastError());
+    }
+    // ---- the update proper (:258-297)
+    if (!anyWork) return EQF_OK;
     return launchUpdate(f, bearings, bearStride, identity ? nullptr : f->dPerm, Nmax);
 }
 
@@ -1157,27 +1202,55 @@ int resolveGate(eqf_filter* f) {
     HIPC(hipSetDevice(f->device));
     HIPC(hipEventSynchronize(f->evGate));
     f->gate.pending = false;
-    const int B = f->B;
+    const int B = f->B, cap = f->cap;
     bool any = false;
     std::vector<char> act(B, 0);
-    std::vector<int> mask(B, 0);
-    for (int b = 0; b < B; ++b)
-        if (f->hGate[b] && f->gate.active[b]) {
+    for (int b = 0; b < B; ++b) {
+        const bool hit = f->hGate[b] && f->gate.active[b];
+        f->hGate[b] = hit ? 1 : 0;  // the mask k_set_update_ok reads: only the flagged filters take part in the redo
+        if (hit) {
             any = true;
             act[b] = 1;
-            mask[b] = 1;
         }
+    }
     if (!any) return EQF_OK;
-    HIPC(hipMemcpyAsync(f->dMask, mask.data(), sizeof(int) * B, hipMemcpyHostToDevice, f->stream));
-    hipLaunchKernelGGL(k_set_update_ok, dim3((B + 63) / 64), dim3(64), 0, f->stream, f->g[f->pG], f->dMask, B);
-    HIPC(hipStreamSynchronize(f->stream));  // mask.data() is pageable host memory
+    hipLaunchKernelGGL(k_set_update_ok, dim3((B + 63) / 64), dim3(64), 0, f->stream, f->g[f->pG], f->hGateDev, B);
+    HIPC(hipEventRecord(f->evMask, f->stream));
+    f->maskPending = true;
+    // The flagged filters: their update did not run, their new landmarks of that frame were appended.  One compaction takes out the
+    // outliers -- the probe left every chord in pinned memory: no second probe, no readback -- and the appended landmarks (the redo
+    // initialises them again, at the median depth of what is left: the reference's order, VIOFilter.cpp:429-443 then :345-391).
+    std::vector<std::vector<int>> keep(B);
+    std::vector<std::vector<char>> gated(B);
+    for (int b = 0; b < B; ++b) {
+        const int n = int(f->ids[b].size());
+        gated[b].assign(f->gate.nb[b], 0);
+        if (!act[b]) {
+            keep[b].resize(n);
+            for (int i = 0; i < n; ++i) keep[b][i] = i;
+            continue;
+        }
+        const int nOld = std::min(n, f->gate.nOld[b]);
+        const int* mi = f->gate.ids[b].data();
+        for (int i = 0; i < nOld; ++i) {
+            if (f->hChord[(size_t)b * cap + i] > f->set.outlierThreshold) {
+                const int* it = std::lower_bound(mi, mi + f->gate.nb[b], f->ids[b][i]);
+                gated[b][int(it - mi)] = 1;
+            } else {
+                keep[b].push_back(i);
+            }
+        }
+    }
+    int rc = compact(f, keep);
+    if (rc) return rc;
+    for (int b = 0; b < B; ++b) {
+        std::vector<int> nid;
+        for (int o : keep[b]) nid.push_back(f->ids[b][o]);
+        f->ids[b] = nid;
+    }
     std::vector<const int*> mids(B);
     for (int b = 0; b < B; ++b) mids[b] = f->gate.ids[b].data();
-    const int keep = f->gateSpeculative;
-    f->gateSpeculative = 0;
-    const int rc = visionCore(f, mids, f->gate.nb, f->gate.bearings, f->gate.bearStride, act, nullptr);
-    f->gateSpeculative = keep;
-    return rc;
+    return visionCore(f, mids, f->gate.nb, f->gate.bearings, f->gate.bearStride, act, nullptr, &gated);
 }
 
 void freeAll(eqf_filter* f) {
@@ -1189,16 +1262,16 @@ void freeAll(eqf_filter* f) {
     }
     for (void* p : {(void*)f->p0, (void*)f->lmc, (void*)f->SA, (void*)f->SL, (void*)f->YW, (void*)f->YO, (void*)f->EA, (void*)f->EL, (void*)f->ZW,
              (void*)f->ZO, (void*)f->dbgDelta, (void*)f->dbgGamma, (void*)f->dbgGammaTot, (void*)f->red, (void*)f->errflag, (void*)f->dMap,
-             (void*)f->dNewN, (void*)f->dPerm, (void*)f->dSrc, (void*)f->dChord, (void*)f->dDepth2, (void*)f->dDepthSel, (void*)f->dScratch, (void*)f->dMeas,
+             (void*)f->dPerm, (void*)f->dChord, (void*)f->dDepth2, (void*)f->dDepthSel, (void*)f->dScratch, (void*)f->dMeas,
              (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn, f->dBlk, (void*)f->dBlkCommon, f->dColRec, f->dRowRec, (void*)f->dSteps, (void*)f->dFlags, (void*)f->dReadyA, (void*)f->dReadyY, (void*)f->dResCounters, (void*)f->dStageFlags, (void*)f->dPrepFlags, (void*)f->dBuildFlags, (void*)f->dGammaPart,
              (void*)f->dG11Part, (void*)f->dRoles})
         hipFree(p);
     if (f->hGate) hipHostFree(f->hGate);
     if (f->dMask) hipFree(f->dMask);
     if (f->evGate) hipEventDestroy(f->evGate);
+    if (f->evMask) hipEventDestroy(f->evMask);
     stageFree(f->stMap);
     stageFree(f->stPerm);
-    stageFree(f->stSrc);
     for (void* p : {(void*)f->hChord, (void*)f->hMeas,
              (void*)f->hOut, (void*)f->hRing})
         if (p) hipHostFree(p);
@@ -1356,8 +1429,8 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     chk(dmalloc(&f->dbgGammaTot, (size_t)(9 + 3 * cap) * B));
     chk(dmalloc(&f->red, (size_t)256 * B));
     chk(dmalloc(&f->errflag, 1));
-    chk(dmalloc(&f->dMap, (size_t)cap * B)); chk(dmalloc(&f->dNewN, B)); chk(dmalloc(&f->dPerm, (size_t)cap * B));
-    chk(dmalloc(&f->dSrc, cap)); chk(dmalloc(&f->dChord, (size_t)cap * B)); chk(dmalloc(&f->dDepth2, (size_t)cap * B));
+    chk(dmalloc(&f->dMap, (size_t)cap * B + B)); if (!rc) f->dNewN = f->dMap + (size_t)cap * B;  /* (one copy brings both) */ chk(dmalloc(&f->dPerm, (size_t)cap * B));
+    chk(dmalloc(&f->dChord, (size_t)cap * B)); chk(dmalloc(&f->dDepth2, (size_t)cap * B));
     chk(dmalloc(&f->dScratch, (size_t)kLmRec * cap * B)); chk(dmalloc(&f->dMeas, (size_t)3 * cap * B));
     chk(dmalloc(&f->dOut, (size_t)f->nTot * f->nTot + 16));
     chk(dmalloc(&f->dRing, (size_t)kRing * B));
@@ -1419,11 +1492,12 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     chk(dmalloc(&f->dFlags, (size_t)2 * f->flagStride * B));
     if (!rc && hipMemset(f->dFlags, 0, sizeof(int) * 2 * f->flagStride * B) != hipSuccess) rc = EQF_ERR_HIP;
     if (const char* e = std::getenv("EQF_GATE_SPECULATIVE")) f->gateSpeculative = std::atoi(e);
-    chk(stageInit(f->stMap, (size_t)cap * B + B)); chk(stageInit(f->stPerm, (size_t)cap * B)); chk(stageInit(f->stSrc, cap));
+    chk(stageInit(f->stMap, (size_t)cap * B + B)); chk(stageInit(f->stPerm, (size_t)cap * B));
     chk(hmalloc(&f->hChord, (size_t)cap * B)); chk(dmalloc(&f->dDepthSel, B));
     chk(hmalloc(&f->hGate, B)); chk(dmalloc(&f->dMask, B));
     if (!rc && hipHostGetDevicePointer(reinterpret_cast<void**>(&f->hGateDev), f->hGate, 0) != hipSuccess) rc = EQF_ERR_HIP;
     if (!rc && hipEventCreateWithFlags(&f->evGate, hipEventDisableTiming) != hipSuccess) rc = EQF_ERR_HIP;
+    if (!rc && hipEventCreateWithFlags(&f->evMask, hipEventDisableTiming) != hipSuccess) rc = EQF_ERR_HIP;
     if (!rc && hipHostGetDevicePointer(reinterpret_cast<void**>(&f->hChordDev), f->hChord, 0) != hipSuccess) rc = EQF_ERR_HIP;
     chk(hmalloc(&f->hMeas, (size_t)3 * cap * B)); chk(hmalloc(&f->hOut, (size_t)f->nTot * f->nTot + 16));
     chk(hmalloc(&f->hRing, (size_t)kRing * B));

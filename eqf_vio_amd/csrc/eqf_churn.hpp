@@ -63,8 +63,7 @@ __global__ void k_median_depth(const Glob* g, const double* depth2, int cap, dou
 // Remove landmarks: Sigma_out = Sigma_in with the rows/cols of dropped landmarks erased, map[b][newI] = oldI.
 // Filters without removals pass the identity map (the ping-pong parity is shared by the whole batch).
 template <typename T>
-__global__ __launch_bounds__(256) void k_compact_sigma(const Glob* g, const int* map, const int* newN, int cap,
-    const T* Sin, T* Sout, long long sigmaStride, int ld) {
+__device__ __forceinline__ void compactSigmaRow(const int* map, const int* newN, int cap, const T* Sin, T* Sout, long long sigmaStride, int ld) {
     const int b = blockIdx.z;
     const int Nn = newN[b];
     const int nvn = kLm0 + 3 * Nn;
@@ -79,38 +78,55 @@ __global__ __launch_bounds__(256) void k_compact_sigma(const Glob* g, const int*
         dst[Cc] = src[Cs];
     }
 }
-// Compact the per-landmark arrays through a scratch copy (gather then write back), one workgroup per filter.
 constexpr int kLmRec = 3 + 5 + 15;  // scratch record per landmark: p0, Q, constants
-__global__ void k_compact_lm_gather(const int* map, const int* newN, int cap, const double* p0, const double* Q, const double* lmc,
-    double* scratch) {
-    const int b = blockIdx.x;
+// grid = (ceil(nvn / 256), nvn, B) over the output of the largest filter, block = 256
+template <typename T>
+__global__ __launch_bounds__(256) void k_compact(Glob* g, const int* map, const int* newN, int cap, const T* Sin, T* Sout, long long sigmaStride,
+    int ld, double* p0, double* Q, double* lmc, double* scratch) {
+    compactSigmaRow<T>(map, newN, cap, Sin, Sout, sigmaStride, ld);
+    if (blockIdx.x != 0 || blockIdx.y != 0) return;
+    const int b = blockIdx.z;
     const int* mp = map + (long long)b * cap;
-    for (int i = threadIdx.x; i < newN[b]; i += blockDim.x) {
+    const int Nn = newN[b];
+    for (int i = threadIdx.x; i < Nn; i += blockDim.x) {
         const int o = mp[i];
         for (int c = 0; c < 3; ++c) scratch[((long long)b * kLmRec + c) * cap + i] = p0[((long long)b * 3 + c) * cap + o];
         for (int c = 0; c < 5; ++c) scratch[((long long)b * kLmRec + 3 + c) * cap + i] = Q[((long long)b * 5 + c) * cap + o];
         for (int c = 0; c < 15; ++c) scratch[((long long)b * kLmRec + 8 + c) * cap + i] = lmc[((long long)b * 15 + c) * cap + o];
     }
-}
-__global__ void k_compact_lm_scatter(Glob* g, const int* newN, int cap, double* p0, double* Q, double* lmc, const double* scratch) {
-    const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < newN[b]; i += blockDim.x) {
+    __threadfence_block();
+    __syncthreads();
+    for (int i = threadIdx.x; i < Nn; i += blockDim.x) {
         for (int c = 0; c < 3; ++c) p0[((long long)b * 3 + c) * cap + i] = scratch[((long long)b * kLmRec + c) * cap + i];
         for (int c = 0; c < 5; ++c) Q[((long long)b * 5 + c) * cap + i] = scratch[((long long)b * kLmRec + 3 + c) * cap + i];
         for (int c = 0; c < 15; ++c) lmc[((long long)b * 15 + c) * cap + i] = scratch[((long long)b * kLmRec + 8 + c) * cap + i];
     }
-    if (threadIdx.x == 0) g[b].N = newN[b];
+    if (threadIdx.x == 0) g[b].N = Nn;
 }
 
 // Append landmarks to filter b: p0 = bearing * depth, Q = identity, Sigma grows with zero cross terms and
-// initialPointVariance on the new diagonal (VIOFilter.cpp:367-390).  src[j] = index of the bearing of the
-// j-th new landmark; depthSel[b] = k_median_depth's result.
+// initialPointVariance on the new diagonal (VIOFilter.cpp:367-390).  The bearing of the j-th new landmark is measurement entry
+// perm[b][nOld + j] (the permutation the update will use; nullptr: the identity).  depth: the median scene depth of the current estimate
+// (:357-366) -- depthSel[b] if given (k_median_depth's result), else every workgroup selects it itself from the squared depths k_probe left
+// (the same order statistic by the same rank counting; nOld <= kMedianInAppend) -- or initialSceneDepth for an empty filter.
+constexpr int kMedianInAppend = 1024;
 template <typename T>
-__global__ __launch_bounds__(256) void k_append(Glob* g, int b, int nOld, int nNew, const double* depthSel, double depthDefault, double pointVar, int cap,
-    const double* bearings /* filter b */, const int* src, double* p0, double* Q, double* lmc, int* errflag, T* S, long long sigmaStride,
-    int ld) {
+__global__ __launch_bounds__(256) void k_append(Glob* g, int b, int nOld, int nNew, const double* depthSel, const double* depth2, double depthDefault,
+    double pointVar, int cap, const double* bearings /* filter b */, const int* perm, double* p0, double* Q, double* lmc, int* errflag, T* S,
+    long long sigmaStride, int ld) {
     const int nvo = kLm0 + 3 * nOld, nvn = kLm0 + 3 * (nOld + nNew);
-    const double depth = nOld > 0 ? depthSel[b] : depthDefault;  // median of the current estimate, or initialSceneDepth (:361-366)
+    __shared__ double sDepth;
+    if (nOld > 0 && !depthSel) {
+        const double* d = depth2 + (long long)b * cap;
+        for (int i = threadIdx.x; i < nOld; i += blockDim.x) {
+            const double di = d[i];
+            int rank = 0;
+            for (int j = 0; j < nOld; ++j) rank += (d[j] < di) || (d[j] == di && j < i);
+            if (rank == nOld / 2) sDepth = sqrt(di);
+        }
+        __syncthreads();
+    }
+    const double depth = nOld > 0 ? (depthSel ? depthSel[b] : sDepth) : depthDefault;  // (:361-366)
     T* Sb = S + (long long)b * sigmaStride;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     // new rows (all columns) and new columns (old rows)
@@ -128,8 +144,8 @@ __global__ __launch_bounds__(256) void k_append(Glob* g, int b, int nOld, int nN
         Sb[(long long)R * ld + Cc] = (R == Cc) ? (T)pointVar : (T)0;
     }
     for (int j = tid; j < nNew; j += nth) {
-        const double* y = bearings + 3 * src[j];
         const int i = nOld + j;
+        const double* y = bearings + 3 * (perm ? perm[(long long)b * cap + i] : i);
         p0[((long long)b * 3 + 0) * cap + i] = y[0] * depth;
         p0[((long long)b * 3 + 1) * cap + i] = y[1] * depth;
         p0[((long long)b * 3 + 2) * cap + i] = y[2] * depth;

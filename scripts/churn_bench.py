@@ -40,6 +40,11 @@ def run(mode):
     return dt, len(ev), fb.num_landmarks(), nch / max(nvis - 1, 1), fb.device_error()
 
 
+if os.environ.get("CHURN_MODE"):  # one mode, once after a warm-up (for a rocprofv3 kernel summary: scripts/churn_profile.sh)
+    run("fixed")
+    dt, n, N, ch, err = run(os.environ["CHURN_MODE"])
+    print(f"{os.environ['CHURN_MODE']:20s}: {n} calls, {dt*1e3:.1f} ms = {n/dt:.0f} steps/s, N at end {N}, landmark changes per frame {ch:.1f}, device error {err}")
+    sys.exit(0)
 run("fixed")  # warm-up: module load, first launches
 for mode in ("fixed", "fixed+outlier-gate", "churn", "churn+outlier-gate"):
     res = [run(mode) for _ in range(3)]

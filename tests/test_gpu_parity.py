@@ -213,6 +213,50 @@ def test_speculative_outlier_gate(oracle_lib, hip, peek):
     assert fg.device_error() == 0
 
 
+@pytest.mark.parametrize("peek", [True, False])
+def test_speculative_gate_on_frames_that_also_bring_new_landmarks(oracle_lib, hip, peek):
+    """Round 4: the gate is speculative on frames with NEW landmarks too -- the probe decides on the device, the new landmarks are appended
+    (at the median depth of the set the probe saw) and the update is enqueued without waiting.  If the frame did have an outlier, the host
+    takes the appended landmarks out again and redoes the frame the reference's way: outliers removed first, THEN the new landmarks
+    initialised at the median depth of what is left (VIOFilter.cpp:429-443, :345-391).  Frames 3 and 7 carry an outlier AND five new
+    landmarks each; frames 5 and 9 bring new landmarks without an outlier; against the oracle after every frame (peek) or at the end."""
+    from eqf_vio_amd import synth
+
+    pool = 50
+    st = synth.make_stream(pool, seed=321, duration=0.6)
+    d = synth.template_settings_dict()
+    d["outlierThreshold"] = 0.05
+    fo = oracle_lib.OracleFilter(d)
+    fg = hip.FilterBatch(d, capacity=pool, batch=1)
+    visible = 30
+    for kind, k in st.events():
+        if kind == "imu":
+            r = st.imu[k]
+            fo.processIMUData(r[0], r[1:4], r[4:7])
+            fg.process_imu([r[0]], r[1:4], r[4:7])
+            continue
+        if k in (3, 5, 7, 9):
+            visible += 5
+        ids = st.ids[:visible]
+        y = st.bearings[k, :visible].copy()
+        if k in (3, 7):  # rotate one old bearing by ~0.2 rad: chord 0.2 >> 0.05
+            axis = np.cross(y[5], np.array([1.0, 0.3, -0.2]))
+            axis /= np.linalg.norm(axis)
+            y[5] = y[5] * np.cos(0.2) + np.cross(axis, y[5]) * np.sin(0.2)
+        fo.processVisionData(st.vision_stamps[k], ids, y)
+        fg.process_vision([st.vision_stamps[k]], ids, y)
+        if peek:
+            assert fg.num_landmarks() == fo.N, k
+            assert np.array_equal(fg.ids(), fo.ids()), k
+            assert rel_fro(fg.sigma(), fo.stateCovariance()) < SIGMA_TOL, k
+    assert fg.num_landmarks() == fo.N
+    assert np.array_equal(fg.ids(), fo.ids())
+    assert rel_fro(fg.sigma(), fo.stateCovariance()) < SIGMA_TOL
+    eo, eg = fo.stateEstimate(), fg.state_estimate()
+    assert np.abs(eo["x"] - eg["x"]).max() < POSE_TOL and np.abs(eo["q"] - eg["q"]).max() < POSE_TOL
+    assert fg.device_error() == 0
+
+
 def test_reset_returns_to_the_constructed_state(hip):
     """eqf_reset: a handle that has run (landmarks, churned Sigma, advanced time) and is reset behaves bitwise like a
     fresh one."""
