@@ -388,6 +388,28 @@ __global__ __launch_bounds__(256) void k_tile_trsm(const double* A, int ld, int 
         *idx = (long long)gr * ldb + gc;
         return right ? (gr < m && gc < n) : (gr < n && gc < m);
     };
+    // The strip is a chain of nb (nb + 1) / 2 block products, each behind two 32 KB operand blocks: the blocks of product (kb, j + 1) -- or
+    // (kb + 1, 0) -- travel global -> REGISTERS while product (kb, j) runs from LDS (round 4: a step took 10 us, nearly all of it the
+    // exposed latency of the loads; a block-row solve of the partitioned filter is one such chain per 64 columns, 0.77 ms at n = 500).
+    double pP[16], pQ[16];
+    auto issue = [&](int kb, int j) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + 256 * u, r = e >> 6, c = e & 63;
+            long long idx;
+            pP[u] = bAt(j, r, c, &idx) ? B[idx] : 0.0;
+            const int gr = kSB * kb + r, gc = kSB * j + c;
+            pQ[u] = (gr < n && gc < n) ? A[(long long)gr * ld + gc] : 0.0;
+        }
+    };
+    auto toLds = [&]() {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + 256 * u;
+            s.P[e >> 6][e & 63] = pP[u];
+            s.Q[e >> 6][e & 63] = pQ[u];
+        }
+    };
     for (int kb = 0; kb < nb; ++kb) {
         // the strip's block kb in the accumulator layout (wave wv: rows 16 wv.., four 16-column tiles)
         f64x4 acc[4];
@@ -398,16 +420,12 @@ __global__ __launch_bounds__(256) void k_tile_trsm(const double* A, int ld, int 
                 long long idx;
                 acc[i][q] = bAt(kb, kQB * wv + (lane >> 4) + 4 * q, kQB * i + (lane & 15), &idx) ? B[idx] : 0.0;
             }
+        if (kb > 0) issue(kb, 0);  // (the strip's solved blocks j < kb were written by this workgroup: fenced at the end of their step)
         for (int j = 0; j < kb; ++j) {
-            // P <- the strip's solved block j (written by this workgroup) ; Q <- L_kb,j
-            for (int e = tid; e < kSB * kSB; e += 256) {
-                const int r = e >> 6, c = e & 63;
-                long long idx;
-                s.P[r][c] = bAt(j, r, c, &idx) ? B[idx] : 0.0;
-                const int gr = kSB * kb + r, gc = kSB * j + c;
-                s.Q[r][c] = (gr < n && gc < n) ? A[(long long)gr * ld + gc] : 0.0;
-            }
+            // P <- the strip's solved block j ; Q <- L_kb,j
+            toLds();
             __syncthreads();
+            if (j + 1 < kb) issue(kb, j + 1);
             if (right) {  // X_kb -= X_j L_kb,j^T
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] = mmTile<true, kSB>(acc[i], &s.P[0][0], kSP, kQB * wv, &s.Q[0][0], kSP, kQB * i, lane, -1.0);
