@@ -399,7 +399,14 @@ class TiledFilter:
         self.g, self.be, self.bl = grid, backend, int(block_landmarks)
         # the two factorisations of an update are independent: they run side by side on two streams, each with its own exchange buffers
         # and -- on more than one rank -- its own process groups (two communicators: collectives of different streams must not share one)
-        self.overlap_chains = True
+        # Two RCCL communicators with kernels in flight on different streams of one process can deadlock when the ranks' GPUs schedule them in
+        # different orders, and this schedule has never run on more than one GPU: over nccl with more than one rank the chains run one after
+        # the other unless EQF_TILED_OVERLAP_CHAINS=1 asks for it (one rank, or gloo -- host-blocking collectives --: side by side).
+        import os
+
+        backend_name = grid.dist.get_backend() if (grid.dist is not None and grid.world > 1) else ""
+        env = os.environ.get("EQF_TILED_OVERLAP_CHAINS")
+        self.overlap_chains = (env != "0") if env is not None else not (grid.world > 1 and backend_name == "nccl")
         self.gE = ProcessGrid(grid.dist, grid.Pr, grid.Pc, grid.device) if grid.world > 1 else grid
         self.geo = None
         self.Sll = self.M = self.E = None
