@@ -570,7 +570,8 @@ def main():
             "events": {"imu": sum(1 for k, _ in timed if k == "imu"), "vision": sum(1 for k, _ in timed if k == "vision")},
             "parallelism": "independent filters sharded over %d GPU(s), RCCL scatter/gather only" % world,
             "imu_burst": "IMU calls between two vision frames + the vision call's integrateUpToTime leave as one burst of <= 16 steps "
-                         "(2 launches, Sigma read/written once; every step is the reference's step); EQF_IMU_BURST=0: one launch per call",
+                         "(one launch for a single small fp64 filter -- builder and block workgroups together, k_burst_fused -- else two; Sigma read/written "
+                         "once; every step is the reference's step); EQF_IMU_BURST=0: one launch per call",
         },
         "device_error_flag": err,
         "sigma_fro_filter0": float(res[0, 7]) if res is not None else None,
@@ -594,6 +595,10 @@ def main():
             "frames_per_s": round(line["value"] / B / world * n_upd / max(n_imu_vis, 1), 1),
             "note": "kernel time of the profiled pass (dispatch gaps excluded); a frame = 10 IMU calls + 1 vision call",
         }
+        if isinstance(rl, dict) and "k_update_prep" not in t and "k_chol_resident" in t:
+            rl["note"] = ("this launch of k_chol_resident CONTAINS the prep work (residuals, C Sigma, S, first diagonal blocks: prep roles, round 4) that "
+                          "rounds 1-3 ran as a launch of its own in front of it (k_update_prep64, 12 us at N = 200): compare per_call.update_us "
+                          "across rounds, not this kernel's duration alone; EQF_RES_FOLD_PREP=0 gives the two-launch shape")
     del fb  # free the GPU for the next legs
 
     # ---- steady-state leg: the driver's default run times 20 steps (two frames, half a millisecond); the same workload over 10 s of

@@ -114,6 +114,8 @@ if [ -f $ROOT/build_variants/libeqf_bstamps.so ]; then
     EQF_BURST_FUSED=0 EQF_VIO_AMD_LIB=$ROOT/build_variants/libeqf_bstamps.so timeout 300 $PY $ROOT/scripts/burst_fused_stamps.py; } > "$OUT/${TAG}_burst_stamps_N200.txt" 2>&1
 fi
 EQF_BURST_FUSED=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-batch64 --no-parity --no-traffic --no-tiled --no-churn --no-steady-state > "$OUT/${TAG}_bench_N200_burst_two_launches.json" 2>/dev/null
+# 7c. landmark churn and the outlier gate on the per-call API: which launches a frame consists of in each mode
+timeout 600 bash $ROOT/scripts/churn_profile.sh > "$OUT/${TAG}_churn_profile.txt" 2>&1
 # 8. factor64 alone (scripts/micro/factor64_bench.hip, if built): cycles per 64-column block, per-wave stamps
 for b in factor64_bench factor64_bench_ns; do
   [ -x $ROOT/scripts/micro/$b ] && ( $ROOT/scripts/micro/$b 0 1 4; $ROOT/scripts/micro/$b 0 0 4 ) > "$OUT/${TAG}_${b}.txt" 2>&1
