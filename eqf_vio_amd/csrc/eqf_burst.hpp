@@ -70,7 +70,7 @@ struct BurstArgs {
     int epoch, nBuild, nBuildCap;
     // elements between two steps' records: kColRec * cap and cap * kBlkRec rounded up to whole 128-byte lines (burstRecStep), so that no
     // cache line holds entries of two steps -- the fused launch reads a step's lines through the L2 while later steps are still being written
-    long long colStep, rowStep;
+    int colStep, rowStep;
     Params prm;
 };
 
@@ -602,8 +602,8 @@ EQF_DI void burstBuildBody(const BurstArgs& a, const int bxIdx, const int b) {
                 const double Qa = s.Q[cur][lane][4];
                 m33 Dm, Lvm;
                 buildDLv(s.com[st & 3], Qq, Qa, q0, &Dm, &Lvm);
-                T* cr = colRec + (long long)st * a.colStep + li;
-                T* rr = rowRec + (long long)st * a.rowStep + (long long)li * kBlkRec;
+                T* cr = colRec + (long long)(st * a.colStep) + li;
+                T* rr = rowRec + (long long)(st * a.rowStep) + (long long)li * kBlkRec;
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const T d = (T)Dm.a[k], lv = (T)Lvm.a[k];
@@ -645,7 +645,7 @@ EQF_DI void burstBuildBody(const BurstArgs& a, const int bxIdx, const int b) {
         const T* srcL[7];   // slot 0 of the LDS ring
         int srcStride[7];   // elements per slot
         double* dstG[7];    // step 0
-        long long dstStride[7];
+        int dstStride[7];
         bool on[7];
 #pragma unroll
         for (int p = 0; p < 7; ++p) {
@@ -727,8 +727,8 @@ EQF_DI void burstBuildBody(const BurstArgs& a, const int bxIdx, const int b) {
                 const double Qa = s.Q[cur][lane][4];
                 const StepCommon& c = s.com[st & 3];
                 const m33 Lwm = buildLw(c.T, c.RICt, c.xIC, Qq, Qa, q0);
-                T* cr = colRec + (long long)st * a.colStep + li;
-                T* rr = rowRec + (long long)st * a.rowStep + (long long)li * kBlkRec;
+                T* cr = colRec + (long long)(st * a.colStep) + li;
+                T* rr = rowRec + (long long)(st * a.rowStep) + (long long)li * kBlkRec;
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const T lw = (T)Lwm.a[k];
@@ -781,8 +781,8 @@ EQF_DI void burstBuildBody(const BurstArgs& a, const int bxIdx, const int b) {
                 // records: Gn / Gv for the row side, Sw / Sv (entering the step) for the column side
                 if (pOk && (pc < 3 || (pc >= 8 && pc < 11))) {
                     const int cc = pc < 3 ? pc : pc - 8;
-                    T* cr = colRec + (long long)st * a.colStep + plm;
-                    T* rw = rowRec + (long long)st * a.rowStep + (long long)plm * kBlkRec;
+                    T* cr = colRec + (long long)(st * a.colStep) + plm;
+                    T* rw = rowRec + (long long)(st * a.rowStep) + (long long)plm * kBlkRec;
                     const T swT = s.swT[sl];
 #pragma unroll
                     for (int rr = 0; rr < 3; ++rr) {
@@ -970,13 +970,13 @@ EQF_DI void burstRingBody(const BurstArgs& a, const int tileIdx, const int b) {
     T xA[kRingTrips + kRowTrips], xB[kRingTrips + kRowTrips];
     auto fetch = [&](int st, T* x) __attribute__((always_inline)) {
         const int sc = min(st, K - 1);  // (past the end: re-read the last step, nobody uses it)
-        const T* cp = colRec + (long long)sc * a.colStep;
+        const T* cp = colRec + (long long)(sc * a.colStep);
 #pragma unroll
         for (int j = 0; j < kRingTrips; ++j) {
             const int q = min(wv + 4 * j, kBlkRec - 1);
             x[j] = cp[(long long)(q < 27 ? q : q + 18) * cap];
         }
-        const T* rp = rowRec + (long long)sc * a.rowStep;
+        const T* rp = rowRec + (long long)(sc * a.rowStep);
 #pragma unroll
         for (int u = 0; u < kRowTrips; ++u) x[kRingTrips + u] = rp[min(lane + 64 * u, nI * kBlkRec - 1)];
     };
@@ -1002,7 +1002,7 @@ EQF_DI void burstRingBody(const BurstArgs& a, const int tileIdx, const int b) {
     const int nIu = __builtin_amdgcn_readfirstlane(nI);
     CT* const rowC = (CT*)(unsigned long long)(static_cast<const T*>(a.rowRec) + (long long)b * kBurstMax * a.rowStep + (long long)I0u * kBlkRec);
     auto rowConst = [&](int st, int i) __attribute__((always_inline)) {
-        if constexpr (R > 1) return rowC + (long long)st * a.rowStep + (long long)min(i, nIu - 1) * kBlkRec;
+        if constexpr (R > 1) return rowC + (long long)(st * a.rowStep) + (long long)min(i, nIu - 1) * kBlkRec;
         else return (const T*)(sRow[wv][st & 1] + i * kBlkRec);  // wave-uniform: LDS broadcast reads
     };
     auto math = [&](int st) __attribute__((always_inline)) {
@@ -1089,7 +1089,7 @@ EQF_DI void burstRingBody(const BurstArgs& a, const int tileIdx, const int b) {
       if constexpr (R > 1) {
         static_assert(R == 1 || R % 2 == 0, "5 R chunks in groups of two");
         const int sl = st & 1;
-        CT* const base = rowC + (long long)st * a.rowStep;
+        CT* const base = rowC + (long long)(st * a.rowStep);
         auto chunkPtr = [&](int c) __attribute__((always_inline)) {
             const int i = c < 3 * R ? c / 3 : (c - 3 * R) % R;
             const int off = c < 3 * R ? 9 * (c % 3) : (c < 4 * R ? 27 : 36);
@@ -1374,10 +1374,10 @@ EQF_DI void burstRingFusedBody(const BurstArgs& a, const int tileIdx, const int 
             while (ldsFlagLoad(&sHave) < st + 1) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
             T x[kBlkRec + 3];
-            const T* cp = colRec + (long long)st * a.colStep;
+            const T* cp = colRec + (long long)(st * a.colStep);
 #pragma unroll
             for (int q = 0; q < kBlkRec; ++q) x[q] = cp[(long long)(q < 27 ? q : q + 18) * cap];
-            const T* rp = rowRec + (long long)st * a.rowStep;
+            const T* rp = rowRec + (long long)(st * a.rowStep);
 #pragma unroll
             for (int u = 0; u < 3; ++u) x[kBlkRec + u] = rp[rowOff[u]];
             if (st >= kSlots) {  // the slot was read by step st - 3: every arithmetic wave must be past it

@@ -470,8 +470,8 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     a.colRec = f->dColRec;
     a.rowRec = f->dRowRec;
     a.steps = f->dSteps;
-    a.colStep = burstRecStep((long long)kColRec * f->cap);
-    a.rowStep = burstRecStep((long long)kBlkRec * f->cap);
+    a.colStep = (int)burstRecStep((long long)kColRec * f->cap);
+    a.rowStep = (int)burstRecStep((long long)kBlkRec * f->cap);
     a.prm = f->prm;
     const int nmx = maxN(f);
     // builder: 4 landmarks per workgroup (its eight stages on eight wavefronts, shortest tick) while that launch fits the chip,
