@@ -257,6 +257,36 @@ def test_speculative_gate_on_frames_that_also_bring_new_landmarks(oracle_lib, hi
     assert fg.device_error() == 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [21, 70])
+def test_fused_burst_launch_with_two_filters_in_the_handle(hip, monkeypatch, N):
+    """k_burst_fused with more than one filter per handle (small N: every workgroup of both filters still has a CU of its own): the builder
+    flags, their replicas and the step records are per filter.  Two filters with different streams, bit for bit against the two launches."""
+    from eqf_vio_amd import synth
+
+    B = 2
+    sts = [synth.make_stream(N, seed=900 + b, duration=0.5) for b in range(B)]
+    d = synth.template_settings_dict()
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("EQF_BURST_FUSED", fused)
+        fg = hip.FilterBatch(d, capacity=N, batch=B)
+        seq = []
+        for kind, k in sts[0].events():
+            if kind == "imu":
+                fg.process_imu([s.imu[k, 0] for s in sts], [s.imu[k, 1:4] for s in sts], [s.imu[k, 4:7] for s in sts])
+            else:
+                fg.process_vision([s.vision_stamps[k] for s in sts], sts[0].ids, np.stack([s.bearings[k] for s in sts]))
+                seq.append(tuple(fg.sigma(b).copy() for b in range(B)) + tuple(fg.state_estimate(b)["x"].copy() for b in range(B)))
+        assert fg.device_error() == 0
+        outs.append(seq)
+    monkeypatch.delenv("EQF_BURST_FUSED")
+    assert len(outs[0]) == len(outs[1]) > 5
+    for f, (a, b) in enumerate(zip(*outs)):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v), (N, f)
+
+
 def test_reset_returns_to_the_constructed_state(hip):
     """eqf_reset: a handle that has run (landmarks, churned Sigma, advanced time) and is reset behaves bitwise like a
     fresh one."""
