@@ -749,7 +749,9 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         // the grid is many times the chip (OCC2)
         resPipeHeads = f->resPipeHeads >= 0 ? f->resPipeHeads != 0 : !residentFits;
         const double perCU = double(f->rolesCount) * B / std::max(f->numCUs, 1);
-        resOcc2 = resident && (f->resOcc2 >= 0 ? f->resOcc2 != 0 : (resPipeHeads && (perCU > 6.0 || (B >= 8 && perCU > 4.5))));
+        // (round 4, measured at N = 200: two per CU wins from 5 filters on -- 5 / 6 / 7 filters 217 -> 227 k, 242 -> 255 k, 270 -> 280 k steps/s -- and
+        // loses below: 4 filters 210 -> 195 k; one filter of N = 400, three roles per CU, 33.5 -> 32.5 k)
+        resOcc2 = resident && (f->resOcc2 >= 0 ? f->resOcc2 != 0 : (resPipeHeads && (perCU > 6.0 || (B >= 5 && perCU > 2.4))));
         resESigma = resOcc2 && resPipeHeads && perCU > 8.0;  // (8 filters of N = 200, 6.3 roles per CU: the kernel loses what the prep launch gains)
     }
     a.eFromSigma = (!resident && splitChain && f->cholTail && f->eFromSigma && f->precision != EQF_PRECISION_F32) ? 1 : 0;
