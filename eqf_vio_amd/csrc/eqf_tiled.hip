@@ -80,6 +80,9 @@ struct eqf_tiled {
     int* errflag = nullptr;
     int *rowMap = nullptr, *colMap = nullptr;
     int nlr = 0, nlc = 0;
+    // landmark slots (eqf_tiled.hpp): device flags, the host's copy of them, the marks of an edit
+    int *active = nullptr, *mark = nullptr;
+    std::vector<char> hostActive;
     // host mirror of the control flow (VIOFilter.cpp:120-131, :146-152, :234-236)
     double curTime = -1.0;
     bool init = false;
@@ -94,7 +97,7 @@ void freeTiled(eqf_tiled* t) {
         hipFree(t->Sb[q]);
     }
     for (void* p : {(void*)t->p0, (void*)t->lmc, (void*)t->blk, (void*)t->blkCommon, (void*)t->delta, (void*)t->Zrows, (void*)t->Vrows, (void*)t->Pg,
-             (void*)t->Lgi, (void*)t->gamma, (void*)t->gammaTot, (void*)t->dBear, (void*)t->dOut, (void*)t->errflag, (void*)t->rowMap, (void*)t->colMap})
+             (void*)t->Lgi, (void*)t->gamma, (void*)t->gammaTot, (void*)t->dBear, (void*)t->dOut, (void*)t->errflag, (void*)t->rowMap, (void*)t->colMap, (void*)t->active, (void*)t->mark})
         hipFree(p);
     delete t;
 }
@@ -135,6 +138,8 @@ int initTiledState(eqf_tiled* t) {
     }
     HIPC(hipMemset(t->p0, 0, sizeof(double) * 3 * t->cap));
     HIPC(hipMemset(t->errflag, 0, sizeof(int)));
+    HIPC(hipMemset(t->active, 0, sizeof(int) * t->cap));
+    t->hostActive.assign(t->cap, 0);
     t->pG = t->pB = 0;
     t->N = 0;
     t->curTime = -1.0;
@@ -165,6 +170,7 @@ TlArgs propArgs(eqf_tiled* t, const ImuRec& r, int isImu, double* Sll, int ldl) 
     a.nlc = t->nlc;
     a.rowMap = t->rowMap;
     a.colMap = t->colMap;
+    a.active = t->active;
     return a;
 }
 }  // namespace
@@ -223,6 +229,8 @@ int eqf_tiled_create(const eqf_settings* settings, int capacity_landmarks, int d
     chk(dmallocT(&t->errflag, 1));
     chk(dmallocT(&t->rowMap, cap));
     chk(dmallocT(&t->colMap, cap));
+    chk(dmallocT(&t->active, cap));
+    chk(dmallocT(&t->mark, cap));
     if (!rc) rc = initTiledState(t);
     if (!rc) rc = tileAttributes(device);
     if (rc) {
@@ -304,13 +312,57 @@ int eqf_tiled_add_landmarks(eqf_tiled* t, int n, const double* bearings, double*
     if (!ds.ok) return EQF_ERR_HIP;
     HIPC(hipMemcpyAsync(t->dBear, bearings, sizeof(double) * 3 * n, hipMemcpyHostToDevice, t->stream));
     hipLaunchKernelGGL(k_tl_append, dim3((n + 127) / 128), dim3(128), 0, t->stream, t->g[0], t->g[1], n, t->set.initialSceneDepth, t->cap, t->dBear, t->p0,
-        t->Q[0], t->Q[1], t->lmc, t->Sb[0], t->Sb[1], t->ldb, t->errflag);
+        t->Q[0], t->Q[1], t->lmc, t->Sb[0], t->Sb[1], t->ldb, t->active, t->errflag);
     if (t->nlr > 0 && t->nlc > 0)
         hipLaunchKernelGGL(k_tl_init_local, dim3((t->nlc + 127) / 128, t->nlr), dim3(128), 0, t->stream, Sll, ldl, t->nlr, t->nlc, t->rowMap, t->colMap,
             t->set.initialPointVariance);
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(t->stream));  // (bearings is pageable host memory)
     t->N = n;
+    std::fill(t->hostActive.begin(), t->hostActive.begin() + n, 1);
+    return EQF_OK;
+}
+
+int eqf_tiled_edit_landmarks(eqf_tiled* t, int n_remove, const int* remove_slots, int n_add, const int* add_slots, const double* add_bearings,
+    double depth, int new_num_slots, double* Sll, int ldl) {
+    if (!t || n_remove < 0 || n_add < 0 || (n_remove && !remove_slots) || (n_add && (!add_slots || !add_bearings))) return EQF_ERR_INVALID;
+    if (new_num_slots < 0 || !(depth > 0.0) || !std::isfinite(depth)) return EQF_ERR_INVALID;
+    if (new_num_slots > t->cap) return EQF_ERR_CAPACITY;
+    const int n = std::max(t->N, new_num_slots);  // slots the edit may touch
+    if (t->nlr > 0 && t->nlc > 0 && (!Sll || ldl < 3 * t->nlc)) return EQF_ERR_INVALID;
+    // argument errors before any effect: every removed slot holds a landmark, every added slot is free (or freed by this call)
+    std::vector<int> mark(t->cap, 0);  // (all of it is uploaded: the geometry in force may name any slot below the capacity)
+    std::vector<double> bear((size_t)3 * std::max(n, 1), 0.0);
+    for (int k = 0; k < n_remove; ++k) {
+        const int s = remove_slots[k];
+        if (s < 0 || s >= t->N || !t->hostActive[s] || mark[s]) return EQF_ERR_INVALID;
+        mark[s] = 1;
+    }
+    for (int k = 0; k < n_add; ++k) {
+        const int s = add_slots[k];
+        if (s < 0 || s >= new_num_slots || mark[s] == 2 || (s < t->N && t->hostActive[s] && mark[s] != 1)) return EQF_ERR_INVALID;
+        mark[s] = 2;
+        for (int c = 0; c < 3; ++c) bear[(size_t)3 * s + c] = add_bearings[(size_t)3 * k + c];
+    }
+    for (int s = new_num_slots; s < t->N; ++s)  // slots given up at the top must be empty after the edit
+        if (t->hostActive[s] && mark[s] != 1) return EQF_ERR_INVALID;
+    // the geometry must cover every slot in use before or after the edit: landmark blocks of marked slots are cleared through it
+    DeviceScope ds(t->device);
+    if (!ds.ok) return EQF_ERR_HIP;
+    HIPC(hipMemcpyAsync(t->mark, mark.data(), sizeof(int) * t->cap, hipMemcpyHostToDevice, t->stream));
+    if (n > 0) {
+        HIPC(hipMemcpyAsync(t->dBear, bear.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, t->stream));
+    }
+    hipLaunchKernelGGL(k_tl_edit_state, dim3((std::max(n, 1) + 127) / 128), dim3(128), 0, t->stream, t->g[0], t->g[1], n, new_num_slots, t->mark, depth,
+        t->cap, t->dBear, t->p0, t->Q[0], t->Q[1], t->lmc, t->Sb[0], t->Sb[1], t->ldb, t->active, t->errflag);
+    if (n > 0 && t->nlr > 0 && t->nlc > 0)
+        hipLaunchKernelGGL(k_tl_edit_local, dim3((t->nlc + 127) / 128, t->nlr), dim3(128), 0, t->stream, Sll, ldl, t->nlr, t->nlc, t->rowMap, t->colMap,
+            t->mark, t->set.initialPointVariance);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(t->stream));  // (mark / bear are pageable host memory)
+    for (int s = 0; s < n; ++s)
+        if (mark[s]) t->hostActive[s] = mark[s] == 2;
+    t->N = new_num_slots;
     return EQF_OK;
 }
 
@@ -345,6 +397,7 @@ int eqf_tiled_update_prep(eqf_tiled* t, const double* bearings, const double* Sl
     a.nlc = t->nlc;
     a.rowMap = t->rowMap;
     a.colMap = t->colMap;
+    a.active = t->active;
     a.M = M;
     a.ldm = ldm;
     a.E = E;
@@ -567,11 +620,14 @@ int eqf_tiled_set_state(eqf_tiled* t, int N, const double* pose_q, const double*
         HIPC(hipMemcpy(t->Sb[q], hb.data(), sizeof(double) * hb.size(), hipMemcpyHostToDevice));
     }
     HIPC(hipMemcpy(t->p0, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice));
+    HIPC(hipMemset(t->active, 0, sizeof(int) * cap));
     for (int q = 0; q < 2; ++q) {
-        hipLaunchKernelGGL(k_tl_restore, dim3(std::max(1, (N + 127) / 128)), dim3(128), 0, t->stream, t->g[q], t->p0, t->lmc, cap, t->errflag);
+        hipLaunchKernelGGL(k_tl_restore, dim3(std::max(1, (N + 127) / 128)), dim3(128), 0, t->stream, t->g[q], t->p0, t->lmc, cap, t->active, t->errflag);
     }
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(t->stream));
+    t->hostActive.assign(cap, 0);
+    std::fill(t->hostActive.begin(), t->hostActive.begin() + N, 1);
     t->N = N;
     t->curTime = currentTime;
     t->init = initialised != 0;

@@ -9,6 +9,12 @@
 //   distributed: its share  Sll  of the landmark x landmark part of Sigma, ScaLAPACK style: landmark blocks I = pr, pr + Pr, ... as
 //     rows and J = pc, pc + Pc, ... as columns of ONE dense local matrix (3 nlr x 3 nlc, row-major).  rowMap / colMap translate a
 //     local landmark index to the global one.
+//   landmark SLOTS: the partition is over N physical slots; a slot whose landmark was removed (removeOldLandmarks / removeOutliers,
+//     VIOFilter.cpp:393-443) stays where it is, INACTIVE: its rows and columns of Sigma are zero with a unit diagonal block, its
+//     linearisation is the identity (D = I, L = 0), its measurement rows are C = 0, delta = 0, Z = 0 -- so it is carried through both
+//     factorisations as a decoupled block that contributes exact zeros, and no row or column ever moves between ranks.  New landmarks
+//     take the lowest free slots (k_tl_edit_state / k_tl_edit_local).  The reference's ORDER of landmarks (insertion order) lives
+//     with the caller (eqf_vio_amd/tiled.py), as a permutation over the slots: the recursion is equivariant under it.
 //
 // Kernels (same device functions as the single-GPU path: stepCommon / buildBlocks / stepLandmark / stepGlobal of
 // eqf_propagate.hpp, liftRows / updateFinishBody of eqf_update.hpp, i.e. the same restatement of VIOFilter.cpp:146-209, :264-297,
@@ -54,6 +60,7 @@ struct TlArgs {
     int ldl, nlr, nlc;
     const int* rowMap;  // [nlr] local row landmark -> global landmark
     const int* colMap;  // [nlc]
+    const int* active;  // [cap] 1: the slot holds a landmark; 0: hole (see the header of this file)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -105,6 +112,7 @@ __global__ __launch_bounds__(128) void k_tl_build(TlArgs a) {
     const quat Qq = quat{a.Qin[i], a.Qin[cap + i], a.Qin[2 * cap + i], a.Qin[3 * cap + i]};
     const double Qa = a.Qin[4 * cap + i];
     const d3 q0 = mk3(a.p0[i], a.p0[cap + i], a.p0[2 * cap + i]);
+    const bool act = a.active[i] != 0;
     if (wv == 0) {
         if (riccati) {
             StepCommon c;
@@ -114,9 +122,10 @@ __global__ __launch_bounds__(128) void k_tl_build(TlArgs a) {
             double D[9], Lw[9], Lv[9];
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                D[k] = blk.D.a[k];
-                Lw[k] = blk.Lw.a[k];
-                Lv[k] = blk.Lv.a[k];
+                // a hole steps with the identity: its zero rows stay zero (only T p lands on its diagonal block)
+                D[k] = act ? blk.D.a[k] : ((k % 4 == 0) ? 1.0 : 0.0);
+                Lw[k] = act ? blk.Lw.a[k] : 0.0;
+                Lv[k] = act ? blk.Lv.a[k] : 0.0;
                 bp[k] = D[k];
                 bp[9 + k] = Lw[k];
                 bp[18 + k] = Lv[k];
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(128) void k_tl_build(TlArgs a) {
     } else {
         quat Qo = Qq;
         double ao = Qa;
-        if (step) {
+        if (step && act) {
             StepCommon c;
             stepCommon(G, r, a, c, kPartBase | kPartLift, &bad);
             stepLandmark(c, a, Qq, Qa, q0, &Qo, &ao, &bad);
@@ -385,6 +394,7 @@ struct TlUpdArgs {
     int ldl, nlr, nlc;
     const int* rowMap;
     const int* colMap;
+    const int* active;  // [cap]
     double* M;  // S-chain operand [2 nlr][ldm]: columns [0, 2 nlc) S, [2 nlc, 5 nlc) C Sigma, [5 nlc, 5 nlc + 18) narrow
     int ldm;
     double* E;  // E-chain operand [3 nlr][lde]: columns [0, 3 nlc) Schur complement, [3 nlc, 3 nlc + 11) narrow
@@ -398,6 +408,12 @@ __global__ __launch_bounds__(64) void k_tl_prep(TlUpdArgs a) {
     const int N = g.N, cap = a.cap;
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (!g.updateOk || i >= N) return;
+    if (!a.active[i]) {  // a hole measures nothing: with C = 0 (lmc) its two rows of S are R, everything else of it exact zeros
+        a.delta[2 * i] = a.delta[2 * i + 1] = 0.0;
+        for (int k = 0; k < 18; ++k) a.Zrows[(long long)i * 18 + k] = 0.0;
+        for (int k = 0; k < 12; ++k) a.Vrows[(long long)i * 12 + k] = 0.0;
+        return;
+    }
     const quat Qq = quat{a.Q[i], a.Q[cap + i], a.Q[2 * cap + i], a.Q[3 * cap + i]};
     const double Qa = a.Q[4 * cap + i];
     const d3 q0 = mk3(a.p0[i], a.p0[cap + i], a.p0[2 * cap + i]);
@@ -665,10 +681,11 @@ __global__ __launch_bounds__(256) void k_tl_finish(TlFinArgs a) {
 // addNewLandmarks on an EMPTY state (VIOFilter.cpp:345-391 with :361-366's initialSceneDepth branch): p0 = y depth, Q = identity,
 // constants; base panel columns zero.  grid = ceil(n / 128), block = 128.
 __global__ void k_tl_append(Glob* g0, Glob* g1, int n, double depth, int cap, const double* bearings, double* p0, double* Q0, double* Q1, double* lmc,
-    double* Sb0, double* Sb1, int ldb, int* errflag) {
+    double* Sb0, double* Sb1, int ldb, int* active, int* errflag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) g0->N = g1->N = n;
     if (i >= n) return;
+    active[i] = 1;
     const double* y = bearings + 3 * i;
     const d3 p = mk3(y[0] * depth, y[1] * depth, y[2] * depth);
     p0[i] = p.x; p0[cap + i] = p.y; p0[2 * cap + i] = p.z;
@@ -692,12 +709,59 @@ __global__ void k_tl_init_local(double* Sll, int ldl, int nlr, int nlc, const in
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) Sll[(long long)(3 * il + r) * ldl + 3 * jl + c] = (diag && r == c) ? pointVar : 0.0;
 }
+// ---------------------------------------------------------------------------------------------------------------------------
+// Landmark churn on slots (removeOldLandmarks / removeOutliers / addNewLandmarks, VIOFilter.cpp:345-443; which slots is the caller's
+// decision).  mark[i] = 1: slot i loses its landmark, 2: slot i receives the landmark with bearing bearings[3 i ..] at `depth` (the
+// median scene depth, :358-366), 0: untouched.  k_tl_edit_state: the replicated part -- origin landmark, group element (identity,
+// :377-381), constants, base panel columns (zero, :385-386), the slot's flag; newN slots are in use afterwards.  grid = ceil(n / 128).
+__global__ void k_tl_edit_state(Glob* g0, Glob* g1, int n, int newN, const int* mark, double depth, int cap, const double* bearings, double* p0,
+    double* Q0, double* Q1, double* lmc, double* Sb0, double* Sb1, int ldb, int* active, int* errflag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) g0->N = g1->N = newN;
+    if (i >= n) return;
+    const int m = mark[i];
+    if (m == 0) return;
+    int bad = 0;
+    d3 p = mk3(1.0, 0.0, 0.0);  // (a hole's origin landmark is never evaluated; any finite point away from the chart pole e3)
+    double cst[15];
+    if (m == 2) {
+        const double* y = bearings + 3 * i;
+        p = mk3(y[0] * depth, y[1] * depth, y[2] * depth);
+        landmarkConstants(p, cst, &bad);
+    } else {
+        for (int c = 0; c < 15; ++c) cst[c] = (c >= 6 && (c - 6) % 4 == 0) ? 1.0 : 0.0;  // C = 0, R_s = I
+    }
+    active[i] = m == 2 ? 1 : 0;
+    p0[i] = p.x; p0[cap + i] = p.y; p0[2 * cap + i] = p.z;
+    for (double* Q : {Q0, Q1}) {
+        Q[i] = 1.0; Q[cap + i] = 0.0; Q[2 * cap + i] = 0.0; Q[3 * cap + i] = 0.0; Q[4 * cap + i] = 1.0;
+    }
+    for (int c = 0; c < 15; ++c) lmc[(long long)c * cap + i] = cst[c];
+    for (double* Sb : {Sb0, Sb1})
+        for (int r = 0; r < 12; ++r)
+            for (int c = 0; c < 3; ++c) Sb[(long long)r * ldb + kLm0 + 3 * i + c] = 0.0;
+    if (bad && errflag) atomicOr(errflag, 16);
+}
+// ... and the rank's share of the landmark x landmark part: every 3 x 3 block in a marked row or column <- 0 (removeRows / removeCols of
+// :421-427, resp. the zero off-diagonal blocks of :384-386), the diagonal block of a marked slot <- I (hole) or initialPointVariance I
+// (:387-388).  grid = (ceil(nlc / 128), nlr), block = 128.
+__global__ void k_tl_edit_local(double* Sll, int ldl, int nlr, int nlc, const int* rowMap, const int* colMap, const int* mark, double pointVar) {
+    const int jl = blockIdx.x * blockDim.x + threadIdx.x, il = blockIdx.y;
+    if (jl >= nlc || il >= nlr) return;
+    const int I = rowMap[il], J = colMap[jl];
+    const int mi = mark[I], mj = mark[J];
+    if (!(mi | mj)) return;
+    const double dv = (I == J) ? (mi == 2 ? pointVar : 1.0) : 0.0;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Sll[(long long)(3 * il + r) * ldl + 3 * jl + c] = (r == c) ? dv : 0.0;
+}
 // constants after a state injection
-__global__ void k_tl_restore(Glob* g, const double* p0, double* lmc, int cap, int* errflag) {
+__global__ void k_tl_restore(Glob* g, const double* p0, double* lmc, int cap, int* active, int* errflag) {
     Glob& s = *g;
     int bad = 0;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     for (int i = tid; i < s.N; i += gridDim.x * blockDim.x) {
+        active[i] = 1;
         double cst[15];
         landmarkConstants(mk3(p0[i], p0[cap + i], p0[2 * cap + i]), cst, &bad);
         for (int c = 0; c < 15; ++c) lmc[(long long)c * cap + i] = cst[c];

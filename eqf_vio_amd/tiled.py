@@ -30,6 +30,14 @@ Per block row k (owner process row k mod Pr):
   A rank receives (1/Pr + 1/Pc) of every block row instead of all of it (SUMMA-restricted; the round-2 prototype gathered every panel
   to every rank): at N = 4000 on 2 x 4 that is 0.75 x (0.26 + 0.77) GB per update.
 
+Landmark churn (VIOFilter.cpp:345-443: removeOldLandmarks, removeOutliers, addNewLandmarks) works on SLOTS.  The partition is over
+physical landmark slots; a removed landmark leaves an INACTIVE slot where it was (zero rows / columns of Sigma with a unit diagonal
+block, identity linearisation, no measurement rows: both factorisations carry it along as a decoupled block of exact zeros), a new
+landmark takes the lowest free slot -- so no row or column of Sigma ever moves between ranks, and only the ranks that own a slot's blocks
+touch them.  The reference's landmark ORDER (insertion order, VIOFilter.cpp:211-230) is kept here, on the host, as the permutation
+`slot_of`; the recursion is equivariant under it, and every getter of TiledFilter answers in the reference's order.  The decisions --
+which ids left, which bearings fail the gate, the median scene depth -- are O(N) on the replicated state and identical on every rank.
+
 The tile mathematics is NOT here: `HipBackend` calls the HIP kernels through the C ABI (include/eqf_vio_amd.h, eqf_tiled_* /
 eqf_tile_*) on torch CUDA tensors' device pointers, and fails loudly without the library or a GPU.  The CPU tests drive the same
 schedule with a test double of the backend (tests/tiled_double.py) over gloo.
@@ -263,6 +271,22 @@ class HipBackend:
         self.b._check(self.lib.eqf_tiled_add_landmarks(self._h, len(y), self._dp(y), self._p(Sll), Sll.stride(0) if Sll is not None else 0),
                       "eqf_tiled_add_landmarks")
 
+    def edit_landmarks(self, remove_slots, add_slots, add_bearings, depth, new_num_slots, Sll):
+        """removeLandmarkAtIndex for remove_slots, then addNewLandmarks into add_slots (include/eqf_vio_amd.h: eqf_tiled_edit_landmarks);
+        the geometry in force must cover max(old, new) slots."""
+        self._sync_stream()
+        rs = np.ascontiguousarray(remove_slots, dtype=np.int32).reshape(-1)
+        ads = np.ascontiguousarray(add_slots, dtype=np.int32).reshape(-1)
+        y = np.ascontiguousarray(add_bearings, dtype=np.float64).reshape(-1, 3)
+        assert len(y) == len(ads)
+        ip = ctypes.POINTER(ctypes.c_int)
+        self.b._check(self.lib.eqf_tiled_edit_landmarks(self._h, len(rs), rs.ctypes.data_as(ip), len(ads), ads.ctypes.data_as(ip), self._dp(y), float(depth),
+                                                        int(new_num_slots), self._p(Sll), Sll.stride(0) if Sll is not None else 0),
+                      "eqf_tiled_edit_landmarks")
+
+    def initial_scene_depth(self):
+        return float(self.settings.initialSceneDepth)
+
     def update_prep(self, bearings, Sll, M, E, G11):
         self._sync_stream()
         y = np.ascontiguousarray(bearings, dtype=np.float64).reshape(-1, 3)
@@ -387,16 +411,14 @@ class HipBackend:
                                                    self._dp(av), float(st["accumulatedTime"]), int(st["initialised"])), "eqf_tiled_set_state")
 
 
-class TiledOutlierError(RuntimeError):
-    """A vision frame tripped the outlier gate of the fixed-landmark-set filter (TiledFilter._outlier_gate)."""
-
-
 class TiledFilter:
     """VIOFilter (VIOFilter.h:41-88) for one filter whose Sigma is partitioned over `grid`.  Every rank of the grid makes the same calls
-    with the same arguments.  `backend`: HipBackend (the product path), or the CPU test double."""
+    with the same arguments.  `backend`: HipBackend (the product path), or the CPU test double.  `capacity`: landmark slots the local
+    storage is sized for (default: the backend's capacity)."""
 
-    def __init__(self, grid, backend, block_landmarks):
+    def __init__(self, grid, backend, block_landmarks, capacity=None):
         self.g, self.be, self.bl = grid, backend, int(block_landmarks)
+        self.cap = int(capacity if capacity is not None else backend.cap)
         # the two factorisations of an update are independent: they run side by side on two streams, each with its own exchange buffers
         # and -- on more than one rank -- its own process groups (two communicators: collectives of different streams must not share one)
         # Two RCCL communicators with kernels in flight on different streams of one process can deadlock when the ranks' GPUs schedule them in
@@ -410,7 +432,13 @@ class TiledFilter:
         self.gE = ProcessGrid(grid.dist, grid.Pr, grid.Pc, grid.device) if grid.world > 1 else grid
         self.geo = None
         self.Sll = self.M = self.E = None
+        # landmark bookkeeping (host; identical on every rank): ids in the REFERENCE's order (X.id, VIOFilter.cpp:211-230), the slot of
+        # each, and which slots are taken.  nslots = slots in use = 1 + the highest taken slot (at least 1 once storage exists).
         self.ids = None
+        self.slot_of = np.zeros(0, dtype=np.int64)
+        self.taken = np.zeros(self.cap, dtype=bool)
+        self.nslots = 0
+        self.churn_stats = dict(removed_old=0, removed_outliers=0, added=0)
         self.lookahead = True  # factor the next diagonal block on a second stream in the shadow of the trailing update (_chain)
         self.phase_ms = None  # set to a dict to collect GPU time per phase (bench.py): {"propagate": ms, "prep": ms, "chain_S": ...}
         self._pending = []
@@ -441,43 +469,61 @@ class TiledFilter:
             self._pending = []
         return self.phase_ms
 
-    # ---- storage
-    def _alloc(self, N):
-        g, be = self.g, self.be
-        self.geo = geo = BlockCyclic(N, self.bl, g.Pr, g.Pc, g.pr, g.pc)
-        be.set_geometry(geo)
+    # ---- storage: allocated ONCE for `cap` slots; the working set is a view of it for the slots in use.  Growing the number of slots
+    # never moves a block: only the globally last block is ragged, so the local position of a slot does not depend on how many follow it.
+    def _alloc(self):
+        g, be, cap = self.g, self.be, self.cap
+        full = BlockCyclic(cap, self.bl, g.Pr, g.Pc, g.pr, g.pc)
         r16 = lambda x: (x + 15) // 16 * 16
-        self.Sll = be.zeros(max(3 * geo.nlr, 1), r16(max(3 * geo.nlc, 1)))[: 3 * geo.nlr, : 3 * geo.nlc]
-        self.M = be.empty(max(2 * geo.nlr, 1), r16(5 * geo.nlc + NARROW_S))[: 2 * geo.nlr, : 5 * geo.nlc + NARROW_S]
-        self.E = be.empty(max(3 * geo.nlr, 1), r16(3 * geo.nlc + NARROW_E))[: 3 * geo.nlr, : 3 * geo.nlc + NARROW_E]
+        self._Sll_buf = be.zeros(max(3 * full.nlr, 1), r16(max(3 * full.nlc, 1)))
+        self._M_buf = be.empty(max(2 * full.nlr, 1), r16(5 * full.nlc + NARROW_S))
+        self._E_buf = be.empty(max(3 * full.nlr, 1), r16(3 * full.nlc + NARROW_E))
         self.G11 = be.zeros(11, 11)
         # exchange buffers: a solved block row piece per process column of my row (B operand / contributions to the A operand)
-        bsmax = 3 * min(self.bl, N)
-        self._wmax = {c: 5 * geo.ncols_of(c) + NARROW_S for c in range(g.Pc)}
-        self._wmax_e = {c: 3 * geo.ncols_of(c) + NARROW_E for c in range(g.Pc)}
+        bsmax = 3 * min(self.bl, cap)
+        wmax = {c: 5 * full.ncols_of(c) + NARROW_S for c in range(g.Pc)}
+        wmax_e = {c: 3 * full.ncols_of(c) + NARROW_E for c in range(g.Pc)}
         mine = [c for c in range(g.Pc) if c == g.pc or c % g.Pr == g.pr]
         self._bufs = {  # per chain: solved block row pieces, the diagonal factor + records (double-buffered), the interleaved row operand
-            "S": dict(buf={c: be.empty(bsmax * self._wmax[c]) for c in mine},
-                      pack=[be.empty(bsmax * bsmax + ((bsmax + 63) // 64) * HipBackend.DREC) for _ in range(2)], aopA=be.empty(bsmax, max(3 * geo.nlr, 1))),
-            "E": dict(buf={c: be.empty(bsmax * self._wmax_e[c]) for c in mine},
-                      pack=[be.empty(bsmax * bsmax + ((bsmax + 63) // 64) * HipBackend.DREC) for _ in range(2)], aopA=be.empty(bsmax, max(3 * geo.nlr, 1))),
+            "S": dict(buf={c: be.empty(bsmax * wmax[c]) for c in mine},
+                      pack=[be.empty(bsmax * bsmax + ((bsmax + 63) // 64) * HipBackend.DREC) for _ in range(2)], aopA=be.empty(bsmax, max(3 * full.nlr, 1))),
+            "E": dict(buf={c: be.empty(bsmax * wmax_e[c]) for c in mine},
+                      pack=[be.empty(bsmax * bsmax + ((bsmax + 63) // 64) * HipBackend.DREC) for _ in range(2)], aopA=be.empty(bsmax, max(3 * full.nlr, 1))),
         }
-        self._aopW = be.empty(bsmax, max(3 * geo.nlr, 1))
+        self._aopW = be.empty(bsmax, max(3 * full.nlr, 1))
         # the downdate Sigma_IJ -= sum_k Y_kI^T Y_kJ is ONE product per update (K = m = 2 N: Sll is read and written once instead of once
         # per block row, and the product's prologue / epilogue are amortised): the solved block rows are kept -- the columns of my
         # process column (B operand) and of my row blocks (A operand; the same matrix on a symmetric rank)
         self.symmetric = g.Pr == g.Pc and g.pr == g.pc  # my row blocks ARE my column blocks: the local matrix is symmetric
-        self._Yc = be.empty(2 * N, max(3 * geo.nlc, 1))
-        self._Yr = self._Yc if self.symmetric else be.empty(2 * N, max(3 * geo.nlr, 1))
-        self._accS = be.zeros(NARROW_S, 3 * geo.nlc + NARROW_S)
+        self._Yc_buf = be.empty(2 * cap, max(3 * full.nlc, 1))
+        self._Yr_buf = self._Yc_buf if self.symmetric else be.empty(2 * cap, max(3 * full.nlr, 1))
+        self._accS_buf = be.zeros(NARROW_S, 3 * full.nlc + NARROW_S)
         self._accE = be.zeros(NARROW_E, NARROW_E)
+
+    def _set_slots(self, n):
+        """the working set for n >= 1 slots in use: geometry (host + device) and the views of the storage"""
+        g, be = self.g, self.be
+        if self.geo is not None and self.geo.N == n:
+            return
+        if self.geo is None:
+            self._alloc()
+        self.geo = geo = BlockCyclic(n, self.bl, g.Pr, g.Pc, g.pr, g.pc)
+        be.set_geometry(geo)
+        self.Sll = self._Sll_buf[: 3 * geo.nlr, : 3 * geo.nlc]
+        self.M = self._M_buf[: 2 * geo.nlr, : 5 * geo.nlc + NARROW_S]
+        self.E = self._E_buf[: 3 * geo.nlr, : 3 * geo.nlc + NARROW_E]
+        self._wmax = {c: 5 * geo.ncols_of(c) + NARROW_S for c in range(g.Pc)}
+        self._wmax_e = {c: 3 * geo.ncols_of(c) + NARROW_E for c in range(g.Pc)}
+        self._Yc = self._Yc_buf[: 2 * n, : 3 * geo.nlc]
+        self._Yr = self._Yc if self.symmetric else self._Yr_buf[: 2 * n, : 3 * geo.nlr]
+        self._accS = self._accS_buf[:, : 3 * geo.nlc + NARROW_S]
 
     # ---- VIOFilter::processIMUData (VIOFilter.cpp:120-131)
     def processIMUData(self, stamp, omega, accel):
         with self.be.main(), self._Phase(self, "propagate"):
             return self.be.propagate(stamp, omega, accel, True, self.Sll)
 
-    # ---- VIOFilter::processVisionData (VIOFilter.cpp:232-302) for a FIXED landmark set: the first frame defines it
+    # ---- VIOFilter::processVisionData (VIOFilter.cpp:232-302)
     def processVisionData(self, stamp, ids, bearings):
         with self.be.main():
             return self._process_vision(stamp, ids, bearings)
@@ -487,43 +533,70 @@ class TiledFilter:
         y = np.asarray(bearings, dtype=np.float64).reshape(-1, 3)
         if len(ids) != len(y) or (len(ids) > 1 and not np.all(np.diff(ids) > 0)):
             raise ValueError("bearings must come with strictly ascending ids (VIOFilter.cpp:239-240)")
-        if self.ids is not None and not np.array_equal(ids, self.ids):
-            raise NotImplementedError("the 2-D partitioned filter keeps the landmark set of its first frame (landmark churn lives in the "
-                                      "single-GPU path)")
         with self._Phase(self, "propagate"):
             st = self.be.propagate(stamp, None, None, False, self.Sll)  # :233 integrateUpToTime
         if st != 0:
             return st  # :234-236
-        if len(ids) == 0:
+        with self._Phase(self, "churn"):
+            y_slots = self._churn(ids, y)  # :242-249
+        if y_slots is None:
             return 4  # EQF_SKIPPED_NO_BEARINGS, :258-259
-        if self.ids is None:
-            self._alloc(len(ids))  # addNewLandmarks on the empty state, :345-391
-            self.be.add_landmarks(y, self.Sll)
-            self.ids = ids.copy()
-        else:
-            self._outlier_gate(y)
-        self._update(y)
+        self._update(y_slots)
         return 0
 
-    def _outlier_gate(self, y):
-        """removeOutliers (VIOFilter.cpp:429-443) for a landmark set that cannot change: the reference drops every landmark whose measured
-        bearing is further than settings.outlierThreshold (chord of unit vectors) from the estimated one BEFORE the update.  Dropping needs
-        landmark churn, which lives in the single-GPU path; fusing the outlier silently would leave the reference's trajectory.  So the gate
-        is evaluated -- O(N) on the replicated state, identical on every rank -- and a frame that trips it is REFUSED (TiledOutlierError,
-        raised on every rank before anything of the update has run).  A threshold >= 2 (no chord of unit vectors is longer) skips the test
-        and its readback."""
-        thr = self.be.outlier_threshold()
-        if not thr < 2.0:
-            return
-        p = np.asarray(self.be.state_estimate()["p"], dtype=np.float64).reshape(-1, 3)
-        yhat = p / np.linalg.norm(p, axis=1, keepdims=True)
-        chord = np.linalg.norm(y - yhat, axis=1)
-        bad = np.nonzero(chord > thr)[0]
-        if len(bad):
-            raise TiledOutlierError(
-                f"{len(bad)} bearing(s) beyond outlierThreshold={thr} (largest chord {chord.max():.3g}, first id {int(self.ids[bad[0]])}): "
-                "the reference removes these landmarks (VIOFilter.cpp:429-443); the 2-D partitioned filter keeps a fixed landmark set and "
-                "refuses the frame instead of fusing an outlier")
+    def _churn(self, ids, y):
+        """removeOldLandmarks, removeOutliers, addNewLandmarks (VIOFilter.cpp:242-249, :345-443) on slots.  Returns the bearings in SLOT
+        order (holes carry a dummy the device ignores), or None when no landmark is left to update with."""
+        be = self.be
+        have = self.ids if self.ids is not None else np.zeros(0, dtype=np.int64)
+        pos = np.searchsorted(ids, have)  # ids ascending: where each state id sits in the measurement, if it does
+        pos_c = np.minimum(pos, max(len(ids) - 1, 0))
+        seen = (ids[pos_c] == have) if len(ids) else np.zeros(len(have), dtype=bool)  # removeOldLandmarks :393-419
+        new_k = np.nonzero(~np.isin(ids, have))[0]  # measurement entries without a landmark, ascending ids (:211-230 puts them last)
+        keep = seen.copy()
+        depth = be.initial_scene_depth()
+        thr = be.outlier_threshold()
+        gate = thr < 2.0 and seen.any()  # (no chord of unit vectors is longer than 2: such a threshold switches the gate off, no readback)
+        if gate or (len(new_k) and seen.any()):
+            p = np.asarray(be.state_estimate()["p"], dtype=np.float64).reshape(-1, 3)[self.slot_of]  # reference order
+            if gate:  # removeOutliers :429-443: chord between the measured and the expected bearing
+                yhat = p / np.linalg.norm(p, axis=1, keepdims=True)
+                chord = np.linalg.norm(y[pos_c] - yhat, axis=1)
+                keep &= ~(chord > thr)
+            if len(new_k) and keep.any():  # median scene depth of what is left, :353-366 (nth_element at size / 2)
+                d2 = np.sort(np.sum(p[keep] * p[keep], axis=1))
+                depth = float(np.sqrt(d2[len(d2) // 2]))
+        n_old = int((~seen).sum())
+        n_out = int((seen & ~keep).sum())
+        remove_slots = self.slot_of[~keep]
+        taken = self.taken.copy()
+        taken[remove_slots] = False
+        free = np.nonzero(~taken)[0]
+        if len(new_k) > len(free):
+            raise RuntimeError(f"{int(taken.sum()) + len(new_k)} landmarks in view, the partitioned filter was created for {self.cap}")
+        add_slots = free[: len(new_k)]  # lowest free slots first: holes are refilled before the partition grows
+        taken[add_slots] = True
+        top = np.nonzero(taken)[0]
+        nslots = max(int(top[-1]) + 1 if len(top) else 0, 1)
+        if self.ids is None and len(new_k) == 0:
+            return None  # nothing yet, nothing to add: no storage either
+        if len(remove_slots) or len(add_slots):
+            self._set_slots(max(self.nslots, nslots))
+            be.edit_landmarks(remove_slots, add_slots, y[new_k], depth, nslots, self.Sll)
+            self._set_slots(nslots)
+            self.ids = np.concatenate([have[keep], ids[new_k]])
+            self.slot_of = np.concatenate([self.slot_of[keep], add_slots]).astype(np.int64)
+            self.taken, self.nslots = taken, nslots
+            self.churn_stats["removed_old"] += n_old
+            self.churn_stats["removed_outliers"] += n_out
+            self.churn_stats["added"] += len(new_k)
+        if len(self.ids) == 0:
+            return None
+        # the measurement in slot order: landmarks that stayed, then the new ones (:211-230 matchMeasurementsToState)
+        y_slots = np.zeros((self.nslots, 3))
+        y_slots[:, 2] = 1.0
+        y_slots[self.slot_of] = np.concatenate([y[pos_c[keep]], y[new_k]]) if len(self.ids) else y[:0]
+        return y_slots
 
     def initialise_from(self, st):
         """Restart from a single-GPU snapshot (FilterBatch.dump_state(); every rank holds the dense Sigma once, here)."""
@@ -532,14 +605,20 @@ class TiledFilter:
             self._initialise_from(st, N)
 
     def _initialise_from(self, st, N):
-        self._alloc(N)
+        if N > self.cap:
+            raise RuntimeError(f"snapshot with {N} landmarks, the partitioned filter was created for {self.cap}")
+        self._set_slots(max(N, 1))
         S = torch.as_tensor(np.asarray(st["sigma"]), dtype=torch.float64)
         rows = torch.as_tensor(np.repeat(3 * self.geo.rowMap.astype(np.int64), 3) + np.tile(np.arange(3), self.geo.nlr) + 11)
         cols = torch.as_tensor(np.repeat(3 * self.geo.colMap.astype(np.int64), 3) + np.tile(np.arange(3), self.geo.nlc) + 11)
-        if self.geo.nlr and self.geo.nlc:
+        if N and self.geo.nlr and self.geo.nlc:
             self.Sll.copy_(S[rows][:, cols].to(self.Sll.device))
         self.be.set_state(st)
         self.ids = np.asarray(st["ids"], dtype=np.int64)
+        self.slot_of = np.arange(N, dtype=np.int64)  # the snapshot's order is the reference's: slot i = landmark i
+        self.taken = np.zeros(self.cap, dtype=bool)
+        self.taken[:N] = True
+        self.nslots = N
 
     # ---- the update
     def _update(self, y):
@@ -732,11 +811,39 @@ class TiledFilter:
     def getTime(self):
         return self.be.time()
 
+    def _coords(self, unit, base):
+        """coordinates of the landmarks, reference order, in a slot-ordered vector with `unit` entries per slot after `base` leading ones"""
+        return (base + unit * np.repeat(self.slot_of, unit) + np.tile(np.arange(unit), len(self.slot_of))).astype(np.int64)
+
     def stateEstimate(self):
-        return self.be.state_estimate()
+        """VIOFilter::stateEstimate (:304): landmarks in the reference's order"""
+        e = dict(self.be.state_estimate())
+        e["p"] = np.asarray(e["p"]).reshape(-1, 3)[self.slot_of]
+        e["ids"] = self.ids.copy() if self.ids is not None else np.zeros(0, dtype=np.int64)
+        return e
+
+    def bias(self):
+        return self.be.bias()
+
+    def lastUpdate(self):
+        """delta (2 N), gamma (11 + 3 N), Gamma (9 + 3 N) of the last update, landmarks in the reference's order"""
+        lu = self.be.last_update()
+        out = {"delta": np.asarray(lu["delta"])[self._coords(2, 0)]}
+        out["gamma"] = np.concatenate([np.asarray(lu["gamma"])[:11], np.asarray(lu["gamma"])[self._coords(3, 11)]])
+        G = lu.get("Gamma")
+        out["Gamma"] = None if G is None else np.concatenate([np.asarray(G)[:9], np.asarray(G)[self._coords(3, 9)]])
+        return out
 
     def stateCovariance(self):
-        """Dense Sigma (reference index map) gathered to every rank -- tests and snapshots (VIOFilter::stateCovariance, :306-309)."""
+        """Dense Sigma (reference index map and landmark order) gathered to every rank -- tests and snapshots
+        (VIOFilter::stateCovariance, :306-309)."""
+        with self.be.main():
+            S = self._state_covariance()
+        idx = np.concatenate([np.arange(11), self._coords(3, 11)])
+        return S[np.ix_(idx, idx)]
+
+    def slotCovariance(self):
+        """Dense Sigma over ALL slots in use, holes included (slot order) -- tests of the hole invariants."""
         with self.be.main():
             return self._state_covariance()
 
@@ -745,7 +852,7 @@ class TiledFilter:
         N = geo.N
         n = 11 + 3 * N
         S = np.zeros((n, n))
-        base = self.be.base_rows()
+        base = np.asarray(self.be.base_rows())[:, :n]
         S[:, :11] = base.T  # (only the base ROWS are kept: the columns are their transpose)
         S[:11, :] = base
         rmax = 3 * max(len(BlockCyclic(N, self.bl, g.Pr, g.Pc, r, 0).rowMap) for r in range(g.Pr))

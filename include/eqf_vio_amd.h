@@ -204,8 +204,12 @@ const char* eqf_profile_class_name(int cls);
  * rank advances its own identical copy inside its eqf_tiled handle, with the same device functions as the single-GPU path.  The
  * exchange schedule (which block row is factored where, the RCCL broadcasts of the solved block rows) is eqf_vio_amd/tiled.py; the
  * entry points below are what a rank runs between two exchanges.  They enqueue on the handle's stream (eqf_tiled_set_stream; NULL = the
- * default stream) and return; getters synchronise.  fp64 only.  The landmark set is fixed by the first vision frame (or by
- * eqf_tiled_set_state): landmark churn (VIOFilter.cpp:345-443) lives in the single-GPU path, this is the fixed-N throughput configuration.
+ * default stream) and return; getters synchronise.  fp64 only.
+ * Landmark churn (VIOFilter.cpp:345-443) works on SLOTS: the partition is over the handle's N physical landmark slots, a removed
+ * landmark leaves an inactive slot behind (zero rows / columns of Sigma with a unit diagonal block, identity linearisation, no
+ * measurement rows: a decoupled block that both factorisations carry along as exact zeros), a new landmark takes a free slot -- nothing
+ * ever moves between ranks (eqf_tiled_edit_landmarks).  Which landmark sits in which slot, and the reference's landmark ORDER, are the
+ * caller's (eqf_vio_amd/tiled.py: TiledFilter); every per-landmark array of the getters below is in SLOT order, holes included.
  * ================================================================================================================================ */
 typedef struct eqf_tiled eqf_tiled; /* opaque */
 
@@ -225,6 +229,15 @@ int eqf_tiled_propagate(eqf_tiled* t, double stamp, const double* omega, const d
  * bearings[n][3] host memory.  Sll (geometry set for n landmarks) is initialised: initialPointVariance on the diagonal.
  * EQF_ERR_UNSUPPORTED if the filter already has landmarks. */
 int eqf_tiled_add_landmarks(eqf_tiled* t, int n, const double* bearings, double* Sll, int ldl);
+/* removeLandmarkAtIndex (VIOFilter.cpp:421-427; called by removeOldLandmarks :393-419 and removeOutliers :429-443) for the n_remove
+ * slots remove_slots[], then addNewLandmarks (:345-391) into the n_add free slots add_slots[] (slots freed by this very call included):
+ * p0 = add_bearings[k] * depth (the caller's median scene depth, :358-366), Q = identity, zero cross-covariances,
+ * initialPointVariance I on the diagonal.  new_num_slots = slots in use afterwards (>= 1 + the highest active slot; eqf_tiled_num_landmarks
+ * returns it).  The geometry in force (eqf_tiled_set_geometry) must cover max(old, new) slots -- the rank's blocks of the marked slots
+ * are cleared in Sll through it; shrink the geometry AFTER the call.  Host arrays; synchronises.  EQF_ERR_INVALID (before any effect) if
+ * a removed slot is empty, an added slot taken, or an active slot would fall above new_num_slots; EQF_ERR_CAPACITY beyond the capacity. */
+int eqf_tiled_edit_landmarks(eqf_tiled* t, int n_remove, const int* remove_slots, int n_add, const int* add_slots,
+    const double* add_bearings, double depth, int new_num_slots, double* Sll, int ldl);
 /* First half of the update (VIOFilter.cpp:264-277, EqFMatrices.cpp:319-344, :221-235): residual, C0i, lift rows; then the operands of
  * the two factorisations from the local blocks:
  *   M (2 nlr x ldm): columns [0, 2 nlc) S_IJ = C_I Sigma_IJ C_J^T (+ measurementVariance on the global diagonal), [2 nlc, 5 nlc)
@@ -232,7 +245,7 @@ int eqf_tiled_add_landmarks(eqf_tiled* t, int n, const double* bearings, double*
  *   E (3 nlr x lde): columns [0, 3 nlc) Sigma_IJ - Pg_I^T Pg_J (Schur complement of Sigma_e = Sigma[6:, 6:] after its five base
  *     coordinates, EqFMatrices.cpp:239), [3 nlc, 3 nlc + 11) [Z_I (6) | -Pg_I^T Lg^-1 (5)];  G11 (11 x 11): the base part of
  *     [Zt | Et]^T [Zt | Et].
- * bearings[N][3] host memory, in state order (ids ascending = insertion order for the fixed set). */
+ * bearings[N][3] host memory, in SLOT order (an inactive slot's entry is ignored). */
 int eqf_tiled_update_prep(eqf_tiled* t, const double* bearings, const double* Sll, int ldl, double* M, int ldm, double* E, int lde,
     double* G11);
 /* Second half (VIOFilter.cpp:279-297, EqFMatrices.cpp:173-275): acc (18 x ldacc, columns = 3 N in GLOBAL landmark order) = sum_k

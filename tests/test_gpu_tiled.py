@@ -368,3 +368,177 @@ def test_tiled_filter_multi_rank_grids_with_the_hip_kernels(tmp_path, Pr, Pc, N,
         S, pose, gamma, n_upd, err = np.load(tmp_path / f"w_{r}.npy")
         assert n_upd >= 3 and err == 0
         assert S < 1e-9 and pose < 1e-8 and gamma < 1e-8, (r, S, pose, gamma)
+
+
+# ---- landmark churn in the partitioned filter (VIOFilter.cpp:345-443 on slots: eqf_tiled_edit_landmarks) ----------------------------------
+def _drive_churn(tf, fo, st, meas, fg=None):
+    """closed loop with a changing landmark set; after every frame ids (reference order), Sigma, state, bias, innovation against the oracle
+    (and Sigma against the single-GPU product path), and the inactive slots decoupled exactly"""
+    rel = lambda A, B: float(np.linalg.norm(A - B) / np.linalg.norm(B))
+    worst = dict(S=0.0, S_product=0.0, pose=0.0, gamma=0.0, Gamma=0.0, delta=0.0, hole=0.0)
+    n_upd, sizes = 0, set()
+    for kind, k in st.events():
+        if kind == "imu":
+            r = st.imu[k]
+            fo.processIMUData(r[0], r[1:4], r[4:7])
+            tf.processIMUData(r[0], r[1:4], r[4:7])
+            if fg is not None:
+                fg.process_imu([r[0]], r[1:4], r[4:7])
+            continue
+        ids, y = meas[k]
+        fo.processVisionData(st.vision_stamps[k], ids, y)
+        assert tf.processVisionData(st.vision_stamps[k], ids, y) == 0
+        if fg is not None:
+            fg.process_vision([st.vision_stamps[k]], ids, y)
+        n_upd += 1
+        assert np.array_equal(tf.ids, fo.ids()), (k, tf.ids, fo.ids())
+        sizes.add(len(tf.ids))
+        St = tf.stateCovariance()
+        worst["S"] = max(worst["S"], rel(St, fo.stateCovariance()))
+        if fg is not None:
+            worst["S_product"] = max(worst["S_product"], rel(St, fg.sigma()))
+        eo, et = fo.stateEstimate(), tf.stateEstimate()
+        worst["pose"] = max(worst["pose"], float(np.abs(eo["x"] - et["x"]).max()), float(np.abs(eo["q"] - et["q"]).max()),
+                            float(np.abs(eo["p"] - et["p"]).max()), float(np.abs(fo.bias() - tf.bias()).max()))
+        lo, lt = fo.last_update(), tf.lastUpdate()
+        for key in ("delta", "gamma", "Gamma"):
+            worst[key] = max(worst[key], float(np.abs(lo[key] - lt[key]).max() / max(1.0, np.abs(lo[key]).max())))
+        Sfull = tf.slotCovariance()
+        for s_ in np.nonzero(~tf.taken[: tf.nslots])[0]:
+            blk = Sfull[11 + 3 * s_: 14 + 3 * s_].copy()
+            dg = blk[:, 11 + 3 * s_: 14 + 3 * s_].copy()
+            blk[:, 11 + 3 * s_: 14 + 3 * s_] = 0.0
+            worst["hole"] = max(worst["hole"], float(np.abs(blk).max()), float(np.abs(dg - dg[0, 0] * np.eye(3)).max()))
+            assert dg[0, 0] >= 1.0
+    return worst, n_upd, sizes
+
+
+@pytest.mark.parametrize("N,bl,cap", [(40, 8, 40), (150, 32, 160), (150, 64, 150)])
+def test_tiled_filter_landmark_churn_and_outlier_gate_on_the_gpu(oracle_lib, N, bl, cap):
+    """1 x 1 grid, HIP kernels: landmarks enter and leave the field of view, three frames carry a bearing 0.05 rad off, the gate at the
+    reference default 0.01 -- the slots of the partitioned filter against the dense oracle AND against the single-GPU product path (which
+    compacts its Sigma instead, csrc/eqf_churn.hpp)."""
+    from eqf_vio_amd import binding, synth, tiled
+
+    d = synth.template_settings_dict()
+    d["outlierThreshold"] = 0.01
+    st = synth.make_stream(N, duration=0.66)
+    meas = synth.churn_measurements(st, seed=11, outlier_frames=(4, 7, 8), outlier_angle=0.05)
+    be = tiled.HipBackend(d, capacity=cap)
+    tf = tiled.TiledFilter(tiled.ProcessGrid(None, 1, 1, device=be.device), be, bl)
+    fo = oracle_lib.OracleFilter(d)
+    fg = binding.FilterBatch(d, capacity=N, batch=1)
+    worst, n_upd, sizes = _drive_churn(tf, fo, st, meas, fg)
+    cs = tf.churn_stats
+    assert n_upd >= 12 and cs["removed_old"] >= 3 and cs["removed_outliers"] >= 2 and cs["added"] > N // 3 and len(sizes) >= 3, (cs, sizes)
+    assert be.device_error() == 0 and fg.device_error() == 0
+    assert worst["S"] <= 1e-9 and worst["S_product"] <= 1e-9 and worst["pose"] <= 1e-8, worst
+    assert worst["delta"] <= 1e-10 and worst["gamma"] <= 1e-8 and worst["Gamma"] <= 1e-8, worst
+    assert worst["hole"] == 0.0  # exact zeros: a hole never couples to anything
+
+
+def test_tiled_edit_landmarks_argument_errors_come_before_any_effect():
+    """eqf_tiled_edit_landmarks through the C ABI: removing an empty slot, adding into a taken one, leaving an active slot above the new
+    slot count, exceeding the capacity -- refused with the handle untouched; then a valid edit."""
+    import ctypes
+
+    import torch
+
+    from eqf_vio_amd import binding, synth, tiled
+
+    d = synth.template_settings_dict()
+    be = tiled.HipBackend(d, capacity=12)
+    tf = tiled.TiledFilter(tiled.ProcessGrid(None, 1, 1, device=be.device), be, 4)
+    st = synth.make_stream(8, duration=0.06)
+    for kind, k in st.events():
+        if kind == "imu":
+            r = st.imu[k]
+            tf.processIMUData(r[0], r[1:4], r[4:7])
+        else:
+            assert tf.processVisionData(st.vision_stamps[k], st.ids, st.bearings[k]) == 0
+            break
+    S0, e0 = tf.stateCovariance(), tf.stateEstimate()
+    lib, ip = be.lib, ctypes.POINTER(ctypes.c_int)
+    y = np.ascontiguousarray(st.bearings[0][:2])
+    Sll = tf.Sll
+
+    def edit(rem, add, nb, depth=1.0):
+        r = np.asarray(rem, dtype=np.int32)
+        a = np.asarray(add, dtype=np.int32)
+        return lib.eqf_tiled_edit_landmarks(be._h, len(r), r.ctypes.data_as(ip), len(a), a.ctypes.data_as(ip), be._dp(y), depth, nb, be._p(Sll), Sll.stride(0))
+
+    tf._set_slots(12)
+    Sll = tf.Sll
+    assert edit([9], [], 8) == -1            # slot 9 is empty
+    assert edit([], [3], 8) == -1            # slot 3 is taken
+    assert edit([2, 2], [], 8) == -1         # twice
+    assert edit([], [8, 8], 10) == -1        # twice
+    assert edit([], [], 6) == -1             # slots 6, 7 hold landmarks
+    assert edit([], [8], 13) == -4           # EQF_ERR_CAPACITY
+    assert edit([], [8], 9, depth=0.0) == -1
+    tf._set_slots(8)
+    assert np.array_equal(tf.stateCovariance(), S0) and np.array_equal(tf.stateEstimate()["p"], e0["p"])
+    assert be.num_landmarks() == 8
+    tf._set_slots(9)
+    Sll = tf.Sll
+    assert edit([3], [3, 8], 9, depth=2.0) == 0  # a slot freed by the call may be refilled by it
+    torch.cuda.synchronize()
+    assert be.num_landmarks() == 9
+    p = be.state_estimate()["p"]
+    assert np.allclose(p[3], 2.0 * y[0], atol=1e-14) and np.allclose(p[8], 2.0 * y[1], atol=1e-14)
+
+
+def _multi_rank_churn_worker(rank, world, port, Pr, Pc, N, bl, cap, out_dir):
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch.distributed as dist
+
+    from eqf_vio_amd import synth, tiled
+    from oracle import binding as ob
+    from test_gpu_tiled import _drive_churn
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = synth.template_settings_dict()
+    d["outlierThreshold"] = 0.01
+    be = tiled.HipBackend(d, capacity=cap, device_index=0, reserve_cus=0)
+    tf = tiled.TiledFilter(tiled.ProcessGrid(dist, Pr, Pc, device=be.device), be, bl)
+    tf.lookahead = False
+    fo = ob.OracleFilter(d)
+    st = synth.make_stream(N, duration=0.46)
+    meas = synth.churn_measurements(st, seed=11, outlier_frames=(3, 6), outlier_angle=0.05)
+    worst, n_upd, sizes = _drive_churn(tf, fo, st, meas)
+    cs = tf.churn_stats
+    np.save(os.path.join(out_dir, f"c_{rank}.npy"), np.array([worst["S"], worst["pose"], worst["gamma"], worst["hole"], n_upd, be.device_error(),
+                                                              cs["removed_old"], cs["removed_outliers"], cs["added"]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("Pr,Pc,N,bl,cap", [(2, 2, 44, 8, 48), (2, 4, 70, 8, 70)])
+def test_tiled_filter_landmark_churn_on_multi_rank_grids_with_the_hip_kernels(tmp_path, Pr, Pc, N, bl, cap):
+    """The slot edits on block-cyclic local matrices with Pr, Pc > 1 (every rank clears its own blocks of a marked slot, nothing moves
+    between ranks): Pr x Pc processes share the one MI355X, broadcasts over gloo; every rank against the dense oracle."""
+    import gc
+    import socket
+
+    import torch
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = Pr * Pc
+    gc.collect()
+    torch.cuda.synchronize()
+    mp.spawn(_multi_rank_churn_worker, args=(world, port, Pr, Pc, N, bl, cap, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        S, pose, gamma, hole, n_upd, err, rem_old, rem_out, added = np.load(tmp_path / f"c_{r}.npy")
+        assert n_upd >= 8 and err == 0 and rem_old >= 2 and rem_out >= 1 and added > N // 3
+        assert S < 1e-9 and pose < 1e-8 and gamma < 1e-8 and hole == 0.0, (r, S, pose, gamma, hole)

@@ -6,6 +6,8 @@ What the double computes per call is written to mirror csrc/eqf_tiled.hpp one to
 
     propagate      <-> k_tl_build + k_tl_base + k_tl_riccati     (VIOFilter.cpp:146-209)
     add_landmarks  <-> k_tl_append + k_tl_init_local             (VIOFilter.cpp:345-391 on an empty state)
+    edit_landmarks <-> k_tl_edit_state + k_tl_edit_local         (VIOFilter.cpp:345-443 on landmark SLOTS: a removed landmark leaves an
+                                                                  inactive slot -- zero rows / columns, unit diagonal, D = I, L = 0, C = 0)
     update_prep    <-> k_tl_prep + k_tl_eprep + k_tl_form_s + k_tl_form_e
     update_finish  <-> k_tl_finish (updateFinishBody)            (EqFMatrices.cpp:173-275, VIOFilter.cpp:295-296)
     potrf / trsm_left / gemm_tn <-> eqf_tile_potrf / eqf_tile_trsm / eqf_tile_gemm_tn
@@ -38,6 +40,7 @@ class NumpyBackend:
         self.Sb = np.zeros((11, 0))          # replicated base rows of the landmark columns
         self._info = 0
         self.last = {}
+        self.active = np.zeros(0, dtype=bool)  # per slot: holds a landmark
 
     # ---- plumbing
     def zeros(self, *shape):
@@ -90,6 +93,10 @@ class NumpyBackend:
             F = np.eye(n) + Ab * T
             Bn = np.zeros((n, 6))
             Bn[6:] = Bt
+            for i in np.nonzero(~self.active)[0]:  # a hole steps with the identity (k_tl_build): D = I, L = 0, no input noise
+                F[11 + 3 * i: 14 + 3 * i, :] = 0.0
+                F[11 + 3 * i: 14 + 3 * i, 11 + 3 * i: 14 + 3 * i] = np.eye(3)
+                Bn[11 + 3 * i: 14 + 3 * i] = 0.0
             R = np.array([s.velOmegaVariance] * 3 + [s.velAccelVariance] * 3)
             P = np.array([s.biasOmegaProcessVariance] * 3 + [s.biasAccelProcessVariance] * 3 + [s.gravityProcessVariance] * 2
                          + [s.velocityProcessVariance] * 3 + [s.pointProcessVariance] * (3 * N))
@@ -109,6 +116,8 @@ class NumpyBackend:
             f.X = f.X * O.lift_velocity_discrete(currentState, f.currentVelocity, dt)
         else:
             f.X = f.X * O.vio_exp(dt * O.lift_velocity(currentState, f.currentVelocity))
+        for i in np.nonzero(~self.active)[0]:
+            f.X.Q[i] = O.SOT3()
         f.currentTime = newTime
         return 0
 
@@ -123,11 +132,57 @@ class NumpyBackend:
         f.X.ids = ids.copy()
         f.X.Q = [O.SOT3() for _ in range(N)]
         self.Sb = np.zeros((11, 3 * N))
+        self.active = np.ones(N, dtype=bool)
         if Sll is not None and Sll.numel():
             Sl = Sll.numpy()
             Sl[...] = 0.0
             eq = self.rows[:, None] == self.cols[None, :]
             Sl[eq] = f.settings.initialPointVariance
+
+    def initial_scene_depth(self):
+        return float(self.f.settings.initialSceneDepth)
+
+    def edit_landmarks(self, remove_slots, add_slots, add_bearings, depth, new_num_slots, Sll):
+        f = self.f
+        oldN = len(f.xi0.ids)
+        n = max(oldN, int(new_num_slots))
+        assert self.geo.N == n, "the geometry in force must cover max(old, new) slots"
+        hole = np.array([1.0, 0.0, 0.0])
+        if n > oldN:
+            f.xi0.p = np.vstack([f.xi0.p.reshape(-1, 3), np.tile(hole, (n - oldN, 1))])
+            f.X.Q = list(f.X.Q) + [O.SOT3() for _ in range(n - oldN)]
+            self.Sb = np.hstack([self.Sb, np.zeros((11, 3 * (n - oldN)))])
+            self.active = np.concatenate([self.active, np.zeros(n - oldN, dtype=bool)])
+        mark = np.zeros(n, dtype=int)
+        for s_ in np.asarray(remove_slots, dtype=int):
+            assert self.active[s_] and mark[s_] == 0
+            mark[s_] = 1
+            f.xi0.p[s_] = hole
+        y = np.asarray(add_bearings, dtype=float).reshape(-1, 3)
+        for k, s_ in enumerate(np.asarray(add_slots, dtype=int)):
+            assert (not self.active[s_] or mark[s_] == 1) and mark[s_] != 2 and s_ < new_num_slots
+            mark[s_] = 2
+            f.xi0.p[s_] = y[k] * depth
+        for s_ in np.nonzero(mark)[0]:
+            f.X.Q[s_] = O.SOT3()
+            self.Sb[:, 3 * s_: 3 * s_ + 3] = 0.0
+            self.active[s_] = mark[s_] == 2
+        if Sll is not None and Sll.numel():
+            Sl = Sll.numpy()
+            mr, mc = mark[self.rows // 3], mark[self.cols // 3]
+            Sl[mr > 0, :] = 0.0
+            Sl[:, mc > 0] = 0.0
+            eq = self.rows[:, None] == self.cols[None, :]
+            Sl[eq & (mr[:, None] == 1)] = 1.0
+            Sl[eq & (mr[:, None] == 2)] = f.settings.initialPointVariance
+        assert not self.active[new_num_slots:].any()
+        n = int(new_num_slots)
+        f.xi0.p = f.xi0.p[:n].copy()
+        f.X.Q = list(f.X.Q)[:n]
+        self.Sb = self.Sb[:, : 3 * n].copy()
+        self.active = self.active[:n].copy()
+        f.xi0.ids = np.arange(n, dtype=np.int64)
+        f.X.ids = np.arange(n, dtype=np.int64)
 
     # ---- first half of the update
     def _lift_rows(self):
@@ -155,6 +210,10 @@ class NumpyBackend:
         delta = O.output_coordinate_chart(O.output_group_action(f.X.inverse(), y), y0)
         C0 = O.eqf_output_matrix_C(f.xi0)[:, 5:]        # (2N x 3N), block diagonal
         Z = self._lift_rows()
+        for i in np.nonzero(~self.active)[0]:  # a hole measures nothing (k_tl_prep, lmc = 0)
+            delta[2 * i: 2 * i + 2] = 0.0
+            C0[2 * i: 2 * i + 2, :] = 0.0
+            Z[3 * i: 3 * i + 3] = 0.0
         V = C0 @ Z
         self.last = {"delta": delta}
         r, c = self.rows, self.cols
