@@ -500,6 +500,38 @@ def tiled_leg(args, dist, rank, world, device):
     if world > 1:
         out["note"] += "; UNMEASURED on more than one GPU until a node is available to the builder -- this line is then the first measurement"
     del tf, be
+    # Landmark churn in the partitioned filter (VIOFilter.cpp:345-443 on slots, eqf_tiled_edit_landmarks) with the outlier gate at the
+    # reference default: the same frames, but every frame `turn` landmarks (1 %) are out of view and the ones hidden a frame earlier come
+    # back as new landmarks.  A fresh filter (the gate is a setting of the handle); one warm-up frame, then the timed frames.
+    try:
+        dc = dict(d)
+        dc["outlierThreshold"] = 0.01
+        be = tiled.HipBackend(dc, capacity=N, device_index=device)
+        tf = tiled.TiledFilter(tiled.ProcessGrid(dist if world > 1 else None, Pr, Pc, device=be.device), be, bl)
+        tf.check_every = 0
+        turn = max(N // 100, 1)
+        frame_no = [0]
+
+        def vis_churn(stamp, ids, y):
+            f = frame_no[0]
+            frame_no[0] += 1
+            hidden = (np.arange(turn) + f * turn) % N
+            vis = np.ones(N, dtype=bool)
+            vis[hidden] = False
+            return tf.processVisionData(stamp, ids[vis], y[vis])
+
+        dtc = timed_run(tf.processIMUData, vis_churn, lambda: torch.cuda.synchronize())
+        tf.check()
+        cs = tf.churn_stats
+        out["churn"] = {"value": len(timed) / dtc, "unit": "steps/s", "ms_per_frame": dtc * 1e3 / max(n_vis, 1), "vs_fixed_set": dt / dtc,
+                        "outlierThreshold": 0.01, "landmarks_in_view": N - turn, "slots_in_use": int(tf.nslots),
+                        "removed_old": cs["removed_old"], "removed_outliers": cs["removed_outliers"], "added": cs["added"] - N + turn,
+                        "device_error_flag": be.device_error(),
+                        "note": "per frame %d landmarks leave and %d enter (slots: a removed landmark leaves a decoupled hole, the next new one "
+                                "refills it; nothing moves between ranks), gate evaluated on the replicated state every frame" % (turn, turn)}
+        del tf, be
+    except Exception as e:  # the fixed-set figure above stands on its own
+        out["churn"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if world == 1 and rank == 0:
         fb = binding.FilterBatch(d, capacity=N, batch=1, device=device)
         dtm = timed_run(lambda s_, w_, a_: fb.process_imu([s_], w_, a_), lambda s_, i_, y_: fb.process_vision([s_], i_, y_), fb.synchronize)

@@ -542,3 +542,45 @@ def test_tiled_filter_landmark_churn_on_multi_rank_grids_with_the_hip_kernels(tm
         S, pose, gamma, hole, n_upd, err, rem_old, rem_out, added = np.load(tmp_path / f"c_{r}.npy")
         assert n_upd >= 8 and err == 0 and rem_old >= 2 and rem_out >= 1 and added > N // 3
         assert S < 1e-9 and pose < 1e-8 and gamma < 1e-8 and hole == 0.0, (r, S, pose, gamma, hole)
+
+
+@pytest.mark.parametrize("N,bl,frames", [(1000, 125, 4), (4000, 250, 2)])
+def test_tiled_filter_churn_at_size_against_the_single_gpu_product_path(N, bl, frames):
+    """cfg 5's size (and N = 1000): every frame 1 % of the landmarks are out of view and the ones hidden a frame earlier come back as new
+    landmarks, gate at 0.01 -- the slots of the partitioned filter against the single-GPU product path's compacting churn
+    (csrc/eqf_churn.hpp), two HIP implementations that share no churn code; plus symmetry and the trace of the result."""
+    import torch
+
+    from eqf_vio_amd import binding, synth, tiled
+
+    d = synth.template_settings_dict()
+    d["outlierThreshold"] = 0.01
+    st = synth.make_stream(N, duration=(frames + 1) / 20.0 + 0.011)
+    be = tiled.HipBackend(d, capacity=N)
+    tf = tiled.TiledFilter(tiled.ProcessGrid(None, 1, 1, device=be.device), be, bl)
+    fg = binding.FilterBatch(d, capacity=N, batch=1)
+    turn, f = N // 100, 0
+    rel = lambda A, B: float(np.linalg.norm(A - B) / np.linalg.norm(B))
+    for kind, k in st.events():
+        if kind == "imu":
+            r = st.imu[k]
+            tf.processIMUData(r[0], r[1:4], r[4:7])
+            fg.process_imu([r[0]], r[1:4], r[4:7])
+            continue
+        vis = np.ones(N, dtype=bool)
+        vis[(np.arange(turn) + f * turn) % N] = False
+        f += 1
+        ids, y = st.ids[vis], st.bearings[k][vis]
+        assert tf.processVisionData(st.vision_stamps[k], ids, y) == 0
+        fg.process_vision([st.vision_stamps[k]], ids, y)
+        assert np.array_equal(tf.ids, fg.ids()), f
+        St, Sg = tf.stateCovariance(), fg.sigma()
+        assert rel(St, Sg) <= 1e-9, (f, rel(St, Sg))
+        assert np.abs(St - St.T).max() <= 1e-9 * np.abs(St).max() and abs(np.trace(St) - np.trace(Sg)) <= 1e-9 * np.trace(Sg)
+        et, eg = tf.stateEstimate(), fg.state_estimate()
+        assert np.abs(et["x"] - eg["x"]).max() <= 1e-9 and np.abs(et["q"] - eg["q"]).max() <= 1e-9 and np.abs(et["p"] - eg["p"]).max() <= 1e-8
+        del St, Sg
+    cs = tf.churn_stats  # (a landmark the gate took out earlier is not there to leave the field of view)
+    assert f >= frames and cs["removed_old"] + cs["removed_outliers"] >= (f - 1) * turn and cs["added"] >= N - turn + (f - 1) * turn and tf.nslots <= N
+    assert be.device_error() == 0 and fg.device_error() == 0
+    torch.cuda.synchronize()
