@@ -21,6 +21,7 @@
 //                      or B <- L^-1 B (left; B is n x m); one workgroup per 64 rows (columns) of B, register-chained MFMA
 //                      substitution per 64 x 64 block, the earlier blocks of the strip applied first.
 #pragma once
+#include <type_traits>
 #include "eqf_chol64.hpp"
 
 namespace eqf {
@@ -204,23 +205,62 @@ __global__ __launch_bounds__(256, 2) void k_tile_gemm_tn(double* C, int ldc, int
     stage(0);
     __syncthreads();
     const int nc = (k + kGemmKC - 1) / kGemmKC;
-    for (int c = 0; c < nc; ++c) {
-        if (c + 1 < nc) fetch((c + 1) * kGemmKC);  // in flight during this chunk's MFMAs
-        const double* sa = sGemm + ((c & 1) * 2 + 0) * kGemmKC * kGemmPitch + 64 * wi + lr;
-        const double* sb = sGemm + ((c & 1) * 2 + 1) * kGemmKC * kGemmPitch + 64 * wj + lr;
+    auto fetchFull = [&](int k0) {
 #pragma unroll
-        for (int s = 0; s < kGemmKC / 4; ++s) {
+        for (int r = 0; r < 4; ++r) {
+            const long long row = k0 + wv + 4 * r;
+            const f64x2u va = *reinterpret_cast<const f64x2u*>(A + row * lda + I0 + sc);
+            const f64x2u vb = *reinterpret_cast<const f64x2u*>(B + row * ldb + J0 + sc);
+            pa[2 * r] = va.x; pa[2 * r + 1] = va.y;
+            pb[2 * r] = vb.x; pb[2 * r + 1] = vb.y;
+        }
+    };
+    // operands of k step s of the chunk in LDS buffer `buf`: four 16-row slices of A and of B, one double per lane each
+    auto operands = [&](int buf, int s, double* av, double* bv) {
+        const double* sa = sGemm + (buf * 2 + 0) * kGemmKC * kGemmPitch + 64 * wi + lr + (4 * s + lk) * kGemmPitch;
+        const double* sb = sGemm + (buf * 2 + 1) * kGemmKC * kGemmPitch + 64 * wj + lr + (4 * s + lk) * kGemmPitch;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            av[u] = sa[16 * u];
+            bv[u] = sb[16 * u];
+        }
+    };
+    auto mfma16 = [&](const double* av, const double* bv, auto fullTag) {
+        constexpr bool FULL = decltype(fullTag)::value;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (FULL || (u < mu && v < nv)) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[v], acc[u][v], 0, 0, 0);
+    };
+    // Whole tiles: chunks c with c + 1 entirely inside k run a straight-line body (no predicate anywhere: one basic block per chunk, in which
+    // the scheduler places the global loads, the LDS reads and the LDS writes in the shadow of the matrix instructions -- a 16x16x4 f64 MFMA
+    // holds the pipe for 64 cycles, fifteen issue slots each; it also takes the staging stores and the barrier in front of the last dozen
+    // MFMAs).  The predicated body below tests (u < mu && v < nv) per MFMA and every fetched element: dozens of scalar branches per chunk
+    // during which the wave feeds nothing to the matrix pipe -- 50.7 -> 56.0 TFLOP/s at 12000 x 12000 x 750 (MFMA-busy 0.65 -> 0.74).
+    // Measured and not kept (same rate): two chunks in flight (the loads are not late), the loop rotated around the barrier with the next
+    // chunk's first operands read behind it.
+    const bool whole = fullA && fullB && mu == 4 && nv == 4;
+    const int nFast = whole ? max(0, k / kGemmKC - 1) : 0;
+    int c = 0;
+    for (; c < nFast; ++c) {
+        fetchFull((c + 1) * kGemmKC);
+#pragma unroll
+        for (int s_ = 0; s_ < kGemmKC / 4; ++s_) {
             double av[4], bv[4];
+            operands(c & 1, s_, av, bv);
+            mfma16(av, bv, std::true_type{});
+        }
+        stage((c + 1) & 1);
+        __syncthreads();
+    }
+    for (; c < nc; ++c) {
+        if (c + 1 < nc) fetch((c + 1) * kGemmKC);  // in flight during this chunk's MFMAs
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                av[u] = sa[(4 * s + lk) * kGemmPitch + 16 * u];
-                bv[u] = sb[(4 * s + lk) * kGemmPitch + 16 * u];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    if (u < mu && v < nv) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[v], acc[u][v], 0, 0, 0);
+        for (int s_ = 0; s_ < kGemmKC / 4; ++s_) {
+            double av[4], bv[4];
+            operands(c & 1, s_, av, bv);
+            mfma16(av, bv, std::false_type{});
         }
         if (c + 1 < nc) stage((c + 1) & 1);
         __syncthreads();

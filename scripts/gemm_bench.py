@@ -30,3 +30,14 @@ for (m, n, k, mask, what) in shapes:
     ms = a.elapsed_time(b) / reps
     fl = 2.0 * m * n * k * (0.5 if mask else 1.0)
     print(f"{m:6d} x {n:6d} x {k:4d}  {ms:8.3f} ms  {fl / ms / 1e9:7.2f} TFLOP/s ({fl / ms / 1e9 / 78.6 * 100:5.1f} % of the fp64 MFMA peak)  {what}")
+    if mask is None and m >= 1000 and os.environ.get("EQF_GEMM_YARDSTICK", "1") != "0":
+        # yardstick only (never on the product path): the vendor library's DGEMM on the same operands, C = C - A^T B
+        C.addmm_(A.t(), B, alpha=-1.0)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(reps):
+            C.addmm_(A.t(), B, alpha=-1.0)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        print(f"{'':27s}{ms:8.3f} ms  {fl / ms / 1e9:7.2f} TFLOP/s ({fl / ms / 1e9 / 78.6 * 100:5.1f} %)  yardstick: torch.addmm (rocBLAS / hipBLASLt DGEMM), same operands")
