@@ -273,8 +273,11 @@ __global__ __launch_bounds__(256, 2) void k_tile_gemm_tn(double* C, int ldc, int
             for (int q = 0; q < 4; ++q) {
                 const int R = I0 + 64 * wi + 16 * u + lk + 4 * q, Cc = J0 + 64 * wj + 16 * v + lr;
                 if (R < m && Cc < n) {
-                    double* cp = C + (long long)R * ldc + Cc;
-                    *cp = fma(alpha, acc[u][v][q], *cp);
+                    // C += alpha acc as a fire-and-forget global_atomic_add_f64: the wave does not wait for C to arrive (a read-modify-write
+                    // epilogue is a load -> fma -> store chain per element while the tile's matrix-pipe slot sits empty: 5-10 % of the kernel
+                    // by ablation), the L2 does the addition.  Every element of C has exactly ONE writer in a launch, so the result is
+                    // deterministic, and for alpha = +-1 (every product of the update) it is the same rounding as fma(alpha, acc, C).
+                    unsafeAtomicAdd(C + (long long)R * ldc + Cc, alpha * acc[u][v][q]);
                 }
             }
 }
