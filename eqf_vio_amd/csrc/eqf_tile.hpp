@@ -135,24 +135,83 @@ struct GemmMask {
 };
 constexpr int kGemmTile = 128, kGemmKC = 16, kGemmPitch = 144;
 constexpr int kGemmLdsBytes = 2 * 2 * kGemmKC * kGemmPitch * 8;
-__global__ __launch_bounds__(256, 2) void k_tile_gemm_tn(double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k,
-    double alpha, GemmMask mk, int tm, int tn) {
-    extern __shared__ __attribute__((aligned(16))) double sGemm[];  // [2][2][KC][pitch]: buffer, operand
-    // ---- tile of this workgroup (XCD-contiguous grouped order)
-    // (masked launches: round-robin instead -- a contiguous range per XCD would give the XCDs that hold the last tile rows, mostly below
-    // the block diagonal, almost nothing to do)
-    const int T = tm * tn, per = (T + 7) / 8;
-    const int L = blockIdx.x, id = mk.rb > 0 ? L : (L & 7) * per + (L >> 3);
-    if ((L >> 3) >= per || id >= T) return;
-    constexpr int G = 8;
-    const int grp = id / (G * tn), first = grp * G, gsz = min(tm - first, G);
-    const int ti = first + (id % (G * tn)) % gsz, tj = (id % (G * tn)) / gsz;
+// Masked launches walk ONLY the tiles the mask leaves, in the same XCD-contiguous grouped order as unmasked ones (round 4; until then they
+// were dealt round-robin over the whole rectangle, which put each XCD on one tile row per group -- every B panel fetched by all eight L2s).
+// The host lays the walk out (a mask is a staircase: row ti is active from column tile first[ti] on, first[] nondecreasing) and hands it over
+// by value in the kernel arguments: first[] per tile row and the number of active tiles in front of every group of kGemmGroup rows.
+constexpr int kGemmGroup = 8, kGemmPlanRows = 256;
+struct GemmPlan {
+    int tact;                                        // active tiles (0: no plan -- unmasked launch, or more than kGemmPlanRows tile rows)
+    int before[kGemmPlanRows / kGemmGroup + 1];      // active tiles in the groups before group g
+    int first[kGemmPlanRows];                        // first active column tile of tile row ti (tn: none)
+};
+// tile (ti, tj) holds something the mask keeps
+EQF_DI bool gemmTileActive(const GemmMask& mk, int ti, int tj, int n) {
     const int I0 = ti * kGemmTile, J0 = tj * kGemmTile;
-    if (mk.rb > 0) {
-        const int Ilo = (mk.rblk0 + I0 / mk.rb) * mk.Pr + mk.pr;
-        const int Jhi = (mk.cblk0 + (min(J0 + kGemmTile, n) - 1) / mk.cb) * mk.Pc + mk.pc;
-        if (Ilo > Jhi) return;
+    const int Ilo = (mk.rblk0 + I0 / mk.rb) * mk.Pr + mk.pr;
+    const int Jend = (J0 + kGemmTile < n ? J0 + kGemmTile : n) - 1;
+    const int Jhi = (mk.cblk0 + Jend / mk.cb) * mk.Pc + mk.pc;
+    return Ilo <= Jhi;
+}
+inline void gemmMakePlan(const GemmMask& mk, int tm, int tn, int n, GemmPlan* pl) {
+    pl->tact = 0;
+    if (mk.rb <= 0 || tm > kGemmPlanRows) return;
+    int total = 0;
+    for (int ti = 0; ti < tm; ++ti) {
+        if (ti % kGemmGroup == 0) pl->before[ti / kGemmGroup] = total;
+        int c = ti > 0 ? pl->first[ti - 1] : 0;  // (nondecreasing in ti)
+        while (c < tn && !gemmTileActive(mk, ti, c, n)) ++c;
+        pl->first[ti] = c;
+        total += tn - c;
     }
+    pl->before[(tm + kGemmGroup - 1) / kGemmGroup] = total;
+    pl->tact = total;
+}
+__global__ __launch_bounds__(256, 2) void k_tile_gemm_tn(double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k,
+    double alpha, GemmMask mk, int tm, int tn, GemmPlan pl) {
+    extern __shared__ __attribute__((aligned(16))) double sGemm[];  // [2][2][KC][pitch]: buffer, operand
+    // ---- tile of this workgroup (XCD-contiguous grouped order: the hardware deals workgroup L to XCD L % 8; XCD x walks tiles [x per, (x + 1) per))
+    constexpr int G = kGemmGroup;
+    const int L = blockIdx.x;
+    int ti, tj;
+    if (pl.tact > 0) {
+        const int per = (pl.tact + 7) / 8;
+        int id = (L & 7) * per + (L >> 3);
+        if ((L >> 3) >= per || id >= pl.tact) return;
+        int g = 0;
+        while (pl.before[g + 1] <= id) ++g;
+        id -= pl.before[g];
+        const int first = g * G, gsz = min(tm - first, G);
+        // inside the group: column by column from the first column its top row keeps; a column holds the rows whose staircase has reached it
+        // (the top `a` rows: first[] is nondecreasing), from the last row's first column on all gsz of them
+        tj = pl.first[first];
+        const int cfull = pl.first[first + gsz - 1];
+        ti = -1;
+        while (tj < cfull) {
+            int a = 0;
+            for (int r = 0; r < gsz; ++r) a += pl.first[first + r] <= tj;
+            if (id < a) {
+                ti = first + id;
+                break;
+            }
+            id -= a;
+            ++tj;
+        }
+        if (ti < 0) {
+            tj = cfull + id / gsz;
+            ti = first + id % gsz;
+        }
+    } else {
+        // (a mask without a plan -- more than kGemmPlanRows tile rows --: round-robin over the rectangle, inactive tiles leave at once)
+        const int T = tm * tn, per = (T + 7) / 8;
+        const int id = mk.rb > 0 ? L : (L & 7) * per + (L >> 3);
+        if ((L >> 3) >= per || id >= T) return;
+        const int grp = id / (G * tn), first = grp * G, gsz = min(tm - first, G);
+        ti = first + (id % (G * tn)) % gsz;
+        tj = (id % (G * tn)) / gsz;
+        if (mk.rb > 0 && !gemmTileActive(mk, ti, tj, n)) return;
+    }
+    const int I0 = ti * kGemmTile, J0 = tj * kGemmTile;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wi = wv >> 1, wj = wv & 1, lr = lane & 15, lk = lane >> 4;
     // 16-row / 16-column sub-tiles of this wave that hold anything (ragged edges, narrow products)

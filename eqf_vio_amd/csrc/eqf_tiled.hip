@@ -674,10 +674,13 @@ int eqf_tile_gemm_tn(int device, void* stream, double* C, int ldc, int m, int n,
     if (rc) return rc;
     GemmMask mk{mask_rb, mask_cb, rblk0, Pr, pr, cblk0, Pc, pc};
     const int tm = (m + kGemmTile - 1) / kGemmTile, tn = (n + kGemmTile - 1) / kGemmTile;
-    const long long T = (long long)tm * tn;
+    GemmPlan pl;
+    gemmMakePlan(mk, tm, tn, n, &pl);  // (masked launches: only the tiles the mask keeps are dispatched, XCD-contiguous like the others)
+    if (mask_rb > 0 && tm <= kGemmPlanRows && pl.tact == 0) return EQF_OK;  // the mask leaves nothing
+    const long long T = pl.tact > 0 ? pl.tact : (long long)tm * tn;
     const int grid = int(8 * ((T + 7) / 8));
     hipLaunchKernelGGL(k_tile_gemm_tn, dim3(grid), dim3(256), kGemmLdsBytes, static_cast<hipStream_t>(stream), C, ldc, m, n, A, lda, B, ldb, k, alpha, mk, tm,
-        tn);
+        tn, pl);
     HIPC(hipGetLastError());
     return EQF_OK;
 }

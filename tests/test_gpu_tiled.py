@@ -59,6 +59,22 @@ def test_tile_gemm_tn_against_numpy():
             else:
                 skipped += int(np.array_equal(got[blk], C[blk]))
     assert skipped >= 1  # (whole tiles below the diagonal really are skipped)
+    # masked launches walk only the active tiles (GemmPlan): staircases of several shapes -- blocks that are no multiple of the 128-wide tile,
+    # ragged last blocks, a non-square process grid with offsets into the local matrix, a mask that leaves nothing
+    for (m, n, k, rb, cb, rblk0, Pr, pr, cblk0, Pc, pc) in ((1500, 1500, 40, 750, 750, 0, 1, 0, 0, 1, 0), (1000, 1380, 33, 300, 300, 0, 1, 0, 0, 1, 0),
+                                                            (900, 700, 20, 150, 100, 1, 2, 1, 2, 4, 3), (640, 512, 16, 128, 128, 0, 2, 0, 0, 2, 1),
+                                                            (300, 260, 8, 100, 100, 2, 1, 0, 0, 1, 0)):
+        A, B, C = rng.standard_normal((k, m)), rng.standard_normal((k, n)), rng.standard_normal((m, n))
+        Cd = t(C)
+        be.gemm_tn(Cd, t(A), t(B), -1.0, mask=(rb, cb, rblk0, Pr, pr, cblk0, Pc, pc))
+        got, want = Cd.cpu().numpy(), C - A.T @ B
+        I = (rblk0 + np.arange(m) // rb) * Pr + pr
+        J = (cblk0 + np.arange(n) // cb) * Pc + pc
+        keep = I[:, None] <= J[None, :]
+        assert np.abs(got - want)[keep].max(initial=0.0) <= 1e-12 * 100, (m, n, rb, cb)
+        # below the staircase an element is either untouched or the full product (tiles are skipped or computed whole), never garbage
+        low = ~keep
+        assert (np.isclose(got, C, rtol=0, atol=0) | (np.abs(got - want) <= 1e-10))[low].all(), (m, n, rb, cb)
 
 
 def test_tile_propagate_against_dense_formula():
