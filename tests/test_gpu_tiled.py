@@ -600,3 +600,54 @@ def test_tiled_filter_churn_at_size_against_the_single_gpu_product_path(N, bl, f
     assert f >= frames and cs["removed_old"] + cs["removed_outliers"] >= (f - 1) * turn and cs["added"] >= N - turn + (f - 1) * turn and tf.nslots <= N
     assert be.device_error() == 0 and fg.device_error() == 0
     torch.cuda.synchronize()
+
+
+def test_tiled_filter_restart_from_a_churned_single_gpu_snapshot_and_churn_on(oracle_lib):
+    """The product path runs a stream with landmarks entering / leaving / gated out (its state order is no longer id order), its snapshot
+    restarts the partitioned filter (slot i = landmark i of the snapshot), and both go on through more churn: ids, Sigma and state stay
+    together, and a later snapshot of the tiled filter's covariance equals the oracle's."""
+    from eqf_vio_amd import binding, synth, tiled
+
+    N, bl = 60, 16
+    d = synth.template_settings_dict()
+    d["outlierThreshold"] = 0.01
+    st = synth.make_stream(N, duration=0.66)
+    meas = synth.churn_measurements(st, seed=11, outlier_frames=(4, 7, 8), outlier_angle=0.05)
+    fg = binding.FilterBatch(d, capacity=N, batch=1)
+    fo = oracle_lib.OracleFilter(d)
+    ev = list(st.events())
+    cut = next(i for i, (kind, k) in enumerate(ev) if kind == "vision" and k == 5) + 3
+    for kind, k in ev[:cut]:
+        if kind == "imu":
+            r = st.imu[k]
+            fg.process_imu([r[0]], r[1:4], r[4:7])
+            fo.processIMUData(r[0], r[1:4], r[4:7])
+        else:
+            fg.process_vision([st.vision_stamps[k]], *meas[k])
+            fo.processVisionData(st.vision_stamps[k], *meas[k])
+    snap = fg.dump_state()
+    assert not np.array_equal(np.sort(snap["ids"]), snap["ids"]) or len(snap["ids"]) < N  # (the set did change before the cut)
+    be = tiled.HipBackend(d, capacity=N)
+    tf = tiled.TiledFilter(tiled.ProcessGrid(None, 1, 1, device=be.device), be, bl)
+    tf.initialise_from(snap)
+    assert np.array_equal(tf.ids, fo.ids())
+    rel = lambda A, B: float(np.linalg.norm(A - B) / np.linalg.norm(B))
+    n_upd = 0
+    for kind, k in ev[cut:]:
+        if kind == "imu":
+            r = st.imu[k]
+            fg.process_imu([r[0]], r[1:4], r[4:7])
+            fo.processIMUData(r[0], r[1:4], r[4:7])
+            tf.processIMUData(r[0], r[1:4], r[4:7])
+        else:
+            fg.process_vision([st.vision_stamps[k]], *meas[k])
+            fo.processVisionData(st.vision_stamps[k], *meas[k])
+            assert tf.processVisionData(st.vision_stamps[k], *meas[k]) == 0
+            n_upd += 1
+            assert np.array_equal(tf.ids, fg.ids()) and np.array_equal(tf.ids, fo.ids())
+            S = tf.stateCovariance()
+            assert rel(S, fg.sigma()) <= 1e-9 and rel(S, fo.stateCovariance()) <= 1e-9
+    cs = tf.churn_stats
+    assert n_upd >= 5 and cs["removed_old"] + cs["removed_outliers"] >= 2 and cs["added"] >= 2, (n_upd, cs)
+    e1, e2 = tf.stateEstimate(), fo.stateEstimate()
+    assert np.abs(e1["x"] - e2["x"]).max() <= 1e-9 and np.abs(e1["p"] - e2["p"]).max() <= 1e-8 and be.device_error() == 0
