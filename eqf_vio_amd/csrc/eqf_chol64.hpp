@@ -237,7 +237,6 @@ EQF_DI void potrf16v2(double* rowPtr, bool store, bool scatterW, double (*Wj)[kW
 #pragma unroll
     for (int c = 0; c < kQB; ++c) {
         const double d = readlane64(row[c], c);
-        const double rd = rsqrtPivot(d);
         if (c >= 1) {
             // all broadcasts of the column first (distinct SGPR pairs, pinned), then the FMAs: one v_readlane -> VALU hazard per column
             double bc[kQB];
@@ -250,7 +249,7 @@ EQF_DI void potrf16v2(double* rowPtr, bool store, bool scatterW, double (*Wj)[kW
 #pragma unroll
             for (int c2 = c + 1; c2 < kQB; ++c2) row[c2] = fma(-ljPrev, bc[c2], row[c2]);
         }
-        const double lj = row[c] * rd;
+        const double lj = scaleRsqrtPivot(row[c], d);
         if (c + 1 < kQB) row[c + 1] = fma(-lj, readlane64(lj, c + 1), row[c + 1]);
         row[c] = lj;
         ljPrev = lj;

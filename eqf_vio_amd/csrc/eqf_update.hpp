@@ -393,6 +393,23 @@ EQF_DI double rsqrtPivot(double d) {
     return y;
 }
 
+// a / sqrt(d) for the pivot chains' column scaling, with as few DEPENDENT fp64 operations behind v_rsq_f64 as accuracy allows: the chain of
+// a pivot is a lone wave issuing in order, every dependent operation is its full latency.  v_rsq_f64 is good to 2^-24.2
+// (scripts/micro/rsq_acc.hip); ONE third-order step y1 = y (1 + e / 2 + 3 e^2 / 8), e = 1 - d y^2, takes that to 2^-72, below the rounding
+// of the result, and folded into the product with a it is four dependent operations -- t = d y; e = 1 - t y; {p = 1/2 + 3/8 e, q = (a y) e};
+// a y + q p -- against seven for two Newton steps (three each) and the product.  Relative error of the result <= 1.5 ulp, as before.
+EQF_DI double scaleRsqrtPivot(double a, double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = __builtin_amdgcn_rsq(d);
+#else
+    const double y = 1.0 / sqrt(d);
+#endif
+    const double ay = a * y;
+    const double e = fma(-(d * y), y, 1.0);
+    const double p = fma(0.375, e, 0.5);
+    return fma(ay * e, p, ay);
+}
+
 struct ChainArgs {
     Glob* g;
     double *A, *D, *W, *WO;   // work matrix, diagonal factors [nb][2][32][32] (L_kk, inv L_kk), rhs work, rhs solved
