@@ -77,6 +77,14 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  eqf_vio_amd has no CPU fallback."
             )
+        # torch wheels ship their own HIP runtime (torch/lib/libamdhip64.so).  A process must end up with ONE runtime: if this library pulled
+        # in the system's first, a later `import torch` + torch.cuda initialisation sees "No HIP GPUs" (measured on the MI355X box: the
+        # partitioned filter, whose device memory is torch's, created after a FilterBatch).  So when torch is installed it is imported
+        # first and this library binds to the runtime torch loaded; hosts without torch get the system runtime as before.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp = C.c_void_p
         L.eqf_settings_default.argtypes = [C.POINTER(Settings)]
