@@ -62,7 +62,7 @@ EXPORTED_SYMBOLS = [
     "eqf_set_sigma", "eqf_set_state", "eqf_set_camera_offset", "eqf_get_integrator", "eqf_get_last_update", "eqf_debug_get_blocks", "eqf_device_error", "eqf_set_dense_propagate", "eqf_set_imu_burst", "eqf_profile_enable",
     "eqf_profile_get", "eqf_profile_class_name", "eqf_version", "eqf_tile_propagate", "eqf_tile_downdate", "eqf_tile_potrf", "eqf_tile_trsm", "eqf_tile_gemm_tn", "eqf_tile_mirror", "eqf_stream_create_masked", "eqf_stream_destroy",
     "eqf_tiled_create", "eqf_tiled_destroy", "eqf_tiled_set_stream", "eqf_tiled_set_geometry", "eqf_tiled_propagate", "eqf_tiled_add_landmarks",
-    "eqf_tiled_edit_landmarks",
+    "eqf_tiled_edit_landmarks", "eqf_tiled_propagate_burst",
     "eqf_tiled_update_prep", "eqf_tiled_update_finish", "eqf_tiled_synchronize", "eqf_tiled_num_landmarks", "eqf_tiled_get_time",
     "eqf_tiled_device_error", "eqf_tiled_get_state_estimate", "eqf_tiled_get_origin", "eqf_tiled_get_group", "eqf_tiled_get_bias",
     "eqf_tiled_get_last_update", "eqf_tiled_get_integrator", "eqf_tiled_get_base", "eqf_tiled_set_state",
@@ -138,6 +138,7 @@ def lib():
         L.eqf_tiled_set_geometry.argtypes = [vp, C.c_int, _ip, C.c_int, _ip]
         L.eqf_tiled_propagate.argtypes = [vp, C.c_double, _dp, _dp, C.c_int, vpp, C.c_int]
         L.eqf_tiled_add_landmarks.argtypes = [vp, C.c_int, _dp, vpp, C.c_int]
+        L.eqf_tiled_propagate_burst.argtypes = [vp, C.c_int, _dp, _dp, _dp, C.c_int, vpp, C.c_int, _ip]
         L.eqf_tiled_edit_landmarks.argtypes = [vp, C.c_int, _ip, C.c_int, _ip, _dp, C.c_double, C.c_int, vpp, C.c_int]
         L.eqf_tiled_update_prep.argtypes = [vp, _dp, vpp, C.c_int, vpp, C.c_int, vpp, C.c_int, vpp]
         L.eqf_tiled_update_finish.argtypes = [vp, vpp, C.c_int, vpp, vpp]

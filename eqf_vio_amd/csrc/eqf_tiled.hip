@@ -83,6 +83,10 @@ struct eqf_tiled {
     // landmark slots (eqf_tiled.hpp): device flags, the host's copy of them, the marks of an edit
     int *active = nullptr, *mark = nullptr;
     std::vector<char> hostActive;
+    // IMU bursts (eqf_tiled_propagate_burst): one record set, one base panel and one step-constant block per step of a burst, allocated at
+    // the first burst
+    double *histBlk = nullptr, *histBlkT = nullptr, *histSb = nullptr;
+    CommonLds* histCommon = nullptr;
     // host mirror of the control flow (VIOFilter.cpp:120-131, :146-152, :234-236)
     double curTime = -1.0;
     bool init = false;
@@ -97,7 +101,8 @@ void freeTiled(eqf_tiled* t) {
         hipFree(t->Sb[q]);
     }
     for (void* p : {(void*)t->p0, (void*)t->lmc, (void*)t->blk, (void*)t->blkCommon, (void*)t->delta, (void*)t->Zrows, (void*)t->Vrows, (void*)t->Pg,
-             (void*)t->Lgi, (void*)t->gamma, (void*)t->gammaTot, (void*)t->dBear, (void*)t->dOut, (void*)t->errflag, (void*)t->rowMap, (void*)t->colMap, (void*)t->active, (void*)t->mark})
+             (void*)t->Lgi, (void*)t->gamma, (void*)t->gammaTot, (void*)t->dBear, (void*)t->dOut, (void*)t->errflag, (void*)t->rowMap, (void*)t->colMap, (void*)t->active, (void*)t->mark, (void*)t->histBlk, (void*)t->histBlkT, (void*)t->histSb,
+             (void*)t->histCommon})
         hipFree(p);
     delete t;
 }
@@ -301,6 +306,81 @@ int eqf_tiled_propagate(eqf_tiled* t, double stamp, const double* omega, const d
     if (step || is_imu) t->curTime = stamp;
     if (!is_imu && st == EQF_OK && !t->init) st = EQF_SKIPPED_NOT_INITIALISED;
     return st;
+}
+
+int eqf_tiled_propagate_burst(eqf_tiled* t, int K, const double* stamps, const double* omega, const double* accel, int last_is_vision, double* Sll,
+    int ldl, int* status) {
+    if (!t || K < 1 || K > kTlBurstMax || !stamps || !status) return EQF_ERR_INVALID;
+    const int nImu = K - (last_is_vision ? 1 : 0);
+    if (nImu > 0 && (!omega || !accel)) return EQF_ERR_INVALID;
+    const bool local = t->N > 0 && t->nlr > 0 && t->nlc > 0;
+    if (local && (!Sll || ldl < 3 * t->nlc)) return EQF_ERR_INVALID;
+    DeviceScope ds(t->device);
+    if (!ds.ok) return EQF_ERR_HIP;
+    const int cap = t->cap;
+    const size_t blkN = (size_t)kBlkRec * cap, blkTN = (size_t)27 * cap, sbN = (size_t)12 * t->ldb;
+    if (!t->histBlk) {
+        int rc = EQF_OK;
+        auto chk = [&](int r) { if (r && !rc) rc = r; };
+        chk(dmallocT(&t->histBlk, blkN * kTlBurstMax));
+        chk(dmallocT(&t->histBlkT, blkTN * kTlBurstMax));
+        chk(dmallocT(&t->histSb, sbN * kTlBurstMax));
+        chk(dmallocT(&t->histCommon, kTlBurstMax));
+        if (rc) return rc;
+    }
+    TlBurstArgs b{};
+    const int N = t->N;
+    for (int k = 0; k < K; ++k) {
+        const bool isImu = k < nImu;
+        ImuRec r{};
+        r.stamp = stamps[k];
+        if (isImu)
+            for (int i = 0; i < 3; ++i) {
+                r.w[i] = omega[3 * k + i];
+                r.a[i] = accel[3 * k + i];
+            }
+        // host mirror of the control flow, call by call (VIOFilter.cpp:120-131, :146-152, :207, :234-236), as in eqf_tiled_propagate
+        int st = EQF_OK;
+        if (t->curTime < 0) st = EQF_SKIPPED_BEFORE_FIRST_IMU;
+        else if (!(stamps[k] - t->curTime > 0)) st = EQF_SKIPPED_NONPOSITIVE_DT;
+        const bool step = st == EQF_OK;
+        TlArgs a = propArgs(t, r, isImu ? 1 : 0, Sll, ldl);
+        // the burst's base panels: the current one, K - 1 in the history, the other half of the ping-pong pair
+        a.SbIn = k == 0 ? t->Sb[t->pB] : t->histSb + sbN * k;
+        a.SbOut = k == K - 1 ? t->Sb[t->pB ^ 1] : t->histSb + sbN * (k + 1);
+        a.blk = t->histBlk + blkN * k;
+        a.blkT = t->histBlkT + blkTN * k;
+        a.blkCommon = t->histCommon + k;
+        hipLaunchKernelGGL(k_tl_build, dim3((std::max(N, 1) + 63) / 64 + 1), dim3(128), 0, t->stream, a);
+        hipLaunchKernelGGL(k_tl_base, dim3(std::max(1, (N + 255) / 256)), dim3(256), 0, t->stream, a);
+        if (step && a.doRiccati && local) {
+            const int q = b.nSteps++;
+            b.blk[q] = a.blk;
+            b.blkT[q] = a.blkT;
+            b.SbIn[q] = a.SbIn;
+            b.common[q] = a.blkCommon;
+        }
+        t->pG ^= 1;
+        if (isImu) t->init = true;
+        if (step || isImu) t->curTime = stamps[k];
+        if (!isImu && st == EQF_OK && !t->init) st = EQF_SKIPPED_NOT_INITIALISED;
+        status[k] = st;
+    }
+    t->pB ^= 1;
+    if (b.nSteps > 0) {
+        b.pointVar = t->prm.pointProcessVariance;
+        b.ldb = t->ldb;
+        b.cap = cap;
+        b.Sll = Sll;
+        b.ldl = ldl;
+        b.nlr = t->nlr;
+        b.nlc = t->nlc;
+        b.rowMap = t->rowMap;
+        b.colMap = t->colMap;
+        hipLaunchKernelGGL(k_tl_riccati_burst, dim3((t->nlc + 255) / 256, (t->nlr + kBurstRows - 1) / kBurstRows), dim3(256), 0, t->stream, b);
+    }
+    HIPC(hipGetLastError());
+    return EQF_OK;
 }
 
 int eqf_tiled_add_landmarks(eqf_tiled* t, int n, const double* bearings, double* Sll, int ldl) {

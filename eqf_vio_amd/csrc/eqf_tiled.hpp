@@ -61,6 +61,7 @@ struct TlArgs {
     const int* rowMap;  // [nlr] local row landmark -> global landmark
     const int* colMap;  // [nlc]
     const int* active;  // [cap] 1: the slot holds a landmark; 0: hole (see the header of this file)
+    double* blkT;       // [27][cap] or nullptr: D, Lw, Lv of every landmark once more, transposed -- the column side of k_tl_riccati_burst
 };
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -129,6 +130,11 @@ __global__ __launch_bounds__(128) void k_tl_build(TlArgs a) {
                 bp[k] = D[k];
                 bp[9 + k] = Lw[k];
                 bp[18 + k] = Lv[k];
+                if (a.blkT) {
+                    a.blkT[(long long)k * cap + i] = D[k];
+                    a.blkT[(long long)(9 + k) * cap + i] = Lw[k];
+                    a.blkT[(long long)(18 + k) * cap + i] = Lv[k];
+                }
             }
             // G_I[:, 0:3] and G_I[:, 8:11] of G_I = Lw Sigma[0:3, :] + Lv Sigma[8:11, :] + D Sigma_Ib, Sigma_Ib[k][c] = Sb[c][12 + 3 i + k]
             // (same expression order as k_build_blocks)
@@ -288,6 +294,38 @@ __global__ __launch_bounds__(256) void k_tl_base(TlArgs a) {
     }
 }
 
+// One Riccati step of one 3 x 3 block: out = (D_I S + Lw_I Sw_J + Lv_I Sv_J) D_J^T + Gn_I Lw_J^T + Gv_I Lv_J^T (+ diagAdd on the diagonal);
+// rc = the row landmark's record (D, Lw, Lv, Gn, Gv).  ONE function for k_tl_riccati and k_tl_riccati_burst: same operations, same order.
+EQF_DI void tlRiccatiBlock(const double* Sc, const double* rc, const double* DJ, const double* LwJ, const double* LvJ, const double* SwJ,
+    const double* SvJ, double diagAdd, double* out) {
+    double H[9];
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            double acc = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {  // (explicit fma chain: the compiler's contraction choices must not differ between the two kernels)
+                acc = fma(rc[3 * rr + k], Sc[3 * k + cc], acc);
+                acc = fma(rc[9 + 3 * rr + k], SwJ[3 * k + cc], acc);
+                acc = fma(rc[18 + 3 * rr + k], SvJ[3 * k + cc], acc);
+            }
+            H[3 * rr + cc] = acc;
+        }
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            double acc = (rr == cc) ? diagAdd : 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                acc = fma(H[3 * rr + k], DJ[3 * cc + k], acc);
+                acc = fma(rc[27 + 3 * rr + k], LwJ[3 * cc + k], acc);
+                acc = fma(rc[36 + 3 * rr + k], LvJ[3 * cc + k], acc);
+            }
+            out[3 * rr + cc] = acc;
+        }
+}
 // ---------------------------------------------------------------------------------------------------------------------------
 // Local blocks, IN PLACE:  Sigma'_IJ = (D_I Sigma_IJ + Lw_I Sigma_wJ + Lv_I Sigma_vJ) D_J^T + Gn_I Lw_J^T + Gv_I Lv_J^T (+ T p I on the
 // global diagonal).  One lane per local COLUMN landmark, a workgroup walks kStreamRows local ROW landmarks whose records are
@@ -346,31 +384,103 @@ __global__ __launch_bounds__(256) void k_tl_riccati(TlArgs a) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) Sc[k] = S[k];
         if (i + 1 < nI) fetch(i + 1);
-        const double* rc = sRow[i];
-        double H[9];
-#pragma unroll
-        for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) {
-                double acc = 0;
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    acc += rc[3 * rr + k] * Sc[3 * k + cc] + rc[9 + 3 * rr + k] * SwJ[3 * k + cc] + rc[18 + 3 * rr + k] * SvJ[3 * k + cc];
-                H[3 * rr + cc] = acc;
-            }
+        double out[9];
+        tlRiccatiBlock(Sc, sRow[i], DJ, LwJ, LvJ, SwJ, SvJ, sGI[i] == J ? TtP : 0.0, out);
         const long long ro = (long long)(3 * (I0 + i)) * ldl;
-        const bool diag = sGI[i] == J;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc)
+                if (validJ) col[ro + (long long)rr * ldl + cc] = out[3 * rr + cc];
+    }
+}
+
+// K consecutive Riccati steps of the local blocks in ONE pass over Sll (IMU bursts: the calls between two vision frames + the vision call's
+// integrateUpToTime).  A step of a 3 x 3 block needs the block itself, the records of its row and column landmark FOR THAT STEP and the
+// base panel BEFORE that step -- all O(N) per step, produced by the K (k_tl_build, k_tl_base) pairs that ran first with one record set
+// and one panel per step.  So a thread keeps kBurstRows blocks of its column landmark in registers, walks the steps, and Sll is read and
+// written once instead of K times (2 |Sll| 8 bytes per burst instead of per step: 2.3 GB at N = 4000 on one GPU).  Same tlRiccatiBlock,
+// same order: the result of a burst equals the K single steps.  grid = (ceil(nlc / 256), ceil(nlr / kBurstRows)), block = 256.
+constexpr int kBurstRows = 4, kTlBurstMax = 16;
+struct TlBurstArgs {
+    int nSteps;
+    const double* blk[kTlBurstMax];     // per step: [cap][kBlkRec] row records
+    const double* blkT[kTlBurstMax];    // per step: [27][cap] column records
+    const double* SbIn[kTlBurstMax];    // per step: the base panel before the step
+    const CommonLds* common[kTlBurstMax];
+    double pointVar;
+    int ldb, cap;
+    double* Sll;
+    int ldl, nlr, nlc;
+    const int* rowMap;
+    const int* colMap;
+};
+__global__ __launch_bounds__(256) void k_tl_riccati_burst(TlBurstArgs a) {
+    const int tid = threadIdx.x;
+    const int I0 = blockIdx.y * kBurstRows;
+    const int jl = blockIdx.x * 256 + tid;
+    const int nI = max(0, min(kBurstRows, a.nlr - I0));
+    const bool validJ = jl < a.nlc;
+    const int ldl = a.ldl, ldb = a.ldb, cap = a.cap;
+    __shared__ double sRow[kTlBurstMax][kBurstRows][kBlkRec];
+    __shared__ int sGI[kBurstRows];
+    __shared__ double sTtP[kTlBurstMax];
+    for (int e = tid; e < a.nSteps * nI * kBlkRec; e += 256) {
+        const int s_ = e / (nI * kBlkRec), r = e % (nI * kBlkRec), il = r / kBlkRec, q = r % kBlkRec;
+        sRow[s_][il][q] = a.blk[s_][(long long)a.rowMap[I0 + il] * kBlkRec + q];
+    }
+    if (tid < nI) sGI[tid] = a.rowMap[I0 + tid];
+    if (tid < a.nSteps) sTtP[tid] = a.common[tid]->T * a.pointVar;
+    const int J = validJ ? a.colMap[jl] : 0;
+    double* col = a.Sll + 3 * (validJ ? jl : 0);
+    double S[kBurstRows][9];
+#pragma unroll
+    for (int i = 0; i < kBurstRows; ++i)
+        if (i < nI) {
+            const long long ro = (long long)(3 * (I0 + i)) * ldl;
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) S[i][3 * rr + cc] = col[ro + (long long)rr * ldl + cc];
+        }
+    __syncthreads();
+    for (int s_ = 0; s_ < a.nSteps; ++s_) {
+        double DJ[9], LwJ[9], LvJ[9], SwJ[9], SvJ[9];
+        const double* bt = a.blkT[s_] + J;
+        const double* colIn = a.SbIn[s_] + kLm0 + 3 * J;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            DJ[k] = bt[(long long)k * cap];
+            LwJ[k] = bt[(long long)(9 + k) * cap];
+            LvJ[k] = bt[(long long)(18 + k) * cap];
+        }
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc) {
-                double acc = (diag && rr == cc) ? TtP : 0.0;
+                SwJ[3 * rr + cc] = colIn[(long long)rr * ldb + cc];
+                SvJ[3 * rr + cc] = colIn[(long long)(8 + rr) * ldb + cc];
+            }
+        const double TtP = sTtP[s_];
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    acc += H[3 * rr + k] * DJ[3 * cc + k] + rc[27 + 3 * rr + k] * LwJ[3 * cc + k] + rc[36 + 3 * rr + k] * LvJ[3 * cc + k];
-                if (validJ) col[ro + (long long)rr * ldl + cc] = acc;
+        for (int i = 0; i < kBurstRows; ++i)
+            if (i < nI) {
+                double out[9];
+                tlRiccatiBlock(S[i], sRow[s_][i], DJ, LwJ, LvJ, SwJ, SvJ, sGI[i] == J ? TtP : 0.0, out);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) S[i][k] = out[k];
             }
     }
+    if (!validJ) return;
+#pragma unroll
+    for (int i = 0; i < kBurstRows; ++i)
+        if (i < nI) {
+            const long long ro = (long long)(3 * (I0 + i)) * ldl;
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) col[ro + (long long)rr * ldl + cc] = S[i][3 * rr + cc];
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

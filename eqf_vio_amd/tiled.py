@@ -271,6 +271,26 @@ class HipBackend:
         self.b._check(self.lib.eqf_tiled_add_landmarks(self._h, len(y), self._dp(y), self._p(Sll), Sll.stride(0) if Sll is not None else 0),
                       "eqf_tiled_add_landmarks")
 
+    BURST_MAX = 16
+
+    def propagate_burst(self, records, vision_stamp, Sll):
+        """records: [(stamp, omega, accel), ...] IMU calls; vision_stamp: the stamp of the vision call whose integrateUpToTime closes the burst
+        (or None).  One pass over Sll for all of them (eqf_tiled_propagate_burst).  Returns the status of every call."""
+        self._sync_stream()
+        K = len(records) + (1 if vision_stamp is not None else 0)
+        assert 1 <= K <= self.BURST_MAX
+        stamps = np.zeros(K)
+        w, a = np.zeros((K, 3)), np.zeros((K, 3))
+        for k, (st, om, ac) in enumerate(records):
+            stamps[k], w[k], a[k] = st, om, ac
+        if vision_stamp is not None:
+            stamps[K - 1] = vision_stamp
+        status = np.zeros(K, dtype=np.int32)
+        ld = Sll.stride(0) if Sll is not None else 0
+        self.b._check(self.lib.eqf_tiled_propagate_burst(self._h, K, self._dp(stamps), self._dp(w), self._dp(a), int(vision_stamp is not None), self._p(Sll),
+                                                         ld, status.ctypes.data_as(ctypes.POINTER(ctypes.c_int))), "eqf_tiled_propagate_burst")
+        return [int(x) for x in status]
+
     def edit_landmarks(self, remove_slots, add_slots, add_bearings, depth, new_num_slots, Sll):
         """removeLandmarkAtIndex for remove_slots, then addNewLandmarks into add_slots (include/eqf_vio_amd.h: eqf_tiled_edit_landmarks);
         the geometry in force must cover max(old, new) slots."""
@@ -439,6 +459,7 @@ class TiledFilter:
         self.taken = np.zeros(self.cap, dtype=bool)
         self.nslots = 0
         self.churn_stats = dict(removed_old=0, removed_outliers=0, added=0)
+        self._queue, self._mirror_time = [], None  # IMU calls waiting for their burst; the filter's time as the queued calls leave it
         self.lookahead = True  # factor the next diagonal block on a second stream in the shadow of the trailing update (_chain)
         self.phase_ms = None  # set to a dict to collect GPU time per phase (bench.py): {"propagate": ms, "prep": ms, "chain_S": ...}
         self._pending = []
@@ -519,9 +540,35 @@ class TiledFilter:
         self._accS = self._accS_buf[:, : 3 * geo.nlc + NARROW_S]
 
     # ---- VIOFilter::processIMUData (VIOFilter.cpp:120-131)
+    # IMU calls are QUEUED (up to HipBackend.BURST_MAX - 1 of them) and leave for the device with the next vision call, getter or full queue as
+    # one burst: every call keeps its own linearisation, but the local blocks of Sigma are read and written once per burst instead of once
+    # per call (eqf_tiled_propagate_burst).  The status a call returns is the reference's control flow (VIOFilter.cpp:120-131, :146-152),
+    # mirrored here: it only depends on the stamps.  burst = False: one launch sequence per call, as before.
+    burst = True
+
     def processIMUData(self, stamp, omega, accel):
+        if not (self.burst and hasattr(self.be, "propagate_burst")):
+            with self.be.main(), self._Phase(self, "propagate"):
+                return self.be.propagate(stamp, omega, accel, True, self.Sll)
+        if self._mirror_time is None:
+            self._mirror_time = self.be.time()
+        st = 1 if self._mirror_time < 0 else (2 if not (stamp - self._mirror_time > 0) else 0)  # EQF_SKIPPED_BEFORE_FIRST_IMU / _NONPOSITIVE_DT
+        self._mirror_time = float(stamp)
+        self._queue.append((float(stamp), np.array(omega, dtype=np.float64), np.array(accel, dtype=np.float64)))
+        if len(self._queue) >= self.be.BURST_MAX - 1:
+            self._flush()
+        return st
+
+    def _flush(self, vision_stamp=None):
+        """the queued IMU calls (and the vision call's integration) -> the device; returns the status of the vision call's integration"""
+        if not self._queue and vision_stamp is None:
+            return 0
+        recs, self._queue = self._queue, []
         with self.be.main(), self._Phase(self, "propagate"):
-            return self.be.propagate(stamp, omega, accel, True, self.Sll)
+            status = self.be.propagate_burst(recs, vision_stamp, self.Sll)
+        if vision_stamp is not None and status[-1] == 0:
+            self._mirror_time = float(vision_stamp)
+        return status[-1]
 
     # ---- VIOFilter::processVisionData (VIOFilter.cpp:232-302)
     def processVisionData(self, stamp, ids, bearings):
@@ -533,8 +580,11 @@ class TiledFilter:
         y = np.asarray(bearings, dtype=np.float64).reshape(-1, 3)
         if len(ids) != len(y) or (len(ids) > 1 and not np.all(np.diff(ids) > 0)):
             raise ValueError("bearings must come with strictly ascending ids (VIOFilter.cpp:239-240)")
-        with self._Phase(self, "propagate"):
-            st = self.be.propagate(stamp, None, None, False, self.Sll)  # :233 integrateUpToTime
+        if self.burst and hasattr(self.be, "propagate_burst"):
+            st = self._flush(stamp)  # the queued IMU calls + :233 integrateUpToTime, one pass over the local blocks
+        else:
+            with self._Phase(self, "propagate"):
+                st = self.be.propagate(stamp, None, None, False, self.Sll)  # :233 integrateUpToTime
         if st != 0:
             return st  # :234-236
         with self._Phase(self, "churn"):
@@ -615,6 +665,7 @@ class TiledFilter:
             self.Sll.copy_(S[rows][:, cols].to(self.Sll.device))
         self.be.set_state(st)
         self.ids = np.asarray(st["ids"], dtype=np.int64)
+        self._queue, self._mirror_time = [], None
         self.slot_of = np.arange(N, dtype=np.int64)  # the snapshot's order is the reference's: slot i = landmark i
         self.taken = np.zeros(self.cap, dtype=bool)
         self.taken[:N] = True
@@ -809,6 +860,7 @@ class TiledFilter:
 
     # ---- getters
     def getTime(self):
+        self._flush()
         return self.be.time()
 
     def _coords(self, unit, base):
@@ -817,12 +869,14 @@ class TiledFilter:
 
     def stateEstimate(self):
         """VIOFilter::stateEstimate (:304): landmarks in the reference's order"""
+        self._flush()
         e = dict(self.be.state_estimate())
         e["p"] = np.asarray(e["p"]).reshape(-1, 3)[self.slot_of]
         e["ids"] = self.ids.copy() if self.ids is not None else np.zeros(0, dtype=np.int64)
         return e
 
     def bias(self):
+        self._flush()
         return self.be.bias()
 
     def lastUpdate(self):
@@ -837,6 +891,7 @@ class TiledFilter:
     def stateCovariance(self):
         """Dense Sigma (reference index map and landmark order) gathered to every rank -- tests and snapshots
         (VIOFilter::stateCovariance, :306-309)."""
+        self._flush()
         with self.be.main():
             S = self._state_covariance()
         idx = np.concatenate([np.arange(11), self._coords(3, 11)])
@@ -844,6 +899,7 @@ class TiledFilter:
 
     def slotCovariance(self):
         """Dense Sigma over ALL slots in use, holes included (slot order) -- tests of the hole invariants."""
+        self._flush()
         with self.be.main():
             return self._state_covariance()
 

@@ -225,6 +225,13 @@ int eqf_tiled_set_geometry(eqf_tiled* t, int nlr, const int* rowMap, int nlc, co
  * (VIOFilter.cpp:188-189, F = [[F_bb, 0], [L, D]]).  Sll may be NULL while there are no landmarks.  Returns EQF_OK or the
  * EQF_SKIPPED_* code of the reference's silent early-outs. */
 int eqf_tiled_propagate(eqf_tiled* t, double stamp, const double* omega, const double* accel, int is_imu, double* Sll, int ldl);
+/* K <= 16 consecutive calls of eqf_tiled_propagate as ONE pass over the local blocks: the IMU calls between two vision frames and, with
+ * last_is_vision, the vision call's integrateUpToTime as the last one (stamps[K]; omega / accel [K][3], rows of IMU calls only are read).
+ * Every call keeps its own linearisation and its own base panel (K small O(N) launches), the Riccati steps of the local blocks are applied
+ * back to back in registers (VIOFilter.cpp:188-189 K times; Sll is read and written once).  status[k] = what eqf_tiled_propagate would have
+ * returned for call k; the state afterwards is the state after the K calls, call for call. */
+int eqf_tiled_propagate_burst(eqf_tiled* t, int K, const double* stamps, const double* omega, const double* accel, int last_is_vision,
+    double* Sll, int ldl, int* status);
 /* addNewLandmarks on an empty state (VIOFilter.cpp:345-391, :361-366): n landmarks p0 = y * initialSceneDepth, Q = identity;
  * bearings[n][3] host memory.  Sll (geometry set for n landmarks) is initialised: initialPointVariance on the diagonal.
  * EQF_ERR_UNSUPPORTED if the filter already has landmarks. */

@@ -299,6 +299,7 @@ def test_tiled_filter_N4000_against_the_single_gpu_product_path():
                 prior_tr = 11.0 + 3 * N * d["initialPointVariance"]  # (an upper bound of the prior's trace: the new landmarks' variance)
             else:
                 # the two halves of processVisionData by hand, to see the prior: integrateUpToTime (VIOFilter.cpp:233), then the update
+                tf._flush()  # (the queued IMU calls first: this test drives the backend by hand)
                 assert be.propagate(stamp, None, None, False, tf.Sll) == 0
                 prior_tr = float(np.trace(tf.stateCovariance()))
                 tf._update(np.asarray(st.bearings[k], dtype=np.float64))
@@ -651,3 +652,48 @@ def test_tiled_filter_restart_from_a_churned_single_gpu_snapshot_and_churn_on(or
     assert n_upd >= 5 and cs["removed_old"] + cs["removed_outliers"] >= 2 and cs["added"] >= 2, (n_upd, cs)
     e1, e2 = tf.stateEstimate(), fo.stateEstimate()
     assert np.abs(e1["x"] - e2["x"]).max() <= 1e-9 and np.abs(e1["p"] - e2["p"]).max() <= 1e-8 and be.device_error() == 0
+
+
+@pytest.mark.parametrize("N,bl,imu_rate", [(50, 16, 200.0), (150, 64, 400.0), (37, 8, 1000.0)])
+def test_tiled_imu_bursts_equal_the_single_calls_bitwise(oracle_lib, N, bl, imu_rate):
+    """eqf_tiled_propagate_burst: the IMU calls between two vision frames + the vision call's integration as ONE pass over the local blocks
+    (every call its own linearisation and base panel) against one launch sequence per call -- Sigma, state, bias bitwise equal after every
+    frame, with queues that overflow (20 and 50 calls per frame against 15 per burst), with churn and the gate; and against the oracle."""
+    from eqf_vio_amd import synth, tiled
+
+    d = synth.template_settings_dict()
+    d["outlierThreshold"] = 0.01
+    st = synth.make_stream(N, duration=0.36, imu_rate=imu_rate)
+    meas = synth.churn_measurements(st, seed=5, outlier_frames=(3,), outlier_angle=0.05)
+    fo = oracle_lib.OracleFilter(d)
+    tfs = []
+    for burst in (True, False):
+        be = tiled.HipBackend(d, capacity=N)
+        tf = tiled.TiledFilter(tiled.ProcessGrid(None, 1, 1, device=be.device), be, bl)
+        tf.burst = burst
+        tfs.append(tf)
+    n_upd, statuses = 0, [[], []]
+    for kind, k in st.events():
+        if kind == "imu":
+            r = st.imu[k]
+            fo.processIMUData(r[0], r[1:4], r[4:7])
+            for q, tf in enumerate(tfs):
+                statuses[q].append(tf.processIMUData(r[0], r[1:4], r[4:7]))
+        else:
+            fo.processVisionData(st.vision_stamps[k], *meas[k])
+            for q, tf in enumerate(tfs):
+                statuses[q].append(tf.processVisionData(st.vision_stamps[k], *meas[k]))
+            n_upd += 1
+            Sa, Sb = tfs[0].stateCovariance(), tfs[1].stateCovariance()
+            assert np.array_equal(Sa, Sb), (n_upd, float(np.abs(Sa - Sb).max()))
+            ea, eb = tfs[0].stateEstimate(), tfs[1].stateEstimate()
+            assert all(np.array_equal(ea[key], eb[key]) for key in ("q", "x", "v", "p")) and np.array_equal(tfs[0].bias(), tfs[1].bias())
+            So = fo.stateCovariance()
+            assert np.linalg.norm(Sa - So) / np.linalg.norm(So) <= 1e-9
+    assert statuses[0] == statuses[1] and n_upd >= 6
+    # a trailing queue is flushed by a getter
+    r = st.imu[-1]
+    for tf in tfs:
+        tf.processIMUData(r[0] + 0.001, r[1:4], r[4:7])
+    assert np.array_equal(tfs[0].stateCovariance(), tfs[1].stateCovariance()) and tfs[0].getTime() == tfs[1].getTime() == r[0] + 0.001
+    assert tfs[0].be.device_error() == 0 and tfs[1].be.device_error() == 0
