@@ -71,6 +71,15 @@ class NumpyBackend:
             return 3
         return status
 
+    BURST_MAX = 16
+
+    def propagate_burst(self, records, vision_stamp, Sll):
+        """eqf_tiled_propagate_burst's contract: the state after the calls, call for call (the device does it in one pass over Sll)"""
+        status = [self.propagate(st, w, a, True, Sll) for (st, w, a) in records]
+        if vision_stamp is not None:
+            status.append(self.propagate(vision_stamp, None, None, False, Sll))
+        return status
+
     def _integrate(self, newTime, doRiccati, Sll):
         f, s = self.f, self.f.settings
         if f.currentTime < 0:
