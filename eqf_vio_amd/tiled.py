@@ -328,8 +328,32 @@ class HipBackend:
                       "eqf_tile_potrf")
         return drec
 
+    TRSM_SPLIT = 6  # block rows of 64 from which a solve is split in two (see trsm_left)
+
     def trsm_left(self, L, drec, Bm):
-        """In place: Bm (n x m view) <- L^-1 Bm."""
+        """In place: Bm (n x m view) <- L^-1 Bm.
+        eqf_tile_trsm is one workgroup per 64-column strip, and a strip is a CHAIN of nb (nb + 1) / 2 block products (nb = n / 64): its time
+        is that chain's latency whatever the width.  So from TRSM_SPLIT block rows on the solve is split once, [L11 0; L21 L22]:
+        X1 = L11^-1 B1 (a chain of a quarter of the products), B2 -= L21 X1 as ONE product on the whole chip (eqf_tile_gemm_tn, with L21
+        transposed into a scratch operand), X2 = L22^-1 B2 -- the records of L22's block columns are the tail of L's."""
+        n = L.shape[0]
+        nb = (n + 63) // 64
+        if nb < self.TRSM_SPLIT or Bm.shape[1] < 256:
+            self._trsm_launch(L, drec, Bm)
+            return
+        h = 64 * (nb // 2)
+        self._trsm_launch(L[:h, :h], drec, Bm[:h])
+        key = (n - h, h, self._cur().value)  # (one scratch operand per shape AND stream: the two chains solve side by side)
+        if not hasattr(self, "_l21t"):
+            self._l21t = {}
+        if key not in self._l21t:
+            self._l21t[key] = self.empty(h, n - h)
+        l21t = self._l21t[key]
+        l21t.copy_(L[h:, :h].t())
+        self.gemm_tn(Bm[h:], l21t, Bm[:h], -1.0)
+        self._trsm_launch(L[h:, h:], drec[(h // 64) * self.DREC:], Bm[h:])
+
+    def _trsm_launch(self, L, drec, Bm):
         self.b._check(self.lib.eqf_tile_trsm(self.dev, self._cur(), self._p(L), L.stride(0), L.shape[0], self._p(drec), self._p(Bm),
                                              Bm.stride(0), Bm.shape[1], 0), "eqf_tile_trsm")
 
@@ -700,13 +724,30 @@ class TiledFilter:
         prepared = be.record()
         e_done = None
         if self.overlap_chains:
+            # The two chains are enqueued ALTERNATELY, block row by block row: a chain is a few hundred launches, and enqueued one chain
+            # after the other the second stream sat idle until the host was through with the first -- 32 of an update's 84 ms under the
+            # profiler (scripts/queue_summary.py), the update was bound by the HOST's launch rate, not by the GPU.
+            stepsE = self._chain_steps(self.E, 3, 3 * geo.nlc, hook_e, self._wmax_e, self.gE, self._bufs["E"], be.aux_side)
+            stepsS = self._chain_steps(self.M, 2, nA, hook_s, self._wmax, self.g, self._bufs["S"], be.side)
+            phE, phS = self._Phase(self, "chain_E"), self._Phase(self, "chain_S")
             with be.aux():
                 be.wait(prepared)
-                with self._Phase(self, "chain_E"):
-                    self._chain(self.E, 3, 3 * geo.nlc, hook_e, self._wmax_e, self.gE, self._bufs["E"], be.aux_side)
+                phE.__enter__()
+            phS.__enter__()
+            doneE = doneS = False
+            while not (doneE and doneS):
+                if not doneE:
+                    with be.aux():
+                        doneE = next(stepsE, None) is None
+                if not doneS:
+                    doneS = next(stepsS, None) is None
+            with be.aux():
+                phE.__exit__(None, None, None)
                 e_done = be.record()
-        with self._Phase(self, "chain_S"):
-            self._chain(self.M, 2, nA, hook_s, self._wmax, self.g, self._bufs["S"], be.side)
+            phS.__exit__(None, None, None)
+        else:
+            with self._Phase(self, "chain_S"):
+                self._chain(self.M, 2, nA, hook_s, self._wmax, self.g, self._bufs["S"], be.side)
         with self._Phase(self, "downdate"):
             # Sigma_IJ -= Y_I^T Y_J (VIOFilter.cpp:297), one product; on a symmetric rank only the blocks on and above the block
             # diagonal are computed and the rest is mirrored
@@ -790,7 +831,13 @@ class TiledFilter:
         return out[:, il0 * bsF:]
 
     def _chain(self, X, unit, nA, hook, wmax, g, bufs, side):
-        """Blocked right-looking Cholesky by block ROWS of the SPD matrix in X[:, :nA] (upper blocks, block size unit * bl, block-cyclic
+        """all block rows of _chain_steps, one after the other"""
+        for _ in self._chain_steps(X, unit, nA, hook, wmax, g, bufs, side):
+            pass
+
+    def _chain_steps(self, X, unit, nA, hook, wmax, g, bufs, side):
+        """(a generator: one block row per step, so that the caller can feed two factorisations to their streams alternately)
+        Blocked right-looking Cholesky by block ROWS of the SPD matrix in X[:, :nA] (upper blocks, block size unit * bl, block-cyclic
         over the grid) with the right-hand sides X[:, nA:]; X is consumed.  hook(k, bk, Bop, off, contributions) runs on every rank once
         block row k is solved: Bop[:, off:] holds the right-hand-side part of my process column.
         Look-ahead: the diagonal block is the serial part (one workgroup, eqf_tile_potrf).  As soon as block row k is solved, the owner of
@@ -857,6 +904,7 @@ class TiledFilter:
                     be.gemm_tn(Ct[:, : nA - c0], Ua, Bop[:, : nA - c0], -1.0, mask=(bsF, bsF, il0, g.Pr, g.pr, jl0, g.Pc, g.pc))
                 be.gemm_tn(Ct[:, nA - c0:], Ua, Bop[:, nA - c0:], -1.0)
             hook(k, bk, Bop, nA - c0, contributions)
+            yield k
 
     # ---- getters
     def getTime(self):
