@@ -88,18 +88,32 @@ __global__ __launch_bounds__(256) void k_compact(Glob* g, const int* map, const 
     const int b = blockIdx.z;
     const int* mp = map + (long long)b * cap;
     const int Nn = newN[b];
+    // (all 23 loads of a landmark first, then its stores: with a store between two loads the compiler must assume they alias and the
+    // record becomes 23 serial round trips -- this one workgroup was the long pole of the launch)
     for (int i = threadIdx.x; i < Nn; i += blockDim.x) {
         const int o = mp[i];
-        for (int c = 0; c < 3; ++c) scratch[((long long)b * kLmRec + c) * cap + i] = p0[((long long)b * 3 + c) * cap + o];
-        for (int c = 0; c < 5; ++c) scratch[((long long)b * kLmRec + 3 + c) * cap + i] = Q[((long long)b * 5 + c) * cap + o];
-        for (int c = 0; c < 15; ++c) scratch[((long long)b * kLmRec + 8 + c) * cap + i] = lmc[((long long)b * 15 + c) * cap + o];
+        double v[kLmRec];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = p0[((long long)b * 3 + c) * cap + o];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) v[3 + c] = Q[((long long)b * 5 + c) * cap + o];
+#pragma unroll
+        for (int c = 0; c < 15; ++c) v[8 + c] = lmc[((long long)b * 15 + c) * cap + o];
+#pragma unroll
+        for (int c = 0; c < kLmRec; ++c) scratch[((long long)b * kLmRec + c) * cap + i] = v[c];
     }
     __threadfence_block();
     __syncthreads();
     for (int i = threadIdx.x; i < Nn; i += blockDim.x) {
-        for (int c = 0; c < 3; ++c) p0[((long long)b * 3 + c) * cap + i] = scratch[((long long)b * kLmRec + c) * cap + i];
-        for (int c = 0; c < 5; ++c) Q[((long long)b * 5 + c) * cap + i] = scratch[((long long)b * kLmRec + 3 + c) * cap + i];
-        for (int c = 0; c < 15; ++c) lmc[((long long)b * 15 + c) * cap + i] = scratch[((long long)b * kLmRec + 8 + c) * cap + i];
+        double v[kLmRec];
+#pragma unroll
+        for (int c = 0; c < kLmRec; ++c) v[c] = scratch[((long long)b * kLmRec + c) * cap + i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p0[((long long)b * 3 + c) * cap + i] = v[c];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) Q[((long long)b * 5 + c) * cap + i] = v[3 + c];
+#pragma unroll
+        for (int c = 0; c < 15; ++c) lmc[((long long)b * 15 + c) * cap + i] = v[8 + c];
     }
     if (threadIdx.x == 0) g[b].N = Nn;
 }
