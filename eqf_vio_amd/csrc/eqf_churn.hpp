@@ -129,20 +129,36 @@ __global__ __launch_bounds__(256) void k_append(Glob* g, int b, int nOld, int nN
     double pointVar, int cap, const double* bearings /* filter b */, const int* perm, double* p0, double* Q, double* lmc, int* errflag, T* S,
     long long sigmaStride, int ld) {
     const int nvo = kLm0 + 3 * nOld, nvn = kLm0 + 3 * (nOld + nNew);
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    // (the bearing of this thread's new landmark -- a permutation entry, then three values behind it -- is requested BEFORE the median
+    // selection: two dependent round trips that used to come after it)
+    double yb[3] = {0.0, 0.0, 1.0};
+    if (tid < nNew) {
+        const int i = nOld + tid;
+        const double* y = bearings + 3 * (perm ? perm[(long long)b * cap + i] : i);
+        yb[0] = y[0]; yb[1] = y[1]; yb[2] = y[2];
+    }
     __shared__ double sDepth;
     if (nOld > 0 && !depthSel) {
         const double* d = depth2 + (long long)b * cap;
         for (int i = threadIdx.x; i < nOld; i += blockDim.x) {
             const double di = d[i];
-            int rank = 0;
-            for (int j = 0; j < nOld; ++j) rank += (d[j] < di) || (d[j] == di && j < i);
-            if (rank == nOld / 2) sDepth = sqrt(di);
+            int r0 = 0, r1 = 0, r2 = 0, r3 = 0;  // (four independent counters: the loads of a trip are in flight together)
+            int j = 0;
+            for (; j + 3 < nOld; j += 4) {
+                const double d0 = d[j], d1 = d[j + 1], d2 = d[j + 2], d3 = d[j + 3];
+                r0 += (d0 < di) || (d0 == di && j < i);
+                r1 += (d1 < di) || (d1 == di && j + 1 < i);
+                r2 += (d2 < di) || (d2 == di && j + 2 < i);
+                r3 += (d3 < di) || (d3 == di && j + 3 < i);
+            }
+            for (; j < nOld; ++j) r0 += (d[j] < di) || (d[j] == di && j < i);
+            if (r0 + r1 + r2 + r3 == nOld / 2) sDepth = sqrt(di);
         }
         __syncthreads();
     }
     const double depth = nOld > 0 ? (depthSel ? depthSel[b] : sDepth) : depthDefault;  // (:361-366)
     T* Sb = S + (long long)b * sigmaStride;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     // new rows (all columns) and new columns (old rows)
     const long long total = (long long)(nvn - nvo) * nvn + (long long)nvo * (nvn - nvo);
     for (long long e = tid; e < total; e += nth) {
@@ -159,10 +175,22 @@ __global__ __launch_bounds__(256) void k_append(Glob* g, int b, int nOld, int nN
     }
     for (int j = tid; j < nNew; j += nth) {
         const int i = nOld + j;
-        const double* y = bearings + 3 * (perm ? perm[(long long)b * cap + i] : i);
-        p0[((long long)b * 3 + 0) * cap + i] = y[0] * depth;
-        p0[((long long)b * 3 + 1) * cap + i] = y[1] * depth;
-        p0[((long long)b * 3 + 2) * cap + i] = y[2] * depth;
+        double yv[3] = {yb[0], yb[1], yb[2]};
+        if (j != tid) {  // (more new landmarks than threads in the launch: cannot happen with its grid, kept for safety)
+            const double* yp = bearings + 3 * (perm ? perm[(long long)b * cap + i] : i);
+            yv[0] = yp[0]; yv[1] = yp[1]; yv[2] = yp[2];
+        }
+        const double* y = yv;
+        // The origin landmark as it is STORED is what its constants must come from: a restored filter recomputes them from p0
+        // (k_restore_constants) and has to continue bitwise (tests/test_replay.py).  Without the barrier the compiler may fuse y * depth
+        // into the first operations of landmarkConstants -- it did, after an unrelated change of this kernel's shape.
+        double px = y[0] * depth, py = y[1] * depth, pz = y[2] * depth;
+#if defined(__HIP_DEVICE_COMPILE__)
+        __asm__ volatile("" : "+v"(px), "+v"(py), "+v"(pz));
+#endif
+        p0[((long long)b * 3 + 0) * cap + i] = px;
+        p0[((long long)b * 3 + 1) * cap + i] = py;
+        p0[((long long)b * 3 + 2) * cap + i] = pz;
         Q[((long long)b * 5 + 0) * cap + i] = 1.0;
         Q[((long long)b * 5 + 1) * cap + i] = 0.0;
         Q[((long long)b * 5 + 2) * cap + i] = 0.0;
@@ -170,7 +198,7 @@ __global__ __launch_bounds__(256) void k_append(Glob* g, int b, int nOld, int nN
         Q[((long long)b * 5 + 4) * cap + i] = 1.0;
         double cst[15];
         int bad = 0;
-        landmarkConstants(mk3(y[0] * depth, y[1] * depth, y[2] * depth), cst, &bad);
+        landmarkConstants(mk3(px, py, pz), cst, &bad);
         for (int c = 0; c < 15; ++c) lmc[((long long)b * 15 + c) * cap + i] = cst[c];
         if (bad && errflag) atomicOr(errflag, 16);
     }
