@@ -797,7 +797,10 @@ __global__ void k_tl_append(Glob* g0, Glob* g1, int n, double depth, int cap, co
     if (i >= n) return;
     active[i] = 1;
     const double* y = bearings + 3 * i;
-    const d3 p = mk3(y[0] * depth, y[1] * depth, y[2] * depth);
+    d3 p = mk3(y[0] * depth, y[1] * depth, y[2] * depth);
+#if defined(__HIP_DEVICE_COMPILE__)
+    __asm__ volatile("" : "+v"(p.x), "+v"(p.y), "+v"(p.z));  // (the constants must come from p0 AS STORED: eqf_churn.hpp, k_append)
+#endif
     p0[i] = p.x; p0[cap + i] = p.y; p0[2 * cap + i] = p.z;
     for (double* Q : {Q0, Q1}) {
         Q[i] = 1.0; Q[cap + i] = 0.0; Q[2 * cap + i] = 0.0; Q[3 * cap + i] = 0.0; Q[4 * cap + i] = 1.0;
@@ -837,6 +840,9 @@ __global__ void k_tl_edit_state(Glob* g0, Glob* g1, int n, int newN, const int* 
     if (m == 2) {
         const double* y = bearings + 3 * i;
         p = mk3(y[0] * depth, y[1] * depth, y[2] * depth);
+#if defined(__HIP_DEVICE_COMPILE__)
+        __asm__ volatile("" : "+v"(p.x), "+v"(p.y), "+v"(p.z));  // (as in k_tl_append)
+#endif
         landmarkConstants(p, cst, &bad);
     } else {
         for (int c = 0; c < 15; ++c) cst[c] = (c >= 6 && (c - 6) % 4 == 0) ? 1.0 : 0.0;  // C = 0, R_s = I
