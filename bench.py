@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--tiled-timeout", type=int, default=240, help="several GPUs: seconds after which the cfg 5 leg is given up")
     ap.add_argument("--tiled-frames", type=int, default=3, help="timed frames (a frame = 10 IMU calls + 1 vision call) after one warm-up frame")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle-checked prefix (parity block of the JSON line)")
+    ap.add_argument("--no-n1000", action="store_true", help="skip the BASELINE cfg 3 leg (one filter of N = 1000, 220 steps, with its own roofline)")
+    ap.add_argument("--no-batch8", action="store_true", help="skip the 8-filters-per-GPU leg (one GPU's share of the 64-filter batch on an 8-GPU node)")
     ap.add_argument("--no-churn", action="store_true", help="skip the landmark-churn + outlier-gate leg (per-call API, N ~ 200)")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed throw-away run that precedes the measured job")
     ap.add_argument("--no-roofline", action="store_true")
@@ -609,6 +611,9 @@ def main():
         "sigma_fro_filter0": float(res[0, 7]) if res is not None else None,
         "prewarm": None if args.no_prewarm else "66 untimed events on a separate throw-away handle before the measured one is created",
     }
+    from eqf_vio_amd import binding as _binding
+
+    line["build"] = _binding.build_info()  # which .so ran, and that it was built from the sources beside it
     if rank == 0 and not args.no_roofline:
         rl, rows, cover = roofline(fb, timed, N, B, args.precision)
         line["roofline"] = rl
@@ -665,6 +670,44 @@ def main():
             "device_error_flag": err2,
             "sigma_fro_min_max": [float(res2[:, 7].min()), float(res2[:, 7].max())] if res2 is not None else None,
         }
+
+    # ---- 8 filters per GPU: ONE GPU's share of BASELINE configs[3] on an 8-GPU node -- the figure the 0.9x strong-scaling target hangs on
+    # (8 GPUs x this against 8 x the one-GPU batch of 64 above).  One GPU only: on several GPUs batch64_strong already runs 64 / world.
+    if not args.no_batch8 and world == 1 and not args.dense_propagate and N == 200 and B == 1 and args.precision == "f64":
+        fb8, timed8, dt8, _ = timed_job(args, dist, rank, world, device, 200, 8, 880, 110)
+        err8 = fb8.device_error()
+        leg8 = {"metric": "EqF propagate+update steps/sec, 8 filters of N=200 on one GPU (one GPU's share of the 64-filter batch on 8 GPUs)",
+                "value": len(timed8) * 8 / dt8, "unit": "steps/s", "filters_per_gpu": 8, "steps": len(timed8), "warmup": 110,
+                "ms_per_step": dt8 * 1e3 / len(timed8), "us_per_frame": dt8 * 1e6 / max(sum(1 for k, _ in timed8 if k == "vision"), 1),
+                "device_error_flag": err8}
+        if not args.no_roofline:
+            rl8, rows8, cover8 = roofline(fb8, timed8, 200, 8, args.precision)
+            leg8["roofline"] = rl8
+            leg8["kernels"] = [{k: r[k] for k in ("kernel", "launches", "avg_us") if k in r} for r in rows8]
+            leg8["profile_coverage"] = cover8["kernel_time_over_wall"]
+        if "batch64_strong" in line:
+            leg8["strong_scaling_projection_8gpu"] = round(8.0 * leg8["value"] / (8.0 * line["batch64_strong"]["value"]), 3)
+            leg8["projection_note"] = ("8 GPUs x 8 filters over 8 x (one GPU x 64 filters): what `batch64_strong` at --gpus 8 would show relative to "
+                                       "linear if the ranks do not disturb each other (no data-path collective); a projection from ONE GPU, not a measurement")
+        del fb8
+        line["batch8"] = leg8
+
+    # ---- BASELINE configs[2]: one filter of N = 1000 (Sigma 3011 x 3011), the structured product path, with its own roofline
+    if not args.no_n1000 and world == 1 and not args.dense_propagate and N == 200 and B == 1 and args.precision == "f64":
+        fbk, timedk, dtk, _ = timed_job(args, dist, rank, world, device, 1000, 1, 220, 55)
+        errk = fbk.device_error()
+        legk = {"metric": "EqF propagate+update steps/sec at N=1000 landmarks (BASELINE configs[2]), structured product path, 1 GPU",
+                "value": len(timedk) / dtk, "unit": "steps/s", "steps": len(timedk), "warmup": 55, "ms_per_step": dtk * 1e3 / len(timedk),
+                "device_error_flag": errk, "dtype": args.precision}
+        if not args.no_roofline:
+            rlk, rowsk, coverk = roofline(fbk, timedk, 1000, 1, args.precision)
+            legk["roofline"] = rlk
+            legk["kernels"] = [{k: r[k] for k in ("kernel", "launches", "avg_us", "bound", "achieved", "unit", "frac") if k in r} for r in rowsk]
+            legk["profile_coverage"] = coverk["kernel_time_over_wall"]
+            legk["roofline_note"] = ("`frac` prices SURVEY 8(d)'s 2 n^2 m for the downdate, the kernel executes n^2 m (symmetry): read `frac_executed` "
+                                     "beside it; the dense MFMA Riccati backend of this config is `bench.py --landmarks 1000 --dense-propagate`")
+        del fbk
+        line["n1000"] = legk
 
     # ---- BASELINE configs[4]: one N = 4000 filter partitioned over the ranks of the job
     if not args.no_tiled and world in GRIDS and not args.dense_propagate and not args.pmc_child:

@@ -59,8 +59,8 @@ EXPORTED_SYMBOLS = [
     "eqf_settings_default", "eqf_create", "eqf_destroy", "eqf_reset", "eqf_process_imu", "eqf_process_vision",
     "eqf_stream_upload", "eqf_stream_imu", "eqf_stream_vision", "eqf_synchronize", "eqf_get_time", "eqf_num_landmarks",
     "eqf_get_ids", "eqf_get_state_estimate", "eqf_get_origin", "eqf_get_group", "eqf_get_bias", "eqf_get_sigma",
-    "eqf_set_sigma", "eqf_set_state", "eqf_set_camera_offset", "eqf_get_integrator", "eqf_get_last_update", "eqf_debug_get_blocks", "eqf_device_error", "eqf_set_dense_propagate", "eqf_set_imu_burst", "eqf_profile_enable",
-    "eqf_profile_get", "eqf_profile_class_name", "eqf_version", "eqf_tile_propagate", "eqf_tile_downdate", "eqf_tile_potrf", "eqf_tile_trsm", "eqf_tile_gemm_tn", "eqf_tile_mirror", "eqf_stream_create_masked", "eqf_stream_destroy",
+    "eqf_set_sigma", "eqf_set_state", "eqf_set_camera_offset", "eqf_get_integrator", "eqf_get_last_update", "eqf_debug_get_blocks", "eqf_device_error", "eqf_debug_drop_role", "eqf_set_dense_propagate", "eqf_set_imu_burst", "eqf_profile_enable",
+    "eqf_profile_get", "eqf_profile_class_name", "eqf_version", "eqf_build_info", "eqf_tile_propagate", "eqf_tile_downdate", "eqf_tile_potrf", "eqf_tile_trsm", "eqf_tile_gemm_tn", "eqf_tile_mirror", "eqf_stream_create_masked", "eqf_stream_destroy",
     "eqf_tiled_create", "eqf_tiled_destroy", "eqf_tiled_set_stream", "eqf_tiled_set_geometry", "eqf_tiled_propagate", "eqf_tiled_add_landmarks",
     "eqf_tiled_edit_landmarks", "eqf_tiled_propagate_burst",
     "eqf_tiled_update_prep", "eqf_tiled_update_finish", "eqf_tiled_synchronize", "eqf_tiled_num_landmarks", "eqf_tiled_get_time",
@@ -113,6 +113,7 @@ def lib():
         L.eqf_get_integrator.argtypes = [vp, C.c_int, _dp, _dp, _dp, _ip]
         L.eqf_debug_get_blocks.argtypes = [vp, C.c_int, _dp, _dp, _dp]
         L.eqf_device_error.argtypes = [vp]
+        L.eqf_debug_drop_role.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
         L.eqf_set_dense_propagate.argtypes = [vp, C.c_int]
         L.eqf_set_imu_burst.argtypes = [vp, C.c_int]
         L.eqf_profile_enable.argtypes = [vp, C.c_int]
@@ -120,6 +121,7 @@ def lib():
         L.eqf_profile_class_name.argtypes = [C.c_int]
         L.eqf_profile_class_name.restype = C.c_char_p
         L.eqf_version.restype = C.c_char_p
+        L.eqf_build_info.restype = C.c_char_p
         vpp = C.c_void_p
         L.eqf_tile_propagate.argtypes = [C.c_int, vpp, vpp, vpp, C.c_int, C.c_int, C.c_int, vpp, vpp, vpp, vpp, vpp, vpp, C.c_int, vpp, C.c_int,
                                          vpp, vpp, _dp, C.c_double, C.c_double, C.c_int]
@@ -156,6 +158,28 @@ def lib():
         L.eqf_tiled_set_state.argtypes = [vp, C.c_int] + [_dp] * 11 + [C.c_int, C.c_double, _dp, _dp, C.c_double, C.c_int]
         _lib = L
     return _lib
+
+
+def build_info():
+    """Which library this process loaded and whether it was built from the sources beside it: sha256 of the .so, the source hash the
+    library carries (eqf_build_info) and the same hash recomputed now over csrc/*.hip, csrc/*.hpp, include/eqf_vio_amd.h, csrc/Makefile."""
+    import glob
+    import hashlib
+
+    L = lib()
+    with open(LIB_PATH, "rb") as f:
+        so = hashlib.sha256(f.read()).hexdigest()
+    embedded = L.eqf_build_info().decode().split("=", 1)[1]
+    csrc = os.path.join(_HERE, "csrc")
+    names = sorted([os.path.basename(p) for p in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp"))]
+                   + ["../../include/eqf_vio_amd.h", "Makefile"])  # (the order of the Makefile's $(sort ...))
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(csrc, n), "rb") as f:
+            h.update(f.read())
+    now = h.hexdigest()
+    return {"library": os.path.relpath(LIB_PATH, os.path.dirname(_HERE)), "so_sha256": so, "src_sha256_in_library": embedded,
+            "src_sha256_now": now, "library_matches_sources": embedded == now}
 
 
 def default_settings():
@@ -383,6 +407,10 @@ class FilterBatch:
 
     def device_error(self):
         return lib().eqf_device_error(self._h)
+
+    def debug_drop_role(self, kind, role=0, R=0, C_=0):
+        """Fault injection (tests): one role of the update launch leaves without publishing (kind < 0: off); include/eqf_vio_amd.h."""
+        _check(lib().eqf_debug_drop_role(self._h, int(kind), int(role), int(R), int(C_)), "eqf_debug_drop_role")
 
     # ---- profiling
     def profile_enable(self, on=True):

@@ -1315,8 +1315,9 @@ EQF_DI void burstRingFusedBody(const BurstArgs& a, const int tileIdx, const int 
     __shared__ T sRow[kSlots][4][kBlkRec + 3];
     __shared__ T sTtP[kBurstMax];
     __shared__ int sRicc[kBurstMax];
-    __shared__ int sHave, sReady[2], sDone[4];
+    __shared__ int sHave, sReady[2], sDone[4], sAbort;
     if (tid < 7) ldsFlagStore(tid == 0 ? &sHave : (tid < 3 ? &sReady[tid - 1] : &sDone[tid - 3]), 0);
+    if (tid == 7) ldsFlagStore(&sAbort, 0);
     ldsBarrier();  // (the only barrier before the mirror-image pass: every live wave, i.e. 0 .. 6)
     const T* const colRec = static_cast<const T*>(a.colRec) + (long long)b * kBurstMax * a.colStep + Jc;
     const T* const rowRec = static_cast<const T*>(a.rowRec) + (long long)b * kBurstMax * a.rowStep;
@@ -1339,8 +1340,11 @@ EQF_DI void burstRingFusedBody(const BurstArgs& a, const int tileIdx, const int 
             }
             __builtin_amdgcn_s_sleep(12);  // ~0.3 us: a tick of the builders takes 1.4
             if ((++polls & 63) == 0 && wall_clock64() - t0 > 50000000LL) {  // 0.5 s: never hang the GPU
+                // (the builders never came: the waves of this workgroup are let through -- they compute on whatever the record arrays hold --
+                // but nothing of it is stored: sAbort.  The sticky bit makes the host fail the call; the handle must be reset or restored.)
                 if (lane == 0) {
                     if (a.errflag) atomicOr(a.errflag, kHoErrTimeout);
+                    ldsFlagStore(&sAbort, 1);
                     ldsFlagStore(&sHave, K);
                 }
                 break;
@@ -1487,7 +1491,8 @@ EQF_DI void burstRingFusedBody(const BurstArgs& a, const int tileIdx, const int 
         if (lane == 0) ldsFlagStore(&sDone[wv], st + 1);
         EQF_RSTAMP(4 + 3 * st);
     }
-    if (validJ && I0raw < N && I0raw >= J) {
+    const bool aborted = ldsFlagLoad(&sAbort) != 0;  // (set before the sHave that let this wave's last step through)
+    if (!aborted && validJ && I0raw < N && I0raw >= J) {
         T* dst = Sout + (long long)(kLm0 + 3 * I0raw) * ld + kLm0 + 3 * J;
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr)
@@ -1511,7 +1516,7 @@ EQF_DI void burstRingFusedBody(const BurstArgs& a, const int tileIdx, const int 
     for (int e = tid; e < kRowsPass * kWd; e += 256) {
         const int r = e / kWd, c = e % kWd;
         const int Jm = bx * 64 + r / 3, Im = by * 4 + c / 3;
-        if (Im < N && Im > Jm) Sout[(long long)(kLm0 + 3 * Jm + r % 3) * ld + kLm0 + 3 * Im + c % 3] = stage[r * kPitch + c];
+        if (!aborted && Im < N && Im > Jm) Sout[(long long)(kLm0 + 3 * Jm + r % 3) * ld + kLm0 + 3 * Im + c % 3] = stage[r * kPitch + c];
     }
 }
 

@@ -171,6 +171,7 @@ struct eqf_filter {
     int burstOcc2 = -1;            // EQF_BURST_OCC2: the 16-landmark builder built for two workgroups per CU (1), one (0), by launch size (-1)
     int resOcc2 = -1;              // EQF_RES_OCC2: k_chol_resident built for two workgroups per CU (1), one (0), by grid size (-1)
     int rolesN = -1, rolesCount = 0;  // chain shape (nbS, nbE, wtS) the role table was built for
+    int dropRole[4] = {-1, 0, 0, 0};  // eqf_debug_drop_role: (kind, role, R, C) of the role whose workgroup leaves without publishing anything
     // profiling
     bool prof = false;
     std::vector<ProfPair> profPairs;
@@ -619,6 +620,11 @@ int buildRoles(eqf_filter* f, int Nmax, bool fold) {
             for (int R = s + 2; R < nb; ++R) r.push_back({kind, 1, R, s});
             for (int t = 0; t < wt; ++t) r.push_back({kind, 2, t, s});
         }
+    // fault injection (eqf_debug_drop_role): the matching role gets an index beyond every chain -- its workgroup returns at once (`R >= nb`)
+    // and the flag it owes is never published: the hand-off time-out path of the kernel, on demand
+    if (f->dropRole[0] >= 0)
+        for (auto& q : r)
+            if (q.kind == f->dropRole[0] && q.role == f->dropRole[1] && q.R == f->dropRole[2] && q.C == f->dropRole[3]) q.R = 1 << 20;
     HIPC(hipStreamSynchronize(f->stream));
     hipFree(f->dRoles);
     f->dRoles = nullptr;
@@ -1334,6 +1340,13 @@ extern "C" int eqf_debug_burst_stamps(long long* out) {
 #endif
 const char* eqf_version(void) { return "eqf_vio_amd 0.1 (gfx950)"; }
 
+// sha256 of the sources this library was built from (csrc/Makefile: eqf_build_id.inc)
+const char* eqf_build_info(void) {
+    return "src_sha256="
+#include "eqf_build_id.inc"
+        ;
+}
+
 void eqf_settings_default(eqf_settings* s) {  // VIOFilterSettings.h:29-50
     std::memset(s, 0, sizeof(*s));
     s->biasOmegaProcessVariance = 0.001;
@@ -1986,6 +1999,14 @@ int eqf_device_error(eqf_filter* f) {
     int e = 0;
     if (hipMemcpy(&e, f->errflag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return EQF_ERR_HIP;
     return e;
+}
+
+int eqf_debug_drop_role(eqf_filter* f, int kind, int role, int R, int C) {
+    if (!f || kind > 1 || (kind >= 0 && (role < 0 || role > 2))) return EQF_ERR_INVALID;
+    GATE(f);
+    f->dropRole[0] = kind; f->dropRole[1] = role; f->dropRole[2] = R; f->dropRole[3] = C;
+    f->rolesN = -1;  // the role table is rebuilt by the next update
+    return EQF_OK;
 }
 
 int eqf_set_imu_burst(eqf_filter* f, int max_steps) {

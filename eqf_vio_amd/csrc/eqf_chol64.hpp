@@ -1298,7 +1298,7 @@ __global__ __launch_bounds__(256, (PHASE == 2 || PHASE == 3) ? 2 : 1) void k_cho
             EQF_STAMP(5);
         }
     }
-    if (bad && errflag && tid == 0) atomicOr(errflag, bad == 8 ? 8 : 4);
+    if (bad && errflag && tid == 0) atomicOr(errflag, bad == 8 ? kHoErrTimeout : 4);
 }
 
 }  // namespace eqf

@@ -33,10 +33,11 @@ EQF_DEV void hoDrain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // one thread, after the barrier that follows every storing thread's hoDrain()
 EQF_DEV void hoPublish(int* flag, int epoch) { __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // one lane; false = timed out (the producer never came: the caller raises the error flag instead of hanging the GPU).
-// `err` (the handle's sticky device error word): a timeout sets bit 8 there AT ONCE, and every wait looks at that bit every few microseconds
+// `err` (the handle's sticky device error word): a timeout sets bit 128 (kHoErrTimeout: a bit of its own -- bit 8 is a NUMERIC condition of one
+// filter, antipodal vectors in the innovation lift, and must not switch the other filters of a batch handle off) there AT ONCE, and every wait looks at that bit every few microseconds
 // and gives up as soon as it is set -- so ONE timeout anywhere in a launch unwinds the whole launch in microseconds instead of every
 // dependent wait rediscovering it after its own 0.5 s (a launch of 70 000 workgroups would spin for hours; the advisor's round-3 finding).
-constexpr int kHoErrTimeout = 8;
+constexpr int kHoErrTimeout = 128;
 EQF_DEV bool hoAborted(const int* err) { return err && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kHoErrTimeout); }
 EQF_DEV bool hoWait(const int* flag, int epoch, int* err = nullptr) {
     const long long t0 = wall_clock64();  // 100 MHz

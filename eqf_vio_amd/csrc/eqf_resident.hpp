@@ -24,7 +24,7 @@
 // (roles: the groups before theirs; downdate tiles: the S-chain's roles) -- so whatever part of the grid is resident contains a
 // workgroup that can run, co-resident grid or not.  (Until late in round 3 a co-resident grid ran the downdate in the finished role
 // workgroups, which waited for higher block indices while holding their CUs: removed.)  Every wait is bounded (eqf_handoff.hpp,
-// 0.5 s): a timeout raises the sticky device error flag (bit 8 -> EQF_ERR_NUMERIC from eqf_device_error) and the workgroup that saw it
+// 0.5 s): a timeout raises the sticky device error flag (bit 128 -> EQF_ERR_NUMERIC from eqf_device_error) and the workgroup that saw it
 // publishes nothing more, so the downdate tiles never see the S-chain complete: Sigma_out is not overwritten from stale operands.
 // The host uses this kernel at every size whose chains are of unequal length (eqf_capi.hip: since the build for two workgroups per CU,
 // OCC2 below, it beats the per-column launches from one filter of N = 200 to 96 of them and to one filter of N = 4000).
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
 #endif
         return;
     }
-    // (bit 8 of the sticky device error word: a hand-off of this launch -- or of an earlier one: the handle must be reset -- timed out.
+    // (bit 128 of the sticky device error word: a hand-off of this launch -- or of an earlier one: the handle must be reset -- timed out.
     // Role workgroups that start after that leave at once; nothing they would publish could be complete.)
     if (hoAborted(ra.errflag)) return;
     const ResRole role = ra.roles[roleIdx];
@@ -472,7 +472,10 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         factorFirstFromSigma<T, true>(a, ch, b, s, &bad);
         hoDrain();
         __syncthreads();
-        if (tid == 0 && !bad) hoPublish(ch.flags + (long long)b * ch.strideF, epoch);
+        // (published whatever the pivots said, like every D[R] of the row heads: a non-positive pivot is reported through bit 4 at the end of
+        // the kernel and the chain runs on -- withholding the flag turned a numeric error into a 0.5 s stall of every role of the chain.
+        // `bad` is the pivot wave's verdict: v_readlane broadcasts make it uniform over wave 0, thread 0 included; F0 waits for nobody.)
+        if (tid == 0) hoPublish(ch.flags + (long long)b * ch.strideF, epoch);
     } else if (role.role == 0) {
         // =========================================================================================== H(R)
         const int R = role.R;
@@ -828,8 +831,8 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
             EQF_WSTAMP(5);
         }
     }
-    if (bad && ra.errflag && tid == 0) atomicOr(ra.errflag, bad == 8 ? 8 : 4);
-    // A hand-off that timed out left this workgroup with stale operands.  The sticky flag (bit 8, include/eqf_vio_amd.h) makes the host
+    if (bad && ra.errflag && tid == 0) atomicOr(ra.errflag, bad == 8 ? kHoErrTimeout : 4);  // (`bad == 8` is this kernel's LOCAL code for a failed wait)
+    // A hand-off that timed out left this workgroup with stale operands.  The sticky flag (bit 128, include/eqf_vio_amd.h) makes the host
     // report EQF_ERR_NUMERIC, and the workgroup has published NOTHING since (`bad != 8` at every publish above): the workgroups that depend
     // on it time out in turn, the count of finished Y tiles stays short, the downdate tiles give up -- Sigma_out is not overwritten with
     // a plausible-looking wrong matrix.

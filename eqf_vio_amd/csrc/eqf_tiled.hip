@@ -142,6 +142,7 @@ int initTiledState(eqf_tiled* t) {
         HIPC(hipMemcpy(t->Sb[q], base.data(), sizeof(double) * 12 * t->ldb, hipMemcpyHostToDevice));
     }
     HIPC(hipMemset(t->p0, 0, sizeof(double) * 3 * t->cap));
+    HIPC(hipMemset(t->lmc, 0, sizeof(double) * 15 * t->cap));  // (C = 0 for every slot that has never held a landmark)
     HIPC(hipMemset(t->errflag, 0, sizeof(int)));
     HIPC(hipMemset(t->active, 0, sizeof(int) * t->cap));
     t->hostActive.assign(t->cap, 0);
@@ -424,6 +425,8 @@ int eqf_tiled_edit_landmarks(eqf_tiled* t, int n_remove, const int* remove_slots
         mark[s] = 2;
         for (int c = 0; c < 3; ++c) bear[(size_t)3 * s + c] = add_bearings[(size_t)3 * k + c];
     }
+    for (int s = t->N; s < new_num_slots; ++s)  // the working set only grows over slots this call fills: a slot that was never initialised has
+        if (mark[s] != 2) return EQF_ERR_INVALID;  // no identity constants / unit diagonal block (the hole invariants) to decouple it
     for (int s = new_num_slots; s < t->N; ++s)  // slots given up at the top must be empty after the edit
         if (t->hostActive[s] && mark[s] != 1) return EQF_ERR_INVALID;
     // the geometry must cover every slot in use before or after the edit: landmark blocks of marked slots are cleared through it

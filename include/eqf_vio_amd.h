@@ -149,19 +149,27 @@ int eqf_get_last_update(eqf_filter* f, int b, double* delta, double* gamma, doub
 int eqf_debug_get_blocks(eqf_filter* f, int b, double* common, double* rec, double* c0);
 /* Sticky device-side error flag, 0 if none; a bit mask (any bit -> the C++ facade throws std::domain_error, like the reference's
  * SO3FromVectors, SO3.cpp:160): 1 antipodal vectors / singular gravity chart in a propagate step; 2 the same while building the residual
- * or C0i; 4 a pivot of S or Sigma_e not positive; 8 antipodal vectors in the innovation lift, OR an in-launch hand-off of k_chol_resident
- * timed out (0.5 s: the GPU was taken away from the launch for that long) -- that update's Sigma was NOT written and the
- * filter must be reset or restored; 16 / 32 a new / restored landmark on the chart pole.
- * About the hand-offs behind bit 8: k_chol_resident (one launch per vision update, csrc/eqf_resident.hpp) lets workgroups of ONE launch
+ * or C0i; 4 a pivot of S or Sigma_e not positive; 8 antipodal vectors in the innovation lift (numeric, one filter: the other filters of a
+ * batch handle keep running); 16 / 32 a new / restored landmark on the chart pole; 64 singular gravity chart in the dense Riccati backend;
+ * 128 an in-launch hand-off of k_chol_resident / k_burst_fused timed out (0.5 s: the GPU was taken away from the launch for that long) --
+ * that launch did not write Sigma and the handle must be reset (eqf_reset) or restored (eqf_set_state): until then every later launch
+ * with hand-offs leaves at once.  (After a timeout inside an IMU burst the covariance the handle points at is the other ping-pong
+ * buffer, i.e. NOT a valid state: restore, do not continue.)
+ * About the hand-offs behind bit 128: k_chol_resident (one launch per vision update, csrc/eqf_resident.hpp) lets workgroups of ONE launch
  * wait for each other.  It is free of deadlock on any grid -- also many times larger than the chip -- under ONE assumption about the
  * hardware that HIP does not document: workgroups are started in the order of their linear index (a workgroup only ever waits for
  * lower indices, so whatever is resident contains a runnable one).  If a device or driver ever broke that order, or took the GPU away
- * for more than 0.5 s (preemption, a debugger), nothing hangs and nothing wrong is written: the first wait that times out sets bit 8 at
+ * for more than 0.5 s (preemption, a debugger), nothing hangs and nothing wrong is written: the first wait that times out sets bit 128 at
  * once, every other wait of the launch sees the bit within microseconds and gives up, no workgroup publishes anything after a failed
  * wait, the covariance downdate does not run (Sigma keeps its pre-update value), and the call that next touches the handle returns
  * EQF_ERR_NUMERIC.  The flag is sticky: later updates of the handle leave at once until eqf_reset.
  * EQF_CHOL_RESIDENT=0 selects one launch per 64-wide block column instead (no in-launch dependency at all). */
 int eqf_device_error(eqf_filter* f);
+/* Fault injection for the in-launch hand-offs (tests only): from the next update on, the workgroup of k_chol_resident with role (kind:
+ * 0 S-chain / 1 E-chain; role: 0 row head H(R), 1 interior tile T(R, C), 2 right-hand-side tile W(t = R, C)) leaves without doing or
+ * publishing anything, as if it had never been scheduled: its consumers time out after 0.5 s, bit 128 is raised, the launch unwinds, the
+ * covariance downdate does not run.  kind < 0 switches the injection off.  The handle needs eqf_reset / eqf_set_state afterwards. */
+int eqf_debug_drop_role(eqf_filter* f, int kind, int role, int R, int C);
 
 /* IMU bursts.  processIMUData calls (VIOFilter.cpp:120-131) only depend on each other and on the state, so the library
  * queues them on the host and launches up to 15 of them -- plus the integrateUpToTime of the processVisionData call
@@ -242,7 +250,9 @@ int eqf_tiled_add_landmarks(eqf_tiled* t, int n, const double* bearings, double*
  * initialPointVariance I on the diagonal.  new_num_slots = slots in use afterwards (>= 1 + the highest active slot; eqf_tiled_num_landmarks
  * returns it).  The geometry in force (eqf_tiled_set_geometry) must cover max(old, new) slots -- the rank's blocks of the marked slots
  * are cleared in Sll through it; shrink the geometry AFTER the call.  Host arrays; synchronises.  EQF_ERR_INVALID (before any effect) if
- * a removed slot is empty, an added slot taken, or an active slot would fall above new_num_slots; EQF_ERR_CAPACITY beyond the capacity. */
+ * a removed slot is empty, an added slot taken, an active slot would fall above new_num_slots, or the working set would GROW over a slot
+ * that this call does not fill (every slot in [old count, new_num_slots) must be in add_slots: a slot that was never initialised has no
+ * unit diagonal block to decouple it); EQF_ERR_CAPACITY beyond the capacity. */
 int eqf_tiled_edit_landmarks(eqf_tiled* t, int n_remove, const int* remove_slots, int n_add, const int* add_slots,
     const double* add_bearings, double depth, int new_num_slots, double* Sll, int ldl);
 /* First half of the update (VIOFilter.cpp:264-277, EqFMatrices.cpp:319-344, :221-235): residual, C0i, lift rows; then the operands of
@@ -287,6 +297,10 @@ int eqf_tiled_set_state(eqf_tiled* t, int N, const double* pose_q, const double*
  *   (VIOFilter.cpp:276-277, EqFMatrices.cpp:239), the downdate Sigma_IJ -= Y_kI^T Y_kJ (VIOFilter.cpp:297), the reductions.
  *   mask_rb > 0: C is the matrix part of a block-cyclic local matrix whose strictly-lower blocks are never read; tiles entirely below
  *   the block diagonal are skipped (row r is in global block (rblk0 + r / mask_rb) * Pr + pr, column c in (cblk0 + c / mask_cb) * Pc + pc).
+ *   The epilogue is C += alpha * acc as fire-and-forget global_atomic_add_f64 (one writer per element and launch: deterministic).  Two
+ *   consequences for a caller: C must be ordinary (coarse-grained) device memory -- hipMalloc / a torch CUDA tensor; on fine-grained or
+ *   host-coherent allocations hardware fp64 atomics may be unsupported -- and for alpha other than +-1 the result is rounded twice
+ *   (alpha * acc, then the addition) instead of once as fma(alpha, acc, C); every product of the filter uses alpha = +-1.
  * eqf_tile_downdate = eqf_tile_gemm_tn with alpha = -1 and no mask.
  * eqf_tile_potrf: A (n x n, ld, lower triangle) <- L with A = L L^T: the diagonal block of a block row; drec [ceil(n / 64)][5120]
  *   receives, per 64-wide block column, L_jj and the inverses of its four 16 x 16 diagonal blocks (what eqf_tile_trsm multiplies with);
@@ -316,6 +330,9 @@ int eqf_tile_potrf(int device, void* stream, double* A, int ld, int n, double* d
 int eqf_tile_trsm(int device, void* stream, const double* A, int ld, int n, const double* drec, double* B, int ldb, int m, int right);
 
 const char* eqf_version(void);
+/* "src_sha256=<hex>": sha256 over the library's sources (every .hip and .hpp file of csrc/, this header, csrc/Makefile; concatenated in sorted
+ * order) at build time -- lets a caller prove that the .so it loaded was built from the sources beside it (bench.py's `build` block). */
+const char* eqf_build_info(void);
 
 #ifdef __cplusplus
 }

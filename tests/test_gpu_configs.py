@@ -381,3 +381,69 @@ def test_single_propagate_and_single_update_from_an_injected_state(oracle_lib, h
     assert before < 1e-11 and one_upd < 2e-9, (before, one_upd)
     assert fg.device_error() == 0
     print(f"one propagate {one_prop:.2e}, eleven propagates {before:.2e}, one update {one_upd:.2e}")
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_withheld_handoff_unwinds_the_update_launch_and_reset_recovers(oracle_lib, hip, batch):
+    """The failure path of the in-launch hand-offs (csrc/eqf_handoff.hpp, include/eqf_vio_amd.h: bit 128), on demand:
+    eqf_debug_drop_role lets one role of k_chol_resident -- the interior tile T(3, 0) of the S-chain -- leave without publishing its block.
+    Its consumers time out (0.5 s), the launch unwinds, the covariance downdate never runs: the call that next touches the handle sees the
+    sticky flag, NO covariance buffer has been written by the failed launch (the handle's current buffer still holds, bit for bit, the
+    last covariance a complete update left there), later updates leave at once, and eqf_reset gives a handle that tracks the oracle again.
+    batch = 1: the co-resident kernel with the prep roles inside (FOLD); batch = 2: the grid-larger-than-the-chip build (PIPEH)."""
+    import time
+
+    from eqf_vio_amd import synth
+
+    ob = oracle_lib
+    N = 200
+    st = synth.make_stream(N, duration=0.16)
+    d = synth.template_settings_dict()
+    d["outlierThreshold"] = 1e9
+    fg = hip.FilterBatch(d, capacity=N, batch=batch)
+    ev = list(st.events())
+    vis = [i for i, (kind, _) in enumerate(ev) if kind == "vision"]
+    assert len(vis) >= 3
+
+    def feed(lo, hi):
+        for kind, k in ev[lo:hi]:
+            if kind == "imu":
+                r = st.imu[k]
+                fg.process_imu([r[0]] * batch, r[1:4], r[4:7])
+            else:
+                fg.process_vision([st.vision_stamps[k]] * batch, st.ids, st.bearings[k])
+
+    feed(0, vis[1] + 1)  # two complete frames
+    assert fg.device_error() == 0
+    S_good = [fg.sigma(b) for b in range(batch)]
+    fg.debug_drop_role(0, 1, 3, 0)
+    t0 = time.time()
+    feed(vis[1] + 1, vis[2] + 1)  # IMU burst + the update whose hand-off never comes
+    err = fg.device_error()
+    dt = time.time() - t0
+    assert err & 128, err
+    assert not (err & ~(128 | 4)), err  # (nothing else; bit 4 cannot appear either, but a pivot verdict would not be a failure of THIS test)
+    assert dt < 5.0, f"the launch must unwind after ONE timeout (0.5 s), took {dt:.2f} s"
+    for b in range(batch):
+        # the failed launch wrote nothing: the buffer it should have filled still holds the previous update's result
+        assert np.array_equal(fg.sigma(b), S_good[b]), b
+    # sticky: a later frame leaves at once and changes nothing either
+    fg.debug_drop_role(-1)
+    t0 = time.time()
+    feed(vis[2] + 1, min(vis[2] + 12, len(ev)))
+    assert fg.device_error() & 128 and time.time() - t0 < 1.0
+    # eqf_reset: the same handle from the start of the stream, against the oracle
+    fg.reset()
+    assert fg.device_error() == 0
+    fo = ob.OracleFilter(d, structured=True)
+    for kind, k in ev[: vis[1] + 1]:
+        if kind == "imu":
+            r = st.imu[k]
+            fo.processIMUData(r[0], r[1:4], r[4:7])
+        else:
+            fo.processVisionData(st.vision_stamps[k], st.ids, st.bearings[k])
+    feed(0, vis[1] + 1)
+    assert fg.device_error() == 0
+    for b in range(batch):
+        assert rel_fro(fg.sigma(b), fo.stateCovariance()) < SIGMA_TOL
+        assert np.array_equal(fg.sigma(b), S_good[b])  # and bitwise the run before the fault

@@ -491,6 +491,7 @@ def test_tiled_edit_landmarks_argument_errors_come_before_any_effect():
     assert edit([2, 2], [], 8) == -1         # twice
     assert edit([], [8, 8], 10) == -1        # twice
     assert edit([], [], 6) == -1             # slots 6, 7 hold landmarks
+    assert edit([], [9], 10) == -1           # the working set would grow over slot 8, which nobody fills (never initialised: advisor r4)
     assert edit([], [8], 13) == -4           # EQF_ERR_CAPACITY
     assert edit([], [8], 9, depth=0.0) == -1
     tf._set_slots(8)
