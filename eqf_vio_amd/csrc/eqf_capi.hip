@@ -638,8 +638,12 @@ int buildRoles(eqf_filter* f, int Nmax, bool fold) {
 
 // (the FOLD build only exists for fp64: the fp32 mode keeps the prep launch)
 template <typename T>
-void launchFold(dim3 rg, hipStream_t st, const ResArgs& ra) {
-    if constexpr (std::is_same<T, double>::value) hipLaunchKernelGGL((k_chol_resident<double, false, false, true>), rg, dim3(256), sizeof(Step64Lds), st, ra);
+void launchFold(dim3 rg, hipStream_t st, const ResArgs& ra, bool pipeHeads, bool occ2) {
+    if constexpr (std::is_same<T, double>::value) {
+        if (pipeHeads && occ2) hipLaunchKernelGGL((k_chol_resident<double, true, true, true>), rg, dim3(256), kLdsRes2Bytes, st, ra);
+        else if (pipeHeads) hipLaunchKernelGGL((k_chol_resident<double, true, false, true>), rg, dim3(256), sizeof(Step64Lds), st, ra);
+        else hipLaunchKernelGGL((k_chol_resident<double, false, false, true>), rg, dim3(256), sizeof(Step64Lds), st, ra);
+    }
 }
 
 template <typename T>
@@ -676,6 +680,8 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<float>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRes2Bytes));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<float, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRes2Bytes));
@@ -737,6 +743,16 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         // instead of behind a 12 us launch and a dispatch gap; the S-chain and the right-hand sides wait for the prep roles' flags.
         fold = f->resFoldPrep && residentFits && std::is_same<T, double>::value && f->cholResident < 2 && f->resPipeHeads <= 0 && f->resOcc2 <= 0 &&
                nb64E > 1 && f->dPrepFlags && lmBlocks + eBlocks <= f->nPrepCap && lds <= sizeof(Step64Lds);
+        // Round 5: the same on a grid LARGER than the chip (the PIPEH / OCC2 builds with the prep roles in front; filter index fastest, so the
+        // prep workgroups of all filters are dispatched first and wait for nobody).  Measured at N = 200 (profiles/r05_fold_batch.txt, steps/s,
+        // prep launch -> prep roles): 2 filters 113.7 k -> 118.6 k; 4: 210.2 -> 210.7 k; 8: 316 -> 321 k (the update launch grows by what the
+        // prep launch took: 166 -> 195 us -- the prep workgroups fill the chip first and the E-chains start behind them all the same); 16:
+        // 436 -> 419 k; 64: 500 -> 465 k.  So: only while prep roles + chain roles together are at most two per CU (2, 3 filters of N = 200);
+        // EQF_RES_FOLD_PREP=3 forces it on every batch (the bitwise test does), = 2 keeps it to co-resident grids.
+        const bool foldBatch = (f->resFoldPrep == 1 || f->resFoldPrep == 3) && !residentFits && std::is_same<T, double>::value && f->cholResident < 2 &&
+                               nb64E > 1 && f->dPrepFlags && lmBlocks + eBlocks <= f->nPrepCap && lds <= (size_t)kLdsRes2Bytes &&
+                               (f->resFoldPrep == 3 || (long long)(lmBlocks + eBlocks + rolesAll) * B <= 2LL * f->numCUs);
+        fold = fold || foldBatch;
         rc = buildRoles(f, Nmax, fold);
         if (rc) return rc;
         // Beyond co-residency the grid is interleaved (filter index fastest: all filters advance together, group by group) and nothing
@@ -818,7 +834,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             // 64 x 64 downdate tiles: a tile costs the same 14 dependent chunk fetches whatever its size, and there are enough
             // finished workgroups to take one each
             // (a grid larger than what is co-resident must not wait for later workgroups while holding CUs: no-wait mode, see the kernel)
-            ra.ddNt = fold ? nt32 : nt64;
+            ra.ddNt = (fold && !resPipeHeads) ? nt32 : nt64;  // (the FOLD build without PIPEH -- co-resident grids: 32 x 32 tiles, see the kernel)
             // (the downdate tiles are workgroups of their own behind the roles, also when the whole grid is co-resident: nothing in the kernel
             // waits for a higher block index)
             ra.nRoles = f->rolesCount;
@@ -833,9 +849,10 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
                 const int perFilter = ra.nPrep + f->rolesCount + ddGrid;
                 ra.rolesPerRow = std::min(perFilter, 32768);
                 const dim3 rg(B * ra.rolesPerRow, (perFilter + ra.rolesPerRow - 1) / ra.rolesPerRow);
-                if (pipeHeads && occ2) hipLaunchKernelGGL((k_chol_resident<T, true, true>), rg, dim3(256), kLdsRes2Bytes, f->stream, ra);
+                if (fold && pipeHeads) launchFold<T>(rg, f->stream, ra, true, occ2);
+                else if (pipeHeads && occ2) hipLaunchKernelGGL((k_chol_resident<T, true, true>), rg, dim3(256), kLdsRes2Bytes, f->stream, ra);
                 else if (pipeHeads) hipLaunchKernelGGL((k_chol_resident<T, true>), rg, dim3(256), sizeof(Step64Lds), f->stream, ra);
-                else if (fold) launchFold<T>(rg, f->stream, ra);
+                else if (fold) launchFold<T>(rg, f->stream, ra, false, false);
                 else hipLaunchKernelGGL((k_chol_resident<T, false>), rg, dim3(256), sizeof(Step64Lds), f->stream, ra);
             });
             if (rc) return rc;

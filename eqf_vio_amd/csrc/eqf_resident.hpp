@@ -192,6 +192,38 @@ EQF_DEV void hoLoadStages012(const double* Dk, const Lds64& s, int tid) {
         }
     }
 }
+// All four stages at once (ten loads in flight: ONE round trip): what a row head asks for when D[K] is already complete on its arrival.
+EQF_DEV void hoLoadStages0123(const double* Dk, const Lds64& s, int tid) {
+    const int w0 = tid, w1 = tid + 256;
+    const char* pl0 = reinterpret_cast<const char*>(Dk + (w0 >> 3) * kSB + 2 * (w0 & 7));
+    const char* pl1 = reinterpret_cast<const char*>(Dk + (w1 >> 3) * kSB + 2 * (w1 & 7));
+    const char* pw = reinterpret_cast<const char*>(Dk + kSB * kSB + 2 * (tid & 127));
+    const char* pw2 = pw + 2 * kQB * kQB * 8;  // (W_22, W_33: beyond the 13-bit immediate offset)
+    v4i32 a[3], b[3], c[4];
+    asm volatile(
+        "global_load_dwordx4 %0, %10, off sc0 sc1\n\tglobal_load_dwordx4 %1, %10, off offset:128 sc0 sc1\n\t"
+        "global_load_dwordx4 %2, %10, off offset:256 sc0 sc1\n\tglobal_load_dwordx4 %3, %11, off sc0 sc1\n\t"
+        "global_load_dwordx4 %4, %11, off offset:128 sc0 sc1\n\tglobal_load_dwordx4 %5, %11, off offset:256 sc0 sc1\n\t"
+        "global_load_dwordx4 %6, %12, off sc0 sc1\n\tglobal_load_dwordx4 %7, %12, off offset:2048 sc0 sc1\n\t"
+        "global_load_dwordx4 %8, %13, off sc0 sc1\n\tglobal_load_dwordx4 %9, %13, off offset:2048 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
+        : "v"(pl0), "v"(pl1), "v"(pw), "v"(pw2)
+        : "memory");
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        s.L[w0 >> 3][kQB * j + 2 * (w0 & 7)] = hoLo(a[j]);
+        s.L[w0 >> 3][kQB * j + 2 * (w0 & 7) + 1] = hoHi(a[j]);
+        s.L[w1 >> 3][kQB * j + 2 * (w1 & 7)] = hoLo(b[j]);
+        s.L[w1 >> 3][kQB * j + 2 * (w1 & 7) + 1] = hoHi(b[j]);
+    }
+    if (tid < 128) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s.Wd[j][tid >> 3][2 * (tid & 7)] = hoLo(c[j]);
+            s.Wd[j][tid >> 3][2 * (tid & 7) + 1] = hoHi(c[j]);
+        }
+    }
+}
 EQF_DEV void hoLoadW3(const double* Dk, const Lds64& s, int tid) {
     const char* pw = reinterpret_cast<const char*>(Dk + kSB * kSB + 3 * kQB * kQB + 2 * (tid & 127));
     v4i32 c;
@@ -241,6 +273,12 @@ EQF_DEV void stagedPanelSolve(const f64x4 (&acc)[4], const Lds64& s, const doubl
     const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
     for (int i = 0; i < 4; ++i) stTile(acc[i], &s.P[0][0], kSP, kQB * wv, kQB * i, lane);
+    // (round 5) A head whose panels came late finds D[K] COMPLETE: then stage by stage buys nothing and costs a second round trip -- in steady
+    // state every other head of a chain arrives late (a head that could hide its solve shortens the next one's panel time: stamps in
+    // profiles/r05_res_stamps_N200.txt), so one look at the whole-record flag decides between "four stages in one round trip" and the
+    // staged path.  The same products in the same order either way.
+    __shared__ int sWholeThere;
+    if (tid == 0) sWholeThere = (*bad != 8 && __hip_atomic_load(flagWhole, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) ? 1 : 0;
     __syncthreads();
     f64x4 Z[4], X[4];
     const int lc = lane & 15, lg = lane >> 4, x0 = kQB * wv;
@@ -249,6 +287,22 @@ EQF_DEV void stagedPanelSolve(const f64x4 (&acc)[4], const Lds64& s, const doubl
 #pragma unroll
         for (int q = 0; q < 4; ++q) Z[j][q] = s.P[x0 + lc][kQB * j + lg + 4 * q];
     const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+    if (sWholeThere) {
+        hoLoadStages0123(Dk, s, tid);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            X[j] = mmRegB(zero, &s.Wd[j][0][0], kWP, 0, 0, Z[j], lane, 1.0);
+#pragma unroll
+            for (int j2 = j + 1; j2 < 4; ++j2) Z[j2] = mmRegB(Z[j2], &s.L[0][0], kSP, kQB * j2, kQB * j, X[j], lane, -1.0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s.P[x0 + lc][kQB * j + lg + 4 * q] = X[j][q];
+        __syncthreads();
+        return;
+    }
     hoWait3(stageIn + 2, nullptr, nullptr, epoch, tid, bad, err);
     hoLoadStages012(Dk, s, tid);
     __syncthreads();
@@ -333,7 +387,9 @@ __device__ long long g_resF64[2][16][128];  // [chain][R]: factor64's per-wave s
 // 237 registers, and the 78 KB LDS view in which L aliases Q (ldsRes2).  Twice the workgroups in flight reach twice as many block columns
 // ahead of the pivot chains: 8 filters 181 -> 170 us per update, 12: 254 -> 220, 16: 312 -> 255, 20: 401 -> 315, N = 1000 1.54 -> 1.28 ms.
 // On lightly oversubscribed grids two workgroups on a CU only get in each other's way (4 filters 134 -> 153 us, N = 600 455 -> 475).
-// FOLD: the build with the prep roles inside (ResArgs::nPrep; co-resident grids).  A build of its own because the mere presence of the prep
+// FOLD: the build with the prep roles inside (ResArgs::nPrep).  Round 4: co-resident grids (one filter).  Round 5: also with PIPEH / OCC2 for
+// batches on grids larger than the chip -- filter index fastest, so the prep workgroups of ALL filters are dispatched first, and they wait for
+// nobody: the dependency order of the block indices holds as before.  A build of its own because the mere presence of the prep
 // role and of the agent-scope loads of S / the right-hand sides cost the other builds 3 + 7 us per update (124 -> 134: this kernel is
 // bound by a chain of latencies and feels every change of its code layout).
 template <typename T, bool PIPEH = false, bool OCC2 = false, bool FOLD = false>
@@ -370,7 +426,9 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         const int slot = tile == 0 ? 0 : (tile == 27 ? 1 : (tile == 54 ? 2 : -1));
         if (t == 0 && bb == EQF_STAMP_B && slot >= 0) g_resStamps[0][15][3 * slot] = wall_clock64();
 #endif
-        if (gg.updateOk && gg.N != 0) {
+        constexpr bool kGated = !(FOLD && !PIPEH);  // the 64 x 64 tiles follow the S-chain block row by block row (downdateTile's Gate)
+        const int* const ryAll = ra.readyY + ((long long)bb * 2 + 0) * ra.nbCap * ra.wtCap;
+        if (!kGated && gg.updateOk && gg.N != 0) {
             // (the Y tiles of the S-chain's LAST block row carry the epoch when they are out, and a tile of block row C is only solved after
             // the tiles above it: one flag per column tile says "all of Y".  A counter said the same until round 4; it had to be zeroed by
             // an earlier launch, which the prep roles of this launch are not.)
@@ -378,7 +436,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
             chainDims64(ra.c0, gg.N, &nS, &wS);
             // (ONE lane, long sleeps: on a co-resident grid these 55 workgroups poll from the first microsecond on -- with every lane of
             // ten polling at hoWait's rate the flags of the chains' own hand-offs got slower: 124 -> 133 us per update)
-            const int* ry = ra.readyY + ((long long)bb * 2 + 0) * ra.nbCap * ra.wtCap + (nS - 1) * ra.wtCap;
+            const int* ry = ryAll + (nS - 1) * ra.wtCap;
             if (t == 0) {
                 const long long t0 = wall_clock64();
                 for (int i = 0; i < wS && !late; ++i)
@@ -400,9 +458,40 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
 #ifdef EQF_RES_STAMPS
         if (t == 0 && bb == EQF_STAMP_B && slot >= 0) g_resStamps[0][15][3 * slot + 1] = wall_clock64();
 #endif
+        // Round 5, grids larger than the chip: the tile workgroups are dispatched while the S-chain is still running (8 filters of N = 200:
+        // 65 .. 120 us into a launch whose last Y tile comes at 128), so each wave waits for the two Y tiles of a block row right before it
+        // asks for that block row's first chunk -- one lane per wave, long sleeps (see above) -- and the downdate ends a few microseconds after
+        // the S-chain's last right-hand-side tile instead of 45 us after it.
+        auto gate = [&](int C, int ti, int tj) -> bool {
+            int ok = 1;
+            if ((t & 63) == 0) {
+                const long long t0 = wall_clock64();
+                const int* f0 = ryAll + C * ra.wtCap + ti;
+                const int* f1 = ryAll + C * ra.wtCap + tj;
+                for (int i = 0; i < 2 && ok; ++i) {
+                    const int* fl = i ? f1 : f0;
+                    while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ra.c0.epoch) {
+                        __builtin_amdgcn_s_sleep(32);
+                        if (hoAborted(ra.errflag)) {
+                            ok = 0;
+                            break;
+                        }
+                        if (wall_clock64() - t0 > 50000000LL) {  // 0.5 s
+                            if (ra.errflag) atomicOr(ra.errflag, kHoErrTimeout);
+                            ok = 0;
+                            break;
+                        }
+                    }
+                }
+            }
+            asm volatile("" ::: "memory");
+            return __builtin_amdgcn_readfirstlane(ok) != 0;
+        };
         // (FOLD: 32 x 32 tiles -- with the S-chain starting behind the prep roles the downdate ends the launch, and a 64 x 64 tile is 28 us
         // of dependent fetches for one workgroup; four times the workgroups, each a third of that)
-        if (FOLD) downdateTile<T, 32>(ra.a, ra.ddNt, bb, tile, reinterpret_cast<T*>(smemR));
+        // (a grid larger than the chip -- FOLD with PIPEH, round 5 -- keeps the 64 x 64 tiles: there the tile workgroups are many and throughput counts)
+        if constexpr (!kGated) downdateTile<T, 32>(ra.a, ra.ddNt, bb, tile, reinterpret_cast<T*>(smemR));
+        else if (gg.updateOk && gg.N != 0) downdateTile<T, 64, 4>(ra.a, ra.ddNt, bb, tile, reinterpret_cast<T*>(smemR), gate);
         else downdateTile<T, 64, 4>(ra.a, ra.ddNt, bb, tile, reinterpret_cast<T*>(smemR));
 #ifdef EQF_RES_STAMPS
         __syncthreads();

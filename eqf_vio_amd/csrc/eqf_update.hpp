@@ -22,6 +22,8 @@
 // All factorisation work is fp64 (v_mfma_f64_16x16x4_f64 for the 32x32x32 block products): Sigma has a
 // condition number of 1e6..1e8 while landmarks converge, fp32 cannot carry it.
 #pragma once
+#include <type_traits>
+
 #include "eqf_device.hpp"
 #include "eqf_math.hpp"
 
@@ -652,8 +654,16 @@ struct MfmaT<float> {
 // DEPTH = chunks in flight ahead of the one the matrix cores work on.  1 where the launch is bound by throughput (the per-column launches of
 // a large batch: the other workgroups of the CU cover the wait); 4 inside k_chol_resident, whose downdate tiles are few and LATE -- a tile is
 // 13 dependent 2 us fetches of Y written on other XCDs a moment ago, against 0.3 us of MFMAs per chunk.
-template <typename T, int TS, int DEPTH = 1>
-EQF_DI void downdateTile(const UpdArgs& a, int nt, int b, int tileIdx, T* lds) {
+// Gate (64 x 64 tiles only): gate(C, ti, tj) is called by EVERY WAVE before it asks for the first rows of block row C of Y (64 rows = four
+// chunks: exactly the look-ahead) and returns false if those rows will never come.  k_chol_resident passes a wait for the two Y tiles (C, ti),
+// (C, tj) of its S-chain: the downdate then runs BEHIND the right-hand-side roles block row by block row instead of starting when the last
+// Y tile is out (8 filters of N = 200: the launch ended 21 us after the innovation lift, with 45 us of downdate behind the last Y tile).
+// Same chunks in the same order: the same bits.  After a failed gate nothing is written.
+struct DdNoGate {
+    EQF_DI bool operator()(int, int, int) const { return true; }
+};
+template <typename T, int TS, int DEPTH = 1, typename Gate = DdNoGate>
+EQF_DI void downdateTile(const UpdArgs& a, int nt, int b, int tileIdx, T* lds, Gate gate = Gate()) {
     constexpr int WM = TS / 32;  // MFMA tiles per wave and dimension
     const Glob& g = a.g[b];
     const int N = g.N;
@@ -684,6 +694,7 @@ EQF_DI void downdateTile(const UpdArgs& a, int nt, int b, int tileIdx, T* lds) {
     const int mp = roundUp(sDim(N), a.pad);
     const double* Y = a.YO + (long long)b * a.strideY;
     const int ldY = a.ldY;
+    int late = 0;
     constexpr int KC = 32;                 // rows of Y per chunk
     T (*sI)[TS + 1] = reinterpret_cast<T (*)[TS + 1]>(lds);                    // Y[k0 + r][I0 + c]
     T (*sJ)[TS + 1] = reinterpret_cast<T (*)[TS + 1]>(lds + KC * (TS + 1));    // Y[k0 + r][J0 + c]
@@ -706,7 +717,10 @@ EQF_DI void downdateTile(const UpdArgs& a, int nt, int b, int tileIdx, T* lds) {
         // row pitch 80 doubles (= 16 modulo the 32-double bank window), so the two k rows a half-wavefront reads for an MFMA operand fall
         // on disjoint banks (pitch 65 made every operand read a 2-way conflict: SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE), and a
         // half-wavefront stages one whole 64-value row (lane l: columns 2 l, 2 l + 1 -- one 512-byte global read, one conflict-free write).
-        constexpr int KC2 = 16, PITCH = 80, D = 4;
+#ifndef EQF_DD_DEPTH
+#define EQF_DD_DEPTH 4
+#endif
+        constexpr int KC2 = 16, PITCH = 80, D = std::is_same<Gate, DdNoGate>::value ? 4 : EQF_DD_DEPTH;
         static_assert(2 * 2 * KC2 * PITCH >= TS * (TS + 1), "the epilogue's transposed tile lives in the same LDS");
         const int h = lane >> 5, c2 = 2 * (lane & 31);
         const bool fastI = I0 > 11 && I0 + TS <= nv, fastJ = J0 > 11 && J0 + TS <= nv;
@@ -746,11 +760,18 @@ EQF_DI void downdateTile(const UpdArgs& a, int nt, int b, int tileIdx, T* lds) {
             }
         };
         const int nc = mp / KC2;  // (mp is a multiple of 64)
+        static_assert((D * KC2) % 64 == 0, "the look-ahead is whole 64-row block rows of Y: one gate per block row, at its first chunk");
 #pragma unroll
         for (int d = 0; d < D; ++d)
-            if (d < nc) fetch2(d, d);
+            if (d < nc) {
+                if ((d & 3) == 0 && !late && !gate(d >> 2, ti, tj)) late = 1;
+                fetch2(d, d);
+            }
         stage2(0, 0);
-        if (D < nc) fetch2(0, D);
+        if (D < nc) {
+            if (!late && !gate(D >> 2, ti, tj)) late = 1;
+            fetch2(0, D);
+        }
         __syncthreads();
         for (int c0 = 0; c0 < nc; c0 += D) {
 #pragma unroll
@@ -760,7 +781,10 @@ EQF_DI void downdateTile(const UpdArgs& a, int nt, int b, int tileIdx, T* lds) {
                     const int nd = (d + 1) % D;
                     if (c + 1 < nc) {
                         stage2(nd, (c + 1) & 1);
-                        if (c + 1 + D < nc) fetch2(nd, c + 1 + D);
+                        if (c + 1 + D < nc) {
+                            if (((c + 1 + D) & 3) == 0 && !late && !gate((c + 1 + D) >> 2, ti, tj)) late = 1;  // (wave-uniform)
+                            fetch2(nd, c + 1 + D);
+                        }
                     }
                     const T* sa = lds + ((c & 1) * 2 + 0) * KC2 * PITCH + 16 * WM * qi + lr;
                     const T* sb = lds + ((c & 1) * 2 + 1) * KC2 * PITCH + 16 * WM * qj + lr;
@@ -825,6 +849,9 @@ EQF_DI void downdateTile(const UpdArgs& a, int nt, int b, int tileIdx, T* lds) {
                 }
             }
         }
+    }
+    if constexpr (!std::is_same<Gate, DdNoGate>::value) {
+        if (__syncthreads_or(late)) return;  // (a gate failed: Sigma_out keeps what it holds)
     }
     // ---- epilogue.  Every read of Sigma_in is issued before the first write of Sigma_out (a load the compiler cannot prove
     // independent of the previous store waits for that store's acknowledgement: 32 dependent round trips per thread), and

@@ -84,3 +84,25 @@ def drive_pair(stream, a_imu, a_vis, b_imu, b_vis, on_frame=None):
             b_vis(stream.vision_stamps[k], stream.ids, stream.bearings[k])
             if on_frame is not None:
                 on_frame(k)
+
+
+def check_large_golden(d, f, est, bias, S, last=None, what=""):
+    """One vision frame of a tests/golden/large_N*.npz fixture (structured fp64 oracle, tests/golden/make_golden_large.py) against a filter's
+    outputs: pose / velocity / bias, |Sigma|_F, trace, the 11 x 11 base block, 600 sampled entries of Sigma, and -- when given -- delta / gamma /
+    Gamma of that update (norms + first 64 entries).  Returns the worst relative deviation of the covariance quantities."""
+    ref = d["frames"][f]
+    assert np.abs(est["q"] - ref[0:4]).max() < 1e-8 and np.abs(est["x"] - ref[4:7]).max() < 1e-8, (what, f, "pose")
+    assert np.abs(est["v"] - ref[7:10]).max() < 1e-8 and np.abs(bias - ref[10:16]).max() < 1e-8, (what, f, "velocity / bias")
+    fro, tr = float(np.linalg.norm(S)), float(np.trace(S))
+    w = max(abs(fro / ref[16] - 1.0), abs(tr / ref[17] - 1.0))
+    smp, want = S[d["sample_rows"], d["sample_cols"]], d["sigma_samples"][f]
+    w = max(w, float(np.abs(smp - want).max() / np.abs(want).max()))
+    w = max(w, float(np.linalg.norm(S[:11, :11] - d["sigma_base"][f]) / np.linalg.norm(d["sigma_base"][f])))
+    assert w < 1e-8, (what, f, w)
+    if last is not None and f > 0:  # (the first frame's residual is zero: its landmarks were initialised on their bearings)
+        lu = d["last_update"][f]
+        for i, (key, tol) in enumerate((("delta", 1e-9), ("gamma", 1e-7), ("Gamma", 1e-7))):
+            v = last[key]
+            assert abs(np.linalg.norm(v) / lu[i] - 1.0) < tol, (what, f, key)
+            assert np.abs(v[:64] - lu[3 + 64 * i: 3 + 64 * (i + 1)]).max() < tol * max(lu[i], 1.0), (what, f, key)
+    return w

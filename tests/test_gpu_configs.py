@@ -401,17 +401,16 @@ def test_withheld_handoff_unwinds_the_update_launch_and_reset_recovers(oracle_li
     d = synth.template_settings_dict()
     d["outlierThreshold"] = 1e9
     fg = hip.FilterBatch(d, capacity=N, batch=batch)
+    # (the resident-stream API: the IMU calls of a frame and the vision call's integrateUpToTime leave as ONE burst at every batch size, so
+    # the covariance buffer the update launch should fill is the one the previous update filled)
+    fg.stream_upload(st.imu, st.vision_stamps, st.ids, st.bearings)
     ev = list(st.events())
     vis = [i for i, (kind, _) in enumerate(ev) if kind == "vision"]
     assert len(vis) >= 3
 
     def feed(lo, hi):
         for kind, k in ev[lo:hi]:
-            if kind == "imu":
-                r = st.imu[k]
-                fg.process_imu([r[0]] * batch, r[1:4], r[4:7])
-            else:
-                fg.process_vision([st.vision_stamps[k]] * batch, st.ids, st.bearings[k])
+            (fg.stream_imu if kind == "imu" else fg.stream_vision)(k)
 
     feed(0, vis[1] + 1)  # two complete frames
     assert fg.device_error() == 0
@@ -447,3 +446,29 @@ def test_withheld_handoff_unwinds_the_update_launch_and_reset_recovers(oracle_li
     for b in range(batch):
         assert rel_fro(fg.sigma(b), fo.stateCovariance()) < SIGMA_TOL
         assert np.array_equal(fg.sigma(b), S_good[b])  # and bitwise the run before the fault
+
+
+@pytest.mark.parametrize("N", [2000, 4000])
+def test_large_filters_against_the_committed_oracle_vectors(hip, N):
+    """N = 2000 and BASELINE configs[4]'s N = 4000 on the monolithic single-GPU path (one k_chol_resident launch per update, two-per-CU build)
+    against tests/golden/large_N*.npz: numbers the structured fp64 oracle produced in the dev container (minutes of one core per frame at
+    N = 4000: not affordable inside a test), frozen as data together with the inputs -- pose, bias, |Sigma|_F, trace, base block, 600 sampled
+    covariance entries and the update internals after EVERY vision frame."""
+    from helpers import check_large_golden, events_of, load_golden
+
+    d, settings = load_golden(f"large_N{N}")
+    fg = hip.FilterBatch(settings, capacity=N, batch=1)
+    f = 0
+    worst = 0.0
+    for kind, k in events_of(d["imu"], d["vision_stamps"]):
+        if kind == "imu":
+            r = d["imu"][k]
+            fg.process_imu([r[0]], r[1:4], r[4:7])
+        else:
+            fg.process_vision([d["vision_stamps"][k]], d["ids"], d["bearings"][k])
+            S = fg.sigma()
+            worst = max(worst, check_large_golden(d, f, fg.state_estimate(), fg.bias(), S, fg.last_update(), what=f"N={N}"))
+            del S
+            f += 1
+    assert f == len(d["vision_stamps"]) and fg.device_error() == 0
+    print(f"N={N}: {f} updates against the committed oracle vectors, worst covariance deviation {worst:.2e}")

@@ -1044,6 +1044,42 @@ def test_prep_roles_inside_the_update_launch_equal_the_prep_launch(hip, monkeypa
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,N", [(2, 200), (3, 107), (8, 200), (16, 200)])
+def test_prep_roles_inside_the_update_launch_of_a_batch_equal_the_prep_launch(hip, monkeypatch, B, N):
+    """Round 5: the same on grids LARGER than the chip -- the PIPEH and the two-per-CU builds of k_chol_resident with the prep roles in front
+    (filter index fastest: the prep workgroups of all filters are dispatched first).  Every filter of the batch runs its own stream; bit for
+    bit against the prep launch (EQF_RES_FOLD_PREP=0) after every vision update."""
+    from eqf_vio_amd import synth
+
+    sts = [synth.make_stream(N, seed=500 + b, duration=0.26) for b in range(B)]
+    imu = np.stack([s.imu for s in sts], axis=1)
+    vst = np.stack([s.vision_stamps for s in sts], axis=1)
+    bear = np.stack([s.bearings for s in sts], axis=1)
+    d = synth.template_settings_dict()
+    outs = []
+    for fold in ("3", "0"):  # (3: on every batch size; the default keeps it to grids of at most two workgroups per CU)
+        monkeypatch.setenv("EQF_RES_FOLD_PREP", fold)
+        fg = hip.FilterBatch(d, capacity=N, batch=B)
+        fg.stream_upload(imu, vst, sts[0].ids, bear)
+        seq = []
+        for kind, k in sts[0].events():
+            if kind == "imu":
+                fg.stream_imu(k)
+            else:
+                fg.stream_vision(k)
+                for b in (0, B // 2, B - 1):
+                    e = fg.state_estimate(b)
+                    seq.append((fg.sigma(b).copy(), e["x"].copy(), e["q"].copy(), e["p"].copy(), fg.bias(b).copy()))
+        assert fg.device_error() == 0
+        outs.append(seq)
+    monkeypatch.delenv("EQF_RES_FOLD_PREP")
+    assert len(outs[0]) == len(outs[1]) >= 12
+    for f, (a, b) in enumerate(zip(*outs)):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v), (B, N, f)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N", [3, 21, 70, 130, 200])
 def test_builder_and_block_workgroups_in_one_launch_equal_the_two_launches(hip, monkeypatch, N):
     """Round 4: in the latency case (one small filter: 4 landmarks per builder workgroup, one row landmark per wave of the block kernel)

@@ -271,15 +271,18 @@ def test_tiled_filter_N1000_against_the_structured_oracle(oracle_lib):
 def test_tiled_filter_N4000_against_the_single_gpu_product_path():
     """BASELINE configs[4] at its size: N = 4000 (Sigma 12011 x 12011, 1.15 GB), blocks of 250 (16 x 16 blocks of 750 x 750), on the 1 x 1
     grid: the first frame (4000 landmarks appended + update), a burst of IMU steps, the second frame's update -- Sigma against the
-    single-GPU product path to 1e-9 (which profiles/r02_parity_large_N.txt ties to the structured oracle at this size), symmetry,
+    single-GPU product path to 1e-9 AND against the committed vectors of the structured fp64 oracle (tests/golden/large_N4000.npz), symmetry,
     positive definiteness (Cholesky succeeds), and the trace going down in every update."""
     import torch
 
     from eqf_vio_amd import binding, synth, tiled
 
+    from helpers import check_large_golden, load_golden
+
     N, bl = 4000, 250
     d = synth.template_settings_dict()
     st = synth.make_stream(N, duration=0.11)
+    gold, _ = load_golden("large_N4000")
     be = tiled.HipBackend(d, capacity=N)
     tf = tiled.TiledFilter(tiled.ProcessGrid(None, 1, 1, device=be.device), be, bl)
     fg = binding.FilterBatch(d, capacity=N, batch=1)
@@ -305,6 +308,9 @@ def test_tiled_filter_N4000_against_the_single_gpu_product_path():
                 tf._update(np.asarray(st.bearings[k], dtype=np.float64))
             St, Sg = tf.stateCovariance(), fg.sigma()
             assert rel(St, Sg) <= 1e-9, (k, rel(St, Sg))
+            # ... and against the committed vectors of the structured fp64 oracle for exactly this stream (tests/golden/large_N4000.npz)
+            assert np.array_equal(st.bearings[k], gold["bearings"][n_upd - 1]) and st.vision_stamps[k] == gold["vision_stamps"][n_upd - 1]
+            check_large_golden(gold, n_upd - 1, tf.stateEstimate(), be.bias(), St, be.last_update(), what="partitioned N=4000")
             assert np.abs(St - St.T).max() <= 1e-9 * np.abs(St).max()
             assert float(np.trace(St)) < prior_tr  # Sigma - K C Sigma takes a positive semi-definite matrix away
             if n_upd == 2:
