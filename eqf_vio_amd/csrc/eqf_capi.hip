@@ -171,6 +171,8 @@ struct eqf_filter {
     int burstOcc2 = -1;            // EQF_BURST_OCC2: the 16-landmark builder built for two workgroups per CU (1), one (0), by launch size (-1)
     int resOcc2 = -1;              // EQF_RES_OCC2: k_chol_resident built for two workgroups per CU (1), one (0), by grid size (-1)
     int rolesN = -1, rolesCount = 0;  // chain shape (nbS, nbE, wtS) the role table was built for
+    int rolesFront = 0;               // roles in front of the prep roles (buildRoles' `front`)
+    int resFoldFront = 1;             // EQF_RES_FOLD_FRONT: dependency groups of the E-chain in front of the prep roles of a batch
     int dropRole[4] = {-1, 0, 0, 0};  // eqf_debug_drop_role: (kind, role, R, C) of the role whose workgroup leaves without publishing anything
     // profiling
     bool prof = false;
@@ -603,21 +605,31 @@ UpdArgs makeUpdArgs(eqf_filter* f, const double* bearings, long long bearStride,
 // Role table of k_chol_resident for chains of nbS / nbE block columns (wtS right-hand-side column tiles in the S-chain):
 // block index = dependency order -- group s holds the workgroups whose last step consumes D[s]; they only wait for groups < s.
 // fold: the prep work runs as roles of the same launch (ResArgs::nPrep), so the chains' first diagonal blocks are roles too (F0, in front).
-int buildRoles(eqf_filter* f, int Nmax, bool fold) {
+// front (fold on a grid larger than the chip): the first diagonal blocks and the row heads / interior tiles of the E-chain's first `front`
+// dependency groups go in FRONT of the prep roles (ResArgs::nFront): they read Sigma only, wait for nothing the prep roles write, and the
+// E-chain -- the update's critical path -- starts at t = 0 instead of behind the prep workgroups of all filters.
+int buildRoles(eqf_filter* f, int Nmax, bool fold, int front = 0) {
     const int nbS = roundUp(sDim(Nmax), kSB) / kSB, nbE = roundUp(eDim(Nmax), kSB) / kSB, wtS = roundUp(yCols(Nmax), kSB) / kSB;
-    const int key = (fold ? 1 << 30 : 0) | (nbS << 20) | (nbE << 10) | wtS;  // the table only changes when a chain crosses a 64-block boundary
+    const int key = (fold ? 1 << 30 : 0) | (front << 27) | (nbS << 18) | (nbE << 9) | wtS;  // the table only changes when a chain crosses a 64-block boundary
     if (f->rolesN == key) return EQF_OK;
     std::vector<ResRole> r;
     if (fold) {
         r.push_back({1, 6, 0, 0});
         r.push_back({0, 6, 0, 0});
+        for (int s = 0; s < std::min(front, nbE - 1); ++s) {
+            r.push_back({1, 0, s + 1, 0});
+            for (int R = s + 2; R < nbE; ++R) r.push_back({1, 1, R, s});
+        }
     }
+    f->rolesFront = fold ? int(r.size()) : 0;
+    if (!(fold && front > 0)) f->rolesFront = 0;
     for (int s = 0; s < std::max(nbS, nbE); ++s)
         for (int kind = 1; kind >= 0; --kind) {  // the E-chain (the longer one) first
             const int nb = kind ? nbE : nbS, wt = kind ? 1 : wtS;
             if (s >= nb) continue;
-            if (s + 1 < nb) r.push_back({kind, 0, s + 1, 0});
-            for (int R = s + 2; R < nb; ++R) r.push_back({kind, 1, R, s});
+            const bool moved = fold && kind == 1 && s < front;  // (its row head and interior tiles are in front; the right-hand-side tile waits for the prep roles)
+            if (s + 1 < nb && !moved) r.push_back({kind, 0, s + 1, 0});
+            for (int R = s + 2; R < nb && !moved; ++R) r.push_back({kind, 1, R, s});
             for (int t = 0; t < wt; ++t) r.push_back({kind, 2, t, s});
         }
     // fault injection (eqf_debug_drop_role): the matching role gets an index beyond every chain -- its workgroup returns at once (`R >= nb`)
@@ -747,13 +759,16 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         // prep workgroups of all filters are dispatched first and wait for nobody).  Measured at N = 200 (profiles/r05_fold_batch.txt, steps/s,
         // prep launch -> prep roles): 2 filters 113.7 k -> 118.6 k; 4: 210.2 -> 210.7 k; 8: 316 -> 321 k (the update launch grows by what the
         // prep launch took: 166 -> 195 us -- the prep workgroups fill the chip first and the E-chains start behind them all the same); 16:
-        // 436 -> 419 k; 64: 500 -> 465 k.  So: only while prep roles + chain roles together are at most two per CU (2, 3 filters of N = 200);
-        // EQF_RES_FOLD_PREP=3 forces it on every batch (the bitwise test does), = 2 keeps it to co-resident grids.
+        // 436 -> 419 k; 64: 500 -> 465 k.  With the E-chain's first dependency group IN FRONT of the prep roles (buildRoles' `front`,
+        // EQF_RES_FOLD_FRONT; profiles/r05_fold_front.txt): 4 filters 212 -> 219.6 k, 8 and 16 unchanged -- there the path prep -> S-chain ->
+        // right-hand sides -> downdate is as long as the E-chain's, and the prep work is on it wherever it runs.  So: while prep roles + chain
+        // roles together are at most four per CU (2 .. 4 filters of N = 200); EQF_RES_FOLD_PREP=3 forces it on every batch (the bitwise test
+        // does), = 2 keeps it to co-resident grids.
         const bool foldBatch = (f->resFoldPrep == 1 || f->resFoldPrep == 3) && !residentFits && std::is_same<T, double>::value && f->cholResident < 2 &&
                                nb64E > 1 && f->dPrepFlags && lmBlocks + eBlocks <= f->nPrepCap && lds <= (size_t)kLdsRes2Bytes &&
-                               (f->resFoldPrep == 3 || (long long)(lmBlocks + eBlocks + rolesAll) * B <= 2LL * f->numCUs);
+                               (f->resFoldPrep == 3 || (long long)(lmBlocks + eBlocks + rolesAll) * B <= 4LL * f->numCUs);
         fold = fold || foldBatch;
-        rc = buildRoles(f, Nmax, fold);
+        rc = buildRoles(f, Nmax, fold, foldBatch ? f->resFoldFront : 0);
         if (rc) return rc;
         // Beyond co-residency the grid is interleaved (filter index fastest: all filters advance together, group by group) and nothing
         // waits for later workgroups.  Its workgroups mostly wait for hand-offs, so the chip carries several per CU without slowing the
@@ -825,6 +840,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             if (fold) {
                 ra.waitD0 = 3;
                 ra.nPrep = lmBlocks + eBlocks;
+                ra.nFront = f->rolesFront;
                 ra.lmBlocks = lmBlocks;
                 ra.prepWpb = wpb;
                 ra.prepNvPad = nvPad;
@@ -1485,6 +1501,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (const char* e = std::getenv("EQF_CHOL_RESIDENT")) f->cholResident = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_STAGED")) f->resStaged = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_FOLD_PREP")) f->resFoldPrep = std::atoi(e);
+    if (const char* e = std::getenv("EQF_RES_FOLD_FRONT")) f->resFoldFront = std::max(0, std::min(7, std::atoi(e)));
     if (const char* e = std::getenv("EQF_BURST_FUSED")) f->burstFused = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_OVERSUB")) f->resOversub = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("EQF_E_FROM_SIGMA")) f->eFromSigma = std::atoi(e);

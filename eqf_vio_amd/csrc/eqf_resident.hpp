@@ -58,6 +58,8 @@ struct ResArgs {
     // what k_update_prep64's landmark waves and Z-row workgroups do (updatePrepBody, write-through), each raising prepFlags[b][i] = epoch;
     // the roles that read S, the right-hand sides or Z_P wait for all of them and read through agent-scope loads.  0: a prep launch came first.
     int nPrep, lmBlocks, prepWpb, prepNvPad;
+    int nFront;            // roles[0 .. nFront) sit IN FRONT of the prep roles in the grid (they need nothing of the prep work: the first diagonal blocks and the
+                           // E-chain's first dependency group), the prep roles follow, then roles[nFront ..)
     int* prepFlags;        // [B][nPrepCap]
     int nPrepCap;
     int eFromSigma;        // the E-chain's tiles are first read straight from Sigma (EA = Sigma[6:, 6:] with the pad row / column 5 and
@@ -341,6 +343,21 @@ EQF_DEV void panelIssue(PanelRegs& r, const double* srcP, int ldP, const double*
         r.q[u] = hoLoad8(srcQ + (long long)row * ldQ + col);
     }
 }
+// (one block of the pair at a time: at the frontier the two flags of a panel come microseconds apart -- see the right-hand-side roles)
+EQF_DEV void panelIssueP(PanelRegs& r, const double* srcP, int ldP, int tid) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int e = tid + 256 * u, row = e >> 6, col = e & 63;
+        r.p[u] = hoLoad8(srcP + (long long)row * ldP + col);
+    }
+}
+EQF_DEV void panelIssueQ(PanelRegs& r, const double* srcQ, int ldQ, int tid) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int e = tid + 256 * u, row = e >> 6, col = e & 63;
+        r.q[u] = hoLoad8(srcQ + (long long)row * ldQ + col);
+    }
+}
 EQF_DEV void panelToLds(const PanelRegs& r, double (*dstP)[kSP], double (*dstQ)[kSP], int tid) {
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
@@ -402,18 +419,19 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
     // downdate tiles of a filter are more than 32768 -- N > ~2700)
     const int nB = (int)gridDim.x / ra.rolesPerRow;
     const int roleIdxAll = (int)blockIdx.x / nB + ra.rolesPerRow * (int)blockIdx.y, bIdx = (int)blockIdx.x % nB;
-    if (FOLD && roleIdxAll < ra.nPrep) {
-        // ---- a prep role (see ResArgs::nPrep): the lowest block indices of the grid -- nothing they need is produced in this launch
+    if (FOLD && roleIdxAll >= ra.nFront && roleIdxAll < ra.nFront + ra.nPrep) {
+        // ---- a prep role (see ResArgs::nPrep): among the lowest block indices of the grid -- nothing they need is produced in this launch
+        const int prepIdx = roleIdxAll - ra.nFront;
         const Glob& gp = ra.a.g[bIdx];
         if (gp.updateOk && gp.N != 0) {
-            updatePrepBody<T, true>(ra.a, roleIdxAll, bIdx, ra.lmBlocks, ra.prepWpb, ra.prepNvPad, reinterpret_cast<double*>(smemR));
+            updatePrepBody<T, true>(ra.a, prepIdx, bIdx, ra.lmBlocks, ra.prepWpb, ra.prepNvPad, reinterpret_cast<double*>(smemR));
             hoDrain();
         }
         __syncthreads();
-        if (threadIdx.x == 0) hoPublish(ra.prepFlags + (long long)bIdx * ra.nPrepCap + roleIdxAll, ra.c0.epoch);
+        if (threadIdx.x == 0) hoPublish(ra.prepFlags + (long long)bIdx * ra.nPrepCap + prepIdx, ra.c0.epoch);
         return;
     }
-    const int roleIdx = roleIdxAll - (FOLD ? ra.nPrep : 0);
+    const int roleIdx = roleIdxAll - ((FOLD && roleIdxAll >= ra.nFront) ? ra.nPrep : 0);
     if (roleIdx >= ra.nRoles + ra.nDdTiles) return;
     if (roleIdx >= ra.nRoles) {
         // ---- a downdate tile of filter blockIdx.x.  These workgroups have the HIGHEST block indices: they are dispatched when
@@ -833,8 +851,20 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
             auto look = [&](int K) {
                 return (tid == 0 && K < C) ? hoProbe3(readyA + C * nbCap + K, readyY + K * wtCap + t, isS ? readyY + K * wtCap : nullptr, epoch) : false;
             };
-            hoWait3(readyA + C * nbCap, readyY + t, isS ? readyY : nullptr, epoch, tid, &bad, ra.errflag);
-            issue(0);
+            // At the frontier -- the newest panel not complete yet -- its two blocks come from different producers at different times: L_{C,K}
+            // from the row head H(C) / an interior tile a few microseconds after D[K], Y_{K,t} from the right-hand-side tile above, which
+            // itself waited for the one above it: on a grid larger than the chip the right-hand-side tiles of a column are a chain of
+            // their own that lags the row heads (8 filters of N = 200: the S-chain's last Y tile 36 us after its last D,
+            // profiles/r05_res_stamps_B8_before.txt).  So L_{C,K} is asked for as soon as ITS flag is up and only Y_{K,t} travels behind the
+            // late flag: 32 KB on the chain instead of 64.
+            auto issueSplit = [&](int K) {
+                hoWait3(readyA + C * nbCap + K, nullptr, nullptr, epoch, tid, &bad, ra.errflag);
+                panelIssueQ(pr, rowQ + K * kSB, ldA, tid);
+                hoWait3(readyY + K * wtCap + t, isS ? readyY + K * wtCap : nullptr, nullptr, epoch, tid, &bad, ra.errflag);
+                panelIssueP(pr, colP + (long long)(K * kSB) * ldW, ldW, tid);
+                if (isS && tid < kSB) zNext = hoLoad8(WO + (long long)(K * kSB + tid) * ldW + 11);
+            };
+            issueSplit(0);
             bool probe = look(1);
             for (int K = 0; K < C; ++K) {
                 panelToLds(pr, s.P, s.Q, tid);
@@ -857,8 +887,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
                 __syncthreads();
                 if (K + 1 < C && !ahead) {
                     if (lastFast && K + 2 == C) collect();  // (the last panel is not out yet: this wait is idle time on the critical path's side)
-                    hoWait3(readyA + C * nbCap + K + 1, readyY + (K + 1) * wtCap + t, isS ? readyY + (K + 1) * wtCap : nullptr, epoch, tid, &bad, ra.errflag);
-                    issue(K + 1);
+                    issueSplit(K + 1);
                     probe = look(K + 2);
                 }
             }

@@ -718,7 +718,7 @@ EQF_DI void downdateTile(const UpdArgs& a, int nt, int b, int tileIdx, T* lds, G
         // on disjoint banks (pitch 65 made every operand read a 2-way conflict: SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE), and a
         // half-wavefront stages one whole 64-value row (lane l: columns 2 l, 2 l + 1 -- one 512-byte global read, one conflict-free write).
 #ifndef EQF_DD_DEPTH
-#define EQF_DD_DEPTH 4
+#define EQF_DD_DEPTH 8  // (two block rows of look-ahead: 4 -> 8 gave +0.5 .. 1 % at every batch size, profiles/r05_downdate_depth.txt)
 #endif
         constexpr int KC2 = 16, PITCH = 80, D = std::is_same<Gate, DdNoGate>::value ? 4 : EQF_DD_DEPTH;
         static_assert(2 * 2 * KC2 * PITCH >= TS * (TS + 1), "the epilogue's transposed tile lives in the same LDS");
