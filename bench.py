@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--batch64-steps", type=int, default=440)
     ap.add_argument("--no-steady-state", action="store_true", help="skip the 2200-step leg that accompanies a short --steps run")
     ap.add_argument("--no-tiled", action="store_true", help="skip the cfg 5 leg: one N = --tiled-landmarks filter with Sigma 2-D block-partitioned "
-                    "over the ranks of the job (1 x 1 grid on one GPU, 2 x 4 on eight), closed loop through eqf_vio_amd/tiled.py")
+                    "over the ranks of the job (1 x 1 grid on one GPU, 2 x 4 on eight), closed loop through the C++ host loop eqf_tf_* (csrc/eqf_tiledf.hip)")
     ap.add_argument("--tiled", action="store_true", help="(the cfg 5 leg is on by default; kept for explicitness)")
     ap.add_argument("--tiled-landmarks", type=int, default=4000)
     ap.add_argument("--tiled-block", type=int, default=250, help="landmarks per block of the 2-D partition")
@@ -422,7 +422,7 @@ GRIDS = {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (2, 4)}
 
 
 def tiled_leg(args, dist, rank, world, device):
-    """BASELINE configs[4]: ONE filter of N landmarks, Sigma 2-D block-partitioned over the ranks of the job (eqf_vio_amd/tiled.py), closed
+    """BASELINE configs[4]: ONE filter of N landmarks, Sigma 2-D block-partitioned over the ranks of the job (eqf_tf_*: csrc/eqf_tiledf.hip), closed
     loop, the same stream on every rank.  One warm-up frame (the first frame: landmarks appended + update), then `frames` timed frames of
     10 IMU calls + 1 vision call, bracketed by barrier + synchronize, maximum over the ranks.  On one GPU the monolithic single-GPU path
     runs the same events right after, for the number next to it."""

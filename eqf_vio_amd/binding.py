@@ -66,6 +66,10 @@ EXPORTED_SYMBOLS = [
     "eqf_tiled_update_prep", "eqf_tiled_update_finish", "eqf_tiled_synchronize", "eqf_tiled_num_landmarks", "eqf_tiled_get_time",
     "eqf_tiled_device_error", "eqf_tiled_get_state_estimate", "eqf_tiled_get_origin", "eqf_tiled_get_group", "eqf_tiled_get_bias",
     "eqf_tiled_get_last_update", "eqf_tiled_get_integrator", "eqf_tiled_get_base", "eqf_tiled_set_state",
+    "eqf_tf_create", "eqf_tf_destroy", "eqf_tf_set_option", "eqf_tf_process_imu", "eqf_tf_process_vision", "eqf_tf_synchronize", "eqf_tf_check",
+    "eqf_tf_device_error", "eqf_tf_num_landmarks", "eqf_tf_num_slots", "eqf_tf_get_ids", "eqf_tf_get_time", "eqf_tf_get_state_estimate",
+    "eqf_tf_get_bias", "eqf_tf_get_last_update", "eqf_tf_get_sigma", "eqf_tf_set_state", "eqf_tf_get_churn_stats", "eqf_tf_local_matrix",
+    "eqf_tf_get_phases", "eqf_tf_phase_name", "eqf_tf_last_error", "eqf_tf_tiled_handle",
 ]
 
 

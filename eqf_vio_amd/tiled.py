@@ -1,190 +1,152 @@
 """One EqF filter with Sigma 2-D block-partitioned over a process grid -- BASELINE configs[4] (N = 4000 landmarks, Sigma = 1.15 GB
-fp64), SURVEY.md 8(e) row 2.  One process per GPU over torch.distributed (backend "nccl" = RCCL over xGMI on a GPU node, "gloo" in
-the CPU tests); the host side of eqf_vio/include/eqf_vio/VIOFilter.h:41-88 for this configuration: `TiledFilter.processIMUData`,
-`processVisionData`, `stateEstimate`, `stateCovariance`.
+fp64), SURVEY.md 8(e) row 2.  One process per GPU; the host side of eqf_vio/include/eqf_vio/VIOFilter.h:41-88 for this configuration:
+`TiledFilter.processIMUData`, `processVisionData`, `stateEstimate`, `stateCovariance`.
 
-What is partitioned.  Sigma in the reference's index map (eqf_vio/src/VIOFilter.cpp:54-57): 11 base coordinates, then 3 per
-landmark.  Landmarks are cut into blocks of `bl`; process (pr, pc) of the Pr x Pc grid owns the landmark blocks I = pr, pr + Pr, ...
-as rows and J = pc, pc + Pc, ... as columns of ONE dense local matrix Sll (3 nlr x 3 nlc, ScaLAPACK's block-cyclic local storage), so
-every step is a handful of launches over the whole local matrix.  The 11-row base panel Sigma[0:11, :] (88 KB per 1000 landmarks) and
-the O(N) filter state are REPLICATED: every rank advances its own identical copy (csrc/eqf_tiled.hpp, the device functions of the
-single-GPU path).  Pr must divide Pc (1 x 1, 1 x 2, 2 x 2, 2 x 4 for one 8-GPU node, 1 x 8).
-
-Riccati propagate (VIOFilter.cpp:160-194), F = I + T A_b = [[F_bb, 0], [L, D]] with D block-diagonal:
-    Sigma'_IJ = (D_I Sigma_IJ + L_I Sigma_bJ) D_J^T + (L_I Sigma_bb + D_I Sigma_Ib) L_J^T + Q_IJ      local, in place
-    Sigma'_bJ = F_bb (Sigma_bb L_J^T + Sigma_bJ D_J^T) + Q_bJ ,  Sigma'_bb = F_bb Sigma_bb F_bb^T + Q_bb   replicated
-  -> NO communication.
-
-Update (VIOFilter.cpp:264-297) in the Cholesky form of the single-GPU path (csrc/eqf_update.hpp): S = U^T U, Y = U^-T [C Sigma | C
-Sigma_b, delta, V], gamma = Y^T z, Sigma <- Sigma - Y^T Y; bundleLift's weights (EqFMatrices.cpp:239) from a second factorisation, of
-the Schur complement of Sigma_e = Sigma[6:, 6:] after its five base coordinates.  Both run through `_chain`: a right-looking blocked
-Cholesky that keeps block ROWS (upper factor), so that every dense product has the one form C += alpha A^T B (eqf_tile_gemm_tn).
-Per block row k (owner process row k mod Pr):
-    1. the owner of the diagonal block factors it (eqf_tile_potrf) and broadcasts L_kk ALONG ITS PROCESS ROW;
-    2. that process row solves its pieces of block row k in place:  [U_k,k+1.. | Y_k] = L_kk^-1 [A_k,k+1.. | W_k]  (eqf_tile_trsm);
-    3. every rank of the row broadcasts its solved piece DOWN ITS PROCESS COLUMN  (-> the "B operand" of every product);
-    4. the ranks (pr, c) with c = pr mod Pr re-broadcast the piece they just received ALONG THEIR PROCESS ROW; interleaved these give
-       the "A operand": the blocks U_ki / Y_kI of the rank's own ROW blocks (this needs Pr | Pc);
-    5. trailing updates of the local matrix, the rank's share of the downdate Sigma_IJ -= Y_kI^T Y_kJ and of the reductions -- no
-       further traffic.
-  A rank receives (1/Pr + 1/Pc) of every block row instead of all of it (SUMMA-restricted; the round-2 prototype gathered every panel
-  to every rank): at N = 4000 on 2 x 4 that is 0.75 x (0.26 + 0.77) GB per update.
-
-Landmark churn (VIOFilter.cpp:345-443: removeOldLandmarks, removeOutliers, addNewLandmarks) works on SLOTS.  The partition is over
-physical landmark slots; a removed landmark leaves an INACTIVE slot where it was (zero rows / columns of Sigma with a unit diagonal
-block, identity linearisation, no measurement rows: both factorisations carry it along as a decoupled block of exact zeros), a new
-landmark takes the lowest free slot -- so no row or column of Sigma ever moves between ranks, and only the ranks that own a slot's blocks
-touch them.  The reference's landmark ORDER (insertion order, VIOFilter.cpp:211-230) is kept here, on the host, as the permutation
-`slot_of`; the recursion is equivariant under it, and every getter of TiledFilter answers in the reference's order.  The decisions --
-which ids left, which bearings fail the gate, the median scene depth -- are O(N) on the replicated state and identical on every rank.
-
-The tile mathematics is NOT here: `HipBackend` calls the HIP kernels through the C ABI (include/eqf_vio_amd.h, eqf_tiled_* /
-eqf_tile_*) on torch CUDA tensors' device pointers, and fails loudly without the library or a GPU.  The CPU tests drive the same
-schedule with a test double of the backend (tests/tiled_double.py) over gloo.
+This module is GLUE.  The filter's host loop -- the landmark bookkeeping on slots, the IMU bursts, the two distributed Cholesky
+factorisations of an update with their look-ahead, the covariance downdate -- is C++ behind the C ABI (csrc/eqf_tiledf.hip: eqf_tf_*,
+include/eqf_vio_amd.h); what is here is (1) the ctypes binding of those entry points and (2) `ProcessGrid`: the ONE callback the C++
+loop needs from its host, "broadcast this device buffer along my process row / column, ordered on this HIP stream", answered with
+torch.distributed (backend "nccl" = RCCL over xGMI on a GPU node, "gloo" in the tests).  A C++ host answers the same callback with
+ncclBroadcast.  The per-rank kernels can also be driven directly (eqf_vio_amd/tiled_backend.py: HipBackend); the schedule
+as an executable specification in Python, with a numpy double of the kernels for CPU process grids, is tests/tiled_reference.py.
 """
-import ctypes
+import ctypes as C
 
 import numpy as np
 import torch
 
-NARROW_S = 18  # (C Sigma)_Ib (11) | delta | V (6)
-NARROW_E = 11  # Z_P (6) | E_top (5)
+from . import binding
+from .tiled_backend import HipBackend  # noqa: F401  (re-exported: kernel-level tests and scripts)
+
+_BCAST = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
-class BlockCyclic:
-    """Geometry of the partition: N landmarks in blocks of bl, block I on process row I mod Pr, block J on process column J mod Pc."""
+class _Comm(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("bcast", _BCAST)]
 
-    def __init__(self, N, bl, Pr, Pc, pr, pc):
-        assert N >= 1 and bl >= 1 and Pc % Pr == 0, "the process grid needs Pr | Pc"
-        self.N, self.bl, self.Pr, self.Pc, self.pr, self.pc = N, bl, Pr, Pc, pr, pc
-        self.nb = (N + bl - 1) // bl
-        self.row_blocks = list(range(pr, self.nb, Pr))
-        self.col_blocks = list(range(pc, self.nb, Pc))
-        self.rowMap = self.landmarks_of(self.row_blocks)
-        self.colMap = self.landmarks_of(self.col_blocks)
-        self.nlr, self.nlc = len(self.rowMap), len(self.colMap)
 
-    def block_size(self, b):
-        return min(self.bl, self.N - b * self.bl)
+class _DevBuf:
+    """`nbytes` bytes of device memory at `ptr` as a CUDA-array-interface object (-> torch.as_tensor without a copy)."""
 
-    def landmarks_of(self, blocks):
-        out = [np.arange(b * self.bl, b * self.bl + self.block_size(b), dtype=np.int32) for b in blocks]
-        return np.concatenate(out) if out else np.zeros(0, dtype=np.int32)
+    def __init__(self, ptr, count, typestr="<f8"):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 3, "strides": None}
 
-    def ncols_of(self, c):
-        """landmarks in the local columns of process column c"""
-        return sum(self.block_size(b) for b in range(c, self.nb, self.Pc))
 
-    @staticmethod
-    def blocks_upto(k, p, P):
-        """number of blocks b <= k with b mod P == p"""
-        return (k - p) // P + 1 if k >= p else 0
+def _lib():
+    L = binding.lib()
+    if not getattr(L, "_eqf_tf_bound", False):
+        vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)
+        L.eqf_tf_create.argtypes = [C.POINTER(binding.Settings), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_Comm), C.POINTER(vp)]
+        L.eqf_tf_destroy.argtypes = [vp]
+        L.eqf_tf_destroy.restype = None
+        L.eqf_tf_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+        L.eqf_tf_process_imu.argtypes = [vp, C.c_double, dp, dp]
+        L.eqf_tf_process_vision.argtypes = [vp, C.c_double, C.c_int, ip, dp]
+        for name in ("eqf_tf_synchronize", "eqf_tf_check", "eqf_tf_device_error", "eqf_tf_num_landmarks", "eqf_tf_num_slots"):
+            getattr(L, name).argtypes = [vp]
+        L.eqf_tf_get_ids.argtypes = [vp, ip, ip]
+        L.eqf_tf_get_time.argtypes = [vp, dp]
+        L.eqf_tf_get_state_estimate.argtypes = [vp, dp, dp, dp, dp]
+        L.eqf_tf_get_bias.argtypes = [vp, dp]
+        L.eqf_tf_get_last_update.argtypes = [vp, dp, dp, dp]
+        L.eqf_tf_get_sigma.argtypes = [vp, dp, C.c_int, C.c_int]
+        L.eqf_tf_set_state.argtypes = [vp, C.c_int, ip] + [dp] * 11 + [C.c_int, C.c_double, dp, dp, C.c_double, C.c_int]
+        L.eqf_tf_get_churn_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
+        L.eqf_tf_local_matrix.argtypes = [vp, C.POINTER(dp), ip, ip, ip]
+        L.eqf_tf_get_phases.argtypes = [vp, dp]
+        L.eqf_tf_phase_name.argtypes = [C.c_int]
+        L.eqf_tf_phase_name.restype = C.c_char_p
+        L.eqf_tf_last_error.argtypes = [vp]
+        L.eqf_tf_last_error.restype = C.c_char_p
+        L.eqf_tf_tiled_handle.argtypes = [vp]
+        L.eqf_tf_tiled_handle.restype = vp
+        L._eqf_tf_bound = True
+    return L
 
 
 class ProcessGrid:
-    """Pr x Pc process grid over a torch.distributed group, rank = pr * Pc + pc, with one sub-group per process row / column."""
+    """Pr x Pc process grid over a torch.distributed group, rank = pr * Pc + pc, with one sub-group per process row / column -- and a second
+    set for the E-chain of an update, which runs next to the S-chain on its own stream (two collectives of ONE communicator must not be in
+    flight at the same time).  `bcast` is the callback of eqf_tf_comm (include/eqf_vio_amd.h)."""
 
     def __init__(self, dist, Pr, Pc, device="cpu"):
         self.dist, self.Pr, self.Pc, self.device = dist, Pr, Pc, device
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
-        assert self.world == Pr * Pc and Pc % Pr == 0
+        assert self.world == Pr * Pc and Pc % Pr == 0, "the process grid needs Pr | Pc"
         self.pr, self.pc = divmod(self.rank, Pc)
-        self.row_group = self.col_group = None
+        self.groups = [[None, None, None], [None, None, None]]  # [chain][row, column, everybody]
         if dist is not None and self.world > 1:
             # (new_group is collective over the whole job: every rank creates every group, in the same order)
-            for r in range(Pr):
-                grp = dist.new_group([r * Pc + c for c in range(Pc)])
-                if r == self.pr:
-                    self.row_group = grp
-            for c in range(Pc):
-                grp = dist.new_group([r * Pc + c for r in range(Pr)])
-                if c == self.pc:
-                    self.col_group = grp
+            for chain in range(2):
+                for r in range(Pr):
+                    grp = dist.new_group([r * Pc + c for c in range(Pc)])
+                    if r == self.pr:
+                        self.groups[chain][0] = grp
+                for c in range(Pc):
+                    grp = dist.new_group([r * Pc + c for r in range(Pr)])
+                    if c == self.pc:
+                        self.groups[chain][1] = grp
+        self.error = None
+        self._cb = _BCAST(self._bcast)
+        self.comm = _Comm(None, self._cb)
 
-    def bcast_row(self, t, root_pc):
-        if self.Pc > 1:
-            self.dist.broadcast(t, src=self.pr * self.Pc + root_pc, group=self.row_group)
-        return t
+    def backend_name(self):
+        return self.dist.get_backend() if (self.dist is not None and self.world > 1) else ""
 
-    def bcast_col(self, t, root_pr):
-        if self.Pr > 1:
-            self.dist.broadcast(t, src=root_pr * self.Pc + self.pc, group=self.col_group)
-        return t
-
-    def allgather_row(self, t):
-        """every rank of my process row contributes t (same shape); returns the Pc pieces.  Done as Pc broadcasts: small, once per update,
-        and it works for device tensors on every backend (gloo has no device all_gather)."""
-        if self.Pc == 1:
-            return [t]
-        out = []
-        for c in range(self.Pc):
-            piece = t if c == self.pc else torch.empty_like(t)
-            self.dist.broadcast(piece, src=self.pr * self.Pc + c, group=self.row_group)
-            out.append(piece)
-        return out
-
-    def allgather_all(self, t):
-        if self.world == 1:
-            return [t]
-        out = []
-        for r in range(self.world):
-            piece = t if r == self.rank else torch.empty_like(t)
-            self.dist.broadcast(piece, src=r)
-            out.append(piece)
-        return out
+    def _bcast(self, ctx, group, chain, root, buf, nbytes, stream):
+        try:
+            t = torch.as_tensor(_DevBuf(buf, nbytes // 8), device=self.device)
+            src = (self.pr * self.Pc + root) if group == 0 else ((root * self.Pc + self.pc) if group == 1 else root)
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)):
+                self.dist.broadcast(t, src=src, group=self.groups[chain][group] if group < 2 else None)
+            return 0
+        except Exception as e:  # (an exception must not unwind through the C++ frames)
+            self.error = e
+            return 1
 
 
-class HipBackend:
-    """The per-rank device side through the C ABI: an eqf_tiled handle (replicated state + base panel) and the dense tile kernels, on
-    torch CUDA tensors of `device_index` and torch's current stream."""
+class TiledFilter:
+    """VIOFilter (VIOFilter.h:41-88) for one filter whose Sigma is partitioned over `grid`; every rank of the grid makes the same calls with
+    the same arguments.  `backend`: a HipBackend -- its settings, capacity, device and CU reservation are taken, and from then on it answers
+    for the filter's replicated state (its getters, in SLOT order) -- or a settings dict with capacity= / device_index= given."""
 
-    DREC = 64 * 64 + 4 * 16 * 16  # doubles per 64-wide block column of a diagonal-factor record
-
-    def __init__(self, settings, capacity, device_index=0, reserve_cus=None, cu_range=None):
-        """cu_range = (first_cu, num_cus): confine EVERY stream of this rank to that slice of the GPU (experiments with several ranks on one
-        device, scripts/tiled_cumask.py: main streams on [first + reserve, first + num), look-ahead streams on [first, first + reserve))."""
-        from . import binding
-
-        self.b = binding
-        self.lib = binding.lib()  # raises when libeqf_vio_amd.so is missing: there is no CPU fallback
-        if isinstance(settings, dict):
-            settings = binding.settings_from_dict(settings)
-        self.settings = settings
-        self.dev = int(device_index)
-        self.device = torch.device("cuda", self.dev)
-        self.cap = int(capacity)
-        self._h = ctypes.c_void_p()
-        binding._check(self.lib.eqf_tiled_create(ctypes.byref(settings), self.cap, self.dev, ctypes.byref(self._h)), "eqf_tiled_create")
-        self._stream = None
-        self._info = torch.zeros(1, dtype=torch.int32, device=self.device)
-        # Two streams with disjoint CU sets: `reserve` CUs for the look-ahead factorisation of the next diagonal block (side()), all the
-        # others for everything else (main()).  EQF_TILED_RESERVE_CUS=0: no reservation -- main() is torch's current stream and the
-        # look-ahead only runs when the trailing update happens to leave room.
+    def __init__(self, grid, backend, block_landmarks, capacity=None, device_index=None, reserve_cus=None):
+        L = self.lib = _lib()
+        self.g, self.bl = grid, int(block_landmarks)
+        if isinstance(backend, HipBackend):
+            self.be = backend
+            settings, dev = backend.settings, backend.dev
+            cap = int(capacity if capacity is not None else backend.cap)
+            reserve = backend.reserve if reserve_cus is None else int(reserve_cus)
+        else:
+            self.be = None
+            settings = binding.settings_from_dict(backend) if isinstance(backend, dict) else backend
+            dev, cap = int(device_index or 0), int(capacity)
+            reserve = -1 if reserve_cus is None else int(reserve_cus)
+        self.settings, self.cap, self.dev = settings, cap, dev
+        self.device = torch.device("cuda", dev)
+        torch.cuda.init()
+        self._h = C.c_void_p()
+        comm = C.byref(grid.comm) if grid.world > 1 else None
+        binding._check(L.eqf_tf_create(C.byref(settings), cap, self.bl, grid.Pr, grid.Pc, grid.rank, dev, reserve, comm, C.byref(self._h)), "eqf_tf_create")
+        if self.be is not None:
+            self.be.adopt(L.eqf_tf_tiled_handle(self._h))
+        # Two RCCL communicators with kernels in flight on different streams of one process can deadlock when the ranks' GPUs schedule them in
+        # different orders, and this schedule has never run on more than one GPU: over nccl with more than one rank the chains run one after
+        # the other unless EQF_TILED_OVERLAP_CHAINS=1 asks for it (one rank, or gloo -- host-blocking collectives --: side by side).
         import os
 
-        self.reserve = int(os.environ.get("EQF_TILED_RESERVE_CUS", "8")) if reserve_cus is None else int(reserve_cus)
-        self._raw = []
-        self._main = self._side = self._aux = self._aux_side = None
-        if self.reserve > 0:
-            ptrs = [ctypes.c_void_p() for _ in range(4)]
-            for i, p in enumerate(ptrs):  # main, side, and a second pair for the E-chain, which runs next to the S-chain (TiledFilter._update)
-                if cu_range is None:
-                    first, count, comp = 0, self.reserve, 1 if i % 2 == 0 else 0
-                else:
-                    first, count, comp = (cu_range[0] + self.reserve, cu_range[1] - self.reserve, 0) if i % 2 == 0 else (cu_range[0], self.reserve, 0)
-                binding._check(self.lib.eqf_stream_create_masked(self.dev, first, count, comp, ctypes.byref(p)), "eqf_stream_create_masked")
-            self._raw = ptrs
-            self._main, self._side, self._aux, self._aux_side = [torch.cuda.ExternalStream(p.value, device=self.device) for p in ptrs]
-        self._sync_stream()
+        env = os.environ.get("EQF_TILED_OVERLAP_CHAINS")
+        self.overlap_chains = (env != "0") if env is not None else not (grid.world > 1 and grid.backend_name() == "nccl")
+        self._phases_on = False
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            self.lib.eqf_tiled_destroy(self._h)
-            self._h = ctypes.c_void_p()
-            for p in getattr(self, "_raw", []):
-                self.lib.eqf_stream_destroy(self.dev, p)
-            self._raw = []
+            if self.be is not None:
+                self.be.release()
+            self.lib.eqf_tf_destroy(self._h)
+            self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -192,252 +154,153 @@ class HipBackend:
         except Exception:
             pass
 
-    # ---- plumbing
-    def _sync_stream(self):
-        s = torch.cuda.current_stream(self.dev).cuda_stream
-        if s != self._stream:
-            self.b._check(self.lib.eqf_tiled_set_stream(self._h, ctypes.c_void_p(s)), "eqf_tiled_set_stream")
-            self._stream = s
-        return ctypes.c_void_p(s)
+    def _check(self, rc, what):
+        if self.g.error is not None:
+            e, self.g.error = self.g.error, None
+            raise e
+        if rc < 0:
+            msg = self.lib.eqf_tf_last_error(self._h).decode()
+            if rc == binding.ERR_NUMERIC:
+                raise ArithmeticError(msg or "a pivot of S or Sigma_e was not positive (distributed factorisation)")
+            if rc == binding.ERR_CAPACITY:
+                raise RuntimeError(msg or "capacity exceeded")
+            if rc == binding.ERR_UNSORTED:
+                raise ValueError("bearings must come with strictly ascending ids (VIOFilter.cpp:239-240)")
+            raise binding.EqfError(rc, what)
+        return rc
 
-    def _cur(self):
-        """torch's current stream, for the dense tile kernels (they take the stream as an argument; the handle's own stream -- the
-        state kernels -- only follows torch's stream outside side())"""
-        return ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+    def _opt(self, name, value):
+        self._check(self.lib.eqf_tf_set_option(self._h, name.encode(), int(value)), "eqf_tf_set_option")
 
-    # ---- a second stream for the look-ahead factorisation of the next diagonal block (TiledFilter._chain)
-    def main(self):
-        """context: the stream every call of the filter runs on (all CUs but the reserved ones)"""
-        import contextlib
+    # ---- options (attributes, as the Python loop had them)
+    overlap_chains = property(lambda s: s._overlap, lambda s, v: (setattr(s, "_overlap", bool(v)), s._opt("overlap_chains", v))[0])
+    lookahead = property(lambda s: getattr(s, "_lookahead", True), lambda s, v: (setattr(s, "_lookahead", bool(v)), s._opt("lookahead", v))[0])
+    burst = property(lambda s: getattr(s, "_burst", True), lambda s, v: (setattr(s, "_burst", bool(v)), s._opt("burst", v))[0])
+    check_every = property(lambda s: getattr(s, "_check_every", 1), lambda s, v: (setattr(s, "_check_every", int(v)), s._opt("check_every", v))[0])
 
-        return torch.cuda.stream(self._main) if self._main is not None else contextlib.nullcontext()
+    @property
+    def phase_ms(self):
+        return self._phase_ms if self._phases_on else None
 
-    def side(self):
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        return torch.cuda.stream(self._side)
+    @phase_ms.setter
+    def phase_ms(self, v):
+        self._phases_on = v is not None
+        self._phase_ms = {} if v is not None else None
+        self._opt("profiling", 1 if v is not None else 0)
 
-    def aux(self):
-        """context: a second 'main' stream (same CU set), for the factorisation that runs next to the other one"""
-        if self._aux is None:
-            self._aux = torch.cuda.Stream(device=self.device)
-        return torch.cuda.stream(self._aux)
+    def collect_phases(self):
+        ms = np.zeros(7)
+        self._check(self.lib.eqf_tf_get_phases(self._h, binding._p(ms)), "eqf_tf_get_phases")
+        self._phase_ms = {self.lib.eqf_tf_phase_name(i).decode(): float(ms[i]) for i in range(7) if ms[i] > 0}
+        return self._phase_ms
 
-    def aux_side(self):
-        if self._aux_side is None:
-            self._aux_side = torch.cuda.Stream(device=self.device)
-        return torch.cuda.stream(self._aux_side)
+    # ---- VIOFilter::processIMUData / processVisionData (VIOFilter.cpp:120-131, :232-302)
+    def processIMUData(self, stamp, omega, accel):
+        w, a = np.ascontiguousarray(omega, dtype=np.float64), np.ascontiguousarray(accel, dtype=np.float64)
+        return self._check(self.lib.eqf_tf_process_imu(self._h, float(stamp), binding._p(w), binding._p(a)), "eqf_tf_process_imu")
 
-    def record(self):
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.dev))
-        return ev
-
-    def wait(self, ev):
-        if ev is not None:
-            torch.cuda.current_stream(self.dev).wait_event(ev)
-
-    @staticmethod
-    def _p(t):
-        return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()
-
-    @staticmethod
-    def _dp(a):
-        return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
-
-    def zeros(self, *shape):
-        return torch.zeros(*shape, dtype=torch.float64, device=self.device)
-
-    def empty(self, *shape):
-        return torch.empty(*shape, dtype=torch.float64, device=self.device)
-
-    # ---- replicated state + local blocks
-    def set_geometry(self, geo):
-        rm, cm = np.ascontiguousarray(geo.rowMap, dtype=np.int32), np.ascontiguousarray(geo.colMap, dtype=np.int32)
-        ip = ctypes.POINTER(ctypes.c_int)
-        self.b._check(self.lib.eqf_tiled_set_geometry(self._h, len(rm), rm.ctypes.data_as(ip), len(cm), cm.ctypes.data_as(ip)), "eqf_tiled_set_geometry")
-
-    def propagate(self, stamp, omega, accel, is_imu, Sll):
-        self._sync_stream()
-        w = np.ascontiguousarray(omega if omega is not None else np.zeros(3), dtype=np.float64)
-        a = np.ascontiguousarray(accel if accel is not None else np.zeros(3), dtype=np.float64)
-        ld = Sll.stride(0) if Sll is not None else 0
-        return self.b._check(self.lib.eqf_tiled_propagate(self._h, float(stamp), self._dp(w), self._dp(a), int(bool(is_imu)), self._p(Sll), ld),
-                             "eqf_tiled_propagate")
-
-    def add_landmarks(self, bearings, Sll):
-        self._sync_stream()
+    def processVisionData(self, stamp, ids, bearings):
+        ids = np.ascontiguousarray(ids, dtype=np.int32).reshape(-1)
         y = np.ascontiguousarray(bearings, dtype=np.float64).reshape(-1, 3)
-        self.b._check(self.lib.eqf_tiled_add_landmarks(self._h, len(y), self._dp(y), self._p(Sll), Sll.stride(0) if Sll is not None else 0),
-                      "eqf_tiled_add_landmarks")
+        if len(ids) != len(y):
+            raise ValueError("bearings must come with strictly ascending ids (VIOFilter.cpp:239-240)")
+        return self._check(self.lib.eqf_tf_process_vision(self._h, float(stamp), len(ids), ids.ctypes.data_as(C.POINTER(C.c_int)), binding._p(y)),
+                           "eqf_tf_process_vision")
 
-    BURST_MAX = 16
+    def check(self):
+        """Raises if a pivot of S or Sigma_e was not positive since the last look (synchronises)."""
+        self._check(self.lib.eqf_tf_check(self._h), "eqf_tf_check")
 
-    def propagate_burst(self, records, vision_stamp, Sll):
-        """records: [(stamp, omega, accel), ...] IMU calls; vision_stamp: the stamp of the vision call whose integrateUpToTime closes the burst
-        (or None).  One pass over Sll for all of them (eqf_tiled_propagate_burst).  Returns the status of every call."""
-        self._sync_stream()
-        K = len(records) + (1 if vision_stamp is not None else 0)
-        assert 1 <= K <= self.BURST_MAX
-        stamps = np.zeros(K)
-        w, a = np.zeros((K, 3)), np.zeros((K, 3))
-        for k, (st, om, ac) in enumerate(records):
-            stamps[k], w[k], a[k] = st, om, ac
-        if vision_stamp is not None:
-            stamps[K - 1] = vision_stamp
-        status = np.zeros(K, dtype=np.int32)
-        ld = Sll.stride(0) if Sll is not None else 0
-        self.b._check(self.lib.eqf_tiled_propagate_burst(self._h, K, self._dp(stamps), self._dp(w), self._dp(a), int(vision_stamp is not None), self._p(Sll),
-                                                         ld, status.ctypes.data_as(ctypes.POINTER(ctypes.c_int))), "eqf_tiled_propagate_burst")
-        return [int(x) for x in status]
-
-    def edit_landmarks(self, remove_slots, add_slots, add_bearings, depth, new_num_slots, Sll):
-        """removeLandmarkAtIndex for remove_slots, then addNewLandmarks into add_slots (include/eqf_vio_amd.h: eqf_tiled_edit_landmarks);
-        the geometry in force must cover max(old, new) slots."""
-        self._sync_stream()
-        rs = np.ascontiguousarray(remove_slots, dtype=np.int32).reshape(-1)
-        ads = np.ascontiguousarray(add_slots, dtype=np.int32).reshape(-1)
-        y = np.ascontiguousarray(add_bearings, dtype=np.float64).reshape(-1, 3)
-        assert len(y) == len(ads)
-        ip = ctypes.POINTER(ctypes.c_int)
-        self.b._check(self.lib.eqf_tiled_edit_landmarks(self._h, len(rs), rs.ctypes.data_as(ip), len(ads), ads.ctypes.data_as(ip), self._dp(y), float(depth),
-                                                        int(new_num_slots), self._p(Sll), Sll.stride(0) if Sll is not None else 0),
-                      "eqf_tiled_edit_landmarks")
-
-    def initial_scene_depth(self):
-        return float(self.settings.initialSceneDepth)
-
-    def update_prep(self, bearings, Sll, M, E, G11):
-        self._sync_stream()
-        y = np.ascontiguousarray(bearings, dtype=np.float64).reshape(-1, 3)
-        self.b._check(self.lib.eqf_tiled_update_prep(self._h, self._dp(y), self._p(Sll), Sll.stride(0), self._p(M), M.stride(0), self._p(E),
-                                                     E.stride(0), self._p(G11)), "eqf_tiled_update_prep")
-
-    def update_finish(self, acc, Gnn, G11):
-        self._sync_stream()
-        assert acc.stride(1) == 1 and Gnn.is_contiguous() and G11.is_contiguous()
-        self.b._check(self.lib.eqf_tiled_update_finish(self._h, self._p(acc), acc.stride(0), self._p(Gnn), self._p(G11)), "eqf_tiled_update_finish")
-
-    # ---- dense tile kernels (csrc/eqf_tile.hpp)
-    def potrf(self, Akk, drec=None):
-        """In place: lower triangle of the (n x n) view Akk <- L.  Returns (fills) the diagonal-factor records trsm() multiplies with."""
-        n = Akk.shape[0]
-        if drec is None:
-            drec = torch.empty(((n + 63) // 64) * self.DREC, dtype=torch.float64, device=self.device)
-        self.b._check(self.lib.eqf_tile_potrf(self.dev, self._cur(), self._p(Akk), Akk.stride(0), n, self._p(drec), self._p(self._info)),
-                      "eqf_tile_potrf")
-        return drec
-
-    TRSM_SPLIT = 6  # block rows of 64 from which a solve is split in two (see trsm_left)
-
-    def trsm_left(self, L, drec, Bm):
-        """In place: Bm (n x m view) <- L^-1 Bm.
-        eqf_tile_trsm is one workgroup per 64-column strip, and a strip is a CHAIN of nb (nb + 1) / 2 block products (nb = n / 64): its time
-        is that chain's latency whatever the width.  So from TRSM_SPLIT block rows on the solve is split once, [L11 0; L21 L22]:
-        X1 = L11^-1 B1 (a chain of a quarter of the products), B2 -= L21 X1 as ONE product on the whole chip (eqf_tile_gemm_tn, with L21
-        transposed into a scratch operand), X2 = L22^-1 B2 -- the records of L22's block columns are the tail of L's."""
-        n = L.shape[0]
-        nb = (n + 63) // 64
-        if nb < self.TRSM_SPLIT or Bm.shape[1] < 256:
-            self._trsm_launch(L, drec, Bm)
-            return
-        h = 64 * (nb // 2)
-        self._trsm_launch(L[:h, :h], drec, Bm[:h])
-        key = (n - h, h, self._cur().value)  # (one scratch operand per shape AND stream: the two chains solve side by side)
-        if not hasattr(self, "_l21t"):
-            self._l21t = {}
-        if key not in self._l21t:
-            self._l21t[key] = self.empty(h, n - h)
-        l21t = self._l21t[key]
-        l21t.copy_(L[h:, :h].t())
-        self.gemm_tn(Bm[h:], l21t, Bm[:h], -1.0)
-        self._trsm_launch(L[h:, h:], drec[(h // 64) * self.DREC:], Bm[h:])
-
-    def _trsm_launch(self, L, drec, Bm):
-        self.b._check(self.lib.eqf_tile_trsm(self.dev, self._cur(), self._p(L), L.stride(0), L.shape[0], self._p(drec), self._p(Bm),
-                                             Bm.stride(0), Bm.shape[1], 0), "eqf_tile_trsm")
-
-    def gemm_tn(self, Cm, A, B, alpha, mask=None):
-        """Cm (m x n view) += alpha A^T B; A (k x m), B (k x n) views with unit column stride.  mask = (rb, cb, rblk0, Pr, pr, cblk0, Pc,
-        pc): skip tiles entirely below the block diagonal of a block-cyclic local matrix."""
-        m, n = Cm.shape
-        k = A.shape[0]
-        if m == 0 or n == 0 or k == 0:
-            return
-        assert A.shape[1] == m and B.shape == (k, n) and Cm.stride(1) == 1 and A.stride(1) == 1 and B.stride(1) == 1
-        mk = mask if mask is not None else (0, 0, 0, 1, 0, 0, 1, 0)
-        self.b._check(self.lib.eqf_tile_gemm_tn(self.dev, self._cur(), self._p(Cm), Cm.stride(0), m, n, self._p(A), A.stride(0), self._p(B),
-                                                B.stride(0), k, float(alpha), *[int(x) for x in mk]), "eqf_tile_gemm_tn")
-
-    def mirror_lower(self, Cm, rb):
-        """Cm (n x n view): every element below the block diagonal (blocks of rb) <- its mirror image."""
-        self.b._check(self.lib.eqf_tile_mirror(self.dev, self._cur(), self._p(Cm), Cm.stride(0), Cm.shape[0], int(rb)), "eqf_tile_mirror")
-
-    def factor_info(self):
-        """non-zero if a pivot of any diagonal block since the last call was not positive (synchronises)"""
-        v = int(self._info.item())
-        self._info.zero_()
-        return v
-
-    # ---- getters (synchronise)
-    def num_landmarks(self):
-        return self.lib.eqf_tiled_num_landmarks(self._h)
-
-    def time(self):
-        t = ctypes.c_double()
-        self.lib.eqf_tiled_get_time(self._h, ctypes.byref(t))
-        return t.value
+    def synchronize(self):
+        self._check(self.lib.eqf_tf_synchronize(self._h), "eqf_tf_synchronize")
 
     def device_error(self):
-        return self.lib.eqf_tiled_device_error(self._h)
+        return self.lib.eqf_tf_device_error(self._h)
 
-    def outlier_threshold(self):
-        return float(self.settings.outlierThreshold)
+    # ---- bookkeeping the tests and the bench look at
+    @property
+    def ids(self):
+        n = self.lib.eqf_tf_num_landmarks(self._h)
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        self.lib.eqf_tf_get_ids(self._h, out.ctypes.data_as(C.POINTER(C.c_int)), None)
+        return out[:n].astype(np.int64)
 
-    def state_estimate(self):
-        N = self.num_landmarks()
-        q, x, v, p = np.zeros(4), np.zeros(3), np.zeros(3), np.zeros((max(N, 1), 3))
-        self.b._check(self.lib.eqf_tiled_get_state_estimate(self._h, self._dp(q), self._dp(x), self._dp(v), self._dp(p)), "eqf_tiled_get_state_estimate")
-        return {"q": q, "x": x, "v": v, "p": p[:N]}
+    @property
+    def slot_of(self):
+        n = self.lib.eqf_tf_num_landmarks(self._h)
+        ids, sl = np.zeros(max(n, 1), dtype=np.int32), np.zeros(max(n, 1), dtype=np.int32)
+        self.lib.eqf_tf_get_ids(self._h, ids.ctypes.data_as(C.POINTER(C.c_int)), sl.ctypes.data_as(C.POINTER(C.c_int)))
+        return sl[:n].astype(np.int64)
 
-    def origin(self):
-        N = self.num_landmarks()
-        q, x, v, p = np.zeros(4), np.zeros(3), np.zeros(3), np.zeros((max(N, 1), 3))
-        self.b._check(self.lib.eqf_tiled_get_origin(self._h, self._dp(q), self._dp(x), self._dp(v), self._dp(p)), "eqf_tiled_get_origin")
-        return {"q": q, "x": x, "v": v, "p": p[:N]}
+    @property
+    def nslots(self):
+        return self.lib.eqf_tf_num_slots(self._h)
 
-    def group(self):
-        N = self.num_landmarks()
-        Aq, Ax, w, Qq, Qa = np.zeros(4), np.zeros(3), np.zeros(3), np.zeros((max(N, 1), 4)), np.zeros(max(N, 1))
-        self.b._check(self.lib.eqf_tiled_get_group(self._h, self._dp(Aq), self._dp(Ax), self._dp(w), self._dp(Qq), self._dp(Qa)), "eqf_tiled_get_group")
-        return {"Aq": Aq, "Ax": Ax, "w": w, "Qq": Qq[:N], "Qa": Qa[:N]}
+    @property
+    def taken(self):
+        t = np.zeros(self.cap, dtype=bool)
+        t[self.slot_of] = True
+        return t
+
+    @property
+    def churn_stats(self):
+        s = (C.c_longlong * 3)()
+        self.lib.eqf_tf_get_churn_stats(self._h, s)
+        return dict(removed_old=int(s[0]), removed_outliers=int(s[1]), added=int(s[2]))
+
+    @property
+    def Sll(self):
+        """the rank's local matrix (3 nlr x 3 nlc) as a torch view of the handle's device memory"""
+        p, r, c, ld = C.POINTER(C.c_double)(), C.c_int(), C.c_int(), C.c_int()
+        self.lib.eqf_tf_local_matrix(self._h, C.byref(p), C.byref(r), C.byref(c), C.byref(ld))
+        if not p or r.value == 0 or c.value == 0:
+            return torch.zeros(0, 0, dtype=torch.float64, device=self.device)
+        flat = torch.as_tensor(_DevBuf(C.cast(p, C.c_void_p).value, r.value * ld.value), device=self.device)
+        return flat.view(r.value, ld.value)[:, : c.value]
+
+    # ---- getters (reference order)
+    def getTime(self):
+        t = C.c_double()
+        self._check(self.lib.eqf_tf_get_time(self._h, C.byref(t)), "eqf_tf_get_time")
+        return t.value
+
+    def stateEstimate(self):
+        """VIOFilter::stateEstimate (:304): landmarks in the reference's order"""
+        n = self.lib.eqf_tf_num_landmarks(self._h)
+        q, x, v, p = np.zeros(4), np.zeros(3), np.zeros(3), np.zeros((max(n, 1), 3))
+        self._check(self.lib.eqf_tf_get_state_estimate(self._h, binding._p(q), binding._p(x), binding._p(v), binding._p(p)), "eqf_tf_get_state_estimate")
+        return {"q": q, "x": x, "v": v, "p": p[:n], "ids": self.ids}
 
     def bias(self):
-        b6 = np.zeros(6)
-        self.b._check(self.lib.eqf_tiled_get_bias(self._h, self._dp(b6)), "eqf_tiled_get_bias")
-        return b6
+        b = np.zeros(6)
+        self._check(self.lib.eqf_tf_get_bias(self._h, binding._p(b)), "eqf_tf_get_bias")
+        return b
 
-    def integrator(self):
-        cv, av, at, ini = np.zeros(6), np.zeros(6), ctypes.c_double(), ctypes.c_int()
-        self.b._check(self.lib.eqf_tiled_get_integrator(self._h, self._dp(cv), self._dp(av), ctypes.byref(at), ctypes.byref(ini)), "eqf_tiled_get_integrator")
-        return {"currentVelocity": cv, "accumulatedVelocity": av, "accumulatedTime": at.value, "initialised": bool(ini.value)}
+    def lastUpdate(self):
+        """delta (2 N), gamma (11 + 3 N), Gamma (9 + 3 N) of the last update, landmarks in the reference's order"""
+        n = self.lib.eqf_tf_num_landmarks(self._h)
+        d, g, G = np.zeros(max(2 * n, 1)), np.zeros(11 + 3 * n), np.zeros(9 + 3 * n)
+        self._check(self.lib.eqf_tf_get_last_update(self._h, binding._p(d), binding._p(g), binding._p(G)), "eqf_tf_get_last_update")
+        return {"delta": d[: 2 * n], "gamma": g, "Gamma": G}
 
-    def last_update(self):
-        N = self.num_landmarks()
-        d, g, G = np.zeros(2 * N), np.zeros(11 + 3 * N), np.zeros(9 + 3 * N)
-        self.b._check(self.lib.eqf_tiled_get_last_update(self._h, self._dp(d), self._dp(g), self._dp(G)), "eqf_tiled_get_last_update")
-        return {"delta": d, "gamma": g, "Gamma": G}
+    def _sigma(self, slot_order):
+        n = 11 + 3 * (self.nslots if slot_order else self.lib.eqf_tf_num_landmarks(self._h))
+        S = np.zeros((n, n))
+        self._check(self.lib.eqf_tf_get_sigma(self._h, binding._p(S), n, int(slot_order)), "eqf_tf_get_sigma")
+        return S
 
-    def base_rows(self):
-        N = self.num_landmarks()
-        out = np.zeros((11, 11 + 3 * N))
-        self.b._check(self.lib.eqf_tiled_get_base(self._h, self._dp(out), out.shape[1]), "eqf_tiled_get_base")
-        return out
+    def stateCovariance(self):
+        """Dense Sigma (reference index map and landmark order) gathered to every rank (VIOFilter::stateCovariance, :306-309); collective."""
+        return self._sigma(False)
 
-    def set_state(self, st):
-        """st: a snapshot as FilterBatch.dump_state() makes it (ids, origin, group, bias, sigma, time, currentVelocity, accumulatedVelocity,
-        accumulatedTime, initialised); only the first 11 rows of sigma are taken (the replicated base panel)."""
-        N = len(st["ids"])
+    def slotCovariance(self):
+        """Dense Sigma over ALL slots in use, holes included (slot order) -- tests of the hole invariants; collective."""
+        return self._sigma(True)
+
+    def initialise_from(self, st):
+        """Restart from a single-GPU snapshot (FilterBatch.dump_state(); every rank holds the dense Sigma once, here)."""
+        ids = np.ascontiguousarray(st["ids"], dtype=np.int32)
+        N = len(ids)
         o, g = st["origin"], st["group"]
 
         def arr(a, shape):
@@ -447,526 +310,10 @@ class HipBackend:
             return np.ascontiguousarray(out)
 
         p0, Qq, Qa = arr(o["p"], (max(N, 1), 3)), arr(g["Qq"], (max(N, 1), 4)), arr(g["Qa"], (max(N, 1),))
-        sb = np.ascontiguousarray(np.asarray(st["sigma"], dtype=np.float64)[:11])
+        S = np.ascontiguousarray(st["sigma"], dtype=np.float64)
         f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
-        arrs = [f(x) for x in (o["q"], o["x"], o["v"], p0, g["Aq"], g["Ax"], g["w"], Qq, Qa, st["bias"], sb)]
+        arrs = [f(x) for x in (o["q"], o["x"], o["v"], p0, g["Aq"], g["Ax"], g["w"], Qq, Qa, st["bias"], S)]
         cv, av = f(st["currentVelocity"]), f(st["accumulatedVelocity"])
-        self.b._check(self.lib.eqf_tiled_set_state(self._h, N, *[self._dp(a) for a in arrs], sb.shape[1], float(st["time"]), self._dp(cv),
-                                                   self._dp(av), float(st["accumulatedTime"]), int(st["initialised"])), "eqf_tiled_set_state")
-
-
-class TiledFilter:
-    """VIOFilter (VIOFilter.h:41-88) for one filter whose Sigma is partitioned over `grid`.  Every rank of the grid makes the same calls
-    with the same arguments.  `backend`: HipBackend (the product path), or the CPU test double.  `capacity`: landmark slots the local
-    storage is sized for (default: the backend's capacity)."""
-
-    def __init__(self, grid, backend, block_landmarks, capacity=None):
-        self.g, self.be, self.bl = grid, backend, int(block_landmarks)
-        self.cap = int(capacity if capacity is not None else backend.cap)
-        # the two factorisations of an update are independent: they run side by side on two streams, each with its own exchange buffers
-        # and -- on more than one rank -- its own process groups (two communicators: collectives of different streams must not share one)
-        # Two RCCL communicators with kernels in flight on different streams of one process can deadlock when the ranks' GPUs schedule them in
-        # different orders, and this schedule has never run on more than one GPU: over nccl with more than one rank the chains run one after
-        # the other unless EQF_TILED_OVERLAP_CHAINS=1 asks for it (one rank, or gloo -- host-blocking collectives --: side by side).
-        import os
-
-        backend_name = grid.dist.get_backend() if (grid.dist is not None and grid.world > 1) else ""
-        env = os.environ.get("EQF_TILED_OVERLAP_CHAINS")
-        self.overlap_chains = (env != "0") if env is not None else not (grid.world > 1 and backend_name == "nccl")
-        self.gE = ProcessGrid(grid.dist, grid.Pr, grid.Pc, grid.device) if grid.world > 1 else grid
-        self.geo = None
-        self.Sll = self.M = self.E = None
-        # landmark bookkeeping (host; identical on every rank): ids in the REFERENCE's order (X.id, VIOFilter.cpp:211-230), the slot of
-        # each, and which slots are taken.  nslots = slots in use = 1 + the highest taken slot (at least 1 once storage exists).
-        self.ids = None
-        self.slot_of = np.zeros(0, dtype=np.int64)
-        self.taken = np.zeros(self.cap, dtype=bool)
-        self.nslots = 0
-        self.churn_stats = dict(removed_old=0, removed_outliers=0, added=0)
-        self._queue, self._mirror_time = [], None  # IMU calls waiting for their burst; the filter's time as the queued calls leave it
-        self.lookahead = True  # factor the next diagonal block on a second stream in the shadow of the trailing update (_chain)
-        self.phase_ms = None  # set to a dict to collect GPU time per phase (bench.py): {"propagate": ms, "prep": ms, "chain_S": ...}
-        self._pending = []
-
-    class _Phase:
-        """torch.cuda event bracket around a phase of a call, summed into TiledFilter.phase_ms when the filter is asked for its timings
-        (no synchronisation inside the loop)."""
-
-        def __init__(self, tf, name):
-            self.tf, self.name = tf, name
-            self.on = tf.phase_ms is not None and getattr(tf.be, "device", None) is not None and tf.be.device.type == "cuda"
-
-        def __enter__(self):
-            if self.on:
-                self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                self.a.record()
-
-        def __exit__(self, *exc):
-            if self.on:
-                self.b.record()
-                self.tf._pending.append((self.name, self.a, self.b))
-
-    def collect_phases(self):
-        if self._pending:
-            torch.cuda.synchronize()
-            for name, a, b in self._pending:
-                self.phase_ms[name] = self.phase_ms.get(name, 0.0) + a.elapsed_time(b)
-            self._pending = []
-        return self.phase_ms
-
-    # ---- storage: allocated ONCE for `cap` slots; the working set is a view of it for the slots in use.  Growing the number of slots
-    # never moves a block: only the globally last block is ragged, so the local position of a slot does not depend on how many follow it.
-    def _alloc(self):
-        g, be, cap = self.g, self.be, self.cap
-        full = BlockCyclic(cap, self.bl, g.Pr, g.Pc, g.pr, g.pc)
-        r16 = lambda x: (x + 15) // 16 * 16
-        self._Sll_buf = be.zeros(max(3 * full.nlr, 1), r16(max(3 * full.nlc, 1)))
-        self._M_buf = be.empty(max(2 * full.nlr, 1), r16(5 * full.nlc + NARROW_S))
-        self._E_buf = be.empty(max(3 * full.nlr, 1), r16(3 * full.nlc + NARROW_E))
-        self.G11 = be.zeros(11, 11)
-        # exchange buffers: a solved block row piece per process column of my row (B operand / contributions to the A operand)
-        bsmax = 3 * min(self.bl, cap)
-        wmax = {c: 5 * full.ncols_of(c) + NARROW_S for c in range(g.Pc)}
-        wmax_e = {c: 3 * full.ncols_of(c) + NARROW_E for c in range(g.Pc)}
-        mine = [c for c in range(g.Pc) if c == g.pc or c % g.Pr == g.pr]
-        self._bufs = {  # per chain: solved block row pieces, the diagonal factor + records (double-buffered), the interleaved row operand
-            "S": dict(buf={c: be.empty(bsmax * wmax[c]) for c in mine},
-                      pack=[be.empty(bsmax * bsmax + ((bsmax + 63) // 64) * HipBackend.DREC) for _ in range(2)], aopA=be.empty(bsmax, max(3 * full.nlr, 1))),
-            "E": dict(buf={c: be.empty(bsmax * wmax_e[c]) for c in mine},
-                      pack=[be.empty(bsmax * bsmax + ((bsmax + 63) // 64) * HipBackend.DREC) for _ in range(2)], aopA=be.empty(bsmax, max(3 * full.nlr, 1))),
-        }
-        self._aopW = be.empty(bsmax, max(3 * full.nlr, 1))
-        # the downdate Sigma_IJ -= sum_k Y_kI^T Y_kJ is ONE product per update (K = m = 2 N: Sll is read and written once instead of once
-        # per block row, and the product's prologue / epilogue are amortised): the solved block rows are kept -- the columns of my
-        # process column (B operand) and of my row blocks (A operand; the same matrix on a symmetric rank)
-        self.symmetric = g.Pr == g.Pc and g.pr == g.pc  # my row blocks ARE my column blocks: the local matrix is symmetric
-        self._Yc_buf = be.empty(2 * cap, max(3 * full.nlc, 1))
-        self._Yr_buf = self._Yc_buf if self.symmetric else be.empty(2 * cap, max(3 * full.nlr, 1))
-        self._accS_buf = be.zeros(NARROW_S, 3 * full.nlc + NARROW_S)
-        self._accE = be.zeros(NARROW_E, NARROW_E)
-
-    def _set_slots(self, n):
-        """the working set for n >= 1 slots in use: geometry (host + device) and the views of the storage"""
-        g, be = self.g, self.be
-        if self.geo is not None and self.geo.N == n:
-            return
-        if self.geo is None:
-            self._alloc()
-        self.geo = geo = BlockCyclic(n, self.bl, g.Pr, g.Pc, g.pr, g.pc)
-        be.set_geometry(geo)
-        self.Sll = self._Sll_buf[: 3 * geo.nlr, : 3 * geo.nlc]
-        self.M = self._M_buf[: 2 * geo.nlr, : 5 * geo.nlc + NARROW_S]
-        self.E = self._E_buf[: 3 * geo.nlr, : 3 * geo.nlc + NARROW_E]
-        self._wmax = {c: 5 * geo.ncols_of(c) + NARROW_S for c in range(g.Pc)}
-        self._wmax_e = {c: 3 * geo.ncols_of(c) + NARROW_E for c in range(g.Pc)}
-        self._Yc = self._Yc_buf[: 2 * n, : 3 * geo.nlc]
-        self._Yr = self._Yc if self.symmetric else self._Yr_buf[: 2 * n, : 3 * geo.nlr]
-        self._accS = self._accS_buf[:, : 3 * geo.nlc + NARROW_S]
-
-    # ---- VIOFilter::processIMUData (VIOFilter.cpp:120-131)
-    # IMU calls are QUEUED (up to HipBackend.BURST_MAX - 1 of them) and leave for the device with the next vision call, getter or full queue as
-    # one burst: every call keeps its own linearisation, but the local blocks of Sigma are read and written once per burst instead of once
-    # per call (eqf_tiled_propagate_burst).  The status a call returns is the reference's control flow (VIOFilter.cpp:120-131, :146-152),
-    # mirrored here: it only depends on the stamps.  burst = False: one launch sequence per call, as before.
-    burst = True
-
-    def processIMUData(self, stamp, omega, accel):
-        if not (self.burst and hasattr(self.be, "propagate_burst")):
-            with self.be.main(), self._Phase(self, "propagate"):
-                return self.be.propagate(stamp, omega, accel, True, self.Sll)
-        if self._mirror_time is None:
-            self._mirror_time = self.be.time()
-        st = 1 if self._mirror_time < 0 else (2 if not (stamp - self._mirror_time > 0) else 0)  # EQF_SKIPPED_BEFORE_FIRST_IMU / _NONPOSITIVE_DT
-        self._mirror_time = float(stamp)
-        self._queue.append((float(stamp), np.array(omega, dtype=np.float64), np.array(accel, dtype=np.float64)))
-        if len(self._queue) >= self.be.BURST_MAX - 1:
-            self._flush()
-        return st
-
-    def _flush(self, vision_stamp=None):
-        """the queued IMU calls (and the vision call's integration) -> the device; returns the status of the vision call's integration"""
-        if not self._queue and vision_stamp is None:
-            return 0
-        recs, self._queue = self._queue, []
-        with self.be.main(), self._Phase(self, "propagate"):
-            status = self.be.propagate_burst(recs, vision_stamp, self.Sll)
-        if vision_stamp is not None and status[-1] == 0:
-            self._mirror_time = float(vision_stamp)
-        return status[-1]
-
-    # ---- VIOFilter::processVisionData (VIOFilter.cpp:232-302)
-    def processVisionData(self, stamp, ids, bearings):
-        with self.be.main():
-            return self._process_vision(stamp, ids, bearings)
-
-    def _process_vision(self, stamp, ids, bearings):
-        ids = np.asarray(ids, dtype=np.int64)
-        y = np.asarray(bearings, dtype=np.float64).reshape(-1, 3)
-        if len(ids) != len(y) or (len(ids) > 1 and not np.all(np.diff(ids) > 0)):
-            raise ValueError("bearings must come with strictly ascending ids (VIOFilter.cpp:239-240)")
-        if self.burst and hasattr(self.be, "propagate_burst"):
-            st = self._flush(stamp)  # the queued IMU calls + :233 integrateUpToTime, one pass over the local blocks
-        else:
-            with self._Phase(self, "propagate"):
-                st = self.be.propagate(stamp, None, None, False, self.Sll)  # :233 integrateUpToTime
-        if st != 0:
-            return st  # :234-236
-        with self._Phase(self, "churn"):
-            y_slots = self._churn(ids, y)  # :242-249
-        if y_slots is None:
-            return 4  # EQF_SKIPPED_NO_BEARINGS, :258-259
-        self._update(y_slots)
-        return 0
-
-    def _churn(self, ids, y):
-        """removeOldLandmarks, removeOutliers, addNewLandmarks (VIOFilter.cpp:242-249, :345-443) on slots.  Returns the bearings in SLOT
-        order (holes carry a dummy the device ignores), or None when no landmark is left to update with."""
-        be = self.be
-        have = self.ids if self.ids is not None else np.zeros(0, dtype=np.int64)
-        pos = np.searchsorted(ids, have)  # ids ascending: where each state id sits in the measurement, if it does
-        pos_c = np.minimum(pos, max(len(ids) - 1, 0))
-        seen = (ids[pos_c] == have) if len(ids) else np.zeros(len(have), dtype=bool)  # removeOldLandmarks :393-419
-        new_k = np.nonzero(~np.isin(ids, have))[0]  # measurement entries without a landmark, ascending ids (:211-230 puts them last)
-        keep = seen.copy()
-        depth = be.initial_scene_depth()
-        thr = be.outlier_threshold()
-        gate = thr < 2.0 and seen.any()  # (no chord of unit vectors is longer than 2: such a threshold switches the gate off, no readback)
-        if gate or (len(new_k) and seen.any()):
-            p = np.asarray(be.state_estimate()["p"], dtype=np.float64).reshape(-1, 3)[self.slot_of]  # reference order
-            if gate:  # removeOutliers :429-443: chord between the measured and the expected bearing
-                yhat = p / np.linalg.norm(p, axis=1, keepdims=True)
-                chord = np.linalg.norm(y[pos_c] - yhat, axis=1)
-                keep &= ~(chord > thr)
-            if len(new_k) and keep.any():  # median scene depth of what is left, :353-366 (nth_element at size / 2)
-                d2 = np.sort(np.sum(p[keep] * p[keep], axis=1))
-                depth = float(np.sqrt(d2[len(d2) // 2]))
-        n_old = int((~seen).sum())
-        n_out = int((seen & ~keep).sum())
-        remove_slots = self.slot_of[~keep]
-        taken = self.taken.copy()
-        taken[remove_slots] = False
-        free = np.nonzero(~taken)[0]
-        if len(new_k) > len(free):
-            raise RuntimeError(f"{int(taken.sum()) + len(new_k)} landmarks in view, the partitioned filter was created for {self.cap}")
-        add_slots = free[: len(new_k)]  # lowest free slots first: holes are refilled before the partition grows
-        taken[add_slots] = True
-        top = np.nonzero(taken)[0]
-        nslots = max(int(top[-1]) + 1 if len(top) else 0, 1)
-        if self.ids is None and len(new_k) == 0:
-            return None  # nothing yet, nothing to add: no storage either
-        if len(remove_slots) or len(add_slots):
-            self._set_slots(max(self.nslots, nslots))
-            be.edit_landmarks(remove_slots, add_slots, y[new_k], depth, nslots, self.Sll)
-            self._set_slots(nslots)
-            self.ids = np.concatenate([have[keep], ids[new_k]])
-            self.slot_of = np.concatenate([self.slot_of[keep], add_slots]).astype(np.int64)
-            self.taken, self.nslots = taken, nslots
-            self.churn_stats["removed_old"] += n_old
-            self.churn_stats["removed_outliers"] += n_out
-            self.churn_stats["added"] += len(new_k)
-        if len(self.ids) == 0:
-            return None
-        # the measurement in slot order: landmarks that stayed, then the new ones (:211-230 matchMeasurementsToState)
-        y_slots = np.zeros((self.nslots, 3))
-        y_slots[:, 2] = 1.0
-        y_slots[self.slot_of] = np.concatenate([y[pos_c[keep]], y[new_k]]) if len(self.ids) else y[:0]
-        return y_slots
-
-    def initialise_from(self, st):
-        """Restart from a single-GPU snapshot (FilterBatch.dump_state(); every rank holds the dense Sigma once, here)."""
-        N = len(st["ids"])
-        with self.be.main():
-            self._initialise_from(st, N)
-
-    def _initialise_from(self, st, N):
-        if N > self.cap:
-            raise RuntimeError(f"snapshot with {N} landmarks, the partitioned filter was created for {self.cap}")
-        self._set_slots(max(N, 1))
-        S = torch.as_tensor(np.asarray(st["sigma"]), dtype=torch.float64)
-        rows = torch.as_tensor(np.repeat(3 * self.geo.rowMap.astype(np.int64), 3) + np.tile(np.arange(3), self.geo.nlr) + 11)
-        cols = torch.as_tensor(np.repeat(3 * self.geo.colMap.astype(np.int64), 3) + np.tile(np.arange(3), self.geo.nlc) + 11)
-        if N and self.geo.nlr and self.geo.nlc:
-            self.Sll.copy_(S[rows][:, cols].to(self.Sll.device))
-        self.be.set_state(st)
-        self.ids = np.asarray(st["ids"], dtype=np.int64)
-        self._queue, self._mirror_time = [], None
-        self.slot_of = np.arange(N, dtype=np.int64)  # the snapshot's order is the reference's: slot i = landmark i
-        self.taken = np.zeros(self.cap, dtype=bool)
-        self.taken[:N] = True
-        self.nslots = N
-
-    # ---- the update
-    def _update(self, y):
-        be, geo = self.be, self.geo
-        with self._Phase(self, "prep"):
-            be.update_prep(y, self.Sll, self.M, self.E, self.G11)  # E and M are formed from the PRE-update Sigma (VIOFilter.cpp:285 before :297)
-        nA = 2 * geo.nlc
-        self._accS.zero_()
-        self._accE.zero_()
-
-        def hook_s(k, bk, Bop, off, contributions):
-            # Bop[:, off:] = [Y_k (3 nlc) | Yn_k (18)] of my process column; the rank's share of the downdate and of the reductions
-            Yw = Bop[:, off: off + 3 * geo.nlc]
-            Yn = Bop[:, off + 3 * geo.nlc: off + 3 * geo.nlc + NARROW_S]
-            r0 = 2 * k * geo.bl
-            self._Yc[r0: r0 + bk].copy_(Yw)
-            if not self.symmetric:
-                YI = self._rows_operand(contributions, 3, lambda c, wc: (wc - 3 * geo.ncols_of(c) - NARROW_S, 0), bk, self._aopW, all_blocks=True)
-                self._Yr[r0: r0 + bk].copy_(YI)
-            be.gemm_tn(self._accS, Yn, Bop[:, off:], 1.0)               # [Sigma_b's downdate ; gamma_L ; .. | Gnn] += Yn_k^T [Y_k | Yn_k]
-
-        def hook_e(k, bk, Bop, off, contributions):
-            En = Bop[:, off: off + NARROW_E]
-            be.gemm_tn(self._accE, En, En, 1.0)
-
-        # the E-chain (bundleLift's weights) needs nothing of the S-chain: it runs on its own stream next to it.  It is bound by its serial
-        # diagonal blocks, the S-chain and the downdate by the matrix cores -- side by side they take little more than the longer one
-        prepared = be.record()
-        e_done = None
-        if self.overlap_chains:
-            # The two chains are enqueued ALTERNATELY, block row by block row: a chain is a few hundred launches, and enqueued one chain
-            # after the other the second stream sat idle until the host was through with the first -- 32 of an update's 84 ms under the
-            # profiler (scripts/queue_summary.py), the update was bound by the HOST's launch rate, not by the GPU.
-            stepsE = self._chain_steps(self.E, 3, 3 * geo.nlc, hook_e, self._wmax_e, self.gE, self._bufs["E"], be.aux_side)
-            stepsS = self._chain_steps(self.M, 2, nA, hook_s, self._wmax, self.g, self._bufs["S"], be.side)
-            phE, phS = self._Phase(self, "chain_E"), self._Phase(self, "chain_S")
-            with be.aux():
-                be.wait(prepared)
-                phE.__enter__()
-            phS.__enter__()
-            doneE = doneS = False
-            while not (doneE and doneS):
-                if not doneE:
-                    with be.aux():
-                        doneE = next(stepsE, None) is None
-                if not doneS:
-                    doneS = next(stepsS, None) is None
-            with be.aux():
-                phE.__exit__(None, None, None)
-                e_done = be.record()
-            phS.__exit__(None, None, None)
-        else:
-            with self._Phase(self, "chain_S"):
-                self._chain(self.M, 2, nA, hook_s, self._wmax, self.g, self._bufs["S"], be.side)
-        with self._Phase(self, "downdate"):
-            # Sigma_IJ -= Y_I^T Y_J (VIOFilter.cpp:297), one product; on a symmetric rank only the blocks on and above the block
-            # diagonal are computed and the rest is mirrored
-            if geo.nlr and geo.nlc:
-                w3 = 3 * geo.bl
-                if self.symmetric:
-                    be.gemm_tn(self.Sll, self._Yr, self._Yc, -1.0, mask=(w3, w3, 0, 1, 0, 0, 1, 0))
-                    be.mirror_lower(self.Sll, w3)
-                else:
-                    be.gemm_tn(self.Sll, self._Yr, self._Yc, -1.0)
-        if self.overlap_chains:
-            be.wait(e_done)
-        else:
-            with self._Phase(self, "chain_E"):
-                self._chain(self.E, 3, 3 * geo.nlc, hook_e, self._wmax_e, self.g, self._bufs["E"], be.side)
-        with self._Phase(self, "finish"):
-            # gamma_L and the base panel's downdate live with the process COLUMNS: gather them along the process row, global landmark order
-            acc = self._gather_columns(self._accS[:, : 3 * geo.nlc])
-            Gnn = self._accS[:, 3 * geo.nlc:].contiguous()
-            G11 = (self.G11 + self._accE).contiguous()
-            be.update_finish(acc, Gnn, G11)
-        self._frames_since_check = getattr(self, "_frames_since_check", 0) + 1
-        if self.check_every and self._frames_since_check >= self.check_every:
-            self.check()
-
-    check_every = 1  # frames between two looks at the factorisations' pivot flag (a look synchronises the stream)
-
-    def check(self):
-        """Raises if a pivot of S or Sigma_e was not positive since the last look (synchronises)."""
-        self._frames_since_check = 0
-        if self.be.factor_info():
-            raise ArithmeticError("a pivot of S or Sigma_e was not positive (distributed factorisation)")
-
-    def _gather_columns(self, mine):
-        g, geo = self.g, self.geo
-        rows = mine.shape[0]
-        wmax = 3 * max(geo.ncols_of(c) for c in range(g.Pc))
-        pad = self.be.zeros(rows, wmax)
-        pad[:, : mine.shape[1]] = mine
-        parts = g.allgather_row(pad)
-        out = self.be.empty(rows, 3 * geo.N)
-        for c, part in enumerate(parts):
-            o = 0
-            for b in range(c, geo.nb, g.Pc):
-                w = 3 * geo.block_size(b)
-                out[:, 3 * b * geo.bl: 3 * b * geo.bl + w] = part[:, o: o + w]
-                o += w
-        return out
-
-    def _rows_operand(self, contributions, unit, part_of, bk, buf, all_blocks, k=None):
-        """The A operand of the products of block row k: for each of MY local row blocks (all of them, or the trailing ones i > k) the
-        (bk x unit * size) block of the solved block row -- found in the piece of the process column c = i mod Pc, which the rank (pr, c)
-        re-broadcast along the process row.  contributions: {c: (piece (bk x w_c), jl0_c)}; part_of(c, w_c) -> (column offset of the part
-        inside the piece, 1 if the part starts at local block jl0_c else 0)."""
-        g, geo = self.g, self.geo
-        q = g.Pc // g.Pr
-        bsF = unit * geo.bl
-        il0 = 0 if all_blocks else BlockCyclic.blocks_upto(k, g.pr, g.Pr)
-        ncol = unit * geo.nlr - il0 * bsF
-        if ncol <= 0:
-            return None
-        if q == 1:
-            # one contributor, c = pr: its local column blocks ARE my local row blocks, in order -> a view, no copy
-            piece, jl0 = contributions[g.pr]
-            off, trailing = part_of(g.pr, piece.shape[1])
-            start = off + ((il0 - jl0) * bsF if trailing else il0 * bsF)
-            return piece[:, start: start + ncol]
-        out = buf[:bk, : unit * geo.nlr]
-        for s in range(q):
-            c = g.pr + g.Pr * s
-            piece, jl0 = contributions[c]
-            off, trailing = part_of(c, piece.shape[1])
-            # my local row block ilb = s + t q  <->  local column block t of process column c
-            for ilb in range(s, len(geo.row_blocks), q):
-                if ilb < il0:
-                    continue
-                t = (ilb - s) // q
-                w = unit * geo.block_size(geo.row_blocks[ilb])
-                src = off + ((t - jl0) if trailing else t) * bsF
-                out[:, ilb * bsF: ilb * bsF + w] = piece[:, src: src + w]
-        return out[:, il0 * bsF:]
-
-    def _chain(self, X, unit, nA, hook, wmax, g, bufs, side):
-        """all block rows of _chain_steps, one after the other"""
-        for _ in self._chain_steps(X, unit, nA, hook, wmax, g, bufs, side):
-            pass
-
-    def _chain_steps(self, X, unit, nA, hook, wmax, g, bufs, side):
-        """(a generator: one block row per step, so that the caller can feed two factorisations to their streams alternately)
-        Blocked right-looking Cholesky by block ROWS of the SPD matrix in X[:, :nA] (upper blocks, block size unit * bl, block-cyclic
-        over the grid) with the right-hand sides X[:, nA:]; X is consumed.  hook(k, bk, Bop, off, contributions) runs on every rank once
-        block row k is solved: Bop[:, off:] holds the right-hand-side part of my process column.
-        Look-ahead: the diagonal block is the serial part (one workgroup, eqf_tile_potrf).  As soon as block row k is solved, the owner of
-        block (k+1, k+1) applies row k to a COPY of that block and factors the copy on a second stream, in the shadow of the trailing
-        update of step k; step k+1 then starts from the finished factor."""
-        geo, be = self.geo, self.be
-        bsF = unit * geo.bl
-        W = X.shape[1]
-        ahead = None  # event: the look-ahead factor of the current block is in bufs["pack"][k & 1]
-        for k in range(geo.nb):
-            prk, pck = k % g.Pr, k % g.Pc
-            bk = unit * geo.block_size(k)
-            klr, klc = k // g.Pr, k // g.Pc
-            jl0 = BlockCyclic.blocks_upto(k, g.pc, g.Pc)
-            c0 = min(jl0 * bsF, nA)
-            width = W - c0
-            Bop = bufs["buf"][g.pc][: bk * width].view(bk, width)
-            if g.pr == prk:
-                # 1. the diagonal block, L_kk and its records along the process row
-                nrec = ((bk + 63) // 64) * HipBackend.DREC
-                pack = bufs["pack"][k & 1][: bk * bk + nrec]
-                Lkk, drec = pack[: bk * bk].view(bk, bk), pack[bk * bk:]
-                if g.pc == pck:
-                    if ahead is not None:
-                        be.wait(ahead)
-                        ahead = None
-                    else:
-                        Lkk.copy_(X[klr * bsF: klr * bsF + bk, klc * bsF: klc * bsF + bk])
-                        be.potrf(Lkk, drec)
-                g.bcast_row(pack, pck)
-                # 2. my piece of block row k
-                R = X[klr * bsF: klr * bsF + bk, c0:]
-                be.trsm_left(Lkk, drec, R)
-                Bop.copy_(R)
-            # 3. down the process column
-            g.bcast_col(Bop, prk)
-            # 4. along the process row, from the ranks whose column blocks are this process row's row blocks
-            contributions = {}
-            for c in range(g.pr, g.Pc, g.Pr):
-                jl0c = BlockCyclic.blocks_upto(k, c, g.Pc)
-                wc = wmax[c] - min(jl0c * bsF, unit * geo.ncols_of(c))
-                piece = Bop if c == g.pc else bufs["buf"][c][: bk * wc].view(bk, wc)
-                g.bcast_row(piece, c)
-                contributions[c] = (piece, jl0c)
-            # 5. trailing updates of what this rank owns: rows of blocks i > k, columns from block jl0 on
-            il0 = BlockCyclic.blocks_upto(k, g.pr, g.Pr)
-            if il0 * bsF < X.shape[0]:
-                Ua = self._rows_operand(contributions, unit, lambda c, wc: (0, 1), bk, bufs["aopA"], all_blocks=False, k=k)
-                if self.lookahead and k + 1 < geo.nb and g.pr == (k + 1) % g.Pr and g.pc == (k + 1) % g.Pc:
-                    # look-ahead: block (k+1, k+1) is the first trailing block of my rows and of my columns
-                    b1 = unit * geo.block_size(k + 1)
-                    nrec1 = ((b1 + 63) // 64) * HipBackend.DREC
-                    pack1 = bufs["pack"][(k + 1) & 1][: b1 * b1 + nrec1]
-                    L1, drec1 = pack1[: b1 * b1].view(b1, b1), pack1[b1 * b1:]
-                    L1.copy_(X[il0 * bsF: il0 * bsF + b1, c0: c0 + b1])
-                    ready = be.record()
-                    with side():
-                        be.wait(ready)
-                        be.gemm_tn(L1, Ua[:, :b1], Bop[:, :b1], -1.0)
-                        be.potrf(L1, drec1)
-                        ahead = be.record()
-                Ct = X[il0 * bsF:, c0:]
-                if nA - c0 > 0:
-                    be.gemm_tn(Ct[:, : nA - c0], Ua, Bop[:, : nA - c0], -1.0, mask=(bsF, bsF, il0, g.Pr, g.pr, jl0, g.Pc, g.pc))
-                be.gemm_tn(Ct[:, nA - c0:], Ua, Bop[:, nA - c0:], -1.0)
-            hook(k, bk, Bop, nA - c0, contributions)
-            yield k
-
-    # ---- getters
-    def getTime(self):
-        self._flush()
-        return self.be.time()
-
-    def _coords(self, unit, base):
-        """coordinates of the landmarks, reference order, in a slot-ordered vector with `unit` entries per slot after `base` leading ones"""
-        return (base + unit * np.repeat(self.slot_of, unit) + np.tile(np.arange(unit), len(self.slot_of))).astype(np.int64)
-
-    def stateEstimate(self):
-        """VIOFilter::stateEstimate (:304): landmarks in the reference's order"""
-        self._flush()
-        e = dict(self.be.state_estimate())
-        e["p"] = np.asarray(e["p"]).reshape(-1, 3)[self.slot_of]
-        e["ids"] = self.ids.copy() if self.ids is not None else np.zeros(0, dtype=np.int64)
-        return e
-
-    def bias(self):
-        self._flush()
-        return self.be.bias()
-
-    def lastUpdate(self):
-        """delta (2 N), gamma (11 + 3 N), Gamma (9 + 3 N) of the last update, landmarks in the reference's order"""
-        lu = self.be.last_update()
-        out = {"delta": np.asarray(lu["delta"])[self._coords(2, 0)]}
-        out["gamma"] = np.concatenate([np.asarray(lu["gamma"])[:11], np.asarray(lu["gamma"])[self._coords(3, 11)]])
-        G = lu.get("Gamma")
-        out["Gamma"] = None if G is None else np.concatenate([np.asarray(G)[:9], np.asarray(G)[self._coords(3, 9)]])
-        return out
-
-    def stateCovariance(self):
-        """Dense Sigma (reference index map and landmark order) gathered to every rank -- tests and snapshots
-        (VIOFilter::stateCovariance, :306-309)."""
-        self._flush()
-        with self.be.main():
-            S = self._state_covariance()
-        idx = np.concatenate([np.arange(11), self._coords(3, 11)])
-        return S[np.ix_(idx, idx)]
-
-    def slotCovariance(self):
-        """Dense Sigma over ALL slots in use, holes included (slot order) -- tests of the hole invariants."""
-        self._flush()
-        with self.be.main():
-            return self._state_covariance()
-
-    def _state_covariance(self):
-        g, geo = self.g, self.geo
-        N = geo.N
-        n = 11 + 3 * N
-        S = np.zeros((n, n))
-        base = np.asarray(self.be.base_rows())[:, :n]
-        S[:, :11] = base.T  # (only the base ROWS are kept: the columns are their transpose)
-        S[:11, :] = base
-        rmax = 3 * max(len(BlockCyclic(N, self.bl, g.Pr, g.Pc, r, 0).rowMap) for r in range(g.Pr))
-        cmax = 3 * max(geo.ncols_of(c) for c in range(g.Pc))
-        pad = self.be.zeros(rmax, cmax)
-        pad[: 3 * geo.nlr, : 3 * geo.nlc] = self.Sll
-        for rank, part in enumerate(g.allgather_all(pad)):
-            r, c = divmod(rank, g.Pc)
-            og = BlockCyclic(N, self.bl, g.Pr, g.Pc, r, c)
-            rows = (np.repeat(3 * og.rowMap.astype(np.int64), 3) + np.tile(np.arange(3), og.nlr)) + 11
-            cols = (np.repeat(3 * og.colMap.astype(np.int64), 3) + np.tile(np.arange(3), og.nlc)) + 11
-            S[np.ix_(rows, cols)] = part[: 3 * og.nlr, : 3 * og.nlc].cpu().numpy()
-        return S
+        self._check(self.lib.eqf_tf_set_state(self._h, N, ids.ctypes.data_as(C.POINTER(C.c_int)), *[binding._p(a) for a in arrs], S.shape[1],
+                                              float(st["time"]), binding._p(cv), binding._p(av), float(st["accumulatedTime"]), int(st["initialised"])),
+                    "eqf_tf_set_state")

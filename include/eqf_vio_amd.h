@@ -16,6 +16,8 @@
 #ifndef EQF_VIO_AMD_H
 #define EQF_VIO_AMD_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -289,6 +291,61 @@ int eqf_tiled_set_state(eqf_tiled* t, int N, const double* pose_q, const double*
     const double* A_q, const double* A_x, const double* w, const double* Q_q, const double* Q_a, const double* bias6,
     const double* sigma_base, int ld, double currentTime, const double* currentVelocity6, const double* accumulatedVelocity6,
     double accumulatedTime, int initialised);
+
+/* ================================================================================================================================
+ * The HOST LOOP of the partitioned filter behind the C ABI (csrc/eqf_tiledf.hip; round 5 -- until then it was Python): one eqf_tf per
+ * rank of a Pr x Pc process grid (Pr | Pc; rank = pr * Pc + pc) IS VIOFilter (VIOFilter.h:41-88) for one filter whose Sigma is
+ * partitioned over the grid.  Every rank makes the same calls with the same arguments.  The handle owns its eqf_tiled, its local matrix,
+ * every exchange buffer and four HIP streams (two pairs with disjoint CU sets: reserve_cus CUs for the look-ahead factorisations, < 0 =
+ * default 8 / EQF_TILED_RESERVE_CUS, 0 = plain streams).  What the ranks exchange goes through ONE callback:
+ *   bcast(ctx, group, chain, root, buf, bytes, stream): broadcast `bytes` bytes of DEVICE memory at `buf` from `root` to the other members
+ *   of `group` -- 0: my process row (root = process COLUMN of the sender), 1: my process column (root = process ROW), 2: every rank (root =
+ *   rank) -- ordered on the HIP stream `stream` (the transfer may start when the stream reaches it; later work on the stream sees the data).
+ *   chain = 0 / 1: the two factorisations of an update run side by side on different streams -- a collective library that cannot have two
+ *   operations of one communicator in flight gets one communicator per chain.  Returns 0 on success.  With RCCL: ncclBroadcast(buf, buf,
+ *   bytes, ncclChar, root, rowComm / colComm / worldComm [chain], stream).  A 1 x 1 grid needs no callback (comm = NULL).
+ * eqf_tf_process_imu / eqf_tf_process_vision return EQF_OK, the EQF_SKIPPED_* code of the reference's silent early-outs, or an error
+ * (EQF_ERR_UNSORTED: ids not strictly ascending, VIOFilter.cpp:239-240; EQF_ERR_CAPACITY; EQF_ERR_NUMERIC: a pivot of S or Sigma_e not
+ * positive, looked at every check_every-th update).  Getters answer in the REFERENCE's landmark order (insertion order, :211-230); the
+ * landmark slots behind it (eqf_tiled, above) are internal.  eqf_tf_get_sigma is collective (every rank calls it).
+ * Options (eqf_tf_set_option): "lookahead" (1), "overlap_chains" (1; EQF_TILED_OVERLAP_CHAINS), "burst" (1: IMU calls queued and sent as
+ * bursts), "check_every" (1), "profiling" (0: event brackets per phase, eqf_tf_get_phases).
+ * ================================================================================================================================ */
+typedef struct eqf_tf eqf_tf; /* opaque */
+typedef struct eqf_tf_comm {
+    void* ctx;
+    int (*bcast)(void* ctx, int group, int chain, int root, void* buf, size_t bytes, void* stream);
+} eqf_tf_comm;
+int eqf_tf_create(const eqf_settings* settings, int capacity_landmarks, int block_landmarks, int Pr, int Pc, int rank, int device,
+    int reserve_cus, const eqf_tf_comm* comm, eqf_tf** out);
+void eqf_tf_destroy(eqf_tf* f);
+int eqf_tf_set_option(eqf_tf* f, const char* name, int value);
+/* VIOFilter::processIMUData (VIOFilter.cpp:120-131) / processVisionData (:232-302; ids[n] strictly ascending, bearings[n][3], host) */
+int eqf_tf_process_imu(eqf_tf* f, double stamp, const double* omega, const double* accel);
+int eqf_tf_process_vision(eqf_tf* f, double stamp, int n, const int* ids, const double* bearings);
+int eqf_tf_synchronize(eqf_tf* f);
+int eqf_tf_check(eqf_tf* f);        /* EQF_ERR_NUMERIC if a pivot was not positive since the last look (synchronises) */
+int eqf_tf_device_error(eqf_tf* f); /* as eqf_device_error */
+int eqf_tf_num_landmarks(eqf_tf* f);
+int eqf_tf_num_slots(eqf_tf* f);
+int eqf_tf_get_ids(eqf_tf* f, int* ids, int* slots); /* reference order; slots may be NULL */
+int eqf_tf_get_time(eqf_tf* f, double* time);
+int eqf_tf_get_state_estimate(eqf_tf* f, double* pose_q, double* pose_x, double* velocity, double* p);
+int eqf_tf_get_bias(eqf_tf* f, double* bias6);
+int eqf_tf_get_last_update(eqf_tf* f, double* delta, double* gamma, double* Gamma);
+/* VIOFilter::stateCovariance (:306-309): dst (n x n, ld), n = 11 + 3 N in the reference's order (slot_order = 0) or 11 + 3 * slots over
+ * all slots in use, holes included (slot_order = 1: tests of the hole invariants).  Host memory. */
+int eqf_tf_get_sigma(eqf_tf* f, double* dst, int ld, int slot_order);
+/* restart from a snapshot, as eqf_set_state (sigma: the DENSE covariance, every rank holds it once) */
+int eqf_tf_set_state(eqf_tf* f, int N, const int* ids, const double* pose_q, const double* pose_x, const double* velocity, const double* p0,
+    const double* A_q, const double* A_x, const double* w, const double* Q_q, const double* Q_a, const double* bias6, const double* sigma, int ld,
+    double currentTime, const double* currentVelocity6, const double* accumulatedVelocity6, double accumulatedTime, int initialised);
+int eqf_tf_get_churn_stats(eqf_tf* f, long long* stats3); /* removed_old, removed_outliers, added */
+int eqf_tf_local_matrix(eqf_tf* f, double** ptr, int* rows, int* cols, int* ld);
+int eqf_tf_get_phases(eqf_tf* f, double* ms7);
+const char* eqf_tf_phase_name(int i);
+const char* eqf_tf_last_error(eqf_tf* f);
+void* eqf_tf_tiled_handle(eqf_tf* f); /* the rank's eqf_tiled (getters of the replicated state in SLOT order, tests) */
 
 /* ---- Dense tile kernels of the distributed factorisations, on CALLER-OWNED device memory of HIP device `device`, enqueued on
  * `stream` (a hipStream_t, NULL = the default stream) without synchronising; the caller's current device is restored.

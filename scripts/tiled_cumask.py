@@ -24,6 +24,8 @@ def worker(rank, world, port, Pr, Pc, N, bl, frames, out_dir):
     import torch
     import torch.distributed as dist
 
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+    import tiled_reference as tiled_ref  # (the Python twin of the host loop: it takes a CU slice per rank, HipBackend's cu_range)
     from eqf_vio_amd import synth, tiled
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -36,7 +38,7 @@ def worker(rank, world, port, Pr, Pc, N, bl, frames, out_dir):
     cus = 256 // world
     d = synth.template_settings_dict()
     be = tiled.HipBackend(d, capacity=N, device_index=0, reserve_cus=8 if world == 1 else 4, cu_range=None if world == 1 else (rank * cus, cus))
-    grid = tiled.ProcessGrid(dist_, Pr, Pc, device=be.device)
+    grid = tiled_ref.ProcessGrid(dist_, Pr, Pc, device=be.device)
     # time inside the grid's collectives (host wall clock around a synchronised call: the schedule is perturbed a little, the split is honest)
     coll = {"wait": 0.0, "xfer": 0.0, "n": 0, "bytes": 0}
 
@@ -62,7 +64,7 @@ def worker(rank, world, port, Pr, Pc, N, bl, frames, out_dir):
     if world > 1 and os.environ.get("CUMASK_MODE", "split") == "split":
         grid.bcast_row = timed(grid.bcast_row, lambda: grid.row_group)
         grid.bcast_col = timed(grid.bcast_col, lambda: grid.col_group)
-    tf = tiled.TiledFilter(grid, be, bl)
+    tf = tiled_ref.TiledFilter(grid, be, bl)
     tf.overlap_chains = world == 1  # (two chains' collectives from two streams over gloo: serialised anyway)
     st = synth.make_stream(N, seed=1234, duration=(frames + 2) / 20.0 + 0.011)
     ev = list(st.events())

@@ -297,22 +297,17 @@ def test_tiled_filter_N4000_against_the_single_gpu_product_path():
             stamp = st.vision_stamps[k]
             fg.process_vision([stamp], st.ids, st.bearings[k])
             n_upd += 1
+            assert tf.processVisionData(stamp, st.ids, st.bearings[k]) == 0
             if n_upd == 1:
-                assert tf.processVisionData(stamp, st.ids, st.bearings[k]) == 0
                 prior_tr = 11.0 + 3 * N * d["initialPointVariance"]  # (an upper bound of the prior's trace: the new landmarks' variance)
-            else:
-                # the two halves of processVisionData by hand, to see the prior: integrateUpToTime (VIOFilter.cpp:233), then the update
-                tf._flush()  # (the queued IMU calls first: this test drives the backend by hand)
-                assert be.propagate(stamp, None, None, False, tf.Sll) == 0
-                prior_tr = float(np.trace(tf.stateCovariance()))
-                tf._update(np.asarray(st.bearings[k], dtype=np.float64))
             St, Sg = tf.stateCovariance(), fg.sigma()
             assert rel(St, Sg) <= 1e-9, (k, rel(St, Sg))
             # ... and against the committed vectors of the structured fp64 oracle for exactly this stream (tests/golden/large_N4000.npz)
             assert np.array_equal(st.bearings[k], gold["bearings"][n_upd - 1]) and st.vision_stamps[k] == gold["vision_stamps"][n_upd - 1]
             check_large_golden(gold, n_upd - 1, tf.stateEstimate(), be.bias(), St, be.last_update(), what="partitioned N=4000")
             assert np.abs(St - St.T).max() <= 1e-9 * np.abs(St).max()
-            assert float(np.trace(St)) < prior_tr  # Sigma - K C Sigma takes a positive semi-definite matrix away
+            assert float(np.trace(St)) < prior_tr  # Sigma - K C Sigma takes a positive semi-definite matrix away (the ten Riccati steps in
+            prior_tr = float(np.trace(St))          # between add 3 N * 0.05 s * pointProcessVariance: nothing next to what an update removes)
             if n_upd == 2:
                 Sd = torch.from_numpy(St).to(be.device)
                 torch.linalg.cholesky(Sd)  # raises if Sigma is not positive definite
@@ -467,11 +462,12 @@ def test_tiled_edit_landmarks_argument_errors_come_before_any_effect():
 
     import torch
 
+    import tiled_reference as tref  # (the Python twin of the host loop: this test drives the per-rank entry points by hand)
     from eqf_vio_amd import binding, synth, tiled
 
     d = synth.template_settings_dict()
     be = tiled.HipBackend(d, capacity=12)
-    tf = tiled.TiledFilter(tiled.ProcessGrid(None, 1, 1, device=be.device), be, 4)
+    tf = tref.TiledFilter(tref.ProcessGrid(None, 1, 1, device=be.device), be, 4)
     st = synth.make_stream(8, duration=0.06)
     for kind, k in st.events():
         if kind == "imu":
@@ -704,3 +700,48 @@ def test_tiled_imu_bursts_equal_the_single_calls_bitwise(oracle_lib, N, bl, imu_
         tf.processIMUData(r[0] + 0.001, r[1:4], r[4:7])
     assert np.array_equal(tfs[0].stateCovariance(), tfs[1].stateCovariance()) and tfs[0].getTime() == tfs[1].getTime() == r[0] + 0.001
     assert tfs[0].be.device_error() == 0 and tfs[1].be.device_error() == 0
+
+
+@pytest.mark.parametrize("N,bl,cap", [(50, 16, 60), (200, 64, 200), (37, 8, 48)])
+def test_cpp_host_loop_equals_the_python_reference_bitwise(oracle_lib, N, bl, cap):
+    """Round 5: the partitioned filter's host loop is C++ behind the C ABI (csrc/eqf_tiledf.hip, eqf_tf_*).  It was written after the Python
+    loop of rounds 3-4, which stays as tests/tiled_reference.py: the same kernels in the same order on the same operands.  On a stream with
+    landmarks entering, leaving and failing the gate the two must agree BIT FOR BIT after every frame -- covariance, state, bias, the update's
+    internals, the landmark order and the slots behind it -- and the C++ loop's statuses must be the reference's."""
+    import tiled_reference as tref
+    from eqf_vio_amd import synth, tiled
+
+    d = synth.template_settings_dict()
+    d["outlierThreshold"] = 0.01
+    st = synth.make_stream(N, duration=0.41)
+    meas = synth.churn_measurements(st, seed=9, outlier_frames=(2, 5), outlier_angle=0.05)
+    bp = tiled.HipBackend(d, capacity=cap)
+    tp = tiled.TiledFilter(tiled.ProcessGrid(None, 1, 1, device=bp.device), bp, bl)
+    br = tiled.HipBackend(d, capacity=cap)
+    tr = tref.TiledFilter(tref.ProcessGrid(None, 1, 1, device=br.device), br, bl)
+    fo = oracle_lib.OracleFilter(d)
+    n_upd = 0
+    for kind, k in st.events():
+        if kind == "imu":
+            r = st.imu[k]
+            fo.processIMUData(r[0], r[1:4], r[4:7])
+            assert tp.processIMUData(r[0], r[1:4], r[4:7]) == tr.processIMUData(r[0], r[1:4], r[4:7])
+        else:
+            ids, y = meas[k]
+            fo.processVisionData(st.vision_stamps[k], ids, y)
+            assert tp.processVisionData(st.vision_stamps[k], ids, y) == tr.processVisionData(st.vision_stamps[k], ids, y) == 0
+            n_upd += 1
+            assert np.array_equal(tp.ids, tr.ids) and np.array_equal(tp.slot_of, tr.slot_of) and tp.nslots == tr.nslots
+            assert np.array_equal(tp.ids, fo.ids())
+            Sp, Sr = tp.stateCovariance(), tr.stateCovariance()
+            assert np.array_equal(Sp, Sr), (n_upd, float(np.abs(Sp - Sr).max()))
+            assert np.array_equal(tp.slotCovariance(), tr.slotCovariance())
+            ep, er = tp.stateEstimate(), tr.stateEstimate()
+            assert all(np.array_equal(ep[key], er[key]) for key in ("q", "x", "v", "p")) and np.array_equal(tp.bias(), tr.bias())
+            lp, lr = tp.lastUpdate(), tr.lastUpdate()
+            assert all(np.array_equal(lp[key], lr[key]) for key in ("delta", "gamma", "Gamma"))
+            So = fo.stateCovariance()
+            assert np.linalg.norm(Sp - So) / np.linalg.norm(So) <= 1e-9
+    assert n_upd >= 7 and tp.churn_stats == tr.churn_stats and tp.churn_stats["removed_outliers"] > 0
+    assert tp.device_error() == 0 and br.device_error() == 0
+    assert tp.getTime() == tr.getTime()

@@ -1,4 +1,4 @@
-"""BASELINE configs[4] / SURVEY.md 8(e) row 2 on CPU: the exchange schedule of eqf_vio_amd/tiled.py -- block-cyclic local matrices, the
+"""BASELINE configs[4] / SURVEY.md 8(e) row 2 on CPU: the exchange schedule of the partitioned filter as tests/tiled_reference.py spells it out (the product's loop is its C++ twin, csrc/eqf_tiledf.hip, compared with it bit for bit on the GPU) -- block-cyclic local matrices, the
 two distributed factorisations with their row / column-restricted broadcasts, the downdate and the reductions -- CLOSED LOOP over gloo on
 1 x 1, 1 x 2, 2 x 2 and 2 x 4 process grids (the grid of one 8-GPU node), whole and ragged landmark blocks.  Every rank runs
 TiledFilter.processIMUData / processVisionData; gamma, the innovation lift and the state come out of the distributed quantities (nothing
@@ -29,7 +29,8 @@ def _worker(rank, world, port, Pr, Pc, N, bl, out_dir):
     import torch
     import torch.distributed as dist
 
-    from eqf_vio_amd import synth, tiled
+    import tiled_reference as tiled
+    from eqf_vio_amd import synth
     from oracle import binding as ob
     from tiled_double import NumpyBackend
 
@@ -91,7 +92,7 @@ def test_tiled_filter_closed_loop_over_a_process_grid_matches_the_single_process
 
 
 def test_block_cyclic_geometry():
-    from eqf_vio_amd.tiled import BlockCyclic
+    from tiled_reference import BlockCyclic
 
     N, bl, Pr, Pc = 34, 4, 2, 4
     seen = np.zeros((N, N), dtype=int)
@@ -113,7 +114,8 @@ def _churn_worker(rank, world, port, Pr, Pc, N, bl, cap, out_dir):
     import torch
     import torch.distributed as dist
 
-    from eqf_vio_amd import synth, tiled
+    import tiled_reference as tiled
+    from eqf_vio_amd import synth
     from oracle import binding as ob
     from tiled_double import NumpyBackend
 
@@ -194,7 +196,8 @@ def test_tiled_filter_churn_argument_and_capacity_errors():
     reports EQF_SKIPPED_NO_BEARINGS like the reference (VIOFilter.cpp:242, :258-259)."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from eqf_vio_amd import synth, tiled
+    import tiled_reference as tiled
+    from eqf_vio_amd import synth
     from oracle import binding as ob
     from tiled_double import NumpyBackend
 
