@@ -62,14 +62,14 @@ EXPORTED_SYMBOLS = [
     "eqf_set_sigma", "eqf_set_state", "eqf_set_camera_offset", "eqf_get_integrator", "eqf_get_last_update", "eqf_debug_get_blocks", "eqf_device_error", "eqf_debug_drop_role", "eqf_set_dense_propagate", "eqf_set_imu_burst", "eqf_profile_enable",
     "eqf_profile_get", "eqf_profile_class_name", "eqf_version", "eqf_build_info", "eqf_tile_propagate", "eqf_tile_downdate", "eqf_tile_potrf", "eqf_tile_trsm", "eqf_tile_gemm_tn", "eqf_tile_mirror", "eqf_stream_create_masked", "eqf_stream_destroy",
     "eqf_tiled_create", "eqf_tiled_destroy", "eqf_tiled_set_stream", "eqf_tiled_set_geometry", "eqf_tiled_propagate", "eqf_tiled_add_landmarks",
-    "eqf_tiled_edit_landmarks", "eqf_tiled_propagate_burst",
+    "eqf_tiled_edit_landmarks", "eqf_tiled_propagate_burst", "eqf_tiled_stage_bearings", "eqf_tiled_pingpong",
     "eqf_tiled_update_prep", "eqf_tiled_update_finish", "eqf_tiled_synchronize", "eqf_tiled_num_landmarks", "eqf_tiled_get_time",
     "eqf_tiled_device_error", "eqf_tiled_get_state_estimate", "eqf_tiled_get_origin", "eqf_tiled_get_group", "eqf_tiled_get_bias",
     "eqf_tiled_get_last_update", "eqf_tiled_get_integrator", "eqf_tiled_get_base", "eqf_tiled_set_state",
     "eqf_tf_create", "eqf_tf_destroy", "eqf_tf_set_option", "eqf_tf_process_imu", "eqf_tf_process_vision", "eqf_tf_synchronize", "eqf_tf_check",
     "eqf_tf_device_error", "eqf_tf_num_landmarks", "eqf_tf_num_slots", "eqf_tf_get_ids", "eqf_tf_get_time", "eqf_tf_get_state_estimate",
     "eqf_tf_get_bias", "eqf_tf_get_last_update", "eqf_tf_get_sigma", "eqf_tf_set_state", "eqf_tf_get_churn_stats", "eqf_tf_local_matrix",
-    "eqf_tf_get_phases", "eqf_tf_phase_name", "eqf_tf_last_error", "eqf_tf_tiled_handle",
+    "eqf_tf_get_phases", "eqf_tf_phase_name", "eqf_tf_last_error", "eqf_tf_tiled_handle", "eqf_tf_graph_launches",
 ]
 
 

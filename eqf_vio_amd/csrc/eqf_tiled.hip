@@ -86,6 +86,10 @@ struct eqf_tiled {
     // IMU bursts (eqf_tiled_propagate_burst): one record set, one base panel and one step-constant block per step of a burst, allocated at
     // the first burst
     double *histBlk = nullptr, *histBlkT = nullptr, *histSb = nullptr;
+    // pinned staging of a frame's bearings (eqf_tiled_update_prep): the caller's array is copied before the call returns, the upload is
+    // asynchronous -- an update is enqueued without waiting for the previous one
+    double* hBear = nullptr;
+    hipEvent_t evBear = nullptr;
     CommonLds* histCommon = nullptr;
     // host mirror of the control flow (VIOFilter.cpp:120-131, :146-152, :234-236)
     double curTime = -1.0;
@@ -104,6 +108,8 @@ void freeTiled(eqf_tiled* t) {
              (void*)t->Lgi, (void*)t->gamma, (void*)t->gammaTot, (void*)t->dBear, (void*)t->dOut, (void*)t->errflag, (void*)t->rowMap, (void*)t->colMap, (void*)t->active, (void*)t->mark, (void*)t->histBlk, (void*)t->histBlkT, (void*)t->histSb,
              (void*)t->histCommon})
         hipFree(p);
+    if (t->hBear) hipHostFree(t->hBear);
+    if (t->evBear) hipEventDestroy(t->evBear);
     delete t;
 }
 // camera-offset constants, same formulas as on the device (and as eqf_create)
@@ -449,14 +455,38 @@ int eqf_tiled_edit_landmarks(eqf_tiled* t, int n_remove, const int* remove_slots
     return EQF_OK;
 }
 
+// The host half of eqf_tiled_update_prep on its own: the frame's bearings (slot order) into the handle's pinned staging buffer.  A caller that
+// replays a captured hipGraph of the update stages the bearings, then launches the graph (eqf_tiled_update_prep with bearings = NULL inside
+// the capture: "already staged").
+int eqf_tiled_stage_bearings(eqf_tiled* t, const double* bearings) {
+    if (!t || !bearings || t->N < 1) return EQF_ERR_INVALID;
+    DeviceScope ds(t->device);
+    if (!ds.ok) return EQF_ERR_HIP;
+    if (!t->hBear) {
+        HIPC(hipHostMalloc(reinterpret_cast<void**>(&t->hBear), sizeof(double) * 3 * t->cap, hipHostMallocDefault));
+        HIPC(hipEventCreateWithFlags(&t->evBear, hipEventDisableTiming));
+    }
+    HIPC(hipEventSynchronize(t->evBear));  // (the previous frame's upload has left the staging buffer: it did long ago)
+    std::memcpy(t->hBear, bearings, sizeof(double) * 3 * t->N);
+    return EQF_OK;
+}
+// bit 0: which of the two scalar-state / landmark buffers is current, bit 1: which base panel (they alternate with every step / burst: the
+// device pointers an update's launches carry depend on them)
+int eqf_tiled_pingpong(eqf_tiled* t) { return t ? (t->pG | (t->pB << 1)) : EQF_ERR_INVALID; }
+
 int eqf_tiled_update_prep(eqf_tiled* t, const double* bearings, const double* Sll, int ldl, double* M, int ldm, double* E, int lde, double* G11) {
-    if (!t || !bearings || !G11 || t->N < 1) return EQF_ERR_INVALID;
+    if (!t || !G11 || t->N < 1 || (!bearings && !t->hBear)) return EQF_ERR_INVALID;
     const bool local = t->nlr > 0 && t->nlc > 0;
     if (local && (!Sll || !M || !E || ldl < 3 * t->nlc || ldm < 5 * t->nlc + kTlNarrowS || lde < 3 * t->nlc + kTlNarrowE)) return EQF_ERR_INVALID;
     DeviceScope ds(t->device);
     if (!ds.ok) return EQF_ERR_HIP;
     const int N = t->N;
-    HIPC(hipMemcpyAsync(t->dBear, bearings, sizeof(double) * 3 * N, hipMemcpyHostToDevice, t->stream));
+    if (bearings) {
+        int rcs = eqf_tiled_stage_bearings(t, bearings);
+        if (rcs) return rcs;
+    }
+    HIPC(hipMemcpyAsync(t->dBear, t->hBear, sizeof(double) * 3 * N, hipMemcpyHostToDevice, t->stream));
+    HIPC(hipEventRecord(t->evBear, t->stream));
     TlUpdArgs a{};
     a.g = t->g[t->pG];
     a.p0 = t->p0;
@@ -494,7 +524,6 @@ int eqf_tiled_update_prep(eqf_tiled* t, const double* bearings, const double* Sl
         hipLaunchKernelGGL(k_tl_form_e, grid, dim3(256), 0, t->stream, a);
     }
     HIPC(hipGetLastError());
-    HIPC(hipStreamSynchronize(t->stream));  // (bearings is pageable host memory)
     return EQF_OK;
 }
 

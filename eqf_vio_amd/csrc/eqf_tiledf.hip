@@ -132,7 +132,17 @@ struct eqf_tf {
     int reserve = 8;
     int* info = nullptr;  // device: or-ed with 1 when a pivot of a diagonal block was not positive
     // options
-    int lookahead = 1, overlapChains = 1, burst = 1, checkEvery = 1, framesSinceCheck = 0, profiling = 0;
+    int lookahead = 1, overlapChains = 1, burst = 1, checkEvery = 1, framesSinceCheck = 0, profiling = 0, graphs = 0;
+    // one rank: the launch sequence of an update is fixed for a given number of slots and buffer parity -- it CAN be captured once as a hipGraph
+    // (the second update of that shape: the first allocates its scratch operands) and replayed: one hipGraphLaunch instead of ~2000 launches.
+    // OFF by default (option "graphs" / EQF_TILED_GRAPHS=1): measured on the MI355X with ROCm 7.2 (profiles/r05_tiled_host_loop.txt) the
+    // replay costs the host 0.1 ms per update instead of 4 .. 35 ms -- and the GPU 110 ms per frame instead of 68 at N = 4000 (19 instead of
+    // 5 at N = 1000): the graph's nodes do not keep the four streams' concurrency nor the CU masks of the look-ahead streams.  The update
+    // is bound by the GPU, not by the host, so the plain launches stay; and inside a process that runs on torch's bundled HIP runtime the
+    // capture of CU-masked streams crashed.
+    std::map<std::pair<int, int>, hipGraphExec_t> graphExec;
+    std::map<std::pair<int, int>, int> graphSeen;
+    long long graphLaunches = 0;
     // geometry + storage (allocated once for `cap` slots; the working set is a view of it for the slots in use)
     bool allocated = false, haveGeo = false, symmetric = false;
     Geo full, geo;
@@ -685,14 +695,15 @@ int checkPivots(eqf_tf* f, int* bad) {
     return EQF_OK;
 }
 
-// ---- the update (VIOFilter.cpp:264-297)
-int update(eqf_tf* f, const std::vector<double>& y) {
+// ---- the update (VIOFilter.cpp:264-297): everything that is ENQUEUED, on the streams of the handle (current stream: main).  The frame's
+// bearings are in the per-rank handle's pinned staging buffer already (eqf_tiled_stage_bearings).
+int enqueueUpdate(eqf_tf* f) {
     const Geo& geo = f->geo;
     f->evNext = 0;
     {
         Phase ph(f, 2);
         // E and M are formed from the PRE-update Sigma (VIOFilter.cpp:285 before :297)
-        RC(eqf_tiled_update_prep(f->t, y.data(), f->Sll.p, f->Sll.ld, f->M.p, f->M.ld, f->E.p, f->E.ld, f->G11));
+        RC(eqf_tiled_update_prep(f->t, nullptr, f->Sll.p, f->Sll.ld, f->M.p, f->M.ld, f->E.p, f->E.ld, f->G11));
     }
     const int nA = 2 * geo.nlc;
     RC(zero2d(f, f->accS));
@@ -779,6 +790,43 @@ int update(eqf_tf* f, const std::vector<double>& y) {
         RC(eqf_tiled_update_finish(f->t, acc.p, acc.ld, f->GnnBuf, f->G11sum));
     }
     HIPC(hipGetLastError());
+    return EQF_OK;
+}
+
+int update(eqf_tf* f, const std::vector<double>& y) {
+    RC(eqf_tiled_stage_bearings(f->t, y.data()));
+    const bool graphable = f->graphs && f->world == 1 && !f->profiling;
+    const std::pair<int, int> key(f->geo.N, eqf_tiled_pingpong(f->t));
+    hipGraphExec_t exec = nullptr;
+    if (graphable) {
+        auto it = f->graphExec.find(key);
+        if (it != f->graphExec.end()) {
+            exec = it->second;
+        } else if (f->graphSeen[key]++ >= 1) {
+            // capture: the forks to the other three streams hang off events recorded on main, and every one of them is joined again before
+            // the update's last launches (the E-chain's end event, the look-ahead events the next block row waits for)
+            hipGraph_t graph = nullptr;
+            HIPC(hipStreamBeginCapture(f->sMain, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueueUpdate(f);
+            const hipError_t e = hipStreamEndCapture(f->sMain, &graph);
+            if (rc || e != hipSuccess || !graph) {
+                if (graph) hipGraphDestroy(graph);
+                f->graphs = 0;  // (not capturable here: plain launches from now on)
+                if (rc) return rc;
+            } else {
+                if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
+                hipGraphDestroy(graph);
+                if (exec) f->graphExec[key] = exec;
+                else f->graphs = 0;
+            }
+        }
+    }
+    if (exec) {
+        HIPC(hipGraphLaunch(exec, f->sMain));
+        ++f->graphLaunches;
+    } else {
+        RC(enqueueUpdate(f));
+    }
     if (f->checkEvery && ++f->framesSinceCheck >= f->checkEvery) {
         int bad = 0;
         RC(checkPivots(f, &bad));
@@ -846,6 +894,7 @@ void freeAll(eqf_tf* f) {
     if (f->t) eqf_tiled_destroy(f->t);
     for (double* p : f->allocs) hipFree(p);
     if (f->info) hipFree(f->info);
+    for (auto& g : f->graphExec) hipGraphExecDestroy(g.second);
     for (hipEvent_t e : f->evPool) hipEventDestroy(e);
     for (auto& p : f->phasePending) {
         hipEventDestroy(p.a);
@@ -890,6 +939,7 @@ int eqf_tf_create(const eqf_settings* settings, int capacity_landmarks, int bloc
     // caller asks for the overlap (two communicators with kernels in flight on different streams are not validated on a node yet)
     f->overlapChains = 1;
     if (const char* e = std::getenv("EQF_TILED_OVERLAP_CHAINS")) f->overlapChains = std::atoi(e) != 0;
+    if (const char* e = std::getenv("EQF_TILED_GRAPHS")) f->graphs = std::atoi(e) != 0;
     int rc = eqf_tiled_create(settings, f->cap, device, &f->t);
     if (!rc && hipMalloc(reinterpret_cast<void**>(&f->info), sizeof(int)) != hipSuccess) rc = EQF_ERR_HIP;
     if (!rc && hipMemset(f->info, 0, sizeof(int)) != hipSuccess) rc = EQF_ERR_HIP;
@@ -934,6 +984,7 @@ int eqf_tf_set_option(eqf_tf* f, const char* name, int value) {
     else if (n == "burst") f->burst = value;
     else if (n == "check_every") f->checkEvery = value;
     else if (n == "profiling") f->profiling = value;
+    else if (n == "graphs") f->graphs = value;
     else return EQF_ERR_INVALID;
     return EQF_OK;
 }
@@ -1184,5 +1235,6 @@ int eqf_tf_get_phases(eqf_tf* f, double* ms7) {
 const char* eqf_tf_phase_name(int i) { return (i >= 0 && i < kPhases) ? kPhaseNames[i] : "?"; }
 const char* eqf_tf_last_error(eqf_tf* f) { return f ? f->lastError.c_str() : ""; }
 void* eqf_tf_tiled_handle(eqf_tf* f) { return f ? f->t : nullptr; }
+long long eqf_tf_graph_launches(eqf_tf* f) { return f ? f->graphLaunches : -1; }
 
 }  // extern "C"

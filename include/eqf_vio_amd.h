@@ -264,7 +264,13 @@ int eqf_tiled_edit_landmarks(eqf_tiled* t, int n_remove, const int* remove_slots
  *   E (3 nlr x lde): columns [0, 3 nlc) Sigma_IJ - Pg_I^T Pg_J (Schur complement of Sigma_e = Sigma[6:, 6:] after its five base
  *     coordinates, EqFMatrices.cpp:239), [3 nlc, 3 nlc + 11) [Z_I (6) | -Pg_I^T Lg^-1 (5)];  G11 (11 x 11): the base part of
  *     [Zt | Et]^T [Zt | Et].
- * bearings[N][3] host memory, in SLOT order (an inactive slot's entry is ignored). */
+ * bearings[N][3] host memory, in SLOT order (an inactive slot's entry is ignored); copied into a pinned staging buffer before the call
+ * returns -- the upload and everything else is enqueued, nothing waits for the device.  bearings = NULL: already staged by
+ * eqf_tiled_stage_bearings (a caller that replays a captured hipGraph of the update stages, then launches the graph).
+ * eqf_tiled_pingpong: bit 0 / bit 1 = which of the two state / base-panel buffers is current (the device pointers of an update's launches
+ * depend on it: a captured graph is valid for one value). */
+int eqf_tiled_stage_bearings(eqf_tiled* t, const double* bearings);
+int eqf_tiled_pingpong(eqf_tiled* t);
 int eqf_tiled_update_prep(eqf_tiled* t, const double* bearings, const double* Sll, int ldl, double* M, int ldm, double* E, int lde,
     double* G11);
 /* Second half (VIOFilter.cpp:279-297, EqFMatrices.cpp:173-275): acc (18 x ldacc, columns = 3 N in GLOBAL landmark order) = sum_k
@@ -309,7 +315,8 @@ int eqf_tiled_set_state(eqf_tiled* t, int N, const double* pose_q, const double*
  * positive, looked at every check_every-th update).  Getters answer in the REFERENCE's landmark order (insertion order, :211-230); the
  * landmark slots behind it (eqf_tiled, above) are internal.  eqf_tf_get_sigma is collective (every rank calls it).
  * Options (eqf_tf_set_option): "lookahead" (1), "overlap_chains" (1; EQF_TILED_OVERLAP_CHAINS), "burst" (1: IMU calls queued and sent as
- * bursts), "check_every" (1), "profiling" (0: event brackets per phase, eqf_tf_get_phases).
+ * bursts), "check_every" (1), "profiling" (0: event brackets per phase, eqf_tf_get_phases), "graphs" (0: hipGraph replay of an update on a
+ * one-rank grid, see eqf_tf_graph_launches).
  * ================================================================================================================================ */
 typedef struct eqf_tf eqf_tf; /* opaque */
 typedef struct eqf_tf_comm {
@@ -346,6 +353,10 @@ int eqf_tf_get_phases(eqf_tf* f, double* ms7);
 const char* eqf_tf_phase_name(int i);
 const char* eqf_tf_last_error(eqf_tf* f);
 void* eqf_tf_tiled_handle(eqf_tf* f); /* the rank's eqf_tiled (getters of the replicated state in SLOT order, tests) */
+/* One rank: the launch sequence of an update (~2000 launches at N = 4000) is captured once per (slots in use, buffer parity) as a hipGraph
+ * and replayed with one hipGraphLaunch -- option "graphs" / EQF_TILED_GRAPHS=1; OFF by default: on ROCm 7.2 the replay takes the GPU 1.6 x
+ * (N = 4000) to 4 x (N = 1000) as long as the plain launches on four streams (csrc/eqf_tiledf.hip).  Updates replayed from a graph so far: */
+long long eqf_tf_graph_launches(eqf_tf* f);
 
 /* ---- Dense tile kernels of the distributed factorisations, on CALLER-OWNED device memory of HIP device `device`, enqueued on
  * `stream` (a hipStream_t, NULL = the default stream) without synchronising; the caller's current device is restored.

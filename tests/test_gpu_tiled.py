@@ -745,3 +745,55 @@ def test_cpp_host_loop_equals_the_python_reference_bitwise(oracle_lib, N, bl, ca
     assert n_upd >= 7 and tp.churn_stats == tr.churn_stats and tp.churn_stats["removed_outliers"] > 0
     assert tp.device_error() == 0 and br.device_error() == 0
     assert tp.getTime() == tr.getTime()
+
+
+def test_cpp_tiled_facade_matches_the_oracle(oracle_lib):
+    """The C++ host facade of the partitioned filter (eqf_vio_amd/cpp/VIOFilterTiled.h: the reference's class interface over eqf_tf_*),
+    driven by a plain g++ program on a 1 x 1 grid with landmarks leaving and coming back, reproduces the oracle on the same inputs."""
+    import os
+    import re
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "eqf_vio_amd", "cpp", "eqf_example_tiled")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    N, frames, bl = 30, 9, 8
+    out = subprocess.run([exe, str(N), str(frames), str(bl)], capture_output=True, text=True, check=True).stdout
+    nums = [float(x) for x in re.findall(r"[-+]?\d+\.\d+(?:e[-+]?\d+)?", out)]
+    t, pos, q, fro = nums[0], nums[1:4], nums[4:8], nums[8]
+    nlm = int(re.search(r"N=(\d+)", out).group(1))
+    i = np.arange(N)
+    lm = np.stack([2 * np.sin(1.3 * i), 2 * np.cos(0.7 * i), 5 + np.sin(0.37 * i)], axis=1)
+    y = lm / np.linalg.norm(lm, axis=1, keepdims=True)
+    fo = oracle_lib.OracleFilter(dict(initialPointVariance=5000.0, measurementVariance=0.003, velOmegaVariance=1e-4,
+                                      velAccelVariance=1e-4, outlierThreshold=1e9))
+    k = 0
+    for f in range(frames):
+        stamp = 0.05 * f + 0.0025
+        while 0.005 * k < stamp:
+            fo.processIMUData(0.005 * k, [0, 0, 0], [9.81, 0, 0])
+            k += 1
+        vis = (f + i) % 7 != 0
+        fo.processVisionData(stamp, i[vis].astype(np.int32), y[vis])
+    e = fo.stateEstimate()
+    assert nlm == fo.N and abs(t - fo.getTime()) < 1e-9
+    assert np.abs(np.array(pos) - e["x"]).max() < 2e-6 and np.abs(np.array(q) - e["q"]).max() < 2e-6  # printed with 6 digits
+    assert abs(fro / np.linalg.norm(fo.stateCovariance()) - 1) < 1e-6
+
+
+def test_update_replayed_from_a_hipgraph_equals_the_plain_launches():
+    """One rank: an update's launch sequence -- prep, the two factorisations on four streams, downdate, finish -- can be captured as a hipGraph
+    and replayed with ONE launch (EQF_TILED_GRAPHS=1; off by default: the replay is slower on the GPU, csrc/eqf_tiledf.hip).  Through the plain
+    C++ example (the system's HIP runtime): the same printed pose and |Sigma|_F as the plain launches, and the replay must actually happen."""
+    import os
+    import re
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "eqf_vio_amd", "cpp", "eqf_example_tiled")
+    outs = []
+    for graphs in ("1", "0"):
+        r = subprocess.run([exe, "150", "14", "64", "timing"], capture_output=True, text=True, check=True, env=dict(os.environ, EQF_TILED_GRAPHS=graphs))
+        outs.append(r.stdout)
+    first = [o.splitlines()[0] for o in outs]
+    assert first[0] == first[1] and "N=150" in first[0], outs
+    replays = [int(re.search(r"(\d+) updates replayed from a hipGraph", o).group(1)) for o in outs]
+    assert replays[0] >= 8 and replays[1] == 0, replays
