@@ -114,10 +114,10 @@ struct Piece {
 };
 typedef std::map<int, Piece> Contributions;
 
-struct ChainBufs {
-    std::map<int, double*> buf;  // per process column of my row (and my own): a solved block row piece
+struct ChainBufs {  // everything double-buffered (k & 1): block row k + 1 is solved and broadcast while the products of block row k still read k's
+    std::map<int, double*> buf[2];  // per process column of my row (and my own): a solved block row piece
     double* pack[2] = {nullptr, nullptr};
-    double* aopA = nullptr;
+    double* aopA[2] = {nullptr, nullptr};
 };
 }  // namespace
 
@@ -128,6 +128,9 @@ struct eqf_tf {
     bool haveComm = false;
     eqf_tiled* t = nullptr;
     hipStream_t sMain = nullptr, sSide = nullptr, sAux = nullptr, sAuxSide = nullptr, cur = nullptr;
+    hipStream_t sPanel[2] = {nullptr, nullptr};  // per chain: the NEXT block row's solve + exchanges, next to the current block row's products
+    hipStream_t sComm = nullptr;                 // every exchange, in program order: one communicator is enough
+    int panelAhead = 0;  // set at creation: 1 on more than one rank (there are exchanges to hide), 0 on a 1 x 1 grid -- see eqf_tf_create
     bool ownStreams = false;
     int reserve = 8;
     int* info = nullptr;  // device: or-ed with 1 when a pivot of a diagonal block was not positive
@@ -260,7 +263,21 @@ int bcast(eqf_tf* f, int group, int chain, int root, double* p, size_t count) {
     if (group == 0 && f->Pc == 1) return EQF_OK;
     if (group == 1 && f->Pr == 1) return EQF_OK;
     if (!f->haveComm || !f->comm.bcast) return EQF_ERR_INVALID;
-    const int rc = f->comm.bcast(f->comm.ctx, group, chain, root, p, count * sizeof(double), f->cur);
+    // every exchange of the handle runs on ONE stream, in program order (identical on every rank): whatever the chains' streams overlap, the
+    // collective library sees one ordered sequence per communicator.  The calling stream hands over and takes back through events.
+    if (!f->sComm || f->sComm == f->cur) {
+        const int rc = f->comm.bcast(f->comm.ctx, group, chain, root, p, count * sizeof(double), f->cur);
+        return rc == 0 ? EQF_OK : EQF_ERR_HIP;
+    }
+    hipEvent_t before = record(f), after = nullptr;
+    int rc;
+    {
+        CurStream cs(f, f->sComm);
+        wait(f, before);
+        rc = f->comm.bcast(f->comm.ctx, group, chain, root, p, count * sizeof(double), f->cur);
+        after = record(f);
+    }
+    wait(f, after);
     return rc == 0 ? EQF_OK : EQF_ERR_HIP;
 }
 
@@ -315,12 +332,14 @@ int allocStorage(eqf_tf* f) {
         if (c == f->pc || c % f->Pr == f->pr) mine.push_back(c);
     for (int chain = 0; chain < 2; ++chain) {
         ChainBufs& cb = chain ? f->bufE : f->bufS;
-        for (int c : mine) {
-            const int w = chain ? 3 * full.ncolsOf(c) + kNarrowE : 5 * full.ncolsOf(c) + kNarrowS;
-            RC(dalloc(f, &cb.buf[c], (size_t)bsmax * w, false));
+        for (int q = 0; q < 2; ++q) {
+            for (int c : mine) {
+                const int w = chain ? 3 * full.ncolsOf(c) + kNarrowE : 5 * full.ncolsOf(c) + kNarrowS;
+                RC(dalloc(f, &cb.buf[q][c], (size_t)bsmax * w, false));
+            }
+            RC(dalloc(f, &cb.pack[q], (size_t)bsmax * bsmax + (size_t)((bsmax + 63) / 64) * kDRec, false));
+            RC(dalloc(f, &cb.aopA[q], (size_t)bsmax * std::max(3 * full.nlr, 1), false));
         }
-        for (int q = 0; q < 2; ++q) RC(dalloc(f, &cb.pack[q], (size_t)bsmax * bsmax + (size_t)((bsmax + 63) / 64) * kDRec, false));
-        RC(dalloc(f, &cb.aopA, (size_t)bsmax * std::max(3 * full.nlr, 1), false));
     }
     RC(dview(f, &f->aopW, bsmax, std::max(3 * full.nlr, 1), false));
     // the downdate Sigma_IJ -= sum_k Y_kI^T Y_kJ is ONE product per update: the solved block rows are kept -- the columns of my process
@@ -407,59 +426,80 @@ struct Chain {
     int unit, nA, chainId;
     const std::vector<int>* wmax;
     ChainBufs* bufs;
-    hipStream_t side;
+    hipStream_t side, panel;
+    hipEvent_t rowReady;  // block row k (the next to be solved) carries every earlier update: at first "the operands are formed"
     std::function<int(int, int, View, int, const Contributions&)> hook;
     int k = 0;
-    hipEvent_t ahead = nullptr;
+    hipEvent_t ahead = nullptr;               // the look-ahead factor of diagonal block k is in pack[k & 1]
+    hipEvent_t updDone[2] = {nullptr, nullptr};  // the products of block row k have read buffer set k & 1
     bool done() const { return k >= f->geo.nb; }
+    // One block row.  Two parts on two streams (round 5; until then one stream did both, block row after block row):
+    //   PANEL (stream `panel`): the diagonal factor along the process row, my piece of block row k solved, down the process column, along
+    //         the process row -- everything the products of block row k need, into buffer set k & 1;
+    //   PRODUCTS (the caller's stream): the rank's trailing updates with block row k, the hook (downdate operands, reductions).  The rows of
+    //         block k + 1 come FIRST and on their own: as soon as they are updated the panel part of block row k + 1 starts -- its solve
+    //         and its exchanges run next to the rest of block row k's products instead of after them.
     int step() {
         const Geo& geo = f->geo;
         const int Pr = f->Pr, Pc = f->Pc, pr = f->pr, pc = f->pc;
-        const int bsF = unit * geo.bl, W = X.c;
+        const int bsF = unit * geo.bl, W = X.c, q = k & 1;
         const int prk = k % Pr, pck = k % Pc, bk = unit * geo.blockSize(k), klr = k / Pr, klc = k / Pc;
         const int jl0 = Geo::blocksUpto(k, pc, Pc);
         const int c0 = std::min(jl0 * bsF, nA), width = W - c0;
-        const View Bop = flat(bufs->buf.at(pc), bk, width);
-        if (pr == prk) {
-            // 1. the diagonal block, L_kk and its records along the process row
-            const size_t nrec = (size_t)((bk + 63) / 64) * kDRec;
-            double* pack = bufs->pack[k & 1];
-            const View Lkk = flat(pack, bk, bk);
-            double* drec = pack + (size_t)bk * bk;
-            if (pc == pck) {
-                if (ahead) {
-                    wait(f, ahead);
-                    ahead = nullptr;
-                } else {
-                    RC(copy2d(f, Lkk, X.sub(klr * bsF, klr * bsF + bk, klc * bsF, klc * bsF + bk)));
-                    RC(potrf(f, Lkk, drec));
-                }
-            }
-            RC(bcast(f, 0, chainId, pck, pack, (size_t)bk * bk + nrec));
-            // 2. my piece of block row k
-            const View R = X.sub(klr * bsF, klr * bsF + bk, c0, W);
-            RC(trsmLeft(f, Lkk, drec, R));
-            RC(copy2d(f, Bop, R));
-        }
-        // 3. down the process column
-        RC(bcast(f, 1, chainId, prk, Bop.p, (size_t)bk * width));
-        // 4. along the process row, from the ranks whose column blocks are this process row's row blocks
+        const View Bop = flat(bufs->buf[q].at(pc), bk, width);
         Contributions con;
-        for (int c = pr; c < Pc; c += Pr) {
-            const int jl0c = Geo::blocksUpto(k, c, Pc);
-            const int wc = (*wmax)[c] - std::min(jl0c * bsF, unit * geo.ncolsOf(c));
-            const View piece = c == pc ? Bop : flat(bufs->buf.at(c), bk, wc);
-            RC(bcast(f, 0, chainId, c, piece.p, (size_t)bk * wc));
-            con[c] = Piece{piece, jl0c};
+        hipEvent_t panelDone = nullptr;
+        {
+            // ---- PANEL
+            CurStream cs(f, f->panelAhead ? panel : f->cur);
+            if (f->panelAhead) {
+                wait(f, rowReady);
+                wait(f, updDone[q]);  // (buffer set q was read by the products of block row k - 2)
+            }
+            if (pr == prk) {
+                // 1. the diagonal block, L_kk and its records along the process row
+                const size_t nrec = (size_t)((bk + 63) / 64) * kDRec;
+                double* pack = bufs->pack[q];
+                const View Lkk = flat(pack, bk, bk);
+                double* drec = pack + (size_t)bk * bk;
+                if (pc == pck) {
+                    if (ahead) {
+                        wait(f, ahead);
+                        ahead = nullptr;
+                    } else {
+                        RC(copy2d(f, Lkk, X.sub(klr * bsF, klr * bsF + bk, klc * bsF, klc * bsF + bk)));
+                        RC(potrf(f, Lkk, drec));
+                    }
+                }
+                RC(bcast(f, 0, chainId, pck, pack, (size_t)bk * bk + nrec));
+                // 2. my piece of block row k
+                const View R = X.sub(klr * bsF, klr * bsF + bk, c0, W);
+                RC(trsmLeft(f, Lkk, drec, R));
+                RC(copy2d(f, Bop, R));
+            }
+            // 3. down the process column
+            RC(bcast(f, 1, chainId, prk, Bop.p, (size_t)bk * width));
+            // 4. along the process row, from the ranks whose column blocks are this process row's row blocks
+            for (int c = pr; c < Pc; c += Pr) {
+                const int jl0c = Geo::blocksUpto(k, c, Pc);
+                const int wc = (*wmax)[c] - std::min(jl0c * bsF, unit * geo.ncolsOf(c));
+                const View piece = c == pc ? Bop : flat(bufs->buf[q].at(c), bk, wc);
+                RC(bcast(f, 0, chainId, c, piece.p, (size_t)bk * wc));
+                con[c] = Piece{piece, jl0c};
+            }
+            if (f->panelAhead) panelDone = record(f);
         }
-        // 5. trailing updates of what this rank owns: rows of blocks i > k, columns from block jl0 on
+        // ---- PRODUCTS: trailing updates of what this rank owns: rows of blocks i > k, columns from block jl0 on
+        wait(f, panelDone);
+        rowReady = nullptr;
         const int il0 = Geo::blocksUpto(k, pr, Pr);
         if (il0 * bsF < X.r) {
             View Ua;
-            RC(rowsOperand(f, con, unit, [](int, int) { return std::make_pair(0, 1); }, bk, bufs->aopA, false, k, &Ua));
-            if (f->lookahead && k + 1 < geo.nb && pr == (k + 1) % Pr && pc == (k + 1) % Pc) {
-                // look-ahead: block (k+1, k+1) is the first trailing block of my rows and of my columns; its factor is ready when step k+1
-                // starts, computed on the side stream (a few reserved CUs) in the shadow of this step's trailing update
+            RC(rowsOperand(f, con, unit, [](int, int) { return std::make_pair(0, 1); }, bk, bufs->aopA[q], false, k, &Ua));
+            const bool ownNextRow = k + 1 < geo.nb && pr == (k + 1) % Pr;  // my first trailing row block IS block row k + 1
+            if (f->lookahead && ownNextRow && pc == (k + 1) % Pc) {
+                // look-ahead: block (k+1, k+1) is the first trailing block of my rows and of my columns; its factor is ready when the panel
+                // part of block row k+1 starts, computed on the side stream (a few reserved CUs) in the shadow of this block row's products
                 const int b1 = unit * geo.blockSize(k + 1);
                 double* pack1 = bufs->pack[(k + 1) & 1];
                 const View L1 = flat(pack1, b1, b1);
@@ -474,14 +514,26 @@ struct Chain {
                     ahead = record(f);
                 }
             }
-            const View Ct = X.sub(il0 * bsF, X.r, c0, W);
-            if (nA - c0 > 0) {
-                const int mask[8] = {bsF, bsF, il0, Pr, pr, jl0, Pc, pc};
-                RC(gemmTn(f, Ct.cols(0, nA - c0), Ua, Bop.cols(0, nA - c0), -1.0, mask));
+            // the rows of block k + 1 first (when they are mine and somebody is waiting for them), then the rest: the same products on the same
+            // elements in two launches instead of one
+            const int split = (f->panelAhead && ownNextRow) ? std::min(unit * geo.blockSize(k + 1), X.r - il0 * bsF) : 0;
+            for (int part = 0; part < 2; ++part) {
+                const int r0 = il0 * bsF + (part ? split : 0), r1 = part ? X.r : il0 * bsF + split;
+                if (r1 > r0) {
+                    const View Ct = X.sub(r0, r1, c0, W), Up = Ua.cols(r0 - il0 * bsF, r1 - il0 * bsF);
+                    if (nA - c0 > 0) {
+                        const int mask[8] = {bsF, bsF, il0 + (part && split ? 1 : 0), Pr, pr, jl0, Pc, pc};
+                        RC(gemmTn(f, Ct.cols(0, nA - c0), Up, Bop.cols(0, nA - c0), -1.0, mask));
+                    }
+                    RC(gemmTn(f, Ct.cols(nA - c0, width), Up, Bop.cols(nA - c0, width), -1.0));
+                }
+                if (part == 0 && f->panelAhead) rowReady = record(f);
             }
-            RC(gemmTn(f, Ct.cols(nA - c0, width), Ua, Bop.cols(nA - c0, width), -1.0));
+        } else if (f->panelAhead) {
+            rowReady = record(f);
         }
         RC(hook(k, bk, Bop, nA - c0, con));
+        if (f->panelAhead) updDone[q] = record(f);
         ++k;
         return EQF_OK;
     }
@@ -689,6 +741,8 @@ int checkPivots(eqf_tf* f, int* bad) {
     if (f->sAux) HIPC(hipStreamSynchronize(f->sAux));
     if (f->sSide) HIPC(hipStreamSynchronize(f->sSide));
     if (f->sAuxSide) HIPC(hipStreamSynchronize(f->sAuxSide));
+    for (hipStream_t ps : {f->sPanel[0], f->sPanel[1], f->sComm})
+        if (ps) HIPC(hipStreamSynchronize(ps));
     HIPC(hipMemcpy(&v, f->info, sizeof(int), hipMemcpyDeviceToHost));
     if (v) HIPC(hipMemset(f->info, 0, sizeof(int)));
     if (bad) *bad = v;
@@ -708,8 +762,9 @@ int enqueueUpdate(eqf_tf* f) {
     const int nA = 2 * geo.nlc;
     RC(zero2d(f, f->accS));
     RC(zero2d(f, f->accE));
-    Chain S{f, f->M, 2, nA, 0, &f->wmaxS, &f->bufS, f->sSide};
-    Chain E{f, f->E, 3, 3 * geo.nlc, 1, &f->wmaxE, &f->bufE, f->sAuxSide};
+    hipEvent_t prepared = record(f);
+    Chain S{f, f->M, 2, nA, 0, &f->wmaxS, &f->bufS, f->sSide, f->sPanel[0], prepared};
+    Chain E{f, f->E, 3, 3 * geo.nlc, 1, &f->wmaxE, &f->bufE, f->sAuxSide, f->sPanel[1], prepared};
     S.hook = [f](int k, int bk, View Bop, int off, const Contributions& con) -> int {
         // Bop[:, off:] = [Y_k (3 nlc) | Yn_k (18)] of my process column; the rank's share of the downdate and of the reductions
         const Geo& g = f->geo;
@@ -730,7 +785,7 @@ int enqueueUpdate(eqf_tf* f) {
     // the E-chain (bundleLift's weights) needs nothing of the S-chain: it runs on its own stream pair next to it.  It is bound by its serial
     // diagonal blocks, the S-chain and the downdate by the matrix cores -- side by side they take little more than the longer one.  The two
     // are enqueued ALTERNATELY, block row by block row, so that neither stream waits for the host to be through with the other chain.
-    hipEvent_t prepared = record(f), eDone = nullptr;
+    hipEvent_t eDone = nullptr;
     const bool overlap = f->overlapChains != 0;
     if (overlap) {
         Phase phS(f, 3);
@@ -889,7 +944,7 @@ int slotCovariance(eqf_tf* f, std::vector<double>* S, int* nOut) {
 void freeAll(eqf_tf* f) {
     if (!f) return;
     hipSetDevice(f->device);
-    for (hipStream_t s : {f->sMain, f->sSide, f->sAux, f->sAuxSide})
+    for (hipStream_t s : {f->sMain, f->sSide, f->sAux, f->sAuxSide, f->sPanel[0], f->sPanel[1], f->sComm})
         if (s) hipStreamSynchronize(s);
     if (f->t) eqf_tiled_destroy(f->t);
     for (double* p : f->allocs) hipFree(p);
@@ -901,7 +956,7 @@ void freeAll(eqf_tf* f) {
         hipEventDestroy(p.b);
     }
     if (f->ownStreams)
-        for (hipStream_t s : {f->sMain, f->sSide, f->sAux, f->sAuxSide})
+        for (hipStream_t s : {f->sMain, f->sSide, f->sAux, f->sAuxSide, f->sPanel[0], f->sPanel[1], f->sComm})
             if (s) eqf_stream_destroy(f->device, s);
     delete f;
 }
@@ -940,6 +995,12 @@ int eqf_tf_create(const eqf_settings* settings, int capacity_landmarks, int bloc
     f->overlapChains = 1;
     if (const char* e = std::getenv("EQF_TILED_OVERLAP_CHAINS")) f->overlapChains = std::atoi(e) != 0;
     if (const char* e = std::getenv("EQF_TILED_GRAPHS")) f->graphs = std::atoi(e) != 0;
+    // Block row k + 1 solved and exchanged NEXT TO the products of block row k (Chain::step): what hides the broadcasts on a node.  On one
+    // rank there is nothing to hide and the extra streams cost: measured on the MI355X, 1 x 1 grid (profiles/r05_tiled_host_loop.txt), N = 4000
+    // 68.0 -> 76.3 ms per frame, N = 1000 5.3 -> 9.4 ms (two more streams, three cross-stream events and two extra product launches per
+    // block row and chain) -- so it is on from two ranks on, and an option ("panel_ahead", EQF_TILED_PANEL_AHEAD) everywhere.
+    f->panelAhead = f->world > 1 ? 1 : 0;
+    if (const char* e = std::getenv("EQF_TILED_PANEL_AHEAD")) f->panelAhead = std::atoi(e) != 0;
     int rc = eqf_tiled_create(settings, f->cap, device, &f->t);
     if (!rc && hipMalloc(reinterpret_cast<void**>(&f->info), sizeof(int)) != hipSuccess) rc = EQF_ERR_HIP;
     if (!rc && hipMemset(f->info, 0, sizeof(int)) != hipSuccess) rc = EQF_ERR_HIP;
@@ -960,6 +1021,18 @@ int eqf_tf_create(const eqf_settings* settings, int capacity_landmarks, int bloc
         f->sSide = (hipStream_t)s[1];
         f->sAux = (hipStream_t)s[2];
         f->sAuxSide = (hipStream_t)s[3];
+        // the panel streams share the main streams' CU set; the exchange stream carries no kernels of ours
+        for (int i = 0; i < 3 && !rc; ++i) {
+            void* ps = nullptr;
+            if (f->reserve > 0) rc = eqf_stream_create_masked(device, 0, f->reserve, 1, &ps);
+            else {
+                hipStream_t st;
+                if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) rc = EQF_ERR_HIP;
+                ps = st;
+            }
+            if (i < 2) f->sPanel[i] = (hipStream_t)ps;
+            else f->sComm = (hipStream_t)ps;
+        }
         f->ownStreams = true;
         f->cur = f->sMain;
     }
@@ -985,6 +1058,7 @@ int eqf_tf_set_option(eqf_tf* f, const char* name, int value) {
     else if (n == "check_every") f->checkEvery = value;
     else if (n == "profiling") f->profiling = value;
     else if (n == "graphs") f->graphs = value;
+    else if (n == "panel_ahead") f->panelAhead = value;
     else return EQF_ERR_INVALID;
     return EQF_OK;
 }
@@ -1049,7 +1123,7 @@ int eqf_tf_synchronize(eqf_tf* f) {
     if (!f) return EQF_ERR_INVALID;
     DeviceScope ds(f->device);
     RC(flushQueue(f, false, 0.0, nullptr));
-    for (hipStream_t s : {f->sMain, f->sSide, f->sAux, f->sAuxSide})
+    for (hipStream_t s : {f->sMain, f->sSide, f->sAux, f->sAuxSide, f->sPanel[0], f->sPanel[1], f->sComm})
         if (s) HIPC(hipStreamSynchronize(s));
     return EQF_OK;
 }

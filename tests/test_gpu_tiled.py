@@ -702,8 +702,8 @@ def test_tiled_imu_bursts_equal_the_single_calls_bitwise(oracle_lib, N, bl, imu_
     assert tfs[0].be.device_error() == 0 and tfs[1].be.device_error() == 0
 
 
-@pytest.mark.parametrize("N,bl,cap", [(50, 16, 60), (200, 64, 200), (37, 8, 48)])
-def test_cpp_host_loop_equals_the_python_reference_bitwise(oracle_lib, N, bl, cap):
+@pytest.mark.parametrize("N,bl,cap,panel_ahead", [(50, 16, 60, 0), (200, 64, 200, 0), (37, 8, 48, 0), (50, 16, 60, 1), (150, 32, 150, 1)])
+def test_cpp_host_loop_equals_the_python_reference_bitwise(oracle_lib, N, bl, cap, panel_ahead):
     """Round 5: the partitioned filter's host loop is C++ behind the C ABI (csrc/eqf_tiledf.hip, eqf_tf_*).  It was written after the Python
     loop of rounds 3-4, which stays as tests/tiled_reference.py: the same kernels in the same order on the same operands.  On a stream with
     landmarks entering, leaving and failing the gate the two must agree BIT FOR BIT after every frame -- covariance, state, bias, the update's
@@ -717,6 +717,9 @@ def test_cpp_host_loop_equals_the_python_reference_bitwise(oracle_lib, N, bl, ca
     meas = synth.churn_measurements(st, seed=9, outlier_frames=(2, 5), outlier_angle=0.05)
     bp = tiled.HipBackend(d, capacity=cap)
     tp = tiled.TiledFilter(tiled.ProcessGrid(None, 1, 1, device=bp.device), bp, bl)
+    # panel_ahead = 1: block row k + 1 solved (and, on several ranks, exchanged) on its own stream next to block row k's products, the trailing
+    # update split in two launches -- the schedule of grids with more than one rank (csrc/eqf_tiledf.hip, Chain::step), forced onto one rank
+    tp._opt("panel_ahead", panel_ahead)
     br = tiled.HipBackend(d, capacity=cap)
     tr = tref.TiledFilter(tref.ProcessGrid(None, 1, 1, device=br.device), br, bl)
     fo = oracle_lib.OracleFilter(d)
