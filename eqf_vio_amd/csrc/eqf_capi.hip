@@ -482,6 +482,8 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     const int cus = std::max(f->numCUs, 1);
     const int lm = f->burstLm ? f->burstLm : ((long long)((nmx + 3) / 4) * f->B <= cus ? 4 : 16);
     const dim3 bgrid(std::max(1, (nmx + lm - 1) / lm), f->B);
+    // (round 5: the 4-landmark builder built for two workgroups per CU so that 8 filters keep its short ticks -- 400 workgroups on 512 slots --
+    // measured: 70.9 against 71.0 us per burst, nothing; not kept)
     const bool occ2 = f->burstOcc2 >= 0 ? f->burstOcc2 != 0 : (lm == 16 && (long long)bgrid.x * bgrid.y > cus);
     // rows per wavefront of the block kernel: one while the launch cannot fill the chip anyway (latency), four once the
     // column constants of a lane are worth sharing between several of its blocks.  (Two rows: 286 VGPRs, one wave per SIMD
@@ -1196,10 +1198,13 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
     if (needDepth) {
         // squared depths of the current estimate on the device (adding landmarks needs no readback); their median is selected by k_append
         // itself, or by a launch of its own for sets too large for that
-        int rc = depthFresh ? EQF_OK : probe(f, nullptr, 0, false, false);  // (the gate's probe left them already)
-        if (rc) return rc;
+        // (k_append computes the squared depths itself, round 5: no probe launch in front of it; only sets too large for its LDS take the
+        // probe + the selection launch)
+        int rc = EQF_OK;
         for (int b = 0; b < B; ++b)
             if (!fresh[b].empty() && nOldV[b] > kMedianInAppend) medianLaunch = true;
+        if (medianLaunch && !depthFresh) rc = probe(f, nullptr, 0, false, false);
+        if (rc) return rc;
         if (medianLaunch) {
             int nmx = 1;
             for (int b = 0; b < B; ++b) nmx = std::max(nmx, nOldV[b]);
@@ -1219,11 +1224,11 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
         const int* permDev = identity ? nullptr : f->dPerm;
         int rc = profiled(f, EQF_PROF_CHURN, [&] {
             if (f->precision == EQF_PRECISION_F32)
-                hipLaunchKernelGGL(k_append<float>, dim3(std::max(1, blocks)), dim3(256), 0, f->stream, f->g[f->pG], b, nOld, nNew, depthSel, f->dDepth2,
+                hipLaunchKernelGGL(k_append<float>, dim3(std::max(1, blocks)), dim3(256), 0, f->stream, f->g[f->pG], b, nOld, nNew, depthSel, (const double*)nullptr,
                     f->set.initialSceneDepth, f->set.initialPointVariance, cap, bearings + (long long)b * bearStride, permDev, f->p0,
                     f->Q[f->pG], f->lmc, f->errflag, static_cast<float*>(f->Sigma[f->pS]), f->sigmaStride, f->ld);
             else
-                hipLaunchKernelGGL(k_append<double>, dim3(std::max(1, blocks)), dim3(256), 0, f->stream, f->g[f->pG], b, nOld, nNew, depthSel, f->dDepth2,
+                hipLaunchKernelGGL(k_append<double>, dim3(std::max(1, blocks)), dim3(256), 0, f->stream, f->g[f->pG], b, nOld, nNew, depthSel, (const double*)nullptr,
                     f->set.initialSceneDepth, f->set.initialPointVariance, cap, bearings + (long long)b * bearStride, permDev, f->p0,
                     f->Q[f->pG], f->lmc, f->errflag, static_cast<double*>(f->Sigma[f->pS]), f->sigmaStride, f->ld);
         });

@@ -139,8 +139,24 @@ __global__ __launch_bounds__(256) void k_append(Glob* g, int b, int nOld, int nN
         yb[0] = y[0]; yb[1] = y[1]; yb[2] = y[2];
     }
     __shared__ double sDepth;
+    __shared__ double sD2[kMedianInAppend];
     if (nOld > 0 && !depthSel) {
-        const double* d = depth2 + (long long)b * cap;
+        // the squared depths of the current estimate (k_probe's expression), once per workgroup into LDS -- the launch no longer needs a probe
+        // launch in front of it (depth2 == nullptr; round 5)
+        if (depth2) {
+            for (int i = threadIdx.x; i < nOld; i += blockDim.x) sD2[i] = depth2[(long long)b * cap + i];
+            __syncthreads();
+        } else {
+            for (int i = threadIdx.x; i < nOld; i += blockDim.x) {
+                const double* P = p0 + (long long)b * 3 * cap;
+                const double* q = Q + (long long)b * 5 * cap;
+                const quat Qq = quat{q[i], q[cap + i], q[2 * cap + i], q[3 * cap + i]};
+                const d3 qhat = scl(1.0 / q[4 * cap + i], qrot(qinv(Qq), mk3(P[i], P[cap + i], P[2 * cap + i])));
+                sD2[i] = dot3(qhat, qhat);
+            }
+            __syncthreads();
+        }
+        const double* d = sD2;
         for (int i = threadIdx.x; i < nOld; i += blockDim.x) {
             const double di = d[i];
             int r0 = 0, r1 = 0, r2 = 0, r3 = 0;  // (four independent counters: the loads of a trip are in flight together)
