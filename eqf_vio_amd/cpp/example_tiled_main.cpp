@@ -2,7 +2,7 @@
 // one rank, no exchange callback needed -- driven like the reference's offline runner (eqf_vio/src/main.cpp:111-170): events interleaved
 // by "imu.stamp < meas.stamp", the state read after every vision call.  Landmark i is in view on frames with (f + i) % 7 != 0, so
 // landmarks leave and come back (VIOFilter.cpp:345-443 on slots).
-// Usage: eqf_example_tiled <N landmarks> <frames> <block landmarks> [timing | host]
+// Usage: eqf_example_tiled <N landmarks> <frames> <block landmarks> [timing | host | -] [option=value ...]
 //   prints the final pose, |Sigma|_F and the landmark count; with "timing" also the wall time per frame and the time the host spends in a
 //   processVisionData call (the call returns when everything is ENQUEUED; the pivot check is switched off, so nothing synchronises -- but a
 //   host that runs a whole frame ahead of the device waits for room in the device's queues); with "host" the device is drained before every
@@ -32,6 +32,11 @@ int main(int argc, char** argv) {
     for (int i = 0; i < N; ++i) lm[i] = {2 * std::sin(1.3 * i), 2 * std::cos(0.7 * i), 5 + std::sin(0.37 * i)};
     VIOFilterTiled filter(s, N, bl);
     if (timing) eqf_tf_set_option(filter.handle(), "check_every", 0);
+    for (int i = 5; i < argc; ++i) {  // options of the host loop (include/eqf_vio_amd.h: eqf_tf_set_option), e.g. graphs=1 panel_ahead=1
+        const std::string kv(argv[i]);
+        const size_t eq = kv.find('=');
+        if (eq != std::string::npos) eqf_tf_set_option(filter.handle(), kv.substr(0, eq).c_str(), std::atoi(kv.c_str() + eq + 1));
+    }
     IMUVelocity imu;
     imu.accel = {GRAVITY_CONSTANT, 0, 0};  // at rest, body x up
     int k = 0;

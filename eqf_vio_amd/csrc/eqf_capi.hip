@@ -375,21 +375,14 @@ int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, con
         a.sigmaExternal = 1;
         const int nmax = maxN(f), nv = kLm0 + 3 * nmax, nt = (nv + 63) / 64;
         const long long bStride = (long long)f->nTot * 6;
-        // 128 x 64 tiles (twice the MFMAs per staged operand byte) measured SLOWER than 64 x 64 at N = 1000 (fp64 43.6 vs
-        // 50.4 TFLOP/s, fp32 73.5 vs 89.4: fewer, fatter workgroups leave a poor last wave); EQF_DENSE_TALL=1 selects them
-        static const char* tallEnv = std::getenv("EQF_DENSE_TALL");
-        const bool tall = tallEnv && tallEnv[0] == '1';
-        const int ntr = tall ? (nv + 127) / 128 : nt;
+        // (128 x 64 tiles -- twice the MFMAs per staged operand byte -- measured SLOWER than 64 x 64 at N = 1000: fp64 43.6 vs 50.4 TFLOP/s,
+        // fp32 73.5 vs 89.4: fewer, fatter workgroups leave a poor last wave; removed in round 5)
+        const int ntr = nt;
         rc = profiled(f, EQF_PROF_DENSE, [&] {
             auto go = [&](auto zero) {
                 typedef decltype(zero) TT;
                 hipLaunchKernelGGL(k_dense_build<TT>, dim3(nmax + 1, f->B), block, 0, f->stream, a, (TT*)f->dF, (TT*)f->dBn, f->sigmaStride, bStride);
-                if (tall) {
-                    hipLaunchKernelGGL((k_dense_gemm<TT, false, 128>), dim3(nt, ntr, f->B), block, 0, f->stream, a.gin, a.recs, a.inl,
-                        (const TT*)f->dF, (const TT*)a.Sin, (TT*)f->dG, (const TT*)nullptr, f->sigmaStride, bStride, f->ld, f->prm);
-                    hipLaunchKernelGGL((k_dense_gemm<TT, true, 128>), dim3(nt, ntr, f->B), block, 0, f->stream, a.gin, a.recs, a.inl,
-                        (const TT*)f->dG, (const TT*)f->dF, (TT*)a.Sout, (const TT*)f->dBn, f->sigmaStride, bStride, f->ld, f->prm);
-                } else {
+                {
                     hipLaunchKernelGGL((k_dense_gemm<TT, false, 64>), dim3(nt, ntr, f->B), block, 0, f->stream, a.gin, a.recs, a.inl,
                         (const TT*)f->dF, (const TT*)a.Sin, (TT*)f->dG, (const TT*)nullptr, f->sigmaStride, bStride, f->ld, f->prm);
                     hipLaunchKernelGGL((k_dense_gemm<TT, true, 64>), dim3(nt, ntr, f->B), block, 0, f->stream, a.gin, a.recs, a.inl,
@@ -689,8 +682,6 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<float, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
-        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<float, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsUpdateBytes));
-        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsUpdateBytes));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<float>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
@@ -907,21 +898,11 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
             if (embed && !ddDone) embed = false;  // (cannot happen while nb64S < nb64E: kept for safety -> tail launch below)
         } else
         for (int k = 0; k < steps; ++k) {
-            if (!splitChain) {
+            {
                 const int dd = (embed && k == nb64S) ? ddTiles : 0;
                 rc = profiled(f, dd ? EQF_PROF_CHOL_DD : EQF_PROF_CHOL_STEP, [&] {
                     hipLaunchKernelGGL((k_chol_step64<T, 0>), dim3(blocks(k, 0) + dd, B), dim3(256), sizeof(Step64Lds), f->stream, cS, cE, a, k,
                         dd ? ddNt : 0, small ? 1 : 0, embed ? 1 : 0, f->errflag);
-                }, k);
-            } else {
-                // the S-chain's right-hand sides are complete after panel launch nb64S - 1: the downdate joins that update launch
-                const int dd = (embed && k == nb64S - 1) ? ddTiles : 0;
-                rc = profiled(f, dd ? EQF_PROF_CHOL_DD : EQF_PROF_CHOL_STEP, [&] {
-                    hipLaunchKernelGGL((k_chol_step64<T, 1>), dim3(blocks(k, 1), B), dim3(256), sizeof(Step64Lds), f->stream, cS, cE, a, k, 0, 0,
-                        embed ? 1 : 0, f->errflag);
-                    if (k + 1 < steps)
-                        hipLaunchKernelGGL((k_chol_step64<T, 2>), dim3(blocks(k, 2) + dd, B), dim3(256), kLdsUpdateBytes, f->stream, cS, cE, a, k,
-                            dd ? ddNt : 0, small ? 1 : 0, embed ? 1 : 0, f->errflag);
                 }, k);
             }
             if (rc) return rc;
@@ -1496,26 +1477,12 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     chk(dmalloc(&f->dBuildFlags, (size_t)f->nBuildCap * kFlagReplicas * B));
     if (!rc && hipMemset(f->dBuildFlags, 0, sizeof(int) * f->nBuildCap * kFlagReplicas * B) != hipSuccess) rc = EQF_ERR_HIP;
     if (const char* e = std::getenv("EQF_BURST_ROWS")) f->burstRows = (std::atoi(e) == 1 || std::atoi(e) == 2 || std::atoi(e) == 4) ? std::atoi(e) : 0;
-    if (const char* e = std::getenv("EQF_BURST_LM")) f->burstLm = std::atoi(e) == 16 ? 16 : (std::atoi(e) == 4 ? 4 : 0);
     if (const char* e = std::getenv("EQF_IMU_BURST")) f->burstMax = std::max(0, std::min(kBurstMax, std::atoi(e)));
     if (const char* e = std::getenv("EQF_SPLIT_PROPAGATE")) f->splitPropagate = std::atoi(e);
-    if (const char* e = std::getenv("EQF_STREAM_PROPAGATE")) f->streamPropagate = std::atoi(e);
-    if (const char* e = std::getenv("EQF_CHOL_EMBED")) f->cholEmbed = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_SPLIT")) f->cholSplit = std::atoi(e);
-    if (const char* e = std::getenv("EQF_CHOL_TAIL")) f->cholTail = std::atoi(e);
     if (const char* e = std::getenv("EQF_CHOL_RESIDENT")) f->cholResident = std::atoi(e);
-    if (const char* e = std::getenv("EQF_RES_STAGED")) f->resStaged = std::atoi(e);
     if (const char* e = std::getenv("EQF_RES_FOLD_PREP")) f->resFoldPrep = std::atoi(e);
-    if (const char* e = std::getenv("EQF_RES_FOLD_FRONT")) f->resFoldFront = std::max(0, std::min(7, std::atoi(e)));
     if (const char* e = std::getenv("EQF_BURST_FUSED")) f->burstFused = std::atoi(e);
-    if (const char* e = std::getenv("EQF_RES_OVERSUB")) f->resOversub = std::max(0, std::atoi(e));
-    if (const char* e = std::getenv("EQF_E_FROM_SIGMA")) f->eFromSigma = std::atoi(e);
-    if (const char* e = std::getenv("EQF_RES_OCC2")) f->resOcc2 = std::atoi(e);
-    if (const char* e = std::getenv("EQF_BURST_OCC2")) f->burstOcc2 = std::atoi(e);
-    if (const char* e = std::getenv("EQF_PREP_OCC2")) f->prepOcc2 = std::atoi(e);
-    if (const char* e = std::getenv("EQF_RES_PIPEH")) f->resPipeHeads = std::atoi(e);
-    if (const char* e = std::getenv("EQF_CHOL_ORDER")) f->cholOrder = std::atoi(e);
-    if (const char* e = std::getenv("EQF_CHOL_STREAMS")) f->cholStreams = std::max(0, std::atoi(e));
     {
         hipDeviceProp_t prop;
         if (!rc && hipGetDeviceProperties(&prop, device) != hipSuccess) rc = EQF_ERR_HIP;

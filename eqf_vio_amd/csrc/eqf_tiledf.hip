@@ -994,13 +994,11 @@ int eqf_tf_create(const eqf_settings* settings, int capacity_landmarks, int bloc
     // caller asks for the overlap (two communicators with kernels in flight on different streams are not validated on a node yet)
     f->overlapChains = 1;
     if (const char* e = std::getenv("EQF_TILED_OVERLAP_CHAINS")) f->overlapChains = std::atoi(e) != 0;
-    if (const char* e = std::getenv("EQF_TILED_GRAPHS")) f->graphs = std::atoi(e) != 0;
     // Block row k + 1 solved and exchanged NEXT TO the products of block row k (Chain::step): what hides the broadcasts on a node.  On one
     // rank there is nothing to hide and the extra streams cost: measured on the MI355X, 1 x 1 grid (profiles/r05_tiled_host_loop.txt), N = 4000
     // 68.0 -> 76.3 ms per frame, N = 1000 5.3 -> 9.4 ms (two more streams, three cross-stream events and two extra product launches per
-    // block row and chain) -- so it is on from two ranks on, and an option ("panel_ahead", EQF_TILED_PANEL_AHEAD) everywhere.
+    // block row and chain) -- so it is on from two ranks on, and an option ("panel_ahead") everywhere.
     f->panelAhead = f->world > 1 ? 1 : 0;
-    if (const char* e = std::getenv("EQF_TILED_PANEL_AHEAD")) f->panelAhead = std::atoi(e) != 0;
     int rc = eqf_tiled_create(settings, f->cap, device, &f->t);
     if (!rc && hipMalloc(reinterpret_cast<void**>(&f->info), sizeof(int)) != hipSuccess) rc = EQF_ERR_HIP;
     if (!rc && hipMemset(f->info, 0, sizeof(int)) != hipSuccess) rc = EQF_ERR_HIP;

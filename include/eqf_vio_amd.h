@@ -354,7 +354,7 @@ const char* eqf_tf_phase_name(int i);
 const char* eqf_tf_last_error(eqf_tf* f);
 void* eqf_tf_tiled_handle(eqf_tf* f); /* the rank's eqf_tiled (getters of the replicated state in SLOT order, tests) */
 /* One rank: the launch sequence of an update (~2000 launches at N = 4000) is captured once per (slots in use, buffer parity) as a hipGraph
- * and replayed with one hipGraphLaunch -- option "graphs" / EQF_TILED_GRAPHS=1; OFF by default: on ROCm 7.2 the replay takes the GPU 1.6 x
+ * and replayed with one hipGraphLaunch -- option "graphs"; OFF by default: on ROCm 7.2 the replay takes the GPU 1.6 x
  * (N = 4000) to 4 x (N = 1000) as long as the plain launches on four streams (csrc/eqf_tiledf.hip).  Updates replayed from a graph so far: */
 long long eqf_tf_graph_launches(eqf_tf* f);
 

@@ -6,7 +6,7 @@ B=${1:-8}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/b${B}_sweep.txt
 mkdir -p $ROOT/gpurun_out
-VARIANTS=${2:-"default EQF_BURST_LM=4 EQF_BURST_ROWS=1 EQF_BURST_ROWS=4 EQF_RES_OCC2=0 EQF_PREP_OCC2=0 EQF_BURST_OCC2=0"}
+VARIANTS=${2:-"default EQF_BURST_ROWS=1 EQF_BURST_ROWS=4 EQF_RES_FOLD_PREP=3 EQF_CHOL_RESIDENT=0"}
 ( echo "# bench.py --filters-per-gpu $B --steps 880 --warmup 110 (N = 200): steps/s, kernel classes (avg us per launch)"
   for V in $VARIANTS; do
     if [ "$V" = default ]; then envs="X=1"; else envs=$(echo "$V" | tr ';' ' '); fi

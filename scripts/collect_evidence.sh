@@ -12,7 +12,7 @@ PY=python
 stats() {  # stats <name> <bench args...>: rocprofv3 kernel-trace summary of one bench invocation
   local name=$1; shift
   rm -rf /tmp/prof_$name
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o b -- $PY $ROOT/bench.py "$@" --no-cpu-baseline --no-traffic --no-roofline --no-batch64 --no-parity --no-steady-state --no-tiled --no-churn > /dev/null 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o b -- $PY $ROOT/bench.py "$@" --no-cpu-baseline --no-traffic --no-roofline --no-batch64 --no-parity --no-steady-state --no-n1000 --no-batch8 --no-tiled --no-churn > /dev/null 2>&1
   f=$(find /tmp/prof_$name -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/${TAG}_${name}_kernel_stats.csv"
 }
@@ -44,35 +44,34 @@ pmc bench_N200 WRITE_SIZE --steps 220 --warmup 110
 pmc bench_N200 SQ_VALU_MFMA_BUSY_CYCLES --steps 220 --warmup 110
 pmc bench_N200 GRBM_GUI_ACTIVE --steps 220 --warmup 110
 # 1b. the same workload with the per-column launches instead of the resident update kernel, and with one launch per IMU call
-EQF_CHOL_RESIDENT=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-batch64 --no-parity --no-tiled --no-churn --no-steady-state > "$OUT/${TAG}_bench_N200_launches.json" 2>/dev/null
-EQF_RES_STAGED=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-batch64 --no-parity --no-traffic --no-tiled --no-churn --no-steady-state > "$OUT/${TAG}_bench_N200_unstaged.json" 2>/dev/null
+EQF_CHOL_RESIDENT=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-batch64 --no-parity --no-tiled --no-churn --no-steady-state --no-n1000 --no-batch8 > "$OUT/${TAG}_bench_N200_launches.json" 2>/dev/null
 # 1c. the same with the prep launch in front of the update launch (round 3's shape) instead of the prep roles inside it
-EQF_RES_FOLD_PREP=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-batch64 --no-parity --no-traffic --no-tiled --no-churn --no-steady-state > "$OUT/${TAG}_bench_N200_preplaunch.json" 2>/dev/null
+EQF_RES_FOLD_PREP=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-batch64 --no-parity --no-traffic --no-tiled --no-churn --no-steady-state --no-n1000 --no-batch8 > "$OUT/${TAG}_bench_N200_preplaunch.json" 2>/dev/null
 EQF_RES_FOLD_PREP=0 stats bench_N200_preplaunch
 EQF_CHOL_RESIDENT=0 stats bench_N200_launches
-EQF_IMU_BURST=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-churn --no-steady-state > "$OUT/${TAG}_bench_N200_noburst.json" 2>/dev/null
+EQF_IMU_BURST=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-churn --no-steady-state --no-n1000 --no-batch8 > "$OUT/${TAG}_bench_N200_noburst.json" 2>/dev/null
 # 2. a batch of 64 filters on one GPU (cfg 4's filters, all on one device)
-timeout 900 $PY $ROOT/bench.py --filters-per-gpu 64 --steps 440 --warmup 110 --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-churn --no-steady-state > "$OUT/${TAG}_bench_batch64.json" 2>/dev/null
+timeout 900 $PY $ROOT/bench.py --filters-per-gpu 64 --steps 440 --warmup 110 --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-churn --no-steady-state --no-n1000 --no-batch8 > "$OUT/${TAG}_bench_batch64.json" 2>/dev/null
 stats bench_N200_batch64 --filters-per-gpu 64 --steps 220 --warmup 110
-timeout 900 $PY $ROOT/bench.py --filters-per-gpu 8 --steps 880 --warmup 110 --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-churn --no-steady-state > "$OUT/${TAG}_bench_batch8.json" 2>/dev/null
+timeout 900 $PY $ROOT/bench.py --filters-per-gpu 8 --steps 880 --warmup 110 --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-churn --no-steady-state --no-n1000 --no-batch8 > "$OUT/${TAG}_bench_batch8.json" 2>/dev/null
 # 2b. small batches: the resident update kernel on an interleaved grid larger than the chip (default) against the per-column launches
 ( echo "# bench.py --filters-per-gpu B --steps 440 --warmup 110 (N = 200): steps/s, update kernels (avg us per launch)"
   for B in 2 4 6 8 12 16; do for O in default 0; do
-    if [ $O = default ]; then envs=""; else envs="EQF_RES_OVERSUB=0"; fi
-    env $envs timeout 600 $PY $ROOT/bench.py --filters-per-gpu $B --steps 440 --warmup 110 --no-batch64 --no-cpu-baseline --no-traffic --no-parity --no-tiled --no-churn --no-steady-state 2>/dev/null | $PY -c "
+    if [ $O = default ]; then envs="X=1"; else envs="EQF_CHOL_RESIDENT=0"; fi
+    env $envs timeout 600 $PY $ROOT/bench.py --filters-per-gpu $B --steps 440 --warmup 110 --no-batch64 --no-cpu-baseline --no-traffic --no-parity --no-tiled --no-churn --no-steady-state --no-n1000 --no-batch8 2>/dev/null | $PY -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('B=$B EQF_RES_OVERSUB=$O', round(d['value']), 'steps/s  err', d['device_error_flag'], [(k['kernel'], k['avg_us']) for k in d['kernels'][:4]])"
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('B=$B EQF_CHOL_RESIDENT=$O', round(d['value']), 'steps/s  err', d['device_error_flag'], [(k['kernel'], k['avg_us']) for k in d['kernels'][:4]])"
   done; done ) > "$OUT/${TAG}_batch_sweep.txt" 2>&1
 # 3. N = 1000: structured kernel and the dense MFMA Riccati backend (cfg 3)
-timeout 900 $PY $ROOT/bench.py --landmarks 1000 --steps 220 --warmup 55 --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-churn --no-steady-state > "$OUT/${TAG}_bench_N1000.json" 2>/dev/null
-timeout 900 $PY $ROOT/bench.py --landmarks 1000 --steps 110 --warmup 22 --dense-propagate --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-churn --no-steady-state > "$OUT/${TAG}_bench_N1000_dense.json" 2>/dev/null
+timeout 900 $PY $ROOT/bench.py --landmarks 1000 --steps 220 --warmup 55 --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-churn --no-steady-state --no-n1000 --no-batch8 > "$OUT/${TAG}_bench_N1000.json" 2>/dev/null
+timeout 900 $PY $ROOT/bench.py --landmarks 1000 --steps 110 --warmup 22 --dense-propagate --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-churn --no-steady-state --no-n1000 --no-batch8 > "$OUT/${TAG}_bench_N1000_dense.json" 2>/dev/null
 # 3b. MFMA busy cycles next to the GPU-active cycles for the N = 1000 runs (structured path and dense Riccati), separate passes
 pmc bench_N1000 SQ_VALU_MFMA_BUSY_CYCLES --landmarks 1000 --steps 44 --warmup 11
 pmc bench_N1000 GRBM_GUI_ACTIVE --landmarks 1000 --steps 44 --warmup 11
 pmc bench_N1000_dense SQ_VALU_MFMA_BUSY_CYCLES --landmarks 1000 --steps 22 --warmup 11 --dense-propagate
 pmc bench_N1000_dense GRBM_GUI_ACTIVE --landmarks 1000 --steps 22 --warmup 11 --dense-propagate
 # 4. N = 4000 (Sigma = 1.15 GB)
-timeout 900 $PY $ROOT/bench.py --landmarks 4000 --steps 22 --warmup 11 --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-churn --no-steady-state > "$OUT/${TAG}_bench_N4000.json" 2>/dev/null
+timeout 900 $PY $ROOT/bench.py --landmarks 4000 --steps 22 --warmup 11 --no-cpu-baseline --no-traffic --no-batch64 --no-parity --no-tiled --no-churn --no-steady-state --no-n1000 --no-batch8 > "$OUT/${TAG}_bench_N4000.json" 2>/dev/null
 # 4b. MFMA busy next to GPU-active cycles for the 64-filter batch and for N = 4000 (separate passes)
 pmc bench_batch64 SQ_VALU_MFMA_BUSY_CYCLES --filters-per-gpu 64 --steps 44 --warmup 22
 pmc bench_batch64 GRBM_GUI_ACTIVE --filters-per-gpu 64 --steps 44 --warmup 22
@@ -113,7 +112,7 @@ if [ -f $ROOT/build_variants/libeqf_bstamps.so ]; then
     echo; echo "## EQF_BURST_FUSED=0: k_burst_build, then k_burst_riccati_ring (block workgroup stamps: math done | handed on | barrier passed)";
     EQF_BURST_FUSED=0 EQF_VIO_AMD_LIB=$ROOT/build_variants/libeqf_bstamps.so timeout 300 $PY $ROOT/scripts/burst_fused_stamps.py; } > "$OUT/${TAG}_burst_stamps_N200.txt" 2>&1
 fi
-EQF_BURST_FUSED=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-batch64 --no-parity --no-traffic --no-tiled --no-churn --no-steady-state > "$OUT/${TAG}_bench_N200_burst_two_launches.json" 2>/dev/null
+EQF_BURST_FUSED=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-batch64 --no-parity --no-traffic --no-tiled --no-churn --no-steady-state --no-n1000 --no-batch8 > "$OUT/${TAG}_bench_N200_burst_two_launches.json" 2>/dev/null
 # 7c. landmark churn and the outlier gate on the per-call API: which launches a frame consists of in each mode
 timeout 600 bash $ROOT/scripts/churn_profile.sh > "$OUT/${TAG}_churn_profile.txt" 2>&1
 # 8. factor64 alone (scripts/micro/factor64_bench.hip, if built): cycles per 64-column block, per-wave stamps

@@ -100,7 +100,7 @@ def test_mid_size_filters_on_the_one_launch_update_kernel(oracle_lib, hip, N, mo
     """One filter between the sizes k_chol_resident was written for (N = 200) and BASELINE's N = 1000: since late in round 3 the host
     keeps such a filter on the one-launch update kernel (a grid several times larger than the chip: 12 + 16 / batch roles per CU,
     csrc/eqf_capi.hip) instead of one launch per block column.  Three vision updates against the structured oracle after every
-    frame, and the per-column launches (EQF_RES_OVERSUB=0) on the same stream to rounding."""
+    frame, and the per-column launches (EQF_CHOL_RESIDENT=0) on the same stream to rounding."""
     from eqf_vio_amd import synth
 
     st = synth.make_stream(N, duration=0.16)
@@ -109,7 +109,7 @@ def test_mid_size_filters_on_the_one_launch_update_kernel(oracle_lib, hip, N, mo
     out = {}
     for oversub in (None, "0"):
         if oversub is not None:
-            monkeypatch.setenv("EQF_RES_OVERSUB", oversub)
+            monkeypatch.setenv("EQF_CHOL_RESIDENT", oversub)
         fg = hip.FilterBatch(d, capacity=N, batch=1)
         fg.stream_upload(st.imu, st.vision_stamps, st.ids, st.bearings)
         fr = 0
@@ -123,7 +123,7 @@ def test_mid_size_filters_on_the_one_launch_update_kernel(oracle_lib, hip, N, mo
         assert fr == 3 and fg.device_error() == 0
         out[oversub] = fg.sigma(0)
         fg.close()
-    monkeypatch.delenv("EQF_RES_OVERSUB")
+    monkeypatch.delenv("EQF_CHOL_RESIDENT")
     assert rel_fro(out[None], out["0"]) < 1e-9
 
 

@@ -539,9 +539,8 @@ def test_split_propagate_path_equals_fused(hip, monkeypatch):
     d = synth.template_settings_dict()
     out = []
     monkeypatch.setenv("EQF_IMU_BURST", "0")  # one launch per call: these are the single-step kernels
-    for mode, stream in (("0", "1"), ("1", "1"), ("1", "0")):  # fused / builder + streaming kernel / builder + tile kernel
+    for mode in ("0", "1"):  # fused / builder + streaming kernel
         monkeypatch.setenv("EQF_SPLIT_PROPAGATE", mode)
-        monkeypatch.setenv("EQF_STREAM_PROPAGATE", stream)
         f = hip.FilterBatch(d, capacity=N, batch=1)
         f.stream_upload(st.imu, st.vision_stamps, st.ids, st.bearings)
         for kind, k in st.events():
@@ -586,22 +585,20 @@ def test_split_path_in_fp32_mode_and_under_the_dense_backend(hip, monkeypatch):
     assert all(np.abs(c[1][k] - e[1][k]).max() < 1e-9 for k in c[1])
 
 
-@pytest.mark.parametrize("embed,split,tail", [("0", "0", "1"), ("1", "1", "1"), ("0", "1", "1"), ("1", "1", "0"), ("0", "1", "0")])
-def test_alternative_factorisation_kernels_agree(hip, monkeypatch, embed, split, tail):
-    """The update's factorisation comes in interchangeable launch shapes of the same mathematics: the fused k_chol_step64 launches
-    (reductions, downdate and innovation lift riding along in the chain launches), the same with downdate / lift as a launch of their
-    own, and the split chain (the throughput variant) -- itself as one launch per block column (update launches that also solve the next
-    column after an in-launch hand-off of the diagonal factor, EQF_CHOL_TAIL=1, default) or as panel + update launches (EQF_CHOL_TAIL=0).
-    They must agree to rounding.  (The 32-wide kernel family of round 1 was removed in round 3.)"""
+def test_alternative_factorisation_kernels_agree(hip, monkeypatch):
+    """The per-column launches of the update's factorisation (EQF_CHOL_RESIDENT=0's path, and the only one for filters whose two chains are
+    equally long) come in two shapes of the same mathematics: the fused k_chol_step64 launches (every tile solves its own panel blocks;
+    reductions, downdate and innovation lift riding along) and the split chain, the throughput variant (update launches that also solve the
+    next block column after an in-launch hand-off of the diagonal factor).  EQF_CHOL_SPLIT forces either; they must agree to rounding.
+    (Round 5 removed the panel + update launch pairs, EQF_CHOL_TAIL=0, and the downdate as a launch of its own on demand, EQF_CHOL_EMBED=0:
+    best at no size.)"""
     from eqf_vio_amd import synth
 
-    N = 70  # S-chain 3 and E-chain 4 block columns of 64; 5 and 7 of 32
-    monkeypatch.setenv("EQF_CHOL_TAIL", tail)
+    N = 70  # S-chain 3 and E-chain 4 block columns of 64
     st = synth.make_stream(N, duration=0.5)
     d = synth.template_settings_dict()
     out = []
-    for e, sp in (("1", "0"), (embed, split)):
-        monkeypatch.setenv("EQF_CHOL_EMBED", e)
+    for sp in ("0", "1"):
         monkeypatch.setenv("EQF_CHOL_SPLIT", sp)
         f = hip.FilterBatch(d, capacity=N, batch=1)
         f.stream_upload(st.imu, st.vision_stamps, st.ids, st.bearings)
@@ -616,16 +613,15 @@ def test_alternative_factorisation_kernels_agree(hip, monkeypatch, embed, split,
 
 
 def test_large_filter_split_chain_agrees_with_the_fused_launches(hip, monkeypatch):
-    """N = 600 (19 / 29 block columns of 64): the default picks the split chain (one launch per block column, in-launch hand-off);
-    cross-check against panel + update launches and against the fused launches (every tile solves its own panel blocks)."""
+    """N = 600 (19 / 29 block columns of 64): the default (the one-launch update kernel) against the split chain (one launch per block
+    column, in-launch hand-off) and against the fused launches (every tile solves its own panel blocks)."""
     from eqf_vio_amd import synth
 
     N = 600
     st = synth.make_stream(N, duration=0.12)
     d = synth.template_settings_dict()
     out = []
-    for sp, tail in ((None, "1"), ("1", "0"), ("0", "1")):
-        monkeypatch.setenv("EQF_CHOL_TAIL", tail)
+    for sp in (None, "1", "0"):
         if sp is None:
             monkeypatch.delenv("EQF_CHOL_SPLIT", raising=False)
         else:
@@ -652,7 +648,6 @@ def test_in_launch_handoff_on_a_ragged_batch(oracle_lib, hip, monkeypatch):
     from eqf_vio_amd import synth
 
     monkeypatch.setenv("EQF_CHOL_SPLIT", "1")
-    monkeypatch.setenv("EQF_CHOL_TAIL", "1")
     Ns = [9, 30, 50, 75, 100]
     B = len(Ns)
     sts = [synth.make_stream(Ns[b], seed=900 + b, duration=1.0) for b in range(B)]
@@ -681,54 +676,6 @@ def test_in_launch_handoff_on_a_ragged_batch(oracle_lib, hip, monkeypatch):
                 eo, eg = fos[b].stateEstimate(), fg.state_estimate(b)
                 assert np.abs(eo["x"] - eg["x"]).max() < POSE_TOL and np.abs(eo["q"] - eg["q"]).max() < POSE_TOL, (k, b)
     assert nf >= 19 and fg.device_error() == 0
-
-
-def test_update_launch_layouts_give_the_same_bits(hip, monkeypatch):
-    """k_chol_step64<T, 3>: the pure trailing updates of a launch are walked by persistent stream workgroups; how many of them
-    there are (EQF_CHOL_STREAMS), in which order the workgroup classes are dispatched (EQF_CHOL_ORDER) and on which XCD a
-    filter's workgroups land (batch a multiple of 8: the XCD-aware split; otherwise the plain one) must not change a single
-    bit -- every tile sees the same operands in the same order.  Ragged batches of 8 and 3 filters, split chain forced."""
-    from eqf_vio_amd import synth
-
-    monkeypatch.setenv("EQF_CHOL_SPLIT", "1")
-    monkeypatch.setenv("EQF_CHOL_TAIL", "1")
-    d = synth.template_settings_dict()
-    for Ns in ([100, 9, 75, 30, 50, 100, 64, 21], [140, 70, 33]):
-        B = len(Ns)
-        stride = max(Ns)
-        sts = [synth.make_stream(Ns[b], seed=300 + b, duration=0.26) for b in range(B)]
-
-        def run():
-            fg = hip.FilterBatch(d, capacity=stride, batch=B)
-            for kind, k in sts[0].events():
-                if kind == "imu":
-                    fg.process_imu([s_.imu[k, 0] for s_ in sts], [s_.imu[k, 1:4] for s_ in sts], [s_.imu[k, 4:7] for s_ in sts])
-                else:
-                    ids = np.zeros((B, stride), dtype=np.int32)
-                    y = np.zeros((B, stride, 3))
-                    for b in range(B):
-                        ids[b, : Ns[b]] = sts[b].ids
-                        y[b, : Ns[b]] = sts[b].bearings[k]
-                    fg.process_vision([s_.vision_stamps[k] for s_ in sts], ids, y, nb=np.array(Ns, dtype=np.int32))
-            assert fg.device_error() == 0
-            return [fg.sigma(b) for b in range(B)], [fg.state_estimate(b) for b in range(B)]
-
-        ref = run()
-        for order, streams in (("0", "0"), ("2", "0"), ("1", "1"), ("1", "3"), ("0", "1000")):
-            monkeypatch.setenv("EQF_CHOL_ORDER", order)
-            monkeypatch.setenv("EQF_CHOL_STREAMS", streams)
-            o = run()
-            for b in range(B):
-                assert np.array_equal(o[0][b], ref[0][b]), (Ns, order, streams, b)
-                assert all(np.array_equal(o[1][b][k], ref[1][b][k]) for k in ref[1][b])
-        monkeypatch.delenv("EQF_CHOL_ORDER")
-        monkeypatch.delenv("EQF_CHOL_STREAMS")
-        # the E-chain's tiles first read straight from Sigma (default) or from the copy the prep launch makes: the same values
-        monkeypatch.setenv("EQF_E_FROM_SIGMA", "0")
-        o = run()
-        monkeypatch.delenv("EQF_E_FROM_SIGMA")
-        for b in range(B):
-            assert np.array_equal(o[0][b], ref[0][b]), (Ns, "copy", b)
 
 
 @pytest.mark.parametrize("Ns", [(70,), (200,), (30, 70), (9, 64, 21), (200,) * 8, (200, 150, 64, 200, 120, 200)])
@@ -931,14 +878,7 @@ def test_imu_bursts_equal_single_step_launches(hip, N, monkeypatch):
         assert np.array_equal(o[0], full[0]), rows
         assert all(np.abs(o[1][k] - full[1][k]).max() < 1e-9 for k in full[1])
     monkeypatch.delenv("EQF_BURST_ROWS")
-    # the builder's two role tables (4 / 16 landmarks per workgroup; chosen by launch size): the same formulas
-    outs = []
-    for lm in ("4", "16"):
-        monkeypatch.setenv("EQF_BURST_LM", lm)
-        outs.append(_run_bursts(hip, st, N, 15))
-    monkeypatch.delenv("EQF_BURST_LM")
-    assert rel_fro(outs[0][0], outs[1][0]) < 1e-9 and rel_fro(outs[0][0], full[0]) < 1e-9
-    assert all(np.abs(outs[0][1][k] - outs[1][1][k]).max() < 1e-9 for k in outs[0][1])
+    # (the builder's 16-landmark role table is what batches of six filters on and large N run: tests/test_gpu_configs.py)
     # against the single-step kernels: the same formulas, differently compiled; rounding amplified by cond(Sigma) ~ 1e7
     assert rel_fro(full[0], ref[0]) < 1e-9
     assert all(np.abs(full[1][k] - ref[1][k]).max() < 1e-9 for k in ref[1])

@@ -785,7 +785,7 @@ def test_cpp_tiled_facade_matches_the_oracle(oracle_lib):
 
 def test_update_replayed_from_a_hipgraph_equals_the_plain_launches():
     """One rank: an update's launch sequence -- prep, the two factorisations on four streams, downdate, finish -- can be captured as a hipGraph
-    and replayed with ONE launch (EQF_TILED_GRAPHS=1; off by default: the replay is slower on the GPU, csrc/eqf_tiledf.hip).  Through the plain
+    and replayed with ONE launch (option "graphs"; off by default: the replay is slower on the GPU, csrc/eqf_tiledf.hip).  Through the plain
     C++ example (the system's HIP runtime): the same printed pose and |Sigma|_F as the plain launches, and the replay must actually happen."""
     import os
     import re
@@ -794,7 +794,7 @@ def test_update_replayed_from_a_hipgraph_equals_the_plain_launches():
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "eqf_vio_amd", "cpp", "eqf_example_tiled")
     outs = []
     for graphs in ("1", "0"):
-        r = subprocess.run([exe, "150", "14", "64", "timing"], capture_output=True, text=True, check=True, env=dict(os.environ, EQF_TILED_GRAPHS=graphs))
+        r = subprocess.run([exe, "150", "14", "64", "timing", "graphs=" + graphs], capture_output=True, text=True, check=True)
         outs.append(r.stdout)
     first = [o.splitlines()[0] for o in outs]
     assert first[0] == first[1] and "N=150" in first[0], outs
