@@ -770,13 +770,26 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         // head H(C+2) waits for: no change, 137.8 against 138.3 us per update -- once the heads consume D stage by stage the pivot chain
         // and its hand-off are the critical path again, 13.6 us per block column: factor64 10.3, store issue + first column 1.1, flag +
         // W_33 0.9, last solve step 0.3, publish 0.45.)
-        hoWait3((C > 0 || waitD0) ? flagD + C : nullptr, nullptr, nullptr, epoch, tid, &bad, ra.errflag);
-        hoLoadRecord(D + (long long)C * kDRec, s, tid);
+        // Round 5: it is tried again for T(C+2, C) only, because the stamps changed: the block this tile publishes is the row head H(C+2)'s OWN
+        // block of its last panel, and that head's work on it (a 32 KB load and the diagonal tile's products, 3.7 us) now ends 1.4 us AFTER the
+        // other block of the panel -- the one the previous head publishes behind its first pivots -- is out: the later this tile publishes, the
+        // later the head sees that block (profiles/r05_res_stamps_N200.txt).  Consumed stage by stage, D[C] costs this tile one round trip of
+        // 2 KB and one 16 x 16 x 16 product behind the producer's last pivot instead of the whole 40 KB record and the whole solve.
+#ifndef EQF_T_STAGED
+#define EQF_T_STAGED 1
+#endif
+        if (EQF_T_STAGED && C > 0 && C + 2 == R && ra.stageFlags) {
+            stagedPanelSolve(acc, s, D + (long long)C * kDRec, ra.stageFlags + (((long long)b * 2 + role.kind) * nbCap + C) * 4, flagD + C, epoch, tid, &bad,
+                ra.errflag);
+        } else {
+            hoWait3((C > 0 || waitD0) ? flagD + C : nullptr, nullptr, nullptr, epoch, tid, &bad, ra.errflag);
+            hoLoadRecord(D + (long long)C * kDRec, s, tid);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) stTile(acc[i], &s.P[0][0], kSP, kQB * wv, kQB * i, lane);
-        __syncthreads();
-        solveStrip<true>(&s.P[0][0], kSP, s, kQB * wv, lane);
-        __syncthreads();
+            for (int i = 0; i < 4; ++i) stTile(acc[i], &s.P[0][0], kSP, kQB * wv, kQB * i, lane);
+            __syncthreads();
+            solveStrip<true>(&s.P[0][0], kSP, s, kQB * wv, lane);
+            __syncthreads();
+        }
         hoStoreBlock(A + (long long)(R * kSB) * ldA + C * kSB, ldA, s.P, tid);
         hoDrain();
         __syncthreads();
