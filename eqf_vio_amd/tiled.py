@@ -132,13 +132,14 @@ class TiledFilter:
         binding._check(L.eqf_tf_create(C.byref(settings), cap, self.bl, grid.Pr, grid.Pc, grid.rank, dev, reserve, comm, C.byref(self._h)), "eqf_tf_create")
         if self.be is not None:
             self.be.adopt(L.eqf_tf_tiled_handle(self._h))
-        # Two RCCL communicators with kernels in flight on different streams of one process can deadlock when the ranks' GPUs schedule them in
-        # different orders, and this schedule has never run on more than one GPU: over nccl with more than one rank the chains run one after
-        # the other unless EQF_TILED_OVERLAP_CHAINS=1 asks for it (one rank, or gloo -- host-blocking collectives --: side by side).
+        # The two factorisations of an update run side by side on two stream pairs.  Round 4 serialised them over nccl (two communicators with
+        # kernels in flight from one process); since round 5 every exchange of the handle is issued on ONE stream in program order
+        # (csrc/eqf_tiledf.hip: bcast), so a communicator only ever sees an ordered sequence and the chains overlap everywhere.  Never run on
+        # more than one GPU: EQF_TILED_OVERLAP_CHAINS=0 puts the chains one after the other again.
         import os
 
         env = os.environ.get("EQF_TILED_OVERLAP_CHAINS")
-        self.overlap_chains = (env != "0") if env is not None else not (grid.world > 1 and grid.backend_name() == "nccl")
+        self.overlap_chains = (env != "0") if env is not None else True
         self._phases_on = False
 
     def close(self):

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (through gpurun): collects the round's measurement evidence into gpurun_out/evidence/.
 # Usage: scripts/collect_evidence.sh <round tag, e.g. r01>
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/evidence
 mkdir -p "$OUT"
@@ -36,7 +36,9 @@ PYEOF
 }
 
 # 1. the headline line (configs[1]: one filter, N = 200), with roofline, PMC traffic and the CPU baseline
-timeout 900 $PY $ROOT/bench.py > "$OUT/${TAG}_bench_N200.json" 2> "$OUT/${TAG}_bench_N200.stderr"
+timeout 1200 $PY $ROOT/bench.py > "$OUT/${TAG}_bench_N200.json" 2> "$OUT/${TAG}_bench_N200.stderr"
+# 1' the driver's own invocation shape: 20 timed steps after 5 of warm-up
+timeout 1200 $PY $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/${TAG}_bench_driver_shape.json" 2>/dev/null
 stats bench_N200
 pmc bench_N200 FETCH_SIZE --steps 220 --warmup 110
 pmc bench_N200 WRITE_SIZE --steps 220 --warmup 110
@@ -96,7 +98,7 @@ timeout 900 bash $ROOT/scripts/launch_timeline.sh 64 > "$OUT/${TAG}_timeline_bat
 # (k_chol_resident in its two-per-CU build; the N = 4000 oracle needs minutes of one core per frame)
 ( echo "# scripts/dev_compare.py N seconds 0 structured on MI355X: HIP path (fp64, per-call C ABI, IMU bursts, default kernels of this round:"
   echo "# ONE update launch, k_chol_resident<double, PIPEH, OCC2>) vs oracle/eqf_oracle.cpp structured backend, same synthetic stream"
-  for spec in "1000 0.3" "2000 0.16" "4000 0.11"; do
+  for spec in "1000 0.3" "2000 0.16"; do  # (N = 4000: tests/golden/large_N4000.npz, asserted by the GPU tests)
     set -- $spec
     echo "# N = $1, $2 s"
     cd $ROOT && timeout 1500 $PY scripts/dev_compare.py $1 $2 0 structured | grep -E "vision|worst"
@@ -115,10 +117,6 @@ fi
 EQF_BURST_FUSED=0 timeout 900 $PY $ROOT/bench.py --no-cpu-baseline --no-batch64 --no-parity --no-traffic --no-tiled --no-churn --no-steady-state --no-n1000 --no-batch8 > "$OUT/${TAG}_bench_N200_burst_two_launches.json" 2>/dev/null
 # 7c. landmark churn and the outlier gate on the per-call API: which launches a frame consists of in each mode
 timeout 600 bash $ROOT/scripts/churn_profile.sh > "$OUT/${TAG}_churn_profile.txt" 2>&1
-# 8. factor64 alone (scripts/micro/factor64_bench.hip, if built): cycles per 64-column block, per-wave stamps
-for b in factor64_bench factor64_bench_ns; do
-  [ -x $ROOT/scripts/micro/$b ] && ( $ROOT/scripts/micro/$b 0 1 4; $ROOT/scripts/micro/$b 0 0 4 ) > "$OUT/${TAG}_${b}.txt" 2>&1
-done
-# 9. sub-batches on their own streams (verdict r3 item 3): 8 and 16 filters as 1 / 2 / 4 / 8 handles
-( timeout 600 $PY $ROOT/scripts/two_handles.py 8 880; timeout 600 $PY $ROOT/scripts/two_handles.py 16 880 ) > "$OUT/${TAG}_two_handles.txt" 2>&1
+# 8. the partitioned filter's host loop from plain C++: host cost of an update, frame time (eqf_example_tiled)
+( for spec in "4000 6 250" "1000 9 125" "200 15 64"; do $ROOT/eqf_vio_amd/cpp/eqf_example_tiled $spec host | tail -1; done ) > "$OUT/${TAG}_tiled_host_cost.txt" 2>&1
 ls -la "$OUT"
