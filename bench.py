@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--no-churn", action="store_true", help="skip the landmark-churn + outlier-gate leg (per-call API, N ~ 200)")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed throw-away run that precedes the measured job")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--debug-option", action="append", default=[], metavar="NAME=VALUE", help="developer toggle of the library (eqf_debug_option), main job only")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -334,6 +335,8 @@ def timed_job(args, dist, rank, world, device, N, B, steps, warmup, dense=False)
     fb = binding.FilterBatch(synth.template_settings_dict(), capacity=N, batch=B, device=device, precision=prec)
     if dense:
         fb.set_dense_propagate(True)
+    for kv in args.debug_option:
+        fb.debug_option(kv.split("=")[0], int(kv.split("=")[1]))
     fb.stream_upload(imu, vst, ids, bear)
     warm, timed = events[:warmup], events[warmup:]
     run_events(fb, warm)

@@ -59,7 +59,7 @@ EXPORTED_SYMBOLS = [
     "eqf_settings_default", "eqf_create", "eqf_destroy", "eqf_reset", "eqf_process_imu", "eqf_process_vision",
     "eqf_stream_upload", "eqf_stream_imu", "eqf_stream_vision", "eqf_synchronize", "eqf_get_time", "eqf_num_landmarks",
     "eqf_get_ids", "eqf_get_state_estimate", "eqf_get_origin", "eqf_get_group", "eqf_get_bias", "eqf_get_sigma",
-    "eqf_set_sigma", "eqf_set_state", "eqf_set_camera_offset", "eqf_get_integrator", "eqf_get_last_update", "eqf_debug_get_blocks", "eqf_device_error", "eqf_debug_drop_role", "eqf_set_dense_propagate", "eqf_set_imu_burst", "eqf_profile_enable",
+    "eqf_set_sigma", "eqf_set_state", "eqf_set_camera_offset", "eqf_get_integrator", "eqf_get_last_update", "eqf_debug_get_blocks", "eqf_device_error", "eqf_debug_drop_role", "eqf_debug_option", "eqf_set_dense_propagate", "eqf_set_imu_burst", "eqf_profile_enable",
     "eqf_profile_get", "eqf_profile_class_name", "eqf_version", "eqf_build_info", "eqf_tile_propagate", "eqf_tile_downdate", "eqf_tile_potrf", "eqf_tile_trsm", "eqf_tile_gemm_tn", "eqf_tile_mirror", "eqf_stream_create_masked", "eqf_stream_destroy",
     "eqf_tiled_create", "eqf_tiled_destroy", "eqf_tiled_set_stream", "eqf_tiled_set_geometry", "eqf_tiled_propagate", "eqf_tiled_add_landmarks",
     "eqf_tiled_edit_landmarks", "eqf_tiled_propagate_burst", "eqf_tiled_stage_bearings", "eqf_tiled_pingpong",
@@ -118,6 +118,7 @@ def lib():
         L.eqf_debug_get_blocks.argtypes = [vp, C.c_int, _dp, _dp, _dp]
         L.eqf_device_error.argtypes = [vp]
         L.eqf_debug_drop_role.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.eqf_debug_option.argtypes = [vp, C.c_char_p, C.c_int]
         L.eqf_set_dense_propagate.argtypes = [vp, C.c_int]
         L.eqf_set_imu_burst.argtypes = [vp, C.c_int]
         L.eqf_profile_enable.argtypes = [vp, C.c_int]
@@ -415,6 +416,10 @@ class FilterBatch:
     def debug_drop_role(self, kind, role=0, R=0, C_=0):
         """Fault injection (tests): one role of the update launch leaves without publishing (kind < 0: off); include/eqf_vio_amd.h."""
         _check(lib().eqf_debug_drop_role(self._h, int(kind), int(role), int(R), int(C_)), "eqf_debug_drop_role")
+
+    def debug_option(self, name, value):
+        """Developer toggle by name (include/eqf_vio_amd.h: eqf_debug_option), e.g. ``"cs_in_burst"``."""
+        _check(lib().eqf_debug_option(self._h, name.encode(), int(value)), "eqf_debug_option")
 
     # ---- profiling
     def profile_enable(self, on=True):

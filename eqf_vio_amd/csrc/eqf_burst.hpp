@@ -72,6 +72,17 @@ struct BurstArgs {
     // cache line holds entries of two steps -- the fused launch reads a step's lines through the L2 while later steps are still being written
     int colStep, rowStep;
     Params prm;
+    // k_burst_riccati_ring, a burst closed by a vision step whose landmark set the update will find unchanged (round 5): the block
+    // workgroups also leave the update's operands that are products of Sigma' blocks -- the landmark columns of C Sigma' (rows 2i, 2i+1 of
+    // YW, columns kLm0 ..) and S = C Sigma' C^T + R (SA, the lower block triangle + the blocks inside the diagonal 16 x 16 tiles) -- from the
+    // blocks they hold in registers: k_update_prep64's landmark waves then read 12 columns of Sigma' instead of all of them
+    // (UpdArgs::csInBurst).  csOut == 0: nothing of this.
+    int csOut;
+    double* YW;
+    double* SA;
+    const double* lmc;  // [B][15][cap]: the output matrix C_i of every landmark (rows 0..5)
+    int ldY, ldS;
+    long long strideY, strideS;
 };
 
 // what stepCommon / stepGlobal / stepLandmark read of their argument block
@@ -1245,6 +1256,70 @@ EQF_DI void burstRingBody(const BurstArgs& a, const int tileIdx, const int b) {
             }
         }
     }
+    // The update's operands from the same registers (BurstArgs::csOut): (C Sigma')_{IJ} = C_I Sigma'_IJ, a lane's three consecutive values of
+    // two rows of YW, and S_IJ = (C Sigma')_IJ C_J^T (+ R on the diagonal) -- in k_update_prep64's expression order.  The blocks above the
+    // diagonal, (C Sigma')_{JI} = C_J Sigma'_IJ^T, go out with the mirror image below; S is only read on and below the diagonal, except
+    // inside the 16 x 16 tiles ON it (landmarks of one group of 8), which the lane stores itself.
+    __shared__ double sCJ[6][64];
+    const bool csOut = a.csOut != 0;
+    double* const YWb = csOut ? a.YW + (long long)b * a.strideY : nullptr;
+    if (csOut) {
+        const double* lmc = a.lmc + (long long)b * 15 * cap;
+        double* SAb = a.SA + (long long)b * a.strideS;
+        double CJ[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) CJ[q] = lmc[(long long)q * cap + Jc];
+        if (wv == 0) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) sCJ[q][lane] = CJ[q];
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int I = I0raw + i;
+            if (validJ && I < N && I >= J) {
+                double CI[6], v[9];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) CI[q] = lmc[(long long)q * cap + I];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) v[k] = (double)S[i][k];
+                double cs[6];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) cs[3 * r + c] = dot3(CI[3 * r], v[c], CI[3 * r + 1], v[3 + c], CI[3 * r + 2], v[6 + c]);
+                double* yw = YWb + (long long)(2 * I) * a.ldY + kLm0 + 3 * J;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) yw[(long long)r * a.ldY + c] = cs[3 * r + c];
+                double sb[4];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) sb[2 * r + t] = dot3(cs[3 * r], CJ[3 * t], cs[3 * r + 1], CJ[3 * t + 1], cs[3 * r + 2], CJ[3 * t + 2]);
+                if (I == J) {
+                    sb[0] += a.prm.measurementVariance;
+                    sb[3] += a.prm.measurementVariance;
+                }
+                double* sa = SAb + (long long)(2 * I) * a.ldS + 2 * J;
+                sa[0] = sb[0]; sa[1] = sb[1]; sa[a.ldS] = sb[2]; sa[a.ldS + 1] = sb[3];
+                if (I > J && (I >> 3) == (J >> 3)) {
+                    // S_JI = (C_J Sigma'_JI) C_I^T, Sigma'_JI = Sigma'_IJ^T
+                    double cm[6];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) cm[3 * r + c] = dot3(CJ[3 * r], v[3 * c], CJ[3 * r + 1], v[3 * c + 1], CJ[3 * r + 2], v[3 * c + 2]);
+                    double* sm = SAb + (long long)(2 * J) * a.ldS + 2 * I;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            sm[(long long)r * a.ldS + t] = dot3(cm[3 * r], CI[3 * t], cm[3 * r + 1], CI[3 * t + 1], cm[3 * r + 2], CI[3 * t + 2]);
+                }
+            }
+        }
+    }
     // Sigma_JI = Sigma_IJ^T for the blocks strictly below the diagonal.  Written from the registers, a lane's three rows would be 8-byte
     // stores 3 ld apart (64 cache lines per instruction: the kernel took LONGER than with every block computed twice); instead the
     // workgroup transposes its tile through the LDS ring (free now), kLanesPass column landmarks at a time, and writes rows of the
@@ -1268,6 +1343,19 @@ EQF_DI void burstRingBody(const BurstArgs& a, const int tileIdx, const int b) {
             const int r = e / kWd, c = e % kWd;
             const int Jm = bx * 64 + p * kLanesPass + r / 3, Im = by * 4 * R + c / 3;
             if (Im < N && Im > Jm) Sout[(long long)(kLm0 + 3 * Jm + r % 3) * ld + kLm0 + 3 * Im + c % 3] = stage[r * kPitch + c];
+        }
+        if (csOut) {
+            // rows 2 Jm, 2 Jm + 1 of C Sigma' at the workgroup's row landmarks: C_Jm times the three staged rows of Sigma'_{Jm, .}
+            for (int e = tid; e < 2 * kLanesPass * kWd; e += 256) {
+                const int r2 = e / kWd, c = e % kWd, jl = r2 >> 1, rr = r2 & 1;
+                const int Jm = bx * 64 + p * kLanesPass + jl, Im = by * 4 * R + c / 3;
+                if (Im < N && Im > Jm) {
+                    const T* st3 = stage + 3 * jl * kPitch + c;
+                    const double* cj = &sCJ[3 * rr][p * kLanesPass + jl];
+                    YWb[(long long)(2 * Jm + rr) * a.ldY + kLm0 + 3 * Im + c % 3] =
+                        dot3(cj[0], (double)st3[0], cj[64], (double)st3[kPitch], cj[128], (double)st3[2 * kPitch]);
+                }
+            }
         }
     }
 }

@@ -127,6 +127,8 @@ struct eqf_filter {
     hipEvent_t evGate = nullptr;
     hipEvent_t evMask = nullptr;   // k_set_update_ok has read hGate (resolveGate's redo): recorded before the host may clear it again
     bool maskPending = false;
+    int csInBurst = 1;           // bursts closed by a vision step also leave C Sigma' and S (BurstArgs::csOut; eqf_debug_option "cs_in_burst")
+    bool csValid = false;        // ... and they are still what the update would compute (nothing moved a landmark since)
     int gateSpeculative = 1;     // EQF_GATE_SPECULATIVE = 0: always wait for the gate's answer before the update
     // IMU bursts (eqf_burst.hpp): processIMUData calls are queued on the host and launched together -- when the queue is
     // full, when the vision call that follows them arrives (whose integrateUpToTime joins the burst), or when the host
@@ -505,6 +507,16 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
         a.nBuild = (int)bgrid.x;
         a.nBuildCap = f->nBuildCap;
     }
+    f->csValid = false;
+    // (measured, round 5, steps/s with / without, profiles/r05_cs_in_burst.txt: 64 filters of N = 200 506.6 k / 497.1 k -- prep launch 117 -> 63 us,
+    // block kernel +23 us; N = 1000 7965 / 7887; 16 filters 439.4 / 439.6 k, 8 filters 325.1 / 325.5 k: what the prep launch saves the block
+    // kernel's extra stores cost; 2 filters, whose prep work hides inside the update launch, 119.3 / 120.5 k.  So: with the four-row tiles of
+    // the throughput sizes; "cs_in_burst" = 2 forces it on every two-launch burst -- the bitwise tests do)
+    if (visionLast && !fused && nmx > 0 && (f->csInBurst == 2 || (f->csInBurst && R == 4)) && f->YW && f->SA) {
+        a.csOut = 1;
+        a.YW = f->YW; a.SA = f->SA; a.lmc = f->lmc;
+        a.ldY = f->ldY; a.ldS = f->ldS; a.strideY = f->strideY; a.strideS = f->strideS;
+    }
     const int rc = profiled(f, EQF_PROF_BURST, [&] {
         if (fused) {
             hipLaunchKernelGGL((k_burst_fused<double>), dim3(bgrid.x + rgrid.x, f->B), dim3(kBuildThreads), 0, f->stream, a);
@@ -531,6 +543,7 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     HIPC(hipGetLastError());
     f->pG ^= 1;
     f->pS ^= 1;
+    f->csValid = a.csOut != 0;
     if (K - (visionLast ? 1 : 0) > 0) std::fill(f->devInit.begin(), f->devInit.end(), 1);
     return EQF_OK;
 }
@@ -594,6 +607,7 @@ UpdArgs makeUpdArgs(eqf_filter* f, const double* bearings, long long bearStride,
     a.errflag = f->errflag;
     a.resCounters = f->dResCounters;
     a.prm = f->prm;
+    a.csInBurst = f->csValid ? 1 : 0;
     return a;
 }
 
@@ -656,6 +670,7 @@ void launchFold(dim3 rg, hipStream_t st, const ResArgs& ra, bool pipeHeads, bool
 template <typename T>
 int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, const int* perm, int Nmax) {
     UpdArgs a = makeUpdArgs(f, bearings, bearStride, perm);
+    f->csValid = false;  // (consumed)
     const int B = f->B;
     // Factorisation kernels: k_chol_step64 / k_chol_resident (64-wide block columns, register-chained MFMA panel solves).  (The 32-wide
     // family of round 1 -- k_chol_step<INVERSE>, k_update_reduce, a separate prep launch -- was dominated at every size measured and has
@@ -930,6 +945,7 @@ int launchUpdate(eqf_filter* f, const double* bearings, long long bearStride, co
 // Batch-wide compaction with host keep-lists keep[b] = old indices that survive (ascending).
 int compact(eqf_filter* f, const std::vector<std::vector<int>>& keep) {
     const int B = f->B, cap = f->cap;
+    f->csValid = false;
     int* h = nullptr;
     int slot = 0;
     int rcs = stageAcquire(f->stMap, &h, &slot);
@@ -1198,6 +1214,7 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
     }
     for (int b = 0; b < B; ++b) {
         if (fresh[b].empty()) continue;
+        f->csValid = false;
         const int nOld = nOldV[b], nNew = int(fresh[b].size());
         const long long work = (long long)3 * nNew * (kLm0 + 3 * (nOld + nNew)) * 2;
         const int blocks = int(std::min<long long>(1024, (work + 255) / 256));
@@ -2013,6 +2030,17 @@ int eqf_debug_drop_role(eqf_filter* f, int kind, int role, int R, int C) {
     f->dropRole[0] = kind; f->dropRole[1] = role; f->dropRole[2] = R; f->dropRole[3] = C;
     f->rolesN = -1;  // the role table is rebuilt by the next update
     return EQF_OK;
+}
+
+int eqf_debug_option(eqf_filter* f, const char* name, int value) {
+    if (!f || !name) return EQF_ERR_INVALID;
+    GATE(f);
+    if (!std::strcmp(name, "cs_in_burst")) {
+        f->csInBurst = value;
+        f->csValid = false;
+        return EQF_OK;
+    }
+    return EQF_ERR_INVALID;
 }
 
 int eqf_set_imu_burst(eqf_filter* f, int max_steps) {

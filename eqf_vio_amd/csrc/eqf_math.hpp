@@ -18,6 +18,9 @@ constexpr double kGravity = 9.81;  // eqf_vio/include/eqf_vio/IMUVelocity.h:22
 struct d3 {
     double x, y, z;
 };
+// a0 b0 + a1 b1 + a2 b2 with the roundings pinned (one product, two fused multiply-adds): the rows of C Sigma and the blocks of S are formed
+// by k_update_prep64's landmark waves OR by the burst's block kernel (BurstArgs::csOut), and the two must agree bit for bit.
+EQF_DI double dot3(double a0, double b0, double a1, double b1, double a2, double b2) { return fma(a2, b2, fma(a1, b1, a0 * b0)); }
 EQF_DI d3 mk3(double x, double y, double z) { return d3{x, y, z}; }
 EQF_DI d3 add(d3 a, d3 b) { return d3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 EQF_DI d3 sub(d3 a, d3 b) { return d3{a.x - b.x, a.y - b.y, a.z - b.z}; }

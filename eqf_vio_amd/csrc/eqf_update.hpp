@@ -68,6 +68,8 @@ struct UpdArgs {
     int* errflag;
     int* resCounters;     // [B][4] work counters of k_chol_resident (zeroed by the prep launch), or nullptr
     int pad;              // chain dimensions are padded (with identity) to multiples of this: 32 (k_chol_step) or 64 (k_chol_step64)
+    int csInBurst;        // the landmark columns of C Sigma and S were left by the burst's block kernel (BurstArgs::csOut): the landmark waves
+                          // build the 12 leading columns, the residual, V and the padding only
     int eFromSigma;       // split 64-wide chain, fp64: the E-chain's tiles are first read straight from Sigma (EA = Sigma[6:, 6:] is a plain
                           // offset there) -- prep only copies the LAST block row, the one that holds the identity padding
     Params prm;
@@ -249,13 +251,16 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int bx, int b, int lmBlocks, int wp
     // scalar chain below (residual, chart, lift rows) runs in its shadow.
     constexpr int kPrepGroups = 10;
     T vr[kPrepGroups][3];
+    const bool lead = a.csInBurst != 0;  // (only the 12 leading columns)
     {
-        const int colHi0 = kLm0 + 3 * min(N, kPrepLmChunk);
+        const int colHi0 = lead ? kLm0 : kLm0 + 3 * min(N, kPrepLmChunk);
 #pragma unroll
         for (int u = 0; u < kPrepGroups; ++u) {
             const int cc = min(lane + 64 * u, colHi0 - 1);
+            if (u == 0 || !lead) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) vr[u][q] = s0[(long long)q * ld + cc];
+                for (int q = 0; q < 3; ++q) vr[u][q] = s0[(long long)q * ld + cc];
+            }
         }
     }
     if (valid) {
@@ -282,9 +287,9 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int bx, int b, int lmBlocks, int wp
 #pragma unroll
             for (int c = 0; c < 6; ++c) V[6 * r + c] = C[3 * r] * Z[c] + C[3 * r + 1] * Z[6 + c] + C[3 * r + 2] * Z[12 + c];
     }
-    for (int q0 = 0; q0 < N; q0 += kPrepLmChunk) {
+    for (int q0 = 0; q0 < (lead ? 1 : N); q0 += kPrepLmChunk) {
         const int q1 = min(N, q0 + kPrepLmChunk);
-        const int colLo = (q0 == 0) ? 0 : kLm0 + 3 * q0, colHi = kLm0 + 3 * q1;
+        const int colLo = (q0 == 0) ? 0 : kLm0 + 3 * q0, colHi = lead ? kLm0 : kLm0 + 3 * q1;
         if (valid) {
             // rows 2i, 2i+1 of C*Sigma for this column chunk: lanes stride the columns (coalesced 3-row reads)
             // (4 column groups per trip: 12 independent loads in flight -- Sigma was written by the previous launch on
@@ -305,8 +310,8 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int bx, int b, int lmBlocks, int wp
                     const int cc = col + 64 * u;
                     if (cc < colHi) {
                         const double v0 = (double)vr[u][0], v1 = (double)vr[u][1], v2 = (double)vr[u][2];
-                        sCS0[cc - colLo] = C[0] * v0 + C[1] * v1 + C[2] * v2;
-                        sCS1[cc - colLo] = C[3] * v0 + C[4] * v1 + C[5] * v2;
+                        sCS0[cc - colLo] = dot3(C[0], v0, C[1], v1, C[2], v2);
+                        sCS1[cc - colLo] = dot3(C[3], v0, C[4], v1, C[5], v2);
                     }
                 }
             }
@@ -319,16 +324,16 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int bx, int b, int lmBlocks, int wp
                 prepStore<WT>(&YW[(long long)(2 * i + 1) * a.ldY + col], isz ? dl[1] : sCS1[col - colLo]);
             }
             // S[2i+r][2j+s] = sum_c CS[r][12+3j+c] C_j[s][c]  (+ measurementVariance on the diagonal)
-            for (int j = q0 + lane; j < q1; j += 64) {
+            for (int j = q0 + lane; j < (lead ? 0 : q1); j += 64) {
                 double Cj[6];
 #pragma unroll
                 for (int q = 0; q < 6; ++q) Cj[q] = lmc[(long long)q * cap + j];
                 const double* c0 = &sCS0[kLm0 + 3 * j - colLo];
                 const double* c1 = &sCS1[kLm0 + 3 * j - colLo];
-                double s00 = c0[0] * Cj[0] + c0[1] * Cj[1] + c0[2] * Cj[2];
-                const double s01 = c0[0] * Cj[3] + c0[1] * Cj[4] + c0[2] * Cj[5];
-                const double s10 = c1[0] * Cj[0] + c1[1] * Cj[1] + c1[2] * Cj[2];
-                double s11 = c1[0] * Cj[3] + c1[1] * Cj[4] + c1[2] * Cj[5];
+                double s00 = dot3(c0[0], Cj[0], c0[1], Cj[1], c0[2], Cj[2]);
+                const double s01 = dot3(c0[0], Cj[3], c0[1], Cj[4], c0[2], Cj[5]);
+                const double s10 = dot3(c1[0], Cj[0], c1[1], Cj[1], c1[2], Cj[2]);
+                double s11 = dot3(c1[0], Cj[3], c1[1], Cj[4], c1[2], Cj[5]);
                 if (j == i) {
                     s00 += a.prm.measurementVariance;
                     s11 += a.prm.measurementVariance;

@@ -172,6 +172,12 @@ int eqf_device_error(eqf_filter* f);
  * publishing anything, as if it had never been scheduled: its consumers time out after 0.5 s, bit 128 is raised, the launch unwinds, the
  * covariance downdate does not run.  kind < 0 switches the injection off.  The handle needs eqf_reset / eqf_set_state afterwards. */
 int eqf_debug_drop_role(eqf_filter* f, int kind, int role, int R, int C);
+/* Developer toggles by name (tests and measurements; a production caller needs none of them).  EQF_ERR_INVALID: unknown name.
+ *   "cs_in_burst"  1 (default): an IMU burst closed by a vision step also leaves the landmark columns of C Sigma and S = C Sigma C^T + R,
+ *                  formed from the covariance blocks its workgroups hold in registers; the update's prep work then reads 12 columns of
+ *                  Sigma per landmark instead of all of them -- at the throughput sizes (many filters, N >= 400), where it pays.
+ *                  2: on every burst that runs as two launches.  0: the prep launch forms them.  Bit for bit the same either way. */
+int eqf_debug_option(eqf_filter* f, const char* name, int value);
 
 /* IMU bursts.  processIMUData calls (VIOFilter.cpp:120-131) only depend on each other and on the state, so the library
  * queues them on the host and launches up to 15 of them -- plus the integrateUpToTime of the processVisionData call

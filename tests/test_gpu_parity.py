@@ -1055,3 +1055,79 @@ def test_builder_and_block_workgroups_in_one_launch_equal_the_two_launches(hip, 
     for f, (a, b) in enumerate(zip(*outs)):
         for u, v in zip(a, b):
             assert np.array_equal(u, v), (N, f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,dur", [(2, 200, 0.26), (3, 107, 0.26), (8, 200, 0.26), (1, 600, 0.16), (1, 1100, 0.11)])
+def test_update_operands_left_by_the_burst_equal_the_prep_launch(hip, B, N, dur):
+    """Round 5: a burst closed by a vision step leaves the landmark columns of C Sigma and S = C Sigma C^T + R from the covariance blocks its
+    block workgroups hold in registers (BurstArgs::csOut, every rows-per-wavefront build: 2 filters -> 1 row, 8 filters -> 2, N >= 600 -> 4;
+    N = 1100 is more than one column chunk of the prep waves); the prep launch then reads 12 columns of Sigma per landmark.  The roundings
+    of both are pinned (dot3): bit for bit against the prep launch forming them, after every vision update."""
+    from eqf_vio_amd import synth
+
+    sts = [synth.make_stream(N, seed=900 + b, duration=dur) for b in range(B)]
+    imu = np.stack([s.imu for s in sts], axis=1)
+    vst = np.stack([s.vision_stamps for s in sts], axis=1)
+    bear = np.stack([s.bearings for s in sts], axis=1)
+    d = synth.template_settings_dict()
+    outs = []
+    for on in (2, 0):  # (2: with every rows-per-wavefront build; the default keeps it to the four-row one)
+        fg = hip.FilterBatch(d, capacity=N, batch=B)
+        fg.debug_option("cs_in_burst", on)
+        fg.stream_upload(imu, vst, sts[0].ids, bear)
+        seq = []
+        for kind, k in sts[0].events():
+            if kind == "imu":
+                fg.stream_imu(k)
+            else:
+                fg.stream_vision(k)
+                for b in sorted({0, B // 2, B - 1}):
+                    e = fg.state_estimate(b)
+                    seq.append((fg.sigma(b).copy(), e["x"].copy(), e["q"].copy(), e["p"].copy(), fg.bias(b).copy()))
+        assert fg.device_error() == 0
+        outs.append(seq)
+    assert len(outs[0]) == len(outs[1]) >= 2
+    for f, (a, b) in enumerate(zip(*outs)):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v), (B, N, f)
+
+
+@pytest.mark.gpu
+def test_update_operands_left_by_the_burst_under_churn_and_the_gate(hip):
+    """... and on the per-call API with landmarks entering and leaving and the outlier gate armed: frames that move a landmark between
+    the burst and the update (compaction, new landmarks, a tripped gate's redo) fall back to the prep launch forming the operands."""
+    from eqf_vio_amd import synth
+
+    B, pools = 3, [40, 90, 130]
+    sts = [synth.make_stream(pools[b], seed=177 + b, duration=0.8) for b in range(B)]
+    meas = [synth.churn_measurements(sts[b], seed=15 + b, max_visible=[30, 70, 110][b], outlier_frames=(5, 9) if b % 2 else ())
+            for b in range(B)]
+    d = synth.template_settings_dict()
+    d["outlierThreshold"] = 0.05
+    stride = max(pools)
+    outs = []
+    for on in (2, 0):
+        fg = hip.FilterBatch(d, capacity=max(pools), batch=B)
+        fg.debug_option("cs_in_burst", on)
+        seq = []
+        for kind, k in sts[0].events():
+            if kind == "imu":
+                fg.process_imu([s.imu[k, 0] for s in sts], [s.imu[k, 1:4] for s in sts], [s.imu[k, 4:7] for s in sts])
+            else:
+                ids = np.zeros((B, stride), dtype=np.int32)
+                y = np.zeros((B, stride, 3))
+                nb = np.zeros(B, dtype=np.int32)
+                for b in range(B):
+                    mi, my = meas[b][k]
+                    nb[b] = len(mi)
+                    ids[b, : len(mi)] = mi
+                    y[b, : len(mi)] = my
+                fg.process_vision([s.vision_stamps[k] for s in sts], ids, y, nb=nb)
+                for b in range(B):
+                    seq.append((fg.ids(b).copy(), fg.sigma(b).copy(), fg.state_estimate(b)["x"].copy()))
+        assert fg.device_error() == 0
+        outs.append(seq)
+    for f, (a, b) in enumerate(zip(*outs)):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v), f
