@@ -81,6 +81,11 @@ struct eqf_filter {
     std::vector<std::vector<int>> permOnDevice;  // what dPerm holds (uploadPerm): the same landmark set in the same order needs no new copy
     double *dChord = nullptr, *dDepth2 = nullptr, *dScratch = nullptr, *dMeas = nullptr, *dOut = nullptr;
     IntStage stMap, stPerm;  // pinned rings: [B*cap + B] (map + new counts), [B*cap]
+    IntStage stEdit;         // pinned ring [2*B*cap + 4*B]: keep map | permutation | counts of a k_edit launch (one upload per frame)
+    int* dEdit = nullptr;    // its device image
+    std::vector<int> editOnDevice;  // ... as last uploaded
+    int* dEditBar = nullptr; // [B][4] k_edit's counters
+    int deviceEdit = 1;      // landmark-set changes and the outlier gate of a frame in ONE launch, decided on the device (eqf_debug_option "device_edit")
     double* dDepthSel = nullptr;    // [B] median scene depth selected on the device
     double *hChord = nullptr, *hMeas = nullptr, *hOut = nullptr;
     double* hChordDev = nullptr;  // device-side address of the pinned hChord
@@ -120,6 +125,8 @@ struct eqf_filter {
         std::vector<int> nOld;              // landmarks per filter before the frame's new ones were appended
         const double* bearings = nullptr;   // device
         long long bearStride = 0;
+        bool onDevice = false;              // k_edit removed the outliers itself: only the host's id lists are left to bring up to date
+        std::vector<int> nKept;             // ... kept landmarks per filter (the chords in hChord are in that order)
     } gate;
     int* hGate = nullptr;        // pinned [B]: raised by k_probe
     int* hGateDev = nullptr;     // device-side address of hGate
@@ -1037,6 +1044,122 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
             keep[b] = kept;
         }
     }
+    // ---- round 5: the whole landmark bookkeeping of the frame in one launch (k_edit, eqf_churn.hpp) -- the host's keep list, the outlier
+    // gate evaluated AND acted upon on the device, the new landmarks -- with one upload, and no frame is ever redone.  Not for a redo
+    // itself, filters beyond kEditMax landmarks, a gate whose previous answer is still pending or switched to the synchronous mode, and
+    // -- gate armed -- filters so small that losing a landmark could make their two chains equally long (the update's launch shape is
+    // chosen from the host's count).
+    {
+        const bool gateArmed = !gated && f->set.outlierThreshold < 2.0 && maxN(f) > 0;
+        bool ok = f->deviceEdit && !gated && f->dEdit && (!gateArmed || (f->gateSpeculative && !f->gate.pending));
+        bool anyFresh = false;
+        for (int b = 0; b < B && ok; ++b) {
+            if (int(f->ids[b].size()) > kEditMax) ok = false;
+            if (!active[b]) continue;
+            if (gateArmed && nb[b] < kEditSafeN) ok = false;  // (kept + new landmarks = the measurement's entries)
+            if (nb[b] > int(keep[b].size())) anyFresh = true;  // (every kept id is in the measurement)
+        }
+        if (ok && (anyLost || anyFresh || gateArmed)) {
+            int* h = nullptr;
+            int slot = 0;
+            int rc = stageAcquire(f->stEdit, &h, &slot);
+            if (rc) return rc;
+            std::vector<int> nKept(B, 0);
+            bool anyWork = false;
+            int Nmax = 0;
+            for (int b = 0; b < B; ++b) {
+                int* hm = h + (size_t)b * cap;
+                int* hp = h + (size_t)(B + b) * cap;
+                int* hc = h + (size_t)2 * B * cap + 4 * b;
+                const int nK = int(keep[b].size());
+                nKept[b] = nK;
+                std::copy(keep[b].begin(), keep[b].end(), hm);
+                std::fill(hm + nK, hm + cap, -1);
+                std::vector<int> nid;
+                for (int o : keep[b]) nid.push_back(f->ids[b][o]);
+                int nNew = 0;
+                std::fill(hp, hp + cap, -1);
+                if (active[b]) {
+                    std::vector<char> used(nb[b], 0);
+                    for (int j = 0; j < nK; ++j) {
+                        const int k = int(std::lower_bound(measIds[b], measIds[b] + nb[b], nid[j]) - measIds[b]);
+                        hp[j] = k;
+                        used[k] = 1;
+                    }
+                    if (nK + (nb[b] - nK) > cap) return EQF_ERR_CAPACITY;  // (cannot happen: every entry point checks nb <= capacity)
+                    for (int k = 0; k < nb[b]; ++k)
+                        if (!used[k]) {
+                            hp[nK + nNew++] = k;
+                            nid.push_back(measIds[b][k]);
+                        }
+                }
+                hc[0] = nK; hc[1] = nNew; hc[2] = (gateArmed && active[b]) ? 1 : 0; hc[3] = 0;
+                f->ids[b] = nid;
+                if (!active[b]) continue;
+                if (nid.empty()) {
+                    if (status) status[b] = EQF_SKIPPED_NO_BEARINGS;
+                    continue;
+                }
+                anyWork = true;
+                Nmax = std::max(Nmax, int(nid.size()));
+            }
+            // (a fixed set behind an armed gate: the same image every frame, nothing to upload)
+            const size_t nInts = (size_t)2 * B * cap + 4 * B;
+            if (f->editOnDevice.size() != nInts || !std::equal(h, h + nInts, f->editOnDevice.begin())) {
+                f->editOnDevice.clear();
+                HIPC(hipMemcpyAsync(f->dEdit, h, sizeof(int) * nInts, hipMemcpyHostToDevice, f->stream));
+                HIPC(hipEventRecord(f->stEdit.ev[slot], f->stream));
+                f->editOnDevice.assign(h, h + nInts);
+            }
+            if (gateArmed) {
+                if (f->maskPending) {
+                    HIPC(hipEventSynchronize(f->evMask));
+                    f->maskPending = false;
+                }
+                std::fill(f->hGate, f->hGate + B, 0);
+            }
+            EditArgs ea{};
+            ea.g = f->g[f->pG];
+            ea.in = f->dEdit;
+            ea.permOut = f->dPerm;
+            ea.B = B; ea.cap = cap;
+            ea.bearings = bearings; ea.bearStride = bearStride;
+            ea.gateThr = f->set.outlierThreshold;
+            ea.gateFlag = gateArmed ? f->hGateDev : nullptr;
+            ea.chordOut = gateArmed ? f->hChordDev : nullptr;
+            ea.depthDefault = f->set.initialSceneDepth; ea.pointVar = f->set.initialPointVariance;
+            ea.p0 = f->p0; ea.Q = f->Q[f->pG]; ea.lmc = f->lmc; ea.scratch = f->dScratch;
+            ea.errflag = f->errflag;
+            ea.Scur = f->Sigma[f->pS]; ea.Soth = f->Sigma[f->pS ^ 1];
+            ea.sigmaStride = f->sigmaStride; ea.ld = f->ld;
+            ea.hostFlip = anyLost ? 1 : 0;
+            ea.bar = f->dEditBar;
+            // (co-resident when an outliers-only compaction may have to wait for its workgroups; a frame whose Sigma the host knows to move
+            // anyway waits for nobody: a workgroup per four rows)
+            const int coRes = std::max(1, std::min(64, std::max(f->numCUs, 1) / B));
+            const int G = anyLost ? std::max(coRes, std::min(1024, (kLm0 + 3 * Nmax + 3) / 4)) : coRes;
+            rc = profiled(f, EQF_PROF_CHURN, [&] {
+                if (f->precision == EQF_PRECISION_F32) hipLaunchKernelGGL(k_edit<float>, dim3(G, B), dim3(256), 0, f->stream, ea);
+                else hipLaunchKernelGGL(k_edit<double>, dim3(G, B), dim3(256), 0, f->stream, ea);
+            });
+            if (rc) return rc;
+            HIPC(hipGetLastError());
+            if (anyLost) f->pS ^= 1;
+            f->csValid = false;
+            f->permOnDevice.clear();  // (dPerm now holds what k_edit made of the upload)
+            if (gateArmed) {
+                HIPC(hipEventRecord(f->evGate, f->stream));
+                f->gate.pending = true;
+                f->gate.onDevice = true;
+                f->gate.nKept = nKept;
+                f->gate.active = active;
+                f->gate.bearings = bearings;
+                f->gate.bearStride = bearStride;
+            }
+            if (!anyWork) return EQF_OK;
+            return launchUpdate(f, bearings, bearStride, f->dPerm, Nmax);
+        }
+    }
     if (anyLost) {
         int rc = compact(f, keep);
         if (rc) return rc;
@@ -1100,6 +1223,7 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
         depthFresh = true;
         HIPC(hipEventRecord(f->evGate, f->stream));
         f->gate.pending = true;
+        f->gate.onDevice = false;
         f->gate.ids.assign(B, {});
         f->gate.nOld.assign(B, 0);
         for (int b = 0; b < B; ++b) {
@@ -1247,6 +1371,34 @@ int resolveGate(eqf_filter* f) {
     HIPC(hipEventSynchronize(f->evGate));
     f->gate.pending = false;
     const int B = f->B, cap = f->cap;
+    if (f->gate.onDevice) {
+        // k_edit took the outliers out before the update ran: the ids follow (kept landmark j of the frame is f->ids[b][j])
+        for (int b = 0; b < B; ++b) {
+            if (!f->hGate[b] || !f->gate.active[b]) continue;
+            std::vector<int> nid;
+            const int nK = f->gate.nKept[b];
+            for (int j = 0; j < int(f->ids[b].size()); ++j)
+                if (j >= nK || !(f->hChord[(size_t)b * cap + j] > f->set.outlierThreshold)) nid.push_back(f->ids[b][j]);
+            f->ids[b] = nid;
+        }
+        // (flag 2: the outliers left the filter with so few landmarks that k_edit switched the queued update off -- it runs now, shaped for
+        // the count the host knows by now; nothing else of the frame is repeated)
+        bool deferred = false;
+        int Nmax = 0;
+        for (int b = 0; b < B; ++b) {
+            const bool d = f->hGate[b] == 2 && f->gate.active[b] && !f->ids[b].empty();
+            f->hGate[b] = d ? 1 : 0;
+            if (d) {
+                deferred = true;
+                Nmax = std::max(Nmax, int(f->ids[b].size()));
+            }
+        }
+        if (!deferred) return EQF_OK;
+        hipLaunchKernelGGL(k_set_update_ok, dim3((B + 63) / 64), dim3(64), 0, f->stream, f->g[f->pG], f->hGateDev, B);
+        HIPC(hipEventRecord(f->evMask, f->stream));
+        f->maskPending = true;
+        return launchUpdate(f, f->gate.bearings, f->gate.bearStride, f->dPerm, Nmax);
+    }
     bool any = false;
     std::vector<char> act(B, 0);
     for (int b = 0; b < B; ++b) {
@@ -1316,6 +1468,9 @@ void freeAll(eqf_filter* f) {
     if (f->evMask) hipEventDestroy(f->evMask);
     stageFree(f->stMap);
     stageFree(f->stPerm);
+    stageFree(f->stEdit);
+    hipFree(f->dEdit);
+    hipFree(f->dEditBar);
     for (void* p : {(void*)f->hChord, (void*)f->hMeas,
              (void*)f->hOut, (void*)f->hRing})
         if (p) hipHostFree(p);
@@ -1531,6 +1686,8 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (!rc && hipMemset(f->dFlags, 0, sizeof(int) * 2 * f->flagStride * B) != hipSuccess) rc = EQF_ERR_HIP;
     if (const char* e = std::getenv("EQF_GATE_SPECULATIVE")) f->gateSpeculative = std::atoi(e);
     chk(stageInit(f->stMap, (size_t)cap * B + B)); chk(stageInit(f->stPerm, (size_t)cap * B));
+    chk(stageInit(f->stEdit, (size_t)2 * cap * B + 4 * B)); chk(dmalloc(&f->dEdit, (size_t)2 * cap * B + 4 * B)); chk(dmalloc(&f->dEditBar, (size_t)4 * B));
+    if (!rc && hipMemset(f->dEditBar, 0, sizeof(int) * 4 * B) != hipSuccess) rc = EQF_ERR_HIP;
     chk(hmalloc(&f->hChord, (size_t)cap * B)); chk(dmalloc(&f->dDepthSel, B));
     chk(hmalloc(&f->hGate, B)); chk(dmalloc(&f->dMask, B));
     if (!rc && hipHostGetDevicePointer(reinterpret_cast<void**>(&f->hGateDev), f->hGate, 0) != hipSuccess) rc = EQF_ERR_HIP;
@@ -2035,6 +2192,10 @@ int eqf_debug_drop_role(eqf_filter* f, int kind, int role, int R, int C) {
 int eqf_debug_option(eqf_filter* f, const char* name, int value) {
     if (!f || !name) return EQF_ERR_INVALID;
     GATE(f);
+    if (!std::strcmp(name, "device_edit")) {
+        f->deviceEdit = value ? 1 : 0;
+        return EQF_OK;
+    }
     if (!std::strcmp(name, "cs_in_burst")) {
         f->csInBurst = value;
         f->csValid = false;

@@ -8,6 +8,7 @@
 #include "eqf_math.hpp"
 #include "eqf_propagate.hpp"
 #include "eqf_update.hpp"
+#include "eqf_handoff.hpp"
 
 namespace eqf {
 
@@ -219,6 +220,296 @@ __global__ __launch_bounds__(256) void k_append(Glob* g, int b, int nOld, int nN
         if (bad && errflag) atomicOr(errflag, 16);
     }
     if (tid == 0) g[b].N = nOld + nNew;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_edit (round 5): everything a vision frame does to the landmark SET in one launch, decided on the device --
+//   removeOldLandmarks (VIOFilter.cpp:393-419: the host's keep list, it owns the ids), removeOutliers (:429-443: the chord of every kept
+//   landmark against its measured bearing, here), addNewLandmarks (:345-391: at the median depth of what is left).
+// Before it the same frame took up to five launches and two uploads (compaction, probe, median, append), and a frame whose gate tripped
+// ran a discarded update launch and was redone from the host.  Now the outliers are compacted away right here and the update that
+// follows in the stream sees the final set (N, the permutation into the measurement and the per-landmark arrays are all device-side);
+// the host learns which ids went when it next touches the handle (chordOut / gateFlag in pinned memory: bookkeeping, nothing relaunched).
+//
+// in[b * cap + j]            map: old index of kept landmark j (ascending; the identity if the filter lost nothing)
+// in[(B + b) * cap + i]      perm: measurement entry of landmark i of the order [kept ..., new ...]
+// in[2 * B * cap + 4 * b]    {kept count, new count, gate armed for this filter, -}
+// hostFlip: some filter of the batch lost a landmark, the host already counts on Sigma being in the OTHER buffer afterwards (the ping-pong
+// parity is shared by the batch).  A filter whose only removals are outliers -- the host cannot know -- compacts into the other buffer,
+// waits for its G workgroups (a counting barrier: the launch is sized to be co-resident) and copies the result back.
+// grid = (G, B), block = 256 -- G any number when hostFlip is set (nobody waits for anybody then), at most the co-resident count otherwise;
+// at most kEditMax kept landmarks per filter (the host falls back to the separate launches beyond).
+constexpr int kEditMax = 1024;
+constexpr int kEditSafeN = 59;  // from here on ceil((3 N + 5) / 64) > ceil(2 N / 64): the E-chain is the longer one whatever N is
+struct EditArgs {
+    Glob* g;
+    const int* in;
+    int* permOut;           // [B][cap]: the permutation the update will use
+    int B, cap;
+    const double* bearings;
+    long long bearStride;
+    double gateThr;
+    int* gateFlag;          // pinned [B]: raised if the filter lost an outlier
+    double* chordOut;       // pinned [B][cap]: chord of kept landmark j (gate armed)
+    double depthDefault, pointVar;
+    double *p0, *Q, *lmc, *scratch;
+    int* errflag;
+    const void* Scur;
+    void* Soth;
+    long long sigmaStride;
+    int ld, hostFlip;
+    int* bar;               // [B][4] barrier arrivals, barrier generation, first-phase arrivals, - (zero-initialised once)
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_edit(EditArgs a) {
+    const int b = blockIdx.y, w = blockIdx.x, G = gridDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cap = a.cap;
+    const int* mp = a.in + (long long)b * cap;
+    const int* pm = a.in + (long long)(a.B + b) * cap;
+    const int* cnt = a.in + (long long)2 * a.B * cap + 4 * b;
+    // (the first trip's map and permutation entries are requested together with the counts: one round trip less on the launch's one chain)
+    const int o0 = mp[min(tid, cap - 1)], k0 = pm[min(tid, cap - 1)];
+    const int nK = min(cnt[0], kEditMax), nNew = cnt[1];
+    const bool gate = cnt[2] != 0;
+    const double* P = a.p0 + (long long)b * 3 * cap;
+    const double* q = a.Q + (long long)b * 5 * cap;
+    __shared__ double sD2[kEditMax];
+    __shared__ int sOld[kEditMax];   // old index of FINAL landmark f
+    __shared__ int sFin[kEditMax];   // kept index j of final landmark f
+    __shared__ unsigned long long sMask[kEditMax / 64];
+    __shared__ int sPre[kEditMax / 64 + 1];
+    __shared__ double sDepth;
+    // ---- every workgroup: depth and chord of the kept landmarks, the final keep list (k_probe's expressions)
+    for (int base = 0; base < nK; base += 256) {
+        const int j = base + tid;
+        bool keep = false;
+        if (j < nK) {
+            const int o = base == 0 ? o0 : mp[j];
+            const int k = base == 0 ? k0 : pm[j];
+            double yv[3] = {0.0, 0.0, 1.0};
+            if (gate && k >= 0) {
+                const double* y = a.bearings + (long long)b * a.bearStride + 3 * k;
+                yv[0] = y[0]; yv[1] = y[1]; yv[2] = y[2];
+            }
+            const quat Qq = quat{q[o], q[cap + o], q[2 * cap + o], q[3 * cap + o]};
+            const d3 qhat = scl(1.0 / q[4 * cap + o], qrot(qinv(Qq), mk3(P[o], P[cap + o], P[2 * cap + o])));
+            sD2[j] = dot3(qhat, qhat);
+            double ch = 0.0;
+            if (gate) {
+                if (k >= 0) {
+                    const double* y = yv;
+                    ch = nrm3(sub(mk3(y[0], y[1], y[2]), unit3(qhat)));
+                }
+                if (w == 0 && a.chordOut) a.chordOut[(long long)b * cap + j] = ch;
+            }
+            keep = !(gate && ch > a.gateThr);
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) sMask[(base >> 6) + wv] = m;
+    }
+    __syncthreads();
+    const int nChunks = (nK + 63) >> 6;
+    if (tid == 0) {
+        int acc = 0;
+        for (int c = 0; c < nChunks; ++c) {
+            sPre[c] = acc;
+            acc += __popcll(sMask[c]);
+        }
+        sPre[nChunks] = acc;
+    }
+    __syncthreads();
+    const int nF = nChunks ? sPre[nChunks] : 0;
+    for (int j = tid; j < nK; j += 256) {
+        const unsigned long long m = sMask[j >> 6];
+        if ((m >> (j & 63)) & 1) {
+            const int f = sPre[j >> 6] + __popcll(m & ((1ull << (j & 63)) - 1));
+            sFin[f] = j;
+            sOld[f] = mp[j];
+        }
+    }
+    __syncthreads();
+    // The per-landmark arrays are edited IN PLACE, and every workgroup has just read them: that work goes to the workgroup that finishes
+    // this phase LAST (a counter, nobody waits), at the end of its share of Sigma.
+    // (a frame that edits nothing in place -- the gate armed, nothing tripped, no new landmark -- skips the counter's round trip)
+    const bool tripped = nF != nK;
+    const bool moved = a.hostFlip || tripped;
+    __shared__ int sLast;
+    if (tid == 0) {
+        if (moved || nNew > 0) {
+            int* arr = a.bar + 4 * b + 2;
+            const int old = __hip_atomic_fetch_add(arr, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            sLast = old == G - 1;
+            if (old == G - 1) __hip_atomic_store(arr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            sLast = w == 0;
+        }
+    }
+    __syncthreads();
+    const bool last = sLast != 0;
+    const int nvF = kLm0 + 3 * nF, nvn = kLm0 + 3 * (nF + nNew);
+    const T* src = static_cast<const T*>(a.Scur) + (long long)b * a.sigmaStride;
+    T* const cur = const_cast<T*>(src);
+    T* dst = moved ? static_cast<T*>(a.Soth) + (long long)b * a.sigmaStride : cur;
+    const int ld = a.ld;
+    if (w == 0) {
+        int* po = a.permOut + (long long)b * cap;
+        for (int f = tid; f < nF; f += 256) po[f] = pm[sFin[f]];
+        for (int t = tid; t < nNew; t += 256) po[nF + t] = pm[nK + t];
+    }
+    // ---- Sigma: the kept rows / columns into the other buffer
+    if (moved) {
+        // (four rows per trip: their loads are in flight together -- a load behind a store waits for it, the compiler cannot know they do not alias)
+        for (int Cc = tid; Cc < nvF; Cc += 256) {
+            const int Cs = (Cc < kLm0) ? Cc : kLm0 + 3 * sOld[(Cc - kLm0) / 3] + (Cc - kLm0) % 3;
+            for (int R0 = w; R0 < nvF; R0 += 4 * G) {
+                T v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int R = min(R0 + u * G, nvF - 1);
+                    const int Rs = (R < kLm0) ? R : kLm0 + 3 * sOld[(R - kLm0) / 3] + (R - kLm0) % 3;
+                    v[u] = src[(long long)Rs * ld + Cs];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (R0 + u * G < nvF) dst[(long long)(R0 + u * G) * ld + Cc] = v[u];
+            }
+        }
+    }
+    // ---- Sigma: rows and columns of the new landmarks (zero cross terms, initialPointVariance on the diagonal, :367-390)
+    {
+        const long long total = (long long)(nvn - nvF) * nvn + (long long)nvF * (nvn - nvF);
+        for (long long e = (long long)w * 256 + tid; e < total; e += (long long)G * 256) {
+            int R, Cc;
+            if (e < (long long)(nvn - nvF) * nvn) {
+                R = nvF + (int)(e / nvn);
+                Cc = (int)(e % nvn);
+            } else {
+                const long long f = e - (long long)(nvn - nvF) * nvn;
+                R = (int)(f / (nvn - nvF));
+                Cc = nvF + (int)(f % (nvn - nvF));
+            }
+            dst[(long long)R * ld + Cc] = (R == Cc) ? (T)a.pointVar : (T)0;
+        }
+    }
+    // ---- per-landmark arrays (the workgroup that left the first phase last): compaction through the scratch records, then the new landmarks
+    if (last) {
+        if (moved) {
+            for (int f = tid; f < nF; f += 256) {
+                const int o = sOld[f];
+                double v[kLmRec];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[c] = a.p0[((long long)b * 3 + c) * cap + o];
+#pragma unroll
+                for (int c = 0; c < 5; ++c) v[3 + c] = a.Q[((long long)b * 5 + c) * cap + o];
+#pragma unroll
+                for (int c = 0; c < 15; ++c) v[8 + c] = a.lmc[((long long)b * 15 + c) * cap + o];
+#pragma unroll
+                for (int c = 0; c < kLmRec; ++c) a.scratch[((long long)b * kLmRec + c) * cap + f] = v[c];
+            }
+            __threadfence_block();
+            __syncthreads();
+            for (int f = tid; f < nF; f += 256) {
+                double v[kLmRec];
+#pragma unroll
+                for (int c = 0; c < kLmRec; ++c) v[c] = a.scratch[((long long)b * kLmRec + c) * cap + f];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) a.p0[((long long)b * 3 + c) * cap + f] = v[c];
+#pragma unroll
+                for (int c = 0; c < 5; ++c) a.Q[((long long)b * 5 + c) * cap + f] = v[3 + c];
+#pragma unroll
+                for (int c = 0; c < 15; ++c) a.lmc[((long long)b * 15 + c) * cap + f] = v[8 + c];
+            }
+        }
+        if (nNew > 0) {
+            // median scene depth of what is left (:357-366): k_append's rank counting over the final order
+            if (nF > 0) {
+                for (int i = tid; i < nF; i += 256) {
+                    const double di = sD2[sFin[i]];
+                    int rank = 0;
+                    for (int j = 0; j < nF; ++j) {
+                        const double dj = sD2[sFin[j]];
+                        rank += (dj < di) || (dj == di && j < i);
+                    }
+                    if (rank == nF / 2) sDepth = sqrt(di);
+                }
+            }
+            __syncthreads();
+            const double depth = nF > 0 ? sDepth : a.depthDefault;
+            for (int t = tid; t < nNew; t += 256) {
+                const int i = nF + t;
+                const double* y = a.bearings + (long long)b * a.bearStride + 3 * pm[nK + t];
+                // (the origin landmark as it is STORED is what its constants come from: see k_append)
+                double px = y[0] * depth, py = y[1] * depth, pz = y[2] * depth;
+#if defined(__HIP_DEVICE_COMPILE__)
+                __asm__ volatile("" : "+v"(px), "+v"(py), "+v"(pz));
+#endif
+                a.p0[((long long)b * 3 + 0) * cap + i] = px;
+                a.p0[((long long)b * 3 + 1) * cap + i] = py;
+                a.p0[((long long)b * 3 + 2) * cap + i] = pz;
+                a.Q[((long long)b * 5 + 0) * cap + i] = 1.0;
+                a.Q[((long long)b * 5 + 1) * cap + i] = 0.0;
+                a.Q[((long long)b * 5 + 2) * cap + i] = 0.0;
+                a.Q[((long long)b * 5 + 3) * cap + i] = 0.0;
+                a.Q[((long long)b * 5 + 4) * cap + i] = 1.0;
+                double cst[15];
+                int bad = 0;
+                landmarkConstants(mk3(px, py, pz), cst, &bad);
+                for (int c = 0; c < 15; ++c) a.lmc[((long long)b * 15 + c) * cap + i] = cst[c];
+                if (bad && a.errflag) atomicOr(a.errflag, 16);
+            }
+        }
+        if (tid == 0) {
+            a.g[b].N = nF + nNew;
+            if (tripped && a.gateFlag) {
+                // The update behind this launch was shaped for the host's count.  Below kEditSafeN landmarks the two chains of a filter can
+                // be equally long, which needs another launch shape: if the outliers took the filter there, its update is switched off and
+                // the host runs it when it looks at the flag (2).
+                const bool defer = nF + nNew < kEditSafeN;
+                if (defer) a.g[b].updateOk = 0;
+                a.gateFlag[b] = defer ? 2 : 1;
+            }
+        }
+    }
+    // ---- outliers only: back into the buffer the host counts on
+    if (tripped && !a.hostFlip) {
+        __threadfence();
+        __syncthreads();
+        __shared__ int sOk;
+        if (tid == 0) {
+            int* arr = a.bar + 4 * b;
+            const int gen = __hip_atomic_load(arr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int ok = 1;
+            if (__hip_atomic_fetch_add(arr, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == G - 1) {
+                __hip_atomic_store(arr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(arr + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                long long spins = 0;
+                while (__hip_atomic_load(arr + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1LL << 24)) {  // (never co-resident after all: seconds, not a hang)
+                        ok = 0;
+                        break;
+                    }
+                }
+            }
+            sOk = ok;
+        }
+        __syncthreads();
+        __threadfence();
+        if (!sOk) {
+            if (tid == 0 && a.errflag) atomicOr(a.errflag, kHoErrTimeout);
+            return;
+        }
+        for (int Cc = tid; Cc < nvn; Cc += 256)
+            for (int R0 = w; R0 < nvn; R0 += 4 * G) {
+                T v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = dst[(long long)min(R0 + u * G, nvn - 1) * ld + Cc];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (R0 + u * G < nvn) cur[(long long)(R0 + u * G) * ld + Cc] = v[u];
+            }
+    }
 }
 
 // Restore path: per-landmark constants and cached pose constants recomputed on the device after eqf_set_state.

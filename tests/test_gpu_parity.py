@@ -1131,3 +1131,146 @@ def test_update_operands_left_by_the_burst_under_churn_and_the_gate(hip):
     for f, (a, b) in enumerate(zip(*outs)):
         for u, v in zip(a, b):
             assert np.array_equal(u, v), f
+
+
+def _rotated(y, angle=0.2):
+    axis = np.cross(y, np.array([1.0, 0.3, -0.2]))
+    axis /= np.linalg.norm(axis)
+    return y * np.cos(angle) + np.cross(axis, y) * np.sin(angle)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("peek", [True, False])
+def test_landmark_bookkeeping_and_gate_in_one_launch(oracle_lib, hip, peek):
+    """Round 5 (k_edit): lost landmarks, the outlier gate -- decided AND acted upon on the device, no frame is redone -- and new landmarks in one
+    launch per frame; the host's id lists follow when it next touches the handle.  Two filters of ~90 landmarks with different histories:
+    filter 1 sees outliers on frames 3 and 7 (two at once on 7), both lose and gain landmarks on other frames, frame 9 has everything at
+    once.  Against the oracle after every frame (peek) or only at the end."""
+    from eqf_vio_amd import synth
+
+    B, pool = 2, 120
+    sts = [synth.make_stream(pool, seed=610 + b, duration=0.6) for b in range(B)]
+    d = synth.template_settings_dict()
+    d["outlierThreshold"] = 0.05
+    fos = [oracle_lib.OracleFilter(d) for _ in range(B)]
+    fg = hip.FilterBatch(d, capacity=pool, batch=B)
+    lo, hi = [0, 0], [90, 85]
+    for kind, k in sts[0].events():
+        if kind == "imu":
+            for b in range(B):
+                r = sts[b].imu[k]
+                fos[b].processIMUData(r[0], r[1:4], r[4:7])
+            fg.process_imu([s.imu[k, 0] for s in sts], [s.imu[k, 1:4] for s in sts], [s.imu[k, 4:7] for s in sts])
+            continue
+        if k in (4, 9):
+            lo[0] += 3; hi[0] += 6
+        if k in (5, 9):
+            lo[1] += 2; hi[1] += 4
+        ids = np.zeros((B, pool), dtype=np.int32)
+        y = np.zeros((B, pool, 3))
+        nb = np.zeros(B, dtype=np.int32)
+        for b in range(B):
+            sel = np.arange(lo[b], hi[b])
+            yy = sts[b].bearings[k, sel].copy()
+            if b == 1 and k in (3, 7, 9):
+                yy[5] = _rotated(yy[5])
+                if k == 7:
+                    yy[40] = _rotated(yy[40], 0.3)
+            fos[b].processVisionData(sts[b].vision_stamps[k], sts[b].ids[sel], yy)
+            nb[b] = len(sel)
+            ids[b, : len(sel)] = sts[b].ids[sel]
+            y[b, : len(sel)] = yy
+        fg.process_vision([s.vision_stamps[k] for s in sts], ids, y, nb=nb)
+        if peek:
+            for b in range(B):
+                assert fg.num_landmarks(b) == fos[b].N, (k, b)
+                assert np.array_equal(fg.ids(b), fos[b].ids()), (k, b)
+                assert rel_fro(fg.sigma(b), fos[b].stateCovariance()) < SIGMA_TOL, (k, b)
+    for b in range(B):
+        assert np.array_equal(fg.ids(b), fos[b].ids())
+        assert rel_fro(fg.sigma(b), fos[b].stateCovariance()) < SIGMA_TOL
+        eo, eg = fos[b].stateEstimate(), fg.state_estimate(b)
+        assert np.abs(eo["x"] - eg["x"]).max() < POSE_TOL and np.abs(eo["q"] - eg["q"]).max() < POSE_TOL
+    assert fg.device_error() == 0
+
+
+@pytest.mark.gpu
+def test_gate_that_leaves_a_filter_too_small_for_the_queued_update(oracle_lib, hip):
+    """k_edit's deferral: 62 landmarks, five outliers in one frame -> 57, where a filter's two chains can be equally long and the update
+    queued behind the launch (shaped for 62) must not run: it is switched off on the device and launched by the host, correctly shaped, when
+    it looks at the gate's answer."""
+    from eqf_vio_amd import synth
+
+    N = 62
+    st = synth.make_stream(N, seed=77, duration=0.4)
+    d = synth.template_settings_dict()
+    d["outlierThreshold"] = 0.05
+    fo = oracle_lib.OracleFilter(d)
+    fg = hip.FilterBatch(d, capacity=N, batch=1)
+    ids = st.ids
+    for kind, k in st.events():
+        if kind == "imu":
+            r = st.imu[k]
+            fo.processIMUData(r[0], r[1:4], r[4:7])
+            fg.process_imu([r[0]], r[1:4], r[4:7])
+            continue
+        y = st.bearings[k].copy()
+        if k == 3:
+            for i in (4, 9, 17, 33, 50):
+                y[i] = _rotated(y[i])
+        if k == 4:
+            ids = fo.ids().copy()  # (the reference would re-add them as new landmarks: keep the set at 57 instead)
+        sel = np.searchsorted(st.ids, ids)
+        fo.processVisionData(st.vision_stamps[k], ids, y[sel])
+        fg.process_vision([st.vision_stamps[k]], ids, y[sel])
+        if k == 3:
+            assert fo.N == 57
+    assert fg.num_landmarks() == fo.N == 57
+    assert np.array_equal(fg.ids(), fo.ids())
+    assert rel_fro(fg.sigma(), fo.stateCovariance()) < SIGMA_TOL
+    eo, eg = fo.stateEstimate(), fg.state_estimate()
+    assert np.abs(eo["x"] - eg["x"]).max() < POSE_TOL and np.abs(eo["q"] - eg["q"]).max() < POSE_TOL
+    assert fg.device_error() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [0, 1])
+def test_one_launch_bookkeeping_equals_the_separate_launches(hip, precision):
+    """... and bit for bit what the separate launches leave (compaction, probe + host decision, append; eqf_debug_option "device_edit" = 0): the
+    same data movement, the same median, the same update -- three filters with churn every frame and the gate at a level that trips."""
+    from eqf_vio_amd import synth
+
+    B, pools = 3, [240, 270, 300]  # (a third of a pool is in view on the first frame: every frame has >= kEditSafeN entries)
+    sts = [synth.make_stream(pools[b], seed=277 + b, duration=0.8) for b in range(B)]
+    meas = [synth.churn_measurements(sts[b], seed=25 + b, max_visible=[150, 200, 260][b], outlier_frames=(5, 9) if b % 2 else (7,), outlier_angle=0.2)
+            for b in range(B)]
+    d = synth.template_settings_dict()
+    d["outlierThreshold"] = 0.05
+    stride = max(pools)
+    outs = []
+    for on in (1, 0):
+        fg = hip.FilterBatch(d, capacity=max(pools), batch=B, precision=precision)
+        fg.debug_option("device_edit", on)
+        seq = []
+        for kind, k in sts[0].events():
+            if kind == "imu":
+                fg.process_imu([s.imu[k, 0] for s in sts], [s.imu[k, 1:4] for s in sts], [s.imu[k, 4:7] for s in sts])
+            else:
+                ids = np.zeros((B, stride), dtype=np.int32)
+                y = np.zeros((B, stride, 3))
+                nb = np.zeros(B, dtype=np.int32)
+                for b in range(B):
+                    mi, my = meas[b][k]
+                    nb[b] = len(mi)
+                    ids[b, : len(mi)] = mi
+                    y[b, : len(mi)] = my
+                fg.process_vision([s.vision_stamps[k] for s in sts], ids, y, nb=nb)
+                for b in range(B):
+                    seq.append((fg.ids(b).copy(), fg.sigma(b).copy(), fg.state_estimate(b)["x"].copy()))
+        assert fg.device_error() == 0
+        outs.append(seq)
+    changed = sum(1 for i in range(B, len(outs[0])) if not np.array_equal(outs[0][i][0], outs[0][i - B][0]))
+    assert changed >= 10  # (the landmark set did change on most frames)
+    for f, (a, b) in enumerate(zip(*outs)):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v), f
