@@ -176,7 +176,11 @@ int eqf_debug_drop_role(eqf_filter* f, int kind, int role, int R, int C);
  *   "cs_in_burst"  1 (default): an IMU burst closed by a vision step also leaves the landmark columns of C Sigma and S = C Sigma C^T + R,
  *                  formed from the covariance blocks its workgroups hold in registers; the update's prep work then reads 12 columns of
  *                  Sigma per landmark instead of all of them -- at the throughput sizes (many filters, N >= 400), where it pays.
- *                  2: on every burst that runs as two launches.  0: the prep launch forms them.  Bit for bit the same either way. */
+ *                  2: on every burst that runs as two launches.  0: the prep launch forms them.  Bit for bit the same either way.
+ *   "device_edit"  1 (default): a vision frame's landmark bookkeeping -- the landmarks that left (VIOFilter.cpp:393-419), the outlier gate
+ *                  (:429-443), the new landmarks (:345-391) -- is ONE launch that decides and acts on the device; the id lists of the handle
+ *                  follow when the caller next touches it and no frame is redone.  0: separate launches, a frame with an outlier is redone
+ *                  from the host.  Bit for bit the same either way. */
 int eqf_debug_option(eqf_filter* f, const char* name, int value);
 
 /* IMU bursts.  processIMUData calls (VIOFilter.cpp:120-131) only depend on each other and on the state, so the library
