@@ -112,9 +112,9 @@ struct eqf_filter {
     void *dF = nullptr, *dG = nullptr, *dBn = nullptr;  // dense backend: F, G = F Sigma, Bn (n x 6)
     void* dBlk = nullptr;          // split propagate path: per-landmark records [B][cap][kBlkRec] (T)
     CommonLds* dBlkCommon = nullptr;
-    int streamPropagate = 1;       // split path: landmark blocks by k_riccati_stream (EQF_STREAM_PROPAGATE = 0: by the tile kernel)
+    int streamPropagate = 1;       // split path: landmark blocks by k_riccati_stream ([no switch since round 5]: by the tile kernel)
     int splitPropagate = -1;       // -1 heuristic, 0 never, 1 always (EQF_SPLIT_PROPAGATE)
-    int cholEmbed = 1;             // EQF_CHOL_EMBED = 0: downdate + innovation lift as a launch of their own
+    int cholEmbed = 1;             // [no switch since round 5]: downdate + innovation lift as a launch of their own
     bool ldsAttrSet[2] = {false, false};  // hipFuncAttributeMaxDynamicSharedMemorySize applied on this handle's device
     // speculative outlier gate: the frame whose gate answer the host has not looked at yet
     struct {
@@ -142,7 +142,7 @@ struct eqf_filter {
     // touches the handle in any other way.  burstMax = 0: every call launches at once through k_propagate.
     int burstMax = kBurstMax;      // EQF_IMU_BURST / eqf_set_imu_burst
     int burstRows = 0;             // block kernel: row landmarks per wavefront, 0 = by launch size (EQF_BURST_ROWS = 1 | 2 | 4)
-    int burstLm = 0;               // builder: landmarks per workgroup, 0 = by launch size (EQF_BURST_LM = 4 | 16)
+    int burstLm = 0;               // builder: landmarks per workgroup, 0 = by launch size ([no switch since round 5])
     struct {
         int kind = 0;              // 0 nothing pending, 1 records k0 .. k0+cnt-1 of the uploaded stream, 2 inline records (one filter)
         int k0 = 0, cnt = 0;
@@ -151,14 +151,14 @@ struct eqf_filter {
     void *dColRec = nullptr, *dRowRec = nullptr;  // per step and landmark records of k_burst_build
     BurstStep* dSteps = nullptr;
     int cholSplit = -1;            // -1 heuristic, 0 fused chain launches, 1 panel + update launches (EQF_CHOL_SPLIT)
-    int cholTail = 1;              // split chain: update launches also solve the next block column (EQF_CHOL_TAIL = 0: panel + update launches)
+    int cholTail = 1;              // split chain: update launches also solve the next block column ([no switch since round 5]: panel + update launches)
     int* dFlags = nullptr;         // [B][2][flagStride]: epoch flags of the in-launch hand-off of the diagonal-factor records
     int flagStride = 0;
     int updateEpoch = 0;           // one per launchUpdate
     // k_chol_resident (one launch per update while the grid fits the chip): EQF_CHOL_RESIDENT = 0 switches it off
     int cholResident = 1;
-    int resOversub = -1;           // EQF_RES_OVERSUB: roles per CU up to which the resident kernel is used on a grid larger than the chip; -1 = no limit
-    int resStaged = 1;             // row heads consume D[R-1] stage by stage (EQF_RES_STAGED = 0: whole record after its last pivot)
+    int resOversub = -1;           // [no switch since round 5]: roles per CU up to which the resident kernel is used on a grid larger than the chip; -1 = no limit
+    int resStaged = 1;             // row heads consume D[R-1] stage by stage ([no switch since round 5]: whole record after its last pivot)
     int resFoldPrep = 1;           // co-resident grid: the prep work as roles of the SAME launch (EQF_RES_FOLD_PREP = 0: k_update_prep64 launched first)
     int* dPrepFlags = nullptr;     // [B][nPrepCap]
     int nPrepCap = 0;
@@ -167,18 +167,18 @@ struct eqf_filter {
     int nBuildCap = 0, burstEpoch = 0;
     bool rolesFold = false;
     int residentPerCU = -1;        // hipOccupancyMaxActiveBlocksPerMultiprocessor of k_chol_resident on this device (lazily queried)
-    int eFromSigma = 1;            // split chain: block column 0 of the E-chain read straight from Sigma (EQF_E_FROM_SIGMA=0: copied by prep)
-    int cholOrder = -1;            // order of the workgroup classes in an update launch, -1 = by launch size (EQF_CHOL_ORDER = 0 | 1 | 2)
-    int cholStreams = 0;           // stream workgroups per filter of an update launch, 0 = by launch size (EQF_CHOL_STREAMS)
+    int eFromSigma = 1;            // split chain: block column 0 of the E-chain read straight from Sigma ([no switch since round 5]: copied by prep)
+    int cholOrder = -1;            // order of the workgroup classes in an update launch, -1 = by launch size ([no switch since round 5])
+    int cholStreams = 0;           // stream workgroups per filter of an update launch, 0 = by launch size ([no switch since round 5])
     int numCUs = 0;
     int nbCap = 0, wtCap = 0;
     int *dReadyA = nullptr, *dReadyY = nullptr, *dResCounters = nullptr, *dStageFlags = nullptr;
     double *dGammaPart = nullptr, *dG11Part = nullptr;
     ResRole* dRoles = nullptr;
-    int resPipeHeads = -1;         // EQF_RES_PIPEH: row heads with the pipelined panel loop (1), without (0), by grid size (-1)
-    int prepOcc2 = -1;             // EQF_PREP_OCC2: the prep launch built for two workgroups per CU (1), one (0), by launch size (-1)
-    int burstOcc2 = -1;            // EQF_BURST_OCC2: the 16-landmark builder built for two workgroups per CU (1), one (0), by launch size (-1)
-    int resOcc2 = -1;              // EQF_RES_OCC2: k_chol_resident built for two workgroups per CU (1), one (0), by grid size (-1)
+    int resPipeHeads = -1;         // [no switch since round 5]: row heads with the pipelined panel loop (1), without (0), by grid size (-1)
+    int prepOcc2 = -1;             // [no switch since round 5]: the prep launch built for two workgroups per CU (1), one (0), by launch size (-1)
+    int burstOcc2 = -1;            // [no switch since round 5]: the 16-landmark builder built for two workgroups per CU (1), one (0), by launch size (-1)
+    int resOcc2 = -1;              // [no switch since round 5]: k_chol_resident built for two workgroups per CU (1), one (0), by grid size (-1)
     int rolesN = -1, rolesCount = 0;  // chain shape (nbS, nbE, wtS) the role table was built for
     int rolesFront = 0;               // roles in front of the prep roles (buildRoles' `front`)
     int resFoldFront = 1;             // EQF_RES_FOLD_FRONT: dependency groups of the E-chain in front of the prep roles of a batch
@@ -413,7 +413,7 @@ int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, con
         if (split) {
             const dim3 bgrid((std::max(1, maxN(f)) + 63) / 64 + 1, f->B);  // landmark workgroups + the scalar-state workgroup
             // builder (blocks + G rows + group step + scalar state), then everything of Sigma by the lean streaming kernel
-            // (EQF_STREAM_PROPAGATE=0: by the tile kernel instead -- kept as a cross-check)
+            // ([no switch since round 5]: by the tile kernel instead -- kept as a cross-check)
             const int nmx = std::max(1, maxN(f));
             const dim3 sgrid((nmx + 255) / 256, (nmx + kStreamRows - 1) / kStreamRows, f->B);
             if (f->precision == EQF_PRECISION_F32) {
@@ -794,7 +794,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         // Since the build for two workgroups per CU (k_chol_resident's OCC2, late in round 3) the resident kernel wins at EVERY size measured
         // -- 24 / 32 / 64 / 96 filters of N = 200: 386 -> 447 k, 410 -> 479 k, 453 -> 509 k, 478 -> 507 k steps/s; one filter of N = 1500 / 2000 /
         // 3000 / 4000: 2.23 -> 2.85 k, 1053 -> 1335, 344 -> 406, 151 -> 174 -- so the default is "whenever its buffers exist"; the per-column
-        // launches remain for EQF_CHOL_RESIDENT=0 / EQF_RES_OVERSUB and for filters whose chains are equally long (a handful of landmarks).
+        // launches remain for EQF_CHOL_RESIDENT=0 / [no switch since round 5] and for filters whose chains are equally long (a handful of landmarks).
         const long long oversub = f->resOversub >= 0 ? f->resOversub : 1000000;
         resident = f->cholResident >= 2 || residentFits || (long long)f->rolesCount * B <= oversub * f->numCUs;
         // the builds of the kernel: row heads with the pipelined panel loop on grids larger than the chip (PIPEH), two workgroups per CU when
@@ -807,10 +807,15 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         resESigma = resOcc2 && resPipeHeads && perCU > 8.0;  // (8 filters of N = 200, 6.3 roles per CU: the kernel loses what the prep launch gains)
     }
     a.eFromSigma = (!resident && splitChain && f->cholTail && f->eFromSigma && f->precision != EQF_PRECISION_F32) ? 1 : 0;
-    // (the OCC2 build reads the E-chain's tiles straight from Sigma: no copy in the prep launch; EQF_E_FROM_SIGMA=0: copied)
+    // (the OCC2 build reads the E-chain's tiles straight from Sigma: no copy in the prep launch; [no switch since round 5]: copied)
     if (resESigma && f->eFromSigma && f->precision != EQF_PRECISION_F32) a.eFromSigma = 2;
     fold = fold && resident;
     if (fold) a.eFromSigma = 2;
+    // (round 5, measured and dropped: with the burst's operands in place, the landmark work as one LANE per landmark -- 128 per workgroup, the
+    // stores from an LDS image -- instead of one wavefront: bit for bit the same and no faster.  Such a workgroup takes 21-31 us (33
+    // uncoalesced loads per lane, then the stores) against 12.7 us for the 4-landmark ones, and a launch of 64 filters is three dispatch
+    // rounds each as long as its longest workgroup: 63 -> 65 us; N = 1000 18 -> 82 us (one workgroup wrote all the padding rows).
+    // profiles/r05_prep_stamps.txt)
     if (!fold) rc = profiled(f, EQF_PROF_UPDATE_PREP, [&] {
         // the landmark waves + E-chain operand + two more workgroups per filter that factor the first diagonal block of each chain
         // straight from Sigma (one launch: measured never slower than a separate factor launch, 4..64 filters)

@@ -622,7 +622,7 @@ EQF_DI void factorFirstFromSigma(const UpdArgs& a, const ChainArgs& ch, int b, c
 // k_update_prep + the two first-block workgroups (grid.x = lmBlocks + eBlocks + 2)
 #ifdef EQF_PREP_STAMPS
 __device__ long long g_prepStamps[512][2];  // per workgroup: first / last cycle
-#define EQF_PREPSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 512 && blockIdx.y == 0) g_prepStamps[blockIdx.x][k] = __builtin_readcyclecounter(); } while (0)
+#define EQF_PREPSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 512 && blockIdx.y == 0) g_prepStamps[blockIdx.x][k] = wall_clock64(); } while (0)
 #else
 #define EQF_PREPSTAMP(k) do { } while (0)
 #endif

@@ -285,7 +285,7 @@ EQF_DI void updatePrepBody(const UpdArgs& a, int bx, int b, int lmBlocks, int wp
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int c = 0; c < 6; ++c) V[6 * r + c] = C[3 * r] * Z[c] + C[3 * r + 1] * Z[6 + c] + C[3 * r + 2] * Z[12 + c];
+            for (int c = 0; c < 6; ++c) V[6 * r + c] = dot3(C[3 * r], Z[c], C[3 * r + 1], Z[6 + c], C[3 * r + 2], Z[12 + c]);
     }
     for (int q0 = 0; q0 < (lead ? 1 : N); q0 += kPrepLmChunk) {
         const int q1 = min(N, q0 + kPrepLmChunk);
