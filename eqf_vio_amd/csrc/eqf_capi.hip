@@ -85,6 +85,12 @@ struct eqf_filter {
     int* dEdit = nullptr;    // its device image
     std::vector<int> editOnDevice;  // ... as last uploaded
     int* dEditBar = nullptr; // [B][4] k_edit's counters
+    // OCC2 grids from this many roles per CU on read the E-chain's tiles in Sigma itself instead of a copy made by the prep launch
+    // (eqf_debug_option "e_sigma_min_percu_x10").  8.0 until late round 5 ("at 8 filters of N = 200, 6.3 roles per CU, the kernel loses what
+    // the prep launch gains"); measured again behind the gated downdate: 8 filters 323.5 -> 331.3 k steps/s (prep 29.6 -> 19.2 us, kernel
+    // 158.9 -> 164.1), 10 filters 345.7 -> 354.3 k; 5 / 6 / 7 filters 232.0 -> 232.9 k, 259.6 -> 262.1 k, 292.1 -> 296.8 k: every grid of the
+    // two-per-CU build (chain roles per CU: 0.57 per filter of N = 200; profiles/r05_e_sigma_threshold.txt)
+    double eSigmaMinPerCU = 2.4;
     int deviceEdit = 1;      // landmark-set changes and the outlier gate of a frame in ONE launch, decided on the device (eqf_debug_option "device_edit")
     double* dDepthSel = nullptr;    // [B] median scene depth selected on the device
     double *hChord = nullptr, *hMeas = nullptr, *hOut = nullptr;
@@ -804,7 +810,7 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         // (round 4, measured at N = 200: two per CU wins from 5 filters on -- 5 / 6 / 7 filters 217 -> 227 k, 242 -> 255 k, 270 -> 280 k steps/s -- and
         // loses below: 4 filters 210 -> 195 k; one filter of N = 400, three roles per CU, 33.5 -> 32.5 k)
         resOcc2 = resident && (f->resOcc2 >= 0 ? f->resOcc2 != 0 : (resPipeHeads && (perCU > 6.0 || (B >= 5 && perCU > 2.4))));
-        resESigma = resOcc2 && resPipeHeads && perCU > 8.0;  // (8 filters of N = 200, 6.3 roles per CU: the kernel loses what the prep launch gains)
+        resESigma = resOcc2 && resPipeHeads && perCU > f->eSigmaMinPerCU;
     }
     a.eFromSigma = (!resident && splitChain && f->cholTail && f->eFromSigma && f->precision != EQF_PRECISION_F32) ? 1 : 0;
     // (the OCC2 build reads the E-chain's tiles straight from Sigma: no copy in the prep launch; [no switch since round 5]: copied)
@@ -2197,6 +2203,10 @@ int eqf_debug_drop_role(eqf_filter* f, int kind, int role, int R, int C) {
 int eqf_debug_option(eqf_filter* f, const char* name, int value) {
     if (!f || !name) return EQF_ERR_INVALID;
     GATE(f);
+    if (!std::strcmp(name, "e_sigma_min_percu_x10")) {
+        f->eSigmaMinPerCU = value / 10.0;
+        return EQF_OK;
+    }
     if (!std::strcmp(name, "device_edit")) {
         f->deviceEdit = value ? 1 : 0;
         return EQF_OK;
