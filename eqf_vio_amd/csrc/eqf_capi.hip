@@ -91,6 +91,12 @@ struct eqf_filter {
     // 158.9 -> 164.1), 10 filters 345.7 -> 354.3 k; 5 / 6 / 7 filters 232.0 -> 232.9 k, 259.6 -> 262.1 k, 292.1 -> 296.8 k: every grid of the
     // two-per-CU build (chain roles per CU: 0.57 per filter of N = 200; profiles/r05_e_sigma_threshold.txt)
     double eSigmaMinPerCU = 2.4;
+    // the fused burst launch up to this many workgroups per CU (eqf_debug_option "burst_fused_max_x10").  It cannot deadlock on any grid (builders
+    // first, and they wait for nobody), but its bodies are the latency ones -- 4-landmark builders, one row per wavefront, 512 threads:
+    // measured at N = 200 (profiles/r05_fused_oversub.txt, steps/s, two launches -> fused): 2 filters (1.2 per CU) 120.3 -> 122.3 k; 3 filters
+    // (1.8) 167.7 -> 160.0 k; 4: 214.8 -> 192.9 k; 8: 331 -> 266 k.  A fused launch for batches would need the throughput bodies (16-landmark
+    // builders, two / four rows per wavefront) with the flag protocol: sized at 27 us of a 262 us frame at 8 filters, not built.
+    double fusedMaxPerCU = 1.25;
     int deviceEdit = 1;      // landmark-set changes and the outlier gate of a frame in ONE launch, decided on the device (eqf_debug_option "device_edit")
     double* dDepthSel = nullptr;    // [B] median scene depth selected on the device
     double *hChord = nullptr, *hMeas = nullptr, *hOut = nullptr;
@@ -488,7 +494,11 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     // builder: 4 landmarks per workgroup (its eight stages on eight wavefronts, shortest tick) while that launch fits the chip,
     // 16 per workgroup (four panel waves, full lanes) otherwise
     const int cus = std::max(f->numCUs, 1);
-    const int lm = f->burstLm ? f->burstLm : ((long long)((nmx + 3) / 4) * f->B <= cus ? 4 : 16);
+    // (the fused launch -- 4-landmark builders + one-row block workgroups -- is deadlock-free on any grid: up to fusedMaxPerCU workgroups per CU)
+    int rb1 = 0;
+    const bool fusedFits = f->burstFused && nmx > 0 && f->precision != EQF_PRECISION_F32 && f->dBuildFlags &&
+                           (double)((nmx + 3) / 4 + ringTiles(nmx, 1, &rb1)) * f->B <= f->fusedMaxPerCU * cus;
+    const int lm = f->burstLm ? f->burstLm : (((long long)((nmx + 3) / 4) * f->B <= cus || fusedFits) ? 4 : 16);
     const dim3 bgrid(std::max(1, (nmx + lm - 1) / lm), f->B);
     // (round 5: the 4-landmark builder built for two workgroups per CU so that 8 filters keep its short ticks -- 400 workgroups on 512 slots --
     // measured: 70.9 against 71.0 us per burst, nothing; not kept)
@@ -502,14 +512,14 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     // wavefront, twice the workgroups: 4 filters 62.8 -> 51.4 us per burst, 8: 75.7 -> 71.1, 12: 94.0 -> 89.6; 16: 101 -> 106)
     int rowTiles4 = 0;
     const int R = f->burstRows ? f->burstRows
-                               : (waves1 <= 11LL * cus ? 1 : ((long long)ringTiles(nmx, 4, &rowTiles4) * f->B <= 3LL * cus / 2 ? 2 : 4));
+                               : ((waves1 <= 11LL * cus || fusedFits) ? 1 : ((long long)ringTiles(nmx, 4, &rowTiles4) * f->B <= 3LL * cus / 2 ? 2 : 4));
     const dim3 rgrid(ringTiles(nmx, R, &a.ringBy), f->B);  // (the tiles on and below the diagonal)
     // every filter past its lazy initialisation (VIOFilter.cpp:122-124): the schedule with the precomputed step halves
     const bool fast = allDevInit(f);
     // the latency case in ONE launch: the block workgroups consume a step's records as soon as the builders have them in memory
     // (k_burst_fused).  Only while every workgroup of the launch has a CU of its own; fp64.
     const bool fused = f->burstFused && fast && lm == 4 && R == 1 && nmx > 0 && f->precision != EQF_PRECISION_F32 && f->dBuildFlags &&
-                       (long long)(bgrid.x + rgrid.x) * f->B <= cus && (int)bgrid.x <= f->nBuildCap - 1088;
+                       fusedFits && (int)bgrid.x <= f->nBuildCap - 1088;
     if (fused) {
         if (f->burstEpoch >= (1 << 25)) {  // (flags are epoch * 32 + steps: start over long before the int wraps)
             HIPC(hipMemsetAsync(f->dBuildFlags, 0, sizeof(int) * f->nBuildCap * kFlagReplicas * f->B, f->stream));
@@ -2205,6 +2215,10 @@ int eqf_debug_option(eqf_filter* f, const char* name, int value) {
     GATE(f);
     if (!std::strcmp(name, "e_sigma_min_percu_x10")) {
         f->eSigmaMinPerCU = value / 10.0;
+        return EQF_OK;
+    }
+    if (!std::strcmp(name, "burst_fused_max_x10")) {
+        f->fusedMaxPerCU = value / 10.0;
         return EQF_OK;
     }
     if (!std::strcmp(name, "device_edit")) {
