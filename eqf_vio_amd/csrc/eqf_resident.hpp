@@ -437,7 +437,17 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         // ---- a downdate tile of filter blockIdx.x.  These workgroups have the HIGHEST block indices: they are dispatched when
         // the role workgroups in front of them have been, i.e. during the last block columns of the E-chain, and they wait -- for LOWER
         // block indices only -- until the S-chain's last Y tile is out (it usually is).  The downdate overlaps the tail of the longer chain.
-        const int bb = bIdx, tile = roleIdx - ra.nRoles, t = threadIdx.x;
+        // Which tile of which filter: with a batch that is a multiple of 8 the workgroups of filter b all run on XCD b mod 8, and in dispatch
+        // order (filter fastest) an XCD would hold the same few tiles of ALL its filters at a time -- at 64 filters 8 x 2.3 MB of Y against 4 MB
+        // of L2: every panel came from the memory side again (3520 tiles x 458 KB = 1.6 GB per update, the 330 us tail of the launch at the
+        // MALL's rate; profiles/r05_res_stamps_B64.txt).  So within an XCD the tiles run filter by filter: one filter's Y at a time.
+        int bb = bIdx, tile = roleIdx - ra.nRoles;
+        if ((nB & 7) == 0 && nB > 8) {
+            const int seq = tile * (nB >> 3) + (bIdx >> 3);
+            bb = (bIdx & 7) + 8 * (seq / ra.nDdTiles);
+            tile = seq % ra.nDdTiles;
+        }
+        const int t = threadIdx.x;
         const Glob& gg = ra.a.g[bb];
         int late = 0;
 #ifdef EQF_RES_STAMPS
@@ -480,13 +490,27 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         // 65 .. 120 us into a launch whose last Y tile comes at 128), so each wave waits for the two Y tiles of a block row right before it
         // asks for that block row's first chunk -- one lane per wave, long sleeps (see above) -- and the downdate ends a few microseconds after
         // the S-chain's last right-hand-side tile instead of 45 us after it.
+        // (A tile that is dispatched when the S-chain is through -- all of them on a grid many times the chip: 64 filters -- would still pay
+        // two dependent flag reads per block row, ~2.5 us each time with every wave of the workgroup behind the next barrier: 7 block rows, a
+        // third of the tile's 50 us.  So every look also reads the column tiles' flags of the LAST block row, in the same round trip: a tile
+        // of block row C is only solved after the tiles above it, so once those two are out nothing is looked at again.)
+        int nSrows = 1, wSdummy = 0;
+        if (kGated && gg.updateOk && gg.N != 0) chainDims64(ra.c0, gg.N, &nSrows, &wSdummy);
+        int allOut = 0;
         auto gate = [&](int C, int ti, int tj) -> bool {
-            int ok = 1;
+            if (allOut) return true;
+            int ok = 1, all = 0;
             if ((t & 63) == 0) {
                 const long long t0 = wall_clock64();
                 const int* f0 = ryAll + C * ra.wtCap + ti;
                 const int* f1 = ryAll + C * ra.wtCap + tj;
-                for (int i = 0; i < 2 && ok; ++i) {
+                const int* l0 = ryAll + (nSrows - 1) * ra.wtCap + ti;
+                const int* l1 = ryAll + (nSrows - 1) * ra.wtCap + tj;
+                const int v0 = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v1 = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int w0 = __hip_atomic_load(l0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), w1 = __hip_atomic_load(l1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                all = (w0 == ra.c0.epoch && w1 == ra.c0.epoch) ? 1 : 0;
+                for (int i = 0; i < 2 && ok && !all; ++i) {
+                    if ((i ? v1 : v0) == ra.c0.epoch) continue;
                     const int* fl = i ? f1 : f0;
                     while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ra.c0.epoch) {
                         __builtin_amdgcn_s_sleep(32);
@@ -503,6 +527,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
                 }
             }
             asm volatile("" ::: "memory");
+            allOut = __builtin_amdgcn_readfirstlane(all);
             return __builtin_amdgcn_readfirstlane(ok) != 0;
         };
         // (FOLD: 32 x 32 tiles -- with the S-chain starting behind the prep roles the downdate ends the launch, and a 64 x 64 tile is 28 us
