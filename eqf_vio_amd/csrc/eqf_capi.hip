@@ -102,6 +102,7 @@ struct eqf_filter {
     double *hChord = nullptr, *hMeas = nullptr, *hOut = nullptr;
     double* hChordDev = nullptr;  // device-side address of the pinned hChord
     hipEvent_t evMeas = nullptr;
+    bool measPending = false;    // eqf_process_vision: the bearings sit in hMeas, their copy is visionCore's to enqueue (with k_edit's image behind them)
     // input ring for per-call records (batch > 1)
     ImuRec* dRing = nullptr;
     ImuRec* hRing = nullptr;
@@ -1049,6 +1050,14 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
     // gated (resolveGate's redo of a frame whose speculative gate tripped): the outliers are known and already removed, (*gated)[b][k] marks
     // their measurement entries -- the gate is not evaluated again
     const int B = f->B, cap = f->cap;
+    // (per-call API: the bearings are still in pinned host memory -- whoever enqueues the first consumer enqueues their copy)
+    auto flushMeas = [&]() -> int {
+        if (!f->measPending) return EQF_OK;
+        f->measPending = false;
+        HIPC(hipMemcpyAsync(f->dMeas, f->hMeas, sizeof(double) * 3 * cap * B, hipMemcpyHostToDevice, f->stream));
+        HIPC(hipEventRecord(f->evMeas, f->stream));
+        return EQF_OK;
+    };
     // ---- removeOldLandmarks (VIOFilter.cpp:393-419): state ids absent from the measurement
     bool anyLost = false;
     std::vector<std::vector<int>> keep(B);
@@ -1081,9 +1090,13 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
             if (nb[b] > int(keep[b].size())) anyFresh = true;  // (every kept id is in the measurement)
         }
         if (ok && (anyLost || anyFresh || gateArmed)) {
+            // (per-call API: the image rides behind the bearings, one copy for both; stream API: a staging ring of its own)
+            const bool withMeas = f->measPending;
             int* h = nullptr;
             int slot = 0;
-            int rc = stageAcquire(f->stEdit, &h, &slot);
+            int rc = EQF_OK;
+            if (withMeas) h = reinterpret_cast<int*>(f->hMeas + (size_t)3 * cap * B);
+            else rc = stageAcquire(f->stEdit, &h, &slot);
             if (rc) return rc;
             std::vector<int> nKept(B, 0);
             bool anyWork = false;
@@ -1126,7 +1139,13 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
             }
             // (a fixed set behind an armed gate: the same image every frame, nothing to upload)
             const size_t nInts = (size_t)2 * B * cap + 4 * B;
-            if (f->editOnDevice.size() != nInts || !std::equal(h, h + nInts, f->editOnDevice.begin())) {
+            const int* devImage = f->dEdit;
+            if (withMeas) {
+                f->measPending = false;
+                HIPC(hipMemcpyAsync(f->dMeas, f->hMeas, sizeof(double) * 3 * cap * B + sizeof(int) * nInts, hipMemcpyHostToDevice, f->stream));
+                HIPC(hipEventRecord(f->evMeas, f->stream));
+                devImage = reinterpret_cast<const int*>(f->dMeas + (size_t)3 * cap * B);
+            } else if (f->editOnDevice.size() != nInts || !std::equal(h, h + nInts, f->editOnDevice.begin())) {
                 f->editOnDevice.clear();
                 HIPC(hipMemcpyAsync(f->dEdit, h, sizeof(int) * nInts, hipMemcpyHostToDevice, f->stream));
                 HIPC(hipEventRecord(f->stEdit.ev[slot], f->stream));
@@ -1141,7 +1160,7 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
             }
             EditArgs ea{};
             ea.g = f->g[f->pG];
-            ea.in = f->dEdit;
+            ea.in = devImage;
             ea.permOut = f->dPerm;
             ea.B = B; ea.cap = cap;
             ea.bearings = bearings; ea.bearStride = bearStride;
@@ -1180,6 +1199,10 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
             if (!anyWork) return EQF_OK;
             return launchUpdate(f, bearings, bearStride, f->dPerm, Nmax);
         }
+    }
+    {
+        int rc = flushMeas();
+        if (rc) return rc;
     }
     if (anyLost) {
         int rc = compact(f, keep);
@@ -1658,7 +1681,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     chk(dmalloc(&f->errflag, 1));
     chk(dmalloc(&f->dMap, (size_t)cap * B + B)); if (!rc) f->dNewN = f->dMap + (size_t)cap * B;  /* (one copy brings both) */ chk(dmalloc(&f->dPerm, (size_t)cap * B));
     chk(dmalloc(&f->dChord, (size_t)cap * B)); chk(dmalloc(&f->dDepth2, (size_t)cap * B));
-    chk(dmalloc(&f->dScratch, (size_t)kLmRec * cap * B)); chk(dmalloc(&f->dMeas, (size_t)3 * cap * B));
+    chk(dmalloc(&f->dScratch, (size_t)kLmRec * cap * B)); chk(dmalloc(&f->dMeas, (size_t)3 * cap * B + ((size_t)2 * cap * B + 4 * B + 1) / 2));  /* (+ k_edit's image behind the bearings: one copy brings both) */
     chk(dmalloc(&f->dOut, (size_t)f->nTot * f->nTot + 16));
     chk(dmalloc(&f->dRing, (size_t)kRing * B));
     if (!rc && hipMalloc(&f->dBlk, f->esz * (size_t)kBlkRec * cap * B) != hipSuccess) rc = EQF_ERR_HIP;
@@ -1715,7 +1738,7 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
     if (!rc && hipEventCreateWithFlags(&f->evGate, hipEventDisableTiming) != hipSuccess) rc = EQF_ERR_HIP;
     if (!rc && hipEventCreateWithFlags(&f->evMask, hipEventDisableTiming) != hipSuccess) rc = EQF_ERR_HIP;
     if (!rc && hipHostGetDevicePointer(reinterpret_cast<void**>(&f->hChordDev), f->hChord, 0) != hipSuccess) rc = EQF_ERR_HIP;
-    chk(hmalloc(&f->hMeas, (size_t)3 * cap * B)); chk(hmalloc(&f->hOut, (size_t)f->nTot * f->nTot + 16));
+    chk(hmalloc(&f->hMeas, (size_t)3 * cap * B + ((size_t)2 * cap * B + 4 * B + 1) / 2)); chk(hmalloc(&f->hOut, (size_t)f->nTot * f->nTot + 16));
     chk(hmalloc(&f->hRing, (size_t)kRing * B));
     if (!rc) {
         for (auto& e : f->evRing)
@@ -1843,9 +1866,13 @@ int eqf_process_vision(eqf_filter* f, const double* stamps, const int* nb, const
         mids[b] = ids + (size_t)b * stride;
         active[b] = st[b] == EQF_OK;
     }
-    HIPC(hipMemcpyAsync(f->dMeas, f->hMeas, sizeof(double) * 3 * cap * B, hipMemcpyHostToDevice, f->stream));
-    HIPC(hipEventRecord(f->evMeas, f->stream));
+    f->measPending = true;
     rc = visionCore(f, mids, nbv, f->dMeas, (long long)3 * cap, active, st.data());
+    if (f->measPending) {  // (visionCore left before it needed them)
+        f->measPending = false;
+        HIPC(hipMemcpyAsync(f->dMeas, f->hMeas, sizeof(double) * 3 * cap * B, hipMemcpyHostToDevice, f->stream));
+        HIPC(hipEventRecord(f->evMeas, f->stream));
+    }
     if (status) std::copy(st.begin(), st.end(), status);
     return rc;
 }

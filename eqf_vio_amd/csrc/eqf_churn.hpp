@@ -394,30 +394,30 @@ __global__ __launch_bounds__(256) void k_edit(EditArgs a) {
     // ---- per-landmark arrays (the workgroup that left the first phase last): compaction through the scratch records, then the new landmarks
     if (last) {
         if (moved) {
-            for (int f = tid; f < nF; f += 256) {
-                const int o = sOld[f];
+            // (in place, 256 landmarks per pass: a record moves DOWN or stays, so a pass only reads what no earlier pass has written, and inside
+            // a pass every load has returned -- the barrier drains them -- before the first store; k_compact's scratch copy, a round trip, is not
+            // needed with one workgroup)
+            for (int f0 = 0; f0 < nF; f0 += 256) {
+                const int f = f0 + tid;
                 double v[kLmRec];
+                if (f < nF) {
+                    const int o = sOld[f];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) v[c] = a.p0[((long long)b * 3 + c) * cap + o];
+                    for (int c = 0; c < 3; ++c) v[c] = a.p0[((long long)b * 3 + c) * cap + o];
 #pragma unroll
-                for (int c = 0; c < 5; ++c) v[3 + c] = a.Q[((long long)b * 5 + c) * cap + o];
+                    for (int c = 0; c < 5; ++c) v[3 + c] = a.Q[((long long)b * 5 + c) * cap + o];
 #pragma unroll
-                for (int c = 0; c < 15; ++c) v[8 + c] = a.lmc[((long long)b * 15 + c) * cap + o];
+                    for (int c = 0; c < 15; ++c) v[8 + c] = a.lmc[((long long)b * 15 + c) * cap + o];
+                }
+                __syncthreads();
+                if (f < nF) {
 #pragma unroll
-                for (int c = 0; c < kLmRec; ++c) a.scratch[((long long)b * kLmRec + c) * cap + f] = v[c];
-            }
-            __threadfence_block();
-            __syncthreads();
-            for (int f = tid; f < nF; f += 256) {
-                double v[kLmRec];
+                    for (int c = 0; c < 3; ++c) a.p0[((long long)b * 3 + c) * cap + f] = v[c];
 #pragma unroll
-                for (int c = 0; c < kLmRec; ++c) v[c] = a.scratch[((long long)b * kLmRec + c) * cap + f];
+                    for (int c = 0; c < 5; ++c) a.Q[((long long)b * 5 + c) * cap + f] = v[3 + c];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) a.p0[((long long)b * 3 + c) * cap + f] = v[c];
-#pragma unroll
-                for (int c = 0; c < 5; ++c) a.Q[((long long)b * 5 + c) * cap + f] = v[3 + c];
-#pragma unroll
-                for (int c = 0; c < 15; ++c) a.lmc[((long long)b * 15 + c) * cap + f] = v[8 + c];
+                    for (int c = 0; c < 15; ++c) a.lmc[((long long)b * 15 + c) * cap + f] = v[8 + c];
+                }
             }
         }
         if (nNew > 0) {
