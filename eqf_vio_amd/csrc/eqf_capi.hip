@@ -300,6 +300,7 @@ int initState(eqf_filter* f) {
     }
     HIPC(hipMemsetAsync(f->p0, 0, sizeof(double) * 3 * f->cap * B, f->stream));
     HIPC(hipMemsetAsync(f->errflag, 0, sizeof(int), f->stream));
+    if (f->dEditBar) HIPC(hipMemsetAsync(f->dEditBar, 0, sizeof(int) * 4 * B, f->stream));  // (k_edit's counters: a launch that timed out leaves them mid-count)
     // Sigma base block diag
     std::vector<double> base(12 * 12, 0.0);
     for (int i = 0; i < 3; ++i) {
@@ -317,6 +318,9 @@ int initState(eqf_filter* f) {
     HIPC(hipStreamSynchronize(f->stream));
     f->pS = f->pG = 0;
     f->gate.pending = false;
+    f->measPending = false;
+    f->csValid = false;
+    f->editOnDevice.clear();
     f->ids.assign(B, {});
     f->curTime.assign(B, -1.0);
     f->init.assign(B, 0);
