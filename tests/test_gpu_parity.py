@@ -1274,3 +1274,57 @@ def test_one_launch_bookkeeping_equals_the_separate_launches(hip, precision):
     for f, (a, b) in enumerate(zip(*outs)):
         for u, v in zip(a, b):
             assert np.array_equal(u, v), f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["edge_of_the_small_filter_guard", "beyond_the_one_launch_limit", "one_filter_without_a_measurement"])
+def test_one_launch_bookkeeping_at_its_limits(hip, case):
+    """k_edit's guards, bit for bit against the separate launches: measurements of 58 / 59 / 60 entries with the gate armed (below 59 the host
+    keeps the separate launches; at 59 and 60 a single outlier takes the filter below the limit: the deferred update); a filter of more than
+    kEditMax = 1024 landmarks (separate launches, whatever the option says); a batch in which one filter gets an empty measurement on some
+    frames (it takes no part in those frames' bookkeeping, the others do)."""
+    from eqf_vio_amd import synth
+
+    d = synth.template_settings_dict()
+    d["outlierThreshold"] = 0.05
+    if case == "edge_of_the_small_filter_guard":
+        B, pool, dur = 3, 70, 0.45
+        sizes = lambda b, k: (58 + b) + (1 if k >= 5 else 0)  # (frame 6: 59 / 60 / 61 entries, one of them an outlier -> 58 / 59 / 60 landmarks)
+    elif case == "beyond_the_one_launch_limit":
+        B, pool, dur = 1, 1100, 0.16
+        sizes = lambda b, k: 1040 + 10 * k
+    else:
+        B, pool, dur = 3, 120, 0.45
+        sizes = lambda b, k: 0 if (b == 1 and k in (2, 3, 6)) else 90 + 3 * k
+    sts = [synth.make_stream(pool, seed=40 + b, duration=dur) for b in range(B)]
+    outs = []
+    for on in (1, 0):
+        fg = hip.FilterBatch(d, capacity=pool, batch=B)
+        fg.debug_option("device_edit", on)
+        seq = []
+        for kind, k in sts[0].events():
+            if kind == "imu":
+                fg.process_imu([s.imu[k, 0] for s in sts], [s.imu[k, 1:4] for s in sts], [s.imu[k, 4:7] for s in sts])
+                continue
+            ids = np.zeros((B, pool), dtype=np.int32)
+            y = np.zeros((B, pool, 3))
+            nb = np.zeros(B, dtype=np.int32)
+            for b in range(B):
+                n = sizes(b, k)
+                lo = 2 * (k // 3)  # (a few landmarks leave every third frame)
+                sel = np.arange(lo, lo + n)
+                yy = sts[b].bearings[k, sel].copy()
+                if n > 10 and k in (3, 6):
+                    yy[7] = _rotated(yy[7])
+                nb[b] = n
+                ids[b, :n] = sts[b].ids[sel]
+                y[b, :n] = yy
+            fg.process_vision([s.vision_stamps[k] for s in sts], ids, y, nb=nb)
+            for b in range(B):
+                seq.append((fg.ids(b).copy(), fg.sigma(b).copy(), fg.state_estimate(b)["x"].copy()))
+        assert fg.device_error() == 0
+        outs.append(seq)
+    assert len(outs[0]) == len(outs[1]) >= 3
+    for f, (a, b) in enumerate(zip(*outs)):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v), (case, f)
