@@ -576,6 +576,9 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     return EQF_OK;
 }
 
+// (Round 5, measured and dropped: launching the first call queued on an IDLE device at once -- one hipStreamQuery per burst -- so that a run that
+// starts from a synchronised handle does not leave the device idle while a frame's calls are queued.  The query costs the host 3 us, a one-step
+// burst 15 us of device time: the driver's 20-step shape 369 -> 393 us, steady state 65.0 -> 64.1 k steps/s.  scripts/short_run_trace.py)
 bool burstEligible(const eqf_filter* f, bool isImu) {
     return f->burstMax > 0 && !f->densePropagate && (!isImu || !f->set.fastRiccati);
 }
@@ -1181,7 +1184,7 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
             // (co-resident when an outliers-only compaction may have to wait for its workgroups; a frame whose Sigma the host knows to move
             // anyway waits for nobody: a workgroup per four rows)
             const int coRes = std::max(1, std::min(64, std::max(f->numCUs, 1) / B));
-            const int G = anyLost ? std::max(coRes, std::min(1024, (kLm0 + 3 * Nmax + 3) / 4)) : coRes;
+            const int G = (anyLost || !gateArmed) ? std::max(coRes, std::min(1024, (kLm0 + 3 * Nmax + 3) / 4)) : coRes;  // (no gate: nothing can trip)
             rc = profiled(f, EQF_PROF_CHURN, [&] {
                 if (f->precision == EQF_PRECISION_F32) hipLaunchKernelGGL(k_edit<float>, dim3(G, B), dim3(256), 0, f->stream, ea);
                 else hipLaunchKernelGGL(k_edit<double>, dim3(G, B), dim3(256), 0, f->stream, ea);
