@@ -180,7 +180,10 @@ int eqf_debug_drop_role(eqf_filter* f, int kind, int role, int R, int C);
  *   "device_edit"  1 (default): a vision frame's landmark bookkeeping -- the landmarks that left (VIOFilter.cpp:393-419), the outlier gate
  *                  (:429-443), the new landmarks (:345-391) -- is ONE launch that decides and acts on the device; the id lists of the handle
  *                  follow when the caller next touches it and no frame is redone.  0: separate launches, a frame with an outlier is redone
- *                  from the host.  Bit for bit the same either way. */
+ *                  from the host.  Bit for bit the same either way.
+ *   "burst_fused_max_x10"    the one-launch IMU burst (k_burst_fused) is used up to value / 10 workgroups per CU (default: 1.25).
+ *   "e_sigma_min_percu_x10"  the two-per-CU build of the update launch reads the E-chain's tiles in Sigma itself from value / 10 chain roles per
+ *                  CU on (default 2.4: every such grid); below, the prep launch copies Sigma[6:, 6:].  Launch shapes only: same results. */
 int eqf_debug_option(eqf_filter* f, const char* name, int value);
 
 /* IMU bursts.  processIMUData calls (VIOFilter.cpp:120-131) only depend on each other and on the state, so the library
