@@ -1328,3 +1328,41 @@ def test_one_launch_bookkeeping_at_its_limits(hip, case):
     for f, (a, b) in enumerate(zip(*outs)):
         for u, v in zip(a, b):
             assert np.array_equal(u, v), (case, f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_one_launch_bookkeeping_against_the_oracle_on_random_histories(oracle_lib, hip, seed):
+    """k_edit against the reference's order of operations (oracle) on random landmark histories: every landmark visible on a random window,
+    up to 110 of a pool of 150 in view, an outlier on a random third of the frames (sometimes on a frame that also loses and gains landmarks),
+    the gate at 0.05 -- ids in the reference's order and Sigma after EVERY frame, the state at the end."""
+    from eqf_vio_amd import synth
+
+    pool = 150
+    st = synth.make_stream(pool, seed=700 + seed, duration=0.8)
+    rng = np.random.default_rng(seed)
+    F = st.bearings.shape[0]
+    out_frames = tuple(int(k) for k in np.where(rng.random(F) < 0.34)[0] if k >= 2)
+    meas = synth.churn_measurements(st, seed=50 + seed, max_visible=110, outlier_frames=out_frames, outlier_angle=0.2)
+    d = synth.template_settings_dict()
+    d["outlierThreshold"] = 0.05
+    fo = oracle_lib.OracleFilter(d)
+    fg = hip.FilterBatch(d, capacity=pool, batch=1)
+    removed = 0
+    for kind, k in st.events():
+        if kind == "imu":
+            r = st.imu[k]
+            fo.processIMUData(r[0], r[1:4], r[4:7])
+            fg.process_imu([r[0]], r[1:4], r[4:7])
+            continue
+        mi, my = meas[k]
+        before = set(fo.ids().tolist())
+        fo.processVisionData(st.vision_stamps[k], mi, my)
+        fg.process_vision([st.vision_stamps[k]], mi, my)
+        removed += len((before & set(mi.tolist())) - set(fo.ids().tolist()))  # (in the measurement and still thrown out: the gate)
+        assert np.array_equal(fg.ids(), fo.ids()), (seed, k)
+        assert rel_fro(fg.sigma(), fo.stateCovariance()) < SIGMA_TOL, (seed, k)
+    assert removed >= 2, "the gate never tripped: the test would not exercise the outlier path"
+    eo, eg = fo.stateEstimate(), fg.state_estimate()
+    assert np.abs(eo["x"] - eg["x"]).max() < POSE_TOL and np.abs(eo["q"] - eg["q"]).max() < POSE_TOL
+    assert fg.device_error() == 0
