@@ -1175,7 +1175,7 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
             ea.gateFlag = gateArmed ? f->hGateDev : nullptr;
             ea.chordOut = gateArmed ? f->hChordDev : nullptr;
             ea.depthDefault = f->set.initialSceneDepth; ea.pointVar = f->set.initialPointVariance;
-            ea.p0 = f->p0; ea.Q = f->Q[f->pG]; ea.lmc = f->lmc; ea.scratch = f->dScratch;
+            ea.p0 = f->p0; ea.Q = f->Q[f->pG]; ea.lmc = f->lmc;
             ea.errflag = f->errflag;
             ea.Scur = f->Sigma[f->pS]; ea.Soth = f->Sigma[f->pS ^ 1];
             ea.sigmaStride = f->sigmaStride; ea.ld = f->ld;

@@ -252,7 +252,7 @@ struct EditArgs {
     int* gateFlag;          // pinned [B]: raised if the filter lost an outlier
     double* chordOut;       // pinned [B][cap]: chord of kept landmark j (gate armed)
     double depthDefault, pointVar;
-    double *p0, *Q, *lmc, *scratch;
+    double *p0, *Q, *lmc;
     int* errflag;
     const void* Scur;
     void* Soth;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void k_edit(EditArgs a) {
             dst[(long long)R * ld + Cc] = (R == Cc) ? (T)a.pointVar : (T)0;
         }
     }
-    // ---- per-landmark arrays (the workgroup that left the first phase last): compaction through the scratch records, then the new landmarks
+    // ---- per-landmark arrays (the workgroup that left the first phase last): compaction in place, then the new landmarks
     if (last) {
         if (moved) {
             // (in place, 256 landmarks per pass: a record moves DOWN or stays, so a pass only reads what no earlier pass has written, and inside
