@@ -89,7 +89,11 @@ int eqf_process_imu(eqf_filter* f, const double* stamps, const double* omega, co
 /* VIOFilter::processVisionData (VIOFilter.cpp:232-302).  For filter b: nb[b] bearings with ids
  * ids[b*stride + k] (STRICTLY ascending) and unit vectors bearings[(b*stride + k)*3 + c].
  * EQF_ERR_INVALID / EQF_ERR_CAPACITY (nb[b] > capacity) / EQF_ERR_UNSORTED are returned before any effect: the
- * filters are exactly as before the call.  status[] is written whenever the call got past those checks. */
+ * filters are exactly as before the call.  status[] is written whenever the call got past those checks.
+ * The call enqueues and returns: the landmark bookkeeping (VIOFilter.cpp:345-443) including the outlier gate is decided and carried out
+ * on the device, the update follows in the stream; the handle's id lists (eqf_num_landmarks, eqf_get_ids) are brought up to date from the
+ * device's answer when the caller next touches the handle.  One consequence for status[]: a frame in which EVERY landmark of a filter is
+ * thrown out as an outlier and none is new reports EQF_OK, not EQF_SKIPPED_NO_BEARINGS (the update is skipped on the device). */
 int eqf_process_vision(eqf_filter* f, const double* stamps, const int* nb, const int* ids, const double* bearings,
     int stride, int* status);
 
