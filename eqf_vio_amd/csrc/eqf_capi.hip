@@ -1567,6 +1567,16 @@ extern "C" int eqf_debug_res_f64_stamps(long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_resF64), sizeof(long long) * 2 * 16 * 128) == hipSuccess ? 0 : -1;
 }
 #endif
+#ifdef EQF_WAIT_STATS
+extern "C" int eqf_debug_wait_stats(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_waitStats), sizeof(unsigned long long) * 48) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[48] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(eqf::g_waitStats), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 #ifdef EQF_PREP_STAMPS
 extern "C" int eqf_debug_prep_stamps(long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(eqf::g_prepStamps), sizeof(long long) * 1024) == hipSuccess ? 0 : -1;

@@ -38,6 +38,18 @@ EQF_DEV void hoPublish(int* flag, int epoch) { __hip_atomic_store(flag, epoch, _
 // and gives up as soon as it is set -- so ONE timeout anywhere in a launch unwinds the whole launch in microseconds instead of every
 // dependent wait rediscovering it after its own 0.5 s (a launch of 70 000 workgroups would spin for hours; the advisor's round-3 finding).
 constexpr int kHoErrTimeout = 128;
+#ifdef EQF_WAIT_STATS
+// instrumented build (scripts/wait_stats.py): per role class of k_chol_resident -- 0 H, 1 T, 2 W, 3 F0, 4 prep, 5 downdate tile; 8 + class for the
+// E-chain -- the 100 MHz ticks its workgroups spent inside hoWait / the downdate's gate, their lifetimes, and how many there were
+__device__ unsigned long long g_waitStats[16][3];
+__shared__ int sStatClass;
+__shared__ unsigned long long sStatWait;
+#define EQF_STAT_CLASS(c) do { if (threadIdx.x == 0) sStatClass = (c); } while (0)
+#define EQF_STAT_WAIT(t) atomicAdd(&sStatWait, (unsigned long long)(t))
+#else
+#define EQF_STAT_CLASS(c) do { } while (0)
+#define EQF_STAT_WAIT(t) do { } while (0)
+#endif
 EQF_DEV bool hoAborted(const int* err) { return err && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kHoErrTimeout); }
 EQF_DEV bool hoWait(const int* flag, int epoch, int* err = nullptr) {
     const long long t0 = wall_clock64();  // 100 MHz
@@ -52,6 +64,7 @@ EQF_DEV bool hoWait(const int* flag, int epoch, int* err = nullptr) {
             }
         }
     }
+    EQF_STAT_WAIT(wall_clock64() - t0);
     return true;
 }
 // Ten 16-byte sc0 sc1 loads at p + 4096 k (k = 0..9: 40 KB per 256-thread workgroup, one diagonal-factor record), all in

@@ -409,8 +409,13 @@ __device__ long long g_resF64[2][16][128];  // [chain][R]: factor64's per-wave s
 // nobody: the dependency order of the block indices holds as before.  A build of its own because the mere presence of the prep
 // role and of the agent-scope loads of S / the right-hand sides cost the other builds 3 + 7 us per update (124 -> 134: this kernel is
 // bound by a chain of latencies and feels every change of its code layout).
+#ifdef EQF_WAIT_STATS
+template <typename T, bool PIPEH = false, bool OCC2 = false, bool FOLD = false>
+__device__ __forceinline__ void residentBody(const ResArgs& ra) {
+#else
 template <typename T, bool PIPEH = false, bool OCC2 = false, bool FOLD = false>
 __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra) {
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smemR[];
     // grid = (batch, roles): the filter index runs FASTEST in dispatch order, so that a grid larger than the chip advances all filters
     // together, dependency group by dependency group (role-major order would run the filters one after the other), and with a batch
@@ -421,6 +426,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
     const int roleIdxAll = (int)blockIdx.x / nB + ra.rolesPerRow * (int)blockIdx.y, bIdx = (int)blockIdx.x % nB;
     if (FOLD && roleIdxAll >= ra.nFront && roleIdxAll < ra.nFront + ra.nPrep) {
         // ---- a prep role (see ResArgs::nPrep): among the lowest block indices of the grid -- nothing they need is produced in this launch
+        EQF_STAT_CLASS(4);
         const int prepIdx = roleIdxAll - ra.nFront;
         const Glob& gp = ra.a.g[bIdx];
         if (gp.updateOk && gp.N != 0) {
@@ -441,6 +447,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         // order (filter fastest) an XCD would hold the same few tiles of ALL its filters at a time -- at 64 filters 8 x 2.3 MB of Y against 4 MB
         // of L2: every panel came from the memory side again (3520 tiles x 458 KB = 1.6 GB per update, the 330 us tail of the launch at the
         // MALL's rate; profiles/r05_res_stamps_B64.txt).  So within an XCD the tiles run filter by filter: one filter's Y at a time.
+        EQF_STAT_CLASS(5);
         int bb = bIdx, tile = roleIdx - ra.nRoles;
         if ((nB & 7) == 0 && nB > 8) {
             const int seq = tile * (nB >> 3) + (bIdx >> 3);
@@ -499,6 +506,9 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         int allOut = 0;
         auto gate = [&](int C, int ti, int tj) -> bool {
             if (allOut) return true;
+#ifdef EQF_WAIT_STATS
+            const long long tGate0 = wall_clock64();
+#endif
             int ok = 1, all = 0;
             if ((t & 63) == 0) {
                 const long long t0 = wall_clock64();
@@ -527,6 +537,9 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
                 }
             }
             asm volatile("" ::: "memory");
+#ifdef EQF_WAIT_STATS
+            if ((t & 63) == 0) EQF_STAT_WAIT(wall_clock64() - tGate0);
+#endif
             allOut = __builtin_amdgcn_readfirstlane(all);
             return __builtin_amdgcn_readfirstlane(ok) != 0;
         };
@@ -546,6 +559,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
     // Role workgroups that start after that leave at once; nothing they would publish could be complete.)
     if (hoAborted(ra.errflag)) return;
     const ResRole role = ra.roles[roleIdx];
+    EQF_STAT_CLASS((role.role == 6 ? 3 : role.role) + 8 * role.kind);
     const int b = bIdx;
     constexpr bool fold = FOLD;
     const ChainArgs& ch = role.kind ? ra.c1 : ra.c0;
@@ -1000,5 +1014,23 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
     // than the chip: finished role workgroups take tiles only if the last Y tile is already out and leave otherwise -- 2 filters 294 us
     // against 135 + 41 us with a follow-up launch; too few workgroups finish after the S-chain.)
 }
+#ifdef EQF_WAIT_STATS
+template <typename T, bool PIPEH = false, bool OCC2 = false, bool FOLD = false>
+__global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra) {
+    const long long t0 = wall_clock64();
+    if (threadIdx.x == 0) {
+        sStatClass = 7;
+        sStatWait = 0;
+    }
+    __syncthreads();
+    residentBody<T, PIPEH, OCC2, FOLD>(ra);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&g_waitStats[sStatClass & 15][0], sStatWait);
+        atomicAdd(&g_waitStats[sStatClass & 15][1], (unsigned long long)(wall_clock64() - t0));
+        atomicAdd(&g_waitStats[sStatClass & 15][2], 1ull);
+    }
+}
+#endif
 
 }  // namespace eqf
