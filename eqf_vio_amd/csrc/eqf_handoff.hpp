@@ -55,7 +55,10 @@ EQF_DEV bool hoWait(const int* flag, int epoch, int* err = nullptr) {
     const long long t0 = wall_clock64();  // 100 MHz
     int polls = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-        __builtin_amdgcn_s_sleep(1);
+#ifndef EQF_POLL_SLEEP
+#define EQF_POLL_SLEEP 1
+#endif
+        __builtin_amdgcn_s_sleep(EQF_POLL_SLEEP);
         if ((++polls & 255) == 0) {
             if (hoAborted(err)) return false;
             if (wall_clock64() - t0 > 50000000LL) {  // 0.5 s (a launch for N = 4000 runs 60 ms)

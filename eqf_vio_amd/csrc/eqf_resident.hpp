@@ -522,8 +522,11 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
                 for (int i = 0; i < 2 && ok && !all; ++i) {
                     if ((i ? v1 : v0) == ra.c0.epoch) continue;
                     const int* fl = i ? f1 : f0;
+#ifndef EQF_GATE_SLEEP
+#define EQF_GATE_SLEEP 32
+#endif
                     while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ra.c0.epoch) {
-                        __builtin_amdgcn_s_sleep(32);
+                        __builtin_amdgcn_s_sleep(EQF_GATE_SLEEP);
                         if (hoAborted(ra.errflag)) {
                             ok = 0;
                             break;
