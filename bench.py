@@ -8,7 +8,9 @@ fastRiccati = false).  The whole input stream is resident in HBM before the time
 
     python bench.py                       # 1 GPU, 1 filter, N = 200  (BASELINE configs[1])
     python bench.py --filters-per-gpu 64  # 64 independent filters batched on one GPU
-    torchrun ... bench.py --gpus 8 --filters-per-gpu 8   # BASELINE configs[3]: 64 filters over 8 GPUs
+    python bench.py --gpus 8              # starts 8 ranks ITSELF (one per GPU, RCCL rendezvous on 127.0.0.1), one JSON line from rank 0;
+                                          # BASELINE configs[3] (64 filters over the 8 GPUs) is its `batch64_strong` leg
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8   # same job
 
 Multi-GPU: independent filters are sharded over ranks (no data-path collective); RCCL is used once to
 scatter the pre-generated input streams from rank 0 and once to gather the results.
@@ -36,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TF = {"f64": 78.6, "f32": 157.3}  # f32: MI355X_MICROARCH.md; f64: half the f32 rate (AMD datasheet)
+VALU_F64_PEAK_TF = 78.6  # vector fp64 FMA rate of the part (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz): what the structured Riccati step runs on
 
 
 def parse():
@@ -67,6 +70,8 @@ def parse():
     ap.add_argument("--debug-option", action="append", default=[], metavar="NAME=VALUE", help="developer toggle of the library (eqf_debug_option), main job only")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--spawn-selftest", action="store_true", help="launcher check without a GPU: the ranks rendezvous over gloo, scatter the "
+                    "input streams and gather a result; no filter runs and the line says so (tests/test_bench_spawn.py)")
     return ap.parse_args()
 
 
@@ -193,6 +198,16 @@ def roofline(fb, events, N, B, precision):
     # bytes a burst really moves: Sigma in + out once, plus the per-step per-landmark records (63 values, written by the builder
     # and read by the block kernel) -- DESIGN.md 4.1b
     burst_moved = (2.0 * n * n + steps_per_burst * N * 63 * 2.0) * esz * B
+    shape = fb.launch_shape()  # of the most recent burst (every burst of a fixed-set run has the same shape)
+    if shape["cs_out"]:
+        # the burst's block kernel also leaves the landmark columns of C Sigma (m x 3N) and S (m x m) for the update (cs_in_burst)
+        burst_moved += (m * 3.0 * N + m * m) * 8.0 * B
+    # what the block kernel executes per Riccati step: 162 FMAs per 3 x 3 block, blocks on and below the diagonal only
+    burst_flops = steps_per_burst * (N * (N + 1) / 2.0) * 324.0 * B
+    # the update's prep work: with the burst's C Sigma / S it touches 12 leading columns per landmark row and the O(N) vectors -- a latency
+    # chain, no byte count to hold against HBM; without, it reads the landmark rows of Sigma (n^2) and writes Y, S and the copy of Sigma_e
+    prep_bytes_cs = 8.0 * (3.0 * N * 12 + m * 19.0 + 15.0 * N + 18.0 * N) * B
+    prep_bytes_full = (n * n * esz + 8.0 * (m * (n + 7) + m * m + ne * ne)) * B
     algo = {
         # propagate = read Sigma once + write Sigma once
         "k_propagate": ("hbm", 2.0 * n * n * esz * B),
@@ -205,7 +220,7 @@ def roofline(fb, events, N, B, precision):
         "k_downdate": ("mfma", downdate_flops * B),
         # dense backend (cfg 3): build F + two n^3 GEMMs = 4 n^3 flops per Riccati step (SURVEY.md 8d "mfma_dense_equiv")
         "k_dense_riccati": ("mfma", 4.0 * n**3 * B),
-        "k_update_prep": ("hbm", (n * n * esz + 8.0 * (m * (n + 7) + m * m + ne * ne)) * B),
+        "k_update_prep": ("latency", prep_bytes_cs) if shape["cs_out"] else ("hbm", prep_bytes_full),
         "k_update_reduce": ("hbm", 8.0 * (m * (n + 7) + ne * 32) * B),
     }
     if prof.get("k_dense_riccati", (0, 0.0))[0]:
@@ -219,11 +234,20 @@ def roofline(fb, events, N, B, precision):
         row = {"kernel": name, "launches": cnt, "total_ms": round(ms, 3), "avg_us": round(avg_us, 3)}
         if name in algo:
             bound, work = algo[name]
-            if bound == "hbm":
+            if bound == "latency":
+                row.update(bound="latency", bytes_touched=work, note="C Sigma and S come from the burst's block kernel (cs_in_burst): this launch "
+                           "reads 12 columns per landmark row -- a dependent chain of O(N) work, no HBM or matrix-core figure applies")
+            elif bound == "hbm":
                 ach = work / (avg_us * 1e-6) / 1e9
                 row.update(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5))
                 if name == "k_imu_burst":
                     row["steps_per_burst"] = round(steps_per_burst, 2)
+                    # the other pipe the burst can be bound by: the structured step's fp64 FMAs on the vector ALUs
+                    vt = burst_flops / (avg_us * 1e-6) / 1e12
+                    row.update(valu_tflops=round(vt, 3), valu_peak=VALU_F64_PEAK_TF, valu_frac=round(vt / VALU_F64_PEAK_TF, 5),
+                               launch_shape=shape,
+                               binds=("fp64 VALU" if vt / VALU_F64_PEAK_TF > ach / HBM_PEAK_GBS else "HBM") + " is the nearer roof (neither is reached: "
+                               "the bracket covers the builder launch, a serial O(N) recurrence, and the block kernel)")
                     # what a step-by-step implementation would have to move (2 n^2 bytes per STEP): NOT a roofline
                     # fraction -- Sigma stays in registers across the steps of a burst
                     row["effective_step_by_step_gbs"] = round(2.0 * n * n * esz * B * steps_per_burst / (avg_us * 1e-6) / 1e9, 2)
@@ -289,8 +313,10 @@ def pmc_traffic(args, kernel):
                os.path.abspath(__file__), "--steps", "220", "--warmup", "110", "--landmarks", str(args.landmarks), "--filters-per-gpu",
                str(args.filters_per_gpu), "--precision", args.precision, "--pmc-child"]
         try:
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                           timeout=300, check=True)
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)  # the counter pass is a plain one-process run, whatever launched this one
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
             path = None
             for root, _, files in os.walk(d):
                 for fn in files:
@@ -422,6 +448,7 @@ def churn_leg(device, seconds=3.0, pool=260, fixed=200):
 
 
 GRIDS = {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (2, 4)}
+KERNEL_KEYS = ("kernel", "launches", "avg_us", "bound", "achieved", "unit", "frac", "valu_tflops", "valu_frac", "binds", "bytes_touched", "launch_shape")
 
 
 def tiled_leg(args, dist, rank, world, device):
@@ -546,11 +573,94 @@ def tiled_leg(args, dist, rank, world, device):
     return out
 
 
+def self_spawn(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks of the job ourselves -- this script once per GPU, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in each child's environment, exactly what torch.distributed.run would
+    set -- and wait for them.  Rank 0 owns stdout (the ONE JSON line); the other ranks' stdout goes to stderr.  The first rank that fails
+    takes the job down: the others are stopped (own PIDs only) and the exit code is that rank's."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    n = args.gpus
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), EQF_BENCH_SELF_SPAWNED="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print("bench.py: rank %d of %d exited with code %d; stopping the job" % (r, n, code), file=sys.stderr, flush=True)
+                deadline = time.time() + 10.0  # (the others get to print their own error first: a missing GPU is missing for all of them)
+                while time.time() < deadline and any(procs[q].poll() is None for q in alive):
+                    time.sleep(0.05)
+                for q in alive:
+                    if procs[q].poll() is None:
+                        procs[q].terminate()
+        time.sleep(0.05)
+    sys.exit(rc)
+
+
+def require_devices(world, rank, need_gpu=True):
+    """Fail loudly, on EVERY rank, before any rendezvous: an N-rank job needs N visible GPUs (one process per GPU)."""
+    import torch
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if need_gpu and have < world:
+        print("bench.py: rank %d of %d: not enough devices -- --gpus %d needs %d visible GPUs (one rank per GPU), this process sees %d"
+              % (rank, world, world, world, have), file=sys.stderr, flush=True)
+        sys.exit(3)
+
+
+def spawn_selftest(args, world, rank):
+    """No GPU, no filter: the launcher's ranks meet over gloo, rank 0's streams reach every rank, a result comes back (shard.py's two
+    collectives, the same calls the real job makes over RCCL).  Test infrastructure for `--gpus N` on a GPU-less box."""
+    import torch.distributed as dist
+
+    from eqf_vio_amd import shard
+
+    dist.init_process_group("gloo")
+    imu, vst, bear, events = shard.scatter_streams(dist, rank, world, 6, 2, 33, device=None)
+    res = np.full((2, 3), float(rank))
+    res[:, 1] = imu[0, :, 0]  # (the first stamp of each of my two filters: proves the slices arrived)
+    res[:, 2] = len(events)
+    allres = shard.gather_results(dist, rank, world, res, device=None)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"selftest": "launcher only: gloo rendezvous + scatter + gather, no filter ran", "n_gpus": world,
+                          "self_spawned": os.environ.get("EQF_BENCH_SELF_SPAWNED") == "1",
+                          "ranks_seen": sorted(set(int(v) for v in allres[:, 0])), "filters": int(allres.shape[0]),
+                          "events": int(allres[0, 2])}))
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_spawn(args)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        print("bench.py: --gpus %d but the launcher's WORLD_SIZE is %d: refusing to print a line with the wrong n_gpus" % (args.gpus, world),
+              file=sys.stderr, flush=True)
+        sys.exit(2)
+    if args.spawn_selftest:
+        spawn_selftest(args, world, rank)
+        return
+    require_devices(world, rank)
     import torch
 
     dist = None
@@ -589,6 +699,8 @@ def main():
         "value": total_steps / dt,
         "unit": "steps/s",
         "n_gpus": world,
+        "launcher": ("bench.py --gpus %d started the ranks itself" % world) if os.environ.get("EQF_BENCH_SELF_SPAWNED") == "1"
+        else ("torch.distributed.run" if "RANK" in os.environ else "single process"),
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt * 1e3 / n_timed,
@@ -658,6 +770,9 @@ def main():
         Bs = 64 // world
         fb2, timed2, dt2, res2 = timed_job(args, dist, rank, world, device, 200, Bs, args.batch64_steps, 110)
         err2 = fb2.device_error()
+        rl2 = rows2 = None
+        if rank == 0 and world == 1 and not args.no_roofline:
+            rl2, rows2, _ = roofline(fb2, timed2, 200, Bs, args.precision)
         del fb2
         line["batch64_strong"] = {
             "metric": "EqF propagate+update steps/sec, 64 filters of N=200 in total",
@@ -673,6 +788,9 @@ def main():
             "device_error_flag": err2,
             "sigma_fro_min_max": [float(res2[:, 7].min()), float(res2[:, 7].max())] if res2 is not None else None,
         }
+        if rows2 is not None:
+            line["batch64_strong"]["roofline"] = rl2
+            line["batch64_strong"]["kernels"] = [{k: r[k] for k in KERNEL_KEYS if k in r} for r in rows2]
 
     # ---- 8 filters per GPU: ONE GPU's share of BASELINE configs[3] on an 8-GPU node -- the figure the 0.9x strong-scaling target hangs on
     # (8 GPUs x this against 8 x the one-GPU batch of 64 above).  One GPU only: on several GPUs batch64_strong already runs 64 / world.
@@ -686,7 +804,7 @@ def main():
         if not args.no_roofline:
             rl8, rows8, cover8 = roofline(fb8, timed8, 200, 8, args.precision)
             leg8["roofline"] = rl8
-            leg8["kernels"] = [{k: r[k] for k in ("kernel", "launches", "avg_us") if k in r} for r in rows8]
+            leg8["kernels"] = [{k: r[k] for k in KERNEL_KEYS if k in r} for r in rows8]
             leg8["profile_coverage"] = cover8["kernel_time_over_wall"]
         if "batch64_strong" in line:
             leg8["strong_scaling_projection_8gpu"] = round(8.0 * leg8["value"] / (8.0 * line["batch64_strong"]["value"]), 3)
@@ -705,7 +823,7 @@ def main():
         if not args.no_roofline:
             rlk, rowsk, coverk = roofline(fbk, timedk, 1000, 1, args.precision)
             legk["roofline"] = rlk
-            legk["kernels"] = [{k: r[k] for k in ("kernel", "launches", "avg_us", "bound", "achieved", "unit", "frac") if k in r} for r in rowsk]
+            legk["kernels"] = [{k: r[k] for k in KERNEL_KEYS if k in r} for r in rowsk]
             legk["profile_coverage"] = coverk["kernel_time_over_wall"]
             legk["roofline_note"] = ("`frac` prices SURVEY 8(d)'s 2 n^2 m for the downdate, the kernel executes n^2 m (symmetry): read `frac_executed` "
                                      "beside it; the dense MFMA Riccati backend of this config is `bench.py --landmarks 1000 --dense-propagate`")

@@ -59,7 +59,7 @@ EXPORTED_SYMBOLS = [
     "eqf_settings_default", "eqf_create", "eqf_destroy", "eqf_reset", "eqf_process_imu", "eqf_process_vision",
     "eqf_stream_upload", "eqf_stream_imu", "eqf_stream_vision", "eqf_synchronize", "eqf_get_time", "eqf_num_landmarks",
     "eqf_get_ids", "eqf_get_state_estimate", "eqf_get_origin", "eqf_get_group", "eqf_get_bias", "eqf_get_sigma",
-    "eqf_set_sigma", "eqf_set_state", "eqf_set_camera_offset", "eqf_get_integrator", "eqf_get_last_update", "eqf_debug_get_blocks", "eqf_device_error", "eqf_debug_drop_role", "eqf_debug_option", "eqf_set_dense_propagate", "eqf_set_imu_burst", "eqf_profile_enable",
+    "eqf_set_sigma", "eqf_set_state", "eqf_set_camera_offset", "eqf_get_integrator", "eqf_get_last_update", "eqf_debug_get_blocks", "eqf_device_error", "eqf_debug_drop_role", "eqf_debug_option", "eqf_debug_launch_shape", "eqf_set_dense_propagate", "eqf_set_imu_burst", "eqf_profile_enable",
     "eqf_profile_get", "eqf_profile_class_name", "eqf_version", "eqf_build_info", "eqf_tile_propagate", "eqf_tile_downdate", "eqf_tile_potrf", "eqf_tile_trsm", "eqf_tile_gemm_tn", "eqf_tile_mirror", "eqf_stream_create_masked", "eqf_stream_destroy",
     "eqf_tiled_create", "eqf_tiled_destroy", "eqf_tiled_set_stream", "eqf_tiled_set_geometry", "eqf_tiled_propagate", "eqf_tiled_add_landmarks",
     "eqf_tiled_edit_landmarks", "eqf_tiled_propagate_burst", "eqf_tiled_stage_bearings", "eqf_tiled_pingpong",
@@ -119,6 +119,7 @@ def lib():
         L.eqf_device_error.argtypes = [vp]
         L.eqf_debug_drop_role.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
         L.eqf_debug_option.argtypes = [vp, C.c_char_p, C.c_int]
+        L.eqf_debug_launch_shape.argtypes = [vp, C.POINTER(C.c_int)]
         L.eqf_set_dense_propagate.argtypes = [vp, C.c_int]
         L.eqf_set_imu_burst.argtypes = [vp, C.c_int]
         L.eqf_profile_enable.argtypes = [vp, C.c_int]
@@ -167,7 +168,7 @@ def lib():
 
 def build_info():
     """Which library this process loaded and whether it was built from the sources beside it: sha256 of the .so, the source hash the
-    library carries (eqf_build_info) and the same hash recomputed now over csrc/*.hip, csrc/*.hpp, include/eqf_vio_amd.h, csrc/Makefile."""
+    library carries (eqf_build_info) and the same hash recomputed now over csrc/*.hip, csrc/*.hpp, include/*.h, csrc/Makefile."""
     import glob
     import hashlib
 
@@ -177,7 +178,7 @@ def build_info():
     embedded = L.eqf_build_info().decode().split("=", 1)[1]
     csrc = os.path.join(_HERE, "csrc")
     names = sorted([os.path.basename(p) for p in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp"))]
-                   + ["../../include/eqf_vio_amd.h", "Makefile"])  # (the order of the Makefile's $(sort ...))
+                   + ["../../include/eqf_vio_amd.h", "../../include/eqf_vio_amd_debug.h", "Makefile"])  # (the order of the Makefile's $(sort ...))
     h = hashlib.sha256()
     for n in names:
         with open(os.path.join(csrc, n), "rb") as f:
@@ -414,12 +415,19 @@ class FilterBatch:
         return lib().eqf_device_error(self._h)
 
     def debug_drop_role(self, kind, role=0, R=0, C_=0):
-        """Fault injection (tests): one role of the update launch leaves without publishing (kind < 0: off); include/eqf_vio_amd.h."""
+        """Fault injection (tests): one role of the update launch leaves without publishing (kind < 0: off); include/eqf_vio_amd_debug.h."""
         _check(lib().eqf_debug_drop_role(self._h, int(kind), int(role), int(R), int(C_)), "eqf_debug_drop_role")
 
     def debug_option(self, name, value):
-        """Developer toggle by name (include/eqf_vio_amd.h: eqf_debug_option), e.g. ``"cs_in_burst"``."""
+        """Developer toggle by name (include/eqf_vio_amd_debug.h: eqf_debug_option), e.g. ``"cs_in_burst"``."""
         _check(lib().eqf_debug_option(self._h, name.encode(), int(value)), "eqf_debug_option")
+
+    def launch_shape(self):
+        """Shape of the most recent IMU burst (include/eqf_vio_amd_debug.h: eqf_debug_launch_shape)."""
+        a = (C.c_int * 8)()
+        _check(lib().eqf_debug_launch_shape(self._h, a), "eqf_debug_launch_shape")
+        return dict(builder_landmarks=a[0], rows_per_wave=a[1], fused=bool(a[2]), cs_out=bool(a[3]), builder_workgroups=a[4],
+                    block_workgroups=a[5], steps=a[6])
 
     # ---- profiling
     def profile_enable(self, on=True):

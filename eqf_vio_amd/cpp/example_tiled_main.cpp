@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <string>
 
+#include "../../include/eqf_vio_amd_debug.h"  // eqf_tf_graph_launches (a measurement hook: this example prints it)
 #include "VIOFilterTiled.h"
 
 using namespace eqf_vio_amd;

@@ -12,7 +12,7 @@
 #include <type_traits>
 #include <vector>
 
-#include "../../include/eqf_vio_amd.h"
+#include "../../include/eqf_vio_amd_debug.h"  // (the public header + the test / measurement hooks this library also exports)
 #include "eqf_churn.hpp"
 #include "eqf_dense.hpp"
 #include "eqf_device.hpp"
@@ -85,6 +85,8 @@ struct eqf_filter {
     int* dEdit = nullptr;    // its device image
     std::vector<int> editOnDevice;  // ... as last uploaded
     int* dEditBar = nullptr; // [B][4] k_edit's counters
+    int lastBurstShape[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // eqf_debug_launch_shape: the most recent IMU burst's launch shape
+    std::vector<char> restoredMark; // [B] eqf_set_state since the last reset: once every filter has been restored a hand-off time-out (bit 128) is forgiven
     // OCC2 grids from this many roles per CU on read the E-chain's tiles in Sigma itself instead of a copy made by the prep launch
     // (eqf_debug_option "e_sigma_min_percu_x10").  8.0 until late round 5 ("at 8 filters of N = 200, 6.3 roles per CU, the kernel loses what
     // the prep launch gains"); measured again behind the gated downdate: 8 filters 323.5 -> 331.3 k steps/s (prep 29.6 -> 19.2 us, kernel
@@ -374,6 +376,7 @@ void mirrorStep(eqf_filter* f, const double* stamps, bool isImu, int* status);
 // integrateUpToTime on the device + host mirror of its control flow.  devRecs == nullptr -> inline (B == 1).
 int launchPropagate(eqf_filter* f, const ImuRec* devRecs, const ImuRec& inl, const double* stamps, bool isImu, bool doRiccati,
     int* status) {
+    f->csValid = false;  // (a single step moves Sigma: columns of C Sigma / S left by an earlier burst are no longer the update's)
     PropArgs a{};
     a.gin = f->g[f->pG];
     a.gout = f->g[f->pG ^ 1];
@@ -544,6 +547,10 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
         a.csOut = 1;
         a.YW = f->YW; a.SA = f->SA; a.lmc = f->lmc;
         a.ldY = f->ldY; a.ldS = f->ldS; a.strideY = f->strideY; a.strideS = f->strideS;
+    }
+    {
+        const int shape[8] = {lm, R, fused ? 1 : 0, a.csOut, (int)bgrid.x, (int)rgrid.x, K, 0};
+        std::copy(shape, shape + 8, f->lastBurstShape);
     }
     const int rc = profiled(f, EQF_PROF_BURST, [&] {
         if (fused) {
@@ -1106,6 +1113,10 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
             else rc = stageAcquire(f->stEdit, &h, &slot);
             if (rc) return rc;
             std::vector<int> nKept(B, 0);
+            // (the new id lists and the "no bearings left" verdicts are committed to the handle only once k_edit is in the stream: an error on
+            // the way there -- capacity, a failed copy, a failed launch -- leaves the host's lists describing what the device still holds)
+            std::vector<std::vector<int>> newIds(B);
+            std::vector<int> skipped;
             bool anyWork = false;
             int Nmax = 0;
             for (int b = 0; b < B; ++b) {
@@ -1135,14 +1146,16 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
                         }
                 }
                 hc[0] = nK; hc[1] = nNew; hc[2] = (gateArmed && active[b]) ? 1 : 0; hc[3] = 0;
-                f->ids[b] = nid;
+                const bool empty = nid.empty();
+                const int nNow = int(nid.size());
+                newIds[b] = std::move(nid);
                 if (!active[b]) continue;
-                if (nid.empty()) {
-                    if (status) status[b] = EQF_SKIPPED_NO_BEARINGS;
+                if (empty) {
+                    skipped.push_back(b);
                     continue;
                 }
                 anyWork = true;
-                Nmax = std::max(Nmax, int(nid.size()));
+                Nmax = std::max(Nmax, nNow);
             }
             // (a fixed set behind an armed gate: the same image every frame, nothing to upload)
             const size_t nInts = (size_t)2 * B * cap + 4 * B;
@@ -1191,6 +1204,9 @@ int visionCore(eqf_filter* f, const std::vector<const int*>& measIds, const std:
             });
             if (rc) return rc;
             HIPC(hipGetLastError());
+            for (int b = 0; b < B; ++b) f->ids[b] = std::move(newIds[b]);
+            if (status)
+                for (int b : skipped) status[b] = EQF_SKIPPED_NO_BEARINGS;
             if (anyLost) f->pS ^= 1;
             f->csValid = false;
             f->permOnDevice.clear();  // (dPerm now holds what k_edit made of the upload)
@@ -2098,6 +2114,7 @@ int eqf_set_sigma(eqf_filter* f, int b, const double* src, int ld) {
     HIPC(hipSetDevice(f->device));
     const int n = kBase + 3 * int(f->ids[b].size());
     if (ld < n) return EQF_ERR_INVALID;
+    f->csValid = false;  // (C Sigma / S left by an earlier burst describe the covariance that is being replaced)
     HIPC(hipStreamSynchronize(f->stream));
     for (int r = 0; r < n; ++r) std::copy(src + (size_t)r * ld, src + (size_t)r * ld + n, f->hOut + (size_t)r * n);
     HIPC(hipMemcpyAsync(f->dOut, f->hOut, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, f->stream));
@@ -2171,7 +2188,25 @@ int eqf_set_state(eqf_filter* f, int b, int N, const int* ids, const double* pos
     f->devInit[b] = f->init[b];
     hipLaunchKernelGGL(k_restore_constants, dim3((N + 127) / 128 + 1), dim3(128), 0, f->stream, f->g[f->pG], b, f->p0, f->lmc, cap, f->errflag);
     HIPC(hipGetLastError());
-    return eqf_set_sigma(f, b, sigma, ld);
+    rc = eqf_set_sigma(f, b, sigma, ld);  // (synchronises)
+    if (rc) return rc;
+    // Recovery from a hand-off time-out (bit 128 of the sticky flag, include/eqf_vio_amd.h): the launch that timed out wrote no covariance,
+    // and once EVERY filter of the handle has been given a state again nothing of it is left -- the bit is cleared (the other bits are
+    // the caller's to look at: eqf_reset clears those) and k_edit's barrier counters, which a timed-out launch leaves mid-count, start
+    // from zero.  With batch = 1 that is this very call.
+    if (f->restoredMark.size() != (size_t)f->B) f->restoredMark.assign(f->B, 0);
+    f->restoredMark[b] = 1;
+    if (std::all_of(f->restoredMark.begin(), f->restoredMark.end(), [](char c) { return c != 0; })) {
+        f->restoredMark.assign(f->B, 0);
+        int e = 0;
+        HIPC(hipMemcpy(&e, f->errflag, sizeof(int), hipMemcpyDeviceToHost));
+        if (e & 128) {
+            e &= ~128;
+            HIPC(hipMemcpy(f->errflag, &e, sizeof(int), hipMemcpyHostToDevice));
+            if (f->dEditBar) HIPC(hipMemset(f->dEditBar, 0, sizeof(int) * 4 * f->B));
+        }
+    }
+    return EQF_OK;
 }
 
 int eqf_set_camera_offset(eqf_filter* f, const double* q, const double* x) {
@@ -2203,6 +2238,12 @@ int eqf_get_last_update(eqf_filter* f, int b, double* delta, double* gamma, doub
         for (int i = 0; i < 3 * N; ++i) gamma[kBase + i] = tmp[kLm0 + i];
     }
     if (Gamma) HIPC(hipMemcpy(Gamma, f->dbgGammaTot + (size_t)b * (9 + 3 * cap), sizeof(double) * (9 + 3 * N), hipMemcpyDeviceToHost));
+    return EQF_OK;
+}
+
+int eqf_debug_launch_shape(eqf_filter* f, int* shape8) {
+    if (!f || !shape8) return EQF_ERR_INVALID;
+    std::copy(f->lastBurstShape, f->lastBurstShape + 8, shape8);
     return EQF_OK;
 }
 
@@ -2297,6 +2338,7 @@ int eqf_set_dense_propagate(eqf_filter* f, int on) {
         HIPC(hipMemset(f->dG, 0, bytes));
     }
     f->densePropagate = on ? 1 : 0;
+    f->csValid = false;
     return EQF_OK;
 }
 

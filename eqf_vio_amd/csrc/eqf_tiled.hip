@@ -1,4 +1,4 @@
-// C ABI of the 2-D block-partitioned filter (include/eqf_vio_amd.h, "eqf_tiled_*" and "eqf_tile_*"): the per-rank device side of
+// C ABI of the 2-D block-partitioned filter (include/eqf_vio_amd.h: "eqf_tiled_*"; include/eqf_vio_amd_debug.h: the dense tile kernels "eqf_tile_*"): the per-rank device side of
 // BASELINE configs[4].  Second translation unit of libeqf_vio_amd.so; kernels in eqf_tiled.hpp (replicated O(N) state, base panel,
 // local blocks) and eqf_tile.hpp (dense tile kernels of the distributed factorisations).  No CPU fallback: without a GPU
 // eqf_tiled_create fails.
@@ -12,7 +12,7 @@
 #include <mutex>
 #include <vector>
 
-#include "../../include/eqf_vio_amd.h"
+#include "../../include/eqf_vio_amd_debug.h"  // (the public header + the test / measurement hooks this library also exports)
 #include "eqf_tile.hpp"
 #include "eqf_tiled.hpp"
 
@@ -468,6 +468,16 @@ int eqf_tiled_stage_bearings(eqf_tiled* t, const double* bearings) {
     }
     HIPC(hipEventSynchronize(t->evBear));  // (the previous frame's upload has left the staging buffer: it did long ago)
     std::memcpy(t->hBear, bearings, sizeof(double) * 3 * t->N);
+    return EQF_OK;
+}
+// (library-internal, csrc/eqf_tiledf.hip) A captured hipGraph of an update contains the upload of the staged bearings, but an event recorded
+// during capture is a node of the graph, not a record a host can wait on: after every replay the host loop records evBear here, on the
+// stream the graph was launched on, so that eqf_tiled_stage_bearings waits for THIS frame's copy node before it overwrites the buffer.
+extern "C" __attribute__((visibility("hidden"))) int eqf_tiled_bearings_consumed(eqf_tiled* t, void* stream) {
+    if (!t || !t->evBear) return EQF_ERR_INVALID;
+    DeviceScope ds(t->device);
+    if (!ds.ok) return EQF_ERR_HIP;
+    HIPC(hipEventRecord(t->evBear, static_cast<hipStream_t>(stream)));
     return EQF_OK;
 }
 // bit 0: which of the two scalar-state / landmark buffers is current, bit 1: which base panel (they alternate with every step / burst: the

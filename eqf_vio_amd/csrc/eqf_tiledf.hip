@@ -28,7 +28,7 @@
 #include <unordered_set>
 #include <vector>
 
-#include "../../include/eqf_vio_amd.h"
+#include "../../include/eqf_vio_amd_debug.h"  // (the public header + the test / measurement hooks this library also exports)
 
 #define HIPC(expr)                                                                              \
     do {                                                                                        \
@@ -43,6 +43,8 @@
         int rc_ = (expr);        \
         if (rc_ < 0) return rc_; \
     } while (0)
+
+extern "C" __attribute__((visibility("hidden"))) int eqf_tiled_bearings_consumed(eqf_tiled* t, void* stream);  // csrc/eqf_tiled.hip
 
 namespace {
 constexpr int kNarrowS = 18;  // (C Sigma)_Ib (11) | delta | V (6)
@@ -878,6 +880,7 @@ int update(eqf_tf* f, const std::vector<double>& y) {
     }
     if (exec) {
         HIPC(hipGraphLaunch(exec, f->sMain));
+        RC(eqf_tiled_bearings_consumed(f->t, f->sMain));  // (the graph's copy node of the staged bearings: see eqf_tiled.hip)
         ++f->graphLaunches;
     } else {
         RC(enqueueUpdate(f));
@@ -990,9 +993,11 @@ int eqf_tf_create(const eqf_settings* settings, int capacity_landmarks, int bloc
     f->taken.assign(f->cap, 0);
     if (const char* e = std::getenv("EQF_TILED_RESERVE_CUS")) reserve_cus = reserve_cus < 0 ? std::atoi(e) : reserve_cus;
     f->reserve = reserve_cus < 0 ? 8 : reserve_cus;
-    // over a collective library whose kernels share the GPU with ours (RCCL) the two chains of an update run one after the other unless the
-    // caller asks for the overlap (two communicators with kernels in flight on different streams are not validated on a node yet)
-    f->overlapChains = 1;
+    // On ONE rank the two chains of an update run side by side (measured: profiles/r05_tiled_*).  Over a collective library whose kernels
+    // share the GPU with ours (RCCL) they run one after the other unless the caller asks for the overlap (option "overlap_chains" /
+    // EQF_TILED_OVERLAP_CHAINS=1): every exchange already goes through one stream in program order, but the interleaved form has only ever
+    // run over gloo with the ranks on one GPU, never on a node -- unvalidated, so not the default there.
+    f->overlapChains = f->world > 1 ? 0 : 1;
     if (const char* e = std::getenv("EQF_TILED_OVERLAP_CHAINS")) f->overlapChains = std::atoi(e) != 0;
     // Block row k + 1 solved and exchanged NEXT TO the products of block row k (Chain::step): what hides the broadcasts on a node.  On one
     // rank there is nothing to hide and the extra streams cost: measured on the MI355X, 1 x 1 grid (profiles/r05_tiled_host_loop.txt), N = 4000

@@ -132,14 +132,14 @@ class TiledFilter:
         binding._check(L.eqf_tf_create(C.byref(settings), cap, self.bl, grid.Pr, grid.Pc, grid.rank, dev, reserve, comm, C.byref(self._h)), "eqf_tf_create")
         if self.be is not None:
             self.be.adopt(L.eqf_tf_tiled_handle(self._h))
-        # The two factorisations of an update run side by side on two stream pairs.  Round 4 serialised them over nccl (two communicators with
-        # kernels in flight from one process); since round 5 every exchange of the handle is issued on ONE stream in program order
-        # (csrc/eqf_tiledf.hip: bcast), so a communicator only ever sees an ordered sequence and the chains overlap everywhere.  Never run on
-        # more than one GPU: EQF_TILED_OVERLAP_CHAINS=0 puts the chains one after the other again.
+        # The two factorisations of an update run side by side on two stream pairs -- on one rank, and over gloo (the process-grid tests: the
+        # ranks share one GPU).  Every exchange of the handle is issued on ONE stream in program order (csrc/eqf_tiledf.hip: bcast), so a
+        # communicator only ever sees an ordered sequence; still, the interleaved form has never run over RCCL on a node, so over nccl the
+        # chains run one after the other unless EQF_TILED_OVERLAP_CHAINS=1 asks for the overlap (the library's own default, eqf_tf_create).
         import os
 
         env = os.environ.get("EQF_TILED_OVERLAP_CHAINS")
-        self.overlap_chains = (env != "0") if env is not None else True
+        self.overlap_chains = (env != "0") if env is not None else not (grid.world > 1 and grid.backend_name() == "nccl")
         self._phases_on = False
 
     def close(self):

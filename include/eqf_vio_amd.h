@@ -146,13 +146,6 @@ int eqf_get_integrator(eqf_filter* f, int b, double* currentVelocity6, double* a
 
 /* Internals of the most recent update of filter b: delta[2N], gamma[11+3N] (K*delta), Gamma[9+3N]. */
 int eqf_get_last_update(eqf_filter* f, int b, double* delta, double* gamma, double* Gamma);
-/* Test hook for block-level parity (A0 / B / C0 blocks): the linearisation blocks of filter b as the most
- * recent single-step launch of the split propagate path (k_build_blocks: EQF_IMU_BURST=0, EQF_SPLIT_PROPAGATE=1) left
- * them, and the per-landmark output blocks.  common[31] = T, B[0:2,0:3] (6), B[2:5,0:3] (9), R_A = B[2:5,3:6] (9),
- * A0[2:5,0:2] (6), row-major (EqFMatrices.cpp:288-289, :364-368).  rec[N][27] per landmark: D = I + T A0[ii] (9),
- * Lw = -T B[5+3i.., 0:3] (9), Lv = T A0[5+3i.., 2:5] (9) (EqFMatrices.cpp:294-314, :370-380).  c0[N][6] = C0i, the 2 x 3
- * block of EqFOutputMatrixC (EqFMatrices.cpp:319-344).  Any pointer may be NULL.  fp64 handles only. */
-int eqf_debug_get_blocks(eqf_filter* f, int b, double* common, double* rec, double* c0);
 /* Sticky device-side error flag, 0 if none; a bit mask (any bit -> the C++ facade throws std::domain_error, like the reference's
  * SO3FromVectors, SO3.cpp:160): 1 antipodal vectors / singular gravity chart in a propagate step; 2 the same while building the residual
  * or C0i; 4 a pivot of S or Sigma_e not positive; 8 antipodal vectors in the innovation lift (numeric, one filter: the other filters of a
@@ -169,27 +162,10 @@ int eqf_debug_get_blocks(eqf_filter* f, int b, double* common, double* rec, doub
  * once, every other wait of the launch sees the bit within microseconds and gives up, no workgroup publishes anything after a failed
  * wait, the covariance downdate does not run (Sigma keeps its pre-update value), and the call that next touches the handle returns
  * EQF_ERR_NUMERIC.  The flag is sticky: later updates of the handle leave at once until eqf_reset.
- * EQF_CHOL_RESIDENT=0 selects one launch per 64-wide block column instead (no in-launch dependency at all). */
+ * EQF_CHOL_RESIDENT=0 selects one launch per 64-wide block column instead (no in-launch dependency at all).
+ * (Fault injection for these hand-offs, the developer toggles, the per-kernel timers and the dense tile kernels behind the partitioned
+ * filter are test / measurement hooks: include/eqf_vio_amd_debug.h -- a caller of the reference's interface needs none of them.) */
 int eqf_device_error(eqf_filter* f);
-/* Fault injection for the in-launch hand-offs (tests only): from the next update on, the workgroup of k_chol_resident with role (kind:
- * 0 S-chain / 1 E-chain; role: 0 row head H(R), 1 interior tile T(R, C), 2 right-hand-side tile W(t = R, C)) leaves without doing or
- * publishing anything, as if it had never been scheduled: its consumers time out after 0.5 s, bit 128 is raised, the launch unwinds, the
- * covariance downdate does not run.  kind < 0 switches the injection off.  The handle needs eqf_reset / eqf_set_state afterwards. */
-int eqf_debug_drop_role(eqf_filter* f, int kind, int role, int R, int C);
-/* Developer toggles by name (tests and measurements; a production caller needs none of them).  EQF_ERR_INVALID: unknown name.
- *   "cs_in_burst"  1 (default): an IMU burst closed by a vision step also leaves the landmark columns of C Sigma and S = C Sigma C^T + R,
- *                  formed from the covariance blocks its workgroups hold in registers; the update's prep work then reads 12 columns of
- *                  Sigma per landmark instead of all of them -- at the throughput sizes (many filters, N >= 400), where it pays.
- *                  2: on every burst that runs as two launches.  0: the prep launch forms them.  Bit for bit the same either way.
- *   "device_edit"  1 (default): a vision frame's landmark bookkeeping -- the landmarks that left (VIOFilter.cpp:393-419), the outlier gate
- *                  (:429-443), the new landmarks (:345-391) -- is ONE launch that decides and acts on the device; the id lists of the handle
- *                  follow when the caller next touches it and no frame is redone.  0: separate launches, a frame with an outlier is redone
- *                  from the host.  Bit for bit the same either way.
- *   "burst_fused_max_x10"    the one-launch IMU burst (k_burst_fused) is used up to value / 10 workgroups per CU (default: 1.25).
- *   "e_sigma_min_percu_x10"  the two-per-CU build of the update launch reads the E-chain's tiles in Sigma itself from value / 10 chain roles per
- *                  CU on (default 2.4: every such grid); below, the prep launch copies Sigma[6:, 6:].  Launch shapes only: same results. */
-int eqf_debug_option(eqf_filter* f, const char* name, int value);
-
 /* IMU bursts.  processIMUData calls (VIOFilter.cpp:120-131) only depend on each other and on the state, so the library
  * queues them on the host and launches up to 15 of them -- plus the integrateUpToTime of the processVisionData call
  * that follows (VIOFilter.cpp:233) -- as ONE pair of kernels that reads and writes Sigma once (csrc/eqf_burst.hpp).
@@ -203,26 +179,6 @@ int eqf_set_imu_burst(eqf_filter* f, int max_steps);
  * 1 = dense F Sigma F^T on MFMA (what the reference executes; BASELINE cfg 3 cross-check). */
 int eqf_set_dense_propagate(eqf_filter* f, int on);
 
-/* Per-kernel-class timing with HIP events on the handle's stream (bench.py roofline leg).
- * eqf_profile_get: for class c in [0, EQF_PROF_CLASSES) -> launches and total milliseconds.  The total is, per launch shape
- * within the class (chain step index, burst length), the median bracket times the number of launches of that shape, minus
- * the calibrated cost of an empty bracket: an event bracket also contains the time the stream waited for the host. */
-#define EQF_PROF_PROPAGATE 0
-#define EQF_PROF_UPDATE_PREP 1
-#define EQF_PROF_CHOL_STEP 2
-#define EQF_PROF_REDUCE 3
-#define EQF_PROF_FINISH 4
-#define EQF_PROF_DOWNDATE 5
-#define EQF_PROF_CHURN 6
-#define EQF_PROF_DENSE 7 /* k_dense_build + the two k_dense_gemm launches of the dense Riccati backend */
-#define EQF_PROF_BURST 8 /* k_burst_build + k_burst_riccati: one bracket per burst of integrateUpToTime steps */
-#define EQF_PROF_CHOL_DD 9 /* the one k_chol_step64 launch per update that also carries Sigma - Y^T Y (64-wide path) */
-#define EQF_PROF_CHOL_RESIDENT 10 /* k_chol_resident: the whole factorisation part of an update as one launch */
-#define EQF_PROF_CLASSES 11
-int eqf_profile_enable(eqf_filter* f, int on);
-int eqf_profile_get(eqf_filter* f, int cls, long long* launches, double* total_ms);
-const char* eqf_profile_class_name(int cls);
-
 /* ================================================================================================================================
  * BASELINE configs[4]: ONE filter with N = 4000 landmarks whose Sigma (1.15 GB) is 2-D block-partitioned over the GPUs of a node.
  * One process per GPU; process (pr, pc) of a Pr x Pc grid owns the landmark blocks I = pr, pr + Pr, ... as rows and J = pc, pc + Pc,
@@ -230,7 +186,8 @@ const char* eqf_profile_class_name(int cls);
  * that torch.distributed can move pieces of it).  The O(N) filter state and the 11-row base panel Sigma[0:11, :] are REPLICATED: every
  * rank advances its own identical copy inside its eqf_tiled handle, with the same device functions as the single-GPU path.  The
  * exchange schedule (which block row is factored where, the RCCL broadcasts of the solved block rows) is eqf_vio_amd/tiled.py; the
- * entry points below are what a rank runs between two exchanges.  They enqueue on the handle's stream (eqf_tiled_set_stream; NULL = the
+ * entry points below (and the dense tile kernels eqf_tile_* of eqf_vio_amd_debug.h, for a host that writes its own schedule) are what a rank
+ * runs between two exchanges.  They enqueue on the handle's stream (eqf_tiled_set_stream; NULL = the
  * default stream) and return; getters synchronise.  fp64 only.
  * Landmark churn (VIOFilter.cpp:345-443) works on SLOTS: the partition is over the handle's N physical landmark slots, a removed
  * landmark leaves an inactive slot behind (zero rows / columns of Sigma with a unit diagonal block, identity linearisation, no
@@ -331,9 +288,9 @@ int eqf_tiled_set_state(eqf_tiled* t, int N, const double* pose_q, const double*
  * (EQF_ERR_UNSORTED: ids not strictly ascending, VIOFilter.cpp:239-240; EQF_ERR_CAPACITY; EQF_ERR_NUMERIC: a pivot of S or Sigma_e not
  * positive, looked at every check_every-th update).  Getters answer in the REFERENCE's landmark order (insertion order, :211-230); the
  * landmark slots behind it (eqf_tiled, above) are internal.  eqf_tf_get_sigma is collective (every rank calls it).
- * Options (eqf_tf_set_option): "lookahead" (1), "overlap_chains" (1; EQF_TILED_OVERLAP_CHAINS), "burst" (1: IMU calls queued and sent as
- * bursts), "check_every" (1), "profiling" (0: event brackets per phase, eqf_tf_get_phases), "graphs" (0: hipGraph replay of an update on a
- * one-rank grid, see eqf_tf_graph_launches).
+ * Options (eqf_tf_set_option): "lookahead" (1), "overlap_chains" (1 on one rank, 0 on a grid: the interleaved chains are not validated over RCCL on a node; EQF_TILED_OVERLAP_CHAINS), "burst" (1: IMU calls queued and sent as
+ * bursts), "check_every" (1), "profiling" (0: event brackets per phase, eqf_tf_get_phases in eqf_vio_amd_debug.h), "graphs" (0: hipGraph replay of an update on a
+ * one-rank grid, see eqf_tf_graph_launches in eqf_vio_amd_debug.h).
  * ================================================================================================================================ */
 typedef struct eqf_tf eqf_tf; /* opaque */
 typedef struct eqf_tf_comm {
@@ -366,56 +323,9 @@ int eqf_tf_set_state(eqf_tf* f, int N, const int* ids, const double* pose_q, con
     double currentTime, const double* currentVelocity6, const double* accumulatedVelocity6, double accumulatedTime, int initialised);
 int eqf_tf_get_churn_stats(eqf_tf* f, long long* stats3); /* removed_old, removed_outliers, added */
 int eqf_tf_local_matrix(eqf_tf* f, double** ptr, int* rows, int* cols, int* ld);
-int eqf_tf_get_phases(eqf_tf* f, double* ms7);
-const char* eqf_tf_phase_name(int i);
 const char* eqf_tf_last_error(eqf_tf* f);
-void* eqf_tf_tiled_handle(eqf_tf* f); /* the rank's eqf_tiled (getters of the replicated state in SLOT order, tests) */
-/* One rank: the launch sequence of an update (~2000 launches at N = 4000) is captured once per (slots in use, buffer parity) as a hipGraph
- * and replayed with one hipGraphLaunch -- option "graphs"; OFF by default: on ROCm 7.2 the replay takes the GPU 1.6 x
- * (N = 4000) to 4 x (N = 1000) as long as the plain launches on four streams (csrc/eqf_tiledf.hip).  Updates replayed from a graph so far: */
-long long eqf_tf_graph_launches(eqf_tf* f);
-
-/* ---- Dense tile kernels of the distributed factorisations, on CALLER-OWNED device memory of HIP device `device`, enqueued on
- * `stream` (a hipStream_t, NULL = the default stream) without synchronising; the caller's current device is restored.
- * eqf_tile_gemm_tn: C (m x n, ldc) += alpha A^T B for A (k x m, lda), B (k x n, ldb), row-major -- every O(n^3) product of the
- *   distributed update in the block-ROW form of the factorisation: trailing updates U_ki^T U_kj and right-hand sides U_ki^T Y_kt
- *   (VIOFilter.cpp:276-277, EqFMatrices.cpp:239), the downdate Sigma_IJ -= Y_kI^T Y_kJ (VIOFilter.cpp:297), the reductions.
- *   mask_rb > 0: C is the matrix part of a block-cyclic local matrix whose strictly-lower blocks are never read; tiles entirely below
- *   the block diagonal are skipped (row r is in global block (rblk0 + r / mask_rb) * Pr + pr, column c in (cblk0 + c / mask_cb) * Pc + pc).
- *   The epilogue is C += alpha * acc as fire-and-forget global_atomic_add_f64 (one writer per element and launch: deterministic).  Two
- *   consequences for a caller: C must be ordinary (coarse-grained) device memory -- hipMalloc / a torch CUDA tensor; on fine-grained or
- *   host-coherent allocations hardware fp64 atomics may be unsupported -- and for alpha other than +-1 the result is rounded twice
- *   (alpha * acc, then the addition) instead of once as fma(alpha, acc, C); every product of the filter uses alpha = +-1.
- * eqf_tile_downdate = eqf_tile_gemm_tn with alpha = -1 and no mask.
- * eqf_tile_potrf: A (n x n, ld, lower triangle) <- L with A = L L^T: the diagonal block of a block row; drec [ceil(n / 64)][5120]
- *   receives, per 64-wide block column, L_jj and the inverses of its four 16 x 16 diagonal blocks (what eqf_tile_trsm multiplies with);
- *   info (device int, may be NULL) is or-ed with 1 if a pivot is not positive.
- * eqf_tile_trsm: right = 1: B (m x n, ldb) <- B L^-T; right = 0: B (n x m, ldb) <- L^-1 B (the solved block row [U_k,k+1.. | Y_k]).
- * eqf_tile_propagate: one structured Riccati step of a (3 nI x 3 nJ) tile from explicit block arrays (kept for the block-level tests;
- *   the closed loop uses eqf_tiled_propagate):
- *     out = (D_I in + L_I Sigma_bJ) D_J^T + (L_I Sigma_bb + D_I Sigma_Ib) L_J^T + T (B_I R B_J^T) [+ diag_noise I on a diagonal tile] */
-/* A HIP stream whose kernels only run on the CUs [first_cu, first_cu + num_cus) (complement = 0) or on all the others (complement = 1)
- * (hipExtStreamCreateWithCUMask).  The look-ahead of the distributed factorisations factors the next diagonal block -- one workgroup
- * with 119 KB of LDS -- on a few reserved CUs while the trailing update fills the rest of the chip; without the reservation the
- * update's workgroups (two per CU, 147 KB of LDS) never leave room for it. */
-int eqf_stream_create_masked(int device, int first_cu, int num_cus, int complement, void** out);
-int eqf_stream_destroy(int device, void* stream);
-int eqf_tile_gemm_tn(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k,
-    double alpha, int mask_rb, int mask_cb, int rblk0, int Pr, int pr, int cblk0, int Pc, int pc);
-/* C (n x n, ldc; symmetric up to rounding, blocks of rb): C[r][c] <- C[c][r] wherever r / rb > c / rb.  Completes a block-upper-masked
- * eqf_tile_gemm_tn on a rank whose local matrix is symmetric (square process grid, diagonal rank): Sigma - K C Sigma = Sigma - Y^T Y
- * (VIOFilter.cpp:297) at half the flops there. */
-int eqf_tile_mirror(int device, void* stream, double* C, int ldc, int n, int rb);
-int eqf_tile_propagate(int device, void* stream, double* out, const double* in, int ld, int nI, int nJ, const double* D_I,
-    const double* L_I, const double* D_J, const double* L_J, const double* Sbb, const double* SbI, int ldbI, const double* SbJ,
-    int ldbJ, const double* BnI, const double* BnJ, const double* R6, double T, double diag_noise, int is_diag);
-int eqf_tile_downdate(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb,
-    int k);
-int eqf_tile_potrf(int device, void* stream, double* A, int ld, int n, double* drec, int* info);
-int eqf_tile_trsm(int device, void* stream, const double* A, int ld, int n, const double* drec, double* B, int ldb, int m, int right);
-
 const char* eqf_version(void);
-/* "src_sha256=<hex>": sha256 over the library's sources (every .hip and .hpp file of csrc/, this header, csrc/Makefile; concatenated in sorted
+/* "src_sha256=<hex>": sha256 over the library's sources (every .hip and .hpp file of csrc/, the two headers of include/, csrc/Makefile; concatenated in sorted
  * order) at build time -- lets a caller prove that the .so it loaded was built from the sources beside it (bench.py's `build` block). */
 const char* eqf_build_info(void);
 
