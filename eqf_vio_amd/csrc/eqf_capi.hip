@@ -188,6 +188,9 @@ struct eqf_filter {
     int numCUs = 0;
     int nbCap = 0, wtCap = 0;
     int *dReadyA = nullptr, *dReadyY = nullptr, *dResCounters = nullptr, *dStageFlags = nullptr;
+    unsigned* dTicket = nullptr;  // k_chol_resident on a grid larger than the chip: arrival tickets, [B][32] (ResArgs::ticket); ticketBase = tickets drawn per filter by earlier launches
+    unsigned ticketBase = 0;
+    int resTickets = 1;           // eqf_debug_option "res_tickets" 0: the block index instead (rounds 3-5)
     double *dGammaPart = nullptr, *dG11Part = nullptr;
     ResRole* dRoles = nullptr;
     int resPipeHeads = -1;         // [no switch since round 5]: row heads with the pipelined panel loop (1), without (0), by grid size (-1)
@@ -548,7 +551,7 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
         a.YW = f->YW; a.SA = f->SA; a.lmc = f->lmc;
         a.ldY = f->ldY; a.ldS = f->ldS; a.strideY = f->strideY; a.strideS = f->strideS;
     }
-    {
+    if (visionLast || f->lastBurstShape[6] == 0) {  // (the bursts that matter to a frame: the ones a vision step closes)
         const int shape[8] = {lm, R, fused ? 1 : 0, a.csOut, (int)bgrid.x, (int)rgrid.x, K, 0};
         std::copy(shape, shape + 8, f->lastBurstShape);
     }
@@ -916,6 +919,11 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
                 const int perFilter = ra.nPrep + f->rolesCount + ddGrid;
                 ra.rolesPerRow = std::min(perFilter, 32768);
                 const dim3 rg(B * ra.rolesPerRow, (perFilter + ra.rolesPerRow - 1) / ra.rolesPerRow);
+                if (pipeHeads && f->resTickets && f->dTicket) {  // (every workgroup of the launch draws exactly one ticket, padding workgroups included)
+                    ra.ticket = f->dTicket;
+                    ra.ticketBase = f->ticketBase;
+                    f->ticketBase += ra.rolesPerRow * rg.y;  // (per filter)
+                }
                 if (fold && pipeHeads) launchFold<T>(rg, f->stream, ra, true, occ2);
                 else if (pipeHeads && occ2) hipLaunchKernelGGL((k_chol_resident<T, true, true>), rg, dim3(256), kLdsRes2Bytes, f->stream, ra);
                 else if (pipeHeads) hipLaunchKernelGGL((k_chol_resident<T, true>), rg, dim3(256), sizeof(Step64Lds), f->stream, ra);
@@ -1526,7 +1534,7 @@ void freeAll(eqf_filter* f) {
     for (void* p : {(void*)f->p0, (void*)f->lmc, (void*)f->SA, (void*)f->SL, (void*)f->YW, (void*)f->YO, (void*)f->EA, (void*)f->EL, (void*)f->ZW,
              (void*)f->ZO, (void*)f->dbgDelta, (void*)f->dbgGamma, (void*)f->dbgGammaTot, (void*)f->red, (void*)f->errflag, (void*)f->dMap,
              (void*)f->dPerm, (void*)f->dChord, (void*)f->dDepth2, (void*)f->dDepthSel, (void*)f->dScratch, (void*)f->dMeas,
-             (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn, f->dBlk, (void*)f->dBlkCommon, f->dColRec, f->dRowRec, (void*)f->dSteps, (void*)f->dFlags, (void*)f->dReadyA, (void*)f->dReadyY, (void*)f->dResCounters, (void*)f->dStageFlags, (void*)f->dPrepFlags, (void*)f->dBuildFlags, (void*)f->dGammaPart,
+             (void*)f->dOut, (void*)f->dRing, (void*)f->sImu, (void*)f->sVis, (void*)f->sBear, f->dF, f->dG, f->dBn, f->dBlk, (void*)f->dBlkCommon, f->dColRec, f->dRowRec, (void*)f->dSteps, (void*)f->dFlags, (void*)f->dReadyA, (void*)f->dReadyY, (void*)f->dResCounters, (void*)f->dTicket, (void*)f->dStageFlags, (void*)f->dPrepFlags, (void*)f->dBuildFlags, (void*)f->dGammaPart,
              (void*)f->dG11Part, (void*)f->dRoles})
         hipFree(p);
     if (f->hGate) hipHostFree(f->hGate);
@@ -1745,6 +1753,8 @@ int eqf_create(const eqf_settings* settings, int capacity_landmarks, int batch, 
             chk(dmalloc(&f->dReadyA, (size_t)2 * f->nbCap * f->nbCap * B));
             chk(dmalloc(&f->dReadyY, (size_t)2 * f->nbCap * f->wtCap * B));
             chk(dmalloc(&f->dResCounters, (size_t)4 * B));
+            chk(dmalloc(&f->dTicket, (size_t)32 * B));  // (one counter per filter, a 128-byte line each)
+            if (!rc && hipMemset(f->dTicket, 0, sizeof(unsigned) * 32 * B) != hipSuccess) rc = EQF_ERR_HIP;
             chk(dmalloc(&f->dStageFlags, (size_t)2 * f->nbCap * 4 * B));
             if (!rc && hipMemset(f->dStageFlags, 0, sizeof(int) * 2 * f->nbCap * 4 * B) != hipSuccess) rc = EQF_ERR_HIP;
             f->nPrepCap = (mpC / 2 + 3) / 1 + nepC / kNB + 8;  // (landmark workgroups carry >= 1 wave each; Z-row workgroups of kNB rows)
@@ -2201,7 +2211,8 @@ int eqf_set_state(eqf_filter* f, int b, int N, const int* ids, const double* pos
         int e = 0;
         HIPC(hipMemcpy(&e, f->errflag, sizeof(int), hipMemcpyDeviceToHost));
         if (e & 128) {
-            e &= ~128;
+            // (bit 4 with it: a chain that unwinds may have judged a pivot of operands it never received -- a by-product of the time-out)
+            e &= ~(128 | 4);
             HIPC(hipMemcpy(f->errflag, &e, sizeof(int), hipMemcpyHostToDevice));
             if (f->dEditBar) HIPC(hipMemset(f->dEditBar, 0, sizeof(int) * 4 * f->B));
         }
@@ -2304,6 +2315,10 @@ int eqf_debug_option(eqf_filter* f, const char* name, int value) {
     }
     if (!std::strcmp(name, "burst_fused_max_x10")) {
         f->fusedMaxPerCU = value / 10.0;
+        return EQF_OK;
+    }
+    if (!std::strcmp(name, "res_tickets")) {
+        f->resTickets = value ? 1 : 0;
         return EQF_OK;
     }
     if (!std::strcmp(name, "device_edit")) {

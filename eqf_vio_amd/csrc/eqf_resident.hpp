@@ -20,9 +20,10 @@
 //   The last right-hand-side workgroup of the E-chain waits for every share, sums them IN BLOCK-ROW ORDER (deterministic)
 //   and runs the innovation lift.  The downdate tiles Sigma - Y^T Y are workgroups of their own BEHIND the roles in the grid: they
 //   wait for the S-chain's last Y tile and overlap the tail of the (longer) E-chain.
-// Deadlock freedom: block indices follow the dependency order -- a workgroup only ever waits for workgroups with a LOWER block index
-// (roles: the groups before theirs; downdate tiles: the S-chain's roles) -- so whatever part of the grid is resident contains a
-// workgroup that can run, co-resident grid or not.  (Until late in round 3 a co-resident grid ran the downdate in the finished role
+// Deadlock freedom: the roles are numbered in dependency order -- a workgroup only ever waits for LOWER numbers (roles: the groups before
+// theirs; downdate tiles: the S-chain's roles).  On a co-resident grid everything is resident.  On a grid larger than the chip the number
+// of a workgroup is a TICKET drawn when it starts (ResArgs::ticket, round 6): whoever holds number i runs, and all lower numbers run or are
+// done -- no assumption about the order in which the hardware starts workgroups (rounds 3-5: the block index, i.e. "in order").  (Until late in round 3 a co-resident grid ran the downdate in the finished role
 // workgroups, which waited for higher block indices while holding their CUs: removed.)  Every wait is bounded (eqf_handoff.hpp,
 // 0.5 s): a timeout raises the sticky device error flag (bit 128 -> EQF_ERR_NUMERIC from eqf_device_error) and the workgroup that saw it
 // publishes nothing more, so the downdate tiles never see the S-chain complete: Sigma_out is not overwritten from stale operands.
@@ -65,6 +66,19 @@ struct ResArgs {
     int eFromSigma;        // the E-chain's tiles are first read straight from Sigma (EA = Sigma[6:, 6:] with the pad row / column 5 and
                            // the rows past n_e as the identity): the prep launch does not copy them
     int* stageFlags;       // [B][2][nbCap][4]  stage j of D[K] of chain c is in the record (epoch valued; factor64's stageFlag)
+    // Grids larger than the chip (the PIPEH builds): WHICH role of its filter a workgroup plays is DRAWN when it starts --
+    // atomicAdd(ticket[32 b], 1) - ticketBase, one counter per filter on a line of its own (the counters run on from launch to launch, the
+    // host keeps the base; the filter itself stays the block index's: with a batch that is a multiple of 8 a filter's workgroups share an
+    // XCD, i.e. an L2) -- instead of read off its block index.  Whoever holds ticket i of a filter is running, and every role it can wait
+    // for is a lower ticket of the same filter, i.e. running or done: the roles are free of deadlock in whatever order the hardware starts
+    // the workgroups (rounds 3-5 relied on "in the order of their linear index", which HIP does not promise).  One exception keeps the
+    // time-out as its only guard: batches that are multiples of 8 above 8 hand a downdate tile to a workgroup of ANOTHER filter of the same
+    // XCD (the L2-friendly order below), which then waits for roles whose tickets it cannot vouch for.  nullptr: the block index
+    // (co-resident grids: everything is resident, nothing to order).  (One counter for the whole grid was measured first: 8 filters 164.6 ->
+    // 181.8 us per update, 64 filters 982 -> 1054 -- 512 workgroups arrive at once and a device-scope atomic on one address takes ~35 ns,
+    // and the arrival order scatters a filter's roles over the XCDs.)
+    unsigned* ticket;
+    unsigned ticketBase;
 };
 
 // ---- 64x64 block <-> LDS through write-through / L1-bypassing 16-byte accesses.  Thread t handles row t / 4, 16 doubles
@@ -423,7 +437,15 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
     // (role index and filter from the linear workgroup index: grid = (B * rolesPerRow, rows), filter fastest; one row unless the roles and
     // downdate tiles of a filter are more than 32768 -- N > ~2700)
     const int nB = (int)gridDim.x / ra.rolesPerRow;
-    const int roleIdxAll = (int)blockIdx.x / nB + ra.rolesPerRow * (int)blockIdx.y, bIdx = (int)blockIdx.x % nB;
+    int roleIdxAll = (int)blockIdx.x / nB + ra.rolesPerRow * (int)blockIdx.y, bIdx = (int)blockIdx.x % nB;
+    if (PIPEH && ra.ticket) {
+        // (see ResArgs::ticket) the role index inside the filter is the order of ARRIVAL among the filter's workgroups
+        int* const sT = reinterpret_cast<int*>(smemR);
+        if (threadIdx.x == 0) *sT = (int)(atomicAdd(ra.ticket + 32 * bIdx, 1u) - ra.ticketBase);
+        __syncthreads();
+        roleIdxAll = *sT;
+        __syncthreads();  // (the first bytes of the dynamic LDS belong to the role from here on)
+    }
     if (FOLD && roleIdxAll >= ra.nFront && roleIdxAll < ra.nFront + ra.nPrep) {
         // ---- a prep role (see ResArgs::nPrep): among the lowest block indices of the grid -- nothing they need is produced in this launch
         EQF_STAT_CLASS(4);

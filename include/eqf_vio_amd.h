@@ -151,8 +151,9 @@ int eqf_get_last_update(eqf_filter* f, int b, double* delta, double* gamma, doub
  * or C0i; 4 a pivot of S or Sigma_e not positive; 8 antipodal vectors in the innovation lift (numeric, one filter: the other filters of a
  * batch handle keep running); 16 / 32 a new / restored landmark on the chart pole; 64 singular gravity chart in the dense Riccati backend;
  * 128 an in-launch hand-off of k_chol_resident / k_burst_fused timed out (0.5 s: the GPU was taken away from the launch for that long) --
- * that launch did not write Sigma and the handle must be reset (eqf_reset) or restored (eqf_set_state): until then every later launch
- * with hand-offs leaves at once.  (After a timeout inside an IMU burst the covariance the handle points at is the other ping-pong
+ * that launch did not write Sigma and the handle must be reset (eqf_reset) or restored (eqf_set_state on EVERY filter of the handle: the call
+ * that restores the last one clears bit 128, and bit 4 with it -- a chain that unwinds may have judged pivots of operands it never got): until
+ * then every later launch with hand-offs leaves at once.  (After a timeout inside an IMU burst the covariance the handle points at is the other ping-pong
  * buffer, i.e. NOT a valid state: restore, do not continue.)
  * About the hand-offs behind bit 128: k_chol_resident (one launch per vision update, csrc/eqf_resident.hpp) lets workgroups of ONE launch
  * wait for each other.  It is free of deadlock on any grid -- also many times larger than the chip -- under ONE assumption about the

@@ -33,11 +33,13 @@ int eqf_debug_drop_role(eqf_filter* f, int kind, int role, int R, int C);
  *                  (:429-443), the new landmarks (:345-391) -- is ONE launch that decides and acts on the device; the id lists of the handle
  *                  follow when the caller next touches it and no frame is redone.  0: separate launches, a frame with an outlier is redone
  *                  from the host.  Bit for bit the same either way.
+ *   "res_tickets"  1 (default): on a grid larger than the chip a workgroup of the update launch draws its place in the dependency order from a
+ *                  counter when it starts (no assumption about the hardware's dispatch order); 0: the block index, as in rounds 3-5.  Same results.
  *   "burst_fused_max_x10"    the one-launch IMU burst (k_burst_fused) is used up to value / 10 workgroups per CU (default: 1.25).
  *   "e_sigma_min_percu_x10"  the two-per-CU build of the update launch reads the E-chain's tiles in Sigma itself from value / 10 chain roles per
  *                  CU on (default 2.4: every such grid); below, the prep launch copies Sigma[6:, 6:].  Launch shapes only: same results. */
 int eqf_debug_option(eqf_filter* f, const char* name, int value);
-/* The launch shape of the handle's most recent IMU burst (bench.py prices the kernels by it): shape8[0] landmarks per builder workgroup,
+/* The launch shape of the handle's most recent IMU burst that a vision step closed (bench.py prices the kernels by it): shape8[0] landmarks per builder workgroup,
  * [1] row landmarks per wavefront of the block kernel, [2] 1 = one launch (k_burst_fused), [3] 1 = the burst also left the landmark columns
  * of C Sigma and S (the update's prep work does not read Sigma then), [4] builder workgroups per filter, [5] block-kernel workgroups per
  * filter, [6] steps in the burst, [7] reserved.  Does not touch the device or flush anything. */

@@ -1,0 +1,291 @@
+// Bounded experiment: can the dense product of the covariance downdate, C = A^T B in fp64 (VIOFilter.cpp:297 as
+// Sigma - Y^T Y), ride the LOW-PRECISION matrix pipe and still be fp64-grade?  The only route that keeps the accumulation exact is the
+// integer one (Ozaki-style splitting): every column of A and B is scaled by a power of two and cut into S signed 7-bit slices (int8, |q| <=
+// 64), slice pairs (ta, tb) with ta + tb < S are multiplied on v_mfma_i32_32x32x32_i8 -- int32 accumulation is EXACT (K * S * 64^2 < 2^31
+// for K <= 70 000) -- and the S accumulators of an element (one per ta + tb) are recombined in fp64.  S (S + 1) / 2 integer products
+// replace one fp64 product: 28 for S = 7 (2^-49 of the column scales), 21 for S = 6 (2^-42), 15 for S = 5 (2^-35).
+//
+// What is measured: the split pass (read fp64, write S int8 slices in MFMA fragment order), the integer GEMM + recombination, the error
+// against a long-double reference on sampled entries, and the fp64-equivalent rate 2 M N K / time -- to hold against k_tile_gemm_tn's 58-60
+// TFLOP/s (fp64 MFMA, scripts/gemm_bench.py) at the same shapes.  Standalone: hipcc --offload-arch=gfx950 -O3 -o i8_split_gemm i8_split_gemm.hip
+//   ./i8_split_gemm [M=2048] [N=2048] [K=2000] [S=7] [wide=0|1] [reps=20]
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#define CK(x)                                                                                   \
+    do {                                                                                        \
+        hipError_t e_ = (x);                                                                    \
+        if (e_ != hipSuccess) {                                                                 \
+            std::fprintf(stderr, "%s: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            std::exit(1);                                                                       \
+        }                                                                                       \
+    } while (0)
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int kSMax = 8;
+constexpr int kBits = 7;  // bits a slice adds below the previous one; the first slice carries 6 (|x / scale| < 1 -> |q0| <= 64)
+
+// ---- pass 1: per column the power of two that bounds it.  X is K x M row-major (the contraction index is the ROW, as in Y^T Y).
+__global__ void k_colmax(const double* X, int K, int M, int ld, int* expo) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= M) return;
+    double mx = 0.0;
+    for (int k = 0; k < K; ++k) mx = fmax(mx, fabs(X[(size_t)k * ld + c]));
+    int e = 0;
+    if (mx > 0.0) frexp(mx, &e);  // mx = f * 2^e, f in [0.5, 1): |x| * 2^-e < 1
+    expo[c] = e;
+}
+
+// ---- pass 2: slices in MFMA fragment order.  For a 32-column tile ct, a 32-row chunk kc and slice t: one 1 KB block, lane l's 16 bytes =
+// column ct * 32 + (l & 31), rows kc * 32 + (l >> 5) * 16 .. + 16  (v_mfma_i32_32x32x32_i8: A[i = l & 31][k = 16 (l >> 5) ..]).
+// Address (bytes) = (((ct * nKc + kc) * S + t) * 64 + l) * 16.
+template <int S>
+__global__ void k_split(const double* X, int K, int M, int ld, const int* expo, int8_t* out, int nKc) {
+    const int ct = blockIdx.x, kc = blockIdx.y, l = threadIdx.x;  // 64 threads
+    const int c = ct * 32 + (l & 31), k0 = kc * 32 + (l >> 5) * 16;
+    const double sc = (c < M) ? ldexp(1.0, -expo[c]) : 0.0;
+    int8_t q[S][16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int k = k0 + j;
+        double r = (c < M && k < K) ? X[(size_t)k * ld + c] * sc : 0.0;  // |r| < 1, exact (power-of-two scale)
+        double w = 64.0;                                              // 2^6, then 2^13, 2^20, ...
+#pragma unroll
+        for (int t = 0; t < S; ++t) {
+            const double qq = rint(r * w);  // |qq| <= 64
+            q[t][j] = (int8_t)qq;
+            r -= qq / w;                    // exact: r and qq / w are multiples of a common power of two within 53 bits
+            w *= 128.0;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+        int4 v;
+        v.x = (uint8_t)q[t][0] | ((uint8_t)q[t][1] << 8) | ((uint8_t)q[t][2] << 16) | ((uint32_t)(uint8_t)q[t][3] << 24);
+        v.y = (uint8_t)q[t][4] | ((uint8_t)q[t][5] << 8) | ((uint8_t)q[t][6] << 16) | ((uint32_t)(uint8_t)q[t][7] << 24);
+        v.z = (uint8_t)q[t][8] | ((uint8_t)q[t][9] << 8) | ((uint8_t)q[t][10] << 16) | ((uint32_t)(uint8_t)q[t][11] << 24);
+        v.w = (uint8_t)q[t][12] | ((uint8_t)q[t][13] << 8) | ((uint8_t)q[t][14] << 16) | ((uint32_t)(uint8_t)q[t][15] << 24);
+        reinterpret_cast<int4*>(out)[(((size_t)ct * nKc + kc) * S + t) * 64 + l] = v;
+    }
+}
+
+// ---- the integer GEMM + recombination.  Workgroup = 256 threads = 2 x 2 waves, tile 128 (columns of A = rows of C) x 64 (columns of B);
+// a wave owns 64 x 32 = two 32 x 32 MFMA tiles.  Per 32-row chunk the workgroup stages 4 S + 2 S one-KB fragment blocks in LDS (double
+// buffered; the global layout IS the LDS layout: linear 16-byte copies, conflict-free ds_read_b128), a wave reads 2 S + S fragments and
+// issues 2 * S (S + 1) / 2 MFMAs: acc[tile][ta + tb] += A[tile][ta] x B[tb].
+template <int S>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_gemm_i8(const int8_t* As, const int8_t* Bs, const int* eA,
+    const int* eB, double* C, int M, int N, int ldc, int nKc, double alpha) {
+    constexpr int kFragA = 4 * S, kFragB = 2 * S, kFrag = kFragA + kFragB;  // one-KB blocks per chunk
+    __shared__ int4 sm[2][kFrag * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv >> 1, wc = wv & 1;
+    const int ctA0 = blockIdx.y * 4, ctB0 = blockIdx.x * 2;
+    const int4* gA = reinterpret_cast<const int4*>(As);
+    const int4* gB = reinterpret_cast<const int4*>(Bs);
+    // this thread's share of a chunk's copy: elements e = tid + 256 j of the kFrag * 64 int4's; A's four column tiles are 4 separate runs of S KB
+    constexpr int kCopies = (kFrag * 64 + 255) / 256;
+    auto src = [&](int kc, int e) -> const int4* {
+        const int blk = e >> 6, l = e & 63;
+        if (blk < kFragA) {
+            const int ct = blk / S, t = blk - ct * S;
+            return gA + (((size_t)(ctA0 + ct) * nKc + kc) * S + t) * 64 + l;
+        }
+        const int b2 = blk - kFragA, ct = b2 / S, t = b2 - ct * S;
+        return gB + (((size_t)(ctB0 + ct) * nKc + kc) * S + t) * 64 + l;
+    };
+    int4 pre[kCopies];
+    auto fetch = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < kCopies; ++j) {
+            const int e = tid + 256 * j;
+            if (e < kFrag * 64) pre[j] = *src(kc, e);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < kCopies; ++j) {
+            const int e = tid + 256 * j;
+            if (e < kFrag * 64) sm[buf][e] = pre[j];
+        }
+    };
+    v16i acc[2][S];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int d = 0; d < S; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][d][r] = 0;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int kc = 0; kc < nKc; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nKc) fetch(kc + 1);
+        v4i a[2][S], b[S];
+#pragma unroll
+        for (int t = 0; t < S; ++t) {
+            const int4 vb = sm[buf][(kFragA + wc * S + t) * 64 + lane];
+            b[t] = v4i{vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int4 va = sm[buf][((wr * 2 + i) * S + t) * 64 + lane];
+                a[i][t] = v4i{va.x, va.y, va.z, va.w};
+            }
+        }
+#pragma unroll
+        for (int ta = 0; ta < S; ++ta)
+#pragma unroll
+            for (int tb = 0; tb + ta < S; ++tb)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i][ta + tb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i][ta], b[tb], acc[i][ta + tb], 0, 0, 0);
+        if (kc + 1 < nKc) {
+            stash(buf ^ 1);  // (buffer buf ^ 1 was last read in iteration kc - 1: the barrier at its end has been passed)
+        }
+        __syncthreads();
+    }
+    // ---- recombination in fp64: C[i][j] += alpha * 2^(eA[i] + eB[j]) * sum_d acc_d * 2^-(12 + 7 d), smallest terms first
+    const int j = (ctB0 + wc) * 32 + (lane & 31);
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+        const int ibase = (ctA0 + wr * 2 + i2) * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = ibase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (i < M && j < N) {
+                double v = 0.0;
+#pragma unroll
+                for (int d = S - 1; d >= 0; --d) v += ldexp((double)acc[i2][d][r], -(12 + kBits * d));
+                double* dst = C + (size_t)i * ldc + j;
+                *dst += alpha * ldexp(v, eA[i] + eB[j]);
+            }
+        }
+    }
+}
+
+// plain fp64 product for the Frobenius check (the long-double reference is on the host, sampled)
+__global__ void k_ref(const double* A, const double* B, double* C, int M, int N, int K, int lda, int ldb, int ldc) {
+    const int j = blockIdx.x * 16 + (threadIdx.x & 15), i = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (i >= M || j >= N) return;
+    double s = 0.0;
+    for (int k = 0; k < K; ++k) s = fma(A[(size_t)k * lda + i], B[(size_t)k * ldb + j], s);
+    C[(size_t)i * ldc + j] = s;
+}
+
+template <int S>
+void run(int M, int N, int K, int wide, int reps) {
+    const int Mp = (M + 127) / 128 * 128, Np = (N + 63) / 64 * 64, nKc = (K + 31) / 32;
+    std::vector<double> hA((size_t)K * M), hB((size_t)K * N);
+    std::mt19937_64 rng(12345);
+    std::normal_distribution<double> g(0.0, 1.0);
+    std::uniform_real_distribution<double> u(-4.0, 4.0);
+    for (auto& x : hA) x = g(rng) * (wide ? std::pow(10.0, u(rng)) : 1.0);
+    for (auto& x : hB) x = g(rng) * (wide ? std::pow(10.0, u(rng)) : 1.0);
+    double *dA, *dB, *dC, *dR;
+    int8_t *sA, *sB;
+    int *eA, *eB;
+    CK(hipMalloc(&dA, hA.size() * 8));
+    CK(hipMalloc(&dB, hB.size() * 8));
+    CK(hipMalloc(&dC, (size_t)M * N * 8));
+    CK(hipMalloc(&dR, (size_t)M * N * 8));
+    CK(hipMalloc(&sA, (size_t)(Mp / 32) * nKc * S * 1024));
+    CK(hipMalloc(&sB, (size_t)(Np / 32) * nKc * S * 1024));
+    CK(hipMalloc(&eA, Mp * 4));
+    CK(hipMalloc(&eB, Np * 4));
+    CK(hipMemset(eA, 0, Mp * 4));
+    CK(hipMemset(eB, 0, Np * 4));
+    CK(hipMemcpy(dA, hA.data(), hA.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dB, hB.data(), hB.size() * 8, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1, e2;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventCreate(&e2));
+    auto split = [&]() {
+        hipLaunchKernelGGL(k_colmax, dim3((M + 255) / 256), dim3(256), 0, 0, dA, K, M, M, eA);
+        hipLaunchKernelGGL(k_colmax, dim3((N + 255) / 256), dim3(256), 0, 0, dB, K, N, N, eB);
+        hipLaunchKernelGGL(k_split<S>, dim3(Mp / 32, nKc), dim3(64), 0, 0, dA, K, M, M, eA, sA, nKc);
+        hipLaunchKernelGGL(k_split<S>, dim3(Np / 32, nKc), dim3(64), 0, 0, dB, K, N, N, eB, sB, nKc);
+    };
+    auto gemm = [&]() { hipLaunchKernelGGL(k_gemm_i8<S>, dim3(Np / 64, Mp / 128), dim3(256), 0, 0, sA, sB, eA, eB, dC, M, N, N, nKc, 1.0); };
+    split();
+    CK(hipMemset(dC, 0, (size_t)M * N * 8));
+    gemm();
+    CK(hipDeviceSynchronize());
+    std::vector<double> hC((size_t)M * N), hR((size_t)M * N);
+    CK(hipMemcpy(hC.data(), dC, hC.size() * 8, hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(k_ref, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, 0, dA, dB, dR, M, N, K, M, N, N);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(hR.data(), dR, hR.size() * 8, hipMemcpyDeviceToHost));
+    // errors: against a long-double reference on 512 sampled entries, relative to (|A|^T |B|)_ij (componentwise) and to |c_ij|; the plain
+    // fp64 fma chain (k_ref) is scored the same way -- that is what the fp64 path delivers
+    double worstComp = 0, worstRel = 0, worstCompF64 = 0, worstScale = 0;
+    std::vector<double> colA(M, 0.0), colB(N, 0.0);
+    for (int k = 0; k < K; ++k) {
+        for (int i = 0; i < M; ++i) colA[i] = std::fmax(colA[i], std::fabs(hA[(size_t)k * M + i]));
+        for (int j = 0; j < N; ++j) colB[j] = std::fmax(colB[j], std::fabs(hB[(size_t)k * N + j]));
+    }
+    std::mt19937 pick(7);
+    for (int sidx = 0; sidx < 512; ++sidx) {
+        const int i = pick() % M, j = pick() % N;
+        long double s = 0, sa = 0;
+        for (int k = 0; k < K; ++k) {
+            const long double p = (long double)hA[(size_t)k * M + i] * (long double)hB[(size_t)k * N + j];
+            s += p;
+            sa += fabsl(p);
+        }
+        const double err = (double)fabsl((long double)hC[(size_t)i * N + j] - s), err64 = (double)fabsl((long double)hR[(size_t)i * N + j] - s);
+        worstComp = std::fmax(worstComp, err / (double)sa);
+        worstCompF64 = std::fmax(worstCompF64, err64 / (double)sa);
+        worstRel = std::fmax(worstRel, err / std::fmax((double)fabsl(s), 1e-300));
+        worstScale = std::fmax(worstScale, err / (K * colA[i] * colB[j]));
+    }
+    long double fe = 0, fr = 0;
+    for (size_t e = 0; e < hC.size(); ++e) {
+        fe += (long double)(hC[e] - hR[e]) * (hC[e] - hR[e]);
+        fr += (long double)hR[e] * hR[e];
+    }
+    // timing
+    split();
+    gemm();
+    CK(hipDeviceSynchronize());
+    float msSplit = 0, msGemm = 0;
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r) split();
+    CK(hipEventRecord(e1));
+    for (int r = 0; r < reps; ++r) gemm();
+    CK(hipEventRecord(e2));
+    CK(hipEventSynchronize(e2));
+    CK(hipEventElapsedTime(&msSplit, e0, e1));
+    CK(hipEventElapsedTime(&msGemm, e1, e2));
+    msSplit /= reps;
+    msGemm /= reps;
+    const double flops = 2.0 * M * N * K, iops = 2.0 * Mp * Np * (nKc * 32.0) * (S * (S + 1) / 2);
+    std::printf("{\"M\": %d, \"N\": %d, \"K\": %d, \"slices\": %d, \"products\": %d, \"wide_dynamic_range\": %d, \"split_ms\": %.4f, \"gemm_ms\": %.4f, "
+                "\"fp64_equiv_tflops_gemm_only\": %.2f, \"fp64_equiv_tflops_with_split\": %.2f, \"int8_tops\": %.1f, "
+                "\"err_vs_longdouble_componentwise\": %.3e, \"fp64_fma_chain_componentwise\": %.3e, \"err_vs_longdouble_rel_to_entry\": %.3e, "
+                "\"err_over_K_colmaxA_colmaxB\": %.3e, \"fro_diff_vs_fp64\": %.3e}\n",
+        M, N, K, S, S * (S + 1) / 2, wide, msSplit, msGemm, flops / (msGemm * 1e-3) / 1e12, flops / ((msGemm + msSplit) * 1e-3) / 1e12,
+        iops / (msGemm * 1e-3) / 1e12, worstComp, worstCompF64, worstRel, worstScale, (double)sqrtl(fe / fr));
+    for (void* p : {(void*)dA, (void*)dB, (void*)dC, (void*)dR, (void*)sA, (void*)sB, (void*)eA, (void*)eB}) (void)hipFree(p);
+}
+
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? std::atoi(argv[1]) : 2048, N = argc > 2 ? std::atoi(argv[2]) : 2048, K = argc > 3 ? std::atoi(argv[3]) : 2000;
+    const int S = argc > 4 ? std::atoi(argv[4]) : 7, wide = argc > 5 ? std::atoi(argv[5]) : 0, reps = argc > 6 ? std::atoi(argv[6]) : 20;
+    switch (S) {
+        case 4: run<4>(M, N, K, wide, reps); break;
+        case 5: run<5>(M, N, K, wide, reps); break;
+        case 6: run<6>(M, N, K, wide, reps); break;
+        case 7: run<7>(M, N, K, wide, reps); break;
+        case 8: run<8>(M, N, K, wide, reps); break;
+        default: std::fprintf(stderr, "slices must be 4..8\n"); return 2;
+    }
+    return 0;
+}

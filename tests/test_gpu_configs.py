@@ -183,6 +183,38 @@ def test_batch_of_16_filters_N200_one_second_every_frame(oracle_lib, hip):
     assert fr == len(refs[0]) and fr >= 19 and fg.device_error() == 0
 
 
+@pytest.mark.parametrize("B", [3, 8])
+def test_arrival_tickets_equal_block_indices_bitwise(hip, B):
+    """Round 6: on a grid larger than the chip a workgroup of the update launch draws its place in the dependency order from a counter
+    when it starts (csrc/eqf_resident.hpp: ResArgs::ticket) instead of reading it off its block index -- no assumption about the order in which
+    the hardware starts workgroups.  Which workgroup plays which role changes, what the roles compute does not: bit for bit the launch of
+    rounds 3-5 ("res_tickets" = 0), over frames that reuse the counter (it runs on from launch to launch)."""
+    from eqf_vio_amd import synth
+
+    N = 200
+    sts = [synth.make_stream(N, seed=777 + b, duration=0.36) for b in range(B)]
+    d = synth.template_settings_dict()
+    out = []
+    for tickets in (1, 0):
+        fg = hip.FilterBatch(d, capacity=N, batch=B)
+        fg.debug_option("res_tickets", tickets)
+        fg.stream_upload(np.stack([s.imu for s in sts], axis=1), np.stack([s.vision_stamps for s in sts], axis=1), sts[0].ids,
+                         np.stack([s.bearings for s in sts], axis=1))
+        frames = 0
+        for kind, k in sts[0].events():
+            if kind == "imu":
+                fg.stream_imu(k)
+            else:
+                fg.stream_vision(k)
+                frames += 1
+        assert frames >= 6 and fg.device_error() == 0
+        out.append([(fg.sigma(b), fg.state_estimate(b)["x"], fg.last_update(b)["Gamma"]) for b in range(B)])
+        del fg
+    for b in range(B):
+        assert np.array_equal(out[0][b][0], out[1][b][0]), b
+        assert np.array_equal(out[0][b][1], out[1][b][1]) and np.array_equal(out[0][b][2], out[1][b][2]), b
+
+
 def test_cfg2_N200_two_seconds_worst_frame(oracle_lib, hip):
     """BASELINE configs[1] over 2 s (400 IMU + 40 vision calls, per-call API, IMU bursts): Sigma and pose after EVERY vision
     update against the structured oracle, worst frame reported; the first second also against the dense oracle."""
