@@ -311,9 +311,14 @@ EQF_DI void burstCommonCam(StepCommon& c, const StepPre& pr, const Params& p) {
 // of the tick are done -- stores them with write-through stores, drains them a tick later (for free) and publishes the step count.
 template <typename T, bool FAST, int LM, bool OCC2, bool FUSE>
 EQF_DI void burstBuildBody(const BurstArgs& a, const int bxIdx, const int b) {
-    static_assert(LM == 4 || LM == 16, "role tables exist for 4 and 16 landmarks per workgroup");
+    static_assert(LM == 4 || LM == 8 || LM == 16, "role tables exist for 4, 8 and 16 landmarks per workgroup");
     static_assert(!FUSE || (FAST && LM == 4 && sizeof(T) == 8), "the fused launch exists for the latency case only");
-    constexpr bool kSpread = LM == 4;  // one panel wave: the Lw blocks and Sigma_bb get wavefronts of their own
+    // LM = 4: one panel wave -- the Lw blocks, Sigma_bb and the camera-frame values get wavefronts of their own (waves 1, 2, 3).
+    // LM = 8 (round 6: batches whose 8-landmark builders still have a CU each, 5 .. 10 filters of N = 200): two panel waves; Lw and Sigma_bb
+    // on waves 2 and 3, the camera-frame values stay with the state recurrence on wave 4 -- six busy stages on eight waves instead of the
+    // eight-on-four-SIMDs crowd of LM = 16.
+    constexpr bool kLwOwn = LM <= 8, kSbbOwn = LM <= 8, kCamOwn = LM == 4;
+    constexpr int kLwW = LM == 4 ? kLwWave : 2, kSbbW = LM == 4 ? kSbbWave : 3;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int L0 = bxIdx * LM;
     __shared__ BurstLds<T> s;
@@ -348,7 +353,7 @@ EQF_DI void burstBuildBody(const BurstArgs& a, const int bxIdx, const int b) {
 #pragma unroll
             for (int rr = 0; rr < 3; ++rr) pP[rr] = Sin[(long long)(kLm0 + 3 * plm + rr) * ld + pc];
         }
-        if (kSpread && wv == kLwWave && lmOk) q0 = mk3(p0[li], p0[cap + li], p0[2 * cap + li]);
+        if (kLwOwn && wv == kLwW && lmOk) q0 = mk3(p0[li], p0[cap + li], p0[2 * cap + li]);
     } else if (wv == 4) {
         if (FAST) {
             rAq = quat{G0.Aq[0], G0.Aq[1], G0.Aq[2], G0.Aq[3]};
@@ -486,13 +491,13 @@ EQF_DI void burstBuildBody(const BurstArgs& a, const int bxIdx, const int b) {
                         c.vhat = vhat;      // (the input blocks B_g^w, B_v^w of F_bb are formed from these by wave 5, one tick later)
                         c.etahat = etahat;
                     }
-                    if (kSpread) {
+                    if (kCamOwn) {
                         // the camera-frame velocities of the step are wave 3's (it has no other work): hand R_A, vhat over now
                         waveSync();
                         ldsFlagStore(&s.handStep, t);
                     }
                     if (pr.step) {
-                        if (!kSpread) burstCommonCam(c, pr, a.prm);
+                        if (!kCamOwn) burstCommonCam(c, pr, a.prm);
                         EQF_BSTAMP(2);
                         // ---- the group step of the scalar state (stepGlobal's; VIOGroup.cpp:214-222 / :182-187, :95-96)
                         const se3 lA = se3{pr.lAq, mv33(pr.VA, scl(pr.dt, vhat))};
@@ -526,7 +531,7 @@ EQF_DI void burstBuildBody(const BurstArgs& a, const int bxIdx, const int b) {
                         stepGlobal(s.glob[cur], &s.glob[cur ^ 1], s.rec[t], v, c, &bad);
                     }
                 }
-                if (!kSpread && t >= 1 && t - 1 < K) burstStepSbb(s, t - 1, lane, sw2, sa2, diagVar);
+                if (!kSbbOwn && t >= 1 && t - 1 < K) burstStepSbb(s, t - 1, lane, sw2, sa2, diagVar);
             }
             EQF_BSTAMP(1);
             ldsBarrier();
@@ -552,7 +557,7 @@ EQF_DI void burstBuildBody(const BurstArgs& a, const int bxIdx, const int b) {
                     burstBuildF(s, (t - 1) & 3, lane, fmap);
                 }
                 EQF_BSTAMP(2);
-                if (!kSpread) {
+                if (!kSbbOwn) {
                     waveSync();
                     if (t >= 2 && t - 2 < K) burstStepSbb(s, t - 2, lane, sw2, sa2, diagVar);
                 }
@@ -627,7 +632,7 @@ EQF_DI void burstBuildBody(const BurstArgs& a, const int bxIdx, const int b) {
                         rr[18 + k] = lv;
                     }
                 }
-                if (!kSpread) {  // (LM = 16: no wavefront to spare for Lw)
+                if (!kLwOwn) {  // (LM = 16: no wavefront to spare for Lw)
                     const StepCommon& c = s.com[st & 3];
                     const m33 Lwm = buildLw(c.T, c.RICt, c.xIC, Qq, Qa, q0);
 #pragma unroll
@@ -642,7 +647,7 @@ EQF_DI void burstBuildBody(const BurstArgs& a, const int bxIdx, const int b) {
             EQF_BSTAMP(1);
             ldsBarrier();
         }
-    } else if (kSpread && FAST && wv == 3) {
+    } else if (kCamOwn && FAST && wv == 3) {
         // ---- the camera-frame common values of step t, inside the tick, as soon as wave 4 has handed R_A / vhat over
         // fused launch: this wave also carries the records out.  Step u's entries are complete in LDS when tick u + 2 ends and are stored at
         // the start of tick u + 3 (while wave 4 is busy with the first part of the recurrence): seven write-through store instructions.
@@ -727,7 +732,7 @@ EQF_DI void burstBuildBody(const BurstArgs& a, const int bxIdx, const int b) {
             hoDrain();
             if (lane < kFlagReplicas) hoPublish(myFlag, ebase + K);
         }
-    } else if (kSpread && wv == kLwWave) {
+    } else if (kLwOwn && wv == kLwW) {
         // ---- Lw = -T B_i of step t-1: needs nothing of the state but T and the landmark's group element
         for (int t = 0; t < K + 2; ++t) {
             EQF_BSTAMP(0);
@@ -753,7 +758,7 @@ EQF_DI void burstBuildBody(const BurstArgs& a, const int bxIdx, const int b) {
             EQF_BSTAMP(1);
             ldsBarrier();
         }
-    } else if (kSpread && wv == kSbbWave) {
+    } else if (kSbbOwn && wv == kSbbW) {
         // ---- Sigma_bb: after step t-1 (generic schedule) / t-2 (fast schedule: F_bb of a step is built one tick later)
         for (int t = 0; t < K + 2; ++t) {
             EQF_BSTAMP(0);
@@ -930,7 +935,7 @@ constexpr int kRingTrips = 12;  // column-constant rows per wave and step: 45 ro
 // of the ring is that the 45 x 64 column constants of a step are fetched ONCE per workgroup (16 row landmarks) instead of once per
 // wavefront, and that a lane holds 13 + 3 prefetched values per register set instead of 46: 2 wavefronts per SIMD instead of 1.
 // grid = (ringTiles(N, R), B).
-template <typename T, int R>
+template <typename T, int R, bool AHEAD2 = (R == 1)>
 EQF_DI void burstRingBody(const BurstArgs& a, const int tileIdx, const int b) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int N = a.gin[b].N, K = a.K, cap = a.cap, ld = a.ld;
@@ -1196,7 +1201,15 @@ EQF_DI void burstRingBody(const BurstArgs& a, const int tileIdx, const int b) {
         }
       }
     };
-    if (R > 1) {
+    // AHEAD2 for R = 2 (round 6, measured and NOT the default): two register sets like R = 1, a step's constants requested TWO steps ahead.
+    // The idea: with one set the loads of step st + 2 have one step's arithmetic to arrive, from records the builder launch wrote on other
+    // XCDs a moment ago.  Measured at 4 .. 12 filters of N = 200 (profiles/r06_burst_shapes.txt): 1.5 - 2.7 us SLOWER per burst (8 filters
+    // 64.6 -> 67.3 us) -- the step is not waiting for these loads; 28 more registers and a longer prologue cost more than they hide.
+    auto stepMath = [&](int st) __attribute__((always_inline)) {
+        if constexpr (R > 1) mathS(st);
+        else math(st);
+    };
+    if (!AHEAD2) {
         // throughput variant: one register set, constants fetched one step ahead (the other wavefront of the SIMD covers the wait)
         fetch(0, xA);
         __builtin_amdgcn_sched_barrier(0);
@@ -1224,7 +1237,7 @@ EQF_DI void burstRingBody(const BurstArgs& a, const int tileIdx, const int b) {
     EQF_RSTAMP(1);
     for (int st = 0; st < K; st += 2) {
         // even step: its constants are in the ring; xB holds step st+1 (issued two steps ago), xA step st+2
-        if (sRicc[st]) math(st);
+        if (sRicc[st]) stepMath(st);
         EQF_RSTAMP(2 + 3 * st);
         pass(st + 1, xB);
         EQF_RSTAMP(3 + 3 * st);
@@ -1233,7 +1246,7 @@ EQF_DI void burstRingBody(const BurstArgs& a, const int tileIdx, const int b) {
         ldsBarrier();
         EQF_RSTAMP(4 + 3 * st);  // (LDS only: __syncthreads() would also drain the prefetches, loads and stores share vmcnt)
         if (st + 1 >= K) break;
-        if (sRicc[st + 1]) math(st + 1);
+        if (sRicc[st + 1]) stepMath(st + 1);
         EQF_RSTAMP(2 + 3 * (st + 1));
         pass(st + 2, xA);
         EQF_RSTAMP(3 + 3 * (st + 1));
@@ -1359,9 +1372,9 @@ EQF_DI void burstRingBody(const BurstArgs& a, const int tileIdx, const int b) {
         }
     }
 }
-template <typename T, int R = 1>
+template <typename T, int R = 1, bool AHEAD2 = (R == 1)>
 __global__ __launch_bounds__(256, R == 1 ? 1 : 2) void k_burst_riccati_ring(BurstArgs a) {
-    burstRingBody<T, R>(a, (int)blockIdx.x, (int)blockIdx.y);
+    burstRingBody<T, R, AHEAD2>(a, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -157,6 +157,7 @@ struct eqf_filter {
     // touches the handle in any other way.  burstMax = 0: every call launches at once through k_propagate.
     int burstMax = kBurstMax;      // EQF_IMU_BURST / eqf_set_imu_burst
     int burstRows = 0;             // block kernel: row landmarks per wavefront, 0 = by launch size (EQF_BURST_ROWS = 1 | 2 | 4)
+    int ringAhead2 = 0;            // block kernel with two row landmarks per wave: constants requested two steps ahead -- measured 1.5-2.7 us SLOWER per burst at 4..12 filters (profiles/r06_burst_shapes.txt), kept behind eqf_debug_option "ring_ahead2"
     int burstLm = 0;               // builder: landmarks per workgroup, 0 = by launch size ([no switch since round 5])
     struct {
         int kind = 0;              // 0 nothing pending, 1 records k0 .. k0+cnt-1 of the uploaded stream, 2 inline records (one filter)
@@ -509,7 +510,9 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
     int rb1 = 0;
     const bool fusedFits = f->burstFused && nmx > 0 && f->precision != EQF_PRECISION_F32 && f->dBuildFlags &&
                            (double)((nmx + 3) / 4 + ringTiles(nmx, 1, &rb1)) * f->B <= f->fusedMaxPerCU * cus;
-    const int lm = f->burstLm ? f->burstLm : (((long long)((nmx + 3) / 4) * f->B <= cus || fusedFits) ? 4 : 16);
+    // (round 6: 8 per workgroup -- two panel waves, every serial stage still on a wave of its own -- while THOSE builders have a CU each)
+    const int lm = f->burstLm ? f->burstLm
+                              : (((long long)((nmx + 3) / 4) * f->B <= cus || fusedFits) ? 4 : ((long long)((nmx + 7) / 8) * f->B <= cus ? 8 : 16));
     const dim3 bgrid(std::max(1, (nmx + lm - 1) / lm), f->B);
     // (round 5: the 4-landmark builder built for two workgroups per CU so that 8 filters keep its short ticks -- 400 workgroups on 512 slots --
     // measured: 70.9 against 71.0 us per burst, nothing; not kept)
@@ -563,6 +566,8 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
         auto go = [&](auto zero) {
             typedef decltype(zero) TT;
             if (fast && lm == 4) hipLaunchKernelGGL((k_burst_build<TT, true, 4>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
+            else if (fast && lm == 8) hipLaunchKernelGGL((k_burst_build<TT, true, 8>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
+            else if (lm == 8) hipLaunchKernelGGL((k_burst_build<TT, false, 8>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
             else if (fast && occ2) hipLaunchKernelGGL((k_burst_build<TT, true, 16, true>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
             else if (fast) hipLaunchKernelGGL((k_burst_build<TT, true, 16>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
             else if (lm == 4) hipLaunchKernelGGL((k_burst_build<TT, false, 4>), bgrid, dim3(kBuildThreads), 0, f->stream, a);
@@ -570,7 +575,8 @@ int launchBurst(eqf_filter* f, int K, const ImuRec* devRecs, long long recStride
             if (nmx > 0) {
                 // (the four wavefronts of a workgroup share a step's column constants through an LDS ring)
                 if (R == 1) hipLaunchKernelGGL((k_burst_riccati_ring<TT, 1>), rgrid, dim3(256), 0, f->stream, a);
-                else if (R == 2) hipLaunchKernelGGL((k_burst_riccati_ring<TT, 2>), rgrid, dim3(256), 0, f->stream, a);
+                else if (R == 2 && f->ringAhead2) hipLaunchKernelGGL((k_burst_riccati_ring<TT, 2, true>), rgrid, dim3(256), 0, f->stream, a);
+                else if (R == 2) hipLaunchKernelGGL((k_burst_riccati_ring<TT, 2, false>), rgrid, dim3(256), 0, f->stream, a);
                 else hipLaunchKernelGGL((k_burst_riccati_ring<TT, 4>), rgrid, dim3(256), 0, f->stream, a);
             }
         };
@@ -2315,6 +2321,20 @@ int eqf_debug_option(eqf_filter* f, const char* name, int value) {
     }
     if (!std::strcmp(name, "burst_fused_max_x10")) {
         f->fusedMaxPerCU = value / 10.0;
+        return EQF_OK;
+    }
+    if (!std::strcmp(name, "ring_ahead2")) {
+        f->ringAhead2 = value ? 1 : 0;
+        return EQF_OK;
+    }
+    if (!std::strcmp(name, "burst_lm")) {  // landmarks per builder workgroup: 0 = by launch size, 4 / 8 / 16
+        if (value != 0 && value != 4 && value != 8 && value != 16) return EQF_ERR_INVALID;
+        f->burstLm = value;
+        return EQF_OK;
+    }
+    if (!std::strcmp(name, "burst_rows")) {  // row landmarks per wavefront of the block kernel: 0 = by launch size, 1 / 2 / 4
+        if (value != 0 && value != 1 && value != 2 && value != 4) return EQF_ERR_INVALID;
+        f->burstRows = value;
         return EQF_OK;
     }
     if (!std::strcmp(name, "res_tickets")) {

@@ -88,6 +88,10 @@ class ProcessGrid:
                     if c == self.pc:
                         self.groups[chain][1] = grp
         self.error = None
+        # what went through the callback (bench.py / tests: the exchange volume of an update against DESIGN.md section 7's SUMMA-restricted figure)
+        self.bcast_calls = 0
+        self.bcast_bytes = 0           # every broadcast this rank took part in
+        self.bcast_bytes_received = 0  # ... of which it was not the root
         self._cb = _BCAST(self._bcast)
         self.comm = _Comm(None, self._cb)
 
@@ -98,6 +102,10 @@ class ProcessGrid:
         try:
             t = torch.as_tensor(_DevBuf(buf, nbytes // 8), device=self.device)
             src = (self.pr * self.Pc + root) if group == 0 else ((root * self.Pc + self.pc) if group == 1 else root)
+            self.bcast_calls += 1
+            self.bcast_bytes += nbytes
+            if src != self.rank:
+                self.bcast_bytes_received += nbytes
             with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)):
                 self.dist.broadcast(t, src=src, group=self.groups[chain][group] if group < 2 else None)
             return 0

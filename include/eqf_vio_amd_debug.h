@@ -33,6 +33,9 @@ int eqf_debug_drop_role(eqf_filter* f, int kind, int role, int R, int C);
  *                  (:429-443), the new landmarks (:345-391) -- is ONE launch that decides and acts on the device; the id lists of the handle
  *                  follow when the caller next touches it and no frame is redone.  0: separate launches, a frame with an outlier is redone
  *                  from the host.  Bit for bit the same either way.
+ *   "burst_lm" / "burst_rows" / "ring_ahead2"   launch shapes of an IMU burst: landmarks per builder workgroup (0 = by launch size, 4, 8, 16), row
+ *                  landmarks per wavefront of the block kernel (0 = by launch size, 1, 2, 4), and whether the two-row block kernel requests a
+ *                  step's constants two steps ahead (1) or one (0, default: two measured slower).  Bit for bit the same results whatever is chosen.
  *   "res_tickets"  1 (default): on a grid larger than the chip a workgroup of the update launch draws its place in the dependency order from a
  *                  counter when it starts (no assumption about the hardware's dispatch order); 0: the block index, as in rounds 3-5.  Same results.
  *   "burst_fused_max_x10"    the one-launch IMU burst (k_burst_fused) is used up to value / 10 workgroups per CU (default: 1.25).

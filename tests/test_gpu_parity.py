@@ -1058,6 +1058,45 @@ def test_builder_and_block_workgroups_in_one_launch_equal_the_two_launches(hip, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,N", [(2, 37), (3, 200), (8, 107)])
+def test_burst_launch_shapes_are_bitwise_interchangeable(hip, B, N):
+    """The shapes an IMU burst can be launched in -- 4 / 8 (round 6) / 16 landmarks per builder workgroup, 1 / 2 / 4 row landmarks per wavefront
+    of the block kernel, the two-row block kernel with its constants requested one or two (round 6) steps ahead -- run the same operations
+    on the same values: bit for bit the same covariance, state and update internals after every frame, whatever the host's size heuristics
+    would have picked.  (Ragged cases included: N = 37 and 107 leave partly filled builder workgroups and row tiles.)"""
+    from eqf_vio_amd import synth
+
+    sts = [synth.make_stream(N, seed=300 + b, duration=0.26) for b in range(B)]
+    d = synth.template_settings_dict()
+    shapes = [(0, 0, 1), (4, 1, 1), (8, 2, 1), (8, 2, 0), (16, 4, 1), (8, 1, 1), (16, 2, 1)]
+    outs = []
+    for lm, rows, ahead in shapes:
+        fg = hip.FilterBatch(d, capacity=N, batch=B)
+        fg.debug_option("burst_lm", lm)
+        fg.debug_option("burst_rows", rows)
+        fg.debug_option("ring_ahead2", ahead)
+        fg.stream_upload(np.stack([s_.imu for s_ in sts], axis=1), np.stack([s_.vision_stamps for s_ in sts], axis=1), sts[0].ids,
+                         np.stack([s_.bearings for s_ in sts], axis=1))
+        seq = []
+        for kind, k in sts[0].events():
+            if kind == "imu":
+                fg.stream_imu(k)
+            else:
+                fg.stream_vision(k)
+                seq.append([(fg.sigma(b), fg.state_estimate(b)["x"], fg.last_update(b)["Gamma"]) for b in range(B)])
+        assert fg.device_error() == 0 and len(seq) >= 4
+        if lm:
+            assert fg.launch_shape()["builder_landmarks"] == lm and fg.launch_shape()["rows_per_wave"] == rows
+        outs.append(seq)
+        del fg
+    for i in range(1, len(shapes)):
+        for fr, (fa, fb_) in enumerate(zip(outs[0], outs[i])):
+            for b in range(B):
+                for u, v in zip(fa[b], fb_[b]):
+                    assert np.array_equal(u, v), (shapes[i], fr, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,N,dur", [(2, 200, 0.26), (3, 107, 0.26), (8, 200, 0.26), (1, 600, 0.16), (1, 1100, 0.11)])
 def test_update_operands_left_by_the_burst_equal_the_prep_launch(hip, B, N, dur):
     """Round 5: a burst closed by a vision step leaves the landmark columns of C Sigma and S = C Sigma C^T + R from the covariance blocks its

@@ -3,6 +3,8 @@
 the base panel, the local blocks and the two distributed factorisations through the C ABI; the oracle and the single-GPU product path
 are the checkers.  Plus the dense tile kernels against numpy.  (The multi-rank exchange schedule is validated on CPU with gloo,
 tests/test_tiled.py.)"""
+import os
+
 import numpy as np
 import pytest
 
@@ -822,27 +824,34 @@ def _multi_rank_golden_worker(rank, world, port, Pr, Pc, N, bl, out_dir):
     tf = tiled.TiledFilter(tiled.ProcessGrid(dist, Pr, Pc, device=be.device), be, bl)
     tf.lookahead = False
     worst, f = 0.0, 0
+    g = tf.g
+    upd_bytes = []  # bytes this rank RECEIVED through the broadcast callback during each vision call (frame 0 adds the landmarks: no exchange yet)
     for kind, k in events_of(d["imu"], d["vision_stamps"]):
         if kind == "imu":
             r = d["imu"][k]
             tf.processIMUData(r[0], r[1:4], r[4:7])
         else:
+            b0 = g.bcast_bytes_received
             assert tf.processVisionData(d["vision_stamps"][k], d["ids"], d["bearings"][k]) == 0
+            tf.synchronize()
+            upd_bytes.append(g.bcast_bytes_received - b0)
             S = tf.stateCovariance()
             worst = max(worst, check_large_golden(d, f, tf.stateEstimate(), tf.bias(), S, tf.lastUpdate(), what=f"{Pr} x {Pc} grid, N={N}, rank {rank}"))
             del S
             f += 1
-    np.save(os.path.join(out_dir, f"g_{rank}.npy"), np.array([worst, f, tf.device_error()]))
+    np.save(os.path.join(out_dir, f"g_{rank}.npy"), np.array([worst, f, tf.device_error(), max(upd_bytes)]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("Pr,Pc,N,bl", [(2, 4, 2000, 125)])
+@pytest.mark.parametrize("Pr,Pc,N,bl", [(2, 4, 2000, 125), (2, 4, 4000, 250)])
 def test_tiled_filter_on_the_node_grid_at_size_against_the_committed_oracle_vectors(tmp_path, Pr, Pc, N, bl):
     """The grid of one 8-GPU node, 2 x 4, AT SIZE: N = 2000 (Sigma 6011 x 6011, 16 x 16 landmark blocks of 125) as eight processes sharing the
     one MI355X, the C++ host loop on every rank with the schedule of grids larger than one rank (block row k + 1 solved and exchanged next
     to block row k's products, every exchange on one ordered stream), the broadcasts over gloo on device memory -- against the committed
-    vectors of the structured fp64 oracle (tests/golden/large_N2000.npz) after every one of the three updates, on every rank.  (What this
+    vectors of the structured fp64 oracle (tests/golden/large_N2000.npz, three updates; round 6: also BASELINE configs[4]'s own size, N = 4000 with
+    blocks of 250, tests/golden/large_N4000.npz, two updates) after every update, on every rank; the bytes every rank received through the
+    broadcast callback during an update are held against DESIGN.md section 7's SUMMA-restricted volume.  (What this
     cannot show is RCCL over xGMI itself, nor a frame time: eight processes time-share the chip.)"""
     import gc
     import socket
@@ -855,9 +864,26 @@ def test_tiled_filter_on_the_node_grid_at_size_against_the_committed_oracle_vect
     port = s.getsockname()[1]
     s.close()
     world = Pr * Pc
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import load_golden
+
+    nframes = len(load_golden(f"large_N{N}")[0]["vision_stamps"])  # (three updates at N = 2000, two at N = 4000)
+    assert nframes >= 2
     gc.collect()
     torch.cuda.synchronize()
     mp.spawn(_multi_rank_golden_worker, args=(world, port, Pr, Pc, N, bl, str(tmp_path)), nprocs=world, join=True)
+    recv = []
     for r in range(world):
-        worst, f, err = np.load(tmp_path / f"g_{r}.npy")
-        assert f == 3 and err == 0 and worst < 1e-8, (r, worst, f, err)
+        worst, f, err, nbytes = np.load(tmp_path / f"g_{r}.npy")
+        assert f == nframes and err == 0 and worst < 1e-8, (r, worst, f, err)
+        recv.append(nbytes)
+    # Exchange volume of an update, per rank, against DESIGN.md section 7: SUMMA-restricted, a rank receives (1 / Pr + 1 / Pc) of every solved
+    # block row [U_k | Y_k] of both chains -- upper block triangle of m x m plus the m x (n + 18) right-hand sides for the S-chain (m = 2 N, n =
+    # 11 + 3 N), upper block triangle of n_e x n_e plus 11 columns for the E-chain (n_e = 5 + 3 N padded to blocks) -- minus what it holds itself.
+    n, m, ne = 11 + 3 * N, 2 * N, 3 * N
+    rows = 8.0 * (m * m / 2 + m * (n + 18) + ne * ne / 2 + ne * 11)
+    model = (1.0 / Pr + 1.0 / Pc) * rows
+    print(f"N={N} grid {Pr}x{Pc}: bytes received per update and rank: min {min(recv) / 1e9:.3f} GB, max {max(recv) / 1e9:.3f} GB; "
+          f"(1/Pr + 1/Pc) x solved block rows = {model / 1e9:.3f} GB (DESIGN.md section 7: 0.75 x (0.26 + 0.77) GB at N = 4000)")
+    assert 0.4 * model < min(recv) and max(recv) < 1.05 * model, (recv, model)  # (a rank does not receive the pieces it holds itself)
