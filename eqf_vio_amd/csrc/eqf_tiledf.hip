@@ -134,7 +134,7 @@ struct eqf_tf {
     hipStream_t sComm = nullptr;                 // every exchange, in program order: one communicator is enough
     int panelAhead = 0;  // set at creation: 1 on more than one rank (there are exchanges to hide), 0 on a 1 x 1 grid -- see eqf_tf_create
     bool ownStreams = false;
-    int reserve = 8;
+    int reserve = 24;
     int* info = nullptr;  // device: or-ed with 1 when a pivot of a diagonal block was not positive
     // options
     int lookahead = 1, overlapChains = 1, burst = 1, checkEvery = 1, framesSinceCheck = 0, profiling = 0, graphs = 0;
@@ -992,7 +992,10 @@ int eqf_tf_create(const eqf_settings* settings, int capacity_landmarks, int bloc
     }
     f->taken.assign(f->cap, 0);
     if (const char* e = std::getenv("EQF_TILED_RESERVE_CUS")) reserve_cus = reserve_cus < 0 ? std::atoi(e) : reserve_cus;
-    f->reserve = reserve_cus < 0 ? 8 : reserve_cus;
+    // (round 6, N = 4000 on one rank, profiles/r06_tiled_reserve_sweep.txt: 0 / 4 / 8 / 12 / 16 / 24 / 32 / 48 reserved CUs -> 157.7 / 153.3 / 162.7 /
+    // 166.3 / 169.2 / 169.5 / 169.3 / 150.7 steps/s, the monolithic single-GPU path 169: with 8 the E-chain's look-ahead factorisations were its
+    // critical path; from 16 on the partitioned filter is level with the monolithic one)
+    f->reserve = reserve_cus < 0 ? 24 : reserve_cus;
     // On ONE rank the two chains of an update run side by side (measured: profiles/r05_tiled_*).  Over a collective library whose kernels
     // share the GPU with ours (RCCL) they run one after the other unless the caller asks for the overlap (option "overlap_chains" /
     // EQF_TILED_OVERLAP_CHAINS=1): every exchange already goes through one stream in program order, but the interleaved form has only ever

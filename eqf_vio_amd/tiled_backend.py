@@ -37,7 +37,7 @@ class HipBackend:
         # look-ahead only runs when the trailing update happens to leave room.
         import os
 
-        self.reserve = int(os.environ.get("EQF_TILED_RESERVE_CUS", "8")) if reserve_cus is None else int(reserve_cus)
+        self.reserve = int(os.environ.get("EQF_TILED_RESERVE_CUS", "24")) if reserve_cus is None else int(reserve_cus)
         self._raw = []
         self._main = self._side = self._aux = self._aux_side = None
         if self.reserve > 0:

@@ -278,7 +278,7 @@ int eqf_tiled_set_state(eqf_tiled* t, int N, const double* pose_q, const double*
  * rank of a Pr x Pc process grid (Pr | Pc; rank = pr * Pc + pc) IS VIOFilter (VIOFilter.h:41-88) for one filter whose Sigma is
  * partitioned over the grid.  Every rank makes the same calls with the same arguments.  The handle owns its eqf_tiled, its local matrix,
  * every exchange buffer and four HIP streams (two pairs with disjoint CU sets: reserve_cus CUs for the look-ahead factorisations, < 0 =
- * default 8 / EQF_TILED_RESERVE_CUS, 0 = plain streams).  What the ranks exchange goes through ONE callback:
+ * default 24 / EQF_TILED_RESERVE_CUS, 0 = plain streams).  What the ranks exchange goes through ONE callback:
  *   bcast(ctx, group, chain, root, buf, bytes, stream): broadcast `bytes` bytes of DEVICE memory at `buf` from `root` to the other members
  *   of `group` -- 0: my process row (root = process COLUMN of the sender), 1: my process column (root = process ROW), 2: every rank (root =
  *   rank) -- ordered on the HIP stream `stream` (the transfer may start when the stream reaches it; later work on the stream sees the data).
