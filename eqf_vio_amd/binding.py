@@ -119,7 +119,8 @@ def lib():
         L.eqf_device_error.argtypes = [vp]
         L.eqf_debug_drop_role.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
         L.eqf_debug_option.argtypes = [vp, C.c_char_p, C.c_int]
-        L.eqf_debug_launch_shape.argtypes = [vp, C.POINTER(C.c_int)]
+        if hasattr(L, "eqf_debug_launch_shape"):  # (an older build loaded through EQF_VIO_AMD_LIB for an A/B run may predate it)
+            L.eqf_debug_launch_shape.argtypes = [vp, C.POINTER(C.c_int)]
         L.eqf_set_dense_propagate.argtypes = [vp, C.c_int]
         L.eqf_set_imu_burst.argtypes = [vp, C.c_int]
         L.eqf_profile_enable.argtypes = [vp, C.c_int]

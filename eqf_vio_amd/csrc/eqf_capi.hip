@@ -191,7 +191,7 @@ struct eqf_filter {
     int *dReadyA = nullptr, *dReadyY = nullptr, *dResCounters = nullptr, *dStageFlags = nullptr;
     unsigned* dTicket = nullptr;  // k_chol_resident on a grid larger than the chip: arrival tickets, [B][32] (ResArgs::ticket); ticketBase = tickets drawn per filter by earlier launches
     unsigned ticketBase = 0;
-    int resTickets = 1;           // eqf_debug_option "res_tickets" 0: the block index instead (rounds 3-5)
+    int resTickets = 0;           // eqf_debug_option "res_tickets": 0 (default) the block index (rounds 3-5), 1 tickets on grids >= 6 x the resident slots, 2 on every grid larger than the chip (non-FOLD)
     double *dGammaPart = nullptr, *dG11Part = nullptr;
     ResRole* dRoles = nullptr;
     int resPipeHeads = -1;         // [no switch since round 5]: row heads with the pipelined panel loop (1), without (0), by grid size (-1)
@@ -753,6 +753,10 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<float, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRes2Bytes));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRes2Bytes));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<float, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<float, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRes2Bytes));
+        HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_resident<double, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRes2Bytes));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<float, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTailBytes));
         HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_step64<double, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTailBytes));
         attrSet = true;
@@ -925,12 +929,24 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
                 const int perFilter = ra.nPrep + f->rolesCount + ddGrid;
                 ra.rolesPerRow = std::min(perFilter, 32768);
                 const dim3 rg(B * ra.rolesPerRow, (perFilter + ra.rolesPerRow - 1) / ra.rolesPerRow);
-                if (pipeHeads && f->resTickets && f->dTicket) {  // (every workgroup of the launch draws exactly one ticket, padding workgroups included)
+                // Arrival tickets (ResArgs::ticket, the TICKET build): eqf_debug_option "res_tickets" 0 (default) = never, 2 = on every grid larger
+                // than the chip that has its prep launch in front (not the FOLD build of 2 - 4 filters), 1 = where they cost least -- grids of at
+                // least six times the resident slots (16+ filters of N = 200, N >= ~700), whose workgroups are dispatched long before they are needed;
+                // on lightly oversubscribed grids a role is dispatched just in time and the ticket's round trip (~2 us) lands on the critical
+                // path at every dependency hop: +12.8 / +7.4 / +14.6 / +3.2 / +8.6 us per update at 2 / 4 / 6 / 8 / 12 filters, +1.1 % at 64, +0.7 %
+                // at N = 1000 in one binary (profiles/r06_tickets_ab.txt), 2.3 % against round 5's library on the same box.  OFF by default: the
+                // block index with the time-outs as its guard, as in rounds 3 - 5 -- the guarantee is there for whoever wants to pay for it.
+                const long long slots = (long long)std::max(f->numCUs, 1) * (occ2 ? 2 : 1);
+                const bool tickets = f->resTickets == 2 || (f->resTickets == 1 && (long long)rg.x * rg.y >= 6 * slots);
+                const bool ticketBuild = pipeHeads && !fold && tickets && f->dTicket;
+                if (ticketBuild) {  // (every workgroup of the launch draws exactly one ticket, padding workgroups included)
                     ra.ticket = f->dTicket;
                     ra.ticketBase = f->ticketBase;
                     f->ticketBase += ra.rolesPerRow * rg.y;  // (per filter)
                 }
-                if (fold && pipeHeads) launchFold<T>(rg, f->stream, ra, true, occ2);
+                if (ticketBuild && occ2) hipLaunchKernelGGL((k_chol_resident<T, true, true, false, true>), rg, dim3(256), kLdsRes2Bytes, f->stream, ra);
+                else if (ticketBuild) hipLaunchKernelGGL((k_chol_resident<T, true, false, false, true>), rg, dim3(256), sizeof(Step64Lds), f->stream, ra);
+                else if (fold && pipeHeads) launchFold<T>(rg, f->stream, ra, true, occ2);
                 else if (pipeHeads && occ2) hipLaunchKernelGGL((k_chol_resident<T, true, true>), rg, dim3(256), kLdsRes2Bytes, f->stream, ra);
                 else if (pipeHeads) hipLaunchKernelGGL((k_chol_resident<T, true>), rg, dim3(256), sizeof(Step64Lds), f->stream, ra);
                 else if (fold) launchFold<T>(rg, f->stream, ra, false, false);
@@ -2338,7 +2354,8 @@ int eqf_debug_option(eqf_filter* f, const char* name, int value) {
         return EQF_OK;
     }
     if (!std::strcmp(name, "res_tickets")) {
-        f->resTickets = value ? 1 : 0;
+        if (value < 0 || value > 2) return EQF_ERR_INVALID;
+        f->resTickets = value;
         return EQF_OK;
     }
     if (!std::strcmp(name, "device_edit")) {

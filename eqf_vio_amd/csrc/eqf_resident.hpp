@@ -424,10 +424,13 @@ __device__ long long g_resF64[2][16][128];  // [chain][R]: factor64's per-wave s
 // role and of the agent-scope loads of S / the right-hand sides cost the other builds 3 + 7 us per update (124 -> 134: this kernel is
 // bound by a chain of latencies and feels every change of its code layout).
 #ifdef EQF_WAIT_STATS
-template <typename T, bool PIPEH = false, bool OCC2 = false, bool FOLD = false>
+template <typename T, bool PIPEH = false, bool OCC2 = false, bool FOLD = false, bool TICKET = false>
 __device__ __forceinline__ void residentBody(const ResArgs& ra) {
 #else
-template <typename T, bool PIPEH = false, bool OCC2 = false, bool FOLD = false>
+// TICKET (round 6): the build that draws its role from ResArgs::ticket.  A build of its own for the same reason as FOLD: with the draw compiled
+// into the default kernels, the SAME box ran them 0.9 % (2, 4 filters) to 2.3 % (16, 64 filters, N = 1000) slower than round 5's library
+// (profiles/r06_ab_against_r05_tickets_auto.txt) -- half of it with the draw switched off.
+template <typename T, bool PIPEH = false, bool OCC2 = false, bool FOLD = false, bool TICKET = false>
 __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra) {
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smemR[];
@@ -437,8 +440,10 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
     // (role index and filter from the linear workgroup index: grid = (B * rolesPerRow, rows), filter fastest; one row unless the roles and
     // downdate tiles of a filter are more than 32768 -- N > ~2700)
     const int nB = (int)gridDim.x / ra.rolesPerRow;
-    int roleIdxAll = (int)blockIdx.x / nB + ra.rolesPerRow * (int)blockIdx.y, bIdx = (int)blockIdx.x % nB;
-    if (PIPEH && ra.ticket) {
+    int roleIdxAll = (int)blockIdx.x / nB + ra.rolesPerRow * (int)blockIdx.y;
+    const int bIdx = (int)blockIdx.x % nB;
+    static_assert(!TICKET || (PIPEH && !FOLD), "the ticket build exists for grids larger than the chip with a prep launch in front");
+    if constexpr (TICKET) {
         // (see ResArgs::ticket) the role index inside the filter is the order of ARRIVAL among the filter's workgroups
         int* const sT = reinterpret_cast<int*>(smemR);
         if (threadIdx.x == 0) *sT = (int)(atomicAdd(ra.ticket + 32 * bIdx, 1u) - ra.ticketBase);
@@ -1040,7 +1045,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
     // against 135 + 41 us with a follow-up launch; too few workgroups finish after the S-chain.)
 }
 #ifdef EQF_WAIT_STATS
-template <typename T, bool PIPEH = false, bool OCC2 = false, bool FOLD = false>
+template <typename T, bool PIPEH = false, bool OCC2 = false, bool FOLD = false, bool TICKET = false>
 __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra) {
     const long long t0 = wall_clock64();
     if (threadIdx.x == 0) {
@@ -1048,7 +1053,7 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void k_chol_resident(ResArgs ra)
         sStatWait = 0;
     }
     __syncthreads();
-    residentBody<T, PIPEH, OCC2, FOLD>(ra);
+    residentBody<T, PIPEH, OCC2, FOLD, TICKET>(ra);
     __syncthreads();
     if (threadIdx.x == 0) {
         atomicAdd(&g_waitStats[sStatClass & 15][0], sStatWait);

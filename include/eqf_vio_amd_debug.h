@@ -36,8 +36,11 @@ int eqf_debug_drop_role(eqf_filter* f, int kind, int role, int R, int C);
  *   "burst_lm" / "burst_rows" / "ring_ahead2"   launch shapes of an IMU burst: landmarks per builder workgroup (0 = by launch size, 4, 8, 16), row
  *                  landmarks per wavefront of the block kernel (0 = by launch size, 1, 2, 4), and whether the two-row block kernel requests a
  *                  step's constants two steps ahead (1) or one (0, default: two measured slower).  Bit for bit the same results whatever is chosen.
- *   "res_tickets"  1 (default): on a grid larger than the chip a workgroup of the update launch draws its place in the dependency order from a
- *                  counter when it starts (no assumption about the hardware's dispatch order); 0: the block index, as in rounds 3-5.  Same results.
+ *   "res_tickets"  a workgroup of the update launch draws its place in its filter's dependency order from a counter when it starts (no assumption
+ *                  about the hardware's dispatch order; a kernel build of its own) instead of reading it off its block index (rounds 3-5: relies
+ *                  on in-order dispatch, guarded by the time-outs).  0 (default): never.  1: on grids of at least six times the resident slots (16+
+ *                  filters of N = 200, N >= ~700: +1-2 % per update there).  2: on every grid larger than the chip with a prep launch in front
+ *                  (below six times the slots +3 .. 15 us per update).  Same results.
  *   "burst_fused_max_x10"    the one-launch IMU burst (k_burst_fused) is used up to value / 10 workgroups per CU (default: 1.25).
  *   "e_sigma_min_percu_x10"  the two-per-CU build of the update launch reads the E-chain's tiles in Sigma itself from value / 10 chain roles per
  *                  CU on (default 2.4: every such grid); below, the prep launch copies Sigma[6:, 6:].  Launch shapes only: same results. */

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (through gpurun): collects the round's measurement evidence into gpurun_out/evidence/.
 # Usage: scripts/collect_evidence.sh <round tag, e.g. r01>
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/evidence
 mkdir -p "$OUT"

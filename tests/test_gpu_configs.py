@@ -183,19 +183,20 @@ def test_batch_of_16_filters_N200_one_second_every_frame(oracle_lib, hip):
     assert fr == len(refs[0]) and fr >= 19 and fg.device_error() == 0
 
 
-@pytest.mark.parametrize("B", [3, 8])
+@pytest.mark.parametrize("B", [6, 16])
 def test_arrival_tickets_equal_block_indices_bitwise(hip, B):
-    """Round 6: on a grid larger than the chip a workgroup of the update launch draws its place in the dependency order from a counter
-    when it starts (csrc/eqf_resident.hpp: ResArgs::ticket) instead of reading it off its block index -- no assumption about the order in which
-    the hardware starts workgroups.  Which workgroup plays which role changes, what the roles compute does not: bit for bit the launch of
-    rounds 3-5 ("res_tickets" = 0), over frames that reuse the counter (it runs on from launch to launch)."""
+    """Round 6: the TICKET build of the update launch (csrc/eqf_resident.hpp: ResArgs::ticket; eqf_debug_option "res_tickets" = 2) -- on a grid
+    larger than the chip a workgroup draws its place in its filter's dependency order from a counter when it starts instead of reading it off
+    its block index, so nothing is assumed about the order in which the hardware starts workgroups.  Which workgroup plays which role
+    changes, what the roles compute does not: bit for bit the default launch (block indices, as in rounds 3-5), over frames that reuse the
+    counters (they run on from launch to launch).  6 filters: one workgroup per CU; 16: two per CU and the cross-filter downdate order."""
     from eqf_vio_amd import synth
 
     N = 200
     sts = [synth.make_stream(N, seed=777 + b, duration=0.36) for b in range(B)]
     d = synth.template_settings_dict()
     out = []
-    for tickets in (1, 0):
+    for tickets in (2, 0):  # (2: on every grid larger than the chip; 0: the default)
         fg = hip.FilterBatch(d, capacity=N, batch=B)
         fg.debug_option("res_tickets", tickets)
         fg.stream_upload(np.stack([s.imu for s in sts], axis=1), np.stack([s.vision_stamps for s in sts], axis=1), sts[0].ids,
