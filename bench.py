@@ -594,12 +594,23 @@ def self_spawn(args):
                                       stdout=None if r == 0 else sys.stderr))
     rc = 0
     alive = set(range(n))
+    rank0_done_at = None
     while alive:
+        if rank0_done_at is not None and time.time() - rank0_done_at > 60.0:
+            # rank 0 has printed the line and left cleanly a minute ago: a straggler (a rank stuck in a collective nobody else will join any
+            # more) must not hold the job -- stop what is left (own PIDs only) and report rank 0's success
+            for q in sorted(alive):
+                if procs[q].poll() is None:
+                    print("bench.py: rank %d still running 60 s after rank 0 finished; stopping it" % q, file=sys.stderr, flush=True)
+                    procs[q].terminate()
+            break
         for r in sorted(alive):
             code = procs[r].poll()
             if code is None:
                 continue
             alive.discard(r)
+            if r == 0 and code == 0:
+                rank0_done_at = time.time()
             if code != 0 and rc == 0:
                 rc = code
                 print("bench.py: rank %d of %d exited with code %d; stopping the job" % (r, n, code), file=sys.stderr, flush=True)

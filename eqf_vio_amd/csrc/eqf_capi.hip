@@ -821,11 +821,13 @@ int launchUpdateT(eqf_filter* f, const double* bearings, long long bearStride, c
         // 436 -> 419 k; 64: 500 -> 465 k.  With the E-chain's first dependency group IN FRONT of the prep roles (buildRoles' `front`,
         // EQF_RES_FOLD_FRONT; profiles/r05_fold_front.txt): 4 filters 212 -> 219.6 k, 8 and 16 unchanged -- there the path prep -> S-chain ->
         // right-hand sides -> downdate is as long as the E-chain's, and the prep work is on it wherever it runs.  So: while prep roles + chain
-        // roles together are at most four per CU (2 .. 4 filters of N = 200); EQF_RES_FOLD_PREP=3 forces it on every batch (the bitwise test
-        // does), = 2 keeps it to co-resident grids.
+        // roles together are at most four per CU (2 .. 4 filters of N = 200) -- round 6, behind the 8-landmark burst builder and this round's
+        // other launches (profiles/r06_fold_batch.txt, best of three, prep launch -> prep roles): 5 filters 234.0 -> 246.0 k, 6: 270.6 -> 283.7 k,
+        // 8: 340.4 -> 338.5 k, 10: 362.4 -> 357.0 k, 12: 397.5 -> 390.4 k -- so now up to SIX per CU (2 .. 6 filters of N = 200);
+        // EQF_RES_FOLD_PREP=3 forces it on every batch (the bitwise test does), = 2 keeps it to co-resident grids.
         const bool foldBatch = (f->resFoldPrep == 1 || f->resFoldPrep == 3) && !residentFits && std::is_same<T, double>::value && f->cholResident < 2 &&
                                nb64E > 1 && f->dPrepFlags && lmBlocks + eBlocks <= f->nPrepCap && lds <= (size_t)kLdsRes2Bytes &&
-                               (f->resFoldPrep == 3 || (long long)(lmBlocks + eBlocks + rolesAll) * B <= 4LL * f->numCUs);
+                               (f->resFoldPrep == 3 || (long long)(lmBlocks + eBlocks + rolesAll) * B <= 6LL * f->numCUs);
         fold = fold || foldBatch;
         rc = buildRoles(f, Nmax, fold, foldBatch ? f->resFoldFront : 0);
         if (rc) return rc;
@@ -2227,12 +2229,16 @@ int eqf_set_state(eqf_filter* f, int b, int N, const int* ids, const double* pos
     // the caller's to look at: eqf_reset clears those) and k_edit's barrier counters, which a timed-out launch leaves mid-count, start
     // from zero.  With batch = 1 that is this very call.
     if (f->restoredMark.size() != (size_t)f->B) f->restoredMark.assign(f->B, 0);
-    f->restoredMark[b] = 1;
-    if (std::all_of(f->restoredMark.begin(), f->restoredMark.end(), [](char c) { return c != 0; })) {
+    int e = 0;
+    HIPC(hipMemcpy(&e, f->errflag, sizeof(int), hipMemcpyDeviceToHost));
+    if (!(e & 128)) {
+        f->restoredMark.assign(f->B, 0);  // (no time-out to recover from: restores of a healthy handle are not counted towards a later one)
+    } else {
+        f->restoredMark[b] = 1;
+    }
+    if ((e & 128) && std::all_of(f->restoredMark.begin(), f->restoredMark.end(), [](char c) { return c != 0; })) {
         f->restoredMark.assign(f->B, 0);
-        int e = 0;
-        HIPC(hipMemcpy(&e, f->errflag, sizeof(int), hipMemcpyDeviceToHost));
-        if (e & 128) {
+        {
             // (bit 4 with it: a chain that unwinds may have judged a pivot of operands it never received -- a by-product of the time-out)
             e &= ~(128 | 4);
             HIPC(hipMemcpy(f->errflag, &e, sizeof(int), hipMemcpyHostToDevice));

@@ -24,10 +24,10 @@ def source_hash():
 
 def test_kernel_sources_have_been_through_the_machine_verifier():
     path = os.path.join(CSRC, "VERIFIED")
-    assert os.path.exists(path), "run `make -C eqf_vio_amd/csrc verify` (about 15 minutes) and commit csrc/VERIFIED"
+    assert os.path.exists(path), "run `make -C eqf_vio_amd/csrc verify` (about 20 minutes) and commit csrc/VERIFIED"
     seen = open(path).read().strip()
     assert seen == source_hash(), ("the kernel sources changed since the last `-verify-machineinstrs` build: run `make -C eqf_vio_amd/csrc verify` "
-                                   "(about 15 minutes, fails on 'Bad machine code') and commit csrc/VERIFIED")
+                                   "(about 20 minutes, fails on 'Bad machine code') and commit csrc/VERIFIED")
 
 
 def test_verify_target_uses_the_product_flags():

@@ -183,13 +183,13 @@ def test_batch_of_16_filters_N200_one_second_every_frame(oracle_lib, hip):
     assert fr == len(refs[0]) and fr >= 19 and fg.device_error() == 0
 
 
-@pytest.mark.parametrize("B", [6, 16])
+@pytest.mark.parametrize("B", [8, 16])
 def test_arrival_tickets_equal_block_indices_bitwise(hip, B):
     """Round 6: the TICKET build of the update launch (csrc/eqf_resident.hpp: ResArgs::ticket; eqf_debug_option "res_tickets" = 2) -- on a grid
     larger than the chip a workgroup draws its place in its filter's dependency order from a counter when it starts instead of reading it off
     its block index, so nothing is assumed about the order in which the hardware starts workgroups.  Which workgroup plays which role
     changes, what the roles compute does not: bit for bit the default launch (block indices, as in rounds 3-5), over frames that reuse the
-    counters (they run on from launch to launch).  6 filters: one workgroup per CU; 16: two per CU and the cross-filter downdate order."""
+    counters (they run on from launch to launch).  8 and 16 filters: the two-per-CU build, 16 with the cross-filter downdate order."""
     from eqf_vio_amd import synth
 
     N = 200
