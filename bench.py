@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--tiled-block", type=int, default=250, help="landmarks per block of the 2-D partition")
     ap.add_argument("--tiled-timeout", type=int, default=240, help="several GPUs: seconds after which the cfg 5 leg is given up")
     ap.add_argument("--tiled-frames", type=int, default=3, help="timed frames (a frame = 10 IMU calls + 1 vision call) after one warm-up frame")
+    ap.add_argument("--no-i8-downdate", action="store_true", help="skip the cfg 5 sub-leg with the covariance downdate on the integer matrix pipe")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle-checked prefix (parity block of the JSON line)")
     ap.add_argument("--no-n1000", action="store_true", help="skip the BASELINE cfg 3 leg (one filter of N = 1000, 220 steps, with its own roofline)")
     ap.add_argument("--no-batch8", action="store_true", help="skip the 8-filters-per-GPU leg (one GPU's share of the 64-filter batch on an 8-GPU node)")
@@ -502,6 +503,7 @@ def tiled_leg(args, dist, rank, world, device):
     tf.phase_ms = None
     dt = timed_run(tf.processIMUData, tf.processVisionData, lambda: torch.cuda.synchronize())
     tf.check()
+    sll_ref = tf.Sll.clone() if (world == 1 and not args.no_i8_downdate) else None  # (what the integer-pipe run below is held against)
     # per-phase GPU time: a second pass over the next frames with event brackets (kept out of the timed region)
     tf.phase_ms = {}
     more = ev[first_vis + 1 + 11 * frames: first_vis + 1 + 11 * (frames + 1)]
@@ -529,6 +531,8 @@ def tiled_leg(args, dist, rank, world, device):
         "note": "closed loop through the C ABI (eqf_tiled_* / eqf_tile_*), torch.distributed only moves solved block rows; "
                 + ("one rank: no exchange" if world == 1 else "RCCL broadcasts along process rows / columns"),
     }
+    if sll_ref is not None:
+        out["_sll_ref"] = sll_ref
     if world > 1:
         out["note"] += "; UNMEASURED on more than one GPU until a node is available to the builder -- this line is then the first measurement"
     del tf, be
@@ -564,6 +568,33 @@ def tiled_leg(args, dist, rank, world, device):
         del tf, be
     except Exception as e:  # the fixed-set figure above stands on its own
         out["churn"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if world == 1 and rank == 0 and not args.no_i8_downdate:
+        # Round 6: the same frames with the covariance downdate on the INTEGER matrix pipe (eqf_tf_set_option "downdate_slices" = 6: Y's columns
+        # as six 7-bit slices, int8 MFMA with exact accumulation, fp64 recombination; csrc/eqf_tile.hpp) -- north_star's "low-precision MFMA for the
+        # dense Sigma contractions, Sigma within 1e-4", for the one product it was built for.  Opt-in; the line's other figures are fp64.
+        try:
+            sll_ref = out.pop("_sll_ref")
+            be = tiled.HipBackend(d, capacity=N, device_index=device)
+            tf = tiled.TiledFilter(tiled.ProcessGrid(None, Pr, Pc, device=be.device), be, bl)
+            tf.check_every = 0
+            tf.downdate_slices = 6
+            tf.phase_ms = None
+            dti = timed_run(tf.processIMUData, tf.processVisionData, lambda: torch.cuda.synchronize())
+            tf.check()
+            diff = float((torch.linalg.norm(tf.Sll - sll_ref) / torch.linalg.norm(sll_ref)).item())
+            tf.phase_ms = {}
+            run(tf.processIMUData, tf.processVisionData, more)
+            tf.collect_phases()
+            out["i8_downdate"] = {"value": len(timed) / dti, "unit": "steps/s", "ms_per_frame": dti * 1e3 / max(n_vis, 1), "slices": 6, "integer_products": 21,
+                                  "vs_fp64_downdate": dt / dti, "device_error_flag": be.device_error(),
+                                  "sigma_rel_frobenius_difference_to_the_fp64_run": diff, "tolerance": 1e-4,
+                                  "phases_ms_per_frame": {k: round(v / n_vis_ph, 3) for k, v in tf.phase_ms.items()},
+                                  "note": "local blocks of Sigma after the same %d timed frames, against the fp64 run of this leg; opt-in "
+                                          "(eqf_tf_set_option \"downdate_slices\"), every other figure of the line is the fp64 path" % frames}
+            del tf, be, sll_ref
+        except Exception as e:
+            out["i8_downdate"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    out.pop("_sll_ref", None)
     if world == 1 and rank == 0:
         fb = binding.FilterBatch(d, capacity=N, batch=1, device=device)
         dtm = timed_run(lambda s_, w_, a_: fb.process_imu([s_], w_, a_), lambda s_, i_, y_: fb.process_vision([s_], i_, y_), fb.synchronize)

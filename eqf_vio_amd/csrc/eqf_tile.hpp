@@ -556,4 +556,161 @@ __global__ __launch_bounds__(256) void k_tile_trsm(const double* A, int ld, int 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// The downdate's product on the INTEGER matrix pipe (round 6; opt-in, eqf_tf_set_option "downdate_slices"): C -= A^T B for A (k x m), B (k x n)
+// row-major (VIOFilter.cpp:297 as Sigma - Y^T Y), with every column of A and B scaled by a power of two and cut into S signed 7-bit slices
+// (int8, |q| <= 64): the S (S + 1) / 2 slice pairs (ta, tb) with ta + tb < S are multiplied on v_mfma_i32_32x32x32_i8 -- int32 accumulation is
+// EXACT (k * S * 64^2 < 2^31 for k <= 70 000) -- and the S accumulators of an element (one per ta + tb) are recombined in fp64.  What is lost
+// is only what the slices do not hold: the bits of an entry below 2^-(6 + 7 (S - 1)) of its column's largest entry (S = 5: 34 bits, 6: 41, 7:
+// 48).  Sigma itself stays fp64 in memory, and unlike an fp32 product nothing is lost in the accumulation -- the two things DESIGN.md section
+// 2 measured fp32 to fail on.  What the filter needs was measured on the bench stream with this truncation put into the fp64 restatement
+// (scripts/slice_precision_study.py, profiles/r06_slice_precision_study*.txt) and with this kernel in the filter (profiles/r06_i8_downdate_error.txt):
+// the truncation alone would allow S = 5 (5e-6), but the slice pairs the product drops (ta + tb >= S: products of the LOWER slices, of the
+// truncation's size) add up coherently over Y's correlated columns -- S = 5: 1.4e-4 .. 9e-4, misses; S = 6: 2e-6 .. 2e-5; S = 7: 1e-8 .. 8e-8.
+//   k_i8_colexp   per column the exponent of its largest |entry| (frexp), as an atomicMax over row slabs (expo zeroed by the caller; stored + 2048)
+//   k_i8_split<S> the slices in MFMA FRAGMENT order: for a 32-column tile ct, a 32-row chunk kc and slice t one 1 KB block whose lane l holds
+//                 column ct * 32 + (l & 31), rows kc * 32 + 16 (l >> 5) .. + 16  -- the operand layout of v_mfma_i32_32x32x32_i8; block index
+//                 ((ct * nKc + kc) * S + t).  Rows past k and columns past m are zero.
+//   k_i8_gemm<S>  512 threads = 8 waves as 4 x 2, workgroup tile 128 (rows of C) x 64, a wave owns ONE 32 x 32 MFMA tile with S accumulators
+//                 (two waves per SIMD); a chunk's 4 S + 2 S fragment blocks go global -> LDS directly (global_load_lds_dwordx4: the global
+//                 layout IS the LDS image), three LDS buffers (chunk kc + 2 in flight while kc is multiplied), one raw s_barrier per chunk
+//                 behind a counted vmcnt.  maskRb > 0: C is a symmetric local matrix in blocks of maskRb, tiles entirely below the block
+//                 diagonal are skipped (k_tile_mirror completes them).  Epilogue: C[i][j] += alpha 2^(eA[i] + eB[j]) sum_d acc_d 2^-(12 + 7 d).
+// Measured (scripts/micro/i8_split_gemm.hip, profiles/r06_i8_split_gemm_v2.txt): S = 5: 84 - 108 fp64-equivalent TFLOP/s at the downdate's
+// shapes (1.3 - 1.6 POPS of int8) against 51 - 57 for k_tile_gemm_tn in the same run.
+typedef int i8v4 __attribute__((ext_vector_type(4)));
+typedef int i8v16 __attribute__((ext_vector_type(16)));
+constexpr int kI8Bits = 7;
+
+__global__ __launch_bounds__(256) void k_i8_colexp(const double* X, int K, int M, int ld, int* expo) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), kq = threadIdx.x >> 6;
+    const int k0 = blockIdx.y * 512, k1 = min(k0 + 512, K);
+    double mx = 0.0;
+    if (c < M)
+        for (int k = k0 + kq; k < k1; k += 4) mx = fmax(mx, fabs(X[(long long)k * ld + c]));
+    __shared__ double sm[4][64];
+    sm[kq][threadIdx.x & 63] = mx;
+    __syncthreads();
+    if (kq == 0 && c < M) {
+        mx = fmax(fmax(sm[0][threadIdx.x], sm[1][threadIdx.x]), fmax(sm[2][threadIdx.x], sm[3][threadIdx.x]));
+        if (mx > 0.0) {
+            int e = 0;
+            frexp(mx, &e);  // mx = f 2^e, f in [0.5, 1): |x| 2^-e < 1
+            atomicMax(expo + c, e + 2048);
+        }
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void k_i8_split(const double* X, int K, int M, int ld, const int* expo, signed char* out, int nKc) {
+    const int ct = blockIdx.x, kc = blockIdx.y * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (kc >= nKc) return;
+    const int c = ct * 32 + (l & 31), k0 = kc * 32 + (l >> 5) * 16;
+    const int es = c < M ? expo[c] : 0;
+    const double sc = (c < M && es > 0) ? ldexp(1.0, -(es - 2048)) : 0.0;
+    signed char q[S][16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int k = k0 + j;
+        double r = (c < M && k < K) ? X[(long long)k * ld + c] * sc : 0.0;  // |r| < 1, exact (power-of-two scale)
+        double w = 64.0;                                                   // 2^6, then 2^13, 2^20, ...
+#pragma unroll
+        for (int t = 0; t < S; ++t) {
+            const double qq = rint(r * w);  // |qq| <= 64
+            q[t][j] = (signed char)qq;
+            r -= qq / w;  // exact
+            w *= 128.0;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+        int4 v;
+        v.x = (unsigned char)q[t][0] | ((unsigned char)q[t][1] << 8) | ((unsigned char)q[t][2] << 16) | ((unsigned)(unsigned char)q[t][3] << 24);
+        v.y = (unsigned char)q[t][4] | ((unsigned char)q[t][5] << 8) | ((unsigned char)q[t][6] << 16) | ((unsigned)(unsigned char)q[t][7] << 24);
+        v.z = (unsigned char)q[t][8] | ((unsigned char)q[t][9] << 8) | ((unsigned char)q[t][10] << 16) | ((unsigned)(unsigned char)q[t][11] << 24);
+        v.w = (unsigned char)q[t][12] | ((unsigned char)q[t][13] << 8) | ((unsigned char)q[t][14] << 16) | ((unsigned)(unsigned char)q[t][15] << 24);
+        reinterpret_cast<int4*>(out)[(((size_t)ct * nKc + kc) * S + t) * 64 + l] = v;
+    }
+}
+
+typedef const void __attribute__((address_space(1)))* i8gptr_t;
+typedef void __attribute__((address_space(3)))* i8lptr_t;
+template <int S>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_i8_gemm(const signed char* As, const signed char* Bs,
+    const int* eA, const int* eB, double* C, int M, int N, int ldc, int nKc, double alpha, int maskRb) {
+    constexpr int kFrag = 6 * S, kPerWave = (kFrag + 7) / 8, kSlots = kPerWave * 8;  // (every wave issues the same number of copies: one vmcnt)
+    __shared__ int4 sm[3][kSlots * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv >> 1, wc = wv & 1;
+    const int ctA0 = blockIdx.y * 4, ctB0 = blockIdx.x * 2;
+    if (maskRb > 0 && (ctA0 * 32) / maskRb > (ctB0 * 32 + 63) / maskRb) return;  // (uniform) entirely below the block diagonal
+    const int4* gA = reinterpret_cast<const int4*>(As);
+    const int4* gB = reinterpret_cast<const int4*>(Bs);
+    auto stage = [&](int kc, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < kPerWave; ++j) {
+            const int slot = wv + 8 * j;
+            const int blk = slot < kFrag ? slot : 0;  // (pad slots re-read block 0 into LDS nobody looks at)
+            const int4* src;
+            if (blk < 4 * S) {
+                const int ct = blk / S, t = blk - ct * S;
+                src = gA + (((size_t)(ctA0 + ct) * nKc + kc) * S + t) * 64 + lane;
+            } else {
+                const int b2 = blk - 4 * S, ct = b2 / S, t = b2 - ct * S;
+                src = gB + (((size_t)(ctB0 + ct) * nKc + kc) * S + t) * 64 + lane;
+            }
+            __builtin_amdgcn_global_load_lds((i8gptr_t)src, (i8lptr_t)&sm[buf][slot * 64], 16, 0, 0);
+        }
+    };
+    i8v16 acc[S];
+#pragma unroll
+    for (int d = 0; d < S; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] = 0;
+    stage(0, 0);
+    if (nKc > 1) stage(1, 1);
+    // chunk 0 complete (the older kPerWave of this wave's copies), then everybody's: the barrier
+    if (nKc > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerWave) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kc = 0; kc < nKc; ++kc) {
+        const int buf = kc % 3;
+        if (kc + 2 < nKc) stage(kc + 2, (kc + 2) % 3);  // (that buffer was read in iteration kc - 1: the barrier at its end has been passed)
+        i8v4 a[S], b[S];
+#pragma unroll
+        for (int t = 0; t < S; ++t) {
+            const int4 va = sm[buf][(wr * S + t) * 64 + lane];
+            const int4 vb = sm[buf][(4 * S + wc * S + t) * 64 + lane];
+            a[t] = i8v4{va.x, va.y, va.z, va.w};
+            b[t] = i8v4{vb.x, vb.y, vb.z, vb.w};
+        }
+#pragma unroll
+        for (int ta = 0; ta < S; ++ta)
+#pragma unroll
+            for (int tb = 0; tb + ta < S; ++tb) acc[ta + tb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ta], b[tb], acc[ta + tb], 0, 0, 0);
+        // chunk kc + 1 must be in LDS before anybody reads it: this wave's copies of it are the older ones of what it has in flight; and
+        // every read of this chunk has returned before its buffer is restaged two iterations on
+        if (kc + 2 < nKc) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerWave) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    const int j = (ctB0 + wc) * 32 + (lane & 31);
+    const int ibase = (ctA0 + wr) * 32;
+    const int ej = j < N ? eB[j] - 2048 : 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = ibase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (i < M && j < N) {
+            double v = 0.0;
+#pragma unroll
+            for (int d = S - 1; d >= 0; --d) v += ldexp((double)acc[d][r], -(12 + kI8Bits * d));  // smallest terms first
+            const int ei = eA[i];
+            if (ei > 0 && eB[j] > 0) {  // (a column that is all zero has no exponent and contributes nothing)
+                double* dst = C + (long long)i * ldc + j;
+                *dst += alpha * ldexp(v, ei - 2048 + ej);
+            }
+        }
+    }
+}
+
 }  // namespace eqf

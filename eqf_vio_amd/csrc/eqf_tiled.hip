@@ -820,6 +820,70 @@ int eqf_tile_downdate(int device, void* stream, double* C, int ldc, int m, int n
     return eqf_tile_gemm_tn(device, stream, C, ldc, m, n, A, lda, B, ldb, k, -1.0, 0, 0, 0, 1, 0, 0, 1, 0);
 }
 
+// ---- the downdate's product on the integer matrix pipe (csrc/eqf_tile.hpp: k_i8_colexp / k_i8_split / k_i8_gemm)
+extern "C++" {
+namespace {
+struct I8Plan {
+    int mp, np, nKc;
+    size_t sliceA, sliceB, offB, offEA, offEB, total;
+};
+I8Plan i8Plan(int m, int n, int k, int slices, int same) {
+    I8Plan p;
+    p.mp = (m + 127) / 128 * 128;                       // rows of C: 128 per workgroup
+    p.np = same ? p.mp : (n + 63) / 64 * 64;            // columns of C: 64 per workgroup (the same operand: one split serves both sides)
+    p.nKc = (k + 31) / 32;
+    p.sliceA = (size_t)(p.mp / 32) * p.nKc * slices * 1024;
+    p.sliceB = same ? 0 : (size_t)(p.np / 32) * p.nKc * slices * 1024;
+    p.offB = p.sliceA;
+    p.offEA = p.sliceA + p.sliceB;
+    p.offEB = p.offEA + sizeof(int) * (size_t)p.mp;
+    p.total = p.offEB + (same ? 0 : sizeof(int) * (size_t)p.np);
+    return p;
+}
+template <int S>
+int i8Downdate(hipStream_t st, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k, int maskRb, bool same,
+    char* ws, const I8Plan& p) {
+    signed char* sA = reinterpret_cast<signed char*>(ws);
+    signed char* sB = same ? sA : reinterpret_cast<signed char*>(ws + p.offB);
+    int* eA = reinterpret_cast<int*>(ws + p.offEA);
+    int* eB = same ? eA : reinterpret_cast<int*>(ws + p.offEB);
+    HIPC(hipMemsetAsync(eA, 0, p.total - p.offEA, st));
+    const dim3 kslabs(1, (k + 511) / 512);
+    hipLaunchKernelGGL(k_i8_colexp, dim3((m + 63) / 64, kslabs.y), dim3(256), 0, st, A, k, m, lda, eA);
+    hipLaunchKernelGGL(k_i8_split<S>, dim3(p.mp / 32, (p.nKc + 3) / 4), dim3(256), 0, st, A, k, m, lda, eA, sA, p.nKc);
+    if (!same) {
+        hipLaunchKernelGGL(k_i8_colexp, dim3((n + 63) / 64, kslabs.y), dim3(256), 0, st, B, k, n, ldb, eB);
+        hipLaunchKernelGGL(k_i8_split<S>, dim3(p.np / 32, (p.nKc + 3) / 4), dim3(256), 0, st, B, k, n, ldb, eB, sB, p.nKc);
+    }
+    hipLaunchKernelGGL(k_i8_gemm<S>, dim3(p.np / 64, p.mp / 128), dim3(512), 0, st, sA, sB, eA, eB, C, m, n, ldc, p.nKc, -1.0, maskRb);
+    HIPC(hipGetLastError());
+    return EQF_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+size_t eqf_tile_i8_workspace_bytes(int m, int n, int k, int slices, int same_operand) {
+    if (m < 1 || n < 1 || k < 1 || slices < 5 || slices > 7) return 0;
+    return i8Plan(m, n, k, slices, same_operand ? 1 : 0).total;
+}
+
+int eqf_tile_downdate_i8(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k,
+    int slices, int mask_rb, void* workspace, size_t workspace_bytes) {
+    if (!C || !A || !B || !workspace || m < 1 || n < 1 || k < 1 || k > 70000 || ldc < n || lda < m || ldb < n || mask_rb < 0) return EQF_ERR_INVALID;
+    if (slices < 5 || slices > 7) return EQF_ERR_INVALID;
+    const bool same = A == B && m == n && lda == ldb;
+    if (mask_rb > 0 && m != n) return EQF_ERR_INVALID;
+    const I8Plan p = i8Plan(m, n, k, slices, same ? 1 : 0);
+    if (workspace_bytes < p.total) return EQF_ERR_INVALID;
+    DeviceScope ds(device);
+    if (!ds.ok) return EQF_ERR_HIP;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    if (slices == 5) return i8Downdate<5>(st, C, ldc, m, n, A, lda, B, ldb, k, mask_rb, same, ws, p);
+    if (slices == 6) return i8Downdate<6>(st, C, ldc, m, n, A, lda, B, ldb, k, mask_rb, same, ws, p);
+    return i8Downdate<7>(st, C, ldc, m, n, A, lda, B, ldb, k, mask_rb, same, ws, p);
+}
+
 int eqf_tile_propagate(int device, void* stream, double* out, const double* in, int ld, int nI, int nJ, const double* D_I,
     const double* L_I, const double* D_J, const double* L_J, const double* Sbb, const double* SbI, int ldbI, const double* SbJ,
     int ldbJ, const double* BnI, const double* BnJ, const double* R6, double T, double diag_noise, int is_diag) {

@@ -138,6 +138,13 @@ struct eqf_tf {
     int* info = nullptr;  // device: or-ed with 1 when a pivot of a diagonal block was not positive
     // options
     int lookahead = 1, overlapChains = 1, burst = 1, checkEvery = 1, framesSinceCheck = 0, profiling = 0, graphs = 0;
+    // "downdate_slices" (round 6): 0 = the downdate Sigma - Y^T Y on the fp64 matrix cores (default, parity grade); 5 / 6 / 7 = on the INTEGER
+    // matrix pipe from that many 7-bit slices of Y's columns, exact accumulation (eqf_tile_downdate_i8): 34 / 41 / 48 bits of every entry
+    // relative to its column's largest -- Sigma within 1e-4 of the fp64 path from SIX slices on: measured 2e-6 .. 2e-5 at N = 200 .. 4000, five
+    // miss it (1.4e-4 .. 9e-4: profiles/r06_i8_downdate_error.txt, r06_slice_precision_study_2s_with_pairs.txt)
+    int ddSlices = 0;
+    void* i8Work = nullptr;
+    size_t i8WorkBytes = 0;
     // one rank: the launch sequence of an update is fixed for a given number of slots and buffer parity -- it CAN be captured once as a hipGraph
     // (the second update of that shape: the first allocates its scratch operands) and replayed: one hipGraphLaunch instead of ~2000 launches.
     // OFF by default (option "graphs" / EQF_TILED_GRAPHS=1): measured on the MI355X with ROCm 7.2 (profiles/r05_tiled_host_loop.txt) the
@@ -823,7 +830,22 @@ int enqueueUpdate(eqf_tf* f) {
         // computed and the rest is mirrored
         if (geo.nlr && geo.nlc) {
             const int w3 = 3 * geo.bl;
-            if (f->symmetric) {
+            if (f->ddSlices > 0) {
+                // (the integer pipe: same product, Y's columns cut into slices; on a symmetric rank Yr IS Yc -- one split)
+                const bool same = f->Yr.p == f->Yc.p && f->Yr.c == f->Yc.c && f->Yr.ld == f->Yc.ld;
+                const size_t need = eqf_tile_i8_workspace_bytes(f->Sll.r, f->Sll.c, f->Yr.r, f->ddSlices, same ? 1 : 0);
+                if (need > f->i8WorkBytes) {
+                    HIPC(hipStreamSynchronize(f->cur));
+                    if (f->i8Work) (void)hipFree(f->i8Work);
+                    f->i8Work = nullptr;
+                    f->i8WorkBytes = 0;
+                    HIPC(hipMalloc(&f->i8Work, need));
+                    f->i8WorkBytes = need;
+                }
+                RC(eqf_tile_downdate_i8(f->device, f->cur, f->Sll.p, f->Sll.ld, f->Sll.r, f->Sll.c, f->Yr.p, f->Yr.ld, f->Yc.p, f->Yc.ld, f->Yr.r,
+                    f->ddSlices, f->symmetric ? w3 : 0, f->i8Work, f->i8WorkBytes));
+                if (f->symmetric) RC(eqf_tile_mirror(f->device, f->cur, f->Sll.p, f->Sll.ld, f->Sll.r, w3));
+            } else if (f->symmetric) {
                 const int mask[8] = {w3, w3, 0, 1, 0, 0, 1, 0};
                 RC(gemmTn(f, f->Sll, f->Yr, f->Yc, -1.0, mask));
                 RC(eqf_tile_mirror(f->device, f->cur, f->Sll.p, f->Sll.ld, f->Sll.r, w3));
@@ -952,6 +974,7 @@ void freeAll(eqf_tf* f) {
     if (f->t) eqf_tiled_destroy(f->t);
     for (double* p : f->allocs) hipFree(p);
     if (f->info) hipFree(f->info);
+    if (f->i8Work) hipFree(f->i8Work);
     for (auto& g : f->graphExec) hipGraphExecDestroy(g.second);
     for (hipEvent_t e : f->evPool) hipEventDestroy(e);
     for (auto& p : f->phasePending) {
@@ -1060,6 +1083,10 @@ int eqf_tf_set_option(eqf_tf* f, const char* name, int value) {
     const std::string n(name);
     if (n == "lookahead") f->lookahead = value;
     else if (n == "overlap_chains") f->overlapChains = value;
+    else if (n == "downdate_slices") {
+        if (value != 0 && (value < 5 || value > 7)) return EQF_ERR_INVALID;
+        f->ddSlices = value;
+    }
     else if (n == "burst") f->burst = value;
     else if (n == "check_every") f->checkEvery = value;
     else if (n == "profiling") f->profiling = value;

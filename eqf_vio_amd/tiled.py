@@ -182,6 +182,8 @@ class TiledFilter:
         self._check(self.lib.eqf_tf_set_option(self._h, name.encode(), int(value)), "eqf_tf_set_option")
 
     # ---- options (attributes, as the Python loop had them)
+    # 0 (default): the covariance downdate on the fp64 matrix cores; 5 / 6 / 7: on the integer matrix pipe from that many 7-bit slices (round 6)
+    downdate_slices = property(lambda s: getattr(s, "_dd_slices", 0), lambda s, v: (setattr(s, "_dd_slices", int(v)), s._opt("downdate_slices", v))[0])
     overlap_chains = property(lambda s: s._overlap, lambda s, v: (setattr(s, "_overlap", bool(v)), s._opt("overlap_chains", v))[0])
     lookahead = property(lambda s: getattr(s, "_lookahead", True), lambda s, v: (setattr(s, "_lookahead", bool(v)), s._opt("lookahead", v))[0])
     burst = property(lambda s: getattr(s, "_burst", True), lambda s, v: (setattr(s, "_burst", bool(v)), s._opt("burst", v))[0])

@@ -258,6 +258,21 @@ class HipBackend:
         self.b._check(self.lib.eqf_tile_gemm_tn(self.dev, self._cur(), self._p(Cm), Cm.stride(0), m, n, self._p(A), A.stride(0), self._p(B),
                                                 B.stride(0), k, float(alpha), *[int(x) for x in mk]), "eqf_tile_gemm_tn")
 
+    def downdate_i8(self, Cm, A, B, slices, mask_rb=0):
+        """Cm (m x n view) -= A^T B on the integer matrix pipe from `slices` 7-bit slices of the operands' columns, exact accumulation
+        (eqf_tile_downdate_i8, include/eqf_vio_amd_debug.h); A is B (the same view): one split."""
+        import torch
+
+        m, n = Cm.shape
+        k = A.shape[0]
+        same = A.data_ptr() == B.data_ptr() and A.shape == B.shape and A.stride(0) == B.stride(0)
+        need = int(self.lib.eqf_tile_i8_workspace_bytes(m, n, k, int(slices), int(same)))
+        assert need > 0
+        ws = torch.empty(need, dtype=torch.uint8, device=Cm.device)
+        self.b._check(self.lib.eqf_tile_downdate_i8(self.dev, self._cur(), self._p(Cm), Cm.stride(0), m, n, self._p(A), A.stride(0), self._p(B),
+                                                    B.stride(0), k, int(slices), int(mask_rb), ws.data_ptr(), need), "eqf_tile_downdate_i8")
+        torch.cuda.current_stream(Cm.device).synchronize()  # (the workspace is a temporary of this call)
+
     def mirror_lower(self, Cm, rb):
         """Cm (n x n view): every element below the block diagonal (blocks of rb) <- its mirror image."""
         self.b._check(self.lib.eqf_tile_mirror(self.dev, self._cur(), self._p(Cm), Cm.stride(0), Cm.shape[0], int(rb)), "eqf_tile_mirror")

@@ -116,6 +116,15 @@ int eqf_tile_propagate(int device, void* stream, double* out, const double* in, 
     int ldbJ, const double* BnI, const double* BnJ, const double* R6, double T, double diag_noise, int is_diag);
 int eqf_tile_downdate(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb,
     int k);
+/* eqf_tile_downdate_i8 (round 6): C (m x n, ldc) -= A^T B as eqf_tile_downdate, but on the INTEGER matrix pipe: every column of A and B is scaled
+ *   by a power of two and cut into `slices` (5, 6 or 7) signed 7-bit pieces, the slice pairs are multiplied on v_mfma_i32_32x32x32_i8 with exact
+ *   int32 accumulation and recombined in fp64 (csrc/eqf_tile.hpp).  The only error is the truncation of an entry below 2^-(6 + 7 (slices - 1)) of
+ *   its column's largest entry; k <= 70 000.  mask_rb > 0 (m == n): C is a symmetric local matrix in blocks of mask_rb, tiles entirely below the
+ *   block diagonal are skipped (eqf_tile_mirror completes them).  workspace: caller-owned device memory of at least
+ *   eqf_tile_i8_workspace_bytes(m, n, k, slices, A == B) bytes (the slices of both operands, once if they are the same matrix). */
+size_t eqf_tile_i8_workspace_bytes(int m, int n, int k, int slices, int same_operand);
+int eqf_tile_downdate_i8(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k,
+    int slices, int mask_rb, void* workspace, size_t workspace_bytes);
 int eqf_tile_potrf(int device, void* stream, double* A, int ld, int n, double* drec, int* info);
 int eqf_tile_trsm(int device, void* stream, const double* A, int ld, int n, const double* drec, double* B, int ldb, int m, int right);
 

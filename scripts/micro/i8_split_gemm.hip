@@ -170,6 +170,84 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// ---- second kernel (round 6, same session): the same product with what the first one lacked.  512 threads = 8 waves as 4 x 2, a wave owns
+// ONE 32 x 32 MFMA tile (S accumulators = 16 S registers: two waves per SIMD fit), the S + S fragments of a chunk go global -> LDS directly
+// (global_load_lds_dwordx4: the fragment-ordered global layout IS the LDS image, a wave instruction moves one 1 KB block), three LDS
+// buffers so that chunk kc + 2 is in flight while chunk kc is multiplied, one raw s_barrier per chunk behind a counted vmcnt.
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
+template <int S>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_i8_v2(const int8_t* As, const int8_t* Bs, const int* eA,
+    const int* eB, double* C, int M, int N, int ldc, int nKc, double alpha) {
+    constexpr int kFrag = 6 * S, kPerWave = (kFrag + 7) / 8, kSlots = kPerWave * 8;  // (every wave issues the same number of copies: one vmcnt)
+    __shared__ int4 sm[3][kSlots * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv >> 1, wc = wv & 1;
+    const int ctA0 = blockIdx.y * 4, ctB0 = blockIdx.x * 2;
+    const int4* gA = reinterpret_cast<const int4*>(As);
+    const int4* gB = reinterpret_cast<const int4*>(Bs);
+    auto stage = [&](int kc, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < kPerWave; ++j) {
+            const int slot = wv + 8 * j;
+            const int blk = slot < kFrag ? slot : 0;  // (pad slots re-read block 0 into LDS nobody looks at)
+            const int4* src;
+            if (blk < 4 * S) {
+                const int ct = blk / S, t = blk - ct * S;
+                src = gA + (((size_t)(ctA0 + ct) * nKc + kc) * S + t) * 64 + lane;
+            } else {
+                const int b2 = blk - 4 * S, ct = b2 / S, t = b2 - ct * S;
+                src = gB + (((size_t)(ctB0 + ct) * nKc + kc) * S + t) * 64 + lane;
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&sm[buf][slot * 64], 16, 0, 0);
+        }
+    };
+    v16i acc[S];
+#pragma unroll
+    for (int d = 0; d < S; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] = 0;
+    stage(0, 0);
+    if (nKc > 1) stage(1, 1);
+    // chunk 0 complete (the older kPerWave of this wave's 2 kPerWave copies), then everybody's
+    if (nKc > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerWave) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kc = 0; kc < nKc; ++kc) {
+        const int buf = kc % 3;
+        if (kc + 2 < nKc) stage(kc + 2, (kc + 2) % 3);  // (that buffer was read in iteration kc - 1: the barrier at its end has been passed)
+        v4i a[S], b[S];
+#pragma unroll
+        for (int t = 0; t < S; ++t) {
+            const int4 va = sm[buf][(wr * S + t) * 64 + lane];
+            const int4 vb = sm[buf][(4 * S + wc * S + t) * 64 + lane];
+            a[t] = v4i{va.x, va.y, va.z, va.w};
+            b[t] = v4i{vb.x, vb.y, vb.z, vb.w};
+        }
+#pragma unroll
+        for (int ta = 0; ta < S; ++ta)
+#pragma unroll
+            for (int tb = 0; tb + ta < S; ++tb) acc[ta + tb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ta], b[tb], acc[ta + tb], 0, 0, 0);
+        // chunk kc + 1 must be in LDS before anybody reads it: this wave's copies of it are the older ones of what it has in flight
+        if (kc + 2 < nKc) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerWave) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    const int j = (ctB0 + wc) * 32 + (lane & 31);
+    const int ibase = (ctA0 + wr) * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = ibase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (i < M && j < N) {
+            double v = 0.0;
+#pragma unroll
+            for (int d = S - 1; d >= 0; --d) v += ldexp((double)acc[d][r], -(12 + kBits * d));
+            double* dst = C + (size_t)i * ldc + j;
+            *dst += alpha * ldexp(v, eA[i] + eB[j]);
+        }
+    }
+}
+
 // plain fp64 product for the Frobenius check (the long-double reference is on the host, sampled)
 __global__ void k_ref(const double* A, const double* B, double* C, int M, int N, int K, int lda, int ldb, int ldc) {
     const int j = blockIdx.x * 16 + (threadIdx.x & 15), i = blockIdx.y * 16 + (threadIdx.x >> 4);
@@ -213,7 +291,11 @@ void run(int M, int N, int K, int wide, int reps) {
         hipLaunchKernelGGL(k_split<S>, dim3(Mp / 32, nKc), dim3(64), 0, 0, dA, K, M, M, eA, sA, nKc);
         hipLaunchKernelGGL(k_split<S>, dim3(Np / 32, nKc), dim3(64), 0, 0, dB, K, N, N, eB, sB, nKc);
     };
-    auto gemm = [&]() { hipLaunchKernelGGL(k_gemm_i8<S>, dim3(Np / 64, Mp / 128), dim3(256), 0, 0, sA, sB, eA, eB, dC, M, N, N, nKc, 1.0); };
+    const bool v2 = std::getenv("I8_V2") && std::atoi(std::getenv("I8_V2")) != 0;
+    auto gemm = [&]() {
+        if (v2) hipLaunchKernelGGL(k_gemm_i8_v2<S>, dim3(Np / 64, Mp / 128), dim3(512), 0, 0, sA, sB, eA, eB, dC, M, N, N, nKc, 1.0);
+        else hipLaunchKernelGGL(k_gemm_i8<S>, dim3(Np / 64, Mp / 128), dim3(256), 0, 0, sA, sB, eA, eB, dC, M, N, N, nKc, 1.0);
+    };
     split();
     CK(hipMemset(dC, 0, (size_t)M * N * 8));
     gemm();
@@ -267,11 +349,11 @@ void run(int M, int N, int K, int wide, int reps) {
     msSplit /= reps;
     msGemm /= reps;
     const double flops = 2.0 * M * N * K, iops = 2.0 * Mp * Np * (nKc * 32.0) * (S * (S + 1) / 2);
-    std::printf("{\"M\": %d, \"N\": %d, \"K\": %d, \"slices\": %d, \"products\": %d, \"wide_dynamic_range\": %d, \"split_ms\": %.4f, \"gemm_ms\": %.4f, "
+    std::printf("{\"kernel\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"slices\": %d, \"products\": %d, \"wide_dynamic_range\": %d, \"split_ms\": %.4f, \"gemm_ms\": %.4f, "
                 "\"fp64_equiv_tflops_gemm_only\": %.2f, \"fp64_equiv_tflops_with_split\": %.2f, \"int8_tops\": %.1f, "
                 "\"err_vs_longdouble_componentwise\": %.3e, \"fp64_fma_chain_componentwise\": %.3e, \"err_vs_longdouble_rel_to_entry\": %.3e, "
                 "\"err_over_K_colmaxA_colmaxB\": %.3e, \"fro_diff_vs_fp64\": %.3e}\n",
-        M, N, K, S, S * (S + 1) / 2, wide, msSplit, msGemm, flops / (msGemm * 1e-3) / 1e12, flops / ((msGemm + msSplit) * 1e-3) / 1e12,
+        v2 ? "v2: 8 waves, direct-to-LDS, 3 buffers" : "v1", M, N, K, S, S * (S + 1) / 2, wide, msSplit, msGemm, flops / (msGemm * 1e-3) / 1e12, flops / ((msGemm + msSplit) * 1e-3) / 1e12,
         iops / (msGemm * 1e-3) / 1e12, worstComp, worstCompF64, worstRel, worstScale, (double)sqrtl(fe / fr));
     for (void* p : {(void*)dA, (void*)dB, (void*)dC, (void*)dR, (void*)sA, (void*)sB, (void*)eA, (void*)eB}) (void)hipFree(p);
 }

@@ -17,6 +17,51 @@ def _t(dev):
     return lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
+def test_tile_downdate_on_the_integer_pipe_against_numpy():
+    """C -= A^T B from 7-bit slices of the operands' columns on v_mfma_i32_32x32x32_i8 with exact int32 accumulation (round 6,
+    eqf_tile_downdate_i8): against numpy, with the error bound the construction gives -- every entry of an operand is truncated below
+    2^-(6 + 7 (S - 1)) of its column's largest entry, so |error_ij| <= k (ca_i cb_j) 2^-(5 + 7 (S - 1)) up to second order, ca / cb the columns'
+    largest entries -- on ragged sizes around the 128 x 64 x 32 tiling, views with leading dimensions, columns of very different scales, an
+    all-zero column, the same matrix on both sides, and the block-upper mask."""
+    import torch
+
+    from eqf_vio_amd import tiled
+
+    dev = torch.device("cuda", 0)
+    be = tiled.HipBackend({}, capacity=8)
+    t = _t(dev)
+    rng = np.random.default_rng(5)
+    for (m, n, k, S) in ((128, 64, 32, 5), (75, 130, 50, 5), (200, 96, 448, 6), (257, 513, 129, 7), (300, 300, 1000, 5)):
+        A = rng.standard_normal((k, m + 5)) * 10.0 ** rng.uniform(-3, 3, size=(1, m + 5))
+        B = rng.standard_normal((k, n + 3)) * 10.0 ** rng.uniform(-3, 3, size=(1, n + 3))
+        A[:, 4] = 0.0
+        C = rng.standard_normal((m, n + 7))
+        Ad, Bd, Cd = t(A), t(B), t(C)
+        be.downdate_i8(Cd[:, 2: 2 + n], Ad[:, 1: 1 + m], Bd[:, 3: 3 + n], S)
+        Av, Bv = A[:, 1: 1 + m], B[:, 3: 3 + n]
+        want = C.copy()
+        want[:, 2: 2 + n] -= Av.T @ Bv
+        bound = k * np.outer(np.abs(Av).max(axis=0), np.abs(Bv).max(axis=0)) * 2.0 ** -(5 + 7 * (S - 1)) * 1.01 + 1e-12 * np.abs(want[:, 2: 2 + n])
+        got = Cd.cpu().numpy()
+        assert np.array_equal(got[:, :2], C[:, :2]) and np.array_equal(got[:, 2 + n:], C[:, 2 + n:])  # nothing outside the view
+        assert (np.abs(got[:, 2: 2 + n] - want[:, 2: 2 + n]) <= bound).all(), (m, n, k, S)
+    # the same matrix on both sides + the block-upper mask of a symmetric local matrix (blocks of 96): on and above the block diagonal as
+    # above, below it whatever the tiles that were not skipped left -- eqf_tile_mirror overwrites it
+    n, k, rb, S = 384, 200, 96, 5
+    Y = rng.standard_normal((k, n))
+    C = rng.standard_normal((n, n))
+    C = C + C.T
+    Yd, Cd = t(Y), t(C)
+    be.downdate_i8(Cd, Yd, Yd, S, mask_rb=rb)
+    be.mirror_lower(Cd, rb)
+    torch.cuda.synchronize()
+    want = C - Y.T @ Y
+    bound = k * np.outer(np.abs(Y).max(axis=0), np.abs(Y).max(axis=0)) * 2.0 ** -(5 + 7 * (S - 1)) * 1.01
+    got = Cd.cpu().numpy()
+    assert (np.abs(got - want) <= bound + 1e-12).all()
+    assert np.array_equal(np.tril(got, -rb), np.tril(got.T, -rb))  # (strictly below the block diagonal: exact mirror images)
+
+
 def test_tile_gemm_tn_against_numpy():
     """C += alpha A^T B (eqf_tile_gemm_tn): ragged sizes around the 128 x 128 x 16 tiling, narrow products, views with leading
     dimensions, both signs, and the block-upper mask of a block-cyclic local matrix."""
@@ -268,6 +313,44 @@ def test_tiled_filter_N1000_against_the_structured_oracle(oracle_lib):
     fo = oracle_lib.OracleFilter(d, structured=True)
     worst, n_upd = _drive(tf, fo, None, st, 99, 1e-7)
     assert n_upd >= 3 and worst["S_oracle"] <= 1e-8, worst
+
+
+@pytest.mark.parametrize("N,bl,dur,slices,tol", [(200, 64, 2.0, 6, 1e-5), (200, 64, 1.0, 7, 1e-7), (1000, 125, 0.26, 6, 5e-5)])
+def test_downdate_on_the_integer_pipe_holds_the_tolerance(N, bl, dur, slices, tol):
+    """Round 6, north_star's "low-precision MFMA for the dense Sigma contractions, Sigma within 1e-4": the partitioned filter with its covariance
+    downdate on the integer matrix pipe (eqf_tf_set_option "downdate_slices": Y's columns cut into 7-bit slices, int8 MFMA, exact accumulation,
+    fp64 recombination) against the fp64 single-GPU product path on the bench stream, Sigma after EVERY update: SIX slices (21 integer products)
+    stay inside north_star's 1e-4 with a margin -- measured 2.2e-6 at N = 200, 1.5e-5 at N = 1000, 4.7e-6 at N = 4000, the worst frame being
+    the fifth, while the landmarks converge -- seven slices at 1e-8, FIVE do not (1.4e-4 / 9e-4: the slice pairs the kernel drops, ta + tb >= S,
+    are of the truncation's size but add up coherently over Y's correlated columns; scripts/slice_precision_study.py reproduces all three
+    figures on the CPU to three digits, profiles/r06_slice_precision_study_2s_with_pairs.txt).  Pose to 1e-6; the error flag stays clear and
+    Sigma symmetric.  (The default, 0 slices, is the fp64 downdate every other test of this file runs.)"""
+    from eqf_vio_amd import binding, synth, tiled
+
+    d = synth.template_settings_dict()
+    st = synth.make_stream(N, duration=dur)
+    be = tiled.HipBackend(d, capacity=N)
+    tf = tiled.TiledFilter(tiled.ProcessGrid(None, 1, 1, device=be.device), be, bl)
+    tf.downdate_slices = slices
+    fg = binding.FilterBatch(d, capacity=N, batch=1)
+    worst, n_upd = 0.0, 0
+    for kind, k in st.events():
+        if kind == "imu":
+            r = st.imu[k]
+            tf.processIMUData(r[0], r[1:4], r[4:7])
+            fg.process_imu([r[0]], r[1:4], r[4:7])
+        else:
+            fg.process_vision([st.vision_stamps[k]], st.ids, st.bearings[k])
+            assert tf.processVisionData(st.vision_stamps[k], st.ids, st.bearings[k]) == 0
+            S1, S0 = tf.stateCovariance(), fg.sigma()
+            worst = max(worst, float(np.linalg.norm(S1 - S0) / np.linalg.norm(S0)))
+            assert np.abs(S1 - S1.T).max() <= 1e-9 * np.abs(S1).max()
+            n_upd += 1
+    e1, e0 = tf.stateEstimate(), fg.state_estimate()
+    print(f"N={N} slices={slices}: worst Sigma rel-Frobenius difference to the fp64 path over {n_upd} updates {worst:.2e}")
+    assert n_upd >= 4 and worst <= tol, worst
+    assert worst > 1e-14  # (the integer pipe really ran: the fp64 downdate would agree to rounding)
+    assert np.abs(e1["x"] - e0["x"]).max() <= 1e-6 and np.abs(e1["q"] - e0["q"]).max() <= 1e-6 and be.device_error() == 0
 
 
 def test_tiled_filter_N4000_against_the_single_gpu_product_path():
