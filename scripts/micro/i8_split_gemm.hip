@@ -178,11 +178,23 @@ typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 template <int S>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_i8_v2(const int8_t* As, const int8_t* Bs, const int* eA,
-    const int* eB, double* C, int M, int N, int ldc, int nKc, double alpha) {
+    const int* eB, double* C, int M, int N, int ldc, int nKc, double alpha, int swz, int nx, int ny) {
     constexpr int kFrag = 6 * S, kPerWave = (kFrag + 7) / 8, kSlots = kPerWave * 8;  // (every wave issues the same number of copies: one vmcnt)
     __shared__ int4 sm[3][kSlots * 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv >> 1, wc = wv & 1;
-    const int ctA0 = blockIdx.y * 4, ctB0 = blockIdx.x * 2;
+    // tile of this workgroup.  swz = 0: (blockIdx.y, blockIdx.x).  swz = 1: a 1-D grid whose workgroup i runs on XCD i mod 8; the tiles an XCD
+    // gets are CONTIGUOUS in a blocked order (supertiles of 4 tile rows x all... see below), so that its L2 holds each A / B fragment run once
+    int ty = blockIdx.y, tx = blockIdx.x;
+    if (swz) {
+        const int T = nx * ny, id = blockIdx.x, xcd = id & 7, seq = id >> 3, q = T >> 3, r = T & 7;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + seq;
+        if (logical >= T || seq >= (xcd < r ? q + 1 : q)) return;
+        // blocked order: groups of `swz` tile rows, column-major inside a group (neighbours share B, a group shares `swz` A runs)
+        const int g = swz, per = g * nx, grp = logical / per, rem = logical - grp * per, rows = min(g, ny - grp * g);
+        ty = grp * g + rem % rows;
+        tx = rem / rows;
+    }
+    const int ctA0 = ty * 4, ctB0 = tx * 2;
     const int4* gA = reinterpret_cast<const int4*>(As);
     const int4* gB = reinterpret_cast<const int4*>(Bs);
     auto stage = [&](int kc, int buf) __attribute__((always_inline)) {
@@ -292,8 +304,11 @@ void run(int M, int N, int K, int wide, int reps) {
         hipLaunchKernelGGL(k_split<S>, dim3(Np / 32, nKc), dim3(64), 0, 0, dB, K, N, N, eB, sB, nKc);
     };
     const bool v2 = std::getenv("I8_V2") && std::atoi(std::getenv("I8_V2")) != 0;
+    const int swz = std::getenv("I8_SWZ") ? std::atoi(std::getenv("I8_SWZ")) : 0;
     auto gemm = [&]() {
-        if (v2) hipLaunchKernelGGL(k_gemm_i8_v2<S>, dim3(Np / 64, Mp / 128), dim3(512), 0, 0, sA, sB, eA, eB, dC, M, N, N, nKc, 1.0);
+        const int nx = Np / 64, ny = Mp / 128;
+        if (v2 && swz) hipLaunchKernelGGL(k_gemm_i8_v2<S>, dim3((nx * ny + 7) / 8 * 8), dim3(512), 0, 0, sA, sB, eA, eB, dC, M, N, N, nKc, 1.0, swz, nx, ny);
+        else if (v2) hipLaunchKernelGGL(k_gemm_i8_v2<S>, dim3(nx, ny), dim3(512), 0, 0, sA, sB, eA, eB, dC, M, N, N, nKc, 1.0, 0, nx, ny);
         else hipLaunchKernelGGL(k_gemm_i8<S>, dim3(Np / 64, Mp / 128), dim3(256), 0, 0, sA, sB, eA, eB, dC, M, N, N, nKc, 1.0);
     };
     split();
