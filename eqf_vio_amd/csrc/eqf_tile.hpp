@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void k_tile_trsm(const double* A, int ld, int 
 // 2 measured fp32 to fail on.  What the filter needs was measured on the bench stream with this truncation put into the fp64 restatement
 // (scripts/slice_precision_study.py, profiles/r06_slice_precision_study*.txt) and with this kernel in the filter (profiles/r06_i8_downdate_error.txt):
 // the truncation alone would allow S = 5 (5e-6), but the slice pairs the product drops (ta + tb >= S: products of the LOWER slices, of the
-// truncation's size) add up coherently over Y's correlated columns -- S = 5: 1.4e-4 .. 9e-4, misses; S = 6: 2e-6 .. 2e-5; S = 7: 1e-8 .. 8e-8.
+// truncation's size) add up coherently over Y's correlated columns -- S = 5: 1.4e-4 .. 9e-4, misses; S = 6: 2e-6 .. 6e-5; S = 7: 1e-8 .. 8e-8.
 //   k_i8_colexp   per column the exponent of its largest |entry| (frexp), as an atomicMax over row slabs (expo zeroed by the caller; stored + 2048)
 //   k_i8_split<S> the slices in MFMA FRAGMENT order: for a 32-column tile ct, a 32-row chunk kc and slice t one 1 KB block whose lane l holds
 //                 column ct * 32 + (l & 31), rows kc * 32 + 16 (l >> 5) .. + 16  -- the operand layout of v_mfma_i32_32x32x32_i8; block index

@@ -140,7 +140,7 @@ struct eqf_tf {
     int lookahead = 1, overlapChains = 1, burst = 1, checkEvery = 1, framesSinceCheck = 0, profiling = 0, graphs = 0;
     // "downdate_slices" (round 6): 0 = the downdate Sigma - Y^T Y on the fp64 matrix cores (default, parity grade); 5 / 6 / 7 = on the INTEGER
     // matrix pipe from that many 7-bit slices of Y's columns, exact accumulation (eqf_tile_downdate_i8): 34 / 41 / 48 bits of every entry
-    // relative to its column's largest -- Sigma within 1e-4 of the fp64 path from SIX slices on: measured 2e-6 .. 2e-5 at N = 200 .. 4000, five
+    // relative to its column's largest -- Sigma within 1e-4 of the fp64 path from SIX slices on: measured 2e-6 .. 6e-5 at N = 200 .. 4000, five
     // miss it (1.4e-4 .. 9e-4: profiles/r06_i8_downdate_error.txt, r06_slice_precision_study_2s_with_pairs.txt)
     int ddSlices = 0;
     void* i8Work = nullptr;

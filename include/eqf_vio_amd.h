@@ -291,7 +291,7 @@ int eqf_tiled_set_state(eqf_tiled* t, int N, const double* pose_q, const double*
  * landmark slots behind it (eqf_tiled, above) are internal.  eqf_tf_get_sigma is collective (every rank calls it).
  * Options (eqf_tf_set_option): "lookahead" (1), "overlap_chains" (1 on one rank, 0 on a grid: the interleaved chains are not validated over RCCL on a node; EQF_TILED_OVERLAP_CHAINS), "burst" (1: IMU calls queued and sent as
  * bursts), "check_every" (1), "downdate_slices" (0: the covariance downdate Sigma - Y^T Y on the fp64 matrix cores, parity grade; 5 / 6 / 7: on the INTEGER matrix pipe from
- * that many 7-bit slices of Y's columns with exact accumulation -- Sigma within 1e-4 of the fp64 path from 6 slices on (measured 2e-6 .. 2e-5), two thirds of the downdate's time;
+ * that many 7-bit slices of Y's columns with exact accumulation -- Sigma within 1e-4 of the fp64 path from 6 slices on (measured 2e-6 at N = 200 .. 6e-5 at N = 4000), two thirds of the downdate's time;
  * round 6, csrc/eqf_tile.hpp), "profiling" (0: event brackets per phase, eqf_tf_get_phases in eqf_vio_amd_debug.h), "graphs" (0: hipGraph replay of an update on a
  * one-rank grid, see eqf_tf_graph_launches in eqf_vio_amd_debug.h).
  * ================================================================================================================================ */
