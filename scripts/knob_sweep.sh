@@ -1,3 +1,7 @@
+#!/bin/bash
+# (round 6, GPU box) the launch-shape knobs that have a name (eqf_debug_option) at 3 .. 64 filters of N = 200, best of three each: are the size
+# heuristics still where the optimum is behind this round's launches?  (They are, within 1 %: profiles/r06_knob_sweep.txt.  The one that was
+# not -- the prep roles inside the update launch at 5 and 6 filters -- has no name: EQF_RES_FOLD_PREP, profiles/r06_fold_batch.txt.)
 run() { # run <label> <bench args...>
   local label=$1; shift
   best=0
