@@ -572,28 +572,35 @@ def tiled_leg(args, dist, rank, world, device):
         # Round 6: the same frames with the covariance downdate on the INTEGER matrix pipe (eqf_tf_set_option "downdate_slices" = 6: Y's columns
         # as six 7-bit slices, int8 MFMA with exact accumulation, fp64 recombination; csrc/eqf_tile.hpp) -- north_star's "low-precision MFMA for the
         # dense Sigma contractions, Sigma within 1e-4", for the one product it was built for.  Opt-in; the line's other figures are fp64.
-        try:
-            sll_ref = out.pop("_sll_ref")
-            be = tiled.HipBackend(d, capacity=N, device_index=device)
-            tf = tiled.TiledFilter(tiled.ProcessGrid(None, Pr, Pc, device=be.device), be, bl)
-            tf.check_every = 0
-            tf.downdate_slices = 6
-            tf.phase_ms = None
-            dti = timed_run(tf.processIMUData, tf.processVisionData, lambda: torch.cuda.synchronize())
-            tf.check()
-            diff = float((torch.linalg.norm(tf.Sll - sll_ref) / torch.linalg.norm(sll_ref)).item())
-            tf.phase_ms = {}
-            run(tf.processIMUData, tf.processVisionData, more)
-            tf.collect_phases()
-            out["i8_downdate"] = {"value": len(timed) / dti, "unit": "steps/s", "ms_per_frame": dti * 1e3 / max(n_vis, 1), "slices": 6, "integer_products": 21,
-                                  "vs_fp64_downdate": dt / dti, "device_error_flag": be.device_error(),
-                                  "sigma_rel_frobenius_difference_to_the_fp64_run": diff, "tolerance": 1e-4,
-                                  "phases_ms_per_frame": {k: round(v / n_vis_ph, 3) for k, v in tf.phase_ms.items()},
-                                  "note": "local blocks of Sigma after the same %d timed frames, against the fp64 run of this leg; opt-in "
-                                          "(eqf_tf_set_option \"downdate_slices\"), every other figure of the line is the fp64 path" % frames}
-            del tf, be, sll_ref
-        except Exception as e:
-            out["i8_downdate"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # "i8_chains": the trailing products of the two factorisations from FIVE slices as well ("chain_slices" = 5: they forgive more than the
+        # downdate, scripts/slice_precision_study_chain.py) -- every large product of the update on the integer pipe, the solves and factors fp64.
+        sll_ref = out.pop("_sll_ref")
+        for key, dd, chain in (("i8_downdate", 6, 0), ("i8_chains", 6, 5)):
+            try:
+                be = tiled.HipBackend(d, capacity=N, device_index=device)
+                tf = tiled.TiledFilter(tiled.ProcessGrid(None, Pr, Pc, device=be.device), be, bl)
+                tf.check_every = 0
+                tf.downdate_slices = dd
+                if chain:
+                    tf.chain_slices = chain
+                tf.phase_ms = None
+                dti = timed_run(tf.processIMUData, tf.processVisionData, lambda: torch.cuda.synchronize())
+                tf.check()
+                diff = float((torch.linalg.norm(tf.Sll - sll_ref) / torch.linalg.norm(sll_ref)).item())
+                tf.phase_ms = {}
+                run(tf.processIMUData, tf.processVisionData, more)
+                tf.collect_phases()
+                out[key] = {"value": len(timed) / dti, "unit": "steps/s", "ms_per_frame": dti * 1e3 / max(n_vis, 1), "downdate_slices": dd,
+                            "chain_slices": chain, "integer_products_per_product": {"downdate": dd * (dd + 1) // 2, "chains": chain * (chain + 1) // 2},
+                            "vs_fp64": dt / dti, "device_error_flag": be.device_error(),
+                            "sigma_rel_frobenius_difference_to_the_fp64_run": diff, "tolerance": 1e-4,
+                            "phases_ms_per_frame": {k: round(v / n_vis_ph, 3) for k, v in tf.phase_ms.items()},
+                            "note": "local blocks of Sigma after the same %d timed frames, against the fp64 run of this leg; opt-in "
+                                    "(eqf_tf_set_option \"downdate_slices\" / \"chain_slices\"), every other figure of the line is the fp64 path" % frames}
+                del tf, be
+            except Exception as e:
+                out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        del sll_ref
     out.pop("_sll_ref", None)
     if world == 1 and rank == 0:
         fb = binding.FilterBatch(d, capacity=N, batch=1, device=device)

@@ -60,7 +60,7 @@ EXPORTED_SYMBOLS = [
     "eqf_stream_upload", "eqf_stream_imu", "eqf_stream_vision", "eqf_synchronize", "eqf_get_time", "eqf_num_landmarks",
     "eqf_get_ids", "eqf_get_state_estimate", "eqf_get_origin", "eqf_get_group", "eqf_get_bias", "eqf_get_sigma",
     "eqf_set_sigma", "eqf_set_state", "eqf_set_camera_offset", "eqf_get_integrator", "eqf_get_last_update", "eqf_debug_get_blocks", "eqf_device_error", "eqf_debug_drop_role", "eqf_debug_option", "eqf_debug_launch_shape", "eqf_set_dense_propagate", "eqf_set_imu_burst", "eqf_profile_enable",
-    "eqf_profile_get", "eqf_profile_class_name", "eqf_version", "eqf_build_info", "eqf_tile_propagate", "eqf_tile_downdate", "eqf_tile_potrf", "eqf_tile_trsm", "eqf_tile_gemm_tn", "eqf_tile_mirror", "eqf_tile_downdate_i8", "eqf_tile_i8_workspace_bytes", "eqf_stream_create_masked", "eqf_stream_destroy",
+    "eqf_profile_get", "eqf_profile_class_name", "eqf_version", "eqf_build_info", "eqf_tile_propagate", "eqf_tile_downdate", "eqf_tile_potrf", "eqf_tile_trsm", "eqf_tile_gemm_tn", "eqf_tile_mirror", "eqf_tile_downdate_i8", "eqf_tile_gemm_tn_i8", "eqf_tile_i8_workspace_bytes", "eqf_stream_create_masked", "eqf_stream_destroy",
     "eqf_tiled_create", "eqf_tiled_destroy", "eqf_tiled_set_stream", "eqf_tiled_set_geometry", "eqf_tiled_propagate", "eqf_tiled_add_landmarks",
     "eqf_tiled_edit_landmarks", "eqf_tiled_propagate_burst", "eqf_tiled_stage_bearings", "eqf_tiled_pingpong",
     "eqf_tiled_update_prep", "eqf_tiled_update_finish", "eqf_tiled_synchronize", "eqf_tiled_num_landmarks", "eqf_tiled_get_time",
@@ -141,6 +141,8 @@ def lib():
             L.eqf_tile_i8_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
             L.eqf_tile_i8_workspace_bytes.restype = C.c_size_t
             L.eqf_tile_downdate_i8.argtypes = [C.c_int, vpp, vpp, C.c_int, C.c_int, C.c_int, vpp, C.c_int, vpp, C.c_int, C.c_int, C.c_int, C.c_int, vpp, C.c_size_t]
+        if hasattr(L, "eqf_tile_gemm_tn_i8"):
+            L.eqf_tile_gemm_tn_i8.argtypes = [C.c_int, vpp, vpp, C.c_int, C.c_int, C.c_int, vpp, C.c_int, vpp, C.c_int, C.c_int, C.c_int] + [C.c_int] * 9 + [vpp, C.c_size_t]
         L.eqf_stream_create_masked.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vpp)]
         L.eqf_stream_destroy.argtypes = [C.c_int, vpp]
         # the 2-D block-partitioned filter (BASELINE configs[4]); device buffers are plain pointers (torch tensors' data_ptr)

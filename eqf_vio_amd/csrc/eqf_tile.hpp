@@ -167,6 +167,12 @@ inline void gemmMakePlan(const GemmMask& mk, int tm, int tn, int n, GemmPlan* pl
     pl->before[(tm + kGemmGroup - 1) / kGemmGroup] = total;
     pl->tact = total;
 }
+// DIRECT (round 6, a build of its own): in the straight-line chunks the next chunk's operand rows go global -> LDS without passing through
+// registers (global_load_lds_dwordx4: one instruction of a wave lands one 1 KB row at that row's padded LDS address) -- no staging stores,
+// 32 registers less in flight; the wave waits for its own copies (vmcnt) in front of the chunk's barrier.
+typedef const void __attribute__((address_space(1)))* gemm_gptr_t;
+typedef void __attribute__((address_space(3)))* gemm_lptr_t;
+template <bool DIRECT>
 __global__ __launch_bounds__(256, 2) void k_tile_gemm_tn(double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k,
     double alpha, GemmMask mk, int tm, int tn, GemmPlan pl) {
     extern __shared__ __attribute__((aligned(16))) double sGemm[];  // [2][2][KC][pitch]: buffer, operand
@@ -302,16 +308,38 @@ __global__ __launch_bounds__(256, 2) void k_tile_gemm_tn(double* C, int ldc, int
     const bool whole = fullA && fullB && mu == 4 && nv == 4;
     const int nFast = whole ? max(0, k / kGemmKC - 1) : 0;
     int c = 0;
-    for (; c < nFast; ++c) {
-        fetchFull((c + 1) * kGemmKC);
+    if constexpr (DIRECT) {
+        for (; c < nFast; ++c) {
+            const int nb_ = (c + 1) & 1;  // (that buffer was read in chunk c - 1: the barrier at its end has been passed)
 #pragma unroll
-        for (int s_ = 0; s_ < kGemmKC / 4; ++s_) {
-            double av[4], bv[4];
-            operands(c & 1, s_, av, bv);
-            mfma16(av, bv, std::true_type{});
+            for (int r = 0; r < 4; ++r) {
+                const long long row = (c + 1) * kGemmKC + wv + 4 * r;
+                __builtin_amdgcn_global_load_lds((gemm_gptr_t)(A + row * lda + I0 + sc),
+                    (gemm_lptr_t)(sGemm + ((nb_ * 2 + 0) * kGemmKC + wv + 4 * r) * kGemmPitch), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gemm_gptr_t)(B + row * ldb + J0 + sc),
+                    (gemm_lptr_t)(sGemm + ((nb_ * 2 + 1) * kGemmKC + wv + 4 * r) * kGemmPitch), 16, 0, 0);
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < kGemmKC / 4; ++s_) {
+                double av[4], bv[4];
+                operands(c & 1, s_, av, bv);
+                mfma16(av, bv, std::true_type{});
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
-        stage((c + 1) & 1);
-        __syncthreads();
+    } else {
+        for (; c < nFast; ++c) {
+            fetchFull((c + 1) * kGemmKC);
+#pragma unroll
+            for (int s_ = 0; s_ < kGemmKC / 4; ++s_) {
+                double av[4], bv[4];
+                operands(c & 1, s_, av, bv);
+                mfma16(av, bv, std::true_type{});
+            }
+            stage((c + 1) & 1);
+            __syncthreads();
+        }
     }
     for (; c < nc; ++c) {
         if (c + 1 < nc) fetch((c + 1) * kGemmKC);  // in flight during this chunk's MFMAs
@@ -567,15 +595,16 @@ __global__ __launch_bounds__(256) void k_tile_trsm(const double* A, int ld, int 
 // (scripts/slice_precision_study.py, profiles/r06_slice_precision_study*.txt) and with this kernel in the filter (profiles/r06_i8_downdate_error.txt):
 // the truncation alone would allow S = 5 (5e-6), but the slice pairs the product drops (ta + tb >= S: products of the LOWER slices, of the
 // truncation's size) add up coherently over Y's correlated columns -- S = 5: 1.4e-4 .. 9e-4, misses; S = 6: 2e-6 .. 6e-5; S = 7: 1e-8 .. 8e-8.
-//   k_i8_colexp   per column the exponent of its largest |entry| (frexp), as an atomicMax over row slabs (expo zeroed by the caller; stored + 2048)
+//   k_i8_colexp   per column the exponent of its largest |entry| (frexp), as an atomicMax over row slabs (expo zeroed by k_i8_zero; stored + 2048)
 //   k_i8_split<S> the slices in MFMA FRAGMENT order: for a 32-column tile ct, a 32-row chunk kc and slice t one 1 KB block whose lane l holds
 //                 column ct * 32 + (l & 31), rows kc * 32 + 16 (l >> 5) .. + 16  -- the operand layout of v_mfma_i32_32x32x32_i8; block index
 //                 ((ct * nKc + kc) * S + t).  Rows past k and columns past m are zero.
 //   k_i8_gemm<S>  512 threads = 8 waves as 4 x 2, workgroup tile 128 (rows of C) x 64, a wave owns ONE 32 x 32 MFMA tile with S accumulators
 //                 (two waves per SIMD); a chunk's 4 S + 2 S fragment blocks go global -> LDS directly (global_load_lds_dwordx4: the global
 //                 layout IS the LDS image), three LDS buffers (chunk kc + 2 in flight while kc is multiplied), one raw s_barrier per chunk
-//                 behind a counted vmcnt.  maskRb > 0: C is a symmetric local matrix in blocks of maskRb, tiles entirely below the block
-//                 diagonal are skipped (k_tile_mirror completes them).  Epilogue: C[i][j] += alpha 2^(eA[i] + eB[j]) sum_d acc_d 2^-(12 + 7 d).
+//                 behind a counted vmcnt.  mk.rb > 0: the first maskCols columns of C are masked as in k_tile_gemm_tn (GemmMask: tiles entirely
+//                 below the block diagonal are skipped -- the downdate's symmetric local matrix, which k_tile_mirror completes, and the
+//                 factorisations' upper block rows); columns from maskCols on (right-hand sides) are always formed.  Epilogue: C[i][j] += alpha 2^(eA[i] + eB[j]) sum_d acc_d 2^-(12 + 7 d).
 // Measured (scripts/micro/i8_split_gemm.hip, profiles/r06_i8_split_gemm_v2.txt): S = 5: 84 - 108 fp64-equivalent TFLOP/s at the downdate's
 // shapes (1.3 - 1.6 POPS of int8) against 51 - 57 for k_tile_gemm_tn in the same run.
 typedef int i8v4 __attribute__((ext_vector_type(4)));
@@ -601,6 +630,11 @@ __global__ __launch_bounds__(256) void k_i8_colexp(const double* X, int K, int M
     }
 }
 
+__global__ __launch_bounds__(256) void k_i8_zero(int* p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
 template <int S>
 __global__ __launch_bounds__(256) void k_i8_split(const double* X, int K, int M, int ld, const int* expo, signed char* out, int nKc) {
     const int ct = blockIdx.x, kc = blockIdx.y * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
@@ -613,13 +647,14 @@ __global__ __launch_bounds__(256) void k_i8_split(const double* X, int K, int M,
     for (int j = 0; j < 16; ++j) {
         const int k = k0 + j;
         double r = (c < M && k < K) ? X[(long long)k * ld + c] * sc : 0.0;  // |r| < 1, exact (power-of-two scale)
-        double w = 64.0;                                                   // 2^6, then 2^13, 2^20, ...
+        double w = 64.0, wi = 0.015625;                                    // 2^6, then 2^13, 2^20, ...
 #pragma unroll
         for (int t = 0; t < S; ++t) {
             const double qq = rint(r * w);  // |qq| <= 64
-            q[t][j] = (signed char)qq;
-            r -= qq / w;  // exact
+            q[t][j] = (signed char)(int)qq;
+            r = fma(-qq, wi, r);  // exact (wi = 1 / w, a power of two)
             w *= 128.0;
+            wi *= 0.0078125;
         }
     }
 #pragma unroll
@@ -637,12 +672,16 @@ typedef const void __attribute__((address_space(1)))* i8gptr_t;
 typedef void __attribute__((address_space(3)))* i8lptr_t;
 template <int S>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_i8_gemm(const signed char* As, const signed char* Bs,
-    const int* eA, const int* eB, double* C, int M, int N, int ldc, int nKc, double alpha, int maskRb) {
+    const int* eA, const int* eB, double* C, int M, int N, int ldc, int nKc, double alpha, GemmMask mk, int maskCols) {
     constexpr int kFrag = 6 * S, kPerWave = (kFrag + 7) / 8, kSlots = kPerWave * 8;  // (every wave issues the same number of copies: one vmcnt)
     __shared__ int4 sm[3][kSlots * 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv >> 1, wc = wv & 1;
     const int ctA0 = blockIdx.y * 4, ctB0 = blockIdx.x * 2;
-    if (maskRb > 0 && (ctA0 * 32) / maskRb > (ctB0 * 32 + 63) / maskRb) return;  // (uniform) entirely below the block diagonal
+    if (mk.rb > 0 && ctB0 * 32 + 63 < maskCols) {  // (uniform) a tile inside the masked columns, entirely below the block diagonal: nobody reads it
+        const int Ilo = (mk.rblk0 + (ctA0 * 32) / mk.rb) * mk.Pr + mk.pr;
+        const int Jhi = (mk.cblk0 + (ctB0 * 32 + 63) / mk.cb) * mk.Pc + mk.pc;
+        if (Ilo > Jhi) return;
+    }
     const int4* gA = reinterpret_cast<const int4*>(As);
     const int4* gB = reinterpret_cast<const int4*>(Bs);
     auto stage = [&](int kc, int buf) __attribute__((always_inline)) {

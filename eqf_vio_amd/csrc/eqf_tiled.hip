@@ -8,7 +8,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -51,7 +53,8 @@ int tileAttributes(int device) {
     if (done[device]) return EQF_OK;
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_potrf), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(Step64Lds))));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_gemm_tn), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLdsBytes));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_gemm_tn<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLdsBytes));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_gemm_tn<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLdsBytes));
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_potrf_trail), hipFuncAttributeMaxDynamicSharedMemorySize, kTrailLdsBytes));
     done[device] = 1;
     return EQF_OK;
@@ -757,6 +760,41 @@ int eqf_tiled_set_state(eqf_tiled* t, int N, const double* pose_q, const double*
 }
 
 // ---- streams restricted to a set of CUs ---------------------------------------------------------------------------------
+// A CU-masked stream is a hardware queue of its own, and the queues of destroyed streams were measured NOT to come back (round 6: the
+// seventh partitioned filter created and destroyed in one process ran at 114 ms a frame instead of 65 -- seven streams a handle, the
+// queues oversubscribed).  So a masked stream that is handed back is kept, per device and mask, and the next request for that mask gets
+// it: a process that creates and destroys handles for hours holds as many queues as its live handles ever needed at once.
+extern "C++" {
+namespace {
+struct MaskedPool {
+    std::mutex mu;
+    std::map<std::pair<int, std::vector<uint32_t>>, std::vector<hipStream_t>> idle;
+    std::map<hipStream_t, std::pair<int, std::vector<uint32_t>>> made;
+};
+MaskedPool& maskedPool();
+// at process exit, before the runtime's own teardown (registered after it was initialised, so run before it): the kept streams go.  (Left alive
+// they crashed rocprofv3's finaliser at exit -- rc 139 after the trace had been written.)
+void drainMaskedPool() {
+    MaskedPool& pool = maskedPool();
+    std::lock_guard<std::mutex> lk(pool.mu);
+    for (auto& kv : pool.idle)
+        for (hipStream_t st : kv.second) {
+            pool.made.erase(st);
+            (void)hipStreamDestroy(st);
+        }
+    pool.idle.clear();
+}
+MaskedPool& maskedPool() {
+    // (the pool object itself is never destroyed: handles may be closed from destructors that run at process exit)
+    static MaskedPool* p = [] {
+        MaskedPool* q = new MaskedPool;
+        std::atexit(drainMaskedPool);
+        return q;
+    }();
+    return *p;
+}
+}  // namespace
+}  // extern "C++"
 int eqf_stream_create_masked(int device, int first_cu, int num_cus, int complement, void** out) {
     if (!out || first_cu < 0 || num_cus < 1) return EQF_ERR_INVALID;
     int ndev = 0;
@@ -772,16 +810,37 @@ int eqf_stream_create_masked(int device, int first_cu, int num_cus, int compleme
         const bool in = c >= first_cu && c < first_cu + num_cus;
         if (in != (complement != 0)) mask[c / 32] |= 1u << (c % 32);
     }
+    MaskedPool& pool = maskedPool();
+    const auto key = std::make_pair(device, mask);
+    std::lock_guard<std::mutex> lk(pool.mu);
+    auto it = pool.idle.find(key);
+    if (it != pool.idle.end() && !it->second.empty()) {
+        *out = it->second.back();
+        it->second.pop_back();
+        return EQF_OK;
+    }
     hipStream_t st = nullptr;
     HIPC(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    pool.made[st] = key;
     *out = st;
     return EQF_OK;
 }
 int eqf_stream_destroy(int device, void* stream) {
     if (!stream) return EQF_OK;
     DeviceScope ds(device);
-    HIPC(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-    HIPC(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPC(hipStreamSynchronize(st));
+    MaskedPool& pool = maskedPool();
+    static const bool keep = !(std::getenv("EQF_STREAM_POOL") && std::atoi(std::getenv("EQF_STREAM_POOL")) == 0);  // (EQF_STREAM_POOL=0: destroy)
+    if (keep) {
+        std::lock_guard<std::mutex> lk(pool.mu);
+        auto it = pool.made.find(st);
+        if (it != pool.made.end()) {  // (idle, in order: whatever was queued on it has finished)
+            pool.idle[it->second].push_back(st);
+            return EQF_OK;
+        }
+    }
+    HIPC(hipStreamDestroy(st));
     return EQF_OK;
 }
 
@@ -801,8 +860,15 @@ int eqf_tile_gemm_tn(int device, void* stream, double* C, int ldc, int m, int n,
     if (mask_rb > 0 && tm <= kGemmPlanRows && pl.tact == 0) return EQF_OK;  // the mask leaves nothing
     const long long T = pl.tact > 0 ? pl.tact : (long long)tm * tn;
     const int grid = int(8 * ((T + 7) / 8));
-    hipLaunchKernelGGL(k_tile_gemm_tn, dim3(grid), dim3(256), kGemmLdsBytes, static_cast<hipStream_t>(stream), C, ldc, m, n, A, lda, B, ldb, k, alpha, mk, tm,
-        tn, pl);
+    // the DIRECT build (operand rows global -> LDS without a register stop) unless EQF_GEMM_DIRECT=0: same arithmetic in the same order, bitwise
+    // the same C; 55.4 -> 57.6 / 58.3 -> 60.3 / 51.8 -> 59.1 TFLOP/s at the update's shapes, cfg 5 64.6 -> 63.3 ms a frame (profiles/r06_gemm_direct.txt)
+    static const bool direct = !(std::getenv("EQF_GEMM_DIRECT") && std::atoi(std::getenv("EQF_GEMM_DIRECT")) == 0);
+    if (direct)
+        hipLaunchKernelGGL(k_tile_gemm_tn<true>, dim3(grid), dim3(256), kGemmLdsBytes, static_cast<hipStream_t>(stream), C, ldc, m, n, A, lda, B, ldb, k, alpha,
+            mk, tm, tn, pl);
+    else
+        hipLaunchKernelGGL(k_tile_gemm_tn<false>, dim3(grid), dim3(256), kGemmLdsBytes, static_cast<hipStream_t>(stream), C, ldc, m, n, A, lda, B, ldb, k, alpha,
+            mk, tm, tn, pl);
     HIPC(hipGetLastError());
     return EQF_OK;
 }
@@ -820,42 +886,45 @@ int eqf_tile_downdate(int device, void* stream, double* C, int ldc, int m, int n
     return eqf_tile_gemm_tn(device, stream, C, ldc, m, n, A, lda, B, ldb, k, -1.0, 0, 0, 0, 1, 0, 0, 1, 0);
 }
 
-// ---- the downdate's product on the integer matrix pipe (csrc/eqf_tile.hpp: k_i8_colexp / k_i8_split / k_i8_gemm)
+// ---- products on the integer matrix pipe (csrc/eqf_tile.hpp: k_i8_colexp / k_i8_split / k_i8_gemm): the downdate, the factorisations' trailing updates
 extern "C++" {
 namespace {
+// aOff >= 0: A is the columns [aOff, aOff + m) of B (aOff a multiple of 32): one split serves both sides, A's tiles are B's from tile aOff / 32 on
 struct I8Plan {
-    int mp, np, nKc;
+    int mp, np, ntB, nKc;
     size_t sliceA, sliceB, offB, offEA, offEB, total;
 };
-I8Plan i8Plan(int m, int n, int k, int slices, int same) {
+I8Plan i8Plan(int m, int n, int k, int slices, int aOff) {
     I8Plan p;
-    p.mp = (m + 127) / 128 * 128;                       // rows of C: 128 per workgroup
-    p.np = same ? p.mp : (n + 63) / 64 * 64;            // columns of C: 64 per workgroup (the same operand: one split serves both sides)
+    p.mp = (m + 127) / 128 * 128;  // rows of C: 128 per workgroup
+    p.np = (n + 63) / 64 * 64;     // columns of C: 64 per workgroup
+    p.ntB = aOff >= 0 ? std::max(p.np, aOff + p.mp) : p.np;  // columns of B that are cut (past n: zero)
     p.nKc = (k + 31) / 32;
-    p.sliceA = (size_t)(p.mp / 32) * p.nKc * slices * 1024;
-    p.sliceB = same ? 0 : (size_t)(p.np / 32) * p.nKc * slices * 1024;
+    p.sliceA = aOff >= 0 ? 0 : (size_t)(p.mp / 32) * p.nKc * slices * 1024;
+    p.sliceB = (size_t)(p.ntB / 32) * p.nKc * slices * 1024;
     p.offB = p.sliceA;
     p.offEA = p.sliceA + p.sliceB;
-    p.offEB = p.offEA + sizeof(int) * (size_t)p.mp;
-    p.total = p.offEB + (same ? 0 : sizeof(int) * (size_t)p.np);
+    p.offEB = p.offEA + (aOff >= 0 ? 0 : sizeof(int) * (size_t)p.mp);
+    p.total = p.offEB + sizeof(int) * (size_t)p.ntB;
     return p;
 }
 template <int S>
-int i8Downdate(hipStream_t st, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k, int maskRb, bool same,
-    char* ws, const I8Plan& p) {
-    signed char* sA = reinterpret_cast<signed char*>(ws);
-    signed char* sB = same ? sA : reinterpret_cast<signed char*>(ws + p.offB);
-    int* eA = reinterpret_cast<int*>(ws + p.offEA);
-    int* eB = same ? eA : reinterpret_cast<int*>(ws + p.offEB);
-    HIPC(hipMemsetAsync(eA, 0, p.total - p.offEA, st));
-    const dim3 kslabs(1, (k + 511) / 512);
-    hipLaunchKernelGGL(k_i8_colexp, dim3((m + 63) / 64, kslabs.y), dim3(256), 0, st, A, k, m, lda, eA);
-    hipLaunchKernelGGL(k_i8_split<S>, dim3(p.mp / 32, (p.nKc + 3) / 4), dim3(256), 0, st, A, k, m, lda, eA, sA, p.nKc);
-    if (!same) {
-        hipLaunchKernelGGL(k_i8_colexp, dim3((n + 63) / 64, kslabs.y), dim3(256), 0, st, B, k, n, ldb, eB);
-        hipLaunchKernelGGL(k_i8_split<S>, dim3(p.np / 32, (p.nKc + 3) / 4), dim3(256), 0, st, B, k, n, ldb, eB, sB, p.nKc);
+int i8Product(hipStream_t st, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k, const GemmMask& mk,
+    int maskCols, int aOff, char* ws, const I8Plan& p) {
+    signed char* sB = reinterpret_cast<signed char*>(ws + p.offB);
+    int* eB = reinterpret_cast<int*>(ws + p.offEB);
+    signed char* sA = aOff >= 0 ? sB + (size_t)(aOff / 32) * p.nKc * S * 1024 : reinterpret_cast<signed char*>(ws);
+    int* eA = aOff >= 0 ? eB + aOff : reinterpret_cast<int*>(ws + p.offEA);
+    const int nExp = (int)((p.total - p.offEA) / sizeof(int));  // (a kernel, not hipMemsetAsync: 32 of these per update on CU-masked streams)
+    hipLaunchKernelGGL(k_i8_zero, dim3((nExp + 255) / 256), dim3(256), 0, st, reinterpret_cast<int*>(ws + p.offEA), nExp);
+    const int kslabs = (k + 511) / 512;
+    if (aOff < 0) {
+        hipLaunchKernelGGL(k_i8_colexp, dim3((m + 63) / 64, kslabs), dim3(256), 0, st, A, k, m, lda, eA);
+        hipLaunchKernelGGL(k_i8_split<S>, dim3(p.mp / 32, (p.nKc + 3) / 4), dim3(256), 0, st, A, k, m, lda, eA, sA, p.nKc);
     }
-    hipLaunchKernelGGL(k_i8_gemm<S>, dim3(p.np / 64, p.mp / 128), dim3(512), 0, st, sA, sB, eA, eB, C, m, n, ldc, p.nKc, -1.0, maskRb);
+    hipLaunchKernelGGL(k_i8_colexp, dim3((n + 63) / 64, kslabs), dim3(256), 0, st, B, k, n, ldb, eB);
+    hipLaunchKernelGGL(k_i8_split<S>, dim3(p.ntB / 32, (p.nKc + 3) / 4), dim3(256), 0, st, B, k, n, ldb, eB, sB, p.nKc);
+    hipLaunchKernelGGL(k_i8_gemm<S>, dim3(p.np / 64, p.mp / 128), dim3(512), 0, st, sA, sB, eA, eB, C, m, n, ldc, p.nKc, -1.0, mk, maskCols);
     HIPC(hipGetLastError());
     return EQF_OK;
 }
@@ -864,24 +933,39 @@ int i8Downdate(hipStream_t st, double* C, int ldc, int m, int n, const double* A
 
 size_t eqf_tile_i8_workspace_bytes(int m, int n, int k, int slices, int same_operand) {
     if (m < 1 || n < 1 || k < 1 || slices < 5 || slices > 7) return 0;
-    return i8Plan(m, n, k, slices, same_operand ? 1 : 0).total;
+    return i8Plan(m, n, k, slices, same_operand && m == n ? 0 : -1).total;
 }
 
-int eqf_tile_downdate_i8(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k,
-    int slices, int mask_rb, void* workspace, size_t workspace_bytes) {
-    if (!C || !A || !B || !workspace || m < 1 || n < 1 || k < 1 || k > 70000 || ldc < n || lda < m || ldb < n || mask_rb < 0) return EQF_ERR_INVALID;
+int eqf_tile_gemm_tn_i8(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k,
+    int slices, int mask_rb, int mask_cb, int rblk0, int Pr, int pr, int cblk0, int Pc, int pc, int mask_cols, void* workspace,
+    size_t workspace_bytes) {
+    if (!C || !A || !B || !workspace || m < 1 || n < 1 || k < 1 || k > 70000 || ldc < n || lda < m || ldb < n) return EQF_ERR_INVALID;
     if (slices < 5 || slices > 7) return EQF_ERR_INVALID;
-    const bool same = A == B && m == n && lda == ldb;
-    if (mask_rb > 0 && m != n) return EQF_ERR_INVALID;
-    const I8Plan p = i8Plan(m, n, k, slices, same ? 1 : 0);
+    if (mask_rb < 0 || mask_cb < 0 || (mask_rb > 0) != (mask_cb > 0) || (mask_rb > 0 && (Pr < 1 || Pc < 1 || mask_cols < 0 || mask_cols > n)))
+        return EQF_ERR_INVALID;
+    // A inside B (the same rows of memory, a column offset that keeps the 32-column tiles aligned): cut once
+    int aOff = -1;
+    if (lda == ldb && A >= B && A - B < ldb) {
+        const long long off = A - B;
+        if (off % 32 == 0 && off + m <= n) aOff = (int)off;
+    }
+    const I8Plan p = i8Plan(m, n, k, slices, aOff);
     if (workspace_bytes < p.total) return EQF_ERR_INVALID;
     DeviceScope ds(device);
     if (!ds.ok) return EQF_ERR_HIP;
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(workspace);
-    if (slices == 5) return i8Downdate<5>(st, C, ldc, m, n, A, lda, B, ldb, k, mask_rb, same, ws, p);
-    if (slices == 6) return i8Downdate<6>(st, C, ldc, m, n, A, lda, B, ldb, k, mask_rb, same, ws, p);
-    return i8Downdate<7>(st, C, ldc, m, n, A, lda, B, ldb, k, mask_rb, same, ws, p);
+    const GemmMask mk{mask_rb, mask_cb, rblk0, Pr, pr, cblk0, Pc, pc};
+    if (slices == 5) return i8Product<5>(st, C, ldc, m, n, A, lda, B, ldb, k, mk, mask_cols, aOff, ws, p);
+    if (slices == 6) return i8Product<6>(st, C, ldc, m, n, A, lda, B, ldb, k, mk, mask_cols, aOff, ws, p);
+    return i8Product<7>(st, C, ldc, m, n, A, lda, B, ldb, k, mk, mask_cols, aOff, ws, p);
+}
+
+int eqf_tile_downdate_i8(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k,
+    int slices, int mask_rb, void* workspace, size_t workspace_bytes) {
+    if (mask_rb < 0 || (mask_rb > 0 && m != n)) return EQF_ERR_INVALID;
+    return eqf_tile_gemm_tn_i8(device, stream, C, ldc, m, n, A, lda, B, ldb, k, slices, mask_rb, mask_rb, 0, 1, 0, 0, 1, 0, mask_rb > 0 ? n : 0,
+        workspace, workspace_bytes);
 }
 
 int eqf_tile_propagate(int device, void* stream, double* out, const double* in, int ld, int nI, int nJ, const double* D_I,

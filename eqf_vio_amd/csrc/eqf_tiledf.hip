@@ -65,6 +65,11 @@ __global__ __launch_bounds__(256) void k_tf_transpose(double* out, int ldo, cons
     for (int i = ty; i < 32; i += 8)
         if (c0 + i < cols && r0 + tx < rows) out[(long long)(c0 + i) * ldo + r0 + tx] = tile[tx][i];
 }
+// out (n x n, leading dimension ld) <- I: the right-hand side of a diagonal factor's inverse (invertFactor)
+__global__ void k_tf_eye(double* out, int ld, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n * n) out[(long long)(i / n) * ld + i % n] = (i / n == i % n) ? 1.0 : 0.0;
+}
 __global__ void k_tf_add(double* out, const double* a, const double* b, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] + b[i];
@@ -145,6 +150,26 @@ struct eqf_tf {
     int ddSlices = 0;
     void* i8Work = nullptr;
     size_t i8WorkBytes = 0;
+    // "chain_slices" (round 6): the same for the trailing products of the two factorisations (every block row's U_k^T U_k and U_k^T Y_k; the
+    // diagonal blocks' look-ahead products, the solves and the factors stay fp64).  A factorisation forgives more than the downdate -- the
+    // products are subtracted from S and Sigma_e, not from Sigma, and K = Sigma C^T S^-1 averages the error over 2 N rows: FIVE slices keep Sigma
+    // to 1e-8 and the pose to 3e-9 of the fp64 path over the bench stream (scripts/slice_precision_study_chain.py,
+    // profiles/r06_slice_precision_study_chain.txt).  One workspace per factorisation (they run next to each other).
+    int trsmLeaf = 0;  // > 0: block-row solves split recursively down to this many 64-row blocks (0: one split); see trsmLeft
+    // "downdate_early" (round 6; percent, with overlapping chains and the fp64 downdate): the downdate Sigma -= Y^T Y is a sum over the S-chain's
+    // block rows, and block row k's share Y_k^T Y_k can be subtracted as soon as that block row is solved.  The S-chain's stream carries the
+    // S-chain AND the downdate (39 + 22 ms at N = 4000), the E-chain's stream 41 ms: the shares of the first `downdate_early` percent of the
+    // block rows are issued on the E-chain's stream, one block row behind the S-chain, the rest stays one product behind the S-chain.
+    int ddEarly = 0;
+    // "solve_inverse" (round 6): a block row's solve R <- L_kk^-1 R as ONE product with the explicit inverse of the diagonal factor.  The strip
+    // solves of eqf_tile_trsm are latency chains that hold a CU each -- 29 ms of kernel time per update at N = 4000 for 0.12 TFLOP, at 4 TFLOP/s,
+    // on CUs the other factorisation's products then do not get; the product costs twice the flops at 55.  L_kk^-T comes from the same strip
+    // kernel on an identity right-hand side (bk / 64 workgroups), behind the factor: for the look-ahead blocks on the reserved CUs, in the
+    // shadow of the previous block row's products.  bk <= 750: the inverse of a Cholesky factor block, error ~ cond(L_kk) eps.
+    int solveInverse = 0;
+    int chainSlices = 0;
+    void* chainWork[2] = {nullptr, nullptr};
+    size_t chainWorkBytes[2] = {0, 0};
     // one rank: the launch sequence of an update is fixed for a given number of slots and buffer parity -- it CAN be captured once as a hipGraph
     // (the second update of that shape: the first allocates its scratch operands) and replayed: one hipGraphLaunch instead of ~2000 launches.
     // OFF by default (option "graphs" / EQF_TILED_GRAPHS=1): measured on the MI355X with ROCm 7.2 (profiles/r05_tiled_host_loop.txt) the
@@ -163,6 +188,7 @@ struct eqf_tf {
     ChainBufs bufS, bufE;
     std::vector<int> wmaxS, wmaxE;
     std::map<std::tuple<int, int, hipStream_t>, double*> l21t;
+    std::vector<hipEvent_t> yReady;  // per block row of the S-chain: Y_k has been copied into the downdate's operands (this update)
     std::map<std::pair<int, int>, std::vector<double*>> padBufs;  // (rows, cols) -> buffers of the small gathers
     std::vector<double*> allocs;
     // landmark bookkeeping (host; identical on every rank): ids in the REFERENCE's order (VIOFilter.cpp:211-230), the slot of each
@@ -298,29 +324,54 @@ int gemmTn(eqf_tf* f, View C, View A, View B, double alpha, const int* mask = nu
     const int* m = mask ? mask : none;
     return eqf_tile_gemm_tn(f->device, f->cur, C.p, C.ld, C.r, C.c, A.p, A.ld, B.p, B.ld, A.r, alpha, m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
 }
+// Tt (n x n) <- L^-T on the current stream: I L^-T by the strip kernel (a workgroup per 64 rows); see solveInverse
+int invertFactor(eqf_tf* f, View L, const double* drec, View Tt) {
+    const int n = L.r;
+    hipLaunchKernelGGL(k_tf_eye, dim3((n * n + 255) / 256), dim3(256), 0, f->cur, Tt.p, Tt.ld, n);
+    return eqf_tile_trsm(f->device, f->cur, L.p, L.ld, n, drec, Tt.p, Tt.ld, n, 1);
+}
 int trsmLaunch(eqf_tf* f, View L, const double* drec, View B) {
     if (B.empty()) return EQF_OK;
     return eqf_tile_trsm(f->device, f->cur, L.p, L.ld, L.r, drec, B.p, B.ld, B.c, 0);
 }
 // B (n x m) <- L^-1 B.  eqf_tile_trsm is one workgroup per 64-column strip, and a strip is a CHAIN of nb (nb + 1) / 2 block products: its
-// time is that chain's latency whatever the width.  So from kTrsmSplit block rows on the solve is split once, [L11 0; L21 L22]:
-// X1 = L11^-1 B1, B2 -= L21 X1 as ONE product on the whole chip (L21 transposed into a scratch operand), X2 = L22^-1 B2.
+// time is that chain's latency whatever the width (at N = 4000: 29 ms of kernel time per update, 4 TFLOP/s).  So from kTrsmSplit block rows
+// on the solve is split once, [L11 0; L21 L22]: X1 = L11^-1 B1, B2 -= L21 X1 as ONE product on the whole chip (L21 transposed into a
+// scratch operand), X2 = L22^-1 B2.  Option "trsm_leaf" > 0 (round 6) splits RECURSIVELY down to that many 64-row blocks (the factor
+// transposed once per block row, every L21^T a view of it): measured at N = 4000 it LOSES -- leaf 1 / 2 / 3: 67.3 / 67.4 / 66.2 ms a frame
+// against 64.8 (profiles/r06_chain_slices_probe.txt): the leaves' 64 x 64 solves are themselves latency chains and the products of a
+// split are short (K = 64 .. 256), while the two factorisations running side by side already fill each other's gaps.  Left as an option.
+int trsmSplit(eqf_tf* f, View L, View Lt, const double* drec, View B, int leaf) {
+    const int n = L.r, nb = (n + 63) / 64;
+    if (nb <= leaf) return trsmLaunch(f, L, drec, B);
+    const int h = 64 * (nb / 2);
+    RC(trsmSplit(f, L.sub(0, h, 0, h), Lt.sub(0, h, 0, h), drec, B.rows(0, h), leaf));
+    RC(gemmTn(f, B.rows(h, n), Lt.sub(0, h, h, n), B.rows(0, h), -1.0));
+    return trsmSplit(f, L.sub(h, n, h, n), Lt.sub(h, n, h, n), drec + (size_t)(h / 64) * kDRec, B.rows(h, n), leaf);
+}
 int trsmLeft(eqf_tf* f, View L, double* drec, View B) {
     const int n = L.r, nb = (n + 63) / 64;
-    if (nb < kTrsmSplit || B.c < 256) return trsmLaunch(f, L, drec, B);
+    if (B.empty()) return EQF_OK;
+    if (B.c < 256 || (f->trsmLeaf > 0 ? nb <= f->trsmLeaf : nb < kTrsmSplit)) return trsmLaunch(f, L, drec, B);
+    const bool once = f->trsmLeaf <= 0;  // (round 5's shape: one split)
     const int h = 64 * (nb / 2);
-    RC(trsmLaunch(f, L.sub(0, h, 0, h), drec, B.rows(0, h)));
-    const auto key = std::make_tuple(n - h, h, f->cur);  // (one scratch operand per shape AND stream: the two chains solve side by side)
+    const auto key = once ? std::make_tuple(n - h, h, f->cur) : std::make_tuple(n, n, f->cur);
     auto it = f->l21t.find(key);
     if (it == f->l21t.end()) {
         double* p = nullptr;
-        RC(dalloc(f, &p, (size_t)h * (n - h), false));
+        RC(dalloc(f, &p, once ? (size_t)h * (n - h) : (size_t)n * n, false));
         it = f->l21t.emplace(key, p).first;
     }
-    const View lt = flat(it->second, h, n - h);
-    hipLaunchKernelGGL(k_tf_transpose, dim3((h + 31) / 32, (n - h + 31) / 32), dim3(256), 0, f->cur, lt.p, lt.ld, L.p + (long long)h * L.ld, L.ld, n - h, h);
-    RC(gemmTn(f, B.rows(h, n), lt, B.rows(0, h), -1.0));
-    return trsmLaunch(f, L.sub(h, n, h, n), drec + (size_t)(h / 64) * kDRec, B.rows(h, n));
+    if (once) {
+        RC(trsmLaunch(f, L.sub(0, h, 0, h), drec, B.rows(0, h)));
+        const View lt = flat(it->second, h, n - h);
+        hipLaunchKernelGGL(k_tf_transpose, dim3((h + 31) / 32, (n - h + 31) / 32), dim3(256), 0, f->cur, lt.p, lt.ld, L.p + (long long)h * L.ld, L.ld, n - h, h);
+        RC(gemmTn(f, B.rows(h, n), lt, B.rows(0, h), -1.0));
+        return trsmLaunch(f, L.sub(h, n, h, n), drec + (size_t)(h / 64) * kDRec, B.rows(h, n));
+    }
+    const View Lt = flat(it->second, n, n);
+    hipLaunchKernelGGL(k_tf_transpose, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, f->cur, Lt.p, Lt.ld, L.p, L.ld, n, n);
+    return trsmSplit(f, L, Lt, drec, B, f->trsmLeaf);
 }
 
 // ---- storage
@@ -346,7 +397,8 @@ int allocStorage(eqf_tf* f) {
                 const int w = chain ? 3 * full.ncolsOf(c) + kNarrowE : 5 * full.ncolsOf(c) + kNarrowS;
                 RC(dalloc(f, &cb.buf[q][c], (size_t)bsmax * w, false));
             }
-            RC(dalloc(f, &cb.pack[q], (size_t)bsmax * bsmax + (size_t)((bsmax + 63) / 64) * kDRec, false));
+            // [L_kk | its diagonal records | L_kk^-T (option "solve_inverse")]
+            RC(dalloc(f, &cb.pack[q], 2 * (size_t)bsmax * bsmax + (size_t)((bsmax + 63) / 64) * kDRec, false));
             RC(dalloc(f, &cb.aopA[q], (size_t)bsmax * std::max(3 * full.nlr, 1), false));
         }
     }
@@ -471,6 +523,7 @@ struct Chain {
                 double* pack = bufs->pack[q];
                 const View Lkk = flat(pack, bk, bk);
                 double* drec = pack + (size_t)bk * bk;
+                const View Tt = flat(drec + nrec, bk, bk);  // L_kk^-T ("solve_inverse")
                 if (pc == pck) {
                     if (ahead) {
                         wait(f, ahead);
@@ -478,13 +531,19 @@ struct Chain {
                     } else {
                         RC(copy2d(f, Lkk, X.sub(klr * bsF, klr * bsF + bk, klc * bsF, klc * bsF + bk)));
                         RC(potrf(f, Lkk, drec));
+                        if (f->solveInverse) RC(invertFactor(f, Lkk, drec, Tt));
                     }
                 }
-                RC(bcast(f, 0, chainId, pck, pack, (size_t)bk * bk + nrec));
+                RC(bcast(f, 0, chainId, pck, pack, (f->solveInverse ? 2 : 1) * (size_t)bk * bk + nrec));
                 // 2. my piece of block row k
                 const View R = X.sub(klr * bsF, klr * bsF + bk, c0, W);
-                RC(trsmLeft(f, Lkk, drec, R));
-                RC(copy2d(f, Bop, R));
+                if (f->solveInverse) {
+                    RC(zero2d(f, Bop));
+                    RC(gemmTn(f, Bop, Tt, R, 1.0));  // Bop = (L_kk^-T)^T R
+                } else {
+                    RC(trsmLeft(f, Lkk, drec, R));
+                    RC(copy2d(f, Bop, R));
+                }
             }
             // 3. down the process column
             RC(bcast(f, 1, chainId, prk, Bop.p, (size_t)bk * width));
@@ -520,13 +579,33 @@ struct Chain {
                     wait(f, ready);
                     RC(gemmTn(f, L1, Ua.cols(0, b1), Bop.cols(0, b1), -1.0));
                     RC(potrf(f, L1, drec1));
+                    if (f->solveInverse) RC(invertFactor(f, L1, drec1, flat(drec1 + (size_t)((b1 + 63) / 64) * kDRec, b1, b1)));
                     ahead = record(f);
                 }
             }
             // the rows of block k + 1 first (when they are mine and somebody is waiting for them), then the rest: the same products on the same
             // elements in two launches instead of one
-            const int split = (f->panelAhead && ownNextRow) ? std::min(unit * geo.blockSize(k + 1), X.r - il0 * bsF) : 0;
-            for (int part = 0; part < 2; ++part) {
+            const int split = (f->panelAhead && ownNextRow && !f->chainSlices) ? std::min(unit * geo.blockSize(k + 1), X.r - il0 * bsF) : 0;
+            if (f->chainSlices > 0) {
+                // (the integer pipe: matrix part and right-hand sides in ONE product -- the operands are cut once per block row; Ua is a view of
+                // Bop on a grid with Pc == Pr, then one split serves both sides)
+                const int m = X.r - il0 * bsF;
+                const size_t need = eqf_tile_i8_workspace_bytes(m, width, bk, f->chainSlices, 0);
+                if (need > f->chainWorkBytes[chainId]) {
+                    HIPC(hipStreamSynchronize(f->cur));
+                    if (f->chainWork[chainId]) (void)hipFree(f->chainWork[chainId]);
+                    f->chainWork[chainId] = nullptr;
+                    f->chainWorkBytes[chainId] = 0;
+                    HIPC(hipMalloc(&f->chainWork[chainId], need));
+                    f->chainWorkBytes[chainId] = need;
+                }
+                const int mcols = std::max(nA - c0, 0);
+                RC(eqf_tile_gemm_tn_i8(f->device, f->cur, X.p + (size_t)(il0 * bsF) * X.ld + c0, X.ld, m, width, Ua.p, Ua.ld, Bop.p, Bop.ld, bk,
+                    f->chainSlices, mcols > 0 ? bsF : 0, mcols > 0 ? bsF : 0, il0, Pr, pr, jl0, Pc, pc, mcols, f->chainWork[chainId],
+                    f->chainWorkBytes[chainId]));
+                if (f->panelAhead) rowReady = record(f);
+            }
+            for (int part = 0; part < 2 && !f->chainSlices; ++part) {
                 const int r0 = il0 * bsF + (part ? split : 0), r1 = part ? X.r : il0 * bsF + split;
                 if (r1 > r0) {
                     const View Ct = X.sub(r0, r1, c0, W), Up = Ua.cols(r0 - il0 * bsF, r1 - il0 * bsF);
@@ -785,6 +864,7 @@ int enqueueUpdate(eqf_tf* f) {
             RC(rowsOperand(f, con, 3, [&g](int c, int wc) { return std::make_pair(wc - 3 * g.ncolsOf(c) - kNarrowS, 0); }, bk, f->aopW.p, true, 0, &YI));
             if (!YI.empty()) RC(copy2d(f, f->Yr.rows(r0, r0 + bk), YI));
         }
+        if (k < (int)f->yReady.size()) f->yReady[k] = record(f);  // (Y_k is in place: its share of the downdate may start)
         return gemmTn(f, f->accS, Yn, Bop.cols(off, Bop.c), 1.0);  // [Sigma_b's downdate ; gamma_L ; .. | Gnn] += Yn_k^T [Y_k | Yn_k]
     };
     E.hook = [f](int, int, View Bop, int off, const Contributions&) -> int {
@@ -796,6 +876,7 @@ int enqueueUpdate(eqf_tf* f) {
     // are enqueued ALTERNATELY, block row by block row, so that neither stream waits for the host to be through with the other chain.
     hipEvent_t eDone = nullptr;
     const bool overlap = f->overlapChains != 0;
+    int ddRows = 0;  // rows of Y whose share of the downdate has been issued already (on the E-chain's stream)
     if (overlap) {
         Phase phS(f, 3);
         Phase* phE = nullptr;
@@ -805,12 +886,37 @@ int enqueueUpdate(eqf_tf* f) {
             phE = new Phase(f, 4);
         }
         int rc = EQF_OK;
+        // block rows whose share of the downdate goes to the E-chain's stream (see ddEarly)
+        const int nEarly = (f->ddSlices == 0 && geo.nlr && geo.nlc) ? std::min(geo.nb, (geo.nb * std::max(0, std::min(f->ddEarly, 100)) + 50) / 100) : 0;
+        auto earlyShare = [&](int kb) -> int {  // Sigma -= Y_kb^T Y_kb on the E-chain's stream, behind the hook of S's block row kb
+            const int r0 = 2 * kb * geo.bl, r1 = r0 + 2 * geo.blockSize(kb);
+            CurStream cs(f, f->sAux);
+            wait(f, f->yReady[kb]);
+            if (f->symmetric) {
+                const int w3 = 3 * geo.bl;
+                const int mask[8] = {w3, w3, 0, 1, 0, 0, 1, 0};
+                return gemmTn(f, f->Sll, f->Yr.rows(r0, r1), f->Yc.rows(r0, r1), -1.0, mask);
+            }
+            return gemmTn(f, f->Sll, f->Yr.rows(r0, r1), f->Yc.rows(r0, r1), -1.0);
+        };
+        f->yReady.assign(geo.nb, nullptr);
         while (!rc && !(E.done() && S.done())) {
             if (!E.done()) {
                 CurStream cs(f, f->sAux);
                 rc = E.step();
             }
-            if (!rc && !S.done()) rc = S.step();
+            if (!rc && !S.done()) {
+                rc = S.step();
+                // (one block row behind: the E-chain's stream should find Y ready, not wait for it)
+                if (!rc && S.k >= 2 && S.k - 2 < nEarly) {
+                    rc = earlyShare(S.k - 2);
+                    ddRows = 2 * geo.bl * (S.k - 1);
+                }
+            }
+        }
+        if (!rc && nEarly >= geo.nb && geo.nb >= 1) {  // (everything early: the last block row's share too)
+            rc = earlyShare(geo.nb - 1);
+            ddRows = f->Yr.r;
         }
         {
             CurStream cs(f, f->sAux);
@@ -847,10 +953,11 @@ int enqueueUpdate(eqf_tf* f) {
                 if (f->symmetric) RC(eqf_tile_mirror(f->device, f->cur, f->Sll.p, f->Sll.ld, f->Sll.r, w3));
             } else if (f->symmetric) {
                 const int mask[8] = {w3, w3, 0, 1, 0, 0, 1, 0};
-                RC(gemmTn(f, f->Sll, f->Yr, f->Yc, -1.0, mask));
+                if (ddRows < f->Yr.r) RC(gemmTn(f, f->Sll, f->Yr.rows(ddRows, f->Yr.r), f->Yc.rows(ddRows, f->Yc.r), -1.0, mask));
+                if (ddRows > 0) wait(f, eDone);  // (the shares on the E-chain's stream: the mirror reads what they wrote)
                 RC(eqf_tile_mirror(f->device, f->cur, f->Sll.p, f->Sll.ld, f->Sll.r, w3));
             } else {
-                RC(gemmTn(f, f->Sll, f->Yr, f->Yc, -1.0));
+                if (ddRows < f->Yr.r) RC(gemmTn(f, f->Sll, f->Yr.rows(ddRows, f->Yr.r), f->Yc.rows(ddRows, f->Yc.r), -1.0));
             }
         }
     }
@@ -966,6 +1073,30 @@ int slotCovariance(eqf_tf* f, std::vector<double>* S, int* nOut) {
     return rc;
 }
 
+// The panel streams (per chain: the next block row's solve and exchanges) share the main streams' CU set; the exchange stream carries no
+// kernels of ours.  Made when "panel_ahead" is on -- from two ranks on, or by option: a CU-masked stream is a hardware queue of its own,
+// and the GPU slows down once a process has used more than a handful of them (scripts/handle_age_probe.py, eqf_stream_create_masked), so
+// the one-rank filter holds four streams, not seven.
+int panelStreams(eqf_tf* f) {
+    for (int i = 0; i < 3; ++i) {
+        hipStream_t* dst = i < 2 ? &f->sPanel[i] : &f->sComm;
+        if (*dst) continue;
+        void* ps = nullptr;
+        // plain streams unless EQF_TILED_PANEL_MASKED=1: with three more CU-masked queues the process is past what the GPU serves at full speed
+        // (one rank, "panel_ahead" = 1, N = 4000: 85 - 99 ms a frame masked, 80 - 82 plain: profiles/r06_handle_age.txt)
+        const char* e = std::getenv("EQF_TILED_PANEL_MASKED");
+        const bool masked = e && std::atoi(e) != 0;
+        if (f->reserve > 0 && masked) RC(eqf_stream_create_masked(f->device, 0, f->reserve, 1, &ps));
+        else {
+            hipStream_t st;
+            HIPC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            ps = st;
+        }
+        *dst = (hipStream_t)ps;
+    }
+    return EQF_OK;
+}
+
 void freeAll(eqf_tf* f) {
     if (!f) return;
     hipSetDevice(f->device);
@@ -975,6 +1106,8 @@ void freeAll(eqf_tf* f) {
     for (double* p : f->allocs) hipFree(p);
     if (f->info) hipFree(f->info);
     if (f->i8Work) hipFree(f->i8Work);
+    for (void* w : f->chainWork)
+        if (w) hipFree(w);
     for (auto& g : f->graphExec) hipGraphExecDestroy(g.second);
     for (hipEvent_t e : f->evPool) hipEventDestroy(e);
     for (auto& p : f->phasePending) {
@@ -1050,20 +1183,10 @@ int eqf_tf_create(const eqf_settings* settings, int capacity_landmarks, int bloc
         f->sSide = (hipStream_t)s[1];
         f->sAux = (hipStream_t)s[2];
         f->sAuxSide = (hipStream_t)s[3];
-        // the panel streams share the main streams' CU set; the exchange stream carries no kernels of ours
-        for (int i = 0; i < 3 && !rc; ++i) {
-            void* ps = nullptr;
-            if (f->reserve > 0) rc = eqf_stream_create_masked(device, 0, f->reserve, 1, &ps);
-            else {
-                hipStream_t st;
-                if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) rc = EQF_ERR_HIP;
-                ps = st;
-            }
-            if (i < 2) f->sPanel[i] = (hipStream_t)ps;
-            else f->sComm = (hipStream_t)ps;
-        }
         f->ownStreams = true;
         f->cur = f->sMain;
+        // (the panel streams and the exchange stream: only where there is an exchange to hide -- panelStreams)
+        if (!rc && f->panelAhead) rc = panelStreams(f);
     }
     if (!rc) rc = eqf_tiled_set_stream(f->t, f->sMain);
     if (rc) {
@@ -1087,11 +1210,30 @@ int eqf_tf_set_option(eqf_tf* f, const char* name, int value) {
         if (value != 0 && (value < 5 || value > 7)) return EQF_ERR_INVALID;
         f->ddSlices = value;
     }
+    else if (n == "solve_inverse") f->solveInverse = value ? 1 : 0;
+    else if (n == "downdate_early") {
+        if (value < 0 || value > 100) return EQF_ERR_INVALID;
+        f->ddEarly = value;
+    }
+    else if (n == "chain_slices") {
+        if (value != 0 && (value < 5 || value > 7)) return EQF_ERR_INVALID;
+        f->chainSlices = value;
+    }
+    else if (n == "trsm_leaf") {
+        if (value < 0 || value > 16) return EQF_ERR_INVALID;
+        f->trsmLeaf = value;
+    }
     else if (n == "burst") f->burst = value;
     else if (n == "check_every") f->checkEvery = value;
     else if (n == "profiling") f->profiling = value;
     else if (n == "graphs") f->graphs = value;
-    else if (n == "panel_ahead") f->panelAhead = value;
+    else if (n == "panel_ahead") {
+        if (value && f->ownStreams) {
+            DeviceScope ds(f->device);
+            RC(panelStreams(f));
+        }
+        f->panelAhead = value;
+    }
     else return EQF_ERR_INVALID;
     return EQF_OK;
 }

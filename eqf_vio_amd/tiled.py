@@ -184,6 +184,14 @@ class TiledFilter:
     # ---- options (attributes, as the Python loop had them)
     # 0 (default): the covariance downdate on the fp64 matrix cores; 5 / 6 / 7: on the integer matrix pipe from that many 7-bit slices (round 6)
     downdate_slices = property(lambda s: getattr(s, "_dd_slices", 0), lambda s, v: (setattr(s, "_dd_slices", int(v)), s._opt("downdate_slices", v))[0])
+    # the same for the trailing products of the two factorisations (five slices are enough there: scripts/slice_precision_study_chain.py)
+    chain_slices = property(lambda s: getattr(s, "_chain_slices", 0), lambda s, v: (setattr(s, "_chain_slices", int(v)), s._opt("chain_slices", v))[0])
+    # > 0: block-row solves split recursively down to this many 64-row blocks (0, the default: one split -- the recursion measured slower)
+    trsm_leaf = property(lambda s: getattr(s, "_trsm_leaf", 0), lambda s, v: (setattr(s, "_trsm_leaf", int(v)), s._opt("trsm_leaf", v))[0])
+    # percent of the S-chain's block rows whose share of the downdate runs on the E-chain's stream while the chains are still going
+    # a block row's solve as one product with the explicit inverse of its diagonal factor (csrc/eqf_tiledf.hip: solveInverse)
+    solve_inverse = property(lambda s: getattr(s, "_solve_inverse", False), lambda s, v: (setattr(s, "_solve_inverse", bool(v)), s._opt("solve_inverse", v))[0])
+    downdate_early = property(lambda s: getattr(s, "_dd_early", 0), lambda s, v: (setattr(s, "_dd_early", int(v)), s._opt("downdate_early", v))[0])
     overlap_chains = property(lambda s: s._overlap, lambda s, v: (setattr(s, "_overlap", bool(v)), s._opt("overlap_chains", v))[0])
     lookahead = property(lambda s: getattr(s, "_lookahead", True), lambda s, v: (setattr(s, "_lookahead", bool(v)), s._opt("lookahead", v))[0])
     burst = property(lambda s: getattr(s, "_burst", True), lambda s, v: (setattr(s, "_burst", bool(v)), s._opt("burst", v))[0])

@@ -38,19 +38,25 @@ class HipBackend:
         import os
 
         self.reserve = int(os.environ.get("EQF_TILED_RESERVE_CUS", "24")) if reserve_cus is None else int(reserve_cus)
+        # The streams are made on first use (round 6): a CU-masked stream is a hardware queue of its own, the GPU slows down once a process has
+        # used more than a handful of them (scripts/handle_age_probe.py), and a backend that only answers for a TiledFilter's handle (adopt())
+        # never runs anything on its own streams.
         self._raw = []
+        self._cu_range = cu_range
         self._main = self._side = self._aux = self._aux_side = None
-        if self.reserve > 0:
-            ptrs = [ctypes.c_void_p() for _ in range(4)]
-            for i, p in enumerate(ptrs):  # main, side, and a second pair for the E-chain, which runs next to the S-chain (TiledFilter._update)
-                if cu_range is None:
-                    first, count, comp = 0, self.reserve, 1 if i % 2 == 0 else 0
-                else:
-                    first, count, comp = (cu_range[0] + self.reserve, cu_range[1] - self.reserve, 0) if i % 2 == 0 else (cu_range[0], self.reserve, 0)
-                binding._check(self.lib.eqf_stream_create_masked(self.dev, first, count, comp, ctypes.byref(p)), "eqf_stream_create_masked")
-            self._raw = ptrs
-            self._main, self._side, self._aux, self._aux_side = [torch.cuda.ExternalStream(p.value, device=self.device) for p in ptrs]
         self._sync_stream()
+
+    def _masked(self, i):
+        """stream i of (main, side, aux, aux_side): main / aux on all CUs but the reserved ones, side / aux_side on the reserved ones"""
+        p = ctypes.c_void_p()
+        if self._cu_range is None:
+            first, count, comp = 0, self.reserve, 1 if i % 2 == 0 else 0
+        else:
+            cr = self._cu_range
+            first, count, comp = (cr[0] + self.reserve, cr[1] - self.reserve, 0) if i % 2 == 0 else (cr[0], self.reserve, 0)
+        self.b._check(self.lib.eqf_stream_create_masked(self.dev, first, count, comp, ctypes.byref(p)), "eqf_stream_create_masked")
+        self._raw.append(p)
+        return torch.cuda.ExternalStream(p.value, device=self.device)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -99,22 +105,26 @@ class HipBackend:
         """context: the stream every call of the filter runs on (all CUs but the reserved ones)"""
         import contextlib
 
-        return torch.cuda.stream(self._main) if self._main is not None else contextlib.nullcontext()
+        if self.reserve <= 0:
+            return contextlib.nullcontext()
+        if self._main is None:
+            self._main = self._masked(0)
+        return torch.cuda.stream(self._main)
 
     def side(self):
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = self._masked(1) if self.reserve > 0 else torch.cuda.Stream(device=self.device)
         return torch.cuda.stream(self._side)
 
     def aux(self):
         """context: a second 'main' stream (same CU set), for the factorisation that runs next to the other one"""
         if self._aux is None:
-            self._aux = torch.cuda.Stream(device=self.device)
+            self._aux = self._masked(2) if self.reserve > 0 else torch.cuda.Stream(device=self.device)
         return torch.cuda.stream(self._aux)
 
     def aux_side(self):
         if self._aux_side is None:
-            self._aux_side = torch.cuda.Stream(device=self.device)
+            self._aux_side = self._masked(3) if self.reserve > 0 else torch.cuda.Stream(device=self.device)
         return torch.cuda.stream(self._aux_side)
 
     def record(self):
@@ -271,6 +281,22 @@ class HipBackend:
         ws = torch.empty(need, dtype=torch.uint8, device=Cm.device)
         self.b._check(self.lib.eqf_tile_downdate_i8(self.dev, self._cur(), self._p(Cm), Cm.stride(0), m, n, self._p(A), A.stride(0), self._p(B),
                                                     B.stride(0), k, int(slices), int(mask_rb), ws.data_ptr(), need), "eqf_tile_downdate_i8")
+        torch.cuda.current_stream(Cm.device).synchronize()  # (the workspace is a temporary of this call)
+
+    def gemm_tn_i8(self, Cm, A, B, slices, mask=None, mask_cols=0):
+        """Cm (m x n view) -= A^T B on the integer matrix pipe behind gemm_tn's block mask; the mask covers the first mask_cols columns
+        (eqf_tile_gemm_tn_i8, include/eqf_vio_amd_debug.h).  A a column range of B at a multiple of 32: one split."""
+        import torch
+
+        m, n = Cm.shape
+        k = A.shape[0]
+        need = int(self.lib.eqf_tile_i8_workspace_bytes(m, n, k, int(slices), 0))
+        assert need > 0
+        ws = torch.empty(need, dtype=torch.uint8, device=Cm.device)
+        mk = mask if mask is not None else (0, 0, 0, 1, 0, 0, 1, 0)
+        self.b._check(self.lib.eqf_tile_gemm_tn_i8(self.dev, self._cur(), self._p(Cm), Cm.stride(0), m, n, self._p(A), A.stride(0), self._p(B),
+                                                   B.stride(0), k, int(slices), *[int(x) for x in mk], int(mask_cols), ws.data_ptr(), need),
+                      "eqf_tile_gemm_tn_i8")
         torch.cuda.current_stream(Cm.device).synchronize()  # (the workspace is a temporary of this call)
 
     def mirror_lower(self, Cm, rb):

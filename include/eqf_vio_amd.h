@@ -292,7 +292,11 @@ int eqf_tiled_set_state(eqf_tiled* t, int N, const double* pose_q, const double*
  * Options (eqf_tf_set_option): "lookahead" (1), "overlap_chains" (1 on one rank, 0 on a grid: the interleaved chains are not validated over RCCL on a node; EQF_TILED_OVERLAP_CHAINS), "burst" (1: IMU calls queued and sent as
  * bursts), "check_every" (1), "downdate_slices" (0: the covariance downdate Sigma - Y^T Y on the fp64 matrix cores, parity grade; 5 / 6 / 7: on the INTEGER matrix pipe from
  * that many 7-bit slices of Y's columns with exact accumulation -- Sigma within 1e-4 of the fp64 path from 6 slices on (measured 2e-6 at N = 200 .. 6e-5 at N = 4000), two thirds of the downdate's time;
- * round 6, csrc/eqf_tile.hpp), "profiling" (0: event brackets per phase, eqf_tf_get_phases in eqf_vio_amd_debug.h), "graphs" (0: hipGraph replay of an update on a
+ * round 6, csrc/eqf_tile.hpp), "chain_slices" (0: the two factorisations' trailing products on the fp64 matrix cores; 5 / 6 / 7: on the integer pipe in the same
+ * way -- they forgive more than the downdate: five slices keep Sigma to 1e-8 and the pose to 3e-9 of the fp64 path on the bench stream), "downdate_early" (50: with the chains side by side and the fp64 downdate, the shares Y_k^T Y_k of this percentage of the S-chain's block rows are subtracted on the
+ * E-chain's stream as soon as each block row is solved, the rest in one product behind the S-chain; 0: the whole downdate behind the S-chain, as until round 6),
+ * "trsm_leaf" (0: a block row's triangular solve is split once into two solves and a product; > 0: recursively, down to this many 64-row blocks -- measured slower at N = 4000),
+ * "profiling" (0: event brackets per phase, eqf_tf_get_phases in eqf_vio_amd_debug.h), "graphs" (0: hipGraph replay of an update on a
  * one-rank grid, see eqf_tf_graph_launches in eqf_vio_amd_debug.h).
  * ================================================================================================================================ */
 typedef struct eqf_tf eqf_tf; /* opaque */

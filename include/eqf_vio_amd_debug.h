@@ -102,7 +102,9 @@ long long eqf_tf_graph_launches(eqf_tf* f);
 /* A HIP stream whose kernels only run on the CUs [first_cu, first_cu + num_cus) (complement = 0) or on all the others (complement = 1)
  * (hipExtStreamCreateWithCUMask).  The look-ahead of the distributed factorisations factors the next diagonal block -- one workgroup
  * with 119 KB of LDS -- on a few reserved CUs while the trailing update fills the rest of the chip; without the reservation the
- * update's workgroups (two per CU, 147 KB of LDS) never leave room for it. */
+ * update's workgroups (two per CU, 147 KB of LDS) never leave room for it.  eqf_stream_destroy waits for the stream and keeps a masked stream
+ * for the next request of the same device and mask (a masked stream is a hardware queue of its own, and destroyed ones were measured not to
+ * come back: see csrc/eqf_tiled.hip); any other stream is destroyed. */
 int eqf_stream_create_masked(int device, int first_cu, int num_cus, int complement, void** out);
 int eqf_stream_destroy(int device, void* stream);
 int eqf_tile_gemm_tn(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k,
@@ -125,6 +127,14 @@ int eqf_tile_downdate(int device, void* stream, double* C, int ldc, int m, int n
 size_t eqf_tile_i8_workspace_bytes(int m, int n, int k, int slices, int same_operand);
 int eqf_tile_downdate_i8(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k,
     int slices, int mask_rb, void* workspace, size_t workspace_bytes);
+/* eqf_tile_gemm_tn_i8 (round 6): the same integer-pipe product behind eqf_tile_gemm_tn's block mask, alpha = -1: what a block row of the two
+ *   factorisations of an update subtracts from its trailing rows (eqf_tf_set_option "chain_slices").  The mask (mask_rb > 0) covers the first
+ *   mask_cols columns of C (the matrix part); the columns from mask_cols on (right-hand sides) are always formed.  When A is a column range of
+ *   B that starts at a multiple of 32 (same rows of memory, lda == ldb) the operands are cut once.  workspace: at least
+ *   eqf_tile_i8_workspace_bytes(m, n, k, slices, 0) bytes. */
+int eqf_tile_gemm_tn_i8(int device, void* stream, double* C, int ldc, int m, int n, const double* A, int lda, const double* B, int ldb, int k,
+    int slices, int mask_rb, int mask_cb, int rblk0, int Pr, int pr, int cblk0, int Pc, int pc, int mask_cols, void* workspace,
+    size_t workspace_bytes);
 int eqf_tile_potrf(int device, void* stream, double* A, int ld, int n, double* drec, int* info);
 int eqf_tile_trsm(int device, void* stream, const double* A, int ld, int n, const double* drec, double* B, int ldb, int m, int right);
 

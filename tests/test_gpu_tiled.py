@@ -62,6 +62,56 @@ def test_tile_downdate_on_the_integer_pipe_against_numpy():
     assert np.array_equal(np.tril(got, -rb), np.tril(got.T, -rb))  # (strictly below the block diagonal: exact mirror images)
 
 
+def test_tile_gemm_tn_on_the_integer_pipe_behind_the_block_mask():
+    """eqf_tile_gemm_tn_i8 (round 6, what "chain_slices" runs for a block row's trailing products): C -= A^T B from slices, behind
+    eqf_tile_gemm_tn's block mask over the first mask_cols columns (the matrix part) with the columns behind them (right-hand sides) always
+    formed; A as a column range of B (cut once: offsets that are a multiple of 32) and as a matrix of its own; the same error bound as the
+    downdate's product.  Below the staircase an element is untouched or the whole product, never garbage."""
+    import torch
+
+    from eqf_vio_amd import tiled
+
+    dev = torch.device("cuda", 0)
+    be = tiled.HipBackend({}, capacity=8)
+    t = _t(dev)
+    rng = np.random.default_rng(11)
+    #        m    n (incl. rhs)  k   rb  rblk0 Pr pr cblk0 Pc pc  mask_cols  A's offset in B (None: separate)  slices
+    cases = ((600, 600 + 37, 150, 150, 0, 1, 0, 0, 1, 0, 600, 0, 5),
+             (450, 600 + 18, 150, 150, 1, 1, 0, 0, 1, 0, 600, None, 5),     # (rows start one block further down than the columns)
+             (512, 640 + 5, 128, 128, 0, 1, 0, 0, 1, 0, 640, 128, 6),       # (A = B's columns 128 .. 640: an aligned offset, cut once)
+             (500, 500 + 9, 96, 100, 2, 2, 1, 1, 2, 0, 500, None, 5),       # (a 2 x 2 grid's rank (1, 0) with block offsets)
+             (300, 77, 64, 0, 0, 1, 0, 0, 1, 0, 0, None, 7),                # (no mask: right-hand sides only)
+             (260, 300, 40, 100, 0, 1, 0, 0, 1, 0, 300, 20, 5))             # (an offset that is NOT a multiple of 32: cut separately)
+    for (m, n, k, rb, rblk0, Pr, pr, cblk0, Pc, pc, mcols, aoff, S) in cases:
+        B = rng.standard_normal((k, n + 3)) * 10.0 ** rng.uniform(-2, 2, size=(1, n + 3))
+        Bd = t(B)
+        Bv, Bdv = B[:, 1: 1 + n], Bd[:, 1: 1 + n]
+        if aoff is None:
+            A = rng.standard_normal((k, m)) * 10.0 ** rng.uniform(-2, 2, size=(1, m))
+            Adv = t(A)
+        else:
+            A, Adv = Bv[:, aoff: aoff + m], Bdv[:, aoff: aoff + m]
+        C = rng.standard_normal((m, n + 4))
+        Cd = t(C)
+        mask = (rb, rb, rblk0, Pr, pr, cblk0, Pc, pc) if rb else None
+        be.gemm_tn_i8(Cd[:, 2: 2 + n], Adv, Bdv, S, mask=mask, mask_cols=mcols)
+        got = Cd.cpu().numpy()
+        assert np.array_equal(got[:, :2], C[:, :2]) and np.array_equal(got[:, 2 + n:], C[:, 2 + n:])
+        got, C0 = got[:, 2: 2 + n], C[:, 2: 2 + n]
+        want = C0 - A.T @ Bv
+        bound = k * np.outer(np.abs(A).max(axis=0), np.abs(Bv).max(axis=0)) * 2.0 ** -(5 + 7 * (S - 1)) * 1.01 + 1e-12 * np.abs(want)
+        keep = np.ones((m, n), dtype=bool)
+        if rb:
+            I = (rblk0 + np.arange(m) // rb) * Pr + pr
+            J = (cblk0 + np.arange(n) // rb) * Pc + pc
+            keep = I[:, None] <= J[None, :]
+            keep[:, mcols:] = True
+        assert (np.abs(got - want) <= bound)[keep].all(), (m, n, k, S)
+        assert ((got == C0) | (np.abs(got - want) <= bound))[~keep].all(), (m, n, k, S)
+        if rb and m >= 384:
+            assert (got == C0)[~keep].any()  # (whole tiles below the staircase really are skipped)
+
+
 def test_tile_gemm_tn_against_numpy():
     """C += alpha A^T B (eqf_tile_gemm_tn): ragged sizes around the 128 x 128 x 16 tiling, narrow products, views with leading
     dimensions, both signs, and the block-upper mask of a block-cyclic local matrix."""
@@ -353,6 +403,158 @@ def test_downdate_on_the_integer_pipe_holds_the_tolerance(N, bl, dur, slices, to
     assert np.abs(e1["x"] - e0["x"]).max() <= 1e-6 and np.abs(e1["q"] - e0["q"]).max() <= 1e-6 and be.device_error() == 0
 
 
+@pytest.mark.parametrize("N,bl,dur,chain,dd,tol", [(200, 64, 2.0, 5, 0, 1e-6), (200, 64, 1.0, 5, 6, 1e-5), (1000, 125, 0.26, 5, 0, 1e-6)])
+def test_factorisations_on_the_integer_pipe_hold_the_tolerance(N, bl, dur, chain, dd, tol):
+    """Round 6: the trailing products of the update's two factorisations (the S-chain with its right-hand sides, the E-chain of bundleLift's
+    Sigma_e) on the integer matrix pipe (eqf_tf_set_option "chain_slices"), against the fp64 single-GPU product path on the bench stream, Sigma
+    after every update.  The factorisations forgive more than the downdate: FIVE slices (15 integer products) keep Sigma to ~1e-8 -- what the
+    CPU study predicted (scripts/slice_precision_study_chain.py: 1.0e-8 at N = 200) -- so the bound here is 1e-6, two orders inside
+    north_star's 1e-4; with the downdate on six slices as well the downdate's error (2e-6) is what is left.  Pose to 1e-6."""
+    from eqf_vio_amd import binding, synth, tiled
+
+    d = synth.template_settings_dict()
+    st = synth.make_stream(N, duration=dur)
+    be = tiled.HipBackend(d, capacity=N)
+    tf = tiled.TiledFilter(tiled.ProcessGrid(None, 1, 1, device=be.device), be, bl)
+    tf.chain_slices = chain
+    tf.downdate_slices = dd
+    fg = binding.FilterBatch(d, capacity=N, batch=1)
+    worst, n_upd = 0.0, 0
+    for kind, k in st.events():
+        if kind == "imu":
+            r = st.imu[k]
+            tf.processIMUData(r[0], r[1:4], r[4:7])
+            fg.process_imu([r[0]], r[1:4], r[4:7])
+        else:
+            fg.process_vision([st.vision_stamps[k]], st.ids, st.bearings[k])
+            assert tf.processVisionData(st.vision_stamps[k], st.ids, st.bearings[k]) == 0
+            S1, S0 = tf.stateCovariance(), fg.sigma()
+            worst = max(worst, float(np.linalg.norm(S1 - S0) / np.linalg.norm(S0)))
+            assert np.abs(S1 - S1.T).max() <= 1e-9 * np.abs(S1).max()
+            n_upd += 1
+    e1, e0 = tf.stateEstimate(), fg.state_estimate()
+    print(f"N={N} chain_slices={chain} downdate_slices={dd}: worst Sigma rel-Frobenius difference to the fp64 path over {n_upd} updates {worst:.2e}")
+    assert n_upd >= 4 and worst <= tol, worst
+    assert worst > 1e-14  # (the integer pipe really ran)
+    assert np.abs(e1["x"] - e0["x"]).max() <= 1e-6 and np.abs(e1["q"] - e0["q"]).max() <= 1e-6 and be.device_error() == 0
+
+
+@pytest.mark.parametrize("opts,tol", [({"solve_inverse": 1}, 1e-9), ({"solve_inverse": 1, "downdate_early": 50}, 1e-9), ({"downdate_early": 100}, 1e-9),
+                                      ({"trsm_leaf": 1}, 1e-9), ({"trsm_leaf": 2, "solve_inverse": 0, "downdate_early": 30}, 1e-9),
+                                      ({"panel_ahead": 1, "chain_slices": 5}, 1e-6), ({"panel_ahead": 1, "solve_inverse": 1}, 1e-9)])
+def test_update_options_of_round_6_hold_the_tolerance(opts, tol):
+    """The host-loop options that round 6 added (eqf_tf_set_option), each against the fp64 single-GPU product path on the bench stream, Sigma after
+    every update: "solve_inverse" (a block row's solve as one product with the explicit inverse of its diagonal factor), "downdate_early" (the
+    downdate's shares of the first block rows on the E-chain's stream while the chains are going), "trsm_leaf" (recursive split of the solves),
+    "panel_ahead" on one rank (the multi-rank schedule's streams) with the integer-pipe products.  All but the integer pipe are the same
+    arithmetic in another order: 1e-9."""
+    from eqf_vio_amd import binding, synth, tiled
+
+    N, bl = 200, 24  # (nine block rows, the last one ragged; diagonal blocks of 48 / 72 rows: one and two 64-row strips)
+    d = synth.template_settings_dict()
+    st = synth.make_stream(N, duration=0.5)
+    be = tiled.HipBackend(d, capacity=N)
+    tf = tiled.TiledFilter(tiled.ProcessGrid(None, 1, 1, device=be.device), be, bl)
+    for name, v in opts.items():
+        tf._opt(name, v)
+    fg = binding.FilterBatch(d, capacity=N, batch=1)
+    worst, n_upd = 0.0, 0
+    for kind, k in st.events():
+        if kind == "imu":
+            r = st.imu[k]
+            tf.processIMUData(r[0], r[1:4], r[4:7])
+            fg.process_imu([r[0]], r[1:4], r[4:7])
+        else:
+            fg.process_vision([st.vision_stamps[k]], st.ids, st.bearings[k])
+            assert tf.processVisionData(st.vision_stamps[k], st.ids, st.bearings[k]) == 0
+            S1, S0 = tf.stateCovariance(), fg.sigma()
+            worst = max(worst, float(np.linalg.norm(S1 - S0) / np.linalg.norm(S0)))
+            assert np.abs(S1 - S1.T).max() <= 1e-9 * np.abs(S1).max()
+            n_upd += 1
+    e1, e0 = tf.stateEstimate(), fg.state_estimate()
+    print(f"{opts}: worst Sigma rel-Frobenius difference to the product path over {n_upd} updates {worst:.2e}")
+    assert n_upd >= 8 and worst <= tol, worst
+    assert np.abs(e1["x"] - e0["x"]).max() <= 1e-6 and np.abs(e1["q"] - e0["q"]).max() <= 1e-6 and be.device_error() == 0
+
+
+def test_product_kernel_builds_agree_bitwise(tmp_path):
+    """k_tile_gemm_tn's two builds -- operand rows global -> LDS directly (the default) and through registers (EQF_GEMM_DIRECT=0) -- do the same
+    arithmetic in the same order: bitwise the same C, on a whole-tile shape, a ragged one, a view at an odd column and a masked launch.  The
+    switch is read once per process, so two processes."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, hashlib, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from eqf_vio_amd import tiled\n"
+        "be = tiled.HipBackend({}, capacity=8)\n"
+        "rng = np.random.default_rng(9)\n"
+        "h = hashlib.sha256()\n"
+        "for (m, n, k, off, mask) in ((512, 640, 96, 0, None), (300, 513, 129, 1, None), (768, 768, 200, 0, (256, 256, 0, 1, 0, 0, 1, 0))):\n"
+        "    A = torch.from_numpy(rng.standard_normal((k, m + 3))).cuda(); B = torch.from_numpy(rng.standard_normal((k, n + 3))).cuda()\n"
+        "    C = torch.from_numpy(rng.standard_normal((m, n))).cuda()\n"
+        "    be.gemm_tn(C, A[:, off: off + m], B[:, off: off + n], -1.0, mask)\n"
+        "    torch.cuda.synchronize(); h.update(C.cpu().numpy().tobytes())\n"
+        "print(h.hexdigest())\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    out = []
+    for direct in ("1", "0"):
+        env = dict(os.environ, EQF_GEMM_DIRECT=direct)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append(r.stdout.strip().splitlines()[-1])
+    assert len(out[0]) == 64 and out[0] == out[1], out
+
+
+def test_a_process_does_not_slow_down_with_the_handles_it_has_closed():
+    """Round 6: the fifth partitioned filter a process creates runs as fast as the first.  It did not: every handle made eleven CU-masked streams
+    (hardware queues of their own), seven of them never used on one rank, and the GPU serves a process at full speed only while the queues it
+    has ever put work on stay a handful -- the frame went 68 -> 88 -> 100 -> 128 -> 150 ms over five handles whether the streams were destroyed,
+    kept or leaked (profiles/r06_handle_age.txt).  Now a stream is made when it is first needed (four per one-rank handle) and a closed
+    handle's streams serve the next one.  One frame (10 IMU calls + the update) of N = 4000 per handle, five handles; 15 % of slack."""
+    import gc
+    import time
+
+    import torch
+
+    from eqf_vio_amd import synth, tiled
+
+    N, bl = 4000, 250
+    d = synth.template_settings_dict()
+    st = synth.make_stream(N, duration=0.11)
+    ev = list(st.events())
+    first_vis = next(i for i, (kind, _) in enumerate(ev) if kind == "vision")
+    warm, timed = ev[: first_vis + 1], ev[first_vis + 1: first_vis + 12]
+    assert sum(1 for kind, _ in timed if kind == "vision") == 1
+    ms = []
+    for cycle in range(5):
+        be = tiled.HipBackend(d, capacity=N)
+        tf = tiled.TiledFilter(tiled.ProcessGrid(None, 1, 1, device=be.device), be, bl)
+        assert len(be._raw) == 0  # (a backend that only answers for the filter's handle makes no streams of its own)
+        tf.check_every = 0
+        for part in (warm, timed):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for kind, k in part:
+                if kind == "imu":
+                    r = st.imu[k]
+                    tf.processIMUData(r[0], r[1:4], r[4:7])
+                else:
+                    assert tf.processVisionData(st.vision_stamps[k], st.ids, st.bearings[k]) == 0
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        ms.append(dt * 1e3)
+        tf.check()
+        assert be.device_error() == 0
+        tf.close()
+        be.close()
+        del tf, be
+        gc.collect()
+    print("ms per frame of the 1st .. 5th handle of the process:", [round(x, 1) for x in ms])
+    assert max(ms[1:]) <= 1.15 * ms[0], ms
+
+
 def test_tiled_filter_N4000_against_the_single_gpu_product_path():
     """BASELINE configs[4] at its size: N = 4000 (Sigma 12011 x 12011, 1.15 GB), blocks of 250 (16 x 16 blocks of 750 x 750), on the 1 x 1
     grid: the first frame (4000 landmarks appended + update), a burst of IMU steps, the second frame's update -- Sigma against the
@@ -402,7 +604,7 @@ def test_tiled_filter_N4000_against_the_single_gpu_product_path():
     assert np.abs(et["x"] - eg["x"]).max() <= 1e-9 and np.abs(et["q"] - eg["q"]).max() <= 1e-9 and np.abs(et["p"] - eg["p"]).max() <= 1e-8
 
 
-def _multi_rank_worker(rank, world, port, Pr, Pc, N, bl, out_dir):
+def _multi_rank_worker(rank, world, port, Pr, Pc, N, bl, out_dir, opts=""):
     """One of `world` processes that SHARE the one GPU: HipBackend on cuda:0, the grid's broadcasts over gloo (device tensors)."""
     import os
     import sys
@@ -422,6 +624,9 @@ def _multi_rank_worker(rank, world, port, Pr, Pc, N, bl, out_dir):
     be = tiled.HipBackend(d, capacity=N, device_index=0, reserve_cus=0)  # (no CU reservation: eight processes share the chip)
     tf = tiled.TiledFilter(tiled.ProcessGrid(dist, Pr, Pc, device=be.device), be, bl)
     tf.lookahead = False  # (one stream per process: several processes time-share the GPU's hardware queues here)
+    for item in filter(None, opts.split(",")):
+        name, v = item.split("=")
+        tf._opt(name, int(v))
     fo = ob.OracleFilter(d)
     st = synth.make_stream(N, duration=0.16)
     rel = lambda A, B: float(np.linalg.norm(A - B) / np.linalg.norm(B))
@@ -446,11 +651,16 @@ def _multi_rank_worker(rank, world, port, Pr, Pc, N, bl, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("Pr,Pc,N,bl", [(1, 2, 50, 8), (2, 2, 44, 8), (2, 4, 76, 8)])
-def test_tiled_filter_multi_rank_grids_with_the_hip_kernels(tmp_path, Pr, Pc, N, bl):
+@pytest.mark.parametrize("Pr,Pc,N,bl,opts,tolS", [(1, 2, 50, 8, "", 1e-9), (2, 2, 44, 8, "", 1e-9), (2, 4, 76, 8, "", 1e-9),
+                                                  (2, 2, 44, 8, "solve_inverse=1,downdate_early=50", 1e-9), (2, 4, 76, 8, "solve_inverse=1,downdate_early=100", 1e-9),
+                                                  (2, 4, 76, 8, "chain_slices=5", 1e-6), (2, 2, 44, 8, "chain_slices=6,downdate_slices=7", 1e-6)])
+def test_tiled_filter_multi_rank_grids_with_the_hip_kernels(tmp_path, Pr, Pc, N, bl, opts, tolS):
     """The multi-rank schedule WITH the HIP backend (block-cyclic local matrices with Pr, Pc > 1, the block-upper mask of the trailing
     products, the interleaved row operand of non-square grids): Pr x Pc processes share the one MI355X, the grid's broadcasts go over
-    gloo on device tensors.  Closed loop against the dense oracle on every rank.  (What this cannot show is RCCL over xGMI itself.)"""
+    gloo on device tensors.  Closed loop against the dense oracle on every rank.  (What this cannot show is RCCL over xGMI itself.)
+    Round 6: the same with the options that change the schedule's products -- the inverse of the diagonal factor travelling with the
+    factor, the downdate's early shares on non-symmetric ranks (Y_I and Y_J different matrices), the integer-pipe products behind the block
+    mask of a 2 x 4 grid (operands cut separately: the row operand is not a column range of the other)."""
     import socket
 
     import torch.multiprocessing as mp
@@ -466,11 +676,11 @@ def test_tiled_filter_multi_rank_grids_with_the_hip_kernels(tmp_path, Pr, Pc, N,
 
     gc.collect()  # (handles of earlier tests hold HIP streams = hardware queues the spawned processes would have to share)
     torch.cuda.synchronize()
-    mp.spawn(_multi_rank_worker, args=(world, port, Pr, Pc, N, bl, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_multi_rank_worker, args=(world, port, Pr, Pc, N, bl, str(tmp_path), opts), nprocs=world, join=True)
     for r in range(world):
         S, pose, gamma, n_upd, err = np.load(tmp_path / f"w_{r}.npy")
         assert n_upd >= 3 and err == 0
-        assert S < 1e-9 and pose < 1e-8 and gamma < 1e-8, (r, S, pose, gamma)
+        assert S < tolS and pose < max(1e-8, 1e-2 * tolS) and gamma < max(1e-8, 1e-2 * tolS), (r, S, pose, gamma)
 
 
 # ---- landmark churn in the partitioned filter (VIOFilter.cpp:345-443 on slots: eqf_tiled_edit_landmarks) ----------------------------------
