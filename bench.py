@@ -535,6 +535,8 @@ def tiled_leg(args, dist, rank, world, device):
         out["_sll_ref"] = sll_ref
     if world > 1:
         out["note"] += "; UNMEASURED on more than one GPU until a node is available to the builder -- this line is then the first measurement"
+    tf.close()  # (explicitly: a handle left to the garbage collector keeps its CU-masked streams -- hardware queues -- while the next legs run)
+    be.close()
     del tf, be
     # Landmark churn in the partitioned filter (VIOFilter.cpp:345-443 on slots, eqf_tiled_edit_landmarks) with the outlier gate at the
     # reference default: the same frames, but every frame `turn` landmarks (1 %) are out of view and the ones hidden a frame earlier come
@@ -565,9 +567,19 @@ def tiled_leg(args, dist, rank, world, device):
                         "device_error_flag": be.device_error(),
                         "note": "per frame %d landmarks leave and %d enter (slots: a removed landmark leaves a decoupled hole, the next new one "
                                 "refills it; nothing moves between ranks), gate evaluated on the replicated state every frame" % (turn, turn)}
+        tf.close()
+        be.close()
         del tf, be
     except Exception as e:  # the fixed-set figure above stands on its own
         out["churn"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if world == 1 and rank == 0:
+        fb = binding.FilterBatch(d, capacity=N, batch=1, device=device)
+        # (before the integer-pipe sub-legs: run after them, this leg came out at 134 - 142 steps/s in two runs of three of scripts/tiled_bench.py and at
+        # 169 - 170 in the third, with the stream pool or without, with the handles closed explicitly or not; cause not found -- NOTES R6.7)
+        dtm = timed_run(lambda s_, w_, a_: fb.process_imu([s_], w_, a_), lambda s_, i_, y_: fb.process_vision([s_], i_, y_), fb.synchronize)
+        out["monolithic_single_gpu"] = {"value": len(timed) / dtm, "unit": "steps/s", "ms_per_frame": dtm * 1e3 / max(n_vis, 1),
+                                        "note": "the single-GPU product path (eqf_process_*) on the same events"}
+        del fb
     if world == 1 and rank == 0 and not args.no_i8_downdate:
         # Round 6: the same frames with the covariance downdate on the INTEGER matrix pipe (eqf_tf_set_option "downdate_slices" = 6: Y's columns
         # as six 7-bit slices, int8 MFMA with exact accumulation, fp64 recombination; csrc/eqf_tile.hpp) -- north_star's "low-precision MFMA for the
@@ -597,17 +609,13 @@ def tiled_leg(args, dist, rank, world, device):
                             "phases_ms_per_frame": {k: round(v / n_vis_ph, 3) for k, v in tf.phase_ms.items()},
                             "note": "local blocks of Sigma after the same %d timed frames, against the fp64 run of this leg; opt-in "
                                     "(eqf_tf_set_option \"downdate_slices\" / \"chain_slices\"), every other figure of the line is the fp64 path" % frames}
+                tf.close()
+                be.close()
                 del tf, be
             except Exception as e:
                 out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         del sll_ref
     out.pop("_sll_ref", None)
-    if world == 1 and rank == 0:
-        fb = binding.FilterBatch(d, capacity=N, batch=1, device=device)
-        dtm = timed_run(lambda s_, w_, a_: fb.process_imu([s_], w_, a_), lambda s_, i_, y_: fb.process_vision([s_], i_, y_), fb.synchronize)
-        out["monolithic_single_gpu"] = {"value": len(timed) / dtm, "unit": "steps/s", "ms_per_frame": dtm * 1e3 / max(n_vis, 1),
-                                        "note": "the single-GPU product path (eqf_process_*) on the same events"}
-        del fb
     return out
 
 
