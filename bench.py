@@ -58,7 +58,8 @@ def parse():
                     "over the ranks of the job (1 x 1 grid on one GPU, 2 x 4 on eight), closed loop through the C++ host loop eqf_tf_* (csrc/eqf_tiledf.hip)")
     ap.add_argument("--tiled", action="store_true", help="(the cfg 5 leg is on by default; kept for explicitness)")
     ap.add_argument("--tiled-landmarks", type=int, default=4000)
-    ap.add_argument("--tiled-block", type=int, default=250, help="landmarks per block of the 2-D partition")
+    ap.add_argument("--tiled-block", type=int, default=0, help="landmarks per block of the 2-D partition (0: 320 on one GPU -- measured best there, "
+                    "profiles/r06_tiled_block_sweep.txt -- and 250 on a grid, where N = 4000 then is 16 blocks: an even deal over 2 x 4)")
     ap.add_argument("--tiled-timeout", type=int, default=240, help="several GPUs: seconds after which the cfg 5 leg is given up")
     ap.add_argument("--tiled-frames", type=int, default=3, help="timed frames (a frame = 10 IMU calls + 1 vision call) after one warm-up frame")
     ap.add_argument("--no-i8-downdate", action="store_true", help="skip the cfg 5 sub-leg with the covariance downdate on the integer matrix pipe")
@@ -461,7 +462,7 @@ def tiled_leg(args, dist, rank, world, device):
 
     from eqf_vio_amd import binding, synth, tiled
 
-    N, bl, frames = args.tiled_landmarks, args.tiled_block, args.tiled_frames
+    N, bl, frames = args.tiled_landmarks, args.tiled_block or (320 if world == 1 else 250), args.tiled_frames
     Pr, Pc = GRIDS[world]
     st = synth.make_stream(N, seed=1234, duration=(frames + 2) / 20.0 + 0.011)
     ev = list(st.events())
