@@ -588,12 +588,14 @@ def tiled_leg(args, dist, rank, world, device):
         # "i8_chains": the trailing products of the two factorisations from FIVE slices as well ("chain_slices" = 5: they forgive more than the
         # downdate, scripts/slice_precision_study_chain.py) -- every large product of the update on the integer pipe, the solves and factors fp64.
         sll_ref = out.pop("_sll_ref")
-        for key, dd, chain in (("i8_downdate", 6, 0), ("i8_chains", 6, 5)):
+        # "i8_chains_fp64_downdate": the factorisations' products alone -- Sigma stays within ~1e-7 of the fp64 run (three orders inside the tolerance).
+        for key, dd, chain in (("i8_downdate", 6, 0), ("i8_chains", 6, 5), ("i8_chains_fp64_downdate", 0, 5)):
             try:
                 be = tiled.HipBackend(d, capacity=N, device_index=device)
                 tf = tiled.TiledFilter(tiled.ProcessGrid(None, Pr, Pc, device=be.device), be, bl)
                 tf.check_every = 0
-                tf.downdate_slices = dd
+                if dd:
+                    tf.downdate_slices = dd
                 if chain:
                     tf.chain_slices = chain
                 tf.phase_ms = None
